@@ -1,0 +1,845 @@
+/*
+ * gs_oracle.c -- CPU restatement of the reference differentiable Gaussian-splat
+ * rasterizer (forward + backward).  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this file's shared object.  The product path (gs_localization_amd/)
+ * never links, imports or calls it.
+ *
+ * What is restated (file:line are relative to /root/reference/gaussian_splatting/
+ * submodules/diff-gaussian-rasterization/, "cr/" = cuda_rasterizer/):
+ *   gso_forward   : cr/rasterizer_impl.cu:197-339  (Rasterizer::forward)
+ *     preprocess  : cr/forward.cu:155-256 (+ :20-71 SH, :74-113 cov2D, :118-152 cov3D)
+ *                   cr/auxiliary.h:41-56 (ndc2Pix, getRect), :139-164 (in_frustum)
+ *     binning     : cr/rasterizer_impl.cu:70-111 (duplicateWithKeys), :304-309 (stable
+ *                   radix sort on bits [0, 32+msb(tiles))), :116-138 (identifyTileRanges)
+ *     compositing : cr/forward.cu:261-379 (renderCUDA)
+ *   gso_backward  : cr/rasterizer_impl.cu:343-444  (Rasterizer::backward)
+ *     render bwd  : cr/backward.cu:399-581
+ *     cov2D bwd   : cr/backward.cu:144-274
+ *     preproc bwd : cr/backward.cu:346-396 (+ :20-139 SH bwd, :278-341 cov3D bwd)
+ *   gso_mark_visible : cr/rasterizer_impl.cu:54-66
+ *
+ * Extras for the un-vendored `diff_gaussian_rasterization_pose` package
+ * (call site gs_localization/pipelines/tools/__init__.py:15-18,58-72,116-141):
+ *   n_touched, depth->mean gradient and dL/dtau (SE(3) left perturbation).  The
+ *   derivative is the exact one stated in SURVEY.md section 8(a)-b3.
+ *
+ * PARITY PINNING STATUS (see DESIGN.md "Oracle"):
+ *   - The reference kernels are CUDA (.cu, need cuda_runtime.h / cub / cooperative_groups,
+ *     none of which exist in this image) => the reference is UNBUILDABLE here and no
+ *     oracle/_ref is produced.  The reference has no tests and no golden vectors.
+ *   - Pinned: SH->RGB and cov3D against the reference's importable Python
+ *     (utils/sh_utils.py eval_sh, utils/general_utils.py build_scaling_rotation) via
+ *     tests/golden/; visible count V, instance count R and R_eff on scene S-1M-640
+ *     against the values SURVEY.md section 8(d) recorded from a run of the reference kernels.
+ *   - The compositing backward is checked against a float64 autograd restatement
+ *     (oracle/autograd_ref.py), not against an execution of the reference:
+ *     "parity unpinned" for that part.
+ *
+ * Arithmetic: fp32 everywhere, source-order evaluation, compiled with
+ * -ffp-contract=off so that no FMA contraction is introduced.  Matrices follow
+ * the reference's column-major (glm) convention: m[c][r].
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define BLOCK_X 16
+#define BLOCK_Y 16
+
+static const float SH_C0 = 0.28209479177387814f;
+static const float SH_C1 = 0.4886025119029199f;
+static const float SH_C2[5] = { 1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                -1.0925484305920792f, 0.5462742152960396f };
+static const float SH_C3[7] = { -0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f,
+                                0.3731763325901154f, -0.4570457994644658f, 1.445305721320277f,
+                                -0.5900435899266435f };
+
+typedef struct { float m[3][3]; } mat3;  /* m[column][row] */
+typedef struct { float x, y, z; } vec3;
+
+static mat3 m3_mul(mat3 a, mat3 b)
+{
+    mat3 r;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            r.m[i][j] = a.m[0][j] * b.m[i][0] + a.m[1][j] * b.m[i][1] + a.m[2][j] * b.m[i][2];
+    return r;
+}
+static mat3 m3_T(mat3 a)
+{
+    mat3 r;
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++)
+            r.m[i][j] = a.m[j][i];
+    return r;
+}
+/* mat3 from 9 scalars in glm constructor order (column by column) */
+static mat3 m3_make(float a0, float a1, float a2, float b0, float b1, float b2, float c0, float c1, float c2)
+{
+    mat3 r;
+    r.m[0][0] = a0; r.m[0][1] = a1; r.m[0][2] = a2;
+    r.m[1][0] = b0; r.m[1][1] = b1; r.m[1][2] = b2;
+    r.m[2][0] = c0; r.m[2][1] = c1; r.m[2][2] = c2;
+    return r;
+}
+
+static vec3 xform4x3(vec3 p, const float* m)
+{
+    vec3 t = { m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12],
+               m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13],
+               m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14] };
+    return t;
+}
+static void xform4x4(vec3 p, const float* m, float out[4])
+{
+    out[0] = m[0] * p.x + m[4] * p.y + m[8] * p.z + m[12];
+    out[1] = m[1] * p.x + m[5] * p.y + m[9] * p.z + m[13];
+    out[2] = m[2] * p.x + m[6] * p.y + m[10] * p.z + m[14];
+    out[3] = m[3] * p.x + m[7] * p.y + m[11] * p.z + m[15];
+}
+static float fminf_(float a, float b) { return a < b ? a : b; }
+static float fmaxf_(float a, float b) { return a > b ? a : b; }
+static int imin(int a, int b) { return a < b ? a : b; }
+static int imax(int a, int b) { return a > b ? a : b; }
+
+/* cr/auxiliary.h:41-44 : written with double literals => evaluated in fp64 */
+static float ndc2pix(float v, int S) { return (float)(((v + 1.0) * S - 1.0) * 0.5); }
+
+/* cr/auxiliary.h:46-56 */
+static void get_rect(float px, float py, int max_radius, int gx, int gy, int* x0, int* y0, int* x1, int* y1)
+{
+    *x0 = imin(gx, imax(0, (int)((px - max_radius) / BLOCK_X)));
+    *y0 = imin(gy, imax(0, (int)((py - max_radius) / BLOCK_Y)));
+    *x1 = imin(gx, imax(0, (int)((px + max_radius + BLOCK_X - 1) / BLOCK_X)));
+    *y1 = imin(gy, imax(0, (int)((py + max_radius + BLOCK_Y - 1) / BLOCK_Y)));
+}
+
+typedef struct gso_state {
+    int P, W, H, gx, gy, R;
+    float* depths;          /* [P]   */
+    uint8_t* clamped;       /* [P*3] */
+    int* radii;             /* [P]   */
+    float* means2D;         /* [P*2] */
+    float* cov3D;           /* [P*6] */
+    float* conic_opacity;   /* [P*4] */
+    float* rgb;             /* [P*3] */
+    uint32_t* tiles_touched;/* [P]   */
+    uint32_t* point_offsets;/* [P]   */
+    uint64_t* keys;         /* [R] sorted */
+    uint32_t* point_list;   /* [R] sorted */
+    uint32_t* ranges;       /* [tiles*2] */
+    uint32_t* n_contrib;    /* [W*H] */
+} gso_state;
+
+static int g_threads = 1;
+void gso_set_threads(int n)
+{
+    g_threads = n > 0 ? n : 1;
+#ifdef _OPENMP
+    omp_set_num_threads(g_threads);
+#endif
+}
+int gso_get_threads(void) { return g_threads; }
+
+/* cr/rasterizer_impl.cu:35-50 */
+static uint32_t higher_msb(uint32_t n)
+{
+    uint32_t msb = sizeof(n) * 4;
+    uint32_t step = msb;
+    while (step > 1) {
+        step /= 2;
+        if (n >> msb) msb += step; else msb -= step;
+    }
+    if (n >> msb) msb++;
+    return msb;
+}
+
+/* cr/forward.cu:20-71 */
+static void sh_to_rgb(int idx, int deg, int M, const float* means, const float* campos, const float* shs,
+                      uint8_t* clamped, float out[3])
+{
+    vec3 pos = { means[3 * idx], means[3 * idx + 1], means[3 * idx + 2] };
+    vec3 dir = { pos.x - campos[0], pos.y - campos[1], pos.z - campos[2] };
+    float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+    dir.x = dir.x / len; dir.y = dir.y / len; dir.z = dir.z / len;
+    const float* sh = shs + (size_t)idx * M * 3;
+    float res[3];
+    for (int c = 0; c < 3; c++) {
+#define S(k) sh[(k) * 3 + c]
+        float r = SH_C0 * S(0);
+        if (deg > 0) {
+            float x = dir.x, y = dir.y, z = dir.z;
+            r = r - SH_C1 * y * S(1) + SH_C1 * z * S(2) - SH_C1 * x * S(3);
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z;
+                float xy = x * y, yz = y * z, xz = x * z;
+                r = r + SH_C2[0] * xy * S(4) + SH_C2[1] * yz * S(5) + SH_C2[2] * (2.0f * zz - xx - yy) * S(6)
+                      + SH_C2[3] * xz * S(7) + SH_C2[4] * (xx - yy) * S(8);
+                if (deg > 2) {
+                    r = r + SH_C3[0] * y * (3.0f * xx - yy) * S(9) + SH_C3[1] * xy * z * S(10)
+                          + SH_C3[2] * y * (4.0f * zz - xx - yy) * S(11)
+                          + SH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(12)
+                          + SH_C3[4] * x * (4.0f * zz - xx - yy) * S(13) + SH_C3[5] * z * (xx - yy) * S(14)
+                          + SH_C3[6] * x * (xx - 3.0f * yy) * S(15);
+                }
+            }
+        }
+#undef S
+        r += 0.5f;
+        res[c] = r;
+    }
+    for (int c = 0; c < 3; c++) {
+        clamped[3 * idx + c] = (res[c] < 0);
+        out[c] = fmaxf_(res[c], 0.0f);
+    }
+}
+
+/* cr/forward.cu:118-152 */
+static void cov3d_from_scale_rot(const float* scale, float mod, const float* rot, float* cov3D)
+{
+    mat3 S = m3_make(1, 0, 0, 0, 1, 0, 0, 0, 1);
+    S.m[0][0] = mod * scale[0];
+    S.m[1][1] = mod * scale[1];
+    S.m[2][2] = mod * scale[2];
+    float r = rot[0], x = rot[1], y = rot[2], z = rot[3];  /* NOT normalised, cr/forward.cu:127 */
+    mat3 R = m3_make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                     2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                     2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+    mat3 Mm = m3_mul(S, R);
+    mat3 Sigma = m3_mul(m3_T(Mm), Mm);
+    cov3D[0] = Sigma.m[0][0]; cov3D[1] = Sigma.m[0][1]; cov3D[2] = Sigma.m[0][2];
+    cov3D[3] = Sigma.m[1][1]; cov3D[4] = Sigma.m[1][2]; cov3D[5] = Sigma.m[2][2];
+}
+
+/* shared by forward (cr/forward.cu:74-113) and backward (cr/backward.cu:166-199) */
+static void cov2d_terms(vec3 mean, float fx, float fy, float tan_fovx, float tan_fovy, const float* cov3D,
+                        const float* view, vec3* t_out, float* txtz_o, float* tytz_o, mat3* T_out, mat3* Vrk_out,
+                        mat3* W_out, mat3* cov_out)
+{
+    vec3 t = xform4x3(mean, view);
+    const float limx = 1.3f * tan_fovx;
+    const float limy = 1.3f * tan_fovy;
+    const float txtz = t.x / t.z;
+    const float tytz = t.y / t.z;
+    t.x = fminf_(limx, fmaxf_(-limx, txtz)) * t.z;
+    t.y = fminf_(limy, fmaxf_(-limy, tytz)) * t.z;
+    mat3 J = m3_make(fx / t.z, 0.0f, -(fx * t.x) / (t.z * t.z),
+                     0.0f, fy / t.z, -(fy * t.y) / (t.z * t.z),
+                     0, 0, 0);
+    mat3 Wm = m3_make(view[0], view[4], view[8], view[1], view[5], view[9], view[2], view[6], view[10]);
+    mat3 T = m3_mul(Wm, J);
+    mat3 Vrk = m3_make(cov3D[0], cov3D[1], cov3D[2], cov3D[1], cov3D[3], cov3D[4], cov3D[2], cov3D[4], cov3D[5]);
+    mat3 cov = m3_mul(m3_mul(m3_T(T), m3_T(Vrk)), T);
+    *t_out = t; *txtz_o = txtz; *tytz_o = tytz; *T_out = T; *Vrk_out = Vrk; *W_out = Wm; *cov_out = cov;
+}
+
+static void state_free(gso_state* s)
+{
+    if (!s) return;
+    free(s->depths); free(s->clamped); free(s->radii); free(s->means2D); free(s->cov3D);
+    free(s->conic_opacity); free(s->rgb); free(s->tiles_touched); free(s->point_offsets);
+    free(s->keys); free(s->point_list); free(s->ranges); free(s->n_contrib);
+    free(s);
+}
+void gso_free(gso_state* s) { state_free(s); }
+
+/* stable LSD radix sort of (key,value) on key bits [0,end_bit) -- the contract of
+ * cub::DeviceRadixSort::SortPairs at cr/rasterizer_impl.cu:304-309 */
+static void radix_sort_pairs(uint64_t* keys, uint32_t* vals, size_t n, int end_bit)
+{
+    if (n == 0) return;
+    uint64_t* k2 = (uint64_t*)malloc(n * sizeof(uint64_t));
+    uint32_t* v2 = (uint32_t*)malloc(n * sizeof(uint32_t));
+    uint64_t *ka = keys, *kb = k2;
+    uint32_t *va = vals, *vb = v2;
+    for (int shift = 0; shift < end_bit; shift += 8) {
+        int bits = end_bit - shift < 8 ? end_bit - shift : 8;
+        uint32_t mask = (1u << bits) - 1u;
+        size_t hist[257];
+        memset(hist, 0, sizeof(hist));
+        for (size_t i = 0; i < n; i++) hist[((ka[i] >> shift) & mask) + 1]++;
+        for (int b = 0; b < 256; b++) hist[b + 1] += hist[b];
+        for (size_t i = 0; i < n; i++) {
+            size_t d = hist[(ka[i] >> shift) & mask]++;
+            kb[d] = ka[i]; vb[d] = va[i];
+        }
+        uint64_t* tk = ka; ka = kb; kb = tk;
+        uint32_t* tv = va; va = vb; vb = tv;
+    }
+    if (ka != keys) { memcpy(keys, ka, n * sizeof(uint64_t)); memcpy(vals, va, n * sizeof(uint32_t)); }
+    free(k2); free(v2);
+}
+
+gso_state* gso_forward(int P, int D, int M, const float* background, int width, int height,
+                       const float* means3D, const float* shs, const float* colors_precomp,
+                       const float* opacities, const float* scales, float scale_modifier,
+                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                       const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                       float* out_color, float* out_depth, float* out_alpha, int* radii_out,
+                       int* n_touched /* nullable; pose package only */)
+{
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+    const int gx = (width + BLOCK_X - 1) / BLOCK_X, gy = (height + BLOCK_Y - 1) / BLOCK_Y;
+    const int N = width * height;
+
+    gso_state* s = (gso_state*)calloc(1, sizeof(gso_state));
+    s->P = P; s->W = width; s->H = height; s->gx = gx; s->gy = gy;
+    size_t Pa = P > 0 ? (size_t)P : 1;
+    s->depths = (float*)calloc(Pa, sizeof(float));
+    s->clamped = (uint8_t*)calloc(Pa * 3, 1);
+    s->radii = (int*)calloc(Pa, sizeof(int));
+    s->means2D = (float*)calloc(Pa * 2, sizeof(float));
+    s->cov3D = (float*)calloc(Pa * 6, sizeof(float));
+    s->conic_opacity = (float*)calloc(Pa * 4, sizeof(float));
+    s->rgb = (float*)calloc(Pa * 3, sizeof(float));
+    s->tiles_touched = (uint32_t*)calloc(Pa, sizeof(uint32_t));
+    s->point_offsets = (uint32_t*)calloc(Pa, sizeof(uint32_t));
+    s->ranges = (uint32_t*)calloc((size_t)gx * gy * 2, sizeof(uint32_t));
+    s->n_contrib = (uint32_t*)calloc((size_t)N, sizeof(uint32_t));
+    if (n_touched) memset(n_touched, 0, Pa * sizeof(int));
+
+    /* ---- K1 preprocess, cr/forward.cu:155-256 ---- */
+#pragma omp parallel for schedule(static) if (g_threads > 1)
+    for (int idx = 0; idx < P; idx++) {
+        s->radii[idx] = 0;
+        s->tiles_touched[idx] = 0;
+        vec3 p_orig = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
+        /* in_frustum, cr/auxiliary.h:139-164 */
+        float p_hom[4];
+        xform4x4(p_orig, projmatrix, p_hom);
+        float p_w = 1.0f / (p_hom[3] + 0.0000001f);
+        vec3 p_proj = { p_hom[0] * p_w, p_hom[1] * p_w, p_hom[2] * p_w };
+        vec3 p_view = xform4x3(p_orig, viewmatrix);
+        if (p_view.z <= 0.2f) continue;
+
+        const float* cov3D;
+        if (cov3D_precomp != NULL) {
+            cov3D = cov3D_precomp + (size_t)idx * 6;
+        } else {
+            cov3d_from_scale_rot(scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx,
+                                 s->cov3D + 6 * (size_t)idx);
+            cov3D = s->cov3D + 6 * (size_t)idx;
+        }
+        vec3 t; float txtz, tytz; mat3 T, Vrk, Wm, cov2;
+        cov2d_terms(p_orig, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &t, &txtz, &tytz, &T, &Vrk, &Wm, &cov2);
+        cov2.m[0][0] += 0.3f;
+        cov2.m[1][1] += 0.3f;
+        float cx = cov2.m[0][0], cy = cov2.m[0][1], cz = cov2.m[1][1];
+
+        float det = (cx * cz - cy * cy);
+        if (det == 0.0f) continue;
+        float det_inv = 1.f / det;
+        float conic[3] = { cz * det_inv, -cy * det_inv, cx * det_inv };
+
+        float mid = 0.5f * (cx + cz);
+        float lambda1 = mid + sqrtf(fmaxf_(0.1f, mid * mid - det));
+        float lambda2 = mid - sqrtf(fmaxf_(0.1f, mid * mid - det));
+        float my_radius = ceilf(3.f * sqrtf(fmaxf_(lambda1, lambda2)));
+        float pix = ndc2pix(p_proj.x, width), piy = ndc2pix(p_proj.y, height);
+        int x0, y0, x1, y1;
+        get_rect(pix, piy, (int)my_radius, gx, gy, &x0, &y0, &x1, &y1);
+        if ((x1 - x0) * (y1 - y0) == 0) continue;
+
+        if (colors_precomp == NULL) {
+            float c[3];
+            sh_to_rgb(idx, D, M, means3D, cam_pos, shs, s->clamped, c);
+            s->rgb[3 * idx] = c[0]; s->rgb[3 * idx + 1] = c[1]; s->rgb[3 * idx + 2] = c[2];
+        }
+        s->depths[idx] = p_view.z;
+        s->radii[idx] = (int)my_radius;
+        s->means2D[2 * idx] = pix; s->means2D[2 * idx + 1] = piy;
+        s->conic_opacity[4 * idx] = conic[0]; s->conic_opacity[4 * idx + 1] = conic[1];
+        s->conic_opacity[4 * idx + 2] = conic[2]; s->conic_opacity[4 * idx + 3] = opacities[idx];
+        s->tiles_touched[idx] = (uint32_t)((y1 - y0) * (x1 - x0));
+    }
+    if (radii_out) memcpy(radii_out, s->radii, (size_t)P * sizeof(int));
+
+    /* ---- K2 inclusive scan, cr/rasterizer_impl.cu:278 ---- */
+    uint32_t acc = 0;
+    for (int i = 0; i < P; i++) { acc += s->tiles_touched[i]; s->point_offsets[i] = acc; }
+    const int R = (int)acc;
+    s->R = R;
+    s->keys = (uint64_t*)malloc((R > 0 ? (size_t)R : 1) * sizeof(uint64_t));
+    s->point_list = (uint32_t*)malloc((R > 0 ? (size_t)R : 1) * sizeof(uint32_t));
+
+    /* ---- K3 duplicateWithKeys, cr/rasterizer_impl.cu:70-111 ---- */
+    for (int idx = 0; idx < P; idx++) {
+        if (s->radii[idx] > 0) {
+            uint32_t off = (idx == 0) ? 0 : s->point_offsets[idx - 1];
+            int x0, y0, x1, y1;
+            get_rect(s->means2D[2 * idx], s->means2D[2 * idx + 1], s->radii[idx], gx, gy, &x0, &y0, &x1, &y1);
+            uint32_t dbits;
+            memcpy(&dbits, &s->depths[idx], 4);
+            for (int y = y0; y < y1; y++)
+                for (int x = x0; x < x1; x++) {
+                    uint64_t key = (uint64_t)(y * gx + x);
+                    key <<= 32;
+                    key |= dbits;
+                    s->keys[off] = key;
+                    s->point_list[off] = (uint32_t)idx;
+                    off++;
+                }
+        }
+    }
+    /* ---- K4 sort ---- */
+    int bit = (int)higher_msb((uint32_t)(gx * gy));
+    radix_sort_pairs(s->keys, s->point_list, (size_t)R, 32 + bit);
+
+    /* ---- K5 identifyTileRanges, cr/rasterizer_impl.cu:116-138 ---- */
+    for (int i = 0; i < R; i++) {
+        uint32_t cur = (uint32_t)(s->keys[i] >> 32);
+        if (i == 0) s->ranges[2 * cur] = 0;
+        else {
+            uint32_t prev = (uint32_t)(s->keys[i - 1] >> 32);
+            if (cur != prev) { s->ranges[2 * prev + 1] = (uint32_t)i; s->ranges[2 * cur] = (uint32_t)i; }
+        }
+        if (i == R - 1) s->ranges[2 * cur + 1] = (uint32_t)R;
+    }
+
+    /* ---- K6 compositing, cr/forward.cu:261-379 (one pixel at a time; the block-level
+     *      early exit of the reference does not change any pixel's result) ---- */
+    const float* feat = colors_precomp != NULL ? colors_precomp : s->rgb;
+#pragma omp parallel for schedule(dynamic, 1) if (g_threads > 1)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        int ty = tile / gx, tx = tile % gx;
+        uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                if (!(px < width && py < height)) continue;
+                int pix_id = width * py + px;
+                float pxf = (float)px, pyf = (float)py;
+                float T = 1.0f;
+                uint32_t contributor = 0, last_contributor = 0;
+                float C[3] = { 0, 0, 0 };
+                float Dd = 0;
+                for (uint32_t k = r0; k < r1; k++) {
+                    contributor++;
+                    uint32_t id = s->point_list[k];
+                    float dx = s->means2D[2 * id] - pxf, dy = s->means2D[2 * id + 1] - pyf;
+                    const float* co = s->conic_opacity + 4 * (size_t)id;
+                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    float alpha = fminf_(0.99f, co[3] * expf(power));
+                    if (alpha < 1.0f / 255.0f) continue;
+                    float test_T = T * (1 - alpha);
+                    if (test_T < 0.0001f) break;   /* done = true */
+                    for (int ch = 0; ch < 3; ch++) C[ch] += feat[id * 3 + ch] * alpha * T;
+                    Dd += s->depths[id] * alpha * T;
+                    if (n_touched && test_T > 0.5f) {
+#pragma omp atomic
+                        n_touched[id] += 1;
+                    }
+                    T = test_T;
+                    last_contributor = contributor;
+                }
+                s->n_contrib[pix_id] = last_contributor;
+                for (int ch = 0; ch < 3; ch++) out_color[(size_t)ch * N + pix_id] = C[ch] + T * background[ch];
+                out_alpha[pix_id] = 1 - T;
+                out_depth[pix_id] = Dd;
+            }
+    }
+    return s;
+}
+
+int gso_num_rendered(const gso_state* s) { return s->R; }
+
+/* R_eff of SURVEY.md section 8(d): sum over tiles of max-over-pixels n_contrib */
+long gso_r_eff(const gso_state* s)
+{
+    long tot = 0;
+    for (int tile = 0; tile < s->gx * s->gy; tile++) {
+        int ty = tile / s->gx, tx = tile % s->gx;
+        uint32_t mx = 0;
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                if (px < s->W && py < s->H) {
+                    uint32_t v = s->n_contrib[s->W * py + px];
+                    if (v > mx) mx = v;
+                }
+            }
+        tot += mx;
+    }
+    return tot;
+}
+
+/* copy internal state out for tests (any pointer may be NULL) */
+void gso_get_state(const gso_state* s, float* depths, float* means2D, float* cov3D, float* conic_opacity,
+                   float* rgb, uint8_t* clamped, uint32_t* tiles_touched, uint32_t* point_list,
+                   uint32_t* ranges, uint32_t* n_contrib)
+{
+    size_t P = (size_t)s->P;
+    if (depths) memcpy(depths, s->depths, P * 4);
+    if (means2D) memcpy(means2D, s->means2D, P * 8);
+    if (cov3D) memcpy(cov3D, s->cov3D, P * 24);
+    if (conic_opacity) memcpy(conic_opacity, s->conic_opacity, P * 16);
+    if (rgb) memcpy(rgb, s->rgb, P * 12);
+    if (clamped) memcpy(clamped, s->clamped, P * 3);
+    if (tiles_touched) memcpy(tiles_touched, s->tiles_touched, P * 4);
+    if (point_list) memcpy(point_list, s->point_list, (size_t)s->R * 4);
+    if (ranges) memcpy(ranges, s->ranges, (size_t)s->gx * s->gy * 8);
+    if (n_contrib) memcpy(n_contrib, s->n_contrib, (size_t)s->W * s->H * 4);
+}
+
+static inline void atomic_addf(float* p, float v)
+{
+#pragma omp atomic
+    *p += v;
+}
+
+/* cr/auxiliary.h:101-112 */
+static vec3 dnormvdv3(vec3 v, vec3 dv)
+{
+    float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    vec3 r;
+    r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+    r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+    return r;
+}
+
+/* cr/backward.cu:20-139.  Returns the SH->mean gradient separately (g_sh) so that the
+ * pose variant can route it to rho only; the caller adds it to dL_dmeans. */
+static vec3 sh_backward(int idx, int deg, int M, const float* means, const float* campos, const float* shs,
+                        const uint8_t* clamped, const float* dL_dcolor, float* dL_dshs)
+{
+    vec3 pos = { means[3 * idx], means[3 * idx + 1], means[3 * idx + 2] };
+    vec3 dir_orig = { pos.x - campos[0], pos.y - campos[1], pos.z - campos[2] };
+    float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+    float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+    const float* sh = shs + (size_t)idx * M * 3;
+    float* dsh = dL_dshs + (size_t)idx * M * 3;
+    float dRGB[3];
+    for (int c = 0; c < 3; c++) dRGB[c] = dL_dcolor[3 * idx + c] * (clamped[3 * idx + c] ? 0.f : 1.f);
+    float dx[3] = { 0, 0, 0 }, dy[3] = { 0, 0, 0 }, dz[3] = { 0, 0, 0 };
+#define SH(k, c) sh[(k) * 3 + (c)]
+#define DSH(k, w) for (int c = 0; c < 3; c++) dsh[(k) * 3 + c] = (w) * dRGB[c]
+    DSH(0, SH_C0);
+    if (deg > 0) {
+        float w1 = -SH_C1 * y, w2 = SH_C1 * z, w3 = -SH_C1 * x;
+        DSH(1, w1); DSH(2, w2); DSH(3, w3);
+        for (int c = 0; c < 3; c++) {
+            dx[c] = -SH_C1 * SH(3, c);
+            dy[c] = -SH_C1 * SH(1, c);
+            dz[c] = SH_C1 * SH(2, c);
+        }
+        if (deg > 1) {
+            float xx = x * x, yy = y * y, zz = z * z;
+            float xy = x * y, yz = y * z, xz = x * z;
+            float w4 = SH_C2[0] * xy, w5 = SH_C2[1] * yz, w6 = SH_C2[2] * (2.f * zz - xx - yy);
+            float w7 = SH_C2[3] * xz, w8 = SH_C2[4] * (xx - yy);
+            DSH(4, w4); DSH(5, w5); DSH(6, w6); DSH(7, w7); DSH(8, w8);
+            for (int c = 0; c < 3; c++) {
+                dx[c] += SH_C2[0] * y * SH(4, c) + SH_C2[2] * 2.f * -x * SH(6, c) + SH_C2[3] * z * SH(7, c) + SH_C2[4] * 2.f * x * SH(8, c);
+                dy[c] += SH_C2[0] * x * SH(4, c) + SH_C2[1] * z * SH(5, c) + SH_C2[2] * 2.f * -y * SH(6, c) + SH_C2[4] * 2.f * -y * SH(8, c);
+                dz[c] += SH_C2[1] * y * SH(5, c) + SH_C2[2] * 2.f * 2.f * z * SH(6, c) + SH_C2[3] * x * SH(7, c);
+            }
+            if (deg > 2) {
+                float w9 = SH_C3[0] * y * (3.f * xx - yy), w10 = SH_C3[1] * xy * z;
+                float w11 = SH_C3[2] * y * (4.f * zz - xx - yy), w12 = SH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                float w13 = SH_C3[4] * x * (4.f * zz - xx - yy), w14 = SH_C3[5] * z * (xx - yy);
+                float w15 = SH_C3[6] * x * (xx - 3.f * yy);
+                DSH(9, w9); DSH(10, w10); DSH(11, w11); DSH(12, w12); DSH(13, w13); DSH(14, w14); DSH(15, w15);
+                for (int c = 0; c < 3; c++) {
+                    dx[c] += (SH_C3[0] * SH(9, c) * 3.f * 2.f * xy + SH_C3[1] * SH(10, c) * yz + SH_C3[2] * SH(11, c) * -2.f * xy
+                              + SH_C3[3] * SH(12, c) * -3.f * 2.f * xz + SH_C3[4] * SH(13, c) * (-3.f * xx + 4.f * zz - yy)
+                              + SH_C3[5] * SH(14, c) * 2.f * xz + SH_C3[6] * SH(15, c) * 3.f * (xx - yy));
+                    dy[c] += (SH_C3[0] * SH(9, c) * 3.f * (xx - yy) + SH_C3[1] * SH(10, c) * xz
+                              + SH_C3[2] * SH(11, c) * (-3.f * yy + 4.f * zz - xx) + SH_C3[3] * SH(12, c) * -3.f * 2.f * yz
+                              + SH_C3[4] * SH(13, c) * -2.f * xy + SH_C3[5] * SH(14, c) * -2.f * yz
+                              + SH_C3[6] * SH(15, c) * -3.f * 2.f * xy);
+                    dz[c] += (SH_C3[1] * SH(10, c) * xy + SH_C3[2] * SH(11, c) * 4.f * 2.f * yz
+                              + SH_C3[3] * SH(12, c) * 3.f * (2.f * zz - xx - yy) + SH_C3[4] * SH(13, c) * 4.f * 2.f * xz
+                              + SH_C3[5] * SH(14, c) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SH
+#undef DSH
+    vec3 dL_ddir = { dx[0] * dRGB[0] + dx[1] * dRGB[1] + dx[2] * dRGB[2],
+                     dy[0] * dRGB[0] + dy[1] * dRGB[1] + dy[2] * dRGB[2],
+                     dz[0] * dRGB[0] + dz[1] * dRGB[1] + dz[2] * dRGB[2] };
+    return dnormvdv3(dir_orig, dL_ddir);
+}
+
+/* cr/backward.cu:278-341 */
+static void cov3d_backward(int idx, const float* scale, float mod, const float* rot, const float* dL_dcov3Ds,
+                           float* dL_dscales, float* dL_drots)
+{
+    float r = rot[0], x = rot[1], y = rot[2], z = rot[3];
+    mat3 R = m3_make(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                     2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                     2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+    mat3 S = m3_make(1, 0, 0, 0, 1, 0, 0, 0, 1);
+    float sx = mod * scale[0], sy = mod * scale[1], sz = mod * scale[2];
+    S.m[0][0] = sx; S.m[1][1] = sy; S.m[2][2] = sz;
+    mat3 Mm = m3_mul(S, R);
+    const float* d = dL_dcov3Ds + 6 * (size_t)idx;
+    mat3 dSig = m3_make(d[0], 0.5f * d[1], 0.5f * d[2], 0.5f * d[1], d[3], 0.5f * d[4], 0.5f * d[2], 0.5f * d[4], d[5]);
+    mat3 MdS = m3_mul(Mm, dSig);
+    mat3 dL_dM;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) dL_dM.m[i][j] = 2.0f * MdS.m[i][j];
+    mat3 Rt = m3_T(R);
+    mat3 dMt = m3_T(dL_dM);
+    float* ds = dL_dscales + 3 * (size_t)idx;
+    ds[0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
+    ds[1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
+    ds[2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
+    for (int j = 0; j < 3; j++) { dMt.m[0][j] *= sx; dMt.m[1][j] *= sy; dMt.m[2][j] *= sz; }
+    float* dq = dL_drots + 4 * (size_t)idx;
+#define A(i, j) dMt.m[i][j]
+    dq[0] = 2 * z * (A(0, 1) - A(1, 0)) + 2 * y * (A(2, 0) - A(0, 2)) + 2 * x * (A(1, 2) - A(2, 1));
+    dq[1] = 2 * y * (A(1, 0) + A(0, 1)) + 2 * z * (A(2, 0) + A(0, 2)) + 2 * r * (A(1, 2) - A(2, 1)) - 4 * x * (A(2, 2) + A(1, 1));
+    dq[2] = 2 * x * (A(1, 0) + A(0, 1)) + 2 * r * (A(2, 0) - A(0, 2)) + 2 * z * (A(1, 2) + A(2, 1)) - 4 * y * (A(2, 2) + A(0, 0));
+    dq[3] = 2 * r * (A(0, 1) - A(1, 0)) + 2 * x * (A(2, 0) + A(0, 2)) + 2 * y * (A(1, 2) + A(2, 1)) - 4 * z * (A(1, 1) + A(0, 0));
+#undef A
+}
+
+/*
+ * Backward.  pose_mode = 0 : package (A) semantics, bit-faithful to the vendored code.
+ *            pose_mode = 1 : package (B): additionally (i) the per-Gaussian depth z_i receives
+ *            dL/dz_i = sum_px dL_ddepth * alpha * T and feeds dL_dmean3D through the view
+ *            matrix, (ii) dL_dtau[6] = [d/drho(3), d/dtheta(3)] is produced.
+ * All output arrays must be zero-initialised by the caller (cr/../rasterize_points.cu:158-166).
+ */
+void gso_backward(const gso_state* s, int D, int M, const float* background, const float* means3D,
+                  const float* shs, const float* colors_precomp, const float* out_alpha, const float* scales,
+                  float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                  const float* viewmatrix, const float* projmatrix, const float* campos, float tan_fovx,
+                  float tan_fovy, const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas,
+                  float* dL_dmean2D /*P*3*/, float* dL_dconic /*P*4*/, float* dL_dopacity /*P*/,
+                  float* dL_dcolor /*P*3*/, float* dL_dmean3D /*P*3*/, float* dL_dcov3D /*P*6*/,
+                  float* dL_dsh /*P*M*3*/, float* dL_dscale /*P*3*/, float* dL_drot /*P*4*/, int pose_mode,
+                  float* dL_dtau /*6, pose_mode only*/)
+{
+    const int P = s->P, W = s->W, H = s->H, gx = s->gx, gy = s->gy;
+    const int N = W * H;
+    const float focal_y = H / (2.0f * tan_fovy);
+    const float focal_x = W / (2.0f * tan_fovx);
+    const float* colors = colors_precomp != NULL ? colors_precomp : s->rgb;
+    float* dL_dz = NULL;
+    if (pose_mode) dL_dz = (float*)calloc(P > 0 ? (size_t)P : 1, sizeof(float));
+
+    /* ---- K7 render backward, cr/backward.cu:399-581 ---- */
+    const float ddelx_dx = (float)(0.5 * W);
+    const float ddely_dy = (float)(0.5 * H);
+#pragma omp parallel for schedule(dynamic, 1) if (g_threads > 1)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        int ty = tile / gx, tx = tile % gx;
+        uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                if (!(px < W && py < H)) continue;
+                int pix_id = W * py + px;
+                float pxf = (float)px, pyf = (float)py;
+                const float T_final = 1 - out_alpha[pix_id];
+                float T = T_final;
+                uint32_t contributor = r1 - r0;
+                const uint32_t last_contributor = s->n_contrib[pix_id];
+                float accum_rec[3] = { 0, 0, 0 }, dL_dpixel[3];
+                float accum_depth_rec = 0, accum_alpha_rec = 0;
+                for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpix[(size_t)i * N + pix_id];
+                float dL_ddepth = dL_ddepths[pix_id];
+                float dL_dalpha = dL_dalphas[pix_id];
+                float last_alpha = 0, last_color[3] = { 0, 0, 0 }, last_depth = 0;
+                for (uint32_t k = r1; k-- > r0;) {
+                    contributor--;
+                    if (contributor >= last_contributor) continue;
+                    uint32_t id = s->point_list[k];
+                    float dx = s->means2D[2 * id] - pxf, dy = s->means2D[2 * id + 1] - pyf;
+                    const float* co = s->conic_opacity + 4 * (size_t)id;
+                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    if (power > 0.0f) continue;
+                    const float G = expf(power);
+                    const float alpha = fminf_(0.99f, co[3] * G);
+                    if (alpha < 1.0f / 255.0f) continue;
+                    T = T / (1.f - alpha);
+                    const float dchannel_dcolor = alpha * T;
+                    float dL_dopa = 0.0f;
+                    for (int ch = 0; ch < 3; ch++) {
+                        const float c = colors[id * 3 + ch];
+                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
+                        last_color[ch] = c;
+                        const float dL_dchannel = dL_dpixel[ch];
+                        dL_dopa += (c - accum_rec[ch]) * dL_dchannel;
+                        atomic_addf(&dL_dcolor[id * 3 + ch], dchannel_dcolor * dL_dchannel);
+                    }
+                    const float c_d = s->depths[id];
+                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
+                    last_depth = c_d;
+                    dL_dopa += (c_d - accum_depth_rec) * dL_ddepth;
+                    if (pose_mode) atomic_addf(&dL_dz[id], dchannel_dcolor * dL_ddepth);
+                    accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
+                    dL_dopa += -(alpha - accum_alpha_rec) * dL_dalpha;   /* cr/backward.cu:545-547 quirk */
+                    dL_dopa *= T;
+                    last_alpha = alpha;
+                    float bg_dot_dpixel = 0;
+                    for (int i = 0; i < 3; i++) bg_dot_dpixel += background[i] * dL_dpixel[i];
+                    dL_dopa += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
+                    const float dL_dG = co[3] * dL_dopa;
+                    const float gdx = G * dx;
+                    const float gdy = G * dy;
+                    const float dG_ddelx = -gdx * co[0] - gdy * co[1];
+                    const float dG_ddely = -gdy * co[2] - gdx * co[1];
+                    atomic_addf(&dL_dmean2D[3 * id], dL_dG * dG_ddelx * ddelx_dx);
+                    atomic_addf(&dL_dmean2D[3 * id + 1], dL_dG * dG_ddely * ddely_dy);
+                    atomic_addf(&dL_dconic[4 * id], -0.5f * gdx * dx * dL_dG);
+                    atomic_addf(&dL_dconic[4 * id + 1], -0.5f * gdx * dy * dL_dG);
+                    atomic_addf(&dL_dconic[4 * id + 3], -0.5f * gdy * dy * dL_dG);
+                    atomic_addf(&dL_dopacity[id], G * dL_dopa);
+                }
+            }
+    }
+
+    /* per-thread tau partials are summed in fp64 then cast (deterministic enough for a checker) */
+    double tau[6] = { 0, 0, 0, 0, 0, 0 };
+
+    /* ---- K8 computeCov2DCUDA (cr/backward.cu:144-274) + K9 preprocessCUDA (:346-396) ---- */
+    const float* cov3Ds = cov3D_precomp != NULL ? cov3D_precomp : s->cov3D;
+    for (int idx = 0; idx < P; idx++) {
+        if (!(s->radii[idx] > 0)) continue;
+        const float* cov3D = cov3Ds + 6 * (size_t)idx;
+        vec3 mean = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
+        float dcx = dL_dconic[4 * idx], dcy = dL_dconic[4 * idx + 1], dcz = dL_dconic[4 * idx + 3];
+        vec3 t; float txtz, tytz; mat3 T, Vrk, Wm, cov2D;
+        cov2d_terms(mean, focal_x, focal_y, tan_fovx, tan_fovy, cov3D, viewmatrix, &t, &txtz, &tytz, &T, &Vrk, &Wm, &cov2D);
+        const float limx = 1.3f * tan_fovx, limy = 1.3f * tan_fovy;
+        const float x_grad_mul = (txtz < -limx || txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (tytz < -limy || tytz > limy) ? 0.f : 1.f;
+        float a = cov2D.m[0][0] += 0.3f;
+        float b = cov2D.m[0][1];
+        float c = cov2D.m[1][1] += 0.3f;
+        float denom = a * c - b * b;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float* dcov = dL_dcov3D + 6 * (size_t)idx;
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-c * c * dcx + 2 * b * c * dcy + (denom - a * c) * dcz);
+            dL_dc = denom2inv * (-a * a * dcz + 2 * a * b * dcy + (denom - a * c) * dcx);
+            dL_db = denom2inv * 2 * (b * c * dcx - (denom + 2 * b * b) * dcy + a * b * dcz);
+#define TT(i, j) T.m[i][j]
+            dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
+            dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
+            dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
+            dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
+            dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
+            dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
+        } else {
+            for (int i = 0; i < 6; i++) dcov[i] = 0;
+        }
+#define VV(i, j) Vrk.m[i][j]
+        float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da + (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
+        float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da + (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
+        float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da + (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
+        float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc + (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
+        float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc + (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
+        float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc + (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
+#undef VV
+#undef TT
+#define WW(i, j) Wm.m[i][j]
+        float dL_dJ00 = WW(0, 0) * dL_dT00 + WW(0, 1) * dL_dT01 + WW(0, 2) * dL_dT02;
+        float dL_dJ02 = WW(2, 0) * dL_dT00 + WW(2, 1) * dL_dT01 + WW(2, 2) * dL_dT02;
+        float dL_dJ11 = WW(1, 0) * dL_dT10 + WW(1, 1) * dL_dT11 + WW(1, 2) * dL_dT12;
+        float dL_dJ12 = WW(2, 0) * dL_dT10 + WW(2, 1) * dL_dT11 + WW(2, 2) * dL_dT12;
+#undef WW
+        float tz = 1.f / t.z;
+        float tz2 = tz * tz;
+        float tz3 = tz2 * tz;
+        float dL_dtx = x_grad_mul * -focal_x * tz2 * dL_dJ02;
+        float dL_dty = y_grad_mul * -focal_y * tz2 * dL_dJ12;
+        float dL_dtz = -focal_x * tz2 * dL_dJ00 - focal_y * tz2 * dL_dJ11 + (2 * focal_x * t.x) * tz3 * dL_dJ02 + (2 * focal_y * t.y) * tz3 * dL_dJ12;
+        /* transformVec4x3Transpose, cr/auxiliary.h:90-98 */
+        vec3 g_cov = { viewmatrix[0] * dL_dtx + viewmatrix[1] * dL_dty + viewmatrix[2] * dL_dtz,
+                       viewmatrix[4] * dL_dtx + viewmatrix[5] * dL_dty + viewmatrix[6] * dL_dtz,
+                       viewmatrix[8] * dL_dtx + viewmatrix[9] * dL_dty + viewmatrix[10] * dL_dtz };
+        float* dm = dL_dmean3D + 3 * (size_t)idx;
+        dm[0] = g_cov.x; dm[1] = g_cov.y; dm[2] = g_cov.z;     /* written, not added (cr/backward.cu:273) */
+
+        /* K9 */
+        const float* proj = projmatrix;
+        float m_hom[4];
+        xform4x4(mean, proj, m_hom);
+        float m_w = 1.0f / (m_hom[3] + 0.0000001f);
+        float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+        float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+        float g2x = dL_dmean2D[3 * idx], g2y = dL_dmean2D[3 * idx + 1];
+        vec3 g_m2d;
+        g_m2d.x = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+        g_m2d.y = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+        g_m2d.z = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+        dm[0] += g_m2d.x; dm[1] += g_m2d.y; dm[2] += g_m2d.z;
+
+        vec3 g_depth = { 0, 0, 0 };
+        if (pose_mode) {
+            /* z_i = view[2] x + view[6] y + view[10] z + view[14] */
+            g_depth.x = viewmatrix[2] * dL_dz[idx];
+            g_depth.y = viewmatrix[6] * dL_dz[idx];
+            g_depth.z = viewmatrix[10] * dL_dz[idx];
+            dm[0] += g_depth.x; dm[1] += g_depth.y; dm[2] += g_depth.z;
+        }
+        vec3 g_sh = { 0, 0, 0 };
+        if (shs) {
+            g_sh = sh_backward(idx, D, M, means3D, campos, shs, s->clamped, dL_dcolor, dL_dsh);
+            dm[0] += g_sh.x; dm[1] += g_sh.y; dm[2] += g_sh.z;
+        }
+        if (scales)
+            cov3d_backward(idx, scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, dL_dcov3D, dL_dscale, dL_drot);
+
+        if (pose_mode && dL_dtau) {
+            /* SURVEY.md section 8(a)-b3.  Rm[r][c] = W2C rotation = view[c*4+r]. */
+            double Rm[3][3];
+            for (int r = 0; r < 3; r++) for (int cc = 0; cc < 3; cc++) Rm[r][cc] = viewmatrix[cc * 4 + r];
+            double gg[3] = { (double)g_cov.x + g_m2d.x + g_depth.x, (double)g_cov.y + g_m2d.y + g_depth.y,
+                             (double)g_cov.z + g_m2d.z + g_depth.z };
+            double gs[3] = { g_sh.x, g_sh.y, g_sh.z };
+            double pc[3], Rg[3], Rs[3];
+            double mw[3] = { mean.x, mean.y, mean.z };
+            for (int r = 0; r < 3; r++) {
+                pc[r] = Rm[r][0] * mw[0] + Rm[r][1] * mw[1] + Rm[r][2] * mw[2] + viewmatrix[12 + r];
+                Rg[r] = Rm[r][0] * gg[0] + Rm[r][1] * gg[1] + Rm[r][2] * gg[2];
+                Rs[r] = Rm[r][0] * gs[0] + Rm[r][1] * gs[1] + Rm[r][2] * gs[2];
+            }
+            /* G_W symmetric from the 6-vector (off-diagonals halved), Sigma_W from cov3D */
+            double GW[3][3] = { { dcov[0], 0.5 * dcov[1], 0.5 * dcov[2] }, { 0.5 * dcov[1], dcov[3], 0.5 * dcov[4] }, { 0.5 * dcov[2], 0.5 * dcov[4], dcov[5] } };
+            double SW[3][3] = { { cov3D[0], cov3D[1], cov3D[2] }, { cov3D[1], cov3D[3], cov3D[4] }, { cov3D[2], cov3D[4], cov3D[5] } };
+            double SC[3][3], GC[3][3], tmp[3][3], A[3][3];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { tmp[i][j] = 0; for (int k = 0; k < 3; k++) tmp[i][j] += Rm[i][k] * SW[k][j]; }
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { SC[i][j] = 0; for (int k = 0; k < 3; k++) SC[i][j] += tmp[i][k] * Rm[j][k]; }
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { tmp[i][j] = 0; for (int k = 0; k < 3; k++) tmp[i][j] += Rm[i][k] * GW[k][j]; }
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { GC[i][j] = 0; for (int k = 0; k < 3; k++) GC[i][j] += tmp[i][k] * Rm[j][k]; }
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+                double v = 0;
+                for (int k = 0; k < 3; k++) v += SC[i][k] * GC[j][k] - GC[k][i] * SC[k][j];
+                A[i][j] = v;
+            }
+            tau[0] += Rg[0] + Rs[0]; tau[1] += Rg[1] + Rs[1]; tau[2] += Rg[2] + Rs[2];
+            tau[3] += pc[1] * Rg[2] - pc[2] * Rg[1] + (A[1][2] - A[2][1]);
+            tau[4] += pc[2] * Rg[0] - pc[0] * Rg[2] + (A[2][0] - A[0][2]);
+            tau[5] += pc[0] * Rg[1] - pc[1] * Rg[0] + (A[0][1] - A[1][0]);
+        }
+    }
+    if (pose_mode && dL_dtau) for (int i = 0; i < 6; i++) dL_dtau[i] = (float)tau[i];
+    free(dL_dz);
+}
+
+/* cr/rasterizer_impl.cu:54-66 */
+void gso_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present)
+{
+    (void)projmatrix;
+    for (int idx = 0; idx < P; idx++) {
+        vec3 p = { means3D[3 * idx], means3D[3 * idx + 1], means3D[3 * idx + 2] };
+        vec3 pv = xform4x3(p, viewmatrix);
+        present[idx] = pv.z > 0.2f;
+    }
+}

@@ -1,0 +1,145 @@
+"""ctypes binding of oracle/gs_oracle.c -- TEST INFRASTRUCTURE ONLY.
+
+May be imported only from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+leg.  The product package gs_localization_amd never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libgs_oracle.so")
+_lib = None
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "gs_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_SO)
+        _lib.gso_forward.restype = C.c_void_p
+        _lib.gso_r_eff.restype = C.c_long
+        _lib.gso_r_eff.argtypes = [C.c_void_p]
+        _lib.gso_num_rendered.argtypes = [C.c_void_p]
+        _lib.gso_free.argtypes = [C.c_void_p]
+    return _lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return None if a is None else np.ascontiguousarray(a, np.float32)
+
+
+def set_threads(n):
+    lib().gso_set_threads(int(n))
+
+
+class Forward:
+    """Result of one oracle forward; owns the opaque state needed by backward()."""
+
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def __del__(self):
+        if getattr(self, "_state", None):
+            lib().gso_free(C.c_void_p(self._state))
+            self._state = None
+
+    def state(self):
+        P, W, H = self.P, self.W, self.H
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        R = self.num_rendered
+        out = dict(depths=np.zeros(P, np.float32), means2D=np.zeros((P, 2), np.float32),
+                   cov3D=np.zeros((P, 6), np.float32), conic_opacity=np.zeros((P, 4), np.float32),
+                   rgb=np.zeros((P, 3), np.float32), clamped=np.zeros((P, 3), np.uint8),
+                   tiles_touched=np.zeros(P, np.uint32), point_list=np.zeros(max(R, 1), np.uint32),
+                   ranges=np.zeros((gx * gy, 2), np.uint32), n_contrib=np.zeros((H, W), np.uint32))
+        lib().gso_get_state(C.c_void_p(self._state), *[_p(out[k]) for k in (
+            "depths", "means2D", "cov3D", "conic_opacity", "rgb", "clamped", "tiles_touched", "point_list",
+            "ranges", "n_contrib")])
+        out["point_list"] = out["point_list"][:R]
+        return out
+
+
+def forward(means3D, opacities, viewmatrix, projmatrix, campos, W, H, tanfovx, tanfovy, bg, sh_degree=0,
+            shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
+            scale_modifier=1.0, want_n_touched=False):
+    L = lib()
+    means3D = _f32(means3D)
+    P = means3D.shape[0]
+    shs, colors_precomp, scales, rotations, cov3D_precomp = map(_f32, (shs, colors_precomp, scales, rotations, cov3D_precomp))
+    opacities = _f32(opacities).reshape(-1)
+    viewmatrix, projmatrix, campos, bg = map(_f32, (viewmatrix, projmatrix, campos, bg))
+    M = shs.shape[1] if shs is not None else 0
+    color = np.zeros((3, H, W), np.float32)
+    depth = np.zeros((1, H, W), np.float32)
+    alpha = np.zeros((1, H, W), np.float32)
+    radii = np.zeros(P, np.int32)
+    n_touched = np.zeros(P, np.int32) if want_n_touched else None
+    st = L.gso_forward(C.c_int(P), C.c_int(sh_degree), C.c_int(M), _p(bg), C.c_int(W), C.c_int(H), _p(means3D),
+                       _p(shs), _p(colors_precomp), _p(opacities), _p(scales), C.c_float(scale_modifier),
+                       _p(rotations), _p(cov3D_precomp), _p(viewmatrix), _p(projmatrix), _p(campos),
+                       C.c_float(tanfovx), C.c_float(tanfovy), _p(color), _p(depth), _p(alpha), _p(radii),
+                       _p(n_touched))
+    R = L.gso_num_rendered(C.c_void_p(st))
+    return Forward(_state=st, P=P, W=W, H=H, M=M, sh_degree=sh_degree, num_rendered=R, color=color, depth=depth,
+                   alpha=alpha, radii=radii, n_touched=n_touched,
+                   _in=dict(means3D=means3D, shs=shs, colors_precomp=colors_precomp, scales=scales,
+                            rotations=rotations, cov3D_precomp=cov3D_precomp, opacities=opacities,
+                            viewmatrix=viewmatrix, projmatrix=projmatrix, campos=campos, bg=bg,
+                            tanfovx=tanfovx, tanfovy=tanfovy, scale_modifier=scale_modifier))
+
+
+def r_eff(fwd):
+    return int(lib().gso_r_eff(C.c_void_p(fwd._state)))
+
+
+def backward(fwd, grad_color, grad_depth, grad_alpha, pose_mode=False):
+    """Returns dict of gradients with the shapes of diff_gaussian_rasterization/__init__.py:146-156
+    (+ 'tau' = [d/drho, d/dtheta] when pose_mode)."""
+    L = lib()
+    i = fwd._in
+    P, M = fwd.P, fwd.M
+    g = dict(means2D=np.zeros((P, 3), np.float32), conic=np.zeros((P, 4), np.float32),
+             opacities=np.zeros((P, 1), np.float32), colors_precomp=np.zeros((P, 3), np.float32),
+             means3D=np.zeros((P, 3), np.float32), cov3Ds_precomp=np.zeros((P, 6), np.float32),
+             sh=np.zeros((P, M, 3), np.float32), scales=np.zeros((P, 3), np.float32),
+             rotations=np.zeros((P, 4), np.float32))
+    tau = np.zeros(6, np.float32)
+    gc, gd, ga = _f32(grad_color), _f32(grad_depth), _f32(grad_alpha)
+    L.gso_backward(C.c_void_p(fwd._state), C.c_int(fwd.sh_degree), C.c_int(M), _p(i["bg"]), _p(i["means3D"]),
+                   _p(i["shs"]), _p(i["colors_precomp"]), _p(fwd.alpha), _p(i["scales"]),
+                   C.c_float(i["scale_modifier"]), _p(i["rotations"]), _p(i["cov3D_precomp"]), _p(i["viewmatrix"]),
+                   _p(i["projmatrix"]), _p(i["campos"]), C.c_float(i["tanfovx"]), C.c_float(i["tanfovy"]), _p(gc),
+                   _p(gd), _p(ga), _p(g["means2D"]), _p(g["conic"]), _p(g["opacities"]), _p(g["colors_precomp"]),
+                   _p(g["means3D"]), _p(g["cov3Ds_precomp"]), _p(g["sh"]), _p(g["scales"]), _p(g["rotations"]),
+                   C.c_int(1 if pose_mode else 0), _p(tau))
+    if pose_mode:
+        g["tau"] = tau
+    return g
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    means3D = _f32(means3D)
+    out = np.zeros(means3D.shape[0], np.uint8)
+    lib().gso_mark_visible(C.c_int(means3D.shape[0]), _p(means3D), _p(_f32(viewmatrix)), _p(_f32(projmatrix)), _p(out))
+    return out.astype(bool)
+
+
+def forward_scene(scene, w2c=None, **kw):
+    from gs_localization_amd import scenes as S
+    view, proj, _, campos = S.camera_matrices(scene, w2c)
+    return forward(scene.means3D, scene.opacities, view, proj, campos, scene.W, scene.H, scene.tanfovx,
+                   scene.tanfovy, scene.bg, sh_degree=scene.sh_degree, shs=scene.shs, scales=scene.scales,
+                   rotations=scene.rotations, **kw)
