@@ -1,0 +1,32 @@
+"""Builds libgsr_hip.so (the C-ABI library of include/gsr.h) for gfx950 with hipcc, in-tree."""
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_HERE)
+SRC = os.path.join(_HERE, "csrc", "gsr_api.hip")
+DEPS = [SRC] + [os.path.join(_HERE, "csrc", f) for f in ("gsr_kernels.h", "gsr_device.h")] + [os.path.join(_ROOT, "include", "gsr.h")]
+OUT = os.path.join(_HERE, "libgsr_hip.so")
+
+
+def hipcc():
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def build(force=False, verbose=False):
+    if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
+        return OUT
+    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           "-I" + os.path.join(_ROOT, "include"), "-o", OUT, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,479 @@
+// gsr_api.hip -- host orchestration + the C ABI declared in include/gsr.h.
+// Replaces CudaRasterizer::Rasterizer::{forward,backward,markVisible}
+// (reference: cuda_rasterizer/rasterizer_impl.cu:141-153,197-339,343-444).
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <mutex>
+
+#include "gsr.h"
+#include "gsr_kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, const char* a = "", const char* b = "")
+{
+    char buf[512];
+    snprintf(buf, sizeof(buf), fmt, a, b);
+    g_err = buf;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) return fail(GSR_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+#define LAUNCHCHK(name)                                                                     \
+    do {                                                                                    \
+        hipError_t e_ = hipGetLastError();                                                  \
+        if (e_ != hipSuccess) return fail(GSR_E_HIP, "launch of %s failed: %s", name, hipGetErrorString(e_)); \
+        if (debug) {                                                                        \
+            e_ = hipStreamSynchronize(st);                                                  \
+            if (e_ != hipSuccess) return fail(GSR_E_HIP, "kernel %s faulted: %s", name, hipGetErrorString(e_)); \
+        }                                                                                   \
+    } while (0)
+
+// ---- optional per-kernel HIP-event timing (gsr_profile_*) ----
+enum KernelId { K_PREPROCESS = 0, K_SCAN, K_EMIT, K_SORT, K_RANGES, K_RENDER_FWD, K_BWD_ZERO, K_RENDER_BWD, K_PREPROCESS_BWD, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"preprocess_fwd", "scan", "emit", "sort", "ranges", "render_fwd",
+                                           "bwd_zero", "render_bwd", "preprocess_bwd"};
+struct Profiler {
+    std::mutex mu;
+    unsigned mask = 0;
+    std::vector<hipEvent_t> pool;
+    struct Pending { int id; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    hipEvent_t get()
+    {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e = nullptr;
+        (void)hipEventCreate(&e);
+        return e;
+    }
+};
+Profiler g_prof;
+struct ProfScope {
+    int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on((g_prof.mask >> id_) & 1u)
+    {
+        if (!on) return;
+        std::lock_guard<std::mutex> l(g_prof.mu);
+        a = g_prof.get(); b = g_prof.get();
+        (void)hipEventRecord(a, st);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        (void)hipEventRecord(b, st);
+        std::lock_guard<std::mutex> l(g_prof.mu);
+        g_prof.pending.push_back({id, a, b});
+    }
+};
+
+// 256-byte aligned carving of an opaque workspace; with base == nullptr it only measures.
+struct Carver {
+    char* base;
+    size_t off = 0;
+    explicit Carver(char* b) : base(b) {}
+    template <class T>
+    T* take(size_t n)
+    {
+        off = (off + 255) & ~(size_t)255;
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return r;
+    }
+    size_t size() const { return (off + 255) & ~(size_t)255; }
+};
+
+struct Geom {   // per-Gaussian state carried from forward to backward
+    float* depths; float2* xy; float4* conic_op; float* rgb; float* cov3D; uint8_t* clamped;
+    uint32_t* tiles_touched; uint32_t* offsets; ushort4* rects; float* dL_dz; double* tau_acc;
+    char* scan_tmp; size_t scan_bytes;
+};
+size_t carve_geom(char* base, int P, Geom& g)
+{
+    Carver c(base);
+    const size_t n = P > 0 ? (size_t)P : 1;
+    g.depths = c.take<float>(n);
+    g.xy = c.take<float2>(n);
+    g.conic_op = c.take<float4>(n);
+    g.rgb = c.take<float>(3 * n);
+    g.cov3D = c.take<float>(6 * n);
+    g.clamped = c.take<uint8_t>(n);
+    g.tiles_touched = c.take<uint32_t>(n);
+    g.offsets = c.take<uint32_t>(n);
+    g.rects = c.take<ushort4>(n);
+    g.dL_dz = c.take<float>(n);
+    g.tau_acc = c.take<double>(8);
+    g.scan_bytes = 0;
+    (void)hipcub::DeviceScan::InclusiveSum(nullptr, g.scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    g.scan_tmp = c.take<char>(g.scan_bytes);
+    return c.size();
+}
+
+struct Img {
+    uint32_t* n_contrib; uint2* ranges;
+};
+size_t carve_img(char* base, int W, int H, Img& im)
+{
+    Carver c(base);
+    const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+    im.n_contrib = c.take<uint32_t>((size_t)W * H);
+    im.ranges = c.take<uint2>((size_t)gx * gy);
+    return c.size();
+}
+
+struct Bin {
+    uint64_t* keys_unsorted; uint64_t* keys; uint32_t* vals_unsorted; uint32_t* vals;
+    char* sort_tmp; size_t sort_bytes;
+};
+size_t carve_bin(char* base, int R, Bin& b)
+{
+    Carver c(base);
+    const size_t n = R > 0 ? (size_t)R : 1;
+    b.vals = c.take<uint32_t>(n);
+    b.vals_unsorted = c.take<uint32_t>(n);
+    b.keys = c.take<uint64_t>(n);
+    b.keys_unsorted = c.take<uint64_t>(n);
+    b.sort_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b.sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
+                                       (uint32_t*)nullptr, (int)n);
+    b.sort_tmp = c.take<char>(b.sort_bytes);
+    return c.size();
+}
+
+// number of bits needed to hold values < n  (same result as rasterizer_impl.cu:35-50 for n >= 1)
+int bits_for(uint32_t n)
+{
+    int b = 0;
+    while ((n >> b) != 0u) b++;
+    return b;
+}
+
+int select_device_of(const void* p)
+{
+    hipPointerAttribute_t attr;
+    hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(GSR_E_NODEVICE, "means3D is not a device pointer (%s)", hipGetErrorString(e)); }
+    if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged)
+        return fail(GSR_E_NODEVICE, "means3D must live in device memory%s", "");
+    e = hipSetDevice(attr.device);
+    if (e != hipSuccess) return fail(GSR_E_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
+    return GSR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gsr_last_error(void) { return g_err.c_str(); }
+
+int gsr_profile_enable(unsigned mask)
+{
+    std::lock_guard<std::mutex> l(g_prof.mu);
+    g_prof.mask = mask;
+    return 0;
+}
+int gsr_profile_kernel_count(void) { return K_COUNT; }
+const char* gsr_profile_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
+int gsr_profile_collect(double* ms, long long* launches)
+{
+    std::vector<Profiler::Pending> todo;
+    {
+        std::lock_guard<std::mutex> l(g_prof.mu);
+        todo.swap(g_prof.pending);
+    }
+    for (auto& p : todo) {
+        HIPCHK(hipEventSynchronize(p.b));
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, p.a, p.b));
+        if (ms) ms[p.id] += t;
+        if (launches) launches[p.id] += 1;
+    }
+    std::lock_guard<std::mutex> l(g_prof.mu);
+    for (auto& p : todo) { g_prof.pool.push_back(p.a); g_prof.pool.push_back(p.b); }
+    return 0;
+}
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+
+int gsr_device_ok(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return 0; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
+}
+
+size_t gsr_geometry_bytes(int P) { Geom g; return carve_geom(nullptr, P, g); }
+size_t gsr_image_bytes(int width, int height) { Img im; return carve_img(nullptr, width, height, im); }
+size_t gsr_binning_bytes(int num_rendered) { Bin b; return carve_bin(nullptr, num_rendered, b); }
+
+int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn binning_buffer, void* binning_ctx,
+                gsr_resize_fn image_buffer, void* image_ctx, int P, int D, int M, const float* background, int width,
+                int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
+                int prefiltered, float* out_color, float* out_depth, float* out_alpha, int* radii, int debug,
+                int* n_touched, void* stream)
+{
+    (void)prefiltered;   // the reference only uses it to trap on a culled point (auxiliary.h:152-156)
+    using namespace gsr;
+    hipStream_t st = (hipStream_t)stream;
+    if (P < 0 || width <= 0 || height <= 0) return fail(GSR_E_INVALID, "P >= 0 and positive image size required%s", "");
+    if (!geometry_buffer || !binning_buffer || !image_buffer) return fail(GSR_E_INVALID, "resize callbacks must not be NULL%s", "");
+    if (!out_color || !out_depth || !out_alpha) return fail(GSR_E_INVALID, "output images must not be NULL%s", "");
+    const size_t N = (size_t)width * height;
+    if (P == 0) {
+        // rasterize_points.cu:81 skips the rasterizer entirely: outputs stay at their zero fill
+        void* probe = out_color;
+        int rc = select_device_of(probe);
+        if (rc != GSR_OK) return rc;
+        HIPCHK(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(out_depth, 0, N * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(out_alpha, 0, N * sizeof(float), st));
+        return 0;
+    }
+    if (!means3D || !opacities || !background || !viewmatrix || !projmatrix || !cam_pos || !radii)
+        return fail(GSR_E_INVALID, "means3D/opacities/background/viewmatrix/projmatrix/cam_pos/radii must not be NULL%s", "");
+    if ((shs == nullptr) == (colors_precomp == nullptr))
+        return fail(GSR_E_INVALID, "provide exactly one of shs / colors_precomp%s", "");
+    if (((scales == nullptr) || (rotations == nullptr)) == (cov3D_precomp == nullptr))
+        return fail(GSR_E_INVALID, "provide exactly one of (scales, rotations) / cov3D_precomp%s", "");
+    if (shs && (M <= 0 || (D + 1) * (D + 1) > M || D < 0 || D > 3))
+        return fail(GSR_E_INVALID, "SH degree / coefficient count mismatch%s", "");
+    int rc = select_device_of(means3D);
+    if (rc != GSR_OK) return rc;
+
+    const int gx = (width + GSR_TILE - 1) / GSR_TILE, gy = (height + GSR_TILE - 1) / GSR_TILE;
+    if (gx > 65535 || gy > 65535) return fail(GSR_E_INVALID, "image too large%s", "");
+    const int ntiles = gx * gy;
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+
+    Geom g;
+    const size_t gbytes = carve_geom(nullptr, P, g);
+    char* gptr = (char*)geometry_buffer(geometry_ctx, gbytes);
+    if (!gptr) return fail(GSR_E_ALLOC, "geometry buffer callback returned NULL%s", "");
+    carve_geom(gptr, P, g);
+    Img im;
+    const size_t ibytes = carve_img(nullptr, width, height, im);
+    char* iptr = (char*)image_buffer(image_ctx, ibytes);
+    if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
+    carve_img(iptr, width, height, im);
+
+    const int pblocks = (P + GSR_BLOCK - 1) / GSR_BLOCK;
+    PreArgs pa;
+    pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.gx = gx; pa.gy = gy;
+    pa.means = means3D; pa.scales = scales; pa.mod = scale_modifier; pa.rots = rotations; pa.opac = opacities;
+    pa.shs = shs; pa.cov3D_pre = cov3D_precomp; pa.colors_pre = colors_precomp;
+    pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos;
+    pa.tanx = tan_fovx; pa.tany = tan_fovy; pa.fx = focal_x; pa.fy = focal_y;
+    pa.radii = radii; pa.xy = g.xy; pa.depths = g.depths; pa.cov3D = g.cov3D; pa.rgb = g.rgb; pa.conic_op = g.conic_op;
+    pa.clamped = g.clamped; pa.tiles_touched = g.tiles_touched; pa.rects = g.rects;
+    {
+        ProfScope ps(K_PREPROCESS, st);
+        hipLaunchKernelGGL(k_preprocess, dim3(pblocks), dim3(GSR_BLOCK), 0, st, pa);
+    }
+    LAUNCHCHK("k_preprocess");
+    {
+        ProfScope ps(K_SCAN, st);
+        HIPCHK(hipcub::DeviceScan::InclusiveSum(g.scan_tmp, g.scan_bytes, g.tiles_touched, g.offsets, P, st));
+    }
+
+    // one blocking 4-byte read, as rasterizer_impl.cu:282
+    uint32_t num_rendered_u = 0;
+    HIPCHK(hipMemcpyAsync(&num_rendered_u, g.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (num_rendered_u > 0x7fffffffu) return fail(GSR_E_INVALID, "more than 2^31 tile instances%s", "");
+    const int R = (int)num_rendered_u;
+
+    Bin b;
+    const size_t bbytes = carve_bin(nullptr, R, b);
+    char* bptr = (char*)binning_buffer(binning_ctx, bbytes);
+    if (!bptr) return fail(GSR_E_ALLOC, "binning buffer callback returned NULL%s", "");
+    carve_bin(bptr, R, b);
+
+    HIPCHK(hipMemsetAsync(im.ranges, 0, (size_t)ntiles * sizeof(uint2), st));
+    if (R > 0) {
+        {
+            ProfScope ps(K_EMIT, st);
+            hipLaunchKernelGGL(k_emit, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const float*)g.depths,
+                               (const uint32_t*)g.offsets, (const uint32_t*)g.tiles_touched, (const ushort4*)g.rects, gx,
+                               b.keys_unsorted, b.vals_unsorted);
+        }
+        LAUNCHCHK("k_emit");
+        const int end_bit = 32 + bits_for((uint32_t)ntiles);
+        {
+            ProfScope ps(K_SORT, st);
+            HIPCHK(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys_unsorted, b.keys, b.vals_unsorted,
+                                                      b.vals, R, 0, end_bit, st));
+        }
+        {
+            ProfScope ps(K_RANGES, st);
+            hipLaunchKernelGGL(k_ranges, dim3((R + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, R,
+                               (const uint64_t*)b.keys, im.ranges);
+        }
+        LAUNCHCHK("k_ranges");
+    }
+    if (n_touched) HIPCHK(hipMemsetAsync(n_touched, 0, (size_t)P * sizeof(int), st));
+    const float* feat = colors_precomp ? colors_precomp : g.rgb;
+    ProfScope* psr = new ProfScope(K_RENDER_FWD, st);
+    if (n_touched)
+        hipLaunchKernelGGL(k_render_fwd<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
+                           (const uint32_t*)b.vals, width, height, gx, ntiles, (const float2*)g.xy, feat,
+                           (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha,
+                           im.n_contrib, n_touched);
+    else
+        hipLaunchKernelGGL(k_render_fwd<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
+                           (const uint32_t*)b.vals, width, height, gx, ntiles, (const float2*)g.xy, feat,
+                           (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha,
+                           im.n_contrib, (int*)nullptr);
+    delete psr;
+    LAUNCHCHK("k_render_fwd");
+    return R;
+}
+
+int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* alphas, const float* scales,
+                 float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                 char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix, const float* dL_ddepths,
+                 const float* dL_dalphas, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
+                 int pose_mode, float* dL_dtau, void* stream)
+{
+    using namespace gsr;
+    hipStream_t st = (hipStream_t)stream;
+    if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(GSR_E_INVALID, "bad sizes%s", "");
+    if (P == 0) {
+        if (pose_mode && dL_dtau) {
+            int rc0 = select_device_of(dL_dtau);
+            if (rc0 != GSR_OK) return rc0;
+            HIPCHK(hipMemsetAsync(dL_dtau, 0, 6 * sizeof(float), st));
+        }
+        return 0;
+    }
+    if (!means3D || !radii || !geom_buffer || !binning_buffer || !img_buffer || !alphas || !dL_dpix || !dL_ddepths ||
+        !dL_dalphas || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+        return fail(GSR_E_INVALID, "a required backward pointer is NULL%s", "");
+    if (pose_mode && !dL_dtau) return fail(GSR_E_INVALID, "pose_mode needs dL_dtau%s", "");
+    int rc = select_device_of(means3D);
+    if (rc != GSR_OK) return rc;
+
+    const int gx = (width + GSR_TILE - 1) / GSR_TILE, gy = (height + GSR_TILE - 1) / GSR_TILE;
+    const int ntiles = gx * gy;
+    const float focal_y = height / (2.0f * tan_fovy);
+    const float focal_x = width / (2.0f * tan_fovx);
+    Geom g; carve_geom(geom_buffer, P, g);
+    Bin b; carve_bin(binning_buffer, R, b);
+    Img im; carve_img(img_buffer, width, height, im);
+
+    // accumulators of K7 (atomically summed); everything else is written exactly once by K8/K9
+    ProfScope* psz = new ProfScope(K_BWD_ZERO, st);
+    HIPCHK(hipMemsetAsync(dL_dmean2D, 0, (size_t)P * 3 * sizeof(float), st));
+    HIPCHK(hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * sizeof(float), st));
+    HIPCHK(hipMemsetAsync(dL_dopacity, 0, (size_t)P * sizeof(float), st));
+    HIPCHK(hipMemsetAsync(dL_dcolor, 0, (size_t)P * 3 * sizeof(float), st));
+    if (pose_mode) {
+        HIPCHK(hipMemsetAsync(g.dL_dz, 0, (size_t)P * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * sizeof(double), st));
+    }
+    delete psz;
+    const float* color_ptr = colors_precomp ? colors_precomp : g.rgb;
+    ProfScope* psb = new ProfScope(K_RENDER_BWD, st);
+    if (pose_mode)
+        hipLaunchKernelGGL(k_render_bwd<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
+                           (const uint32_t*)b.vals, width, height, gx, ntiles, background, (const float2*)g.xy,
+                           (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas,
+                           (const uint32_t*)im.n_contrib, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic,
+                           dL_dopacity, dL_dcolor, g.dL_dz);
+    else
+        hipLaunchKernelGGL(k_render_bwd<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
+                           (const uint32_t*)b.vals, width, height, gx, ntiles, background, (const float2*)g.xy,
+                           (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas,
+                           (const uint32_t*)im.n_contrib, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic,
+                           dL_dopacity, dL_dcolor, (float*)nullptr);
+    delete psb;
+    LAUNCHCHK("k_render_bwd");
+
+    PreBwdArgs pb;
+    pb.P = P; pb.D = D; pb.M = M;
+    pb.means = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = g.clamped;
+    pb.scales = scales; pb.rots = rotations; pb.mod = scale_modifier;
+    pb.cov3D = cov3D_precomp ? cov3D_precomp : g.cov3D;
+    pb.view = viewmatrix; pb.proj = projmatrix; pb.campos = campos;
+    pb.fx = focal_x; pb.fy = focal_y; pb.tanx = tan_fovx; pb.tany = tan_fovy;
+    pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dcolor = dL_dcolor; pb.dL_dz = g.dL_dz;
+    pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale; pb.dL_drot = dL_drot;
+    pb.pose = pose_mode ? 1 : 0; pb.tau_acc = g.tau_acc;
+    {
+        ProfScope ps(K_PREPROCESS_BWD, st);
+        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, pb);
+    }
+    LAUNCHCHK("k_preprocess_bwd");
+    if (pose_mode) {
+        hipLaunchKernelGGL(k_tau_finish, dim3(1), dim3(64), 0, st, (const double*)g.tau_acc, dL_dtau);
+        LAUNCHCHK("k_tau_finish");
+    }
+    return 0;
+}
+
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
+                     void* stream)
+{
+    (void)projmatrix;
+    const int debug = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (P < 0) return fail(GSR_E_INVALID, "P must be >= 0%s", "");
+    if (P == 0) return 0;
+    if (!means3D || !viewmatrix || !present) return fail(GSR_E_INVALID, "NULL pointer%s", "");
+    int rc = select_device_of(means3D);
+    if (rc != GSR_OK) return rc;
+    hipLaunchKernelGGL(gsr::k_mark_visible, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, means3D,
+                       viewmatrix, present);
+    LAUNCHCHK("k_mark_visible");
+    return 0;
+}
+
+int gsr_forward_stats(int P, int width, int height, const int* radii, const char* geom_buffer, const char* img_buffer,
+                      long long stats[4], void* stream)
+{
+    using namespace gsr;
+    const int debug = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (P <= 0 || !radii || !geom_buffer || !img_buffer || !stats) return fail(GSR_E_INVALID, "bad stats arguments%s", "");
+    int rc = select_device_of(radii);
+    if (rc != GSR_OK) return rc;
+    Geom g; carve_geom(const_cast<char*>(geom_buffer), P, g);
+    Img im; carve_img(const_cast<char*>(img_buffer), width, height, im);
+    const int gx = (width + GSR_TILE - 1) / GSR_TILE, gy = (height + GSR_TILE - 1) / GSR_TILE;
+    unsigned long long* d = nullptr;
+    HIPCHK(hipMalloc(&d, 4 * sizeof(unsigned long long)));
+    HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_stats_gauss, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, radii,
+                       (const uint32_t*)g.tiles_touched, d);
+    LAUNCHCHK("k_stats_gauss");
+    hipLaunchKernelGGL(k_stats_tiles, dim3(gx * gy), dim3(GSR_BLOCK), 0, st, width, height, gx,
+                       (const uint32_t*)im.n_contrib, d);
+    LAUNCHCHK("k_stats_tiles");
+    unsigned long long h[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    HIPCHK(hipFree(d));
+    stats[0] = (long long)h[0];
+    stats[1] = (long long)h[1];   // with the reference bounding rule, emitted == R
+    stats[2] = (long long)h[1];
+    stats[3] = (long long)h[2];
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,737 @@
+// gsr_kernels.h -- gfx950 kernels of the splat rasterizer hot path (forward + backward).
+// Included once by gsr_api.hip.  Per-kernel roofline notes are in DESIGN.md section "Kernels".
+#pragma once
+#include "gsr_device.h"
+
+namespace gsr {
+
+// ---------------------------------------------------------------------------------------------
+// K1  per-Gaussian preprocess (replaces forward.cu:155-256 preprocessCUDA).
+// One lane per Gaussian; HBM-streaming: reads 44+12M B, writes <= 80 B per Gaussian.
+// ---------------------------------------------------------------------------------------------
+struct PreArgs {
+    int P, D, M, W, H, gx, gy;
+    const float* means; const float* scales; float mod; const float* rots; const float* opac;
+    const float* shs; const float* cov3D_pre; const float* colors_pre;
+    const float* view; const float* proj; const float* campos;
+    float tanx, tany, fx, fy;
+    int* radii; float2* xy; float* depths; float* cov3D; float* rgb; float4* conic_op;
+    uint8_t* clamped; uint32_t* tiles_touched; ushort4* rects;
+};
+
+__device__ __forceinline__ float3 sh_to_rgb(int deg, int M, float3 pos, const float* campos, const float* sh,
+                                            uint8_t& clamp_bits)
+{
+    float3 dir = make_float3(pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]);
+    float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
+    float x = dir.x / len, y = dir.y / len, z = dir.z / len;
+    float res[3];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#define S(k) sh[(k) * 3 + c]
+        float r = kSH_C0 * S(0);
+        if (deg > 0) {
+            r = r - kSH_C1 * y * S(1) + kSH_C1 * z * S(2) - kSH_C1 * x * S(3);
+            if (deg > 1) {
+                float xx = x * x, yy = y * y, zz = z * z;
+                float xy = x * y, yz = y * z, xz = x * z;
+                r = r + kSH_C2[0] * xy * S(4) + kSH_C2[1] * yz * S(5) + kSH_C2[2] * (2.0f * zz - xx - yy) * S(6)
+                      + kSH_C2[3] * xz * S(7) + kSH_C2[4] * (xx - yy) * S(8);
+                if (deg > 2) {
+                    r = r + kSH_C3[0] * y * (3.0f * xx - yy) * S(9) + kSH_C3[1] * xy * z * S(10)
+                          + kSH_C3[2] * y * (4.0f * zz - xx - yy) * S(11)
+                          + kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(12)
+                          + kSH_C3[4] * x * (4.0f * zz - xx - yy) * S(13) + kSH_C3[5] * z * (xx - yy) * S(14)
+                          + kSH_C3[6] * x * (xx - 3.0f * yy) * S(15);
+                }
+            }
+        }
+#undef S
+        res[c] = r + 0.5f;
+    }
+    clamp_bits = (uint8_t)((res[0] < 0 ? 1 : 0) | (res[1] < 0 ? 2 : 0) | (res[2] < 0 ? 4 : 0));
+    return make_float3(fmaxf(res[0], 0.0f), fmaxf(res[1], 0.0f), fmaxf(res[2], 0.0f));
+}
+
+__global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
+{
+    const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    if (idx >= a.P) return;
+    a.radii[idx] = 0;
+    a.tiles_touched[idx] = 0;
+
+    const float3 p = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
+    const float4 ph = xform4x4(p, a.proj);
+    const float pw = 1.0f / (ph.w + 0.0000001f);
+    const float3 pproj = make_float3(ph.x * pw, ph.y * pw, ph.z * pw);
+    const float3 pview = xform4x3(p, a.view);
+    if (pview.z <= 0.2f) return;     // near cull (auxiliary.h:150)
+
+    float cov6[6];
+    if (a.cov3D_pre != nullptr) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov6[i] = a.cov3D_pre[6 * (size_t)idx + i];
+    } else {
+        float s3[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+        const float4 q = reinterpret_cast<const float4*>(a.rots)[idx];
+        float q4[4] = {q.x, q.y, q.z, q.w};
+        cov3d_from_scale_rot(s3, a.mod, q4, cov6);
+#pragma unroll
+        for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov6[i];
+    }
+    Cov2DTerms ct;
+    cov2d_terms(p, a.fx, a.fy, a.tanx, a.tany, cov6, a.view, ct);
+    const float cx = ct.cov.m[0][0] + 0.3f, cy = ct.cov.m[0][1], cz = ct.cov.m[1][1] + 0.3f;
+    const float det = (cx * cz - cy * cy);
+    if (det == 0.0f) return;
+    const float det_inv = 1.f / det;
+    const float3 conic = make_float3(cz * det_inv, -cy * det_inv, cx * det_inv);
+    const float mid = 0.5f * (cx + cz);
+    const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+    const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+    const float2 pix = make_float2(ndc2pix(pproj.x, a.W), ndc2pix(pproj.y, a.H));
+    int x0, y0, x1, y1;
+    get_rect(pix.x, pix.y, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
+    if ((x1 - x0) * (y1 - y0) == 0) return;
+
+    if (a.colors_pre == nullptr) {
+        uint8_t cb;
+        const float3 c = sh_to_rgb(a.D, a.M, p, a.campos, a.shs + (size_t)idx * a.M * 3, cb);
+        a.rgb[3 * idx] = c.x; a.rgb[3 * idx + 1] = c.y; a.rgb[3 * idx + 2] = c.z;
+        a.clamped[idx] = cb;
+    }
+    a.depths[idx] = pview.z;
+    a.radii[idx] = (int)my_radius;
+    a.xy[idx] = pix;
+    a.conic_op[idx] = make_float4(conic.x, conic.y, conic.z, a.opac[idx]);
+    a.tiles_touched[idx] = (uint32_t)((y1 - y0) * (x1 - x0));
+    a.rects[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3  instance emission (replaces rasterizer_impl.cu:70-111 duplicateWithKeys)
+// key = tile << 32 | depth bits, value = Gaussian index; emitted in index order per Gaussian.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(GSR_BLOCK) k_emit(int P, const float* depths, const uint32_t* offsets,
+                                                    const uint32_t* tiles_touched, const ushort4* rects, int gx,
+                                                    uint64_t* keys, uint32_t* vals)
+{
+    const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    if (idx >= P) return;
+    if (tiles_touched[idx] == 0) return;
+    uint32_t off = (idx == 0) ? 0 : offsets[idx - 1];
+    const ushort4 r = rects[idx];
+    const uint32_t dbits = __float_as_uint(depths[idx]);
+    for (int y = r.y; y < r.w; y++)
+        for (int x = r.x; x < r.z; x++) {
+            keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
+            vals[off] = (uint32_t)idx;
+            off++;
+        }
+}
+
+// K5  per-tile [start,end) in the sorted list (replaces rasterizer_impl.cu:116-138)
+__global__ void __launch_bounds__(GSR_BLOCK) k_ranges(int L, const uint64_t* keys, uint2* ranges)
+{
+    const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    if (idx >= L) return;
+    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    if (idx == 0) ranges[cur].x = 0;
+    else {
+        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        if (cur != prev) { ranges[prev].y = idx; ranges[cur].x = idx; }
+    }
+    if (idx == L - 1) ranges[cur].y = L;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6  per-tile front-to-back compositing (replaces forward.cu:261-379 renderCUDA).
+// One workgroup (4 waves) per 16x16 tile, one lane per pixel.  Batches of 256 splats are gathered
+// once into LDS (44 B each: xy, conic, opacity, rgb, depth, id) and broadcast-read by every lane.
+// ---------------------------------------------------------------------------------------------
+struct SplatLDS {
+    float4 a[GSR_BLOCK];   // x, y, conic.x, conic.y
+    float4 b[GSR_BLOCK];   // conic.z, opacity, depth, id (bits)
+    float4 c[GSR_BLOCK];   // r, g, b, -
+};
+
+template <bool TOUCHED>
+__global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ point_list, int W, int H, int gx,
+                                                          int ntiles, const float2* __restrict__ xy,
+                                                          const float* __restrict__ rgb, const float* __restrict__ depths,
+                                                          const float4* __restrict__ conic_op, const float* __restrict__ bg,
+                                                          float* __restrict__ out_color, float* __restrict__ out_depth,
+                                                          float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
+                                                          int* __restrict__ n_touched)
+{
+    __shared__ SplatLDS s;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x;
+    const int px = tx * GSR_TILE + (tid & 15), py = ty * GSR_TILE + (tid >> 4);
+    const bool inside = px < W && py < H;
+    const int pix_id = W * py + px;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+
+    bool done = !inside;
+    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f;
+    uint32_t contributor = 0, last_contributor = 0;
+
+    for (int base = 0; base < total; base += GSR_BLOCK) {
+        if (__syncthreads_and(done)) break;
+        const int n = min(GSR_BLOCK, total - base);
+        if (tid < n) {
+            const uint32_t id = point_list[range.x + base + tid];
+            const float2 m = xy[id];
+            const float4 co = conic_op[id];
+            s.a[tid] = make_float4(m.x, m.y, co.x, co.y);
+            s.b[tid] = make_float4(co.z, co.w, depths[id], __uint_as_float(id));
+            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], 0.f);
+        }
+        __syncthreads();
+        for (int j = 0; j < n; j++) {
+            if (__all(done)) break;                // whole wave finished: stop early
+            contributor++;
+            const float4 A = s.a[j];
+            const float4 B = s.b[j];
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+            const float alpha = fminf(0.99f, B.y * __expf(power));
+            const float test_T = T * (1.f - alpha);
+            bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (valid && test_T < 0.0001f) { done = true; valid = false; }
+            if (valid) {
+                const float4 Cc = s.c[j];
+                const float w = alpha * T;
+                C0 += Cc.x * w; C1 += Cc.y * w; C2 += Cc.z * w;
+                Dd += B.z * w;
+                T = test_T;
+                last_contributor = contributor;
+            }
+            if (TOUCHED) {
+                // pose package: count pixels where the splat was blended with T still > 0.5;
+                // one atomic per wave instead of one per pixel
+                const unsigned long long m = __ballot(valid && test_T > 0.5f);
+                if (m != 0ull && (tid & 63) == 0) atomicAdd(&n_touched[__float_as_uint(B.w)], (int)__popcll(m));
+            }
+        }
+    }
+    if (inside) {
+        n_contrib[pix_id] = last_contributor;
+        const size_t N = (size_t)W * H;
+        out_color[pix_id] = C0 + T * bg[0];
+        out_color[N + pix_id] = C1 + T * bg[1];
+        out_color[2 * N + pix_id] = C2 + T * bg[2];
+        out_alpha[pix_id] = 1.f - T;
+        out_depth[pix_id] = Dd;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7  per-tile back-to-front gradient (replaces backward.cu:399-581 renderCUDA).
+// Same tile/lane mapping as K6.  Differences from the reference's schedule (results identical up to
+// fp32 summation order):  (1) the walk starts at the tile's deepest contributor (max n_contrib),
+// not at the end of the tile list;  (2) the 9 (+1 for the pose package) per-splat sums are reduced
+// across the 64 lanes with DPP, across the 4 waves with LDS float atomics, and leave the workgroup
+// as ONE global atomic per (tile, splat, quantity) instead of one per (pixel, splat, quantity).
+// ---------------------------------------------------------------------------------------------
+#define GSR_NQ 10
+struct BwdLDS {
+    float4 a[GSR_BLOCK];
+    float4 b[GSR_BLOCK];
+    float4 c[GSR_BLOCK];
+    float acc[GSR_BLOCK][GSR_NQ + 1];   // +1 pad: conflict-free column flush
+    int wmax[4];
+};
+
+template <bool POSE>
+__global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ point_list, int W, int H, int gx,
+                                                          int ntiles, const float* __restrict__ bg,
+                                                          const float2* __restrict__ xy, const float4* __restrict__ conic_op,
+                                                          const float* __restrict__ rgb, const float* __restrict__ depths,
+                                                          const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
+                                                          const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
+                                                          const float* __restrict__ dL_dalphas, float* __restrict__ dL_dmean2D,
+                                                          float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+                                                          float* __restrict__ dL_dcolor, float* __restrict__ dL_dz)
+{
+    __shared__ BwdLDS s;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int px = tx * GSR_TILE + (tid & 15), py = ty * GSR_TILE + (tid >> 4);
+    const bool inside = px < W && py < H;
+    const int pix_id = W * py + px;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = ranges[tile];
+    const size_t N = (size_t)W * H;
+
+    const float T_final = inside ? (1.f - alphas[pix_id]) : 0.f;
+    float T = T_final;
+    const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
+    float dpx = 0.f, dpy = 0.f, dpz = 0.f, dLd = 0.f, dLa = 0.f;
+    if (inside) {
+        dpx = dL_dpix[pix_id]; dpy = dL_dpix[N + pix_id]; dpz = dL_dpix[2 * N + pix_id];
+        dLd = dL_ddepths[pix_id]; dLa = dL_dalphas[pix_id];
+    }
+    const float bg_dot = bg[0] * dpx + bg[1] * dpy + bg[2] * dpz;
+
+    // deepest contributor of the tile
+    int m = last_contributor;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if (lane == 0) s.wmax[wv] = m;
+    __syncthreads();
+    const int total = max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3]));
+
+    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, adr = 0.f, aar = 0.f;
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    int contributor = total;   // 1-based index (within the tile list) of the splat handled next
+
+    for (int base = 0; base < total; base += GSR_BLOCK) {
+        __syncthreads();
+        const int n = min(GSR_BLOCK, total - base);
+        if (tid < n) {
+            const uint32_t id = point_list[range.x + (total - 1 - base - tid)];
+            const float2 mm = xy[id];
+            const float4 co = conic_op[id];
+            s.a[tid] = make_float4(mm.x, mm.y, co.x, co.y);
+            s.b[tid] = make_float4(co.z, co.w, depths[id], __uint_as_float(id));
+            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < GSR_NQ + 1; q++) s.acc[tid][q] = 0.f;
+        __syncthreads();
+        for (int j = 0; j < n; j++, contributor--) {
+            const float4 A = s.a[j];
+            const float4 B = s.b[j];
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+            const float G = __expf(power);
+            const float alpha = fminf(0.99f, B.y * G);
+            const bool valid = (contributor <= last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+            if (__ballot(valid) == 0ull) continue;     // wave-uniform skip
+            float v[GSR_NQ];
+#pragma unroll
+            for (int q = 0; q < GSR_NQ; q++) v[q] = 0.f;
+            if (valid) {
+                const float4 Cc = s.c[j];
+                T = T / (1.f - alpha);
+                const float dchannel_dcolor = alpha * T;
+                float dL_dopa = 0.f;
+                ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = Cc.x; dL_dopa += (Cc.x - ar0) * dpx;
+                ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = Cc.y; dL_dopa += (Cc.y - ar1) * dpy;
+                ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = Cc.z; dL_dopa += (Cc.z - ar2) * dpz;
+                v[0] = dchannel_dcolor * dpx; v[1] = dchannel_dcolor * dpy; v[2] = dchannel_dcolor * dpz;
+                adr = last_alpha * last_depth + (1.f - last_alpha) * adr; last_depth = B.z;
+                dL_dopa += (B.z - adr) * dLd;
+                if (POSE) v[9] = dchannel_dcolor * dLd;
+                aar = last_alpha + (1.f - last_alpha) * aar;
+                dL_dopa += -(alpha - aar) * dLa;
+                dL_dopa *= T;
+                last_alpha = alpha;
+                dL_dopa += (-T_final / (1.f - alpha)) * bg_dot;
+                const float dL_dG = B.y * dL_dopa;
+                const float gdx = G * dx, gdy = G * dy;
+                const float dG_ddelx = -gdx * A.z - gdy * A.w;
+                const float dG_ddely = -gdy * B.x - gdx * A.w;
+                v[3] = dL_dG * dG_ddelx * ddelx_dx;
+                v[4] = dL_dG * dG_ddely * ddely_dy;
+                v[5] = -0.5f * gdx * dx * dL_dG;
+                v[6] = -0.5f * gdx * dy * dL_dG;
+                v[7] = -0.5f * gdy * dy * dL_dG;
+                v[8] = G * dL_dopa;
+            }
+#pragma unroll
+            for (int q = 0; q < (POSE ? GSR_NQ : GSR_NQ - 1); q++) {
+                const float t = wave_sum_to_lane63(v[q]);
+                if (lane == 63) atomicAdd(&s.acc[j][q], t);
+            }
+            if (lane == 63) s.acc[j][GSR_NQ] = 1.f;   // touched flag
+        }
+        __syncthreads();
+        if (tid < n && s.acc[tid][GSR_NQ] != 0.f) {
+            const uint32_t id = __float_as_uint(s.b[tid].w);
+            atomicAdd(&dL_dcolor[3 * id], s.acc[tid][0]);
+            atomicAdd(&dL_dcolor[3 * id + 1], s.acc[tid][1]);
+            atomicAdd(&dL_dcolor[3 * id + 2], s.acc[tid][2]);
+            atomicAdd(&dL_dmean2D[3 * id], s.acc[tid][3]);
+            atomicAdd(&dL_dmean2D[3 * id + 1], s.acc[tid][4]);
+            atomicAdd(&dL_dconic[4 * id], s.acc[tid][5]);
+            atomicAdd(&dL_dconic[4 * id + 1], s.acc[tid][6]);
+            atomicAdd(&dL_dconic[4 * id + 3], s.acc[tid][7]);
+            atomicAdd(&dL_dopacity[id], s.acc[tid][8]);
+            if (POSE) atomicAdd(&dL_dz[id], s.acc[tid][9]);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K8+K9  per-Gaussian chain rule (replaces backward.cu:144-274 computeCov2DCUDA and :346-396
+// preprocessCUDA, fused into one pass) + the SE(3) pose-gradient reduction of the pose package.
+// One lane per Gaussian; HBM-streaming.  Every output element is written exactly once.
+// ---------------------------------------------------------------------------------------------
+struct PreBwdArgs {
+    int P, D, M;
+    const float* means; const int* radii; const float* shs; const uint8_t* clamped;
+    const float* scales; const float* rots; float mod; const float* cov3D;   // cov3D: precomp or geom state
+    const float* view; const float* proj; const float* campos;
+    float fx, fy, tanx, tany;
+    const float* dL_dmean2D; const float* dL_dconic; const float* dL_dcolor; const float* dL_dz;
+    float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
+    int pose; double* tau_acc;
+};
+
+__device__ __forceinline__ float3 dnormvdv3(float3 v, float3 dv)
+{
+    const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
+    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    float3 r;
+    r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
+    r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
+    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
+    return r;
+}
+
+// SH backward (backward.cu:20-139); writes dL_dsh (if non-null) and returns the mean gradient part
+__device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, const float* campos, const float* sh,
+                                              uint8_t cb, float3 dcol, float* dsh)
+{
+    const float3 dir_orig = make_float3(pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]);
+    const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
+    const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+    float dRGB[3] = {dcol.x * ((cb & 1) ? 0.f : 1.f), dcol.y * ((cb & 2) ? 0.f : 1.f), dcol.z * ((cb & 4) ? 0.f : 1.f)};
+    float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
+#define SH(k, c) sh[(k) * 3 + (c)]
+#define DSH(k, w) if (dsh) { _Pragma("unroll") for (int c = 0; c < 3; c++) dsh[(k) * 3 + c] = (w) * dRGB[c]; }
+    DSH(0, kSH_C0);
+    if (deg > 0) {
+        const float w1 = -kSH_C1 * y, w2 = kSH_C1 * z, w3 = -kSH_C1 * x;
+        DSH(1, w1); DSH(2, w2); DSH(3, w3);
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            dx[c] = -kSH_C1 * SH(3, c);
+            dy[c] = -kSH_C1 * SH(1, c);
+            dz[c] = kSH_C1 * SH(2, c);
+        }
+        if (deg > 1) {
+            const float xx = x * x, yy = y * y, zz = z * z;
+            const float xy = x * y, yz = y * z, xz = x * z;
+            const float w4 = kSH_C2[0] * xy, w5 = kSH_C2[1] * yz, w6 = kSH_C2[2] * (2.f * zz - xx - yy);
+            const float w7 = kSH_C2[3] * xz, w8 = kSH_C2[4] * (xx - yy);
+            DSH(4, w4); DSH(5, w5); DSH(6, w6); DSH(7, w7); DSH(8, w8);
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                dx[c] += kSH_C2[0] * y * SH(4, c) + kSH_C2[2] * 2.f * -x * SH(6, c) + kSH_C2[3] * z * SH(7, c) + kSH_C2[4] * 2.f * x * SH(8, c);
+                dy[c] += kSH_C2[0] * x * SH(4, c) + kSH_C2[1] * z * SH(5, c) + kSH_C2[2] * 2.f * -y * SH(6, c) + kSH_C2[4] * 2.f * -y * SH(8, c);
+                dz[c] += kSH_C2[1] * y * SH(5, c) + kSH_C2[2] * 2.f * 2.f * z * SH(6, c) + kSH_C2[3] * x * SH(7, c);
+            }
+            if (deg > 2) {
+                const float w9 = kSH_C3[0] * y * (3.f * xx - yy), w10 = kSH_C3[1] * xy * z;
+                const float w11 = kSH_C3[2] * y * (4.f * zz - xx - yy), w12 = kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
+                const float w13 = kSH_C3[4] * x * (4.f * zz - xx - yy), w14 = kSH_C3[5] * z * (xx - yy);
+                const float w15 = kSH_C3[6] * x * (xx - 3.f * yy);
+                DSH(9, w9); DSH(10, w10); DSH(11, w11); DSH(12, w12); DSH(13, w13); DSH(14, w14); DSH(15, w15);
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    dx[c] += (kSH_C3[0] * SH(9, c) * 3.f * 2.f * xy + kSH_C3[1] * SH(10, c) * yz + kSH_C3[2] * SH(11, c) * -2.f * xy
+                              + kSH_C3[3] * SH(12, c) * -3.f * 2.f * xz + kSH_C3[4] * SH(13, c) * (-3.f * xx + 4.f * zz - yy)
+                              + kSH_C3[5] * SH(14, c) * 2.f * xz + kSH_C3[6] * SH(15, c) * 3.f * (xx - yy));
+                    dy[c] += (kSH_C3[0] * SH(9, c) * 3.f * (xx - yy) + kSH_C3[1] * SH(10, c) * xz
+                              + kSH_C3[2] * SH(11, c) * (-3.f * yy + 4.f * zz - xx) + kSH_C3[3] * SH(12, c) * -3.f * 2.f * yz
+                              + kSH_C3[4] * SH(13, c) * -2.f * xy + kSH_C3[5] * SH(14, c) * -2.f * yz
+                              + kSH_C3[6] * SH(15, c) * -3.f * 2.f * xy);
+                    dz[c] += (kSH_C3[1] * SH(10, c) * xy + kSH_C3[2] * SH(11, c) * 4.f * 2.f * yz
+                              + kSH_C3[3] * SH(12, c) * 3.f * (2.f * zz - xx - yy) + kSH_C3[4] * SH(13, c) * 4.f * 2.f * xz
+                              + kSH_C3[5] * SH(14, c) * (xx - yy));
+                }
+            }
+        }
+    }
+#undef SH
+#undef DSH
+    const float3 dL_ddir = make_float3(dx[0] * dRGB[0] + dx[1] * dRGB[1] + dx[2] * dRGB[2],
+                                       dy[0] * dRGB[0] + dy[1] * dRGB[1] + dy[2] * dRGB[2],
+                                       dz[0] * dRGB[0] + dz[1] * dRGB[1] + dz[2] * dRGB[2]);
+    return dnormvdv3(dir_orig, dL_ddir);
+}
+
+// scale / quaternion gradient from dL/dSigma (backward.cu:278-341)
+__device__ __forceinline__ void cov3d_backward(const float* s3, float mod, const float* q4, const float* d, float* ds,
+                                               float* dq)
+{
+    const float r = q4[0], x = q4[1], y = q4[2], z = q4[3];
+    M3 R = m3_cols(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
+                   2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
+                   2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
+    M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
+    const float sx = mod * s3[0], sy = mod * s3[1], sz = mod * s3[2];
+    S.m[0][0] = sx; S.m[1][1] = sy; S.m[2][2] = sz;
+    const M3 Mm = m3_mul(S, R);
+    const M3 dSig = m3_cols(d[0], 0.5f * d[1], 0.5f * d[2], 0.5f * d[1], d[3], 0.5f * d[4], 0.5f * d[2], 0.5f * d[4], d[5]);
+    const M3 MdS = m3_mul(Mm, dSig);
+    M3 dL_dM;
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) dL_dM.m[i][j] = 2.0f * MdS.m[i][j];
+    const M3 Rt = m3_T(R);
+    M3 dMt = m3_T(dL_dM);
+    ds[0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
+    ds[1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
+    ds[2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
+#pragma unroll
+    for (int j = 0; j < 3; j++) { dMt.m[0][j] *= sx; dMt.m[1][j] *= sy; dMt.m[2][j] *= sz; }
+#define A(i, j) dMt.m[i][j]
+    dq[0] = 2 * z * (A(0, 1) - A(1, 0)) + 2 * y * (A(2, 0) - A(0, 2)) + 2 * x * (A(1, 2) - A(2, 1));
+    dq[1] = 2 * y * (A(1, 0) + A(0, 1)) + 2 * z * (A(2, 0) + A(0, 2)) + 2 * r * (A(1, 2) - A(2, 1)) - 4 * x * (A(2, 2) + A(1, 1));
+    dq[2] = 2 * x * (A(1, 0) + A(0, 1)) + 2 * r * (A(2, 0) - A(0, 2)) + 2 * z * (A(1, 2) + A(2, 1)) - 4 * y * (A(2, 2) + A(0, 0));
+    dq[3] = 2 * r * (A(0, 1) - A(1, 0)) + 2 * x * (A(2, 0) + A(0, 2)) + 2 * y * (A(1, 2) + A(2, 1)) - 4 * z * (A(1, 1) + A(0, 0));
+#undef A
+}
+
+__global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
+{
+    __shared__ double s_tau[4][6];
+    const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float tau[6] = {0, 0, 0, 0, 0, 0};
+    const bool live = idx < a.P;
+    const bool vis = live && a.radii[idx] > 0;
+
+    if (live && !vis) {
+        // invisible Gaussian: every gradient is zero, written explicitly (outputs are not pre-zeroed)
+#pragma unroll
+        for (int i = 0; i < 3; i++) a.dL_dmean3D[3 * (size_t)idx + i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
+        if (a.dL_dsh) for (int i = 0; i < a.M * 3; i++) a.dL_dsh[(size_t)idx * a.M * 3 + i] = 0.f;
+        if (a.dL_dscale) {
+#pragma unroll
+            for (int i = 0; i < 3; i++) a.dL_dscale[3 * (size_t)idx + i] = 0.f;
+        }
+        if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (vis) {
+        const float* cov3D = a.cov3D + 6 * (size_t)idx;
+        float cov6[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov6[i] = cov3D[i];
+        const float3 mean = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
+        const float dcx = a.dL_dconic[4 * idx], dcy = a.dL_dconic[4 * idx + 1], dcz = a.dL_dconic[4 * idx + 3];
+        Cov2DTerms ct;
+        cov2d_terms(mean, a.fx, a.fy, a.tanx, a.tany, cov6, a.view, ct);
+        const float limx = 1.3f * a.tanx, limy = 1.3f * a.tany;
+        const float x_grad_mul = (ct.txtz < -limx || ct.txtz > limx) ? 0.f : 1.f;
+        const float y_grad_mul = (ct.tytz < -limy || ct.tytz > limy) ? 0.f : 1.f;
+        const float ca = ct.cov.m[0][0] + 0.3f, cb = ct.cov.m[0][1], cc = ct.cov.m[1][1] + 0.3f;
+        const float denom = ca * cc - cb * cb;
+        float dL_da = 0, dL_db = 0, dL_dc = 0;
+        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+        float dcov[6];
+        const M3& T = ct.T;
+        const M3& V = ct.Vrk;
+        const M3& Wm = ct.W;
+#define TT(i, j) T.m[i][j]
+#define VV(i, j) V.m[i][j]
+#define WW(i, j) Wm.m[i][j]
+        if (denom2inv != 0) {
+            dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
+            dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
+            dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+            dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
+            dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
+            dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
+            dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
+            dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
+            dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 6; i++) dcov[i] = 0;
+        }
+#pragma unroll
+        for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+
+        const float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da + (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
+        const float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da + (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
+        const float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da + (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
+        const float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc + (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
+        const float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc + (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
+        const float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc + (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
+        const float dL_dJ00 = WW(0, 0) * dL_dT00 + WW(0, 1) * dL_dT01 + WW(0, 2) * dL_dT02;
+        const float dL_dJ02 = WW(2, 0) * dL_dT00 + WW(2, 1) * dL_dT01 + WW(2, 2) * dL_dT02;
+        const float dL_dJ11 = WW(1, 0) * dL_dT10 + WW(1, 1) * dL_dT11 + WW(1, 2) * dL_dT12;
+        const float dL_dJ12 = WW(2, 0) * dL_dT10 + WW(2, 1) * dL_dT11 + WW(2, 2) * dL_dT12;
+#undef TT
+#undef VV
+#undef WW
+        const float3 t = ct.t;
+        const float tz = 1.f / t.z;
+        const float tz2 = tz * tz;
+        const float tz3 = tz2 * tz;
+        const float dL_dtx = x_grad_mul * -a.fx * tz2 * dL_dJ02;
+        const float dL_dty = y_grad_mul * -a.fy * tz2 * dL_dJ12;
+        const float dL_dtz = -a.fx * tz2 * dL_dJ00 - a.fy * tz2 * dL_dJ11 + (2 * a.fx * t.x) * tz3 * dL_dJ02 + (2 * a.fy * t.y) * tz3 * dL_dJ12;
+        const float* vm = a.view;
+        const float3 g_cov = make_float3(vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz,
+                                         vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz,
+                                         vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz);
+        float dm0 = g_cov.x, dm1 = g_cov.y, dm2 = g_cov.z;
+
+        const float* proj = a.proj;
+        const float4 m_hom = xform4x4(mean, proj);
+        const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+        const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+        const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+        const float g2x = a.dL_dmean2D[3 * idx], g2y = a.dL_dmean2D[3 * idx + 1];
+        float3 g_m2d;
+        g_m2d.x = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+        g_m2d.y = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+        g_m2d.z = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+        dm0 += g_m2d.x; dm1 += g_m2d.y; dm2 += g_m2d.z;
+
+        float3 g_depth = make_float3(0.f, 0.f, 0.f);
+        if (a.pose) {
+            const float dz = a.dL_dz[idx];
+            g_depth = make_float3(vm[2] * dz, vm[6] * dz, vm[10] * dz);
+            dm0 += g_depth.x; dm1 += g_depth.y; dm2 += g_depth.z;
+        }
+        float3 g_sh = make_float3(0.f, 0.f, 0.f);
+        if (a.shs) {
+            const float3 dcol = make_float3(a.dL_dcolor[3 * idx], a.dL_dcolor[3 * idx + 1], a.dL_dcolor[3 * idx + 2]);
+            g_sh = sh_backward(a.D, a.M, mean, a.campos, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dcol,
+                               a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
+            dm0 += g_sh.x; dm1 += g_sh.y; dm2 += g_sh.z;
+        }
+        a.dL_dmean3D[3 * (size_t)idx] = dm0;
+        a.dL_dmean3D[3 * (size_t)idx + 1] = dm1;
+        a.dL_dmean3D[3 * (size_t)idx + 2] = dm2;
+
+        if (a.scales && (a.dL_dscale || a.dL_drot)) {
+            float s3[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+            const float4 q = reinterpret_cast<const float4*>(a.rots)[idx];
+            float q4[4] = {q.x, q.y, q.z, q.w};
+            float ds[3], dq[4];
+            cov3d_backward(s3, a.mod, q4, dcov, ds, dq);
+            if (a.dL_dscale) {
+                a.dL_dscale[3 * (size_t)idx] = ds[0]; a.dL_dscale[3 * (size_t)idx + 1] = ds[1]; a.dL_dscale[3 * (size_t)idx + 2] = ds[2];
+            }
+            if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+        } else {
+            if (a.dL_dscale) { a.dL_dscale[3 * (size_t)idx] = 0.f; a.dL_dscale[3 * (size_t)idx + 1] = 0.f; a.dL_dscale[3 * (size_t)idx + 2] = 0.f; }
+            if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+
+        if (a.pose) {
+            // dL/dtau for T_w2c <- exp([rho,theta]) T_w2c at 0:
+            //   drho   = R g_geo + R g_sh
+            //   dtheta = p_C x (R g_geo) + axial(Sigma_C G_C^T - G_C^T Sigma_C)
+            // with R[r][c] = view[4c+r], Sigma_C = R Sigma_W R^T, G_C = R G_W R^T, G_W symmetric.
+            float Rm[3][3];
+#pragma unroll
+            for (int r = 0; r < 3; r++)
+#pragma unroll
+                for (int c = 0; c < 3; c++) Rm[r][c] = vm[c * 4 + r];
+            const float gg[3] = {g_cov.x + g_m2d.x + g_depth.x, g_cov.y + g_m2d.y + g_depth.y, g_cov.z + g_m2d.z + g_depth.z};
+            const float gs[3] = {g_sh.x, g_sh.y, g_sh.z};
+            const float mw[3] = {mean.x, mean.y, mean.z};
+            float pc[3], Rg[3], Rs[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                pc[r] = Rm[r][0] * mw[0] + Rm[r][1] * mw[1] + Rm[r][2] * mw[2] + vm[12 + r];
+                Rg[r] = Rm[r][0] * gg[0] + Rm[r][1] * gg[1] + Rm[r][2] * gg[2];
+                Rs[r] = Rm[r][0] * gs[0] + Rm[r][1] * gs[1] + Rm[r][2] * gs[2];
+            }
+            const float GW[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]}, {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+            const float SW[3][3] = {{cov6[0], cov6[1], cov6[2]}, {cov6[1], cov6[3], cov6[4]}, {cov6[2], cov6[4], cov6[5]}};
+            float SC[3][3], GC[3][3], tmp[3][3];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) tmp[i][j] = Rm[i][0] * SW[0][j] + Rm[i][1] * SW[1][j] + Rm[i][2] * SW[2][j];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) SC[i][j] = tmp[i][0] * Rm[j][0] + tmp[i][1] * Rm[j][1] + tmp[i][2] * Rm[j][2];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) tmp[i][j] = Rm[i][0] * GW[0][j] + Rm[i][1] * GW[1][j] + Rm[i][2] * GW[2][j];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) GC[i][j] = tmp[i][0] * Rm[j][0] + tmp[i][1] * Rm[j][1] + tmp[i][2] * Rm[j][2];
+            // A = SC*GC^T - GC^T*SC ; only the three antisymmetric combinations are needed
+            auto Aij = [&](int i, int j) {
+                float v = 0.f;
+#pragma unroll
+                for (int k = 0; k < 3; k++) v += SC[i][k] * GC[j][k] - GC[k][i] * SC[k][j];
+                return v;
+            };
+            tau[0] = Rg[0] + Rs[0]; tau[1] = Rg[1] + Rs[1]; tau[2] = Rg[2] + Rs[2];
+            tau[3] = pc[1] * Rg[2] - pc[2] * Rg[1] + (Aij(1, 2) - Aij(2, 1));
+            tau[4] = pc[2] * Rg[0] - pc[0] * Rg[2] + (Aij(2, 0) - Aij(0, 2));
+            tau[5] = pc[0] * Rg[1] - pc[1] * Rg[0] + (Aij(0, 1) - Aij(1, 0));
+        }
+    }
+    if (a.pose) {
+        // block reduction in fp64, one fp64 atomic per block and component
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const double t = wave_sum_d((double)tau[i]);
+            if (lane == 0) s_tau[wv][i] = t;
+        }
+        __syncthreads();
+        if (threadIdx.x < 6) {
+            const double t = s_tau[0][threadIdx.x] + s_tau[1][threadIdx.x] + s_tau[2][threadIdx.x] + s_tau[3][threadIdx.x];
+            if (t != 0.0) atomicAdd(&a.tau_acc[threadIdx.x], t);
+        }
+    }
+}
+
+__global__ void k_tau_finish(const double* acc, float* out)
+{
+    if (threadIdx.x < 6) out[threadIdx.x] = (float)acc[threadIdx.x];
+}
+
+// K10  near-plane visibility (replaces rasterizer_impl.cu:54-66 checkFrustum)
+__global__ void __launch_bounds__(GSR_BLOCK) k_mark_visible(int P, const float* means, const float* view, uint8_t* present)
+{
+    const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    if (idx >= P) return;
+    const float3 p = make_float3(means[3 * idx], means[3 * idx + 1], means[3 * idx + 2]);
+    present[idx] = xform4x3(p, view).z > 0.2f ? 1 : 0;
+}
+
+// bench-only statistics: V, sum of tiles_touched, R_eff
+__global__ void __launch_bounds__(GSR_BLOCK) k_stats_gauss(int P, const int* radii, const uint32_t* tiles_touched,
+                                                           unsigned long long* out)
+{
+    const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    unsigned long long v = 0, t = 0;
+    if (idx < P) { v = radii[idx] > 0; t = tiles_touched[idx]; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); t += __shfl_xor(t, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], v); atomicAdd(&out[1], t); }
+}
+__global__ void __launch_bounds__(GSR_BLOCK) k_stats_tiles(int W, int H, int gx, const uint32_t* n_contrib,
+                                                           unsigned long long* out)
+{
+    __shared__ int wm[4];
+    const int tx = blockIdx.x % gx, ty = blockIdx.x / gx;
+    const int px = tx * GSR_TILE + (threadIdx.x & 15), py = ty * GSR_TILE + (threadIdx.x >> 4);
+    int m = (px < W && py < H) ? (int)n_contrib[W * py + px] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&out[2], (unsigned long long)max(max(wm[0], wm[1]), max(wm[2], wm[3])));
+}
+
+}  // namespace gsr

@@ -1,0 +1,311 @@
+"""Host-side mirror of the reference's autograd boundary, on top of the C ABI (include/gsr.h).
+
+Mirrors, name for name and argument for argument:
+  diff_gaussian_rasterization/__init__.py:21-42    rasterize_gaussians
+  diff_gaussian_rasterization/__init__.py:44-158   _RasterizeGaussians (forward / backward)
+  diff_gaussian_rasterization/__init__.py:160-172  GaussianRasterizationSettings  (12 fields)
+  diff_gaussian_rasterization/__init__.py:174-223  GaussianRasterizer (nn.Module, markVisible, forward)
+and the un-vendored pose variant whose only trace is its call site
+  gs_localization/pipelines/tools/__init__.py:15-18,58-72,116-141
+  (13-field settings with projmatrix_raw; forward(..., theta, rho) -> 5-tuple with n_touched).
+
+PyTorch is used for device memory, streams and autograd plumbing only; all arithmetic happens in
+the HIP kernels behind gsr_forward / gsr_backward.  There is no CPU path.
+"""
+from typing import NamedTuple
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def cpu_deep_copy_tuple(input_tuple):
+    copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
+    return tuple(copied_tensors)
+
+
+class GaussianRasterizationSettings(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+class GaussianRasterizationSettingsPose(NamedTuple):
+    image_height: int
+    image_width: int
+    tanfovx: float
+    tanfovy: float
+    bg: torch.Tensor
+    scale_modifier: float
+    viewmatrix: torch.Tensor
+    projmatrix: torch.Tensor
+    projmatrix_raw: torch.Tensor
+    sh_degree: int
+    campos: torch.Tensor
+    prefiltered: bool
+    debug: bool
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("gs_localization_amd: tensors must live on a HIP device (cuda:N); there is no CPU rasterizer")
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+def _ptr(t):
+    """device pointer, or NULL for the reference's 'empty tensor means absent' convention"""
+    return None if (t is None or t.numel() == 0) else t.data_ptr()
+
+
+class _Workspace:
+    """One resizable device byte buffer (the std::function<char*(size_t)> of rasterize_points.cu:27-33)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.t = torch.empty(0, dtype=torch.uint8, device=device)
+        self.fn = _lib.RESIZE_FN(self._resize)
+
+    def _resize(self, _ctx, nbytes):
+        try:
+            self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            return self.t.data_ptr()
+        except Exception:      # surfaces as GSR_E_ALLOC
+            return 0
+
+
+def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, want_touched):
+    lib = _lib.load()
+    _require_gpu(means3D)
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise RuntimeError("means3D must have dimensions (num_points, 3)")
+    dev = means3D.device
+    P = means3D.size(0)
+    H, W = int(rs.image_height), int(rs.image_width)
+    means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp = (
+        _f32c(t) for t in (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
+    bg, view, proj, campos = (_f32c(t.to(dev)) for t in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos))
+    color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
+    depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)
+    n_touched = torch.empty((P,), dtype=torch.int32, device=dev) if want_touched else None
+    M = sh.size(1) if sh.numel() != 0 else 0
+    geom, binning, img = _Workspace(dev), _Workspace(dev), _Workspace(dev)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        rc = lib.gsr_forward(geom.fn, None, binning.fn, None, img.fn, None, P, int(rs.sh_degree), M, _ptr(bg), W, H,
+                             _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
+                             float(rs.scale_modifier), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(view), _ptr(proj),
+                             _ptr(campos), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)),
+                             color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii), int(bool(rs.debug)),
+                             _ptr(n_touched), stream)
+    num_rendered = _lib.check(rc)
+    saved = (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom.t, binning.t, img.t, alpha,
+             opacities)
+    consts = (bg, view, proj, campos)
+    return num_rendered, color, radii, depth, alpha, n_touched, saved, consts
+
+
+def _backward_impl(rs, num_rendered, saved, consts, grad_color, grad_depth, grad_alpha, pose_mode, need):
+    lib = _lib.load()
+    colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, alpha, _ = saved
+    bg, view, proj, campos = consts
+    dev = means3D.device
+    P = means3D.size(0)
+    M = sh.size(1) if sh.numel() != 0 else 0
+    H, W = int(rs.image_height), int(rs.image_width)
+    grad_color, grad_depth, grad_alpha = (_f32c(g) for g in (grad_color, grad_depth, grad_alpha))
+    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors = e(P, 3), e(P, 2, 2), e(P, 1), e(P, 3)
+    dL_dmeans3D, dL_dcov3D = e(P, 3), e(P, 6)
+    # optional outputs: skipped (NULL) when autograd does not need them
+    dL_dsh = e(P, M, 3) if (need["sh"] and M > 0) else None
+    dL_dscales = e(P, 3) if need["scales"] else None
+    dL_drotations = e(P, 4) if need["rotations"] else None
+    dL_dtau = e(6) if pose_mode else None
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    with torch.cuda.device(dev):
+        rc = lib.gsr_backward(P, int(rs.sh_degree), M, int(num_rendered), _ptr(bg), W, H, _ptr(means3D), _ptr(sh),
+                              _ptr(colors_precomp), _ptr(alpha), _ptr(scales), float(rs.scale_modifier),
+                              _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(view), _ptr(proj), _ptr(campos),
+                              float(rs.tanfovx), float(rs.tanfovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
+                              _ptr(imgBuffer), _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha), _ptr(dL_dmeans2D),
+                              _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
+                              _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(rs.debug)),
+                              1 if pose_mode else 0, _ptr(dL_dtau), stream)
+    _lib.check(rc)
+    if dL_dsh is None and need["sh"]:
+        dL_dsh = e(P, M, 3)
+    return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau
+
+
+def _debug_guard(rs, args, fn, dump_name, what):
+    """reference behaviour: in debug mode dump the arguments on failure, then re-raise
+    (diff_gaussian_rasterization/__init__.py:83-90,135-142)"""
+    if not rs.debug:
+        return fn()
+    cpu_args = cpu_deep_copy_tuple(args)
+    try:
+        return fn()
+    except Exception as ex:
+        torch.save(cpu_args, dump_name)
+        print(f"\nAn error occured in {what}. Please forward {dump_name} for debugging.")
+        raise ex
+
+
+class _RasterizeGaussians(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, raster_settings):
+        args = (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+        num_rendered, color, radii, depth, alpha, _, saved, consts = _debug_guard(
+            raster_settings, args, lambda: _forward_impl(*args, raster_settings, False), "snapshot_fw.dump", "forward")
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.consts = consts
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(radii)
+        return color, radii, depth, alpha
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha):
+        rs = ctx.raster_settings
+        nig = ctx.needs_input_grad
+        need = dict(sh=nig[2], scales=nig[5], rotations=nig[6])
+        saved = ctx.saved_tensors
+        fn = lambda: _backward_impl(rs, ctx.num_rendered, saved, ctx.consts, grad_color, grad_depth, grad_alpha, False, need)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations, _) = _debug_guard(rs, saved + (grad_color, grad_depth, grad_alpha), fn, "snapshot_bw.dump", "backward")
+        if saved[11].dim() == 1:
+            grad_opacities = grad_opacities.reshape(-1)
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, None)
+
+
+class _RasterizeGaussiansPose(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta, rho,
+                raster_settings):
+        args = (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp)
+        num_rendered, color, radii, depth, alpha, n_touched, saved, consts = _debug_guard(
+            raster_settings, args, lambda: _forward_impl(*args, raster_settings, True), "snapshot_fw.dump", "forward")
+        ctx.raster_settings = raster_settings
+        ctx.num_rendered = num_rendered
+        ctx.consts = consts
+        ctx.save_for_backward(*saved)
+        ctx.mark_non_differentiable(radii, n_touched)
+        return color, radii, depth, alpha, n_touched
+
+    @staticmethod
+    def backward(ctx, grad_color, grad_radii, grad_depth, grad_alpha, grad_n_touched):
+        rs = ctx.raster_settings
+        nig = ctx.needs_input_grad
+        need = dict(sh=nig[2], scales=nig[5], rotations=nig[6])
+        saved = ctx.saved_tensors
+        fn = lambda: _backward_impl(rs, ctx.num_rendered, saved, ctx.consts, grad_color, grad_depth, grad_alpha, True, need)
+        (grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+         grad_rotations, grad_tau) = _debug_guard(rs, saved + (grad_color, grad_depth, grad_alpha), fn, "snapshot_bw.dump", "backward")
+        if saved[11].dim() == 1:
+            grad_opacities = grad_opacities.reshape(-1)
+        grad_rho = grad_tau[:3]
+        grad_theta = grad_tau[3:]
+        return (grad_means3D, grad_means2D, grad_sh, grad_colors_precomp, grad_opacities, grad_scales, grad_rotations,
+                grad_cov3Ds_precomp, grad_theta, grad_rho, None)
+
+
+def rasterize_gaussians(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                        raster_settings):
+    return _RasterizeGaussians.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp,
+                                     raster_settings)
+
+
+def rasterize_gaussians_pose(means3D, means2D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, theta,
+                             rho, raster_settings):
+    return _RasterizeGaussiansPose.apply(means3D, means2D, sh, colors_precomp, opacities, scales, rotations,
+                                         cov3Ds_precomp, theta, rho, raster_settings)
+
+
+def _mark_visible(positions, raster_settings):
+    lib = _lib.load()
+    _require_gpu(positions)
+    positions = _f32c(positions)
+    dev = positions.device
+    P = positions.size(0)
+    present = torch.empty((P,), dtype=torch.uint8, device=dev)
+    view = _f32c(raster_settings.viewmatrix.to(dev))
+    proj = _f32c(raster_settings.projmatrix.to(dev))
+    with torch.cuda.device(dev):
+        _lib.check(lib.gsr_mark_visible(P, _ptr(positions), _ptr(view), _ptr(proj), _ptr(present),
+                                        torch.cuda.current_stream(dev).cuda_stream))
+    return present.bool()
+
+
+def _check_inputs(shs, colors_precomp, scales, rotations, cov3D_precomp):
+    if (shs is None and colors_precomp is None) or (shs is not None and colors_precomp is not None):
+        raise Exception('Please provide excatly one of either SHs or precomputed colors!')
+    if ((scales is None or rotations is None) and cov3D_precomp is None) or (
+            (scales is not None or rotations is not None) and cov3D_precomp is not None):
+        raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
+
+
+def _empty_if_none(*ts):
+    return tuple(torch.Tensor([]) if t is None else t for t in ts)
+
+
+class GaussianRasterizer(nn.Module):
+    """Package (A): forward(...) -> (color, radii, depth, alpha)."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            return _mark_visible(positions, self.raster_settings)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None):
+        _check_inputs(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        shs, colors_precomp, scales, rotations, cov3D_precomp = _empty_if_none(shs, colors_precomp, scales, rotations,
+                                                                               cov3D_precomp)
+        return rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations, cov3D_precomp,
+                                   self.raster_settings)
+
+
+class GaussianRasterizerPose(nn.Module):
+    """Package (B): forward(..., theta, rho) -> (color, radii, depth, opacity, n_touched)."""
+
+    def __init__(self, raster_settings):
+        super().__init__()
+        self.raster_settings = raster_settings
+
+    def markVisible(self, positions):
+        with torch.no_grad():
+            return _mark_visible(positions, self.raster_settings)
+
+    def forward(self, means3D, means2D, opacities, shs=None, colors_precomp=None, scales=None, rotations=None,
+                cov3D_precomp=None, theta=None, rho=None):
+        _check_inputs(shs, colors_precomp, scales, rotations, cov3D_precomp)
+        shs, colors_precomp, scales, rotations, cov3D_precomp = _empty_if_none(shs, colors_precomp, scales, rotations,
+                                                                               cov3D_precomp)
+        if theta is None:
+            theta = torch.zeros(3, dtype=torch.float32, device=means3D.device)
+        if rho is None:
+            rho = torch.zeros(3, dtype=torch.float32, device=means3D.device)
+        return rasterize_gaussians_pose(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                        cov3D_precomp, theta, rho, self.raster_settings)

@@ -1,0 +1,170 @@
+/*
+ * gsr.h -- C ABI of the MI355X-native differentiable Gaussian-splat rasterizer.
+ *
+ * This is the drop-in boundary for the ONE hot path of RPL-CS-UCL/gs_localization:
+ * everything below `CudaRasterizer::Rasterizer` in the reference
+ *   (gaussian_splatting/submodules/diff-gaussian-rasterization/cuda_rasterizer/rasterizer.h:20-90)
+ * i.e. what rasterize_points.cu:35-227 (the pybind11/torch glue) calls.  Plain pointers and
+ * sizes only -- no torch types.  All pointers are DEVICE pointers (HBM) unless stated otherwise;
+ * all arrays are dense row-major fp32 unless stated otherwise; "nullable" means the reference
+ * passes an empty tensor there (rasterize_points.cu:96-115 hands the dangling data_ptr to
+ * kernels that test it against nullptr, forward.cu:205,241).
+ *
+ * Thread-safety: entry points are re-entrant; they select the device that owns `means3D`
+ * themselves and enqueue on the caller's `stream` (a hipStream_t; NULL = legacy default
+ * stream, which is what the reference's `<<<grid,block>>>` launches use, forward.cu:396,437).
+ * Backward may be called from a different host thread than forward (PyTorch's autograd worker).
+ *
+ * Errors: every entry point returns >= 0 on success and a negative GSR_E_* code on failure;
+ * gsr_last_error() returns the thread-local message (the reference throws std::runtime_error,
+ * rasterizer_impl.cu:243-246, auxiliary.h:166-173).
+ */
+#ifndef GSR_H_INCLUDED
+#define GSR_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+
+enum {
+    GSR_OK = 0,
+    GSR_E_INVALID = -1,   /* bad argument (message says which) */
+    GSR_E_HIP = -2,       /* a HIP runtime call or kernel failed */
+    GSR_E_ALLOC = -3,     /* a resize callback returned NULL */
+    GSR_E_NODEVICE = -4   /* no gfx950 device / pointer is not device memory */
+};
+
+/* Workspace request callback.  Replaces the three `std::function<char*(size_t N)>` buffer
+ * functors of rasterizer.h:31-34 / rasterize_points.cu:27-33: must return a device buffer of
+ * at least `bytes` bytes, 256-byte aligned, that stays valid until the matching backward. */
+typedef void* (*gsr_resize_fn)(void* ctx, size_t bytes);
+
+/* Replaces CudaRasterizer::Rasterizer::forward (rasterizer.h:31-60, rasterizer_impl.cu:197-339).
+ * Same argument order; additions are at the end.
+ *   D = active SH degree, M = SH coefficients per channel (0 if colors_precomp is given).
+ *   shs [P,M,3] nullable | colors_precomp [P,3] nullable   (exactly one)
+ *   scales [P,3] + rotations [P,4] (w,x,y,z; used as given, forward.cu:127) | cov3D_precomp [P,6]
+ *   viewmatrix, projmatrix: 16 floats each, (W2C)^T and (P*W2C)^T row-major; cam_pos: 3 floats
+ *   out_color [3,H,W], out_depth [1,H,W], out_alpha [1,H,W]  (fully written; need not be zeroed)
+ *   radii [P] int32 (fully written)
+ *   n_touched [P] int32 nullable -- `diff_gaussian_rasterization_pose` 5th output
+ *       (gs_localization/pipelines/tools/__init__.py:130); fully written when given.
+ * Returns num_rendered (the `int rendered` of rasterize_points.cu:82) or a negative error.
+ * Performs one blocking device->host read of num_rendered, like rasterizer_impl.cu:282. */
+int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx,
+                gsr_resize_fn binning_buffer, void* binning_ctx,
+                gsr_resize_fn image_buffer, void* image_ctx,
+                int P, int D, int M,
+                const float* background,
+                int width, int height,
+                const float* means3D,
+                const float* shs,
+                const float* colors_precomp,
+                const float* opacities,
+                const float* scales,
+                float scale_modifier,
+                const float* rotations,
+                const float* cov3D_precomp,
+                const float* viewmatrix,
+                const float* projmatrix,
+                const float* cam_pos,
+                float tan_fovx, float tan_fovy,
+                int prefiltered,
+                float* out_color,
+                float* out_depth,
+                float* out_alpha,
+                int* radii,
+                int debug,
+                int* n_touched,
+                void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:62-89, rasterizer_impl.cu:343-444).
+ *   R = value returned by gsr_forward; geom/binning/img buffers = the ones it filled.
+ *   dL_dpix [3,H,W], dL_ddepths [1,H,W], dL_dalphas [1,H,W].
+ *   Outputs (all fully written by this call -- no pre-zeroing needed, unlike
+ *   rasterize_points.cu:158-166):
+ *     dL_dmean2D [P,3] (z = 0), dL_dconic [P,4] (x,y,_,w used), dL_dopacity [P], dL_dcolor [P,3],
+ *     dL_dmean3D [P,3], dL_dcov3D [P,6], dL_dsh [P,M,3] (nullable iff M == 0),
+ *     dL_dscale [P,3], dL_drot [P,4].
+ *   pose_mode = 0: package (A) semantics, faithful to the vendored backward.cu (incl. its quirks).
+ *   pose_mode = 1: package (B): the per-Gaussian depth also back-propagates into dL_dmean3D and
+ *     dL_dtau [6] = [dL/drho(3), dL/dtheta(3)] is written: gradient w.r.t. the left SE(3)
+ *     perturbation T_w2c <- SE3_exp([rho,theta]) * T_w2c at 0
+ *     (gs_localization/pipelines/tools/pose_utils.py:105-122). */
+int gsr_backward(int P, int D, int M, int R,
+                 const float* background,
+                 int width, int height,
+                 const float* means3D,
+                 const float* shs,
+                 const float* colors_precomp,
+                 const float* alphas,
+                 const float* scales,
+                 float scale_modifier,
+                 const float* rotations,
+                 const float* cov3D_precomp,
+                 const float* viewmatrix,
+                 const float* projmatrix,
+                 const float* campos,
+                 float tan_fovx, float tan_fovy,
+                 const int* radii,
+                 char* geom_buffer,
+                 char* binning_buffer,
+                 char* img_buffer,
+                 const float* dL_dpix,
+                 const float* dL_ddepths,
+                 const float* dL_dalphas,
+                 float* dL_dmean2D,
+                 float* dL_dconic,
+                 float* dL_dopacity,
+                 float* dL_dcolor,
+                 float* dL_dmean3D,
+                 float* dL_dcov3D,
+                 float* dL_dsh,
+                 float* dL_dscale,
+                 float* dL_drot,
+                 int debug,
+                 int pose_mode,
+                 float* dL_dtau,
+                 void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer.h:24-29, rasterizer_impl.cu:141-153).
+ * present [P] uint8 (0/1). */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     uint8_t* present, void* stream);
+
+/* Fixed-size parts of the workspace, for callers that pre-allocate instead of resizing
+ * (replaces `required<GeometryState>(P)` etc., rasterizer_impl.h:66-72). */
+size_t gsr_geometry_bytes(int P);
+size_t gsr_image_bytes(int width, int height);
+size_t gsr_binning_bytes(int num_rendered);
+
+/* Statistics of the last forward on this buffer set (host ints, filled by a blocking copy):
+ * stats[0] = visible Gaussians V (radii > 0), stats[1] = R (reference rule),
+ * stats[2] = instances actually emitted after exact tile culling, stats[3] = R_eff
+ * (sum over tiles of the max per-pixel n_contrib). Used by bench.py only. */
+int gsr_forward_stats(int P, int width, int height, const int* radii, const char* geom_buffer,
+                      const char* img_buffer, long long stats[4], void* stream);
+
+/* Optional per-kernel timing with HIP events recorded on the caller's stream around each kernel
+ * (bench.py's roofline leg).  mask bit i enables kernel id i; 0 disables (the default, zero cost).
+ * gsr_profile_collect waits for the recorded events, ADDS elapsed milliseconds / launch counts per
+ * kernel id into ms[] / launches[] (arrays of gsr_profile_kernel_count() entries) and forgets them. */
+int gsr_profile_enable(unsigned mask);
+int gsr_profile_collect(double* ms, long long* launches);
+int gsr_profile_kernel_count(void);
+const char* gsr_profile_kernel_name(int id);
+
+const char* gsr_last_error(void);
+int gsr_abi_version(void);
+/* 1 if a gfx950 device is visible, 0 otherwise (never initialises more than device enumeration) */
+int gsr_device_ok(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_H_INCLUDED */
