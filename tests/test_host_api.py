@@ -1,0 +1,154 @@
+"""CPU: host-side logic, the Python surface of the two drop-in packages, and the C-ABI library
+(loads, exports every symbol include/gsr.h declares; no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "gsr.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsr_[a-z_]+)\s*\(", hdr)) - {"gsr_resize_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    from gs_localization_amd import _lib
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 13
+    for n in names:
+        assert hasattr(lib, n), n
+        assert n in _lib.SIGNATURES, f"{n} missing from the ctypes signature table"
+    assert lib.gsr_abi_version() == 1
+    assert lib.gsr_profile_kernel_count() == 9
+    assert lib.gsr_profile_kernel_name(3) == b"sort"
+
+
+def test_workspace_sizes():
+    from gs_localization_amd import _lib
+    lib = _lib.load()
+    g1, g2 = lib.gsr_geometry_bytes(1000), lib.gsr_geometry_bytes(1_000_000)
+    assert 0 < g1 < g2 and g2 < 200 * 1_000_000
+    assert lib.gsr_image_bytes(640, 480) >= 640 * 480 * 4 + 1200 * 8
+    assert lib.gsr_binning_bytes(1_000_000) >= 24 * 1_000_000
+
+
+def test_entry_points_reject_bad_arguments_without_touching_a_gpu():
+    from gs_localization_amd import _lib
+    lib = _lib.load()
+    cb = _lib.RESIZE_FN(lambda ctx, n: 0)
+    rc = lib.gsr_forward(cb, None, cb, None, cb, None, -1, 0, 0, None, 16, 16, None, None, None, None, None, 1.0, None,
+                         None, None, None, None, 1.0, 1.0, 0, None, None, None, None, 0, None, None)
+    assert rc == -1 and b"P >= 0" in lib.gsr_last_error()
+    with pytest.raises(_lib.GsrError):
+        _lib.check(rc)
+    assert lib.gsr_mark_visible(-3, None, None, None, None, None) == -1
+
+
+def test_package_surface_a():
+    import diff_gaussian_rasterization as A
+    assert A.GaussianRasterizationSettings._fields == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix",
+        "sh_degree", "campos", "prefiltered", "debug")
+    r = A.GaussianRasterizer(raster_settings=None)
+    assert isinstance(r, torch.nn.Module) and hasattr(r, "markVisible")
+    z = torch.zeros(4, 3)
+    with pytest.raises(Exception, match="excatly one of either SHs or precomputed colors"):
+        r(means3D=z, means2D=z, opacities=z[:, :1], scales=z, rotations=torch.zeros(4, 4))
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=z, means2D=z, opacities=z[:, :1], colors_precomp=z, scales=z)
+    with pytest.raises(Exception, match="scale/rotation pair or precomputed 3D covariance"):
+        r(means3D=z, means2D=z, opacities=z[:, :1], colors_precomp=z, scales=z, rotations=torch.zeros(4, 4),
+          cov3D_precomp=torch.zeros(4, 6))
+
+
+def test_package_surface_b():
+    import diff_gaussian_rasterization_pose as B
+    f = B.GaussianRasterizationSettings._fields
+    assert len(f) == 13 and f[8] == "projmatrix_raw" and f[:8] == (
+        "image_height", "image_width", "tanfovx", "tanfovy", "bg", "scale_modifier", "viewmatrix", "projmatrix")
+    import inspect
+    sig = inspect.signature(B.GaussianRasterizer.forward)
+    assert list(sig.parameters)[-2:] == ["theta", "rho"]
+
+
+def test_no_silent_cpu_fallback():
+    """the product path must fail loudly when asked to run without a HIP device"""
+    import diff_gaussian_rasterization as A
+    z = torch.zeros(4, 3)
+    rs = A.GaussianRasterizationSettings(image_height=16, image_width=16, tanfovx=1.0, tanfovy=1.0, bg=torch.zeros(3),
+                                         scale_modifier=1.0, viewmatrix=torch.eye(4), projmatrix=torch.eye(4),
+                                         sh_degree=0, campos=torch.zeros(3), prefiltered=False, debug=False)
+    with pytest.raises(RuntimeError, match="no CPU rasterizer"):
+        A.GaussianRasterizer(rs)(means3D=z, means2D=z, opacities=z[:, :1], colors_precomp=z, scales=z,
+                                 rotations=torch.zeros(4, 4))
+    with pytest.raises(RuntimeError):
+        A.GaussianRasterizer(rs).markVisible(z)
+
+
+def test_product_never_imports_the_oracle():
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gs_localization_amd")):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in src.replace("no oracle", ""), os.path.join(dirpath, fn)
+    for pkg in ("diff_gaussian_rasterization", "diff_gaussian_rasterization_pose"):
+        assert "oracle" not in open(os.path.join(ROOT, pkg, "__init__.py")).read()
+
+
+def test_host_maths_against_reference_python_golden(golden):
+    from gs_localization_amd import pipelines as PL, scenes as S
+    for c, Pref in zip(golden["proj_intr"], golden["proj_P"]):
+        fx, fy, cx, cy, W, H = c
+        P = PL.getProjectionMatrix2(0.01, 100.0, cx=cx, cy=cy, fx=fx, fy=fy, W=int(W), H=int(H)).numpy()
+        assert np.allclose(P, Pref, rtol=1e-6, atol=1e-7)
+        assert np.allclose(S.projection_matrix(0.01, 100.0, fx, fy, cx, cy, int(W), int(H)), Pref, rtol=1e-6, atol=1e-7)
+    for tau, Tref in zip(golden["se3_tau"], golden["se3_T"]):
+        assert np.allclose(PL.SE3_exp(torch.tensor(tau)).numpy(), Tref, atol=1e-12)
+        assert np.allclose(S.se3_exp(tau), Tref, atol=1e-12)
+    Rt = torch.tensor(golden["w2v_in"])
+    assert np.allclose(PL.getWorld2View2(Rt[:3, :3], Rt[:3, 3]).numpy(), golden["w2v_out"], atol=1e-12)
+
+
+def test_tracking_loss_against_reference_python_golden(golden):
+    from gs_localization_amd import pipelines as PL
+
+    class VP:
+        pass
+    vp = VP()
+    vp.exposure_a = torch.tensor([float(golden["loss_exposure"][0])])
+    vp.exposure_b = torch.tensor([float(golden["loss_exposure"][1])])
+    vp.original_image = torch.tensor(golden["loss_gt"])
+    vp.depth = golden["loss_gt_depth"]
+    vp.grad_mask = torch.tensor(golden["loss_grad_mask"])
+    for mono in (True, False):
+        cfg = {"Training": {"monocular": mono, "alpha": 0.99, "opacity_threshold": 0.99}}
+        loss = PL.get_loss_tracking(cfg, torch.tensor(golden["loss_image"]), torch.tensor(golden["loss_depth"]),
+                                    torch.tensor(golden["loss_opacity"]), vp)
+        assert abs(loss.item() - float(golden[f"loss_mono{int(mono)}"])) < 1e-7
+
+
+def test_update_pose_semantics():
+    from gs_localization_amd import pipelines as PL
+    proj = PL.getProjectionMatrix2(0.01, 100.0, 320, 240, 525, 525, 640, 480).transpose(0, 1)
+    cam = PL.Camera(0, None, None, torch.eye(4), proj, 525, 525, 320, 240, 1.0, 1.0, 480, 640, device="cpu")
+    with torch.no_grad():
+        cam.cam_trans_delta.copy_(torch.tensor([0.01, 0.0, -0.02]))
+        cam.cam_rot_delta.copy_(torch.tensor([0.0, 0.01, 0.0]))
+        conv = PL.update_pose(cam, 1e-4)
+    assert not bool(conv)
+    assert float(cam.cam_rot_delta.abs().sum()) == 0 and float(cam.cam_trans_delta.abs().sum()) == 0
+    T = PL.SE3_exp(torch.tensor([0.01, 0.0, -0.02, 0.0, 0.01, 0.0]))
+    assert torch.allclose(cam.R, T[:3, :3], atol=1e-7) and torch.allclose(cam.T, T[:3, 3], atol=1e-7)
+    with torch.no_grad():
+        assert bool(PL.update_pose(cam, 1e-4))          # zero delta => converged
+    # camera_center equals the reference's world_view_transform.inverse()[3,:3]
+    assert torch.allclose(cam.camera_center, cam.world_view_transform.inverse()[3, :3], atol=1e-6)
+    te, re = PL.pose_errors(np.eye(3), np.zeros(3), cam.R.numpy(), cam.T.numpy())
+    assert te > 0.02 and 0.5 < re < 0.6

@@ -1,0 +1,100 @@
+#!/usr/bin/env python3
+"""Condenses rocprofv3 CSV output (gpurun_out/prof_*) into the small files committed under profiles/.
+
+  python tools/prof_summary.py --tag r01 --kt gpurun_out/prof_kt/r01_kernel_stats.csv \
+      [--fetch gpurun_out/prof_fetch/r01_counter_collection.csv --write gpurun_out/prof_write/r01_counter_collection.csv] \
+      --iters 73
+
+Writes profiles/<tag>_kernel_stats.md (rocprofv3 --kernel-trace --stats summary, names shortened),
+profiles/<tag>_traffic.json and profiles/traffic.json (per-launch HBM bytes of OUR kernels from the
+FETCH_SIZE / WRITE_SIZE passes).  Unit and gfx950 correction per MI355X_MICROARCH.md section HBM:
+counters are in KiB; FETCH_SIZE counts 64 B per 128-B request for wide coalesced streaming reads, so
+the read side is reported both raw and x2 ("fetch_x2"); WRITE_SIZE is exact."""
+import argparse
+import csv
+import json
+import os
+import re
+import sys
+from collections import defaultdict
+
+csv.field_size_limit(sys.maxsize)
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+OURS = {"k_preprocess(": "preprocess_fwd", "k_preprocess_bwd": "preprocess_bwd", "k_emit": "emit", "k_ranges": "ranges",
+        "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd", "radix_sort_onesweep_iteration": "sort",
+        "radix_sort_onesweep_global_offsets": "sort", "radix_sort": "sort", "lookback_scan": "scan", "scan": "scan",
+        "k_tile_": "tile_sort", "k_bin": "bin", "k_loss": "loss", "k_pose": "pose_step"}
+
+
+def short(name):
+    n = re.sub(r"\(anonymous namespace\)::", "", name)
+    m = re.match(r"(?:void )?([\w:]+)", n)
+    base = m.group(1) if m else n[:60]
+    if "rocprim" in n:
+        mm = re.search(r"detail::(radix_sort_\w+|\w*scan\w*|\w+_kernel)", n)
+        base = "rocprim::" + (mm.group(1) if mm else "kernel")
+    if "at::native" in n:
+        mm = re.search(r"at::native::(\w+)<[^>]*?(?:at::native::)?(?:binary_internal::)?(\w+Functor|\w+Ops|\w+_kernel)?", n)
+        base = "at::" + (mm.group(1) + (":" + mm.group(2) if mm and mm.group(2) else "") if mm else base)
+    return base[:80]
+
+
+def ours(name):
+    for k, v in OURS.items():
+        if k in name and ("gsr::" in name or "rocprim" in name):
+            return v
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tag", required=True)
+    ap.add_argument("--kt", required=True)
+    ap.add_argument("--fetch")
+    ap.add_argument("--write")
+    ap.add_argument("--iters", type=int, required=True, help="refinement iterations executed under the profiler")
+    ap.add_argument("--cmd", default="")
+    a = ap.parse_args()
+    os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
+    rows = list(csv.DictReader(open(a.kt)))
+    tot = sum(float(r["TotalDurationNs"]) for r in rows)
+    agg = defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        key = ours(r["Name"]) or short(r["Name"])
+        agg[key][0] += int(r["Calls"])
+        agg[key][1] += float(r["TotalDurationNs"])
+    with open(os.path.join(ROOT, "profiles", f"{a.tag}_kernel_stats.md"), "w") as f:
+        f.write(f"# rocprofv3 --kernel-trace --stats summary ({a.tag})\n\ncommand: `{a.cmd}`\n\n")
+        f.write(f"{a.iters} refinement iterations under the profiler; total GPU kernel time {tot/1e6:.2f} ms "
+                f"= {tot/1e6/a.iters:.3f} ms/iteration\n\n| kernel | calls | avg us | us / iteration | % |\n|---|---|---|---|---|\n")
+        for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
+            f.write(f"| {k} | {c} | {t/c/1e3:.2f} | {t/a.iters/1e3:.1f} | {100*t/tot:.1f} |\n")
+    traffic = {}
+    for which, path in (("fetch", a.fetch), ("write", a.write)):
+        if not path:
+            continue
+        acc = defaultdict(lambda: [0, 0.0])
+        for r in csv.DictReader(open(path)):
+            k = ours(r["Kernel_Name"])
+            if k:
+                acc[k][0] += 1
+                acc[k][1] += float(r["Counter_Value"])
+        # per API call: forward kernels run once per render_fwd launch, backward ones once per render_bwd launch
+        n_fwd = max(acc["render_fwd"][0], 1)
+        n_bwd = max(acc["render_bwd"][0], 1)
+        for k, (c, v) in acc.items():
+            traffic.setdefault(k, {})[which + "_KiB_per_iter"] = v / (n_bwd if k.endswith("_bwd") else n_fwd)
+    out = {}
+    for k, d in traffic.items():
+        fe, wr = d.get("fetch_KiB_per_iter", 0.0) * 1024, d.get("write_KiB_per_iter", 0.0) * 1024
+        out[k] = {"fetch_raw_bytes": fe, "fetch_x2_bytes": 2 * fe, "write_bytes": wr, "hbm_bytes_corrected": 2 * fe + wr}
+    if out:
+        json.dump(out, open(os.path.join(ROOT, "profiles", f"{a.tag}_traffic.json"), "w"), indent=1)
+        json.dump({k: v["hbm_bytes_corrected"] for k, v in out.items()}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    print(open(os.path.join(ROOT, "profiles", f"{a.tag}_kernel_stats.md")).read())
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
