@@ -21,6 +21,9 @@ def build(force=False, verbose=False):
     if not force and os.path.exists(OUT) and all(os.path.getmtime(OUT) >= os.path.getmtime(d) for d in DEPS):
         return OUT
     cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+           # one lane already holds the wave total when we issue an atomic: keep hipcc from wrapping it in
+           # its own (iterative) cross-lane reduction loop
+           "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
            "-I" + os.path.join(_ROOT, "include"), "-o", OUT, SRC]
     if verbose:
         print(" ".join(cmd))

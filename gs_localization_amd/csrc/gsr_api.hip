@@ -41,9 +41,9 @@ int fail(int code, const char* fmt, const char* a = "", const char* b = "")
     } while (0)
 
 // ---- optional per-kernel HIP-event timing (gsr_profile_*) ----
-enum KernelId { K_PREPROCESS = 0, K_SCAN, K_EMIT, K_SORT, K_RANGES, K_RENDER_FWD, K_BWD_ZERO, K_RENDER_BWD, K_PREPROCESS_BWD, K_COUNT };
+enum KernelId { K_PREPROCESS = 0, K_SCAN, K_EMIT, K_SORT, K_RANGES, K_RENDER_FWD, K_BWD_ZERO, K_RENDER_BWD, K_PREPROCESS_BWD, K_DEPTH_SORT, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"preprocess_fwd", "scan", "emit", "sort", "ranges", "render_fwd",
-                                           "bwd_zero", "render_bwd", "preprocess_bwd"};
+                                           "bwd_zero", "render_bwd", "preprocess_bwd", "depth_sort"};
 struct Profiler {
     std::mutex mu;
     unsigned mask = 0;
@@ -96,7 +96,8 @@ struct Carver {
 struct Geom {   // per-Gaussian state carried from forward to backward
     float* depths; float2* xy; float4* conic_op; float* rgb; float* cov3D; uint8_t* clamped;
     uint32_t* tiles_touched; uint32_t* offsets; ushort4* rects; float* dL_dz; double* tau_acc;
-    char* scan_tmp; size_t scan_bytes;
+    uint32_t* depth_key; uint32_t* depth_key_sorted; uint32_t* order_in; uint32_t* order; uint32_t* tt_sorted;
+    char* scan_tmp; size_t scan_bytes; char* dsort_tmp; size_t dsort_bytes;
 };
 size_t carve_geom(char* base, int P, Geom& g)
 {
@@ -113,6 +114,15 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.rects = c.take<ushort4>(n);
     g.dL_dz = c.take<float>(n);
     g.tau_acc = c.take<double>(8);
+    g.depth_key = c.take<uint32_t>(n);
+    g.depth_key_sorted = c.take<uint32_t>(n);
+    g.order_in = c.take<uint32_t>(n);
+    g.order = c.take<uint32_t>(n);
+    g.tt_sorted = c.take<uint32_t>(n);
+    g.dsort_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, g.dsort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                             (uint32_t*)nullptr, (int)n);
+    g.dsort_tmp = c.take<char>(g.dsort_bytes);
     g.scan_bytes = 0;
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, g.scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
     g.scan_tmp = c.take<char>(g.scan_bytes);
@@ -131,21 +141,28 @@ size_t carve_img(char* base, int W, int H, Img& im)
     return c.size();
 }
 
-struct Bin {
-    uint64_t* keys_unsorted; uint64_t* keys; uint32_t* vals_unsorted; uint32_t* vals;
+struct Bin {      // per tile instance: tile key (16 bit when the tile count allows, else 32) + Gaussian index
+    void* keys_unsorted; void* keys; uint32_t* vals_unsorted; uint32_t* vals;
     char* sort_tmp; size_t sort_bytes;
 };
-size_t carve_bin(char* base, int R, Bin& b)
+size_t carve_bin(char* base, int R, bool wide_keys, Bin& b)
 {
     Carver c(base);
     const size_t n = R > 0 ? (size_t)R : 1;
     b.vals = c.take<uint32_t>(n);
     b.vals_unsorted = c.take<uint32_t>(n);
-    b.keys = c.take<uint64_t>(n);
-    b.keys_unsorted = c.take<uint64_t>(n);
     b.sort_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b.sort_bytes, (uint64_t*)nullptr, (uint64_t*)nullptr, (uint32_t*)nullptr,
-                                       (uint32_t*)nullptr, (int)n);
+    if (wide_keys) {
+        b.keys = c.take<uint32_t>(n);
+        b.keys_unsorted = c.take<uint32_t>(n);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b.sort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                                 (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    } else {
+        b.keys = c.take<uint16_t>(n);
+        b.keys_unsorted = c.take<uint16_t>(n);
+        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b.sort_bytes, (uint16_t*)nullptr, (uint16_t*)nullptr,
+                                                 (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
+    }
     b.sort_tmp = c.take<char>(b.sort_bytes);
     return c.size();
 }
@@ -215,7 +232,7 @@ int gsr_device_ok(void)
 
 size_t gsr_geometry_bytes(int P) { Geom g; return carve_geom(nullptr, P, g); }
 size_t gsr_image_bytes(int width, int height) { Img im; return carve_img(nullptr, width, height, im); }
-size_t gsr_binning_bytes(int num_rendered) { Bin b; return carve_bin(nullptr, num_rendered, b); }
+size_t gsr_binning_bytes(int num_rendered) { Bin b; return carve_bin(nullptr, num_rendered, true, b); }
 
 int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn binning_buffer, void* binning_ctx,
                 gsr_resize_fn image_buffer, void* image_ctx, int P, int D, int M, const float* background, int width,
@@ -279,14 +296,22 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     pa.tanx = tan_fovx; pa.tany = tan_fovy; pa.fx = focal_x; pa.fy = focal_y;
     pa.radii = radii; pa.xy = g.xy; pa.depths = g.depths; pa.cov3D = g.cov3D; pa.rgb = g.rgb; pa.conic_op = g.conic_op;
     pa.clamped = g.clamped; pa.tiles_touched = g.tiles_touched; pa.rects = g.rects;
+    pa.depth_key = g.depth_key; pa.order_in = g.order_in;
     {
         ProfScope ps(K_PREPROCESS, st);
         hipLaunchKernelGGL(k_preprocess, dim3(pblocks), dim3(GSR_BLOCK), 0, st, pa);
     }
     LAUNCHCHK("k_preprocess");
+    {   // (1) Gaussians in (depth bits, index) order; culled ones carry key 0xFFFFFFFF and end up last
+        ProfScope ps(K_DEPTH_SORT, st);
+        HIPCHK(hipcub::DeviceRadixSort::SortPairs(g.dsort_tmp, g.dsort_bytes, g.depth_key, g.depth_key_sorted, g.order_in,
+                                                  g.order, P, 0, 32, st));
+    }
     {
         ProfScope ps(K_SCAN, st);
-        HIPCHK(hipcub::DeviceScan::InclusiveSum(g.scan_tmp, g.scan_bytes, g.tiles_touched, g.offsets, P, st));
+        hipLaunchKernelGGL(k_gather_counts, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
+                           (const uint32_t*)g.tiles_touched, g.tt_sorted);
+        HIPCHK(hipcub::DeviceScan::InclusiveSum(g.scan_tmp, g.scan_bytes, g.tt_sorted, g.offsets, P, st));
     }
 
     // one blocking 4-byte read, as rasterizer_impl.cu:282
@@ -296,31 +321,51 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     if (num_rendered_u > 0x7fffffffu) return fail(GSR_E_INVALID, "more than 2^31 tile instances%s", "");
     const int R = (int)num_rendered_u;
 
+    const bool wide = ntiles > 65536;
     Bin b;
-    const size_t bbytes = carve_bin(nullptr, R, b);
+    const size_t bbytes = carve_bin(nullptr, R, wide, b);
     char* bptr = (char*)binning_buffer(binning_ctx, bbytes);
     if (!bptr) return fail(GSR_E_ALLOC, "binning buffer callback returned NULL%s", "");
-    carve_bin(bptr, R, b);
+    carve_bin(bptr, R, wide, b);
 
     HIPCHK(hipMemsetAsync(im.ranges, 0, (size_t)ntiles * sizeof(uint2), st));
     if (R > 0) {
-        {
-            ProfScope ps(K_EMIT, st);
-            hipLaunchKernelGGL(k_emit, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const float*)g.depths,
-                               (const uint32_t*)g.offsets, (const uint32_t*)g.tiles_touched, (const ushort4*)g.rects, gx,
-                               b.keys_unsorted, b.vals_unsorted);
-        }
-        LAUNCHCHK("k_emit");
-        const int end_bit = 32 + bits_for((uint32_t)ntiles);
-        {
-            ProfScope ps(K_SORT, st);
-            HIPCHK(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, b.keys_unsorted, b.keys, b.vals_unsorted,
-                                                      b.vals, R, 0, end_bit, st));
-        }
-        {
-            ProfScope ps(K_RANGES, st);
-            hipLaunchKernelGGL(k_ranges, dim3((R + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, R,
-                               (const uint64_t*)b.keys, im.ranges);
+        const int end_bit = bits_for((uint32_t)(ntiles - 1)) > 0 ? bits_for((uint32_t)(ntiles - 1)) : 1;
+        const int rblocks = (R + GSR_BLOCK - 1) / GSR_BLOCK;
+        if (wide) {
+            {
+                ProfScope ps(K_EMIT, st);
+                hipLaunchKernelGGL(k_emit_sorted<uint32_t>, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
+                                   (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
+                                   (const float2*)g.xy, (const float4*)g.conic_op, gx, (uint32_t*)b.keys_unsorted, b.vals_unsorted);
+            }
+            LAUNCHCHK("k_emit_sorted");
+            {
+                ProfScope ps(K_SORT, st);
+                HIPCHK(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, (const uint32_t*)b.keys_unsorted, (uint32_t*)b.keys,
+                                                          (const uint32_t*)b.vals_unsorted, b.vals, R, 0, end_bit, st));
+            }
+            {
+                ProfScope ps(K_RANGES, st);
+                hipLaunchKernelGGL(k_ranges<uint32_t>, dim3(rblocks), dim3(GSR_BLOCK), 0, st, R, (const uint32_t*)b.keys, im.ranges);
+            }
+        } else {
+            {
+                ProfScope ps(K_EMIT, st);
+                hipLaunchKernelGGL(k_emit_sorted<uint16_t>, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
+                                   (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
+                                   (const float2*)g.xy, (const float4*)g.conic_op, gx, (uint16_t*)b.keys_unsorted, b.vals_unsorted);
+            }
+            LAUNCHCHK("k_emit_sorted");
+            {   // (3) stable sort on the tile bits only
+                ProfScope ps(K_SORT, st);
+                HIPCHK(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, (const uint16_t*)b.keys_unsorted, (uint16_t*)b.keys,
+                                                          (const uint32_t*)b.vals_unsorted, b.vals, R, 0, end_bit, st));
+            }
+            {
+                ProfScope ps(K_RANGES, st);
+                hipLaunchKernelGGL(k_ranges<uint16_t>, dim3(rblocks), dim3(GSR_BLOCK), 0, st, R, (const uint16_t*)b.keys, im.ranges);
+            }
         }
         LAUNCHCHK("k_ranges");
     }
@@ -374,7 +419,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     const float focal_y = height / (2.0f * tan_fovy);
     const float focal_x = width / (2.0f * tan_fovx);
     Geom g; carve_geom(geom_buffer, P, g);
-    Bin b; carve_bin(binning_buffer, R, b);
+    Bin b; carve_bin(binning_buffer, R, ntiles > 65536, b);
     Img im; carve_img(img_buffer, width, height, im);
 
     // accumulators of K7 (atomically summed); everything else is written exactly once by K8/K9
@@ -460,7 +505,7 @@ int gsr_forward_stats(int P, int width, int height, const int* radii, const char
     HIPCHK(hipMalloc(&d, 4 * sizeof(unsigned long long)));
     HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), st));
     hipLaunchKernelGGL(k_stats_gauss, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, radii,
-                       (const uint32_t*)g.tiles_touched, d);
+                       (const uint32_t*)g.tiles_touched, (const ushort4*)g.rects, d);
     LAUNCHCHK("k_stats_gauss");
     hipLaunchKernelGGL(k_stats_tiles, dim3(gx * gy), dim3(GSR_BLOCK), 0, st, width, height, gx,
                        (const uint32_t*)im.n_contrib, d);
@@ -470,9 +515,9 @@ int gsr_forward_stats(int P, int width, int height, const int* radii, const char
     HIPCHK(hipStreamSynchronize(st));
     HIPCHK(hipFree(d));
     stats[0] = (long long)h[0];
-    stats[1] = (long long)h[1];   // with the reference bounding rule, emitted == R
-    stats[2] = (long long)h[1];
-    stats[3] = (long long)h[2];
+    stats[1] = (long long)h[1];   // R under the reference's bounding rule
+    stats[2] = (long long)h[3];   // instances actually emitted after exact tile culling
+    stats[3] = (long long)h[2];   // R_eff of THIS binning (max per-pixel n_contrib summed over tiles)
     return 0;
 }
 

@@ -9,8 +9,71 @@ namespace gsr {
 // K1  per-Gaussian preprocess (replaces forward.cu:155-256 preprocessCUDA).
 // One lane per Gaussian; HBM-streaming: reads 44+12M B, writes <= 80 B per Gaussian.
 // ---------------------------------------------------------------------------------------------
+// ---------------------------------------------------------------------------------------------
+// Exact tile culling.  The reference emits one instance for every tile of the bounding SQUARE of
+// radius ceil(3 sigma_max) (forward.cu:229-237).  An instance can only change a pixel if
+// alpha = o*exp(-q) >= 1/255 there (forward.cu:346-348), i.e. q <= ln(255 o).  For each tile of the
+// reference rectangle we compute the exact minimum of the convex quadratic q over the tile's pixel
+// rectangle and drop the instance when even that minimum (minus a safety slack covering fp32
+// rounding of q in the compositing kernels) is above the threshold: a dropped instance would have
+// been skipped by every pixel of the tile, so images and gradients are unchanged while the binned
+// list gets shorter.  Never ADDS tiles outside the reference rectangle; `radii` is still the
+// reference's value.
+// ---------------------------------------------------------------------------------------------
+struct TileTest {
+    float mx, my, A, B, C, det, twoq, dxe, dye, invA;
+    bool cull;       // false: conic not positive definite -> keep every tile of the rectangle
+    bool none;       // opacity so low that alpha < 1/255 everywhere
+};
+__device__ __forceinline__ TileTest make_tile_test(float2 m, float3 conic, float opacity)
+{
+    TileTest t;
+    t.mx = m.x; t.my = m.y; t.A = conic.x; t.B = conic.y; t.C = conic.z;
+    t.det = conic.x * conic.z - conic.y * conic.y;
+    t.cull = (conic.x > 0.f) && (conic.z > 0.f) && (t.det > 0.f);
+    // q <= ln(255 o) + slack.  The slack (0.02 in q, i.e. 2 % in alpha) covers the fp32 rounding of q in
+    // the compositing kernels, also for strongly correlated conics where q is a difference of large terms.
+    const float qmax = (opacity > 0.f) ? (__logf(255.f * opacity) + 0.02f) : -1.f;
+    t.none = t.cull && (qmax < 0.f);
+    t.twoq = 2.f * fmaxf(qmax, 0.f);
+    // extreme points of the ellipse q = qmax in x: dx = +-dxe at dy = -+B dxe / C
+    // (hardware rcp / sqrt, ~1 ulp: the spans are widened by 0.01 px, exact rounding is not needed here)
+    t.invA = t.cull ? __builtin_amdgcn_rcpf(t.A) : 0.f;
+    t.dxe = t.cull ? __builtin_amdgcn_sqrtf(t.twoq * t.C * __builtin_amdgcn_rcpf(t.det)) : 0.f;
+    t.dye = t.cull ? (-t.B * t.dxe * __builtin_amdgcn_rcpf(t.C)) : 0.f;
+    return t;
+}
+// Tiles [lo, hi] (inclusive, within [x0, x1)) of tile row ty that the ellipse q <= qmax can reach; empty if lo > hi.
+// Exact x-extent of (ellipse ∩ row band): attained either at the ellipse's x-extreme points (if they lie in
+// the band) or where the ellipse crosses the band's two boundary lines.  Widened by 0.01 px.
+__device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int x1, int& lo, int& hi)
+{
+    if (!t.cull) { lo = x0; hi = x1 - 1; return; }
+    lo = 1; hi = 0;
+    if (t.none) return;
+    const float dyh = t.my - (float)(ty * GSR_TILE), dyl = dyh - (float)(GSR_TILE - 1);   // d = mean - pixel
+    float dmin = 3.0e38f, dmax = -3.0e38f;
+    const float disc_l = t.A * t.twoq - t.det * dyl * dyl;
+    if (disc_l >= 0.f) {
+        const float sq = __builtin_amdgcn_sqrtf(disc_l), c = -t.B * dyl;
+        dmin = fminf(dmin, (c - sq) * t.invA); dmax = fmaxf(dmax, (c + sq) * t.invA);
+    }
+    const float disc_h = t.A * t.twoq - t.det * dyh * dyh;
+    if (disc_h >= 0.f) {
+        const float sq = __builtin_amdgcn_sqrtf(disc_h), c = -t.B * dyh;
+        dmin = fminf(dmin, (c - sq) * t.invA); dmax = fmaxf(dmax, (c + sq) * t.invA);
+    }
+    if (t.dye >= dyl - 0.01f && t.dye <= dyh + 0.01f) dmax = fmaxf(dmax, t.dxe);
+    if (-t.dye >= dyl - 0.01f && -t.dye <= dyh + 0.01f) dmin = fminf(dmin, -t.dxe);
+    if (dmin > dmax) return;
+    const float pa = t.mx - dmax - 0.01f, pb = t.mx - dmin + 0.01f;        // pixel x-interval
+    lo = max(x0, (int)ceilf((pa - (float)(GSR_TILE - 1)) * (1.f / GSR_TILE)));
+    hi = min(x1 - 1, (int)floorf(pb * (1.f / GSR_TILE)));
+}
+
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
+    uint32_t* depth_key; uint32_t* order_in;
     const float* means; const float* scales; float mod; const float* rots; const float* opac;
     const float* shs; const float* cov3D_pre; const float* colors_pre;
     const float* view; const float* proj; const float* campos;
@@ -59,6 +122,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     if (idx >= a.P) return;
     a.radii[idx] = 0;
     a.tiles_touched[idx] = 0;
+    a.depth_key[idx] = 0xFFFFFFFFu;     // invisible Gaussians sort behind every visible one
+    a.order_in[idx] = (uint32_t)idx;
 
     const float3 p = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
     const float4 ph = xform4x4(p, a.proj);
@@ -101,45 +166,78 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
         a.rgb[3 * idx] = c.x; a.rgb[3 * idx + 1] = c.y; a.rgb[3 * idx + 2] = c.z;
         a.clamped[idx] = cb;
     }
+    const float opacity = a.opac[idx];
     a.depths[idx] = pview.z;
     a.radii[idx] = (int)my_radius;
     a.xy[idx] = pix;
-    a.conic_op[idx] = make_float4(conic.x, conic.y, conic.z, a.opac[idx]);
-    a.tiles_touched[idx] = (uint32_t)((y1 - y0) * (x1 - x0));
+    a.conic_op[idx] = make_float4(conic.x, conic.y, conic.z, opacity);
     a.rects[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+    // exact count of tiles this splat can change
+    const TileTest tt = make_tile_test(pix, conic, opacity);
+    uint32_t cnt = 0;
+    for (int y = y0; y < y1; y++) {
+        int lo, hi;
+        row_span(tt, y, x0, x1, lo, hi);
+        cnt += (uint32_t)max(0, hi - lo + 1);
+    }
+    a.tiles_touched[idx] = cnt;
+    if (cnt) a.depth_key[idx] = __float_as_uint(pview.z);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K3  instance emission (replaces rasterizer_impl.cu:70-111 duplicateWithKeys)
-// key = tile << 32 | depth bits, value = Gaussian index; emitted in index order per Gaussian.
+// Binning.  The reference sorts R (tile<<32 | depth) 64-bit keys (rasterizer_impl.cu:70-111,304-309:
+// 6 radix passes over R pairs).  Same final order, far fewer bytes:
+//   (1) the P Gaussians are sorted ONCE by (depth bits, index)            -- 4 passes over P pairs
+//   (2) instances are emitted in that order with a 16-bit tile key        -- k_emit_sorted
+//   (3) a STABLE radix sort on the tile bits only brings tiles together   -- 2 passes over R pairs
+// Stability keeps (depth, index) order inside each tile, which is exactly the order a stable sort of
+// the reference's 64-bit keys produces (ties in depth resolved by Gaussian index).
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GSR_BLOCK) k_emit(int P, const float* depths, const uint32_t* offsets,
-                                                    const uint32_t* tiles_touched, const ushort4* rects, int gx,
-                                                    uint64_t* keys, uint32_t* vals)
+__global__ void __launch_bounds__(GSR_BLOCK) k_gather_counts(int P, const uint32_t* __restrict__ order,
+                                                             const uint32_t* __restrict__ tiles_touched,
+                                                             uint32_t* __restrict__ tt_sorted)
 {
-    const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
-    if (idx >= P) return;
-    if (tiles_touched[idx] == 0) return;
-    uint32_t off = (idx == 0) ? 0 : offsets[idx - 1];
+    const int k = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    if (k < P) tt_sorted[k] = tiles_touched[order[k]];
+}
+
+template <typename KeyT>
+__global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t* __restrict__ order,
+                                                           const uint32_t* __restrict__ offsets,
+                                                           const uint32_t* __restrict__ tt_sorted,
+                                                           const ushort4* __restrict__ rects, const float2* __restrict__ xy,
+                                                           const float4* __restrict__ conic_op, int gx,
+                                                           KeyT* __restrict__ keys, uint32_t* __restrict__ vals)
+{
+    const int k = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    if (k >= P) return;
+    if (tt_sorted[k] == 0) return;
+    const uint32_t idx = order[k];
+    uint32_t off = (k == 0) ? 0 : offsets[k - 1];
     const ushort4 r = rects[idx];
-    const uint32_t dbits = __float_as_uint(depths[idx]);
-    for (int y = r.y; y < r.w; y++)
-        for (int x = r.x; x < r.z; x++) {
-            keys[off] = ((uint64_t)(uint32_t)(y * gx + x) << 32) | dbits;
-            vals[off] = (uint32_t)idx;
+    const float4 co = conic_op[idx];
+    const TileTest tt = make_tile_test(xy[idx], make_float3(co.x, co.y, co.z), co.w);
+    for (int y = r.y; y < r.w; y++) {
+        int lo, hi;
+        row_span(tt, y, r.x, r.z, lo, hi);
+        for (int x = lo; x <= hi; x++) {
+            keys[off] = (KeyT)(y * gx + x);
+            vals[off] = idx;
             off++;
         }
+    }
 }
 
-// K5  per-tile [start,end) in the sorted list (replaces rasterizer_impl.cu:116-138)
-__global__ void __launch_bounds__(GSR_BLOCK) k_ranges(int L, const uint64_t* keys, uint2* ranges)
+// per-tile [start,end) in the tile-sorted list (replaces rasterizer_impl.cu:116-138)
+template <typename KeyT>
+__global__ void __launch_bounds__(GSR_BLOCK) k_ranges(int L, const KeyT* __restrict__ keys, uint2* __restrict__ ranges)
 {
     const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
     if (idx >= L) return;
-    const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+    const uint32_t cur = (uint32_t)keys[idx];
     if (idx == 0) ranges[cur].x = 0;
     else {
-        const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+        const uint32_t prev = (uint32_t)keys[idx - 1];
         if (cur != prev) { ranges[prev].y = idx; ranges[cur].x = idx; }
     }
     if (idx == L - 1) ranges[cur].y = L;
@@ -348,10 +446,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
                 v[7] = -0.5f * gdy * dy * dL_dG;
                 v[8] = G * dL_dopa;
             }
+            wave_sum10_to_lane63(v);
+            if (lane == 63) {
 #pragma unroll
-            for (int q = 0; q < (POSE ? GSR_NQ : GSR_NQ - 1); q++) {
-                const float t = wave_sum_to_lane63(v[q]);
-                if (lane == 63) atomicAdd(&s.acc[j][q], t);
+                for (int q = 0; q < (POSE ? GSR_NQ : GSR_NQ - 1); q++) atomicAdd(&s.acc[j][q], v[q]);
             }
             if (lane == 63) s.acc[j][GSR_NQ] = 1.f;   // touched flag
         }
@@ -711,14 +809,18 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_mark_visible(int P, const float* 
 
 // bench-only statistics: V, sum of tiles_touched, R_eff
 __global__ void __launch_bounds__(GSR_BLOCK) k_stats_gauss(int P, const int* radii, const uint32_t* tiles_touched,
-                                                           unsigned long long* out)
+                                                           const ushort4* rects, unsigned long long* out)
 {
     const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
-    unsigned long long v = 0, t = 0;
-    if (idx < P) { v = radii[idx] > 0; t = tiles_touched[idx]; }
+    unsigned long long v = 0, t = 0, r = 0;
+    if (idx < P && radii[idx] > 0) {
+        v = 1; t = tiles_touched[idx];
+        const ushort4 rc = rects[idx];
+        r = (unsigned long long)(rc.z - rc.x) * (rc.w - rc.y);      // the reference's bounding-square count
+    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); t += __shfl_xor(t, off, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], v); atomicAdd(&out[1], t); }
+    for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); t += __shfl_xor(t, off, 64); r += __shfl_xor(r, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], v); atomicAdd(&out[1], r); atomicAdd(&out[3], t); }
 }
 __global__ void __launch_bounds__(GSR_BLOCK) k_stats_tiles(int W, int H, int gx, const uint32_t* n_contrib,
                                                            unsigned long long* out)
