@@ -142,24 +142,23 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v)
     GSR_DPP_ADD(v, 0x143, 0xc);   // row_bcast:31 into rows 2,3
     return v;
 }
-// Ten wave sums at once, totals in lane 63.  Written as ONE asm block so that the six DPP steps of the
-// ten independent values interleave: a DPP source written by the previous VALU instruction needs two
-// wait states, which the nine other values provide for free (hipcc serialises each value's chain with
-// s_nop pairs and cannot fold the row_bcast steps into v_add_f32_dpp).  60 VALU instructions in total.
+// Ten 16-lane row sums at once; the total of row r ends up in lane 16 r + 15.  Written as ONE asm block so
+// that the four DPP steps of the ten independent values interleave: a DPP source written by the previous
+// VALU instruction needs two wait states, which the nine other values provide for free (hipcc serialises
+// each value's chain with s_nop pairs).  40 VALU instructions; the four row totals are then combined by
+// the LDS float atomics that merge the four waves anyway.
 #define GSR_R10_STEP(ctrl) \
     "v_add_f32_dpp %0, %0, %0 " ctrl "\n\tv_add_f32_dpp %1, %1, %1 " ctrl "\n\tv_add_f32_dpp %2, %2, %2 " ctrl "\n\t" \
     "v_add_f32_dpp %3, %3, %3 " ctrl "\n\tv_add_f32_dpp %4, %4, %4 " ctrl "\n\tv_add_f32_dpp %5, %5, %5 " ctrl "\n\t" \
     "v_add_f32_dpp %6, %6, %6 " ctrl "\n\tv_add_f32_dpp %7, %7, %7 " ctrl "\n\tv_add_f32_dpp %8, %8, %8 " ctrl "\n\t" \
     "v_add_f32_dpp %9, %9, %9 " ctrl "\n\t"
-__device__ __forceinline__ void wave_sum10_to_lane63(float (&v)[10])
+__device__ __forceinline__ void row_sum10_to_lane15(float (&v)[10])
 {
     asm volatile("s_nop 1\n\t"
                  GSR_R10_STEP("row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1")
                  GSR_R10_STEP("row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1")
                  GSR_R10_STEP("row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1")
                  GSR_R10_STEP("row_shr:8 row_mask:0xf bank_mask:0xf bound_ctrl:1")
-                 GSR_R10_STEP("row_bcast:15 row_mask:0xa bank_mask:0xf")
-                 GSR_R10_STEP("row_bcast:31 row_mask:0xc bank_mask:0xf")
                  : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]),
                    "+v"(v[8]), "+v"(v[9]));
 }

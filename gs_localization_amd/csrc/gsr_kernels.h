@@ -116,72 +116,113 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, int M, float3 pos, const fl
     return make_float3(fmaxf(res[0], 0.0f), fmaxf(res[1], 0.0f), fmaxf(res[2], 0.0f));
 }
 
+// SH rows of one block staged through LDS: the 256 x M x 3 floats of a block are contiguous in HBM, so
+// the block reads (writes) them as one coalesced 16-B-per-lane stream and each lane then works on its own
+// row out of LDS.  Row stride 13 float4 (208 B) keeps the per-lane ds_read_b128 conflict-free.
+#define GSR_SH16_ROW4 12      // float4 per 16-coefficient row
+#define GSR_SH16_LDS4 13      // padded row stride in float4
+
+// the vector path needs 16-coefficient rows and a 16-B aligned table (torch allocations always are)
+__device__ __forceinline__ bool sh16_vector_ok(int M, const float* shs)
+{
+    return M == 16 && ((reinterpret_cast<uintptr_t>(shs) & 15u) == 0);
+}
+
 __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 {
-    const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
-    if (idx >= a.P) return;
-    a.radii[idx] = 0;
-    a.tiles_touched[idx] = 0;
-    a.depth_key[idx] = 0xFFFFFFFFu;     // invisible Gaussians sort behind every visible one
-    a.order_in[idx] = (uint32_t)idx;
+    __shared__ float4 s_sh[GSR_BLOCK * GSR_SH16_LDS4];
+    __shared__ uint8_t s_vis[GSR_BLOCK];
+    const int tid = threadIdx.x;
+    const int idx = blockIdx.x * GSR_BLOCK + tid;
+    const bool live = idx < a.P;
+    bool vis = false;
+    float3 p = make_float3(0.f, 0.f, 0.f);
 
-    const float3 p = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
-    const float4 ph = xform4x4(p, a.proj);
-    const float pw = 1.0f / (ph.w + 0.0000001f);
-    const float3 pproj = make_float3(ph.x * pw, ph.y * pw, ph.z * pw);
-    const float3 pview = xform4x3(p, a.view);
-    if (pview.z <= 0.2f) return;     // near cull (auxiliary.h:150)
-
-    float cov6[6];
-    if (a.cov3D_pre != nullptr) {
+    if (live) {
+        a.radii[idx] = 0;
+        a.tiles_touched[idx] = 0;
+        a.depth_key[idx] = 0xFFFFFFFFu;     // culled Gaussians sort behind every visible one
+        a.order_in[idx] = (uint32_t)idx;
+        p = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
+        const float4 ph = xform4x4(p, a.proj);
+        const float pw = 1.0f / (ph.w + 0.0000001f);
+        const float3 pproj = make_float3(ph.x * pw, ph.y * pw, ph.z * pw);
+        const float3 pview = xform4x3(p, a.view);
+        if (pview.z > 0.2f) {     // near cull (auxiliary.h:150)
+            float cov6[6];
+            if (a.cov3D_pre != nullptr) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) cov6[i] = a.cov3D_pre[6 * (size_t)idx + i];
-    } else {
-        float s3[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
-        const float4 q = reinterpret_cast<const float4*>(a.rots)[idx];
-        float q4[4] = {q.x, q.y, q.z, q.w};
-        cov3d_from_scale_rot(s3, a.mod, q4, cov6);
+                for (int i = 0; i < 6; i++) cov6[i] = a.cov3D_pre[6 * (size_t)idx + i];
+            } else {
+                float s3[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+                const float4 q = reinterpret_cast<const float4*>(a.rots)[idx];
+                float q4[4] = {q.x, q.y, q.z, q.w};
+                cov3d_from_scale_rot(s3, a.mod, q4, cov6);
 #pragma unroll
-        for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov6[i];
+                for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov6[i];
+            }
+            Cov2DTerms ct;
+            cov2d_terms(p, a.fx, a.fy, a.tanx, a.tany, cov6, a.view, ct);
+            const float cx = ct.cov.m[0][0] + 0.3f, cy = ct.cov.m[0][1], cz = ct.cov.m[1][1] + 0.3f;
+            const float det = (cx * cz - cy * cy);
+            if (det != 0.0f) {
+                const float det_inv = 1.f / det;
+                const float3 conic = make_float3(cz * det_inv, -cy * det_inv, cx * det_inv);
+                const float mid = 0.5f * (cx + cz);
+                const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+                const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+                const float2 pix = make_float2(ndc2pix(pproj.x, a.W), ndc2pix(pproj.y, a.H));
+                int x0, y0, x1, y1;
+                get_rect(pix.x, pix.y, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
+                if ((x1 - x0) * (y1 - y0) != 0) {
+                    vis = true;
+                    const float opacity = a.opac[idx];
+                    a.depths[idx] = pview.z;
+                    a.radii[idx] = (int)my_radius;
+                    a.xy[idx] = pix;
+                    a.conic_op[idx] = make_float4(conic.x, conic.y, conic.z, opacity);
+                    a.rects[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
+                    // exact count of tiles this splat can change
+                    const TileTest tt = make_tile_test(pix, conic, opacity);
+                    uint32_t cnt = 0;
+                    for (int y = y0; y < y1; y++) {
+                        int lo, hi;
+                        row_span(tt, y, x0, x1, lo, hi);
+                        cnt += (uint32_t)max(0, hi - lo + 1);
+                    }
+                    a.tiles_touched[idx] = cnt;
+                    if (cnt) a.depth_key[idx] = __float_as_uint(pview.z);
+                }
+            }
+        }
     }
-    Cov2DTerms ct;
-    cov2d_terms(p, a.fx, a.fy, a.tanx, a.tany, cov6, a.view, ct);
-    const float cx = ct.cov.m[0][0] + 0.3f, cy = ct.cov.m[0][1], cz = ct.cov.m[1][1] + 0.3f;
-    const float det = (cx * cz - cy * cy);
-    if (det == 0.0f) return;
-    const float det_inv = 1.f / det;
-    const float3 conic = make_float3(cz * det_inv, -cy * det_inv, cx * det_inv);
-    const float mid = 0.5f * (cx + cz);
-    const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
-    const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
-    const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
-    const float2 pix = make_float2(ndc2pix(pproj.x, a.W), ndc2pix(pproj.y, a.H));
-    int x0, y0, x1, y1;
-    get_rect(pix.x, pix.y, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
-    if ((x1 - x0) * (y1 - y0) == 0) return;
+    if (a.colors_pre != nullptr) return;     // block-uniform
 
-    if (a.colors_pre == nullptr) {
+    // ---- SH -> RGB (forward.cu:20-71), evaluated in the reference's summation order
+    if (sh16_vector_ok(a.M, a.shs)) {
+        s_vis[tid] = vis ? 1 : 0;
+        __syncthreads();
+        const float4* src = reinterpret_cast<const float4*>(a.shs) + (size_t)blockIdx.x * GSR_BLOCK * GSR_SH16_ROW4;
+#pragma unroll
+        for (int i = 0; i < GSR_SH16_ROW4; i++) {
+            const int j = tid + GSR_BLOCK * i;              // float4 index inside the block's contiguous chunk
+            const int g = j / GSR_SH16_ROW4;
+            if (s_vis[g]) s_sh[g * GSR_SH16_LDS4 + (j - g * GSR_SH16_ROW4)] = src[j];
+        }
+        __syncthreads();
+        if (vis) {
+            uint8_t cb;
+            const float3 c = sh_to_rgb(a.D, 16, p, a.campos, reinterpret_cast<const float*>(&s_sh[tid * GSR_SH16_LDS4]), cb);
+            a.rgb[3 * idx] = c.x; a.rgb[3 * idx + 1] = c.y; a.rgb[3 * idx + 2] = c.z;
+            a.clamped[idx] = cb;
+        }
+    } else if (vis) {
         uint8_t cb;
         const float3 c = sh_to_rgb(a.D, a.M, p, a.campos, a.shs + (size_t)idx * a.M * 3, cb);
         a.rgb[3 * idx] = c.x; a.rgb[3 * idx + 1] = c.y; a.rgb[3 * idx + 2] = c.z;
         a.clamped[idx] = cb;
     }
-    const float opacity = a.opac[idx];
-    a.depths[idx] = pview.z;
-    a.radii[idx] = (int)my_radius;
-    a.xy[idx] = pix;
-    a.conic_op[idx] = make_float4(conic.x, conic.y, conic.z, opacity);
-    a.rects[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
-    // exact count of tiles this splat can change
-    const TileTest tt = make_tile_test(pix, conic, opacity);
-    uint32_t cnt = 0;
-    for (int y = y0; y < y1; y++) {
-        int lo, hi;
-        row_span(tt, y, x0, x1, lo, hi);
-        cnt += (uint32_t)max(0, hi - lo + 1);
-    }
-    a.tiles_touched[idx] = cnt;
-    if (cnt) a.depth_key[idx] = __float_as_uint(pview.z);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -268,7 +309,9 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x;
-    const int px = tx * GSR_TILE + (tid & 15), py = ty * GSR_TILE + (tid >> 4);
+    // each wave owns an 8x8 pixel block of the tile (not a 16x4 strip): a splat's footprint then misses
+    // whole waves more often, which is what the wave-level skips below key on
+    const int px = tx * GSR_TILE + ((tid >> 6) & 1) * 8 + (tid & 7), py = ty * GSR_TILE + (tid >> 7) * 8 + ((tid >> 3) & 7);
     const bool inside = px < W && py < H;
     const int pix_id = W * py + px;
     const float pxf = (float)px, pyf = (float)py;
@@ -362,7 +405,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int px = tx * GSR_TILE + (tid & 15), py = ty * GSR_TILE + (tid >> 4);
+    const int px = tx * GSR_TILE + (wv & 1) * 8 + (tid & 7), py = ty * GSR_TILE + (wv >> 1) * 8 + ((tid >> 3) & 7);
     const bool inside = px < W && py < H;
     const int pix_id = W * py + px;
     const float pxf = (float)px, pyf = (float)py;
@@ -420,7 +463,9 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
             for (int q = 0; q < GSR_NQ; q++) v[q] = 0.f;
             if (valid) {
                 const float4 Cc = s.c[j];
-                T = T / (1.f - alpha);
+                // one hardware reciprocal (1 ulp) serves both 1/(1-alpha) uses of backward.cu:516,558
+                const float r1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                T = T * r1ma;
                 const float dchannel_dcolor = alpha * T;
                 float dL_dopa = 0.f;
                 ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = Cc.x; dL_dopa += (Cc.x - ar0) * dpx;
@@ -434,7 +479,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
                 dL_dopa += -(alpha - aar) * dLa;
                 dL_dopa *= T;
                 last_alpha = alpha;
-                dL_dopa += (-T_final / (1.f - alpha)) * bg_dot;
+                dL_dopa += (-T_final * r1ma) * bg_dot;
                 const float dL_dG = B.y * dL_dopa;
                 const float gdx = G * dx, gdy = G * dy;
                 const float dG_ddelx = -gdx * A.z - gdy * A.w;
@@ -446,8 +491,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
                 v[7] = -0.5f * gdy * dy * dL_dG;
                 v[8] = G * dL_dopa;
             }
-            wave_sum10_to_lane63(v);
-            if (lane == 63) {
+            row_sum10_to_lane15(v);
+            if ((lane & 15) == 15) {
 #pragma unroll
                 for (int q = 0; q < (POSE ? GSR_NQ : GSR_NQ - 1); q++) atomicAdd(&s.acc[j][q], v[q]);
             }
@@ -497,21 +542,20 @@ __device__ __forceinline__ float3 dnormvdv3(float3 v, float3 dv)
     return r;
 }
 
-// SH backward (backward.cu:20-139); writes dL_dsh (if non-null) and returns the mean gradient part
+// SH backward (backward.cu:20-139); returns the mean-gradient part and, if dsh is non-null, writes
+// dL_dsh.  All reads of `sh` happen before the first write of `dsh`, so dsh may alias sh (in-place in LDS).
 __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, const float* campos, const float* sh,
                                               uint8_t cb, float3 dcol, float* dsh)
 {
     const float3 dir_orig = make_float3(pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]);
     const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
     const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
+    const float xx = x * x, yy = y * y, zz = z * z;
+    const float xy = x * y, yz = y * z, xz = x * z;
     float dRGB[3] = {dcol.x * ((cb & 1) ? 0.f : 1.f), dcol.y * ((cb & 2) ? 0.f : 1.f), dcol.z * ((cb & 4) ? 0.f : 1.f)};
     float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
 #define SH(k, c) sh[(k) * 3 + (c)]
-#define DSH(k, w) if (dsh) { _Pragma("unroll") for (int c = 0; c < 3; c++) dsh[(k) * 3 + c] = (w) * dRGB[c]; }
-    DSH(0, kSH_C0);
     if (deg > 0) {
-        const float w1 = -kSH_C1 * y, w2 = kSH_C1 * z, w3 = -kSH_C1 * x;
-        DSH(1, w1); DSH(2, w2); DSH(3, w3);
 #pragma unroll
         for (int c = 0; c < 3; c++) {
             dx[c] = -kSH_C1 * SH(3, c);
@@ -519,11 +563,6 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, const 
             dz[c] = kSH_C1 * SH(2, c);
         }
         if (deg > 1) {
-            const float xx = x * x, yy = y * y, zz = z * z;
-            const float xy = x * y, yz = y * z, xz = x * z;
-            const float w4 = kSH_C2[0] * xy, w5 = kSH_C2[1] * yz, w6 = kSH_C2[2] * (2.f * zz - xx - yy);
-            const float w7 = kSH_C2[3] * xz, w8 = kSH_C2[4] * (xx - yy);
-            DSH(4, w4); DSH(5, w5); DSH(6, w6); DSH(7, w7); DSH(8, w8);
 #pragma unroll
             for (int c = 0; c < 3; c++) {
                 dx[c] += kSH_C2[0] * y * SH(4, c) + kSH_C2[2] * 2.f * -x * SH(6, c) + kSH_C2[3] * z * SH(7, c) + kSH_C2[4] * 2.f * x * SH(8, c);
@@ -531,11 +570,6 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, const 
                 dz[c] += kSH_C2[1] * y * SH(5, c) + kSH_C2[2] * 2.f * 2.f * z * SH(6, c) + kSH_C2[3] * x * SH(7, c);
             }
             if (deg > 2) {
-                const float w9 = kSH_C3[0] * y * (3.f * xx - yy), w10 = kSH_C3[1] * xy * z;
-                const float w11 = kSH_C3[2] * y * (4.f * zz - xx - yy), w12 = kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy);
-                const float w13 = kSH_C3[4] * x * (4.f * zz - xx - yy), w14 = kSH_C3[5] * z * (xx - yy);
-                const float w15 = kSH_C3[6] * x * (xx - 3.f * yy);
-                DSH(9, w9); DSH(10, w10); DSH(11, w11); DSH(12, w12); DSH(13, w13); DSH(14, w14); DSH(15, w15);
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
                     dx[c] += (kSH_C3[0] * SH(9, c) * 3.f * 2.f * xy + kSH_C3[1] * SH(10, c) * yz + kSH_C3[2] * SH(11, c) * -2.f * xy
@@ -553,7 +587,26 @@ __device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, const 
         }
     }
 #undef SH
+    if (dsh) {
+#define DSH(k, w) { const float w_ = (w); _Pragma("unroll") for (int c = 0; c < 3; c++) dsh[(k) * 3 + c] = w_ * dRGB[c]; }
+        DSH(0, kSH_C0);
+        if (deg > 0) {
+            DSH(1, -kSH_C1 * y); DSH(2, kSH_C1 * z); DSH(3, -kSH_C1 * x);
+            if (deg > 1) {
+                DSH(4, kSH_C2[0] * xy); DSH(5, kSH_C2[1] * yz); DSH(6, kSH_C2[2] * (2.f * zz - xx - yy));
+                DSH(7, kSH_C2[3] * xz); DSH(8, kSH_C2[4] * (xx - yy));
+                if (deg > 2) {
+                    DSH(9, kSH_C3[0] * y * (3.f * xx - yy)); DSH(10, kSH_C3[1] * xy * z);
+                    DSH(11, kSH_C3[2] * y * (4.f * zz - xx - yy)); DSH(12, kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
+                    DSH(13, kSH_C3[4] * x * (4.f * zz - xx - yy)); DSH(14, kSH_C3[5] * z * (xx - yy));
+                    DSH(15, kSH_C3[6] * x * (xx - 3.f * yy));
+                }
+            }
+        }
+        // coefficients above the active degree receive zero gradient (the reference's buffer is pre-zeroed)
+        for (int k = (deg + 1) * (deg + 1); k < M; k++) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
 #undef DSH
+    }
     const float3 dL_ddir = make_float3(dx[0] * dRGB[0] + dx[1] * dRGB[1] + dx[2] * dRGB[2],
                                        dy[0] * dRGB[0] + dy[1] * dRGB[1] + dy[2] * dRGB[2],
                                        dz[0] * dRGB[0] + dz[1] * dRGB[1] + dz[2] * dRGB[2]);
@@ -596,12 +649,31 @@ __device__ __forceinline__ void cov3d_backward(const float* s3, float mod, const
 
 __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
 {
+    __shared__ float4 s_sh[GSR_BLOCK * GSR_SH16_LDS4];
+    __shared__ uint8_t s_vis[GSR_BLOCK];
     __shared__ double s_tau[4][6];
-    const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    const int tid = threadIdx.x;
+    const int idx = blockIdx.x * GSR_BLOCK + tid;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float tau[6] = {0, 0, 0, 0, 0, 0};
     const bool live = idx < a.P;
     const bool vis = live && a.radii[idx] > 0;
+    // SH rows in (and dL_dsh rows out) as coalesced block streams through LDS, see k_preprocess
+    const bool staged = (a.shs != nullptr) && sh16_vector_ok(a.M, a.shs) &&
+                        (a.dL_dsh == nullptr || (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u) == 0);
+    if (staged) {
+        s_vis[tid] = vis ? 1 : 0;
+        __syncthreads();
+        const float4* src = reinterpret_cast<const float4*>(a.shs) + (size_t)blockIdx.x * GSR_BLOCK * GSR_SH16_ROW4;
+#pragma unroll
+        for (int i = 0; i < GSR_SH16_ROW4; i++) {
+            const int j = tid + GSR_BLOCK * i;
+            const int g = j / GSR_SH16_ROW4;
+            if (s_vis[g]) s_sh[g * GSR_SH16_LDS4 + (j - g * GSR_SH16_ROW4)] = src[j];
+        }
+        __syncthreads();
+    }
+    float* my_row = reinterpret_cast<float*>(&s_sh[tid * GSR_SH16_LDS4]);
 
     if (live && !vis) {
         // invisible Gaussian: every gradient is zero, written explicitly (outputs are not pre-zeroed)
@@ -609,7 +681,14 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
         for (int i = 0; i < 3; i++) a.dL_dmean3D[3 * (size_t)idx + i] = 0.f;
 #pragma unroll
         for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
-        if (a.dL_dsh) for (int i = 0; i < a.M * 3; i++) a.dL_dsh[(size_t)idx * a.M * 3 + i] = 0.f;
+        if (a.dL_dsh) {
+            if (staged) {
+#pragma unroll
+                for (int i = 0; i < GSR_SH16_ROW4; i++) s_sh[tid * GSR_SH16_LDS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                for (int i = 0; i < a.M * 3; i++) a.dL_dsh[(size_t)idx * a.M * 3 + i] = 0.f;
+            }
+        }
         if (a.dL_dscale) {
 #pragma unroll
             for (int i = 0; i < 3; i++) a.dL_dscale[3 * (size_t)idx + i] = 0.f;
@@ -703,8 +782,11 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
         float3 g_sh = make_float3(0.f, 0.f, 0.f);
         if (a.shs) {
             const float3 dcol = make_float3(a.dL_dcolor[3 * idx], a.dL_dcolor[3 * idx + 1], a.dL_dcolor[3 * idx + 2]);
-            g_sh = sh_backward(a.D, a.M, mean, a.campos, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dcol,
-                               a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
+            if (staged)
+                g_sh = sh_backward(a.D, 16, mean, a.campos, my_row, a.clamped[idx], dcol, a.dL_dsh ? my_row : nullptr);
+            else
+                g_sh = sh_backward(a.D, a.M, mean, a.campos, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dcol,
+                                   a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
             dm0 += g_sh.x; dm1 += g_sh.y; dm2 += g_sh.z;
         }
         a.dL_dmean3D[3 * (size_t)idx] = dm0;
@@ -776,6 +858,17 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
             tau[3] = pc[1] * Rg[2] - pc[2] * Rg[1] + (Aij(1, 2) - Aij(2, 1));
             tau[4] = pc[2] * Rg[0] - pc[0] * Rg[2] + (Aij(2, 0) - Aij(0, 2));
             tau[5] = pc[0] * Rg[1] - pc[1] * Rg[0] + (Aij(0, 1) - Aij(1, 0));
+        }
+    }
+    if (staged && a.dL_dsh) {
+        __syncthreads();
+        float4* dst = reinterpret_cast<float4*>(a.dL_dsh) + (size_t)blockIdx.x * GSR_BLOCK * GSR_SH16_ROW4;
+        const int nrows = min(GSR_BLOCK, a.P - blockIdx.x * GSR_BLOCK);
+#pragma unroll
+        for (int i = 0; i < GSR_SH16_ROW4; i++) {
+            const int j = tid + GSR_BLOCK * i;
+            const int g = j / GSR_SH16_ROW4;
+            if (g < nrows) dst[j] = s_sh[g * GSR_SH16_LDS4 + (j - g * GSR_SH16_ROW4)];
         }
     }
     if (a.pose) {

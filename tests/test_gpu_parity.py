@@ -59,6 +59,21 @@ def test_forward_backward_parity(cfg, pose):
     _check_grads(g, go, pose, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
 
 
+def test_active_degree_below_max_degree():
+    """train.py raises the active SH degree every 1000 iterations (train.py:73-74): M=16 rows, degree 1 used;
+    the unused coefficients must receive exactly zero gradient"""
+    sc = S.small(P=700, W=64, H=48, sh_degree=3, seed=17, scale_med=0.06)
+    sc.sh_degree = 1
+    cam = U.scene_inputs(sc, W2C)
+    grads = U.random_grads(sc, seed=17)
+    for pose in (False, True):
+        f, go = U.oracle_run(sc, cam, grads, pose=pose)
+        o, g = U.hip_run(sc, cam, grads, pose=pose)
+        _check_forward(o, f, pose)
+        _check_grads(g, go, pose, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
+        assert np.all(g["sh"][:, 4:, :] == 0)
+
+
 def test_precomputed_inputs_mode():
     """colors_precomp + cov3D_precomp path (pipe.convert_SHs_python / compute_cov3D_python)"""
     sc = S.small(P=600, W=64, H=48, sh_degree=3, seed=7, scale_med=0.06)
