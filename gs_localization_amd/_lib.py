@@ -30,6 +30,38 @@ SIGNATURES = {
     "gsr_device_ok": (_i, []),
 }
 
+class RefineArgs(C.Structure):
+    """mirror of `gsr_refine_args` (include/gsr.h)"""
+    _fields_ = [
+        ("P", _i), ("D", _i), ("M", _i),
+        ("means3D", _vp), ("shs", _vp), ("opacities", _vp), ("scales", _vp), ("rotations", _vp),
+        ("scale_modifier", _f),
+        ("width", _i), ("height", _i), ("tan_fovx", _f), ("tan_fovy", _f),
+        ("background", _vp), ("projmatrix_raw", _vp),
+        ("gt_image", _vp), ("gt_depth", _vp), ("grad_mask", _vp),
+        ("opacity_threshold", _f), ("depth_weight", _f), ("monocular", _i),
+        ("pose_state", _vp),
+        ("out_color", _vp), ("out_depth", _vp), ("out_alpha", _vp), ("radii", _vp), ("n_touched", _vp),
+        ("dL_dimage", _vp), ("dL_ddepth", _vp), ("dL_dalpha", _vp),
+        ("dL_dmean2D", _vp), ("dL_dconic", _vp), ("dL_dopacity", _vp), ("dL_dcolor", _vp),
+        ("dL_dmean3D", _vp), ("dL_dcov3D", _vp), ("dL_dsh", _vp), ("dL_dscale", _vp), ("dL_drot", _vp),
+        ("dL_dtau", _vp), ("loss_out", _vp),
+        ("geometry_buffer", RESIZE_FN), ("geometry_ctx", _vp),
+        ("binning_buffer", RESIZE_FN), ("binning_ctx", _vp),
+        ("image_buffer", RESIZE_FN), ("image_ctx", _vp),
+        ("lr", _f), ("converged_threshold", _f), ("max_iters", _i), ("stop_on_converged", _i),
+        ("stream", _vp),
+    ]
+
+
+POSE_STATE_FLOATS = 96
+SIGNATURES.update({
+    "gsr_tracking_loss": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
+    "gsr_pose_init": (_i, [_vp, _vp, _vp]),
+    "gsr_pose_step": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp]),
+    "gsr_refine": (_i, [C.POINTER(RefineArgs), C.POINTER(_i), C.POINTER(_i)]),
+})
+
 _lib = None
 
 

@@ -396,6 +396,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
                  float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
                  int pose_mode, float* dL_dtau, void* stream)
 {
+    // dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot may be NULL: that gradient is then not written
     using namespace gsr;
     hipStream_t st = (hipStream_t)stream;
     if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(GSR_E_INVALID, "bad sizes%s", "");
@@ -408,7 +409,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
         return 0;
     }
     if (!means3D || !radii || !geom_buffer || !binning_buffer || !img_buffer || !alphas || !dL_dpix || !dL_ddepths ||
-        !dL_dalphas || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D)
+        !dL_dalphas || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor)
         return fail(GSR_E_INVALID, "a required backward pointer is NULL%s", "");
     if (pose_mode && !dL_dtau) return fail(GSR_E_INVALID, "pose_mode needs dL_dtau%s", "");
     int rc = select_device_of(means3D);
@@ -468,6 +469,123 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     if (pose_mode) {
         hipLaunchKernelGGL(k_tau_finish, dim3(1), dim3(64), 0, st, (const double*)g.tau_acc, dL_dtau);
         LAUNCHCHK("k_tau_finish");
+    }
+    return 0;
+}
+
+int gsr_tracking_loss(int width, int height, const float* image, const float* depth, const float* opacity,
+                      const float* gt_image, const float* gt_depth, const uint8_t* grad_mask, const float* exposure,
+                      float opacity_threshold, float depth_weight, int monocular, float* dL_dimage, float* dL_ddepth,
+                      float* dL_dalpha, float* out, void* stream)
+{
+    using namespace gsr;
+    const int debug = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (width <= 0 || height <= 0) return fail(GSR_E_INVALID, "positive image size required%s", "");
+    if (!image || !depth || !opacity || !gt_image || !grad_mask || !exposure || !dL_dimage || !dL_ddepth || !dL_dalpha || !out ||
+        (!monocular && !gt_depth))
+        return fail(GSR_E_INVALID, "gsr_tracking_loss: NULL pointer%s", "");
+    int rc = select_device_of(image);
+    if (rc != GSR_OK) return rc;
+    HIPCHK(hipMemsetAsync(out, 0, 4 * sizeof(float), st));
+    LossArgs la;
+    la.W = width; la.H = height; la.image = image; la.depth = depth; la.opacity = opacity; la.gt_image = gt_image;
+    la.gt_depth = gt_depth; la.grad_mask = grad_mask; la.exposure = exposure; la.opacity_thr = opacity_threshold;
+    la.depth_w = depth_weight; la.monocular = monocular; la.dL_dimage = dL_dimage; la.dL_ddepth = dL_ddepth;
+    la.dL_dalpha = dL_dalpha; la.out = out;
+    const int n = width * height;
+    hipLaunchKernelGGL(k_tracking_loss, dim3((n + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, la);
+    LAUNCHCHK("k_tracking_loss");
+    return 0;
+}
+
+int gsr_pose_init(float* pose_state, const float* projmatrix_raw, void* stream)
+{
+    const int debug = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (!pose_state || !projmatrix_raw) return fail(GSR_E_INVALID, "gsr_pose_init: NULL pointer%s", "");
+    int rc = select_device_of(pose_state);
+    if (rc != GSR_OK) return rc;
+    hipLaunchKernelGGL(gsr::k_pose_init, dim3(1), dim3(64), 0, st, pose_state, projmatrix_raw);
+    LAUNCHCHK("k_pose_init");
+    return 0;
+}
+
+int gsr_pose_step(float* pose_state, const float* dL_dtau, const float* loss_out, const float* projmatrix_raw, float lr,
+                  float converged_threshold, void* stream)
+{
+    const int debug = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (!pose_state || !dL_dtau || !loss_out || !projmatrix_raw) return fail(GSR_E_INVALID, "gsr_pose_step: NULL pointer%s", "");
+    int rc = select_device_of(pose_state);
+    if (rc != GSR_OK) return rc;
+    hipLaunchKernelGGL(gsr::k_pose_step, dim3(1), dim3(64), 0, st, pose_state, dL_dtau, loss_out, projmatrix_raw, lr,
+                       converged_threshold);
+    LAUNCHCHK("k_pose_step");
+    return 0;
+}
+
+namespace {
+// resize callback wrapper that only calls the user's callback when the workspace must grow
+struct CachedBuf { gsr_resize_fn fn; void* ctx; void* ptr; size_t cap; };
+void* cached_resize(void* c, size_t bytes)
+{
+    CachedBuf* b = static_cast<CachedBuf*>(c);
+    if (bytes > b->cap || !b->ptr) {
+        const size_t want = bytes + bytes / 4;       // head-room: R changes a little from iteration to iteration
+        b->ptr = b->fn(b->ctx, want);
+        b->cap = b->ptr ? want : 0;
+    }
+    return b->ptr;
+}
+}  // namespace
+
+int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
+{
+    using namespace gsr;
+    if (!a || !iters_done || !converged) return fail(GSR_E_INVALID, "gsr_refine: NULL argument%s", "");
+    if (!a->pose_state || !a->projmatrix_raw || !a->gt_image || !a->grad_mask || !a->dL_dimage || !a->dL_ddepth ||
+        !a->dL_dalpha || !a->dL_dtau || !a->loss_out || !a->n_touched)
+        return fail(GSR_E_INVALID, "gsr_refine: a required pointer is NULL%s", "");
+    hipStream_t st = (hipStream_t)a->stream;
+    int rc = select_device_of(a->pose_state);
+    if (rc != GSR_OK) return rc;
+    static thread_local int* h_flag = nullptr;           // pinned: the convergence flag rides on forward's own sync
+    if (!h_flag) HIPCHK(hipHostMalloc((void**)&h_flag, 4 * sizeof(float)));
+    float* h_f = reinterpret_cast<float*>(h_flag);
+    CachedBuf gb{a->geometry_buffer, a->geometry_ctx, nullptr, 0}, bb{a->binning_buffer, a->binning_ctx, nullptr, 0},
+        ib{a->image_buffer, a->image_ctx, nullptr, 0};
+    float* ps = a->pose_state;
+    *iters_done = 0;
+    *converged = 0;
+    h_f[0] = 0.f;
+    for (int it = 0; it < a->max_iters; it++) {
+        // convergence flag of the previous iteration: async copy, completed by gsr_forward's num_rendered sync
+        HIPCHK(hipMemcpyAsync(h_f, ps + GSR_PS_CONV, sizeof(float), hipMemcpyDeviceToHost, st));
+        int R = gsr_forward(cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
+                            a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
+                            a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
+                            a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, a->n_touched, a->stream);
+        if (R < 0) return R;
+        if (it > 0 && a->stop_on_converged && h_f[0] != 0.f) { *converged = 1; break; }   // reference: `if converged: break`
+        rc = gsr_tracking_loss(a->width, a->height, a->out_color, a->out_depth, a->out_alpha, a->gt_image, a->gt_depth,
+                               a->grad_mask, ps + GSR_PS_PARAM + 6, a->opacity_threshold, a->depth_weight, a->monocular,
+                               a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->loss_out, a->stream);
+        if (rc < 0) return rc;
+        rc = gsr_backward(a->P, a->D, a->M, R, a->background, a->width, a->height, a->means3D, a->shs, nullptr, a->out_alpha,
+                          a->scales, a->scale_modifier, a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ,
+                          ps + GSR_PS_CAMPOS, a->tan_fovx, a->tan_fovy, a->radii, (char*)gb.ptr, (char*)bb.ptr, (char*)ib.ptr,
+                          a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor,
+                          a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, 0, 1, a->dL_dtau, a->stream);
+        if (rc < 0) return rc;
+        rc = gsr_pose_step(ps, a->dL_dtau, a->loss_out, a->projmatrix_raw, a->lr, a->converged_threshold, a->stream);
+        if (rc < 0) return rc;
+        *iters_done = it + 1;
+    }
+    if (!*converged && a->stop_on_converged) {
+        HIPCHK(hipMemcpyAsync(h_f, ps + GSR_PS_CONV, sizeof(float), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        *converged = h_f[0] != 0.f ? 1 : 0;
     }
     return 0;
 }

@@ -677,10 +677,14 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
 
     if (live && !vis) {
         // invisible Gaussian: every gradient is zero, written explicitly (outputs are not pre-zeroed)
+        if (a.dL_dmean3D) {
 #pragma unroll
-        for (int i = 0; i < 3; i++) a.dL_dmean3D[3 * (size_t)idx + i] = 0.f;
+            for (int i = 0; i < 3; i++) a.dL_dmean3D[3 * (size_t)idx + i] = 0.f;
+        }
+        if (a.dL_dcov3D) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
+            for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
+        }
         if (a.dL_dsh) {
             if (staged) {
 #pragma unroll
@@ -732,8 +736,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
 #pragma unroll
             for (int i = 0; i < 6; i++) dcov[i] = 0;
         }
+        if (a.dL_dcov3D) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+            for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+        }
 
         const float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da + (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
         const float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da + (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
@@ -789,9 +795,11 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
                                    a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
             dm0 += g_sh.x; dm1 += g_sh.y; dm2 += g_sh.z;
         }
-        a.dL_dmean3D[3 * (size_t)idx] = dm0;
-        a.dL_dmean3D[3 * (size_t)idx + 1] = dm1;
-        a.dL_dmean3D[3 * (size_t)idx + 2] = dm2;
+        if (a.dL_dmean3D) {
+            a.dL_dmean3D[3 * (size_t)idx] = dm0;
+            a.dL_dmean3D[3 * (size_t)idx + 1] = dm1;
+            a.dL_dmean3D[3 * (size_t)idx + 2] = dm2;
+        }
 
         if (a.scales && (a.dL_dscale || a.dL_drot)) {
             float s3[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
@@ -889,6 +897,172 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
 __global__ void k_tau_finish(const double* acc, float* out)
 {
     if (threadIdx.x < 6) out[threadIdx.x] = (float)acc[threadIdx.x];
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pose-refinement epilogue: the ~130 tiny launches the reference's Python loop
+// issues per iteration for the tracking loss, its autograd backward, Adam and update_pose become two.
+// ---------------------------------------------------------------------------------------------
+// Tracking loss of gs_localization/pipelines/tools/descent_utils.py:85-123 and its gradient w.r.t. the
+// rendered image / depth and the exposure pair (a, b):
+//   image_ab = exp(a) image + b;  L = mean(om |image_ab gm - gt gm|) [+ w_d mean(|depth dm - gt_d dm|)]
+//   om = opacity > thr, gm = grad_mask, dm = (gt_d > 0.01) om gm.   No gradient flows into opacity.
+struct LossArgs {
+    int W, H;
+    const float* image; const float* depth; const float* opacity; const float* gt_image; const float* gt_depth;
+    const uint8_t* grad_mask; const float* exposure; float opacity_thr, depth_w; int monocular;
+    float* dL_dimage; float* dL_ddepth; float* dL_dalpha; float* out;     // out[0]=loss, [1]=dL/da, [2]=dL/db
+};
+__device__ __forceinline__ float sgnf(float d) { return (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f); }
+
+__global__ void __launch_bounds__(GSR_BLOCK) k_tracking_loss(LossArgs a)
+{
+    __shared__ float s_red[4][3];
+    const int n = a.W * a.H;
+    const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    const float ea = expf(a.exposure[0]), eb = a.exposure[1];
+    float l = 0.f, da = 0.f, db = 0.f;
+    if (i < n) {
+        const bool om = a.opacity[i] > a.opacity_thr;
+        const float gm = a.grad_mask[i] ? 1.f : 0.f;
+        const float inv3n = 1.f / (3.f * (float)n);
+        const float w = om ? gm : 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) {
+            const float img = a.image[(size_t)c * n + i];
+            const float d = (ea * img + eb) * gm - a.gt_image[(size_t)c * n + i] * gm;
+            if (om) l += fabsf(d) * inv3n;
+            const float g = w * sgnf(d) * inv3n;
+            a.dL_dimage[(size_t)c * n + i] = g * ea;
+            da += g * ea * img;
+            db += g;
+        }
+        float gdp = 0.f;
+        if (!a.monocular) {
+            const float gd = a.gt_depth[i];
+            const float dm = (gd > 0.01f && om) ? gm : 0.f;
+            const float dd = a.depth[i] * dm - gd * dm;
+            const float invn = 1.f / (float)n;
+            l += a.depth_w * fabsf(dd) * invn;
+            gdp = a.depth_w * dm * sgnf(dd) * invn;
+        }
+        a.dL_ddepth[i] = gdp;
+        a.dL_dalpha[i] = 0.f;
+    }
+    l = wave_sum(l); da = wave_sum(da); db = wave_sum(db);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { s_red[wv][0] = l; s_red[wv][1] = da; s_red[wv][2] = db; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+        if (t != 0.f) atomicAdd(&a.out[threadIdx.x], t);
+    }
+}
+
+// Device-resident state of one query frame's refinement (floats):
+//   [0..8] R (row-major W2C rotation)  [9..11] T   [12..14] cam_rot_delta  [15..17] cam_trans_delta
+//   [18] exposure_a  [19] exposure_b   [20..27] Adam exp_avg   [28..35] Adam exp_avg_sq   [36] Adam step
+//   [37] converged (0/1)  [38] last loss  [39] |tau|   [48..63] viewmatrix  [64..79] projmatrix  [80..82] campos
+#define GSR_PS_R 0
+#define GSR_PS_T 9
+#define GSR_PS_PARAM 12
+#define GSR_PS_M 20
+#define GSR_PS_V 28
+#define GSR_PS_STEP 36
+#define GSR_PS_CONV 37
+#define GSR_PS_LOSS 38
+#define GSR_PS_TAUN 39
+#define GSR_PS_VIEW 48
+#define GSR_PS_PROJ 64
+#define GSR_PS_CAMPOS 80
+#define GSR_PS_SIZE 96
+
+// view / proj / campos from (R, T): world_view_transform, full_proj_transform, camera_center of
+// gs_localization/pipelines/tools/camera_utils.py:144-158 without the two 4x4 inversions
+__device__ __forceinline__ void pose_write_camera(float* st, const float* proj_raw)
+{
+    const float* R = st + GSR_PS_R;
+    const float* T = st + GSR_PS_T;
+    float* view = st + GSR_PS_VIEW;
+    for (int c = 0; c < 3; c++) {
+        for (int r = 0; r < 3; r++) view[c * 4 + r] = R[r * 3 + c];
+        view[c * 4 + 3] = 0.f;
+    }
+    view[12] = T[0]; view[13] = T[1]; view[14] = T[2]; view[15] = 1.f;
+    float* proj = st + GSR_PS_PROJ;
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            float acc = 0.f;
+            for (int k = 0; k < 4; k++) acc += view[i * 4 + k] * proj_raw[k * 4 + j];
+            proj[i * 4 + j] = acc;
+        }
+    for (int c = 0; c < 3; c++) st[GSR_PS_CAMPOS + c] = -(R[0 * 3 + c] * T[0] + R[1 * 3 + c] * T[1] + R[2 * 3 + c] * T[2]);
+}
+
+__global__ void k_pose_init(float* st, const float* proj_raw)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) pose_write_camera(st, proj_raw);
+}
+
+// Adam (torch.optim.Adam defaults, one lr for the four groups of 7scenes_localize_full_dslam.py:33-64) on
+// [rot(3), trans(3), exposure_a, exposure_b], then update_pose (tools/pose_utils.py:54-122):
+// T_w2c <- SE3_exp([trans, rot]) T_w2c, deltas <- 0, converged = |tau| < threshold.
+__global__ void k_pose_step(float* st, const float* dL_dtau, const float* loss_out, const float* proj_raw, float lr,
+                            float conv_thr)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float g[8] = {dL_dtau[3], dL_dtau[4], dL_dtau[5], dL_dtau[0], dL_dtau[1], dL_dtau[2], loss_out[1], loss_out[2]};
+    const float step = st[GSR_PS_STEP] + 1.f;
+    st[GSR_PS_STEP] = step;
+    const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - 0.9), w2 = (float)(1.0 - 0.999);
+    for (int i = 0; i < 8; i++) {
+        float m = st[GSR_PS_M + i], v = st[GSR_PS_V + i];
+        m = m + w1 * (g[i] - m);                         // exp_avg.lerp_(grad, 1 - beta1)
+        v = v * 0.999f + w2 * (g[i] * g[i]);             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        st[GSR_PS_M + i] = m; st[GSR_PS_V + i] = v;
+        const float denom = sqrtf(v) / bc2_sqrt + 1e-8f;
+        st[GSR_PS_PARAM + i] = st[GSR_PS_PARAM + i] + (-step_size) * (m / denom);
+    }
+    // update_pose
+    const float th[3] = {st[GSR_PS_PARAM + 0], st[GSR_PS_PARAM + 1], st[GSR_PS_PARAM + 2]};
+    const float rho[3] = {st[GSR_PS_PARAM + 3], st[GSR_PS_PARAM + 4], st[GSR_PS_PARAM + 5]};
+    const float Wm[9] = {0.f, -th[2], th[1], th[2], 0.f, -th[0], -th[1], th[0], 0.f};
+    float W2[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) W2[i * 3 + j] = Wm[i * 3] * Wm[j] + Wm[i * 3 + 1] * Wm[3 + j] + Wm[i * 3 + 2] * Wm[6 + j];
+    const float angle = sqrtf(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
+    float cW, cW2, vW, vW2;
+    if (angle < 1e-5f) { cW = 1.f; cW2 = 0.5f; vW = 0.5f; vW2 = 1.0f / 6.0f; }
+    else {
+        cW = sinf(angle) / angle; cW2 = (1.f - cosf(angle)) / (angle * angle);
+        vW = (1.0f - cosf(angle)) / (angle * angle); vW2 = (angle - sinf(angle)) / (angle * angle * angle);
+    }
+    float Re[9], Vm[9];
+    for (int i = 0; i < 9; i++) {
+        const float I = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+        Re[i] = I + cW * Wm[i] + cW2 * W2[i];
+        Vm[i] = I + Wm[i] * vW + W2[i] * vW2;
+    }
+    float te[3];
+    for (int i = 0; i < 3; i++) te[i] = Vm[i * 3] * rho[0] + Vm[i * 3 + 1] * rho[1] + Vm[i * 3 + 2] * rho[2];
+    float Rn[9], Tn[3];
+    const float* R = st + GSR_PS_R;
+    const float* T = st + GSR_PS_T;
+    for (int i = 0; i < 3; i++) {
+        for (int j = 0; j < 3; j++) Rn[i * 3 + j] = Re[i * 3] * R[j] + Re[i * 3 + 1] * R[3 + j] + Re[i * 3 + 2] * R[6 + j];
+        Tn[i] = Re[i * 3] * T[0] + Re[i * 3 + 1] * T[1] + Re[i * 3 + 2] * T[2] + te[i];
+    }
+    const float taun = sqrtf(rho[0] * rho[0] + rho[1] * rho[1] + rho[2] * rho[2] + th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
+    for (int i = 0; i < 9; i++) st[GSR_PS_R + i] = Rn[i];
+    for (int i = 0; i < 3; i++) st[GSR_PS_T + i] = Tn[i];
+    for (int i = 0; i < 6; i++) st[GSR_PS_PARAM + i] = 0.f;          // cam_rot_delta / cam_trans_delta .fill_(0)
+    st[GSR_PS_CONV] = (taun < conv_thr) ? 1.f : 0.f;
+    st[GSR_PS_TAUN] = taun;
+    st[GSR_PS_LOSS] = loss_out[0];
+    pose_write_camera(st, proj_raw);
 }
 
 // K10  near-plane visibility (replaces rasterizer_impl.cu:54-66 checkFrustum)

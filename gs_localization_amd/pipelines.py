@@ -297,6 +297,107 @@ def gradient_decent(viewpoint, config, initial_R, initial_T, Model, pipeline_par
     return viewpoint.R, viewpoint.T, render_pkg
 
 
+class FusedRefiner:
+    """gradient_decent() with the whole loop on the device.
+
+    Same inputs, same hyper-parameters and the same result as `gradient_decent` above -- render (B),
+    tracking loss, backward, Adam step, update_pose, early exit on convergence -- but each iteration is
+    the four native calls of `gsr_refine` (include/gsr.h) instead of ~130 torch launches, and autograd is
+    not involved.  `gaussian_grads=True` keeps computing every Gaussian-parameter gradient like the
+    reference does (its map tensors require grad, tools/gaussian_model.py:437-462) although nothing
+    consumes them; `False` is the pose-only fast path."""
+
+    def __init__(self, Model, image_height, image_width, device="cuda:0", gaussian_grads=True):
+        import ctypes as C
+        from . import _lib
+        from .rasterizer import _Workspace, _f32c
+        self._C, self._lib_mod = C, _lib
+        self.lib = _lib.load()
+        self.dev = torch.device(device)
+        self.H, self.W = int(image_height), int(image_width)
+        self.model = Model
+        dev = self.dev
+        self.means3D = _f32c(Model.get_xyz.detach())
+        self.shs = _f32c(Model.get_features.detach())
+        self.opac = _f32c(Model.get_opacity.detach())
+        sc = Model.get_scaling.detach()
+        self.scales = _f32c(sc.repeat(1, 3) if sc.shape[-1] == 1 else sc)
+        self.rots = _f32c(Model.get_rotation.detach())
+        P, M = self.means3D.shape[0], self.shs.shape[1]
+        self.P, self.M = P, M
+        e = lambda *s, dt=torch.float32: torch.empty(s, dtype=dt, device=dev)
+        H, W = self.H, self.W
+        self.color, self.depth, self.alpha = e(3, H, W), e(1, H, W), e(1, H, W)
+        self.radii, self.n_touched = e(P, dt=torch.int32), e(P, dt=torch.int32)
+        self.g_img, self.g_depth, self.g_alpha = e(3, H, W), e(1, H, W), e(1, H, W)
+        self.g_m2d, self.g_conic, self.g_opac, self.g_col = e(P, 3), e(P, 4), e(P, 1), e(P, 3)
+        if gaussian_grads:
+            self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot = e(P, 3), e(P, 6), e(P, M, 3), e(P, 3), e(P, 4)
+        else:
+            self.g_m3d = self.g_cov = self.g_sh = self.g_scale = self.g_rot = None
+        self.g_tau, self.loss_out = e(6), e(4)
+        self.state = torch.zeros(_lib.POSE_STATE_FLOATS, dtype=torch.float32, device=dev)
+        self.ws = [_Workspace(dev), _Workspace(dev), _Workspace(dev)]
+
+    def refine(self, viewpoint, config, initial_R, initial_T, background, iters=50, lr=0.001, converged_threshold=1e-4,
+               stop_on_converged=True):
+        C, _lib = self._C, self._lib_mod
+        dev = self.dev
+        viewpoint.update_RT(initial_R, initial_T)
+        st = torch.zeros(_lib.POSE_STATE_FLOATS, dtype=torch.float32)
+        st[0:9] = viewpoint.R.detach().float().cpu().reshape(-1)
+        st[9:12] = viewpoint.T.detach().float().cpu()
+        st[18] = float(viewpoint.exposure_a.detach())
+        st[19] = float(viewpoint.exposure_b.detach())
+        self.state.copy_(st)
+        proj_raw = viewpoint.projection_matrix.detach().float().contiguous().to(dev)
+        gt_image = viewpoint.original_image.detach().float().contiguous().to(dev)
+        mono = bool(config["Training"]["monocular"])
+        gt_depth = None
+        if not mono:
+            gd = viewpoint.depth
+            gd = torch.from_numpy(gd) if not torch.is_tensor(gd) else gd
+            gt_depth = gd.to(dtype=torch.float32, device=dev).contiguous()
+        mask = viewpoint.grad_mask.to(device=dev).reshape(self.H, self.W).to(torch.uint8).contiguous()
+        bg = background.detach().float().contiguous().to(dev)
+        alpha_cfg = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.98
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        p = lambda t: None if t is None else t.data_ptr()
+        a = _lib.RefineArgs()
+        a.P, a.D, a.M = self.P, int(self.model.active_sh_degree), self.M
+        a.means3D, a.shs, a.opacities, a.scales, a.rotations = map(p, (self.means3D, self.shs, self.opac, self.scales, self.rots))
+        a.scale_modifier = 1.0
+        a.width, a.height = self.W, self.H
+        a.tan_fovx, a.tan_fovy = math.tan(viewpoint.FoVx * 0.5), math.tan(viewpoint.FoVy * 0.5)
+        a.background, a.projmatrix_raw = p(bg), p(proj_raw)
+        a.gt_image, a.gt_depth, a.grad_mask = p(gt_image), p(gt_depth), p(mask)
+        a.opacity_threshold = float(config["Training"]["opacity_threshold"])
+        a.depth_weight = float(1 - alpha_cfg)
+        a.monocular = int(mono)
+        a.pose_state = p(self.state)
+        a.out_color, a.out_depth, a.out_alpha, a.radii, a.n_touched = map(p, (self.color, self.depth, self.alpha, self.radii, self.n_touched))
+        a.dL_dimage, a.dL_ddepth, a.dL_dalpha = map(p, (self.g_img, self.g_depth, self.g_alpha))
+        a.dL_dmean2D, a.dL_dconic, a.dL_dopacity, a.dL_dcolor = map(p, (self.g_m2d, self.g_conic, self.g_opac, self.g_col))
+        a.dL_dmean3D, a.dL_dcov3D, a.dL_dsh, a.dL_dscale, a.dL_drot = map(p, (self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot))
+        a.dL_dtau, a.loss_out = p(self.g_tau), p(self.loss_out)
+        a.geometry_buffer, a.binning_buffer, a.image_buffer = self.ws[0].fn, self.ws[1].fn, self.ws[2].fn
+        a.lr, a.converged_threshold, a.max_iters = float(lr), float(converged_threshold), int(iters)
+        a.stop_on_converged = int(bool(stop_on_converged))
+        a.stream = stream
+        n_done, conv = C.c_int(0), C.c_int(0)
+        with torch.cuda.device(dev):
+            _lib.check(self.lib.gsr_pose_init(p(self.state), p(proj_raw), stream))
+            _lib.check(self.lib.gsr_refine(C.byref(a), C.byref(n_done), C.byref(conv)))
+        self._keep = (proj_raw, gt_image, gt_depth, mask, bg)        # alive until the stream has drained
+        s = self.state.cpu()
+        viewpoint.update_RT(s[0:9].reshape(3, 3).clone(), s[9:12].clone())
+        with torch.no_grad():
+            viewpoint.exposure_a.fill_(float(s[18]))
+            viewpoint.exposure_b.fill_(float(s[19]))
+        return viewpoint.R, viewpoint.T, {"iters": n_done.value, "converged": bool(conv.value), "loss": float(s[38]),
+                                          "render": self.color, "depth": self.depth, "opacity": self.alpha}
+
+
 def pose_errors(R_gt, t_gt, R, t):
     """(translation error [m], rotation error [deg]) as 7scenes_localize_full_dslam.py:368-377"""
     R_gt, t_gt, R, t = (np.asarray(x, np.float64) for x in (R_gt, t_gt, R, t))

@@ -150,6 +150,67 @@ size_t gsr_binning_bytes(int num_rendered);
 int gsr_forward_stats(int P, int width, int height, const int* radii, const char* geom_buffer,
                       const char* img_buffer, long long stats[4], void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Pose-refinement epilogue, SURVEY.md section 8(f)-1 (the caller-side row next to the rasterizer): fused,
+ * device-resident replacements for what the reference's Python loop does with ~130 tiny torch launches
+ * per iteration (gs_localization/pipelines/7scenes_localize_full_dslam.py:66-91).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Tracking loss + gradient.  Replaces get_loss_tracking / _rgb / _rgbd
+ * (gs_localization/pipelines/tools/descent_utils.py:85-123) and their autograd backward.
+ *   image [3,H,W], depth [1,H,W], opacity [1,H,W]: rasterizer outputs; gt_image [3,H,W];
+ *   gt_depth [H,W] (ignored when monocular != 0); grad_mask [H,W] uint8 0/1;
+ *   exposure: 2 device floats (exposure_a, exposure_b).  depth_weight = 1 - config["Training"]["alpha"].
+ *   Writes dL_dimage [3,H,W], dL_ddepth [1,H,W], dL_dalpha [1,H,W] (zeros: the opacity only feeds a mask)
+ *   and out[0..2] = (loss, dL/dexposure_a, dL/dexposure_b)  (device, 4 floats). */
+int gsr_tracking_loss(int width, int height, const float* image, const float* depth, const float* opacity,
+                      const float* gt_image, const float* gt_depth, const uint8_t* grad_mask,
+                      const float* exposure, float opacity_threshold, float depth_weight, int monocular,
+                      float* dL_dimage, float* dL_ddepth, float* dL_dalpha, float* out, void* stream);
+
+/* Device-resident pose state: GSR_POSE_STATE_FLOATS floats, layout
+ *   [0..8] R (row-major W2C rotation) [9..11] T [12..14] cam_rot_delta [15..17] cam_trans_delta
+ *   [18] exposure_a [19] exposure_b [20..27] Adam exp_avg [28..35] Adam exp_avg_sq [36] Adam step
+ *   [37] converged [38] last loss [39] |tau| [48..63] viewmatrix [64..79] projmatrix [80..82] campos
+ * (viewmatrix/projmatrix/campos are what gsr_forward / gsr_backward take).
+ * gsr_pose_init fills [48..82] from R, T and projmatrix_raw (16 floats, P^T row-major), replacing
+ * Camera.world_view_transform / full_proj_transform / camera_center (tools/camera_utils.py:144-158). */
+#define GSR_POSE_STATE_FLOATS 96
+int gsr_pose_init(float* pose_state, const float* projmatrix_raw, void* stream);
+
+/* One optimiser step + update_pose on the device.  Replaces torch.optim.Adam.step() over the four
+ * parameter groups (7scenes_localize_full_dslam.py:33-64, torch defaults, single lr) and update_pose
+ * (tools/pose_utils.py:105-122).  dL_dtau = gsr_backward's output; loss_out = gsr_tracking_loss's out. */
+int gsr_pose_step(float* pose_state, const float* dL_dtau, const float* loss_out, const float* projmatrix_raw,
+                  float lr, float converged_threshold, void* stream);
+
+/* The whole refinement loop of gradient_decent() (7scenes_localize_full_dslam.py:29-93) in one call:
+ * up to max_iters x { gsr_forward (pose package) -> gsr_tracking_loss -> gsr_backward -> gsr_pose_step },
+ * stopping like the reference when update_pose reports convergence.  Every pointer is a device pointer
+ * owned by the caller; workspaces are requested through the resize callbacks only when they must grow. */
+typedef struct gsr_refine_args {
+    int P, D, M;
+    const float* means3D; const float* shs; const float* opacities; const float* scales; const float* rotations;
+    float scale_modifier;
+    int width, height; float tan_fovx, tan_fovy;
+    const float* background; const float* projmatrix_raw;
+    const float* gt_image; const float* gt_depth; const uint8_t* grad_mask;
+    float opacity_threshold, depth_weight; int monocular;
+    float* pose_state;
+    float* out_color; float* out_depth; float* out_alpha; int* radii; int* n_touched;
+    float* dL_dimage; float* dL_ddepth; float* dL_dalpha;
+    float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;
+    float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;   /* nullable: pose-only */
+    float* dL_dtau; float* loss_out;
+    gsr_resize_fn geometry_buffer; void* geometry_ctx;
+    gsr_resize_fn binning_buffer; void* binning_ctx;
+    gsr_resize_fn image_buffer; void* image_ctx;
+    float lr, converged_threshold; int max_iters;
+    int stop_on_converged;      /* 1 = reference behaviour; 0 = always run max_iters (benchmarks) */
+    void* stream;
+} gsr_refine_args;
+int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
+
 /* Optional per-kernel timing with HIP events recorded on the caller's stream around each kernel
  * (bench.py's roofline leg).  mask bit i enables kernel id i; 0 disables (the default, zero cost).
  * gsr_profile_collect waits for the recorded events, ADDS elapsed milliseconds / launch counts per

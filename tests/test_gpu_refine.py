@@ -1,0 +1,166 @@
+"""-m gpu : the fused pose-refinement epilogue against plain PyTorch fp32 references of
+the same ops: tracking loss + gradient (torch autograd of the mirror of descent_utils.py, itself pinned to
+the reference by tests/golden), Adam + update_pose (torch.optim.Adam + the mirror of pose_utils.py), and
+the whole native loop against the reference-style Python loop on the same rasterizer."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from gs_localization_amd import scenes as S
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+@pytest.mark.parametrize("mono", [False, True])
+def test_tracking_loss_kernel_matches_torch_autograd(mono):
+    from gs_localization_amd import _lib, pipelines as PL
+    lib = _lib.load()
+    torch.manual_seed(0)
+    H, W = 37, 53
+    image = torch.rand(3, H, W, device=DEV, requires_grad=True)
+    depth = (torch.rand(1, H, W, device=DEV) * 4 + 0.5).requires_grad_(True)
+    opacity = torch.rand(1, H, W, device=DEV) * 0.1 + 0.93
+    gt = torch.rand(3, H, W, device=DEV)
+    gt_depth = torch.rand(H, W, device=DEV) * 4
+    gt_depth[torch.rand(H, W, device=DEV) < 0.2] = 0
+    mask = torch.rand(1, H, W, device=DEV) < 0.7
+
+    class VP:
+        pass
+    vp = VP()
+    vp.exposure_a = torch.tensor([0.07], device=DEV, requires_grad=True)
+    vp.exposure_b = torch.tensor([-0.03], device=DEV, requires_grad=True)
+    vp.original_image, vp.depth, vp.grad_mask = gt, gt_depth, mask
+    cfg = {"Training": {"monocular": mono, "alpha": 0.99, "opacity_threshold": 0.99}}
+    loss = PL.get_loss_tracking(cfg, image, depth, opacity, vp)
+    loss.backward()
+    gi, gd, ga = torch.empty_like(image), torch.empty(1, H, W, device=DEV), torch.empty(1, H, W, device=DEV)
+    out = torch.empty(4, device=DEV)
+    expo = torch.tensor([0.07, -0.03], device=DEV)
+    m8 = mask.reshape(H, W).to(torch.uint8).contiguous()
+    _lib.check(lib.gsr_tracking_loss(W, H, _p(image.detach()), _p(depth.detach()), _p(opacity), _p(gt), _p(gt_depth), _p(m8),
+                                     _p(expo), 0.99, 0.01, int(mono), _p(gi), _p(gd), _p(ga), _p(out),
+                                     torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert abs(out[0].item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))
+    assert torch.allclose(gi, image.grad, rtol=1e-5, atol=1e-9)
+    dref = depth.grad if depth.grad is not None else torch.zeros_like(gd)
+    assert torch.allclose(gd, dref, rtol=1e-5, atol=1e-9)
+    assert float(ga.abs().sum()) == 0.0
+    assert abs(out[1].item() - vp.exposure_a.grad.item()) <= 2e-5 * abs(vp.exposure_a.grad.item()) + 1e-8
+    assert abs(out[2].item() - vp.exposure_b.grad.item()) <= 2e-5 * abs(vp.exposure_b.grad.item()) + 1e-8
+
+
+def test_pose_step_matches_torch_adam_and_update_pose():
+    from gs_localization_amd import _lib, pipelines as PL
+    lib = _lib.load()
+    rng = np.random.default_rng(3)
+    proj = PL.getProjectionMatrix2(0.01, 100.0, 320, 240, 525, 525, 640, 480).transpose(0, 1).contiguous()
+    T0 = torch.tensor(S.se3_exp([0.3, -0.2, 0.5, 0.1, -0.3, 0.2]), dtype=torch.float32)
+    cam = PL.Camera(0, None, None, torch.eye(4), proj, 525, 525, 320, 240, 1.0, 1.0, 480, 640, device="cpu")
+    cam.update_RT(T0[:3, :3].clone(), T0[:3, 3].clone())
+    opt = PL.make_pose_optimizer(cam)
+    st = torch.zeros(_lib.POSE_STATE_FLOATS)
+    st[0:9] = T0[:3, :3].reshape(-1)
+    st[9:12] = T0[:3, 3]
+    state = st.to(DEV)
+    proj_d = proj.to(DEV)
+    stream = torch.cuda.current_stream().cuda_stream
+    _lib.check(lib.gsr_pose_init(_p(state), _p(proj_d), stream))
+    torch.cuda.synchronize()
+    assert torch.allclose(state[48:64].cpu().reshape(4, 4), cam.world_view_transform, atol=1e-7)
+    assert torch.allclose(state[64:80].cpu().reshape(4, 4), cam.full_proj_transform, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(state[80:83].cpu(), cam.camera_center, atol=1e-6)
+    for it in range(12):
+        scale = 10.0 ** rng.uniform(-6, 1)           # also drives |tau| below the 1e-4 threshold sometimes
+        g = (rng.normal(size=8) * scale).astype(np.float32)
+        cam.cam_rot_delta.grad = torch.tensor(g[0:3])
+        cam.cam_trans_delta.grad = torch.tensor(g[3:6])
+        cam.exposure_a.grad = torch.tensor(g[6:7])
+        cam.exposure_b.grad = torch.tensor(g[7:8])
+        with torch.no_grad():
+            opt.step()
+            conv = bool(PL.update_pose(cam, 1e-4))
+        dtau = torch.tensor(np.concatenate([g[3:6], g[0:3]]), device=DEV)          # [rho, theta]
+        lo = torch.tensor([0.5, g[6], g[7], 0.0], device=DEV)
+        _lib.check(lib.gsr_pose_step(_p(state), _p(dtau), _p(lo), _p(proj_d), 0.001, 1e-4, stream))
+        torch.cuda.synchronize()
+        s = state.cpu()
+        assert torch.allclose(s[0:9].reshape(3, 3), cam.R, atol=2e-6), it
+        assert torch.allclose(s[9:12], cam.T, atol=2e-6), it
+        assert abs(s[18].item() - cam.exposure_a.item()) < 1e-6 and abs(s[19].item() - cam.exposure_b.item()) < 1e-6
+        assert bool(s[37].item()) == conv, it
+        assert float(s[12:18].abs().sum()) == 0.0
+        assert torch.allclose(s[48:64].reshape(4, 4), cam.world_view_transform, atol=2e-6)
+
+
+def _setup(sc, seed=0):
+    from gs_localization_amd import pipelines as PL
+    W, H = sc.W, sc.H
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    proj = PL.getProjectionMatrix2(0.01, 100.0, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, W=W, H=H).transpose(0, 1).to(DEV)
+    fovx, fovy = PL.focal2fov(sc.fx, W), PL.focal2fov(sc.fy, H)
+    gt = torch.eye(4, device=DEV)
+
+    def view():
+        vp = PL.Camera(0, None, None, gt, proj, sc.fx, sc.fy, sc.cx, sc.cy, fovx, fovy, H, W, device=DEV)
+        with torch.no_grad():
+            pkg = PL.render(vp, model, PL.PipelineParams(), bg)
+        vp.original_image = pkg["render"].detach().clone()
+        vp.depth = pkg["depth"].detach()[0].clone()
+        vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=DEV)
+        return vp
+    rng = np.random.default_rng(seed)
+    dt = rng.normal(size=3); dt *= 0.02 / np.linalg.norm(dt)
+    dr = rng.normal(size=3); dr *= math.radians(1.0) / np.linalg.norm(dr)
+    init = torch.tensor(S.se3_exp(np.concatenate([dt, dr])), dtype=torch.float32, device=DEV)
+    return model, bg, view, init
+
+
+def test_native_loop_matches_python_loop_and_converges():
+    from gs_localization_amd import pipelines as PL
+    sc = S.small(P=20000, W=160, H=120, sh_degree=3, seed=5, scale_med=0.03)
+    model, bg, view, init = _setup(sc)
+    cfg = PL.TRACKING_CONFIG
+    for iters in (1, 8):
+        vp1, vp2 = view(), view()
+        R1, T1, _ = PL.gradient_decent(vp1, cfg, init[:3, :3].clone(), init[:3, 3].clone(), model, PL.PipelineParams(), bg, iters=iters)
+        fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+        R2, T2, info = fr.refine(vp2, cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=iters)
+        assert info["iters"] == iters
+        # every iteration moves each pose component by ~lr = 1e-3 (Adam); both loops must take the same path
+        assert torch.allclose(R1, R2, atol=2e-5), (iters, (R1 - R2).abs().max())
+        assert torch.allclose(T1, T2, atol=2e-5), (iters, (T1 - T2).abs().max())
+        assert abs(vp1.exposure_a.item() - vp2.exposure_a.item()) < 2e-5
+    # known answer (SURVEY 8(c) fixture 9): 2 cm / 1 deg off, 50 iterations bring the pose back
+    vp = view()
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV, gaussian_grads=False)
+    R, T, info = fr.refine(vp, cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=50)
+    te0, re0 = PL.pose_errors(np.eye(3), np.zeros(3), init[:3, :3].cpu().numpy(), init[:3, 3].cpu().numpy())
+    te, re = PL.pose_errors(np.eye(3), np.zeros(3), R.cpu().numpy(), T.cpu().numpy())
+    assert te < 0.5 * te0 and re < 0.5 * re0, (te0, re0, te, re)
+
+
+def test_native_loop_stops_on_convergence_like_reference():
+    from gs_localization_amd import pipelines as PL
+    sc = S.small(P=5000, W=96, H=64, sh_degree=1, seed=6, scale_med=0.05)
+    model, bg, view, init = _setup(sc)
+    vp = view()
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    eye = torch.eye(4, device=DEV)
+    # start AT the ground truth with a huge threshold: the first update_pose already reports convergence
+    R, T, info = fr.refine(vp, PL.TRACKING_CONFIG, eye[:3, :3].clone(), eye[:3, 3].clone(), bg, iters=20, converged_threshold=1.0)
+    assert info["converged"] and info["iters"] == 1
+    vp2 = view()
+    R2, T2, _ = PL.gradient_decent(vp2, PL.TRACKING_CONFIG, eye[:3, :3].clone(), eye[:3, 3].clone(), model, PL.PipelineParams(), bg, iters=20)
+    R3, T3, info3 = fr.refine(view(), PL.TRACKING_CONFIG, eye[:3, :3].clone(), eye[:3, 3].clone(), bg, iters=20, stop_on_converged=False)
+    assert info3["iters"] == 20
