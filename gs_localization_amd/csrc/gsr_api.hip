@@ -95,7 +95,7 @@ struct Carver {
 
 struct Geom {   // per-Gaussian state carried from forward to backward
     float* depths; float2* xy; float4* conic_op; float* rgb; float* cov3D; uint8_t* clamped;
-    uint32_t* tiles_touched; uint32_t* offsets; ushort4* rects; float* dL_dz; double* tau_acc;
+    uint32_t* tiles_touched; uint32_t* offsets; ushort4* rects; float* acc; double* tau_acc;
     uint32_t* depth_key; uint32_t* depth_key_sorted; uint32_t* order_in; uint32_t* order; uint32_t* tt_sorted;
     char* scan_tmp; size_t scan_bytes; char* dsort_tmp; size_t dsort_bytes;
 };
@@ -112,7 +112,7 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.tiles_touched = c.take<uint32_t>(n);
     g.offsets = c.take<uint32_t>(n);
     g.rects = c.take<ushort4>(n);
-    g.dL_dz = c.take<float>(n);
+    g.acc = c.take<float>(GSR_ACC_STRIDE * n);
     g.tau_acc = c.take<double>(8);
     g.depth_key = c.take<uint32_t>(n);
     g.depth_key_sorted = c.take<uint32_t>(n);
@@ -425,14 +425,8 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
 
     // accumulators of K7 (atomically summed); everything else is written exactly once by K8/K9
     ProfScope* psz = new ProfScope(K_BWD_ZERO, st);
-    HIPCHK(hipMemsetAsync(dL_dmean2D, 0, (size_t)P * 3 * sizeof(float), st));
-    HIPCHK(hipMemsetAsync(dL_dconic, 0, (size_t)P * 4 * sizeof(float), st));
-    HIPCHK(hipMemsetAsync(dL_dopacity, 0, (size_t)P * sizeof(float), st));
-    HIPCHK(hipMemsetAsync(dL_dcolor, 0, (size_t)P * 3 * sizeof(float), st));
-    if (pose_mode) {
-        HIPCHK(hipMemsetAsync(g.dL_dz, 0, (size_t)P * sizeof(float), st));
-        HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * sizeof(double), st));
-    }
+    HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
+    if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * sizeof(double), st));
     delete psz;
     const float* color_ptr = colors_precomp ? colors_precomp : g.rgb;
     ProfScope* psb = new ProfScope(K_RENDER_BWD, st);
@@ -440,14 +434,12 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
         hipLaunchKernelGGL(k_render_bwd<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
                            (const uint32_t*)b.vals, width, height, gx, ntiles, background, (const float2*)g.xy,
                            (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas,
-                           (const uint32_t*)im.n_contrib, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_dcolor, g.dL_dz);
+                           (const uint32_t*)im.n_contrib, dL_dpix, dL_ddepths, dL_dalphas, g.acc);
     else
         hipLaunchKernelGGL(k_render_bwd<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
                            (const uint32_t*)b.vals, width, height, gx, ntiles, background, (const float2*)g.xy,
                            (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas,
-                           (const uint32_t*)im.n_contrib, dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic,
-                           dL_dopacity, dL_dcolor, (float*)nullptr);
+                           (const uint32_t*)im.n_contrib, dL_dpix, dL_ddepths, dL_dalphas, g.acc);
     delete psb;
     LAUNCHCHK("k_render_bwd");
 
@@ -458,7 +450,8 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     pb.cov3D = cov3D_precomp ? cov3D_precomp : g.cov3D;
     pb.view = viewmatrix; pb.proj = projmatrix; pb.campos = campos;
     pb.fx = focal_x; pb.fy = focal_y; pb.tanx = tan_fovx; pb.tany = tan_fovy;
-    pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dcolor = dL_dcolor; pb.dL_dz = g.dL_dz;
+    pb.acc = g.acc;
+    pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale; pb.dL_drot = dL_drot;
     pb.pose = pose_mode ? 1 : 0; pb.tau_acc = g.tau_acc;
     {

@@ -381,6 +381,9 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
 // as ONE global atomic per (tile, splat, quantity) instead of one per (pixel, splat, quantity).
 // ---------------------------------------------------------------------------------------------
 #define GSR_NQ 10
+// packed per-Gaussian accumulator record of K7 (floats): 0-2 dL/dcolor, 3-4 dL/dmean2D, 5-7 dL/dconic (a,b,c),
+// 8 dL/dopacity, 9 dL/dz (pose package), 10-11 padding
+#define GSR_ACC_STRIDE 12
 struct BwdLDS {
     float4 a[GSR_BLOCK];
     float4 b[GSR_BLOCK];
@@ -397,9 +400,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
                                                           const float* __restrict__ rgb, const float* __restrict__ depths,
                                                           const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
                                                           const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
-                                                          const float* __restrict__ dL_dalphas, float* __restrict__ dL_dmean2D,
-                                                          float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-                                                          float* __restrict__ dL_dcolor, float* __restrict__ dL_dz)
+                                                          const float* __restrict__ dL_dalphas, float* __restrict__ acc)
 {
     __shared__ BwdLDS s;
     const int tile = xcd_remap(blockIdx.x, ntiles);
@@ -499,18 +500,12 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
             if (lane == 63) s.acc[j][GSR_NQ] = 1.f;   // touched flag
         }
         __syncthreads();
-        if (tid < n && s.acc[tid][GSR_NQ] != 0.f) {
-            const uint32_t id = __float_as_uint(s.b[tid].w);
-            atomicAdd(&dL_dcolor[3 * id], s.acc[tid][0]);
-            atomicAdd(&dL_dcolor[3 * id + 1], s.acc[tid][1]);
-            atomicAdd(&dL_dcolor[3 * id + 2], s.acc[tid][2]);
-            atomicAdd(&dL_dmean2D[3 * id], s.acc[tid][3]);
-            atomicAdd(&dL_dmean2D[3 * id + 1], s.acc[tid][4]);
-            atomicAdd(&dL_dconic[4 * id], s.acc[tid][5]);
-            atomicAdd(&dL_dconic[4 * id + 1], s.acc[tid][6]);
-            atomicAdd(&dL_dconic[4 * id + 3], s.acc[tid][7]);
-            atomicAdd(&dL_dopacity[id], s.acc[tid][8]);
-            if (POSE) atomicAdd(&dL_dz[id], s.acc[tid][9]);
+        // flush: one lane per (splat, quantity) so that a wave instruction adds runs of consecutive floats of
+        // the packed per-Gaussian records (GSR_ACC_STRIDE floats each) instead of 64 scattered rows
+        for (int e = tid; e < n * GSR_NQ; e += GSR_BLOCK) {
+            const int j = e / GSR_NQ, q = e - j * GSR_NQ;
+            const float val = s.acc[j][q];
+            if (val != 0.f) atomicAdd(&acc[(size_t)__float_as_uint(s.b[j].w) * GSR_ACC_STRIDE + q], val);
         }
     }
 }
@@ -526,7 +521,8 @@ struct PreBwdArgs {
     const float* scales; const float* rots; float mod; const float* cov3D;   // cov3D: precomp or geom state
     const float* view; const float* proj; const float* campos;
     float fx, fy, tanx, tany;
-    const float* dL_dmean2D; const float* dL_dconic; const float* dL_dcolor; const float* dL_dz;
+    const float* acc;                                     // packed K7 sums, GSR_ACC_STRIDE floats per Gaussian
+    float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;      // unpacked here, written once
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
     int pose; double* tau_acc;
 };
@@ -658,11 +654,25 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
     float tau[6] = {0, 0, 0, 0, 0, 0};
     const bool live = idx < a.P;
     const bool vis = live && a.radii[idx] > 0;
+    // the packed sums of K7; a Gaussian nobody blended has an all-zero record
+    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+    if (vis) {
+        const float4* rec = reinterpret_cast<const float4*>(a.acc + (size_t)idx * GSR_ACC_STRIDE);
+        r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+    }
+    if (live) {
+        a.dL_dcolor[3 * (size_t)idx] = r0.x; a.dL_dcolor[3 * (size_t)idx + 1] = r0.y; a.dL_dcolor[3 * (size_t)idx + 2] = r0.z;
+        a.dL_dmean2D[3 * (size_t)idx] = r0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = r1.x; a.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+        reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(r1.y, r1.z, 0.f, r1.w);
+        a.dL_dopacity[idx] = r2.x;
+    }
+    // zero colour gradient => zero SH gradient whatever the coefficients are: their row is not even read
+    const bool has_col = vis && (r0.x != 0.f || r0.y != 0.f || r0.z != 0.f);
     // SH rows in (and dL_dsh rows out) as coalesced block streams through LDS, see k_preprocess
     const bool staged = (a.shs != nullptr) && sh16_vector_ok(a.M, a.shs) &&
                         (a.dL_dsh == nullptr || (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u) == 0);
     if (staged) {
-        s_vis[tid] = vis ? 1 : 0;
+        s_vis[tid] = has_col ? 1 : 0;
         __syncthreads();
         const float4* src = reinterpret_cast<const float4*>(a.shs) + (size_t)blockIdx.x * GSR_BLOCK * GSR_SH16_ROW4;
 #pragma unroll
@@ -705,7 +715,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
 #pragma unroll
         for (int i = 0; i < 6; i++) cov6[i] = cov3D[i];
         const float3 mean = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
-        const float dcx = a.dL_dconic[4 * idx], dcy = a.dL_dconic[4 * idx + 1], dcz = a.dL_dconic[4 * idx + 3];
+        const float dcx = r1.y, dcy = r1.z, dcz = r1.w;
         Cov2DTerms ct;
         cov2d_terms(mean, a.fx, a.fy, a.tanx, a.tany, cov6, a.view, ct);
         const float limx = 1.3f * a.tanx, limy = 1.3f * a.tany;
@@ -772,7 +782,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
         const float m_w = 1.0f / (m_hom.w + 0.0000001f);
         const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
         const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-        const float g2x = a.dL_dmean2D[3 * idx], g2y = a.dL_dmean2D[3 * idx + 1];
+        const float g2x = r0.w, g2y = r1.x;
         float3 g_m2d;
         g_m2d.x = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
         g_m2d.y = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
@@ -781,19 +791,28 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
 
         float3 g_depth = make_float3(0.f, 0.f, 0.f);
         if (a.pose) {
-            const float dz = a.dL_dz[idx];
+            const float dz = r2.y;
             g_depth = make_float3(vm[2] * dz, vm[6] * dz, vm[10] * dz);
             dm0 += g_depth.x; dm1 += g_depth.y; dm2 += g_depth.z;
         }
         float3 g_sh = make_float3(0.f, 0.f, 0.f);
         if (a.shs) {
-            const float3 dcol = make_float3(a.dL_dcolor[3 * idx], a.dL_dcolor[3 * idx + 1], a.dL_dcolor[3 * idx + 2]);
-            if (staged)
-                g_sh = sh_backward(a.D, 16, mean, a.campos, my_row, a.clamped[idx], dcol, a.dL_dsh ? my_row : nullptr);
-            else
-                g_sh = sh_backward(a.D, a.M, mean, a.campos, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dcol,
-                                   a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
-            dm0 += g_sh.x; dm1 += g_sh.y; dm2 += g_sh.z;
+            if (has_col) {
+                const float3 dcol = make_float3(r0.x, r0.y, r0.z);
+                if (staged)
+                    g_sh = sh_backward(a.D, 16, mean, a.campos, my_row, a.clamped[idx], dcol, a.dL_dsh ? my_row : nullptr);
+                else
+                    g_sh = sh_backward(a.D, a.M, mean, a.campos, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dcol,
+                                       a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
+                dm0 += g_sh.x; dm1 += g_sh.y; dm2 += g_sh.z;
+            } else if (a.dL_dsh) {
+                if (staged) {
+#pragma unroll
+                    for (int i = 0; i < GSR_SH16_ROW4; i++) s_sh[tid * GSR_SH16_LDS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
+                    for (int i = 0; i < a.M * 3; i++) a.dL_dsh[(size_t)idx * a.M * 3 + i] = 0.f;
+                }
+            }
         }
         if (a.dL_dmean3D) {
             a.dL_dmean3D[3 * (size_t)idx] = dm0;
