@@ -44,6 +44,7 @@ def algorithmic_bytes(P, V, R, R_eff, N, M, ntiles):
         "bwd_zero": 0,
         "render_bwd": N * 24 + R_eff * 44 + R_eff * 36,
         "preprocess_bwd": V * (48 + 36) + P * (44 + 12 * M) + P * (40 + 12 * M),
+        "sh_color": 0,      # bytes are counted in preprocess_fwd (the colour half of the reference's K1)
         "depth_sort": 0,    # our own extra pass (sorting P Gaussians by depth); not part of the reference's byte model
     }
     return per, passes

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,9 +42,9 @@ int fail(int code, const char* fmt, const char* a = "", const char* b = "")
     } while (0)
 
 // ---- optional per-kernel HIP-event timing (gsr_profile_*) ----
-enum KernelId { K_PREPROCESS = 0, K_SCAN, K_EMIT, K_SORT, K_RANGES, K_RENDER_FWD, K_BWD_ZERO, K_RENDER_BWD, K_PREPROCESS_BWD, K_DEPTH_SORT, K_COUNT };
+enum KernelId { K_PREPROCESS = 0, K_SCAN, K_EMIT, K_SORT, K_RANGES, K_RENDER_FWD, K_BWD_ZERO, K_RENDER_BWD, K_PREPROCESS_BWD, K_DEPTH_SORT, K_SH_COLOR, K_COUNT };
 const char* const kKernelNames[K_COUNT] = {"preprocess_fwd", "scan", "emit", "sort", "ranges", "render_fwd",
-                                           "bwd_zero", "render_bwd", "preprocess_bwd", "depth_sort"};
+                                           "bwd_zero", "render_bwd", "preprocess_bwd", "depth_sort", "sh_color"};
 struct Profiler {
     std::mutex mu;
     unsigned mask = 0;
@@ -59,6 +60,7 @@ struct Profiler {
     }
 };
 Profiler g_prof;
+int g_ablate = 0;      // diagnostic builds only (gsr_debug_ablate): switches parts of k_render_bwd off
 struct ProfScope {
     int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
     ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on((g_prof.mask >> id_) & 1u)
@@ -175,6 +177,33 @@ int bits_for(uint32_t n)
     return b;
 }
 
+thread_local int g_dev = 0;      // device chosen by the last select_device_of on this thread
+
+// One side stream + a fork/join event pair per device: independent work (SH colours, zero fills) runs next to
+// the latency-bound sort chain / the VALU-bound backward compositing instead of in front of them.
+// Re-recording an event after a wait on it has been enqueued is safe (the wait binds to the record that
+// preceded it), so one pair per device is enough; a concurrent caller can at worst over-synchronise.
+struct Side {
+    hipStream_t st = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+};
+Side g_side[64];
+std::mutex g_side_mu;
+Side* get_side()
+{
+    static const bool disabled = getenv("GSR_NO_SIDE_STREAM") != nullptr;     // diagnostics
+    if (disabled) return nullptr;
+    if (g_dev < 0 || g_dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> l(g_side_mu);
+    Side& sd = g_side[g_dev];
+    if (!sd.st) {
+        if (hipStreamCreateWithFlags(&sd.st, hipStreamNonBlocking) != hipSuccess) { sd.st = nullptr; (void)hipGetLastError(); return nullptr; }
+        if (hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    }
+    return &sd;
+}
+
 int select_device_of(const void* p)
 {
     hipPointerAttribute_t attr;
@@ -184,6 +213,7 @@ int select_device_of(const void* p)
         return fail(GSR_E_NODEVICE, "means3D must live in device memory%s", "");
     e = hipSetDevice(attr.device);
     if (e != hipSuccess) return fail(GSR_E_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
+    g_dev = attr.device;
     return GSR_OK;
 }
 
@@ -192,6 +222,8 @@ int select_device_of(const void* p)
 extern "C" {
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
+
+int gsr_debug_ablate(int bits) { g_ablate = bits; return 0; }
 
 int gsr_profile_enable(unsigned mask)
 {
@@ -302,6 +334,20 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
         hipLaunchKernelGGL(k_preprocess, dim3(pblocks), dim3(GSR_BLOCK), 0, st, pa);
     }
     LAUNCHCHK("k_preprocess");
+    // SH colours only feed the compositing kernel: fork them onto the side stream, join before K6
+    Side* side = (colors_precomp == nullptr && !debug) ? get_side() : nullptr;
+    if (colors_precomp == nullptr) {
+        if (side) {
+            HIPCHK(hipEventRecord(side->fork, st));
+            HIPCHK(hipStreamWaitEvent(side->st, side->fork, 0));
+            hipLaunchKernelGGL(k_sh_color, dim3(pblocks), dim3(GSR_BLOCK), 0, side->st, pa);
+            HIPCHK(hipEventRecord(side->join, side->st));
+        } else {
+            ProfScope ps(K_SH_COLOR, st);
+            hipLaunchKernelGGL(k_sh_color, dim3(pblocks), dim3(GSR_BLOCK), 0, st, pa);
+        }
+        LAUNCHCHK("k_sh_color");
+    }
     {   // (1) Gaussians in (depth bits, index) order; culled ones carry key 0xFFFFFFFF and end up last
         ProfScope ps(K_DEPTH_SORT, st);
         HIPCHK(hipcub::DeviceRadixSort::SortPairs(g.dsort_tmp, g.dsort_bytes, g.depth_key, g.depth_key_sorted, g.order_in,
@@ -371,6 +417,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     }
     if (n_touched) HIPCHK(hipMemsetAsync(n_touched, 0, (size_t)P * sizeof(int), st));
     const float* feat = colors_precomp ? colors_precomp : g.rgb;
+    if (side) HIPCHK(hipStreamWaitEvent(st, side->join, 0));
     ProfScope* psr = new ProfScope(K_RENDER_FWD, st);
     if (n_touched)
         hipLaunchKernelGGL(k_render_fwd<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
@@ -423,7 +470,27 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     Bin b; carve_bin(binning_buffer, R, ntiles > 65536, b);
     Img im; carve_img(img_buffer, width, height, im);
 
-    // accumulators of K7 (atomically summed); everything else is written exactly once by K8/K9
+    // Gradient tensors are zero-filled on the side stream while K7 runs; K8/K9 then only writes non-zero rows.
+    Side* side = debug ? nullptr : get_side();
+    hipStream_t zs = side ? side->st : st;
+    if (side) {
+        HIPCHK(hipEventRecord(side->fork, st));
+        HIPCHK(hipStreamWaitEvent(side->st, side->fork, 0));
+    }
+    {
+        const size_t Pn = (size_t)P;
+        HIPCHK(hipMemsetAsync(dL_dmean2D, 0, Pn * 3 * sizeof(float), zs));
+        HIPCHK(hipMemsetAsync(dL_dconic, 0, Pn * 4 * sizeof(float), zs));
+        HIPCHK(hipMemsetAsync(dL_dopacity, 0, Pn * sizeof(float), zs));
+        HIPCHK(hipMemsetAsync(dL_dcolor, 0, Pn * 3 * sizeof(float), zs));
+        if (dL_dmean3D) HIPCHK(hipMemsetAsync(dL_dmean3D, 0, Pn * 3 * sizeof(float), zs));
+        if (dL_dcov3D) HIPCHK(hipMemsetAsync(dL_dcov3D, 0, Pn * 6 * sizeof(float), zs));
+        if (dL_dsh && M > 0) HIPCHK(hipMemsetAsync(dL_dsh, 0, Pn * M * 3 * sizeof(float), zs));
+        if (dL_dscale) HIPCHK(hipMemsetAsync(dL_dscale, 0, Pn * 3 * sizeof(float), zs));
+        if (dL_drot) HIPCHK(hipMemsetAsync(dL_drot, 0, Pn * 4 * sizeof(float), zs));
+    }
+    if (side) HIPCHK(hipEventRecord(side->join, side->st));
+    // accumulators of K7 (atomically summed)
     ProfScope* psz = new ProfScope(K_BWD_ZERO, st);
     HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
     if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * sizeof(double), st));
@@ -434,15 +501,16 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
         hipLaunchKernelGGL(k_render_bwd<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
                            (const uint32_t*)b.vals, width, height, gx, ntiles, background, (const float2*)g.xy,
                            (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas,
-                           (const uint32_t*)im.n_contrib, dL_dpix, dL_ddepths, dL_dalphas, g.acc);
+                           (const uint32_t*)im.n_contrib, dL_dpix, dL_ddepths, dL_dalphas, g.acc, g_ablate);
     else
         hipLaunchKernelGGL(k_render_bwd<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
                            (const uint32_t*)b.vals, width, height, gx, ntiles, background, (const float2*)g.xy,
                            (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas,
-                           (const uint32_t*)im.n_contrib, dL_dpix, dL_ddepths, dL_dalphas, g.acc);
+                           (const uint32_t*)im.n_contrib, dL_dpix, dL_ddepths, dL_dalphas, g.acc, g_ablate);
     delete psb;
     LAUNCHCHK("k_render_bwd");
 
+    if (side) HIPCHK(hipStreamWaitEvent(st, side->join, 0));
     PreBwdArgs pb;
     pb.P = P; pb.D = D; pb.M = M;
     pb.means = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = g.clamped;

@@ -130,8 +130,6 @@ __device__ __forceinline__ bool sh16_vector_ok(int M, const float* shs)
 
 __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 {
-    __shared__ float4 s_sh[GSR_BLOCK * GSR_SH16_LDS4];
-    __shared__ uint8_t s_vis[GSR_BLOCK];
     const int tid = threadIdx.x;
     const int idx = blockIdx.x * GSR_BLOCK + tid;
     const bool live = idx < a.P;
@@ -197,9 +195,20 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
             }
         }
     }
-    if (a.colors_pre != nullptr) return;     // block-uniform
+}
 
-    // ---- SH -> RGB (forward.cu:20-71), evaluated in the reference's summation order
+// SH -> RGB (forward.cu:20-71) as its own kernel: it only needs radii > 0 from the geometry pass, so the host
+// runs it on a side stream underneath the (latency-bound) sort chain and joins before compositing.
+// Summation order is the reference's; SH rows arrive as one coalesced stream per block (see above).
+__global__ void __launch_bounds__(GSR_BLOCK) k_sh_color(PreArgs a)
+{
+    __shared__ float4 s_sh[GSR_BLOCK * GSR_SH16_LDS4];
+    __shared__ uint8_t s_vis[GSR_BLOCK];
+    const int tid = threadIdx.x;
+    const int idx = blockIdx.x * GSR_BLOCK + tid;
+    const bool vis = idx < a.P && a.radii[idx] > 0;
+    float3 p = make_float3(0.f, 0.f, 0.f);
+    if (vis) p = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
     if (sh16_vector_ok(a.M, a.shs)) {
         s_vis[tid] = vis ? 1 : 0;
         __syncthreads();
@@ -289,10 +298,35 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_ranges(int L, const KeyT* __restr
 // One workgroup (4 waves) per 16x16 tile, one lane per pixel.  Batches of 256 splats are gathered
 // once into LDS (44 B each: xy, conic, opacity, rgb, depth, id) and broadcast-read by every lane.
 // ---------------------------------------------------------------------------------------------
+// Which of the tile's four 8x8 pixel blocks (= waves) a staged splat can change: bounding box of the ellipse
+// q <= ln(255 o) (+ the same 0.02 slack as the tile culling) against each block, widened by 0.01 px.
+// Bit w set <=> wave w must look at the splat.  Not positive definite => all four.
+__device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, float B, float C, float opacity, int X0, int Y0)
+{
+    const float det = A * C - B * B;
+    if (!(A > 0.f && C > 0.f && det > 0.f)) return 0xFu;
+    const float qmax = (opacity > 0.f) ? (__logf(255.f * opacity) + 0.02f) : -1.f;
+    if (qmax < 0.f) return 0u;
+    const float s2 = 2.f * qmax * __builtin_amdgcn_rcpf(det);
+    const float hx = __builtin_amdgcn_sqrtf(s2 * C) * 1.0001f + 0.01f;
+    const float hy = __builtin_amdgcn_sqrtf(s2 * A) * 1.0001f + 0.01f;
+    const float xl = mx - hx - (float)X0, xh = mx + hx - (float)X0;      // relative to the tile origin
+    const float yl = my - hy - (float)Y0, yh = my + hy - (float)Y0;
+    const uint32_t cx = ((xl <= 7.f && xh >= 0.f) ? 1u : 0u) | ((xl <= 15.f && xh >= 8.f) ? 2u : 0u);     // bit0: left, bit1: right
+    const uint32_t cy = ((yl <= 7.f && yh >= 0.f) ? 1u : 0u) | ((yl <= 15.f && yh >= 8.f) ? 2u : 0u);     // bit0: top, bit1: bottom
+    uint32_t m = 0;
+    if ((cx & 1u) && (cy & 1u)) m |= 1u;
+    if ((cx & 2u) && (cy & 1u)) m |= 2u;
+    if ((cx & 1u) && (cy & 2u)) m |= 4u;
+    if ((cx & 2u) && (cy & 2u)) m |= 8u;
+    return m;
+}
+
 struct SplatLDS {
     float4 a[GSR_BLOCK];   // x, y, conic.x, conic.y
     float4 b[GSR_BLOCK];   // conic.z, opacity, depth, id (bits)
-    float4 c[GSR_BLOCK];   // r, g, b, -
+    float4 c[GSR_BLOCK];   // r, g, b, quadrant mask (bits)
+    uint8_t list[4][GSR_BLOCK];   // per wave: staged splats that can touch its 8x8 block, in list order
 };
 
 template <bool TOUCHED>
@@ -318,9 +352,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
     const uint2 range = ranges[tile];
     const int total = (int)(range.y - range.x);
 
+    const int lane = tid & 63, wv = tid >> 6;
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f;
-    uint32_t contributor = 0, last_contributor = 0;
+    uint32_t last_contributor = 0;
 
     for (int base = 0; base < total; base += GSR_BLOCK) {
         if (__syncthreads_and(done)) break;
@@ -331,12 +366,22 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
             const float4 co = conic_op[id];
             s.a[tid] = make_float4(m.x, m.y, co.x, co.y);
             s.b[tid] = make_float4(co.z, co.w, depths[id], __uint_as_float(id));
-            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], 0.f);
+            const uint32_t qm = quadrant_mask(m.x, m.y, co.x, co.y, co.z, co.w, tx * GSR_TILE, ty * GSR_TILE);
+            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], __uint_as_float(qm));
         }
         __syncthreads();
-        for (int j = 0; j < n; j++) {
+        // this wave's compacted list (order preserved)
+        int cnt = 0;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int jj = c0 + lane;
+            const bool hit = jj < n && ((__float_as_uint(s.c[min(jj, GSR_BLOCK - 1)].w) >> wv) & 1u);
+            const unsigned long long mk = __ballot(hit);
+            if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
+            cnt += (int)__popcll(mk);
+        }
+        for (int k = 0; k < cnt; k++) {
             if (__all(done)) break;                // whole wave finished: stop early
-            contributor++;
+            const int j = __builtin_amdgcn_readfirstlane((int)s.list[wv][k]);
             const float4 A = s.a[j];
             const float4 B = s.b[j];
             const float dx = A.x - pxf, dy = A.y - pyf;
@@ -351,13 +396,13 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
                 C0 += Cc.x * w; C1 += Cc.y * w; C2 += Cc.z * w;
                 Dd += B.z * w;
                 T = test_T;
-                last_contributor = contributor;
+                last_contributor = (uint32_t)(base + j + 1);      // 1-based position in the tile list
             }
             if (TOUCHED) {
                 // pose package: count pixels where the splat was blended with T still > 0.5;
                 // one atomic per wave instead of one per pixel
                 const unsigned long long m = __ballot(valid && test_T > 0.5f);
-                if (m != 0ull && (tid & 63) == 0) atomicAdd(&n_touched[__float_as_uint(B.w)], (int)__popcll(m));
+                if (m != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(B.w)], (int)__popcll(m));
             }
         }
     }
@@ -390,6 +435,7 @@ struct BwdLDS {
     float4 c[GSR_BLOCK];
     float acc[GSR_BLOCK][GSR_NQ + 1];   // +1 pad: conflict-free column flush
     int wmax[4];
+    uint8_t list[4][GSR_BLOCK];         // per wave: staged splats its 8x8 block can see, in walk order
 };
 
 template <bool POSE>
@@ -400,7 +446,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
                                                           const float* __restrict__ rgb, const float* __restrict__ depths,
                                                           const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
                                                           const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
-                                                          const float* __restrict__ dL_dalphas, float* __restrict__ acc)
+                                                          const float* __restrict__ dL_dalphas, float* __restrict__ acc,
+                                                          int ablate)
 {
     __shared__ BwdLDS s;
     const int tile = xcd_remap(blockIdx.x, ntiles);
@@ -431,10 +478,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
     __syncthreads();
     const int total = max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3]));
 
+    const int wave_max = s.wmax[wv];            // deepest contributor among this wave's 64 pixels
     float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, adr = 0.f, aar = 0.f;
     float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-    int contributor = total;   // 1-based index (within the tile list) of the splat handled next
 
     for (int base = 0; base < total; base += GSR_BLOCK) {
         __syncthreads();
@@ -445,12 +492,27 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
             const float4 co = conic_op[id];
             s.a[tid] = make_float4(mm.x, mm.y, co.x, co.y);
             s.b[tid] = make_float4(co.z, co.w, depths[id], __uint_as_float(id));
-            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], 0.f);
+            const uint32_t qm = quadrant_mask(mm.x, mm.y, co.x, co.y, co.z, co.w, tx * GSR_TILE, ty * GSR_TILE);
+            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], __uint_as_float(qm));
         }
 #pragma unroll
         for (int q = 0; q < GSR_NQ + 1; q++) s.acc[tid][q] = 0.f;
         __syncthreads();
-        for (int j = 0; j < n; j++, contributor--) {
+        // this wave's compacted list: splats whose footprint reaches its block and that are not deeper than
+        // the deepest contributor of its pixels.  Entry j of the batch is position total - base - j (1-based).
+        int cnt = 0;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int jj = c0 + lane;
+            const bool hit = jj < n && ((__float_as_uint(s.c[min(jj, GSR_BLOCK - 1)].w) >> wv) & 1u) &&
+                             (total - base - jj) <= wave_max;
+            const unsigned long long mk = __ballot(hit);
+            if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
+            cnt += (int)__popcll(mk);
+        }
+        if (ablate & 8) cnt = 0;
+        for (int k = 0; k < cnt; k++) {
+            const int j = __builtin_amdgcn_readfirstlane((int)s.list[wv][k]);
+            const int contributor = total - base - j;
             const float4 A = s.a[j];
             const float4 B = s.b[j];
             const float dx = A.x - pxf, dy = A.y - pyf;
@@ -492,14 +554,18 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
                 v[7] = -0.5f * gdy * dy * dL_dG;
                 v[8] = G * dL_dopa;
             }
-            row_sum10_to_lane15(v);
-            if ((lane & 15) == 15) {
+            if (!(ablate & 2)) row_sum10_to_lane15(v);
+            else {
+#pragma unroll
+                for (int q = 0; q < GSR_NQ; q++) asm volatile("" ::"v"(v[q]));
+            }
+            if (!(ablate & 1) && (lane & 15) == 15) {
 #pragma unroll
                 for (int q = 0; q < (POSE ? GSR_NQ : GSR_NQ - 1); q++) atomicAdd(&s.acc[j][q], v[q]);
             }
-            if (lane == 63) s.acc[j][GSR_NQ] = 1.f;   // touched flag
         }
         __syncthreads();
+        if (ablate & 4) continue;
         // flush: one lane per (splat, quantity) so that a wave instruction adds runs of consecutive floats of
         // the packed per-Gaussian records (GSR_ACC_STRIDE floats each) instead of 64 scattered rows
         for (int e = tid; e < n * GSR_NQ; e += GSR_BLOCK) {
@@ -660,9 +726,11 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
         const float4* rec = reinterpret_cast<const float4*>(a.acc + (size_t)idx * GSR_ACC_STRIDE);
         r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
     }
-    if (live) {
+    // Every gradient tensor was zero-filled by the host on a side stream while K7 ran, so only rows that can
+    // be non-zero are written here: the ones of visible Gaussians (and SH rows only where colour gradient exists).
+    if (vis) {
         a.dL_dcolor[3 * (size_t)idx] = r0.x; a.dL_dcolor[3 * (size_t)idx + 1] = r0.y; a.dL_dcolor[3 * (size_t)idx + 2] = r0.z;
-        a.dL_dmean2D[3 * (size_t)idx] = r0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = r1.x; a.dL_dmean2D[3 * (size_t)idx + 2] = 0.f;
+        a.dL_dmean2D[3 * (size_t)idx] = r0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = r1.x;
         reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(r1.y, r1.z, 0.f, r1.w);
         a.dL_dopacity[idx] = r2.x;
     }
@@ -685,30 +753,6 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
     }
     float* my_row = reinterpret_cast<float*>(&s_sh[tid * GSR_SH16_LDS4]);
 
-    if (live && !vis) {
-        // invisible Gaussian: every gradient is zero, written explicitly (outputs are not pre-zeroed)
-        if (a.dL_dmean3D) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) a.dL_dmean3D[3 * (size_t)idx + i] = 0.f;
-        }
-        if (a.dL_dcov3D) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
-        }
-        if (a.dL_dsh) {
-            if (staged) {
-#pragma unroll
-                for (int i = 0; i < GSR_SH16_ROW4; i++) s_sh[tid * GSR_SH16_LDS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                for (int i = 0; i < a.M * 3; i++) a.dL_dsh[(size_t)idx * a.M * 3 + i] = 0.f;
-            }
-        }
-        if (a.dL_dscale) {
-#pragma unroll
-            for (int i = 0; i < 3; i++) a.dL_dscale[3 * (size_t)idx + i] = 0.f;
-        }
-        if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
     if (vis) {
         const float* cov3D = a.cov3D + 6 * (size_t)idx;
         float cov6[6];
@@ -805,13 +849,6 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
                     g_sh = sh_backward(a.D, a.M, mean, a.campos, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dcol,
                                        a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
                 dm0 += g_sh.x; dm1 += g_sh.y; dm2 += g_sh.z;
-            } else if (a.dL_dsh) {
-                if (staged) {
-#pragma unroll
-                    for (int i = 0; i < GSR_SH16_ROW4; i++) s_sh[tid * GSR_SH16_LDS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {
-                    for (int i = 0; i < a.M * 3; i++) a.dL_dsh[(size_t)idx * a.M * 3 + i] = 0.f;
-                }
             }
         }
         if (a.dL_dmean3D) {
@@ -830,9 +867,6 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
                 a.dL_dscale[3 * (size_t)idx] = ds[0]; a.dL_dscale[3 * (size_t)idx + 1] = ds[1]; a.dL_dscale[3 * (size_t)idx + 2] = ds[2];
             }
             if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
-        } else {
-            if (a.dL_dscale) { a.dL_dscale[3 * (size_t)idx] = 0.f; a.dL_dscale[3 * (size_t)idx + 1] = 0.f; a.dL_dscale[3 * (size_t)idx + 2] = 0.f; }
-            if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
 
         if (a.pose) {
@@ -895,7 +929,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
         for (int i = 0; i < GSR_SH16_ROW4; i++) {
             const int j = tid + GSR_BLOCK * i;
             const int g = j / GSR_SH16_ROW4;
-            if (g < nrows) dst[j] = s_sh[g * GSR_SH16_LDS4 + (j - g * GSR_SH16_ROW4)];
+            if (g < nrows && s_vis[g]) dst[j] = s_sh[g * GSR_SH16_LDS4 + (j - g * GSR_SH16_ROW4)];
         }
     }
     if (a.pose) {

@@ -216,6 +216,9 @@ int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
  * gsr_profile_collect waits for the recorded events, ADDS elapsed milliseconds / launch counts per
  * kernel id into ms[] / launches[] (arrays of gsr_profile_kernel_count() entries) and forgets them. */
 int gsr_profile_enable(unsigned mask);
+/* Diagnostics only (ablation timing, results become wrong): bit0 no LDS accumulation, bit1 no DPP
+ * reduction, bit2 no global flush, bit3 no splat loop in the backward compositing kernel.  0 = normal. */
+int gsr_debug_ablate(int bits);
 int gsr_profile_collect(double* ms, long long* launches);
 int gsr_profile_kernel_count(void);
 const char* gsr_profile_kernel_name(int id);

@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, f"{n} missing from the ctypes signature table"
     assert lib.gsr_abi_version() == 1
-    assert lib.gsr_profile_kernel_count() == 10
+    assert lib.gsr_profile_kernel_count() == 11
     assert lib.gsr_profile_kernel_name(3) == b"sort"
 
 
