@@ -21,9 +21,9 @@ from collections import defaultdict
 csv.field_size_limit(sys.maxsize)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-OURS = {"k_preprocess(": "preprocess_fwd", "k_preprocess_bwd": "preprocess_bwd", "k_emit": "emit", "k_ranges": "ranges",
-        "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd", "radix_sort_onesweep_iteration": "sort",
-        "radix_sort_onesweep_global_offsets": "sort", "radix_sort": "sort", "lookback_scan": "scan", "scan": "scan",
+OURS = {"k_preprocess(": "preprocess_fwd", "k_sh_color": "sh_color", "k_gather_counts": "scan", "k_tracking_loss": "tracking_loss",
+        "k_pose_step": "pose_step", "k_tau_finish": "pose_step", "k_preprocess_bwd": "preprocess_bwd", "k_emit": "emit", "k_ranges": "ranges",
+        "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd", "radix_sort": "sort(rocPRIM: depth + tile)", "lookback_scan": "scan", "scan": "scan",
         "k_tile_": "tile_sort", "k_bin": "bin", "k_loss": "loss", "k_pose": "pose_step"}
 
 
@@ -53,11 +53,13 @@ def main():
     ap.add_argument("--kt", required=True)
     ap.add_argument("--fetch")
     ap.add_argument("--write")
-    ap.add_argument("--iters", type=int, required=True, help="refinement iterations executed under the profiler")
+    ap.add_argument("--iters", type=int, default=0, help="refinement iterations under the profiler (default: k_render_bwd launches)")
     ap.add_argument("--cmd", default="")
     a = ap.parse_args()
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     rows = list(csv.DictReader(open(a.kt)))
+    if not a.iters:
+        a.iters = sum(int(r["Calls"]) for r in rows if "k_render_bwd" in r["Name"])
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     agg = defaultdict(lambda: [0, 0.0])
     for r in rows:
