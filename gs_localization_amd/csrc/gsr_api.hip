@@ -3,6 +3,7 @@
 // (reference: cuda_rasterizer/rasterizer_impl.cu:141-153,197-339,343-444).
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -79,6 +80,20 @@ struct ProfScope {
     }
 };
 
+// Depth sort of the P Gaussians (32-bit key, 32-bit index).  rocPRIM's default picks a merge sort below 2^20
+// items (1 block sort + 10 merge passes, ~160 us at P = 1 M on MI355X); Onesweep with 512x16-item blocks and
+// wave-match ranking measured 115 us (tools/micro/sort_bench2.hip), so that configuration is pinned here.
+using DepthSortConfig = rocprim::radix_sort_config<
+    rocprim::default_config, rocprim::default_config,
+    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 16>, rocprim::kernel_config<512, 16>, 8,
+                                        rocprim::block_radix_rank_algorithm::match>,
+    64 * 1024>;
+inline hipError_t depth_sort(void* tmp, size_t& bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
+                             uint32_t* vout, unsigned n, hipStream_t st)
+{
+    return rocprim::radix_sort_pairs<DepthSortConfig>(tmp, bytes, kin, kout, vin, vout, n, 0, 32, st);
+}
+
 // 256-byte aligned carving of an opaque workspace; with base == nullptr it only measures.
 struct Carver {
     char* base;
@@ -122,8 +137,7 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.order = c.take<uint32_t>(n);
     g.tt_sorted = c.take<uint32_t>(n);
     g.dsort_bytes = 0;
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, g.dsort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                             (uint32_t*)nullptr, (int)n);
+    (void)depth_sort(nullptr, g.dsort_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned)n, nullptr);
     g.dsort_tmp = c.take<char>(g.dsort_bytes);
     g.scan_bytes = 0;
     (void)hipcub::DeviceScan::InclusiveSum(nullptr, g.scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
@@ -350,8 +364,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     }
     {   // (1) Gaussians in (depth bits, index) order; culled ones carry key 0xFFFFFFFF and end up last
         ProfScope ps(K_DEPTH_SORT, st);
-        HIPCHK(hipcub::DeviceRadixSort::SortPairs(g.dsort_tmp, g.dsort_bytes, g.depth_key, g.depth_key_sorted, g.order_in,
-                                                  g.order, P, 0, 32, st));
+        HIPCHK(depth_sort(g.dsort_tmp, g.dsort_bytes, g.depth_key, g.depth_key_sorted, g.order_in, g.order, (unsigned)P, st));
     }
     {
         ProfScope ps(K_SCAN, st);
@@ -555,7 +568,8 @@ int gsr_tracking_loss(int width, int height, const float* image, const float* de
     la.depth_w = depth_weight; la.monocular = monocular; la.dL_dimage = dL_dimage; la.dL_ddepth = dL_ddepth;
     la.dL_dalpha = dL_dalpha; la.out = out;
     const int n = width * height;
-    hipLaunchKernelGGL(k_tracking_loss, dim3((n + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, la);
+    const int lblocks = (n + GSR_BLOCK - 1) / GSR_BLOCK;
+    hipLaunchKernelGGL(k_tracking_loss, dim3(lblocks < 256 ? lblocks : 256), dim3(GSR_BLOCK), 0, st, la);
     LAUNCHCHK("k_tracking_loss");
     return 0;
 }

@@ -251,6 +251,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_gather_counts(int P, const uint32
     if (k < P) tt_sorted[k] = tiles_touched[order[k]];
 }
 
+// Each lane expands its Gaussian into (tile key, index) instances.  A block's output range is contiguous
+// (the offsets are a prefix sum in block order), so the instances are first laid out in LDS and then leave
+// the block as coalesced stores; a block with more than GSR_EMIT_CAP instances writes directly.
+#define GSR_EMIT_CAP 3072
 template <typename KeyT>
 __global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t* __restrict__ order,
                                                            const uint32_t* __restrict__ offsets,
@@ -259,22 +263,37 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t
                                                            const float4* __restrict__ conic_op, int gx,
                                                            KeyT* __restrict__ keys, uint32_t* __restrict__ vals)
 {
-    const int k = blockIdx.x * GSR_BLOCK + threadIdx.x;
-    if (k >= P) return;
-    if (tt_sorted[k] == 0) return;
-    const uint32_t idx = order[k];
-    uint32_t off = (k == 0) ? 0 : offsets[k - 1];
-    const ushort4 r = rects[idx];
-    const float4 co = conic_op[idx];
-    const TileTest tt = make_tile_test(xy[idx], make_float3(co.x, co.y, co.z), co.w);
-    for (int y = r.y; y < r.w; y++) {
-        int lo, hi;
-        row_span(tt, y, r.x, r.z, lo, hi);
-        for (int x = lo; x <= hi; x++) {
-            keys[off] = (KeyT)(y * gx + x);
-            vals[off] = idx;
-            off++;
+    __shared__ uint32_t s_val[GSR_EMIT_CAP];
+    __shared__ KeyT s_key[GSR_EMIT_CAP];
+    const int k0 = blockIdx.x * GSR_BLOCK;
+    const int k = k0 + threadIdx.x;
+    const int klast = min(k0 + GSR_BLOCK, P) - 1;
+    const uint32_t block_base = (k0 == 0) ? 0u : offsets[k0 - 1];
+    const uint32_t block_total = offsets[klast] - block_base;
+    if (block_total == 0) return;
+    const bool staged = block_total <= GSR_EMIT_CAP;
+    if (k < P && tt_sorted[k] != 0) {
+        const uint32_t idx = order[k];
+        uint32_t off = (k == 0) ? 0u : offsets[k - 1];
+        const ushort4 r = rects[idx];
+        const float4 co = conic_op[idx];
+        const TileTest tt = make_tile_test(xy[idx], make_float3(co.x, co.y, co.z), co.w);
+        if (staged) off -= block_base;
+        for (int y = r.y; y < r.w; y++) {
+            int lo, hi;
+            row_span(tt, y, r.x, r.z, lo, hi);
+            for (int x = lo; x <= hi; x++) {
+                if (staged) { s_key[off] = (KeyT)(y * gx + x); s_val[off] = idx; }
+                else { keys[off] = (KeyT)(y * gx + x); vals[off] = idx; }
+                off++;
+            }
         }
+    }
+    if (!staged) return;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < block_total; i += GSR_BLOCK) {
+        keys[block_base + i] = s_key[i];
+        vals[block_base + i] = s_val[i];
     }
 }
 
@@ -972,13 +991,13 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_tracking_loss(LossArgs a)
 {
     __shared__ float s_red[4][3];
     const int n = a.W * a.H;
-    const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
     const float ea = expf(a.exposure[0]), eb = a.exposure[1];
+    const float inv3n = 1.f / (3.f * (float)n), invn = 1.f / (float)n;
     float l = 0.f, da = 0.f, db = 0.f;
-    if (i < n) {
+    // grid-stride: few blocks, so that the three result words see few same-address atomics
+    for (int i = blockIdx.x * GSR_BLOCK + threadIdx.x; i < n; i += gridDim.x * GSR_BLOCK) {
         const bool om = a.opacity[i] > a.opacity_thr;
         const float gm = a.grad_mask[i] ? 1.f : 0.f;
-        const float inv3n = 1.f / (3.f * (float)n);
         const float w = om ? gm : 0.f;
 #pragma unroll
         for (int c = 0; c < 3; c++) {
@@ -995,7 +1014,6 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_tracking_loss(LossArgs a)
             const float gd = a.gt_depth[i];
             const float dm = (gd > 0.01f && om) ? gm : 0.f;
             const float dd = a.depth[i] * dm - gd * dm;
-            const float invn = 1.f / (float)n;
             l += a.depth_w * fabsf(dd) * invn;
             gdp = a.depth_w * dm * sgnf(dd) * invn;
         }
