@@ -191,6 +191,9 @@ int bits_for(uint32_t n)
     return b;
 }
 
+// set by gsr_refine around its calls: the forward zero-fills the K7 accumulators on the side stream (so the
+// backward need not), and the backward leaves the final dL/dtau conversion to the fused pose step
+thread_local bool tl_native_loop = false;
 thread_local int g_dev = 0;      // device chosen by the last select_device_of on this thread
 
 // One side stream + a fork/join event pair per device: independent work (SH colours, zero fills) runs next to
@@ -355,10 +358,12 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
             HIPCHK(hipEventRecord(side->fork, st));
             HIPCHK(hipStreamWaitEvent(side->st, side->fork, 0));
             hipLaunchKernelGGL(k_sh_color, dim3(pblocks), dim3(GSR_BLOCK), 0, side->st, pa);
+            if (tl_native_loop) HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), side->st));
             HIPCHK(hipEventRecord(side->join, side->st));
         } else {
             ProfScope ps(K_SH_COLOR, st);
             hipLaunchKernelGGL(k_sh_color, dim3(pblocks), dim3(GSR_BLOCK), 0, st, pa);
+            if (tl_native_loop) HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
         }
         LAUNCHCHK("k_sh_color");
     }
@@ -505,7 +510,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     if (side) HIPCHK(hipEventRecord(side->join, side->st));
     // accumulators of K7 (atomically summed)
     ProfScope* psz = new ProfScope(K_BWD_ZERO, st);
-    HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
+    if (!tl_native_loop) HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
     if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * sizeof(double), st));
     delete psz;
     const float* color_ptr = colors_precomp ? colors_precomp : g.rgb;
@@ -540,7 +545,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
         hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, pb);
     }
     LAUNCHCHK("k_preprocess_bwd");
-    if (pose_mode) {
+    if (pose_mode && !tl_native_loop) {
         hipLaunchKernelGGL(k_tau_finish, dim3(1), dim3(64), 0, st, (const double*)g.tau_acc, dL_dtau);
         LAUNCHCHK("k_tau_finish");
     }
@@ -594,8 +599,8 @@ int gsr_pose_step(float* pose_state, const float* dL_dtau, const float* loss_out
     if (!pose_state || !dL_dtau || !loss_out || !projmatrix_raw) return fail(GSR_E_INVALID, "gsr_pose_step: NULL pointer%s", "");
     int rc = select_device_of(pose_state);
     if (rc != GSR_OK) return rc;
-    hipLaunchKernelGGL(gsr::k_pose_step, dim3(1), dim3(64), 0, st, pose_state, dL_dtau, loss_out, projmatrix_raw, lr,
-                       converged_threshold);
+    hipLaunchKernelGGL(gsr::k_pose_step, dim3(1), dim3(64), 0, st, pose_state, dL_dtau, (const double*)nullptr,
+                       (float*)nullptr, loss_out, projmatrix_raw, lr, converged_threshold);
     LAUNCHCHK("k_pose_step");
     return 0;
 }
@@ -634,6 +639,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     *iters_done = 0;
     *converged = 0;
     h_f[0] = 0.f;
+    struct FlagGuard { FlagGuard() { tl_native_loop = true; } ~FlagGuard() { tl_native_loop = false; } } guard;
+    const int debug = 0;
     for (int it = 0; it < a->max_iters; it++) {
         // convergence flag of the previous iteration: async copy, completed by gsr_forward's num_rendered sync
         HIPCHK(hipMemcpyAsync(h_f, ps + GSR_PS_CONV, sizeof(float), hipMemcpyDeviceToHost, st));
@@ -653,8 +660,12 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                           a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor,
                           a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, 0, 1, a->dL_dtau, a->stream);
         if (rc < 0) return rc;
-        rc = gsr_pose_step(ps, a->dL_dtau, a->loss_out, a->projmatrix_raw, a->lr, a->converged_threshold, a->stream);
-        if (rc < 0) return rc;
+        {   // Adam + update_pose; also finishes the fp64 dL/dtau reduction left open by the backward
+            Geom gg; carve_geom((char*)gb.ptr, a->P, gg);
+            hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(64), 0, st, ps, (const float*)a->dL_dtau, (const double*)gg.tau_acc,
+                               a->dL_dtau, (const float*)a->loss_out, a->projmatrix_raw, a->lr, a->converged_threshold);
+            LAUNCHCHK("k_pose_step");
+        }
         *iters_done = it + 1;
     }
     if (!*converged && a->stop_on_converged) {

@@ -1078,11 +1078,16 @@ __global__ void k_pose_init(float* st, const float* proj_raw)
 // Adam (torch.optim.Adam defaults, one lr for the four groups of 7scenes_localize_full_dslam.py:33-64) on
 // [rot(3), trans(3), exposure_a, exposure_b], then update_pose (tools/pose_utils.py:54-122):
 // T_w2c <- SE3_exp([trans, rot]) T_w2c, deltas <- 0, converged = |tau| < threshold.
-__global__ void k_pose_step(float* st, const float* dL_dtau, const float* loss_out, const float* proj_raw, float lr,
-                            float conv_thr)
+// tau_acc (nullable): the fp64 block sums of K8/K9; when given, this kernel also finishes the dL/dtau
+// reduction (writes dL_dtau_out) so that the separate k_tau_finish launch is not needed in the native loop.
+__global__ void k_pose_step(float* st, const float* dL_dtau, const double* tau_acc, float* dL_dtau_out,
+                            const float* loss_out, const float* proj_raw, float lr, float conv_thr)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float g[8] = {dL_dtau[3], dL_dtau[4], dL_dtau[5], dL_dtau[0], dL_dtau[1], dL_dtau[2], loss_out[1], loss_out[2]};
+    float t6[6];
+    for (int i = 0; i < 6; i++) t6[i] = tau_acc ? (float)tau_acc[i] : dL_dtau[i];
+    if (tau_acc && dL_dtau_out) for (int i = 0; i < 6; i++) dL_dtau_out[i] = t6[i];
+    float g[8] = {t6[3], t6[4], t6[5], t6[0], t6[1], t6[2], loss_out[1], loss_out[2]};
     const float step = st[GSR_PS_STEP] + 1.f;
     st[GSR_PS_STEP] = step;
     const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
