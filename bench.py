@@ -194,6 +194,14 @@ def main():
         elapsed, elapsed_py = float(t[0].item()), float(t[1].item())
 
     # ---- pose error of a full 50-iteration refinement (untimed), gathered over ranks
+    timed_info = fr.last_info
+    # per-kernel breakdown of the native loop (separate short run, every kernel bracketed)
+    reset()
+    lib.gsr_profile_enable((1 << nk) - 1)
+    fr.refine(vp, config, init[:3, :3].clone(), init[:3, 3].clone(), background, iters=20, stop_on_converged=False)
+    torch.cuda.synchronize()
+    native_ms = {k: round(v[0] / v[1], 4) if v[1] else 0.0 for k, v in collect().items()}
+    lib.gsr_profile_enable(0)
     reset()
     Rr, Tt, _ = fr.refine(vp, config, init[:3, :3].clone(), init[:3, 3].clone(), background, iters=50)
     te, re = PL.pose_errors(w2c_gt[:3, :3], w2c_gt[:3, 3], Rr.detach().cpu().numpy(), Tt.detach().cpu().numpy())
@@ -230,12 +238,14 @@ def main():
                        "R_eff_own_binning": R_eff_culled, "sort_passes": passes,
                        "algorithmic_bytes_per_iter": total_bytes, "frames_per_rank": 1,
                        "gaussian_grads": not args.pose_only, "parallelism": f"frames x{world}",
-                       "loop": "native gsr_refine (render, tracking loss, backward, Adam, update_pose per iteration)"},
+                       "loop": "native gsr_refine (render, tracking loss, backward, Adam, update_pose per iteration)",
+                       "speculative_binning": {"redone_forwards": timed_info["fallbacks"], "num_rendered_last": timed_info["num_rendered"]}},
             "python_loop_iters_per_s": world * args.steps / elapsed_py,
             "pose_err_cm_median": 100.0 * float(np.median(res[:, 1])),
             "pose_err_deg_median": float(np.median(res[:, 2])),
             "pose_err_init_cm_deg": [100.0 * te0, re0],
             "kernels_ms": {k: round(v, 4) for k, v in kernels_ms.items()},
+            "native_loop_kernels_ms": native_ms,
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_kernel_bytes[dominant], "avg_launch_ms": dom_avg_ms,

@@ -147,6 +147,7 @@ size_t carve_geom(char* base, int P, Geom& g)
 
 struct Img {
     uint32_t* n_contrib; uint2* ranges;
+    float* zb[2]; uint32_t* trunc; uint32_t* fail;      // speculative depth bounds of the native loop
 };
 size_t carve_img(char* base, int W, int H, Img& im)
 {
@@ -154,6 +155,10 @@ size_t carve_img(char* base, int W, int H, Img& im)
     const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
     im.n_contrib = c.take<uint32_t>((size_t)W * H);
     im.ranges = c.take<uint2>((size_t)gx * gy);
+    im.zb[0] = c.take<float>((size_t)gx * gy);
+    im.zb[1] = c.take<float>((size_t)gx * gy);
+    im.trunc = c.take<uint32_t>((size_t)gx * gy);
+    im.fail = c.take<uint32_t>(4);
     return c.size();
 }
 
@@ -194,6 +199,10 @@ int bits_for(uint32_t n)
 // set by gsr_refine around its calls: the forward zero-fills the K7 accumulators on the side stream (so the
 // backward need not), and the backward leaves the final dL/dtau conversion to the fused pose step
 thread_local bool tl_native_loop = false;
+// Speculative per-tile depth bounds (native loop only): mode 0 = off, 1 = bin with the bounds the previous
+// iteration recorded and record new ones, 2 = bin everything but record bounds.  parity picks the buffer.
+struct SpecCtx { int mode = 0; int parity = 0; float mul = 1.05f, add = 0.05f; };
+thread_local SpecCtx tl_spec;
 thread_local int g_dev = 0;      // device chosen by the last select_device_of on this thread
 
 // One side stream + a fork/join event pair per device: independent work (SH colours, zero fills) runs next to
@@ -346,6 +355,13 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     pa.radii = radii; pa.xy = g.xy; pa.depths = g.depths; pa.cov3D = g.cov3D; pa.rgb = g.rgb; pa.conic_op = g.conic_op;
     pa.clamped = g.clamped; pa.tiles_touched = g.tiles_touched; pa.rects = g.rects;
     pa.depth_key = g.depth_key; pa.order_in = g.order_in;
+    const float* zb_prev = (tl_spec.mode == 1) ? im.zb[tl_spec.parity ^ 1] : nullptr;
+    float* zb_next = (tl_spec.mode != 0) ? im.zb[tl_spec.parity] : nullptr;
+    pa.zb = zb_prev; pa.trunc = zb_prev ? im.trunc : nullptr;
+    if (tl_spec.mode != 0) {
+        HIPCHK(hipMemsetAsync(im.trunc, 0, (size_t)ntiles * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(im.fail, 0, 4 * sizeof(uint32_t), st));
+    }
     {
         ProfScope ps(K_PREPROCESS, st);
         hipLaunchKernelGGL(k_preprocess, dim3(pblocks), dim3(GSR_BLOCK), 0, st, pa);
@@ -401,7 +417,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
                 ProfScope ps(K_EMIT, st);
                 hipLaunchKernelGGL(k_emit_sorted<uint32_t>, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
                                    (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
-                                   (const float2*)g.xy, (const float4*)g.conic_op, gx, (uint32_t*)b.keys_unsorted, b.vals_unsorted);
+                                   (const float2*)g.xy, (const float4*)g.conic_op, gx, zb_prev, (const float*)g.depths, (uint32_t*)b.keys_unsorted, b.vals_unsorted);
             }
             LAUNCHCHK("k_emit_sorted");
             {
@@ -418,7 +434,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
                 ProfScope ps(K_EMIT, st);
                 hipLaunchKernelGGL(k_emit_sorted<uint16_t>, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
                                    (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
-                                   (const float2*)g.xy, (const float4*)g.conic_op, gx, (uint16_t*)b.keys_unsorted, b.vals_unsorted);
+                                   (const float2*)g.xy, (const float4*)g.conic_op, gx, zb_prev, (const float*)g.depths, (uint16_t*)b.keys_unsorted, b.vals_unsorted);
             }
             LAUNCHCHK("k_emit_sorted");
             {   // (3) stable sort on the tile bits only
@@ -441,12 +457,14 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
         hipLaunchKernelGGL(k_render_fwd<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
                            (const uint32_t*)b.vals, width, height, gx, ntiles, (const float2*)g.xy, feat,
                            (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha,
-                           im.n_contrib, n_touched);
+                           im.n_contrib, n_touched, zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), im.fail,
+                           tl_spec.mul, tl_spec.add);
     else
         hipLaunchKernelGGL(k_render_fwd<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
                            (const uint32_t*)b.vals, width, height, gx, ntiles, (const float2*)g.xy, feat,
                            (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha,
-                           im.n_contrib, (int*)nullptr);
+                           im.n_contrib, (int*)nullptr, zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), im.fail,
+                           tl_spec.mul, tl_spec.add);
     delete psr;
     LAUNCHCHK("k_render_fwd");
     return R;
@@ -639,17 +657,41 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     *iters_done = 0;
     *converged = 0;
     h_f[0] = 0.f;
-    struct FlagGuard { FlagGuard() { tl_native_loop = true; } ~FlagGuard() { tl_native_loop = false; } } guard;
+    struct FlagGuard { FlagGuard() { tl_native_loop = true; } ~FlagGuard() { tl_native_loop = false; tl_spec.mode = 0; } } guard;
+    int n_fallbacks = 0, last_R = 0;
     const int debug = 0;
     for (int it = 0; it < a->max_iters; it++) {
         // convergence flag of the previous iteration: async copy, completed by gsr_forward's num_rendered sync
         HIPCHK(hipMemcpyAsync(h_f, ps + GSR_PS_CONV, sizeof(float), hipMemcpyDeviceToHost, st));
-        int R = gsr_forward(cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
-                            a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
-                            a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
-                            a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, a->n_touched, a->stream);
-        if (R < 0) return R;
-        if (it > 0 && a->stop_on_converged && h_f[0] != 0.f) { *converged = 1; break; }   // reference: `if converged: break`
+        auto fwd = [&]() {
+            return gsr_forward(cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
+                               a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
+                               a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
+                               a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, a->n_touched, a->stream);
+        };
+        // Speculative binning: from the second iteration on, instances lying behind what their tile needed in
+        // the previous iteration (x margin) are not binned; the compositing kernel verifies the speculation and
+        // a failed one is redone with complete lists, so results never depend on it.
+        tl_spec.mode = a->speculative ? ((it == 0) ? 2 : 1) : 0;
+        tl_spec.parity = it & 1;
+        if (a->bound_margin_mul > 0.f) { tl_spec.mul = a->bound_margin_mul; tl_spec.add = a->bound_margin_add; }
+        int R = fwd();
+        if (R < 0) { tl_spec.mode = 0; return R; }
+        if (it > 0 && a->stop_on_converged && h_f[0] != 0.f) { *converged = 1; tl_spec.mode = 0; break; }   // reference: `if converged: break`
+        if (tl_spec.mode == 1) {
+            Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
+            uint32_t* h_fail = reinterpret_cast<uint32_t*>(h_flag) + 2;
+            HIPCHK(hipMemcpyAsync(h_fail, imv.fail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (*h_fail != 0u) {
+                n_fallbacks++;
+                tl_spec.mode = 2;
+                R = fwd();
+                if (R < 0) { tl_spec.mode = 0; return R; }
+            }
+        }
+        tl_spec.mode = 0;
+        last_R = R;
         rc = gsr_tracking_loss(a->width, a->height, a->out_color, a->out_depth, a->out_alpha, a->gt_image, a->gt_depth,
                                a->grad_mask, ps + GSR_PS_PARAM + 6, a->opacity_threshold, a->depth_weight, a->monocular,
                                a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->loss_out, a->stream);
@@ -668,6 +710,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         }
         *iters_done = it + 1;
     }
+    if (a->stats_out) { a->stats_out[0] = n_fallbacks; a->stats_out[1] = last_R; }
     if (!*converged && a->stop_on_converged) {
         HIPCHK(hipMemcpyAsync(h_f, ps + GSR_PS_CONV, sizeof(float), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));

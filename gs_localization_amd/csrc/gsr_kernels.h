@@ -74,6 +74,7 @@ __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int 
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
     uint32_t* depth_key; uint32_t* order_in;
+    const float* zb; uint32_t* trunc;      // speculative per-tile depth bounds of the native loop (nullable)
     const float* means; const float* scales; float mod; const float* rots; const float* opac;
     const float* shs; const float* cov3D_pre; const float* colors_pre;
     const float* view; const float* proj; const float* campos;
@@ -187,7 +188,13 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                     for (int y = y0; y < y1; y++) {
                         int lo, hi;
                         row_span(tt, y, x0, x1, lo, hi);
-                        cnt += (uint32_t)max(0, hi - lo + 1);
+                        if (a.zb == nullptr) cnt += (uint32_t)max(0, hi - lo + 1);
+                        else
+                            for (int x = lo; x <= hi; x++) {
+                                // behind everything this tile needed last iteration (+ margin): speculatively dropped
+                                if (pview.z <= a.zb[y * a.gx + x]) cnt++;
+                                else a.trunc[y * a.gx + x] = 1u;
+                            }
                     }
                     a.tiles_touched[idx] = cnt;
                     if (cnt) a.depth_key[idx] = __float_as_uint(pview.z);
@@ -261,6 +268,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t
                                                            const uint32_t* __restrict__ tt_sorted,
                                                            const ushort4* __restrict__ rects, const float2* __restrict__ xy,
                                                            const float4* __restrict__ conic_op, int gx,
+                                                           const float* __restrict__ zb, const float* __restrict__ depths,
                                                            KeyT* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     __shared__ uint32_t s_val[GSR_EMIT_CAP];
@@ -278,11 +286,13 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t
         const ushort4 r = rects[idx];
         const float4 co = conic_op[idx];
         const TileTest tt = make_tile_test(xy[idx], make_float3(co.x, co.y, co.z), co.w);
+        const float z = zb ? depths[idx] : 0.f;
         if (staged) off -= block_base;
         for (int y = r.y; y < r.w; y++) {
             int lo, hi;
             row_span(tt, y, r.x, r.z, lo, hi);
             for (int x = lo; x <= hi; x++) {
+                if (zb && !(z <= zb[y * gx + x])) continue;      // same test as the count in k_preprocess
                 if (staged) { s_key[off] = (KeyT)(y * gx + x); s_val[off] = idx; }
                 else { keys[off] = (KeyT)(y * gx + x); vals[off] = idx; }
                 off++;
@@ -356,9 +366,12 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
                                                           const float4* __restrict__ conic_op, const float* __restrict__ bg,
                                                           float* __restrict__ out_color, float* __restrict__ out_depth,
                                                           float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-                                                          int* __restrict__ n_touched)
+                                                          int* __restrict__ n_touched, float* __restrict__ zb_next,
+                                                          const uint32_t* __restrict__ trunc, uint32_t* __restrict__ fail,
+                                                          float margin_mul, float margin_add)
 {
     __shared__ SplatLDS s;
+    __shared__ float s_zmax[4];
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x;
@@ -375,6 +388,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f;
     uint32_t last_contributor = 0;
+    float zneed = 0.f;        // depth of the last list entry this pixel had to look at
 
     for (int base = 0; base < total; base += GSR_BLOCK) {
         if (__syncthreads_and(done)) break;
@@ -403,6 +417,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
             const int j = __builtin_amdgcn_readfirstlane((int)s.list[wv][k]);
             const float4 A = s.a[j];
             const float4 B = s.b[j];
+            if (!done) zneed = B.z;
             const float dx = A.x - pxf, dy = A.y - pyf;
             const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
             const float alpha = fminf(0.99f, B.y * __expf(power));
@@ -423,6 +438,22 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
                 const unsigned long long m = __ballot(valid && test_T > 0.5f);
                 if (m != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(B.w)], (int)__popcll(m));
             }
+        }
+    }
+    if (zb_next != nullptr) {
+        // Native loop bookkeeping: how deep did this tile have to look?  Next iteration's binning drops what
+        // lies behind that (plus a margin); if a pixel is still unsaturated at the end of a list from which
+        // entries were dropped, the speculation failed and the host redoes this forward with full lists.
+        const int unfinished = __syncthreads_or(inside && !done);
+        float zm = inside ? zneed : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) zm = fmaxf(zm, __shfl_xor(zm, off, 64));
+        if (lane == 0) s_zmax[wv] = zm;
+        __syncthreads();
+        if (tid == 0) {
+            zm = fmaxf(fmaxf(s_zmax[0], s_zmax[1]), fmaxf(s_zmax[2], s_zmax[3]));
+            zb_next[tile] = unfinished ? __builtin_huge_valf() : zm * margin_mul + margin_add;
+            if (unfinished && trunc != nullptr && trunc[tile] != 0u) atomicAdd(fail, 1u);
         }
     }
     if (inside) {

@@ -340,9 +340,12 @@ class FusedRefiner:
         self.ws = [_Workspace(dev), _Workspace(dev), _Workspace(dev)]
 
     def refine(self, viewpoint, config, initial_R, initial_T, background, iters=50, lr=0.001, converged_threshold=1e-4,
-               stop_on_converged=True):
+               stop_on_converged=True, speculative=False, bound_margin=(1.05, 0.05)):
         C, _lib = self._C, self._lib_mod
         dev = self.dev
+        # speculative=True: experimental exact optimisation (include/gsr.h, gsr_refine_args.speculative).  It cuts
+        # the binned instances ~9x on S-1M-640 but, with the per-Gaussian passes still running over all P and
+        # one more host sync per iteration, it measured 1142 vs 1225 it/s on MI355X -- hence off by default.
         viewpoint.update_RT(initial_R, initial_T)
         st = torch.zeros(_lib.POSE_STATE_FLOATS, dtype=torch.float32)
         st[0:9] = viewpoint.R.detach().float().cpu().reshape(-1)
@@ -383,6 +386,10 @@ class FusedRefiner:
         a.geometry_buffer, a.binning_buffer, a.image_buffer = self.ws[0].fn, self.ws[1].fn, self.ws[2].fn
         a.lr, a.converged_threshold, a.max_iters = float(lr), float(converged_threshold), int(iters)
         a.stop_on_converged = int(bool(stop_on_converged))
+        a.speculative = int(bool(speculative))
+        a.bound_margin_mul, a.bound_margin_add = float(bound_margin[0]), float(bound_margin[1])
+        stats = (C.c_int * 2)()
+        a.stats_out = stats
         a.stream = stream
         n_done, conv = C.c_int(0), C.c_int(0)
         with torch.cuda.device(dev):
@@ -394,7 +401,9 @@ class FusedRefiner:
         with torch.no_grad():
             viewpoint.exposure_a.fill_(float(s[18]))
             viewpoint.exposure_b.fill_(float(s[19]))
+        self.last_info = {"fallbacks": int(stats[0]), "num_rendered": int(stats[1])}
         return viewpoint.R, viewpoint.T, {"iters": n_done.value, "converged": bool(conv.value), "loss": float(s[38]),
+                                          "fallbacks": int(stats[0]), "num_rendered": int(stats[1]),
                                           "render": self.color, "depth": self.depth, "opacity": self.alpha}
 
 

@@ -207,6 +207,11 @@ typedef struct gsr_refine_args {
     gsr_resize_fn image_buffer; void* image_ctx;
     float lr, converged_threshold; int max_iters;
     int stop_on_converged;      /* 1 = reference behaviour; 0 = always run max_iters (benchmarks) */
+    /* Speculative binning (exact: verified on the device, a failed speculation is redone with full lists):
+     * from the 2nd iteration on, tile instances deeper than bound_margin_mul * z + bound_margin_add, z = the
+     * depth the tile had to look at in the previous iteration, are not binned.  0 disables. */
+    int speculative; float bound_margin_mul, bound_margin_add;     /* margins <= 0: defaults 1.05, 0.05 */
+    int* stats_out;             /* nullable host int[2]: number of redone forwards, last num_rendered */
     void* stream;
 } gsr_refine_args;
 int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);

@@ -164,3 +164,30 @@ def test_native_loop_stops_on_convergence_like_reference():
     R2, T2, _ = PL.gradient_decent(vp2, PL.TRACKING_CONFIG, eye[:3, :3].clone(), eye[:3, 3].clone(), model, PL.PipelineParams(), bg, iters=20)
     R3, T3, info3 = fr.refine(view(), PL.TRACKING_CONFIG, eye[:3, :3].clone(), eye[:3, 3].clone(), bg, iters=20, stop_on_converged=False)
     assert info3["iters"] == 20
+
+
+def test_speculative_binning_is_exact_and_falls_back():
+    """The native loop drops tile instances behind the depth each tile needed one iteration earlier.  The
+    result must not depend on it: same pose as with complete lists, also when the bounds are made
+    absurdly tight so that the device-side check fails and forwards are redone."""
+    from gs_localization_amd import pipelines as PL
+    sc = S.small(P=60000, W=160, H=128, sh_degree=2, seed=9, scale_med=0.04)
+    model, bg, view, init = _setup(sc, seed=2)
+    cfg = PL.TRACKING_CONFIG
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    runs = {}
+    for name, kw in (("full", dict(speculative=False)), ("spec", dict(speculative=True)),
+                     ("tight", dict(speculative=True, bound_margin=(0.6, 0.0)))):
+        vp = view()
+        R, T, info = fr.refine(vp, cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=12, stop_on_converged=False, **kw)
+        runs[name] = (R.clone(), T.clone(), info, fr.color.clone(), fr.depth.clone())
+    Rf, Tf, inf_f, cf, df = runs["full"]
+    assert inf_f["fallbacks"] == 0
+    for name in ("spec", "tight"):
+        R, T, info, c, d = runs[name]
+        assert torch.allclose(R, Rf, atol=2e-6) and torch.allclose(T, Tf, atol=2e-6), name
+        # poses agree to ~1e-6 (fp32 atomics reorder the gradient sums); a 1e-6 rad pose change moves the image by ~1e-4
+        assert torch.allclose(c, cf, atol=5e-4) and torch.allclose(d, df, atol=5e-3), name
+    assert runs["spec"][2]["fallbacks"] == 0
+    assert runs["spec"][2]["num_rendered"] < 0.6 * inf_f["num_rendered"]      # lists really got shorter
+    assert runs["tight"][2]["fallbacks"] > 0                                   # and the safety net really fires
