@@ -2,14 +2,18 @@
 """bench.py -- render+backward pose-refinement iterations/s on the headline scene S-1M-640
 (640x480, 1 M Gaussians, SH3), one process per GPU.
 
-One "step" = one body of the reference's refinement loop
-(gs_localization/pipelines/7scenes_localize_full_dslam.py:66-91): render() through
-`diff_gaussian_rasterization_pose` -> tracking loss -> backward (all Gaussian gradients + dL/dtau)
--> Adam step -> update_pose.  Frames are independent, so with N GPUs every rank refines its own
-query frame against its own replica of the map (weak scaling, no data-path collective); the only
-collective is the final gather of poses / timings.
+One refinement iteration = one body of the reference's loop
+(gs_localization/pipelines/7scenes_localize_full_dslam.py:66-91): render() through the pose rasterizer
+-> tracking loss -> backward (ALL Gaussian gradients + dL/dtau) -> Adam step -> update_pose ->
+convergence flag.  Query frames are independent, so every rank (GPU) refines its own frames against its
+own replica of the map (weak scaling, no data-path collective; one gather of the results at the end),
+and keeps F frames in flight (one host thread + one HIP stream each) so that one frame's latency-bound
+sort chain overlaps another frame's VALU-bound compositing.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+A "step" is one iteration of every frame in flight on a rank; `value` = world * F * K / time.
+Also reported: the single-frame native loop, and the reference-style Python loop on the same kernels.
+
+Prints ONE JSON line on rank 0 with two extra objects:
   roofline     -- dominant kernel's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
   cpu_baseline -- the CPU oracle (a port, oracle/gs_oracle.c, OpenMP) on the same scene, rank 0, N=1
 """
@@ -19,6 +23,7 @@ import json
 import math
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,7 +40,8 @@ def algorithmic_bytes(P, V, R, R_eff, N, M, ntiles):
     """SURVEY.md section 8(d) 'Algorithmic bytes per fwd+bwd iteration', split per kernel."""
     passes = math.ceil((32 + math.ceil(math.log2(ntiles))) / 8)
     per = {
-        "preprocess_fwd": P * (44 + 12 * M) + V * 48,
+        "preprocess_fwd": P * 44 + V * 48,
+        "sh_color": P * 12 * M,
         "scan": 0,
         "emit": R * 12,
         "sort": passes * R * 24,
@@ -44,7 +50,6 @@ def algorithmic_bytes(P, V, R, R_eff, N, M, ntiles):
         "bwd_zero": 0,
         "render_bwd": N * 24 + R_eff * 44 + R_eff * 36,
         "preprocess_bwd": V * (48 + 36) + P * (44 + 12 * M) + P * (40 + 12 * M),
-        "sh_color": 0,      # bytes are counted in preprocess_fwd (the colour half of the reference's K1)
         "depth_sort": 0,    # our own extra pass (sorting P Gaussians by depth); not part of the reference's byte model
     }
     return per, passes
@@ -53,11 +58,12 @@ def algorithmic_bytes(P, V, R, R_eff, N, M, ntiles):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--frames-in-flight", type=int, default=4, help="query frames refined concurrently per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--pose-only", action="store_true", help="map tensors do not require grad (not the headline)")
+    ap.add_argument("--pose-only", action="store_true", help="skip the Gaussian-parameter gradients (not the headline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -66,8 +72,7 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -76,6 +81,7 @@ def main():
     lib = _lib.load()
     assert lib.gsr_device_ok() == 1, "no gfx950 device"
 
+    K, Wm, F = args.steps, max(args.warmup, 1), max(args.frames_in_flight, 1)
     sc = S.s_1m_640(P=args.gaussians)
     W, H, M = sc.W, sc.H, sc.shs.shape[1]
     N, ntiles = W * H, ((W + 15) // 16) * ((H + 15) // 16)
@@ -85,8 +91,9 @@ def main():
     proj = PL.getProjectionMatrix2(znear=0.01, zfar=100.0, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, W=W, H=H).transpose(0, 1).to(dev)
     fovx, fovy = PL.focal2fov(sc.fx, W), PL.focal2fov(sc.fy, H)
     config = PL.TRACKING_CONFIG
+    w2c_gt = np.eye(4)
 
-    def make_view(uid, w2c_gt):
+    def make_view(uid):
         gt = torch.tensor(w2c_gt, dtype=torch.float32, device=dev)
         vp = PL.Camera(uid, None, None, gt, proj, sc.fx, sc.fy, sc.cx, sc.cy, fovx, fovy, H, W, device=dev)
         vp.update_RT(gt[:3, :3].clone(), gt[:3, 3].clone())
@@ -97,21 +104,24 @@ def main():
         vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=dev)
         return vp
 
-    # query frame of this rank: GT pose = identity, start pose perturbed by (2 cm, 1 deg) (SURVEY 8(c) fixture 9)
-    frame_id = shard.shard_frames(world, rank, world)[0]
-    rng = np.random.default_rng(1000 + frame_id)
-    d_t = rng.normal(size=3); d_t *= 0.02 / np.linalg.norm(d_t)
-    d_r = rng.normal(size=3); d_r *= math.radians(1.0) / np.linalg.norm(d_r)
-    w2c_gt = np.eye(4)
-    w2c_init = S.se3_exp(np.concatenate([d_t, d_r])) @ w2c_gt
-    vp = make_view(frame_id, w2c_gt)
-    init = torch.tensor(w2c_init, dtype=torch.float32, device=dev)
+    # query frames of this rank (global ids rank*F .. rank*F+F-1): GT pose = identity, start pose off by
+    # (2 cm, 1 deg) in a per-frame random direction (SURVEY 8(c) fixture 9)
+    frame_ids = [rank * F + f for f in range(F)]
+    w2c_inits, inits, vps = [], [], []
+    for fid in frame_ids:
+        rng = np.random.default_rng(1000 + fid)
+        d_t = rng.normal(size=3); d_t *= 0.02 / np.linalg.norm(d_t)
+        d_r = rng.normal(size=3); d_r *= math.radians(1.0) / np.linalg.norm(d_r)
+        w2c_inits.append(S.se3_exp(np.concatenate([d_t, d_r])) @ w2c_gt)
+        inits.append(torch.tensor(w2c_inits[-1], dtype=torch.float32, device=dev))
+        vps.append(make_view(fid))
+    vp, init, w2c_init = vps[0], inits[0], w2c_inits[0]
 
-    def reset():
-        vp.update_RT(init[:3, :3].clone(), init[:3, 3].clone())
-        for p_ in (vp.cam_rot_delta, vp.cam_trans_delta, vp.exposure_a, vp.exposure_b):
+    def reset(v=vp, i0=init):
+        v.update_RT(i0[:3, :3].clone(), i0[:3, 3].clone())
+        for p_ in (v.cam_rot_delta, v.cam_trans_delta, v.exposure_a, v.exposure_b):
             p_.data.zero_()
-        return PL.make_pose_optimizer(vp)
+        return PL.make_pose_optimizer(v)
 
     def barrier():
         if world > 1:
@@ -126,29 +136,26 @@ def main():
         _lib.check(lib.gsr_profile_collect(ms, cnt))
         return {names[i]: (ms[i], cnt[i]) for i in range(nk)}
 
-    # ---- warmup (W untimed steps) with every kernel bracketed by HIP events -> per-kernel breakdown
+    # ---- (0) warm-up of the Python loop with every kernel bracketed by HIP events -> per-kernel breakdown
     opt = reset()
     lib.gsr_profile_enable((1 << nk) - 1)
-    last_pkg = None
-    for _ in range(max(args.warmup, 1)):
-        conv, last_pkg = PL.refine_iteration(vp, config, model, pipe, background, opt)
+    for _ in range(Wm):
+        conv, _pkg = PL.refine_iteration(vp, config, model, pipe, background, opt)
         bool(conv)
     torch.cuda.synchronize()
-    warm = collect()
-    kernels_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in warm.items()}
-    dominant = max(kernels_ms, key=kernels_ms.get)
+    kernels_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in collect().items()}
+    lib.gsr_profile_enable(0)
+    del _pkg
 
-    # scene statistics of the last forward (V, R, R_eff)
+    # scene statistics at the start pose (V, R under the reference rule, R' emitted, R_eff of own binning)
     stats = (C.c_longlong * 4)()
-    del last_pkg
-    reset()                                               # statistics are quoted at the start pose
-    last_pkg = PL.render(vp, model, pipe, background)     # fresh graph: saved tensors still alive
-    rs_saved = last_pkg["render"].grad_fn
-    geom_t, img_t, radii_t = rs_saved.saved_tensors[7], rs_saved.saved_tensors[9], rs_saved.saved_tensors[5]
-    _lib.check(lib.gsr_forward_stats(sc.P, W, H, radii_t.data_ptr(), geom_t.data_ptr(), img_t.data_ptr(), stats,
+    reset()
+    pkg = PL.render(vp, model, pipe, background)          # fresh graph: saved tensors still alive
+    sv = pkg["render"].grad_fn.saved_tensors
+    _lib.check(lib.gsr_forward_stats(sc.P, W, H, sv[5].data_ptr(), sv[7].data_ptr(), sv[9].data_ptr(), stats,
                                      torch.cuda.current_stream().cuda_stream))
     V, R, R_emit, R_eff_culled = (int(stats[i]) for i in range(4))
-    del last_pkg, rs_saved
+    del pkg, sv
     # the byte model is defined on the REFERENCE's binning (bounding-square rule), whatever the
     # implementation emits.  V and R under that rule come from the GPU stats; R_eff under that rule needs the
     # reference lists, so it is taken from the CPU oracle's forward at this pose (cpu_baseline leg).
@@ -156,57 +163,87 @@ def main():
     R_eff, R_eff_src = R_eff_culled, "own culled binning (no CPU oracle run)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, ref_counts = cpu_baseline(sc, w2c_init)
-        if ref_counts["V"] == V and ref_counts["R"] == R:
+        # (the oracle builds its fp32 camera matrices from the fp64 pose, the GPU path from fp32 R, T: a handful
+        # of Gaussians on the cull boundaries may differ)
+        if abs(ref_counts["V"] - V) <= 1e-3 * V and abs(ref_counts["R"] - R) <= 1e-3 * R:
             R_eff, R_eff_src = ref_counts["R_eff"], "reference bounding rule (CPU oracle at the same pose)"
     per_kernel_bytes, passes = algorithmic_bytes(sc.P, V, R, R_eff, N, M, ntiles)
     total_bytes = sum(per_kernel_bytes.values())
 
-    # ---- (a) the reference's own Python loop on top of the drop-in packages (torch autograd, Adam, update_pose)
+    # ---- (a) the reference's own Python loop on the drop-in packages (torch autograd, Adam, update_pose)
     opt = reset()
-    lib.gsr_profile_enable(0)
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(K):
         conv, _pkg = PL.refine_iteration(vp, config, model, pipe, background, opt)
         bool(conv)          # the reference's `if converged: break` forces this host sync every iteration
     torch.cuda.synchronize(); barrier()
     elapsed_py = time.perf_counter() - t0
     del _pkg
 
-    # ---- (b) timed region of the headline value: the same K iterations through the native loop
-    # (gsr_refine: render -> tracking loss -> backward with ALL Gaussian gradients + dL/dtau -> Adam ->
-    # update_pose -> convergence flag); only the dominant kernel is bracketed by HIP events.
-    fr = PL.FusedRefiner(model, H, W, device=dev, gaussian_grads=not args.pose_only)
-    reset()
-    fr.refine(vp, config, init[:3, :3].clone(), init[:3, 3].clone(), background, iters=max(args.warmup, 1), stop_on_converged=False)
-    reset()
+    # ---- (b) the native loop (gsr_refine), one frame at a time; per-kernel breakdown from a separate short run
+    frs = [PL.FusedRefiner(model, H, W, device=dev, gaussian_grads=not args.pose_only) for _ in range(F)]
+
+    def native(f, iters, stop=False):
+        return frs[f].refine(vps[f], config, inits[f][:3, :3].clone(), inits[f][:3, 3].clone(), background, iters=iters,
+                             stop_on_converged=stop)
+    native(0, Wm)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    native(0, K)
+    torch.cuda.synchronize(); barrier()
+    elapsed_single = time.perf_counter() - t0
+    lib.gsr_profile_enable((1 << nk) - 1)
+    native(0, 20)
+    torch.cuda.synchronize()
+    native_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in collect().items()}
+    lib.gsr_profile_enable(0)
+    dominant = max(native_ms, key=native_ms.get)
+
+    # ---- (c) TIMED REGION of `value`: F frames in flight per rank, K iterations each, native loop.
+    # Only the dominant kernel is bracketed by HIP events (on the stream it is launched on).
+    streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
+    results = [None] * F
+
+    def worker(f, iters, stop):
+        try:
+            with torch.cuda.stream(streams[f]):
+                results[f] = native(f, iters, stop)
+        except Exception as ex:      # re-raised in the main thread
+            results[f] = ex
+
+    def run_all(iters, stop=False):
+        ts = [threading.Thread(target=worker, args=(f, iters, stop)) for f in range(F)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        for e in results:
+            if isinstance(e, Exception):
+                raise e
+    run_all(Wm)
+    torch.cuda.synchronize()
     lib.gsr_profile_enable(1 << names.index(dominant))
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    fr.refine(vp, config, init[:3, :3].clone(), init[:3, 3].clone(), background, iters=args.steps, stop_on_converged=False)
+    run_all(K)
     torch.cuda.synchronize(); barrier()
     elapsed = time.perf_counter() - t0
     dom_ms, dom_n = collect()[dominant]
     lib.gsr_profile_enable(0)
     if world > 1:
-        t = torch.tensor([elapsed, elapsed_py], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, elapsed_py, elapsed_single], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_py = float(t[0].item()), float(t[1].item())
+        elapsed, elapsed_py, elapsed_single = (float(x) for x in t.tolist())
 
-    # ---- pose error of a full 50-iteration refinement (untimed), gathered over ranks
-    timed_info = fr.last_info
-    # per-kernel breakdown of the native loop (separate short run, every kernel bracketed)
-    reset()
-    lib.gsr_profile_enable((1 << nk) - 1)
-    fr.refine(vp, config, init[:3, :3].clone(), init[:3, 3].clone(), background, iters=20, stop_on_converged=False)
+    # ---- pose error of full 50-iteration refinements with the reference's early exit (untimed), all frames gathered
+    run_all(50, stop=True)
     torch.cuda.synchronize()
-    native_ms = {k: round(v[0] / v[1], 4) if v[1] else 0.0 for k, v in collect().items()}
-    lib.gsr_profile_enable(0)
-    reset()
-    Rr, Tt, _ = fr.refine(vp, config, init[:3, :3].clone(), init[:3, 3].clone(), background, iters=50)
-    te, re = PL.pose_errors(w2c_gt[:3, :3], w2c_gt[:3, 3], Rr.detach().cpu().numpy(), Tt.detach().cpu().numpy())
+    rows = []
+    for f in range(F):
+        Rr, Tt, info = results[f]
+        te, re = PL.pose_errors(w2c_gt[:3, :3], w2c_gt[:3, 3], Rr.detach().cpu().numpy(), Tt.detach().cpu().numpy())
+        rows.append([float(frame_ids[f]), te, re, float(info["iters"])])
     te0, re0 = PL.pose_errors(w2c_gt[:3, :3], w2c_gt[:3, 3], w2c_init[:3, :3], w2c_init[:3, 3])
-    res = shard.gather_results(torch.tensor([[float(frame_id), te, re]], dtype=torch.float64, device=dev), world, rank, world)
+    res = shard.gather_results(torch.tensor(rows, dtype=torch.float64, device=dev), world * F, rank, world)
 
     if rank == 0:
         res = res.cpu().numpy()
@@ -219,14 +256,15 @@ def main():
                 traffic = json.load(open(tpath)).get(dominant)
             except Exception:
                 traffic = None
+        iters_total = world * F * K
         out = {
             "metric": "render+backward iters/sec @640x480, 1M Gaussians; median pose err (cm/deg)",
-            "value": world * args.steps / elapsed,
+            "value": iters_total / elapsed,
             "unit": "iters/s",
             "n_gpus": world,
-            "steps": args.steps,
+            "steps": K,
             "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps,
+            "ms_per_step": 1e3 * elapsed / K,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -236,20 +274,23 @@ def main():
                        "width": W, "height": H, "gaussians": sc.P, "sh_degree": sc.sh_degree,
                        "V": V, "R": R, "R_emitted": R_emit, "R_eff": R_eff, "R_eff_source": R_eff_src,
                        "R_eff_own_binning": R_eff_culled, "sort_passes": passes,
-                       "algorithmic_bytes_per_iter": total_bytes, "frames_per_rank": 1,
-                       "gaussian_grads": not args.pose_only, "parallelism": f"frames x{world}",
-                       "loop": "native gsr_refine (render, tracking loss, backward, Adam, update_pose per iteration)",
-                       "speculative_binning": {"redone_forwards": timed_info["fallbacks"], "num_rendered_last": timed_info["num_rendered"]}},
-            "python_loop_iters_per_s": world * args.steps / elapsed_py,
+                       "algorithmic_bytes_per_iter": total_bytes, "frames_in_flight_per_gpu": F,
+                       "iterations_per_step": F, "gaussian_grads": not args.pose_only,
+                       "parallelism": f"frames: {world} GPU x {F} in flight",
+                       "loop": "native gsr_refine (render, tracking loss, backward, Adam, update_pose per iteration)"},
+            "single_frame_iters_per_s": world * K / elapsed_single,
+            "python_loop_iters_per_s": world * K / elapsed_py,
             "pose_err_cm_median": 100.0 * float(np.median(res[:, 1])),
             "pose_err_deg_median": float(np.median(res[:, 2])),
             "pose_err_init_cm_deg": [100.0 * te0, re0],
-            "kernels_ms": {k: round(v, 4) for k, v in kernels_ms.items()},
-            "native_loop_kernels_ms": native_ms,
+            "refine_iters_median": float(np.median(res[:, 3])),
+            "kernels_ms_python_loop": {k: round(v, 4) for k, v in kernels_ms.items()},
+            "kernels_ms_native_single_frame": {k: round(v, 4) for k, v in native_ms.items()},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_kernel_bytes[dominant], "avg_launch_ms": dom_avg_ms,
-                         "whole_iter_frac": total_bytes / (elapsed / args.steps) / 1e9 / HBM_PEAK_GBS},
+                         "avg_launch_ms_single_frame": native_ms[dominant],
+                         "whole_iter_frac": total_bytes * iters_total / elapsed / 1e9 / HBM_PEAK_GBS / world},
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu

@@ -208,19 +208,17 @@ thread_local int g_dev = 0;      // device chosen by the last select_device_of o
 // One side stream + a fork/join event pair per device: independent work (SH colours, zero fills) runs next to
 // the latency-bound sort chain / the VALU-bound backward compositing instead of in front of them.
 // Re-recording an event after a wait on it has been enqueued is safe (the wait binds to the record that
-// preceded it), so one pair per device is enough; a concurrent caller can at worst over-synchronise.
+// preceded it), so one pair per (host thread, device) is enough.
 struct Side {
     hipStream_t st = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
-Side g_side[64];
-std::mutex g_side_mu;
+thread_local Side g_side[64];      // per host thread: concurrent callers (one stream each) do not share events
 Side* get_side()
 {
     static const bool disabled = getenv("GSR_NO_SIDE_STREAM") != nullptr;     // diagnostics
     if (disabled) return nullptr;
     if (g_dev < 0 || g_dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> l(g_side_mu);
     Side& sd = g_side[g_dev];
     if (!sd.st) {
         if (hipStreamCreateWithFlags(&sd.st, hipStreamNonBlocking) != hipSuccess) { sd.st = nullptr; (void)hipGetLastError(); return nullptr; }

@@ -191,3 +191,37 @@ def test_speculative_binning_is_exact_and_falls_back():
     assert runs["spec"][2]["fallbacks"] == 0
     assert runs["spec"][2]["num_rendered"] < 0.6 * inf_f["num_rendered"]      # lists really got shorter
     assert runs["tight"][2]["fallbacks"] > 0                                   # and the safety net really fires
+
+
+def test_concurrent_frames_on_one_gpu_match_sequential():
+    """bench.py keeps several frames in flight per GPU (one host thread + one stream each): the library must be
+    re-entrant -- same poses as refining the frames one after the other."""
+    import threading
+    from gs_localization_amd import pipelines as PL
+    sc = S.small(P=30000, W=160, H=128, sh_degree=3, seed=11, scale_med=0.04)
+    model, bg, view, _ = _setup(sc)
+    cfg = PL.TRACKING_CONFIG
+    F = 3
+    inits = []
+    for f in range(F):
+        rng = np.random.default_rng(50 + f)
+        tau = np.concatenate([rng.normal(size=3) * 0.01, rng.normal(size=3) * 0.01])
+        inits.append(torch.tensor(S.se3_exp(tau), dtype=torch.float32, device=DEV))
+    frs = [PL.FusedRefiner(model, sc.H, sc.W, device=DEV) for _ in range(F)]
+    seq = []
+    for f in range(F):
+        R, T, _ = frs[f].refine(view(), cfg, inits[f][:3, :3].clone(), inits[f][:3, 3].clone(), bg, iters=10, stop_on_converged=False)
+        seq.append((R.clone(), T.clone()))
+    vps = [view() for _ in range(F)]
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(F)]
+    out = [None] * F
+
+    def work(f):
+        with torch.cuda.stream(streams[f]):
+            out[f] = frs[f].refine(vps[f], cfg, inits[f][:3, :3].clone(), inits[f][:3, 3].clone(), bg, iters=10, stop_on_converged=False)
+    ts = [threading.Thread(target=work, args=(f,)) for f in range(F)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    for f in range(F):
+        assert torch.allclose(out[f][0], seq[f][0], atol=2e-6) and torch.allclose(out[f][1], seq[f][1], atol=2e-6), f
