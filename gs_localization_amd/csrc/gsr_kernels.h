@@ -213,7 +213,9 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_sh_color(PreArgs a)
     __shared__ uint8_t s_vis[GSR_BLOCK];
     const int tid = threadIdx.x;
     const int idx = blockIdx.x * GSR_BLOCK + tid;
-    const bool vis = idx < a.P && a.radii[idx] > 0;
+    // only splats that were binned into at least one tile can ever be composited (this also skips everything
+    // the native loop's speculative depth bounds dropped)
+    const bool vis = idx < a.P && a.tiles_touched[idx] > 0;
     float3 p = make_float3(0.f, 0.f, 0.f);
     if (vis) p = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
     if (sh16_vector_ok(a.M, a.shs)) {
@@ -261,7 +263,9 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_gather_counts(int P, const uint32
 // Each lane expands its Gaussian into (tile key, index) instances.  A block's output range is contiguous
 // (the offsets are a prefix sum in block order), so the instances are first laid out in LDS and then leave
 // the block as coalesced stores; a block with more than GSR_EMIT_CAP instances writes directly.
-#define GSR_EMIT_CAP 3072
+// Lane -> Gaussian assignment is interleaved in runs of 16 across the whole depth order: the nearest (largest,
+// most tiles) splats sit at the front of that order, and a contiguous assignment would leave them all to the
+// first few workgroups.  Runs of 16 keep the index / offset reads in whole 64-B lines.
 template <typename KeyT>
 __global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t* __restrict__ order,
                                                            const uint32_t* __restrict__ offsets,
@@ -271,39 +275,24 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t
                                                            const float* __restrict__ zb, const float* __restrict__ depths,
                                                            KeyT* __restrict__ keys, uint32_t* __restrict__ vals)
 {
-    __shared__ uint32_t s_val[GSR_EMIT_CAP];
-    __shared__ KeyT s_key[GSR_EMIT_CAP];
-    const int k0 = blockIdx.x * GSR_BLOCK;
-    const int k = k0 + threadIdx.x;
-    const int klast = min(k0 + GSR_BLOCK, P) - 1;
-    const uint32_t block_base = (k0 == 0) ? 0u : offsets[k0 - 1];
-    const uint32_t block_total = offsets[klast] - block_base;
-    if (block_total == 0) return;
-    const bool staged = block_total <= GSR_EMIT_CAP;
-    if (k < P && tt_sorted[k] != 0) {
-        const uint32_t idx = order[k];
-        uint32_t off = (k == 0) ? 0u : offsets[k - 1];
-        const ushort4 r = rects[idx];
-        const float4 co = conic_op[idx];
-        const TileTest tt = make_tile_test(xy[idx], make_float3(co.x, co.y, co.z), co.w);
-        const float z = zb ? depths[idx] : 0.f;
-        if (staged) off -= block_base;
-        for (int y = r.y; y < r.w; y++) {
-            int lo, hi;
-            row_span(tt, y, r.x, r.z, lo, hi);
-            for (int x = lo; x <= hi; x++) {
-                if (zb && !(z <= zb[y * gx + x])) continue;      // same test as the count in k_preprocess
-                if (staged) { s_key[off] = (KeyT)(y * gx + x); s_val[off] = idx; }
-                else { keys[off] = (KeyT)(y * gx + x); vals[off] = idx; }
-                off++;
-            }
+    const int run = (threadIdx.x >> 4) * gridDim.x + blockIdx.x;       // which run of 16 consecutive Gaussians
+    const int k = run * 16 + (threadIdx.x & 15);
+    if (k >= P || tt_sorted[k] == 0) return;
+    const uint32_t idx = order[k];
+    uint32_t off = (k == 0) ? 0u : offsets[k - 1];
+    const ushort4 r = rects[idx];
+    const float4 co = conic_op[idx];
+    const TileTest tt = make_tile_test(xy[idx], make_float3(co.x, co.y, co.z), co.w);
+    const float z = zb ? depths[idx] : 0.f;
+    for (int y = r.y; y < r.w; y++) {
+        int lo, hi;
+        row_span(tt, y, r.x, r.z, lo, hi);
+        for (int x = lo; x <= hi; x++) {
+            if (zb && !(z <= zb[y * gx + x])) continue;      // same test as the count in k_preprocess
+            keys[off] = (KeyT)(y * gx + x);
+            vals[off] = idx;
+            off++;
         }
-    }
-    if (!staged) return;
-    __syncthreads();
-    for (uint32_t i = threadIdx.x; i < block_total; i += GSR_BLOCK) {
-        keys[block_base + i] = s_key[i];
-        vals[block_base + i] = s_val[i];
     }
 }
 

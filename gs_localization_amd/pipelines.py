@@ -340,12 +340,12 @@ class FusedRefiner:
         self.ws = [_Workspace(dev), _Workspace(dev), _Workspace(dev)]
 
     def refine(self, viewpoint, config, initial_R, initial_T, background, iters=50, lr=0.001, converged_threshold=1e-4,
-               stop_on_converged=True, speculative=False, bound_margin=(1.05, 0.05)):
+               stop_on_converged=True, speculative=True, bound_margin=(1.05, 0.05)):
         C, _lib = self._C, self._lib_mod
         dev = self.dev
-        # speculative=True: experimental exact optimisation (include/gsr.h, gsr_refine_args.speculative).  It cuts
-        # the binned instances ~9x on S-1M-640 but, with the per-Gaussian passes still running over all P and
-        # one more host sync per iteration, it measured 1142 vs 1225 it/s on MI355X -- hence off by default.
+        # speculative=True: exact optimisation (include/gsr.h, gsr_refine_args.speculative): ~9x fewer binned
+        # instances and ~7x fewer SH rows on S-1M-640.  Neutral for one frame at a time (one more host sync per
+        # iteration), +14 % with 4 frames in flight per GPU (median 2075 vs 1812 it/s on MI355X).
         viewpoint.update_RT(initial_R, initial_T)
         st = torch.zeros(_lib.POSE_STATE_FLOATS, dtype=torch.float32)
         st[0:9] = viewpoint.R.detach().float().cpu().reshape(-1)
