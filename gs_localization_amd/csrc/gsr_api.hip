@@ -531,16 +531,19 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     delete psz;
     const float* color_ptr = colors_precomp ? colors_precomp : g.rgb;
     ProfScope* psb = new ProfScope(K_RENDER_BWD, st);
-    if (pose_mode)
-        hipLaunchKernelGGL(k_render_bwd<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
-                           (const uint32_t*)b.vals, width, height, gx, ntiles, background, (const float2*)g.xy,
-                           (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas,
-                           (const uint32_t*)im.n_contrib, dL_dpix, dL_ddepths, dL_dalphas, g.acc, g_ablate);
-    else
-        hipLaunchKernelGGL(k_render_bwd<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
-                           (const uint32_t*)b.vals, width, height, gx, ntiles, background, (const float2*)g.xy,
-                           (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas,
-                           (const uint32_t*)im.n_contrib, dL_dpix, dL_ddepths, dL_dalphas, g.acc, g_ablate);
+    // 0 = DPP/VALU reduction (k_render_bwd), 1 = matrix-core contraction (k_render_bwd_mfma, default)
+    static const int bwd_env = getenv("GSR_BWD_DPP") ? 0 : 1;
+    const int bwd_variant = (g_ablate & 0x100) ? 0 : bwd_env;
+#define GSR_BWD_ARGS (const uint2*)im.ranges, (const uint32_t*)b.vals, width, height, gx, ntiles, background, (const float2*)g.xy, \
+                     (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas, (const uint32_t*)im.n_contrib, dL_dpix, \
+                     dL_ddepths, dL_dalphas, g.acc
+    if (bwd_variant == 1 && (g_ablate & 0xff) == 0) {
+        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS);
+        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS);
+    } else {
+        if (pose_mode) hipLaunchKernelGGL(k_render_bwd<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, g_ablate & 0xff);
+        else hipLaunchKernelGGL(k_render_bwd<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, g_ablate & 0xff);
+    }
     delete psb;
     LAUNCHCHK("k_render_bwd");
 

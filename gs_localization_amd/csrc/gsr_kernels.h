@@ -616,6 +616,213 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
 }
 
 // ---------------------------------------------------------------------------------------------
+// K7, matrix-core form.  Same walk, same per-pixel recurrences as k_render_bwd, but each (pixel, splat) pair
+// only produces TWO weights,
+//     W1 = alpha * T                      (d pixel / d colour_i,  backward.cu:517)
+//     W2 = G * dL/d(alpha_i)              (backward.cu:549-578 before the per-quantity factors)
+// and every per-splat gradient sum is a pixel moment of them:
+//     dL/dcolour = sum W1 (dpx,dpy,dpz)     dL/dz = sum W1 dL_ddepth      dL/dopacity = sum W2
+//     dL/dmean2D, dL/dconic = o * polynomials in (mu,mv) of  sum W2 (1, u, v, uu, uv, vv)
+// with (u,v) the pixel position relative to the tile centre and (mu,mv) the splat mean in the same frame.
+// That is a dense contraction  S[splat][col] = sum_pixel W[splat][pixel] * g[pixel][col]  (10 columns), which
+// goes to the matrix cores: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, MI355X_MICROARCH.md) with
+// A = 8 splats x {W1,W2} (16 rows) by 4 pixels, B = 4 pixels by 16 columns, 16 steps per 64-pixel wave.
+// The weights are transposed through a per-wave LDS buffer ([pixel][17] floats, conflict-free both ways);
+// the 16 B operands per lane are pixel constants and stay in registers for the whole kernel.
+// VALU work per pair drops from ~75 maths + 54 reduction instructions to ~60.
+// ---------------------------------------------------------------------------------------------
+typedef float gsr_f32x4 __attribute__((ext_vector_type(4)));
+#define GSR_WT_STRIDE 17
+// splats staged per batch: 128 keeps the workgroup at 32 KB of LDS = 4-5 workgroups per CU
+#define GSR_BWD_BATCH 128
+struct BwdMfmaLDS {
+    float4 a[GSR_BWD_BATCH];
+    float4 b[GSR_BWD_BATCH];
+    float4 c[GSR_BWD_BATCH];
+    float acc[GSR_BWD_BATCH][10];       // per staged splat: 0-3 = sum W1 (dpx,dpy,dpz,dLd), 4-9 = W2 moments
+    float wt[4][64 * GSR_WT_STRIDE];    // per wave: [pixel][0..7] = W1 of 8 splats, [8..15] = W2
+    int wmax[4];
+    alignas(8) uint8_t list[4][GSR_BWD_BATCH];
+};
+
+template <bool POSE>
+__global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd_mfma(const uint2* __restrict__ ranges,
+                                                               const uint32_t* __restrict__ point_list, int W, int H, int gx,
+                                                               int ntiles, const float* __restrict__ bg,
+                                                               const float2* __restrict__ xy, const float4* __restrict__ conic_op,
+                                                               const float* __restrict__ rgb, const float* __restrict__ depths,
+                                                               const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
+                                                               const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
+                                                               const float* __restrict__ dL_dalphas, float* __restrict__ acc)
+{
+    __shared__ BwdMfmaLDS s;
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int px = tx * GSR_TILE + (wv & 1) * 8 + (tid & 7), py = ty * GSR_TILE + (wv >> 1) * 8 + ((tid >> 3) & 7);
+    const bool inside = px < W && py < H;
+    const int pix_id = W * py + px;
+    const float pxf = (float)px, pyf = (float)py;
+    const uint2 range = ranges[tile];
+    const size_t N = (size_t)W * H;
+    // tile-centred frame for the moments (|u|,|v| <= 7.5 keeps the polynomial recombination well conditioned)
+    const float cx0 = (float)(tx * GSR_TILE) + 7.5f, cy0 = (float)(ty * GSR_TILE) + 7.5f;
+
+    const float T_final = inside ? (1.f - alphas[pix_id]) : 0.f;
+    float T = T_final;
+    const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
+    float dpx = 0.f, dpy = 0.f, dpz = 0.f, dLd = 0.f, dLa = 0.f;
+    if (inside) {
+        dpx = dL_dpix[pix_id]; dpy = dL_dpix[N + pix_id]; dpz = dL_dpix[2 * N + pix_id];
+        dLd = dL_ddepths[pix_id]; dLa = dL_dalphas[pix_id];
+    }
+    const float bg_dot = bg[0] * dpx + bg[1] * dpy + bg[2] * dpz;
+
+    // B operands: lane (k = lane>>4, j = lane&15) needs g[pixel 4t+k][column j] for t = 0..15
+    float* wt = s.wt[wv];
+    {
+        const float u = pxf - cx0, v = pyf - cy0;
+        float* row = wt + lane * GSR_WT_STRIDE;
+        row[0] = dpx; row[1] = dpy; row[2] = dpz; row[3] = POSE ? dLd : 0.f;
+        row[4] = 1.f; row[5] = u; row[6] = v; row[7] = u * u; row[8] = u * v; row[9] = v * v;
+        row[10] = 0.f; row[11] = 0.f; row[12] = 0.f; row[13] = 0.f; row[14] = 0.f; row[15] = 0.f;
+    }
+    float Breg[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) Breg[t] = wt[(4 * t + (lane >> 4)) * GSR_WT_STRIDE + (lane & 15)];
+
+    int m = last_contributor;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
+    if (lane == 0) s.wmax[wv] = m;
+    __syncthreads();
+    const int total = max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3]));
+    const int wave_max = s.wmax[wv];
+
+    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, adr = 0.f, aar = 0.f;
+    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
+    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
+    const int arow = (lane >> 4), acol = (lane & 15);
+
+    for (int base = 0; base < total; base += GSR_BWD_BATCH) {
+        __syncthreads();
+        const int n = min(GSR_BWD_BATCH, total - base);
+        if (tid < n) {
+            const uint32_t id = point_list[range.x + (total - 1 - base - tid)];
+            const float2 mm = xy[id];
+            const float4 co = conic_op[id];
+            s.a[tid] = make_float4(mm.x, mm.y, co.x, co.y);
+            s.b[tid] = make_float4(co.z, co.w, depths[id], __uint_as_float(id));
+            const uint32_t qm = quadrant_mask(mm.x, mm.y, co.x, co.y, co.z, co.w, tx * GSR_TILE, ty * GSR_TILE);
+            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], __uint_as_float(qm));
+        }
+        if (tid < GSR_BWD_BATCH) {
+#pragma unroll
+            for (int q = 0; q < 10; q++) s.acc[tid][q] = 0.f;
+        }
+        __syncthreads();
+        int cnt = 0;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int jj = c0 + lane;
+            const bool hit = jj < n && ((__float_as_uint(s.c[min(jj, GSR_BWD_BATCH - 1)].w) >> wv) & 1u) &&
+                             (total - base - jj) <= wave_max;
+            const unsigned long long mk = __ballot(hit);
+            if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
+            cnt += (int)__popcll(mk);
+        }
+        for (int g0 = 0; g0 < cnt; g0 += 8) {
+            float* row = wt + lane * GSR_WT_STRIDE;
+            // the 8 list entries of this group in one 8-byte LDS read -> scalar registers, so that the splat
+            // records of the whole group can be fetched without waiting for each other
+            const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(&s.list[wv][g0]);
+            const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)packed);
+            const uint32_t phi = __builtin_amdgcn_readfirstlane((uint32_t)(packed >> 32));
+#pragma unroll
+            for (int sidx = 0; sidx < 8; sidx++) {
+                float w1 = 0.f, w2 = 0.f;
+                if (g0 + sidx < cnt) {          // wave-uniform
+                    const int j = (int)(((sidx < 4 ? plo : phi) >> (8 * (sidx & 3))) & 0xFFu);
+                    const int contributor = total - base - j;
+                    const float4 A = s.a[j];
+                    const float4 B = s.b[j];
+                    const float dx = A.x - pxf, dy = A.y - pyf;
+                    const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
+                    const float G = __expf(power);
+                    const float alpha = fminf(0.99f, B.y * G);
+                    const bool valid = (contributor <= last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+                    if (valid) {
+                        const float4 Cc = s.c[j];
+                        const float r1ma = __builtin_amdgcn_rcpf(1.f - alpha);
+                        T = T * r1ma;
+                        w1 = alpha * T;
+                        float dL_dopa = 0.f;
+                        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = Cc.x; dL_dopa += (Cc.x - ar0) * dpx;
+                        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = Cc.y; dL_dopa += (Cc.y - ar1) * dpy;
+                        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = Cc.z; dL_dopa += (Cc.z - ar2) * dpz;
+                        adr = last_alpha * last_depth + (1.f - last_alpha) * adr; last_depth = B.z;
+                        dL_dopa += (B.z - adr) * dLd;
+                        aar = last_alpha + (1.f - last_alpha) * aar;
+                        dL_dopa += -(alpha - aar) * dLa;
+                        dL_dopa *= T;
+                        last_alpha = alpha;
+                        dL_dopa += (-T_final * r1ma) * bg_dot;
+                        w2 = G * dL_dopa;
+                    }
+                }
+                row[sidx] = w1;
+                row[8 + sidx] = w2;
+            }
+            // S[16 rows = {W1,W2} x 8 splats][16 cols] += W[rows][4 pixels] * g[4 pixels][cols], 16 steps
+            // (two accumulators: the 16x16x4 f32 MFMA issues every 32 cycles but a dependent one waits 40)
+            gsr_f32x4 D = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int t = 0; t < 16; t += 2) {
+                const float aop0 = wt[(4 * t + arow) * GSR_WT_STRIDE + acol];
+                const float aop1 = wt[(4 * t + 4 + arow) * GSR_WT_STRIDE + acol];
+                D = __builtin_amdgcn_mfma_f32_16x16x4f32(aop0, Breg[t], D, 0, 0, 0);
+                D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop1, Breg[t + 1], D2, 0, 0, 0);
+            }
+            D = D + D2;
+            // D: lane holds column acol, rows 4*arow + r.  Rows 0-7 are W1 sums (columns 0-3 meaningful),
+            // rows 8-15 are W2 sums (columns 4-9 meaningful); merge the four waves in LDS.
+            const bool w1rows = arow < 2;
+            if ((w1rows && acol < 4) || (!w1rows && acol >= 4 && acol < 10)) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int sidx = (arow & 1) * 4 + r;
+                    if (g0 + sidx < cnt && D[r] != 0.f) atomicAdd(&s.acc[s.list[wv][g0 + sidx]][acol], D[r]);
+                }
+            }
+        }
+        __syncthreads();
+        // per staged splat: recombine the moments into the nine (ten) gradient sums, one run of atomics each
+        if (tid < n) {
+            const float* q = s.acc[tid];
+            const float M0 = q[4], Mu = q[5], Mv = q[6], Muu = q[7], Muv = q[8], Mvv = q[9];
+            if (q[0] != 0.f || q[1] != 0.f || q[2] != 0.f || q[3] != 0.f || M0 != 0.f || Mu != 0.f || Mv != 0.f ||
+                Muu != 0.f || Muv != 0.f || Mvv != 0.f) {
+                const float4 A = s.a[tid];
+                const float4 B = s.b[tid];
+                const float mu = A.x - cx0, mv = A.y - cy0, ca = A.z, cb = A.w, cc = B.x, o = B.y;
+                const float sdx = mu * M0 - Mu, sdy = mv * M0 - Mv;
+                const float sxx = mu * mu * M0 - 2.f * mu * Mu + Muu;
+                const float sxy = mu * mv * M0 - mu * Mv - mv * Mu + Muv;
+                const float syy = mv * mv * M0 - 2.f * mv * Mv + Mvv;
+                float* dst = acc + (size_t)__float_as_uint(B.w) * GSR_ACC_STRIDE;
+                atomicAdd(dst + 0, q[0]); atomicAdd(dst + 1, q[1]); atomicAdd(dst + 2, q[2]);
+                atomicAdd(dst + 3, -o * ddelx_dx * (ca * sdx + cb * sdy));
+                atomicAdd(dst + 4, -o * ddely_dy * (cc * sdy + cb * sdx));
+                atomicAdd(dst + 5, -0.5f * o * sxx);
+                atomicAdd(dst + 6, -0.5f * o * sxy);
+                atomicAdd(dst + 7, -0.5f * o * syy);
+                atomicAdd(dst + 8, M0);
+                if (POSE) atomicAdd(dst + 9, q[3]);
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K8+K9  per-Gaussian chain rule (replaces backward.cu:144-274 computeCov2DCUDA and :346-396
 // preprocessCUDA, fused into one pass) + the SE(3) pose-gradient reduction of the pose package.
 // One lane per Gaussian; HBM-streaming.  Every output element is written exactly once.

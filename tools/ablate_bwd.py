@@ -15,11 +15,11 @@ vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); v
 init = torch.tensor(S.se3_exp([0.01, 0.01, 0.01, 0.01, 0.0, 0.0]), dtype=torch.float32, device=dev)
 fr = PL.FusedRefiner(model, H, W, device=dev)
 nk = lib.gsr_profile_kernel_count(); names = [lib.gsr_profile_kernel_name(i).decode() for i in range(nk)]
-for ab in [0, 1, 2, 3, 4, 7, 8, 15, 0]:
+for ab in [0, 0x100, 0, 0x100, 0, 0x100]:
     lib.gsr_debug_ablate(ab)
-    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False)
+    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False, speculative=False)
     lib.gsr_profile_enable((1 << nk) - 1)
-    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=20, stop_on_converged=False)
+    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=40, stop_on_converged=False, speculative=False)
     torch.cuda.synchronize()
     ms = (C.c_double * nk)(); cnt = (C.c_longlong * nk)(); lib.gsr_profile_collect(ms, cnt); lib.gsr_profile_enable(0)
     d = {names[i]: round(ms[i] / max(cnt[i], 1), 4) for i in range(nk)}
