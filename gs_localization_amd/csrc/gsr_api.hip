@@ -112,7 +112,7 @@ struct Carver {
 
 struct Geom {   // per-Gaussian state carried from forward to backward
     float* depths; float2* xy; float4* conic_op; float* rgb; float* cov3D; uint8_t* clamped;
-    uint32_t* tiles_touched; uint32_t* offsets; ushort4* rects; float* acc; double* tau_acc;
+    uint32_t* tiles_touched; uint32_t* offsets; ushort4* rects; float* acc; double* tau_acc; uint8_t* dirty;
     uint32_t* depth_key; uint32_t* depth_key_sorted; uint32_t* order_in; uint32_t* order; uint32_t* tt_sorted;
     char* scan_tmp; size_t scan_bytes; char* dsort_tmp; size_t dsort_bytes;
 };
@@ -130,6 +130,7 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.offsets = c.take<uint32_t>(n);
     g.rects = c.take<ushort4>(n);
     g.acc = c.take<float>(GSR_ACC_STRIDE * n);
+    g.dirty = c.take<uint8_t>(n);
     g.tau_acc = c.take<double>(8);
     g.depth_key = c.take<uint32_t>(n);
     g.depth_key_sorted = c.take<uint32_t>(n);
@@ -505,13 +506,14 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     Img im; carve_img(img_buffer, width, height, im);
 
     // Gradient tensors are zero-filled on the side stream while K7 runs; K8/K9 then only writes non-zero rows.
-    Side* side = debug ? nullptr : get_side();
+    // (the native loop zero-fills once per frame and keeps the tensors consistent through the dirty bits)
+    Side* side = (debug || tl_native_loop) ? nullptr : get_side();
     hipStream_t zs = side ? side->st : st;
     if (side) {
         HIPCHK(hipEventRecord(side->fork, st));
         HIPCHK(hipStreamWaitEvent(side->st, side->fork, 0));
     }
-    {
+    if (!tl_native_loop) {
         const size_t Pn = (size_t)P;
         HIPCHK(hipMemsetAsync(dL_dmean2D, 0, Pn * 3 * sizeof(float), zs));
         HIPCHK(hipMemsetAsync(dL_dconic, 0, Pn * 4 * sizeof(float), zs));
@@ -559,6 +561,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale; pb.dL_drot = dL_drot;
     pb.pose = pose_mode ? 1 : 0; pb.tau_acc = g.tau_acc;
+    pb.dirty = tl_native_loop ? g.dirty : nullptr;
     {
         ProfScope ps(K_PREPROCESS_BWD, st);
         hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, pb);
@@ -660,6 +663,21 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     h_f[0] = 0.f;
     struct FlagGuard { FlagGuard() { tl_native_loop = true; } ~FlagGuard() { tl_native_loop = false; tl_spec.mode = 0; } } guard;
     int n_fallbacks = 0, last_R = 0;
+    {   // gradient tensors: zero-filled once per call, then maintained row by row (PreBwdArgs::dirty)
+        const size_t Pn = (size_t)a->P;
+        if (!a->dL_dmean2D || !a->dL_dconic || !a->dL_dopacity || !a->dL_dcolor)
+            return fail(GSR_E_INVALID, "gsr_refine: dL_dmean2D/dL_dconic/dL_dopacity/dL_dcolor are required%s", "");
+        HIPCHK(hipMemsetAsync(a->dL_dmean2D, 0, Pn * 3 * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(a->dL_dconic, 0, Pn * 4 * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(a->dL_dopacity, 0, Pn * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(a->dL_dcolor, 0, Pn * 3 * sizeof(float), st));
+        if (a->dL_dmean3D) HIPCHK(hipMemsetAsync(a->dL_dmean3D, 0, Pn * 3 * sizeof(float), st));
+        if (a->dL_dcov3D) HIPCHK(hipMemsetAsync(a->dL_dcov3D, 0, Pn * 6 * sizeof(float), st));
+        if (a->dL_dsh && a->M > 0) HIPCHK(hipMemsetAsync(a->dL_dsh, 0, Pn * a->M * 3 * sizeof(float), st));
+        if (a->dL_dscale) HIPCHK(hipMemsetAsync(a->dL_dscale, 0, Pn * 3 * sizeof(float), st));
+        if (a->dL_drot) HIPCHK(hipMemsetAsync(a->dL_drot, 0, Pn * 4 * sizeof(float), st));
+    }
+    bool dirty_cleared = false;
     const int debug = 0;
     for (int it = 0; it < a->max_iters; it++) {
         // convergence flag of the previous iteration: async copy, completed by gsr_forward's num_rendered sync
@@ -693,6 +711,11 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         }
         tl_spec.mode = 0;
         last_R = R;
+        if (!dirty_cleared) {
+            Geom gg; carve_geom((char*)gb.ptr, a->P, gg);
+            HIPCHK(hipMemsetAsync(gg.dirty, 0, (size_t)a->P, st));
+            dirty_cleared = true;
+        }
         rc = gsr_tracking_loss(a->width, a->height, a->out_color, a->out_depth, a->out_alpha, a->gt_image, a->gt_depth,
                                a->grad_mask, ps + GSR_PS_PARAM + 6, a->opacity_threshold, a->depth_weight, a->monocular,
                                a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->loss_out, a->stream);

@@ -837,6 +837,10 @@ struct PreBwdArgs {
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;      // unpacked here, written once
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
     int pose; double* tau_acc;
+    // Native loop only (nullable).  The gradient tensors are then zero-filled ONCE and kept consistent from one
+    // iteration to the next: bit 0 = this Gaussian's small gradient rows hold values, bit 1 = its dL_dsh row does.
+    // A row is re-zeroed only when it held values and gets none this time, instead of 300 MB of memsets per call.
+    uint8_t* dirty;
 };
 
 __device__ __forceinline__ float3 dnormvdv3(float3 v, float3 dv)
@@ -985,17 +989,41 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
     // SH rows in (and dL_dsh rows out) as coalesced block streams through LDS, see k_preprocess
     const bool staged = (a.shs != nullptr) && sh16_vector_ok(a.M, a.shs) &&
                         (a.dL_dsh == nullptr || (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u) == 0);
+    const uint8_t was = (a.dirty != nullptr && live) ? a.dirty[idx] : (uint8_t)0;
+    // (s_vis bit 0: fetch + compute the SH row, bit 1: store the LDS row -- computed or zeros)
+    const bool zero_sh_row = (was & 2) && !has_col;
+    if (a.dirty != nullptr && live) a.dirty[idx] = (uint8_t)((vis ? 1 : 0) | (has_col ? 2 : 0));
+    if (live && !vis && (was & 1)) {
+        // no longer visible: clear what the previous iteration left in its rows
+        a.dL_dcolor[3 * (size_t)idx] = 0.f; a.dL_dcolor[3 * (size_t)idx + 1] = 0.f; a.dL_dcolor[3 * (size_t)idx + 2] = 0.f;
+        a.dL_dmean2D[3 * (size_t)idx] = 0.f; a.dL_dmean2D[3 * (size_t)idx + 1] = 0.f;
+        reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        a.dL_dopacity[idx] = 0.f;
+        if (a.dL_dmean3D) { a.dL_dmean3D[3 * (size_t)idx] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 1] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 2] = 0.f; }
+        if (a.dL_dcov3D) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
+        }
+        if (a.dL_dscale) { a.dL_dscale[3 * (size_t)idx] = 0.f; a.dL_dscale[3 * (size_t)idx + 1] = 0.f; a.dL_dscale[3 * (size_t)idx + 2] = 0.f; }
+        if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     if (staged) {
-        s_vis[tid] = has_col ? 1 : 0;
+        s_vis[tid] = (uint8_t)((has_col ? 3 : 0) | (zero_sh_row ? 2 : 0));
         __syncthreads();
         const float4* src = reinterpret_cast<const float4*>(a.shs) + (size_t)blockIdx.x * GSR_BLOCK * GSR_SH16_ROW4;
 #pragma unroll
         for (int i = 0; i < GSR_SH16_ROW4; i++) {
             const int j = tid + GSR_BLOCK * i;
             const int g = j / GSR_SH16_ROW4;
-            if (s_vis[g]) s_sh[g * GSR_SH16_LDS4 + (j - g * GSR_SH16_ROW4)] = src[j];
+            if (s_vis[g] & 1) s_sh[g * GSR_SH16_LDS4 + (j - g * GSR_SH16_ROW4)] = src[j];
         }
         __syncthreads();
+        if (zero_sh_row) {
+#pragma unroll
+            for (int i = 0; i < GSR_SH16_ROW4; i++) s_sh[tid * GSR_SH16_LDS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    } else if (zero_sh_row && a.dL_dsh) {
+        for (int i = 0; i < a.M * 3; i++) a.dL_dsh[(size_t)idx * a.M * 3 + i] = 0.f;
     }
     float* my_row = reinterpret_cast<float*>(&s_sh[tid * GSR_SH16_LDS4]);
 
@@ -1175,7 +1203,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
         for (int i = 0; i < GSR_SH16_ROW4; i++) {
             const int j = tid + GSR_BLOCK * i;
             const int g = j / GSR_SH16_ROW4;
-            if (g < nrows && s_vis[g]) dst[j] = s_sh[g * GSR_SH16_LDS4 + (j - g * GSR_SH16_ROW4)];
+            if (g < nrows && (s_vis[g] & 2)) dst[j] = s_sh[g * GSR_SH16_LDS4 + (j - g * GSR_SH16_ROW4)];
         }
     }
     if (a.pose) {

@@ -225,3 +225,35 @@ def test_concurrent_frames_on_one_gpu_match_sequential():
     torch.cuda.synchronize()
     for f in range(F):
         assert torch.allclose(out[f][0], seq[f][0], atol=2e-6) and torch.allclose(out[f][1], seq[f][1], atol=2e-6), f
+
+
+def test_native_loop_gradient_tensors_stay_consistent():
+    """The native loop zero-fills the Gaussian-gradient tensors once and then only touches rows that change
+    (dirty bits).  After several iterations they must equal what a fresh autograd backward gives at the
+    same pose -- including exact zeros in rows that dropped out of view."""
+    from gs_localization_amd import pipelines as PL
+    from tests.util import rel_l1
+    sc = S.small(P=40000, W=160, H=128, sh_degree=3, seed=21, scale_med=0.04)
+    # make visibility change between iterations: a thick shell of splats right at the near plane
+    sc.means3D[:4000, 2] = 0.2 + np.random.default_rng(0).uniform(-0.01, 0.01, 4000).astype(np.float32)
+    model, bg, view, init = _setup(sc, seed=3)
+    cfg = PL.TRACKING_CONFIG
+    frA = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    frA.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=6, stop_on_converged=False)
+    frB = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    vpB = view()
+    frB.refine(vpB, cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=5, stop_on_converged=False)
+    for t in (model.get_xyz, model.get_features, model.get_opacity, model.get_scaling, model.get_rotation):
+        t.grad = None
+    pkg = PL.render(vpB, model, PL.PipelineParams(), bg)
+    PL.get_loss_tracking(cfg, pkg["render"], pkg["depth"], pkg["opacity"], vpB).backward()
+    ref = dict(m3d=model.get_xyz.grad, sh=model.get_features.grad, opac=model.get_opacity.grad,
+               scale=model.get_scaling.grad, rot=model.get_rotation.grad)
+    got = dict(m3d=frA.g_m3d, sh=frA.g_sh, opac=frA.g_opac, scale=frA.g_scale, rot=frA.g_rot)
+    for k in ref:
+        a, b = got[k].detach().cpu().numpy(), ref[k].detach().cpu().numpy().reshape(got[k].shape)
+        assert rel_l1(a, b) < 2e-4, (k, rel_l1(a, b))
+        # rows that are exactly zero in the fresh backward must be exactly zero here too (nothing stale left)
+        zero_rows = np.all(b.reshape(b.shape[0], -1) == 0, axis=1)
+        assert zero_rows.sum() > 1000
+        assert np.all(a.reshape(a.shape[0], -1)[zero_rows] == 0), k
