@@ -149,6 +149,7 @@ size_t carve_geom(char* base, int P, Geom& g)
 struct Img {
     uint32_t* n_contrib; uint2* ranges;
     float* zb[2]; uint32_t* trunc; uint32_t* fail;      // speculative depth bounds of the native loop
+    float* zbc[2]; uint32_t* truncc; int sbx, nsb;       // per 4x4-tile superblock
 };
 size_t carve_img(char* base, int W, int H, Img& im)
 {
@@ -158,8 +159,14 @@ size_t carve_img(char* base, int W, int H, Img& im)
     im.ranges = c.take<uint2>((size_t)gx * gy);
     im.zb[0] = c.take<float>((size_t)gx * gy);
     im.zb[1] = c.take<float>((size_t)gx * gy);
-    im.trunc = c.take<uint32_t>((size_t)gx * gy);
-    im.fail = c.take<uint32_t>(4);
+    im.sbx = (gx + 3) / 4;
+    im.nsb = im.sbx * ((gy + 3) / 4);
+    im.zbc[0] = c.take<float>((size_t)im.nsb);
+    im.zbc[1] = c.take<float>((size_t)im.nsb);
+    // trunc | truncc | fail are contiguous: one memset clears them
+    im.trunc = c.take<uint32_t>((size_t)gx * gy + im.nsb + 4);
+    im.truncc = base ? im.trunc + (size_t)gx * gy : nullptr;
+    im.fail = base ? im.truncc + im.nsb : nullptr;
     return c.size();
 }
 
@@ -329,6 +336,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
 
     const int gx = (width + GSR_TILE - 1) / GSR_TILE, gy = (height + GSR_TILE - 1) / GSR_TILE;
     if (gx > 65535 || gy > 65535) return fail(GSR_E_INVALID, "image too large%s", "");
+    if (tl_spec.mode == 1 && (size_t)gx * gy * sizeof(float) > 60 * 1024) tl_spec.mode = 2;   // bounds must fit in LDS
     const int ntiles = gx * gy;
     const float focal_y = height / (2.0f * tan_fovy);
     const float focal_x = width / (2.0f * tan_fovx);
@@ -357,13 +365,15 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     const float* zb_prev = (tl_spec.mode == 1) ? im.zb[tl_spec.parity ^ 1] : nullptr;
     float* zb_next = (tl_spec.mode != 0) ? im.zb[tl_spec.parity] : nullptr;
     pa.zb = zb_prev; pa.trunc = zb_prev ? im.trunc : nullptr;
+    pa.zbc = zb_prev ? im.zbc[tl_spec.parity ^ 1] : nullptr; pa.truncc = zb_prev ? im.truncc : nullptr; pa.sbx = im.sbx;
+    float* zbc_next = (tl_spec.mode != 0) ? im.zbc[tl_spec.parity] : nullptr;
     if (tl_spec.mode != 0) {
-        HIPCHK(hipMemsetAsync(im.trunc, 0, (size_t)ntiles * sizeof(uint32_t), st));
-        HIPCHK(hipMemsetAsync(im.fail, 0, 4 * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(im.trunc, 0, ((size_t)ntiles + im.nsb + 4) * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(zbc_next, 0, (size_t)im.nsb * sizeof(float), st));
     }
     {
         ProfScope ps(K_PREPROCESS, st);
-        hipLaunchKernelGGL(k_preprocess, dim3(pblocks), dim3(GSR_BLOCK), 0, st, pa);
+        hipLaunchKernelGGL(k_preprocess, dim3(pblocks), dim3(GSR_BLOCK), zb_prev ? (size_t)ntiles * sizeof(float) : 0, st, pa);
     }
     LAUNCHCHK("k_preprocess");
     // SH colours only feed the compositing kernel: fork them onto the side stream, join before K6
@@ -414,9 +424,9 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
         if (wide) {
             {
                 ProfScope ps(K_EMIT, st);
-                hipLaunchKernelGGL(k_emit_sorted<uint32_t>, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
+                hipLaunchKernelGGL(k_emit_sorted<uint32_t>, dim3(pblocks), dim3(GSR_BLOCK), zb_prev ? (size_t)ntiles * sizeof(float) : 0, st, P, (const uint32_t*)g.order,
                                    (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
-                                   (const float2*)g.xy, (const float4*)g.conic_op, gx, zb_prev, (const float*)g.depths, (uint32_t*)b.keys_unsorted, b.vals_unsorted);
+                                   (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, (const float*)g.depths, (uint32_t*)b.keys_unsorted, b.vals_unsorted);
             }
             LAUNCHCHK("k_emit_sorted");
             {
@@ -431,9 +441,9 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
         } else {
             {
                 ProfScope ps(K_EMIT, st);
-                hipLaunchKernelGGL(k_emit_sorted<uint16_t>, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
+                hipLaunchKernelGGL(k_emit_sorted<uint16_t>, dim3(pblocks), dim3(GSR_BLOCK), zb_prev ? (size_t)ntiles * sizeof(float) : 0, st, P, (const uint32_t*)g.order,
                                    (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
-                                   (const float2*)g.xy, (const float4*)g.conic_op, gx, zb_prev, (const float*)g.depths, (uint16_t*)b.keys_unsorted, b.vals_unsorted);
+                                   (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, (const float*)g.depths, (uint16_t*)b.keys_unsorted, b.vals_unsorted);
             }
             LAUNCHCHK("k_emit_sorted");
             {   // (3) stable sort on the tile bits only
@@ -457,13 +467,13 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
                            (const uint32_t*)b.vals, width, height, gx, ntiles, (const float2*)g.xy, feat,
                            (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha,
                            im.n_contrib, n_touched, zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), im.fail,
-                           tl_spec.mul, tl_spec.add);
+                           tl_spec.mul, tl_spec.add, zbc_next, (const uint32_t*)im.truncc, im.sbx);
     else
         hipLaunchKernelGGL(k_render_fwd<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
                            (const uint32_t*)b.vals, width, height, gx, ntiles, (const float2*)g.xy, feat,
                            (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha,
                            im.n_contrib, (int*)nullptr, zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), im.fail,
-                           tl_spec.mul, tl_spec.add);
+                           tl_spec.mul, tl_spec.add, zbc_next, (const uint32_t*)im.truncc, im.sbx);
     delete psr;
     LAUNCHCHK("k_render_fwd");
     return R;

@@ -75,6 +75,7 @@ struct PreArgs {
     int P, D, M, W, H, gx, gy;
     uint32_t* depth_key; uint32_t* order_in;
     const float* zb; uint32_t* trunc;      // speculative per-tile depth bounds of the native loop (nullable)
+    const float* zbc; uint32_t* truncc; int sbx;   // the same per 4x4-tile superblock (max of its tiles): quick reject
     const float* means; const float* scales; float mod; const float* rots; const float* opac;
     const float* shs; const float* cov3D_pre; const float* colors_pre;
     const float* view; const float* proj; const float* campos;
@@ -131,7 +132,12 @@ __device__ __forceinline__ bool sh16_vector_ok(int M, const float* shs)
 
 __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 {
+    extern __shared__ float s_zb[];      // native loop: the per-tile depth bounds (gx*gy floats), else unused
     const int tid = threadIdx.x;
+    if (a.zb != nullptr) {
+        for (int i = tid; i < a.gx * a.gy; i += GSR_BLOCK) s_zb[i] = a.zb[i];
+        __syncthreads();
+    }
     const int idx = blockIdx.x * GSR_BLOCK + tid;
     const bool live = idx < a.P;
     bool vis = false;
@@ -185,16 +191,33 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                     // exact count of tiles this splat can change
                     const TileTest tt = make_tile_test(pix, conic, opacity);
                     uint32_t cnt = 0;
-                    for (int y = y0; y < y1; y++) {
-                        int lo, hi;
-                        row_span(tt, y, x0, x1, lo, hi);
-                        if (a.zb == nullptr) cnt += (uint32_t)max(0, hi - lo + 1);
-                        else
-                            for (int x = lo; x <= hi; x++) {
-                                // behind everything this tile needed last iteration (+ margin): speculatively dropped
-                                if (pview.z <= a.zb[y * a.gx + x]) cnt++;
-                                else a.trunc[y * a.gx + x] = 1u;
-                            }
+                    bool far_everywhere = false;
+                    if (a.zb != nullptr) {
+                        // behind the bound of every superblock the rectangle overlaps => behind every tile's bound
+                        float zc = 0.f;
+                        for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
+                            for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, a.zbc[sy * a.sbx + sx]);
+                        far_everywhere = pview.z > zc;
+                        if (far_everywhere)
+                            for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
+                                for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++)
+                                    if (a.truncc[sy * a.sbx + sx] == 0u) a.truncc[sy * a.sbx + sx] = 1u;   // (test first: ~10^4 lanes per flag)
+                    }
+                    if (!far_everywhere) {
+                        uint32_t full = 0;
+                        for (int y = y0; y < y1; y++) {
+                            int lo, hi;
+                            row_span(tt, y, x0, x1, lo, hi);
+                            full += (uint32_t)max(0, hi - lo + 1);
+                            if (a.zb == nullptr) continue;
+                            // behind everything this tile needed last iteration (+ margin): speculatively dropped
+                            for (int x = lo; x <= hi; x++) cnt += (pview.z <= s_zb[y * a.gx + x]) ? 1u : 0u;
+                        }
+                        if (a.zb == nullptr) cnt = full;
+                        else if (cnt != full)      // something was dropped: remember it per superblock (test first: many lanes per flag)
+                            for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
+                                for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++)
+                                    if (a.truncc[sy * a.sbx + sx] == 0u) a.truncc[sy * a.sbx + sx] = 1u;
                     }
                     a.tiles_touched[idx] = cnt;
                     if (cnt) a.depth_key[idx] = __float_as_uint(pview.z);
@@ -271,10 +294,15 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t
                                                            const uint32_t* __restrict__ offsets,
                                                            const uint32_t* __restrict__ tt_sorted,
                                                            const ushort4* __restrict__ rects, const float2* __restrict__ xy,
-                                                           const float4* __restrict__ conic_op, int gx,
+                                                           const float4* __restrict__ conic_op, int gx, int gy_tiles,
                                                            const float* __restrict__ zb, const float* __restrict__ depths,
                                                            KeyT* __restrict__ keys, uint32_t* __restrict__ vals)
 {
+    extern __shared__ float s_zb[];      // per-tile depth bounds (native loop), see k_preprocess
+    if (zb != nullptr) {
+        for (int i = threadIdx.x; i < gx * gy_tiles; i += GSR_BLOCK) s_zb[i] = zb[i];
+        __syncthreads();
+    }
     const int run = (threadIdx.x >> 4) * gridDim.x + blockIdx.x;       // which run of 16 consecutive Gaussians
     const int k = run * 16 + (threadIdx.x & 15);
     if (k >= P || tt_sorted[k] == 0) return;
@@ -288,7 +316,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t
         int lo, hi;
         row_span(tt, y, r.x, r.z, lo, hi);
         for (int x = lo; x <= hi; x++) {
-            if (zb && !(z <= zb[y * gx + x])) continue;      // same test as the count in k_preprocess
+            if (zb && !(z <= s_zb[y * gx + x])) continue;      // same test as the count in k_preprocess
             keys[off] = (KeyT)(y * gx + x);
             vals[off] = idx;
             off++;
@@ -357,7 +385,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
                                                           float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
                                                           int* __restrict__ n_touched, float* __restrict__ zb_next,
                                                           const uint32_t* __restrict__ trunc, uint32_t* __restrict__ fail,
-                                                          float margin_mul, float margin_add)
+                                                          float margin_mul, float margin_add, float* __restrict__ zbc_next,
+                                                          const uint32_t* __restrict__ truncc, int sbx)
 {
     __shared__ SplatLDS s;
     __shared__ float s_zmax[4];
@@ -441,8 +470,11 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
         __syncthreads();
         if (tid == 0) {
             zm = fmaxf(fmaxf(s_zmax[0], s_zmax[1]), fmaxf(s_zmax[2], s_zmax[3]));
-            zb_next[tile] = unfinished ? __builtin_huge_valf() : zm * margin_mul + margin_add;
-            if (unfinished && trunc != nullptr && trunc[tile] != 0u) atomicAdd(fail, 1u);
+            const float bound = unfinished ? __builtin_huge_valf() : zm * margin_mul + margin_add;
+            zb_next[tile] = bound;
+            const int sb = (ty >> 2) * sbx + (tx >> 2);
+            atomicMax(reinterpret_cast<int*>(zbc_next) + sb, __float_as_int(bound));     // bounds are >= 0: int order = float order
+            if (unfinished && trunc != nullptr && truncc[sb] != 0u) atomicAdd(fail, 1u);
         }
     }
     if (inside) {

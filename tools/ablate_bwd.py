@@ -15,13 +15,13 @@ vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); v
 init = torch.tensor(S.se3_exp([0.01, 0.01, 0.01, 0.01, 0.0, 0.0]), dtype=torch.float32, device=dev)
 fr = PL.FusedRefiner(model, H, W, device=dev)
 nk = lib.gsr_profile_kernel_count(); names = [lib.gsr_profile_kernel_name(i).decode() for i in range(nk)]
-for ab in [0, 0x100, 0, 0x100, 0, 0x100]:
+for ab, spec in [(0, False), (0, True), (0, False), (0, True)]:
     lib.gsr_debug_ablate(ab)
-    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False, speculative=False)
+    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False, speculative=spec)
     lib.gsr_profile_enable((1 << nk) - 1)
-    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=40, stop_on_converged=False, speculative=False)
+    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=40, stop_on_converged=False, speculative=spec)
     torch.cuda.synchronize()
     ms = (C.c_double * nk)(); cnt = (C.c_longlong * nk)(); lib.gsr_profile_collect(ms, cnt); lib.gsr_profile_enable(0)
     d = {names[i]: round(ms[i] / max(cnt[i], 1), 4) for i in range(nk)}
-    print("ablate", ab, "render_bwd", d["render_bwd"], "render_fwd", d["render_fwd"], flush=True)
+    print("spec", spec, d, flush=True)
 lib.gsr_debug_ablate(0)
