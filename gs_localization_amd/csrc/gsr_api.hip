@@ -150,6 +150,7 @@ struct Img {
     uint32_t* n_contrib; uint2* ranges;
     float* zb[2]; uint32_t* trunc; uint32_t* fail;      // speculative depth bounds of the native loop
     float* zbc[2]; uint32_t* truncc; int sbx, nsb;       // per 4x4-tile superblock
+    uint32_t* tile_cursor; size_t clear_words;           // bin-by-tile path: per-tile append cursors (GSR_CURSOR_STRIDE apart)
 };
 size_t carve_img(char* base, int W, int H, Img& im)
 {
@@ -163,10 +164,12 @@ size_t carve_img(char* base, int W, int H, Img& im)
     im.nsb = im.sbx * ((gy + 3) / 4);
     im.zbc[0] = c.take<float>((size_t)im.nsb);
     im.zbc[1] = c.take<float>((size_t)im.nsb);
-    // trunc | truncc | fail are contiguous: one memset clears them
-    im.trunc = c.take<uint32_t>((size_t)gx * gy + im.nsb + 4);
+    // trunc | truncc | fail | tile_cursor are contiguous: one memset clears them
+    im.clear_words = (size_t)gx * gy + im.nsb + 16 + (size_t)gx * gy * GSR_CURSOR_STRIDE;
+    im.trunc = c.take<uint32_t>(im.clear_words);
     im.truncc = base ? im.trunc + (size_t)gx * gy : nullptr;
     im.fail = base ? im.truncc + im.nsb : nullptr;
+    im.tile_cursor = base ? im.trunc + (((size_t)gx * gy + im.nsb + 1 + 15) & ~(size_t)15) : nullptr;
     return c.size();
 }
 
@@ -196,6 +199,16 @@ size_t carve_bin(char* base, int R, bool wide_keys, Bin& b)
     return c.size();
 }
 
+// bin-by-tile path: sorted index lists (same place as Bin::vals, which is all the backward reads) + the bins
+struct BinLocal { uint32_t* vals; unsigned long long* bins; };
+size_t carve_bin_local(char* base, int ntiles, BinLocal& b)
+{
+    Carver c(base);
+    b.vals = c.take<uint32_t>((size_t)ntiles * GSR_LSORT_CAP);
+    b.bins = c.take<unsigned long long>((size_t)ntiles * GSR_LSORT_CAP);
+    return c.size();
+}
+
 // number of bits needed to hold values < n  (same result as rasterizer_impl.cu:35-50 for n >= 1)
 int bits_for(uint32_t n)
 {
@@ -209,7 +222,7 @@ int bits_for(uint32_t n)
 thread_local bool tl_native_loop = false;
 // Speculative per-tile depth bounds (native loop only): mode 0 = off, 1 = bin with the bounds the previous
 // iteration recorded and record new ones, 2 = bin everything but record bounds.  parity picks the buffer.
-struct SpecCtx { int mode = 0; int parity = 0; float mul = 1.05f, add = 0.05f; };
+struct SpecCtx { int mode = 0; int parity = 0; float mul = 1.05f, add = 0.05f; bool local_sort = true; };
 thread_local SpecCtx tl_spec;
 thread_local int g_dev = 0;      // device chosen by the last select_device_of on this thread
 
@@ -367,8 +380,19 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     pa.zb = zb_prev; pa.trunc = zb_prev ? im.trunc : nullptr;
     pa.zbc = zb_prev ? im.zbc[tl_spec.parity ^ 1] : nullptr; pa.truncc = zb_prev ? im.truncc : nullptr; pa.sbx = im.sbx;
     float* zbc_next = (tl_spec.mode != 0) ? im.zbc[tl_spec.parity] : nullptr;
+    // bin-by-tile + in-kernel sort instead of the two global sorts: only with speculative bounds (short lists)
+    const bool local_path = zb_prev != nullptr && tl_spec.local_sort && ntiles <= 65536;
+    BinLocal bl{nullptr, nullptr};
+    if (local_path) {
+        const size_t lbytes = carve_bin_local(nullptr, ntiles, bl);
+        char* lptr = (char*)binning_buffer(binning_ctx, lbytes);
+        if (!lptr) return fail(GSR_E_ALLOC, "binning buffer callback returned NULL%s", "");
+        carve_bin_local(lptr, ntiles, bl);
+    }
+    pa.tile_cursor = local_path ? im.tile_cursor : nullptr;
+    pa.bins = bl.bins;
     if (tl_spec.mode != 0) {
-        HIPCHK(hipMemsetAsync(im.trunc, 0, ((size_t)ntiles + im.nsb + 4) * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(im.trunc, 0, im.clear_words * sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(zbc_next, 0, (size_t)im.nsb * sizeof(float), st));
     }
     {
@@ -392,88 +416,93 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
         }
         LAUNCHCHK("k_sh_color");
     }
-    {   // (1) Gaussians in (depth bits, index) order; culled ones carry key 0xFFFFFFFF and end up last
-        ProfScope ps(K_DEPTH_SORT, st);
-        HIPCHK(depth_sort(g.dsort_tmp, g.dsort_bytes, g.depth_key, g.depth_key_sorted, g.order_in, g.order, (unsigned)P, st));
-    }
-    {
-        ProfScope ps(K_SCAN, st);
-        hipLaunchKernelGGL(k_gather_counts, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
-                           (const uint32_t*)g.tiles_touched, g.tt_sorted);
-        HIPCHK(hipcub::DeviceScan::InclusiveSum(g.scan_tmp, g.scan_bytes, g.tt_sorted, g.offsets, P, st));
-    }
-
-    // one blocking 4-byte read, as rasterizer_impl.cu:282
-    uint32_t num_rendered_u = 0;
-    HIPCHK(hipMemcpyAsync(&num_rendered_u, g.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
-    if (num_rendered_u > 0x7fffffffu) return fail(GSR_E_INVALID, "more than 2^31 tile instances%s", "");
-    const int R = (int)num_rendered_u;
-
-    const bool wide = ntiles > 65536;
-    Bin b;
-    const size_t bbytes = carve_bin(nullptr, R, wide, b);
-    char* bptr = (char*)binning_buffer(binning_ctx, bbytes);
-    if (!bptr) return fail(GSR_E_ALLOC, "binning buffer callback returned NULL%s", "");
-    carve_bin(bptr, R, wide, b);
-
-    HIPCHK(hipMemsetAsync(im.ranges, 0, (size_t)ntiles * sizeof(uint2), st));
-    if (R > 0) {
-        const int end_bit = bits_for((uint32_t)(ntiles - 1)) > 0 ? bits_for((uint32_t)(ntiles - 1)) : 1;
-        const int rblocks = (R + GSR_BLOCK - 1) / GSR_BLOCK;
-        if (wide) {
-            {
-                ProfScope ps(K_EMIT, st);
-                hipLaunchKernelGGL(k_emit_sorted<uint32_t>, dim3(pblocks), dim3(GSR_BLOCK), zb_prev ? (size_t)ntiles * sizeof(float) : 0, st, P, (const uint32_t*)g.order,
-                                   (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
-                                   (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, (const float*)g.depths, (uint32_t*)b.keys_unsorted, b.vals_unsorted);
-            }
-            LAUNCHCHK("k_emit_sorted");
-            {
-                ProfScope ps(K_SORT, st);
-                HIPCHK(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, (const uint32_t*)b.keys_unsorted, (uint32_t*)b.keys,
-                                                          (const uint32_t*)b.vals_unsorted, b.vals, R, 0, end_bit, st));
-            }
-            {
-                ProfScope ps(K_RANGES, st);
-                hipLaunchKernelGGL(k_ranges<uint32_t>, dim3(rblocks), dim3(GSR_BLOCK), 0, st, R, (const uint32_t*)b.keys, im.ranges);
-            }
-        } else {
-            {
-                ProfScope ps(K_EMIT, st);
-                hipLaunchKernelGGL(k_emit_sorted<uint16_t>, dim3(pblocks), dim3(GSR_BLOCK), zb_prev ? (size_t)ntiles * sizeof(float) : 0, st, P, (const uint32_t*)g.order,
-                                   (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
-                                   (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, (const float*)g.depths, (uint16_t*)b.keys_unsorted, b.vals_unsorted);
-            }
-            LAUNCHCHK("k_emit_sorted");
-            {   // (3) stable sort on the tile bits only
-                ProfScope ps(K_SORT, st);
-                HIPCHK(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, (const uint16_t*)b.keys_unsorted, (uint16_t*)b.keys,
-                                                          (const uint32_t*)b.vals_unsorted, b.vals, R, 0, end_bit, st));
-            }
-            {
-                ProfScope ps(K_RANGES, st);
-                hipLaunchKernelGGL(k_ranges<uint16_t>, dim3(rblocks), dim3(GSR_BLOCK), 0, st, R, (const uint16_t*)b.keys, im.ranges);
-            }
+    int R = 0;
+    Bin b{};
+    if (!local_path) {
+        {   // (1) Gaussians in (depth bits, index) order; culled ones carry key 0xFFFFFFFF and end up last
+            ProfScope ps(K_DEPTH_SORT, st);
+            HIPCHK(depth_sort(g.dsort_tmp, g.dsort_bytes, g.depth_key, g.depth_key_sorted, g.order_in, g.order, (unsigned)P, st));
         }
-        LAUNCHCHK("k_ranges");
+        {
+            ProfScope ps(K_SCAN, st);
+            hipLaunchKernelGGL(k_gather_counts, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
+                               (const uint32_t*)g.tiles_touched, g.tt_sorted);
+            HIPCHK(hipcub::DeviceScan::InclusiveSum(g.scan_tmp, g.scan_bytes, g.tt_sorted, g.offsets, P, st));
+        }
+        // one blocking 4-byte read, as rasterizer_impl.cu:282
+        uint32_t num_rendered_u = 0;
+        HIPCHK(hipMemcpyAsync(&num_rendered_u, g.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (num_rendered_u > 0x7fffffffu) return fail(GSR_E_INVALID, "more than 2^31 tile instances%s", "");
+        R = (int)num_rendered_u;
+
+        const bool wide = ntiles > 65536;
+        const size_t bbytes = carve_bin(nullptr, R, wide, b);
+        char* bptr = (char*)binning_buffer(binning_ctx, bbytes);
+        if (!bptr) return fail(GSR_E_ALLOC, "binning buffer callback returned NULL%s", "");
+        carve_bin(bptr, R, wide, b);
+
+        HIPCHK(hipMemsetAsync(im.ranges, 0, (size_t)ntiles * sizeof(uint2), st));
+        if (R > 0) {
+            const int end_bit = bits_for((uint32_t)(ntiles - 1)) > 0 ? bits_for((uint32_t)(ntiles - 1)) : 1;
+            const int rblocks = (R + GSR_BLOCK - 1) / GSR_BLOCK;
+            const size_t zb_lds = zb_prev ? (size_t)ntiles * sizeof(float) : 0;
+            if (wide) {
+                {
+                    ProfScope ps(K_EMIT, st);
+                    hipLaunchKernelGGL(k_emit_sorted<uint32_t>, dim3(pblocks), dim3(GSR_BLOCK), zb_lds, st, P, (const uint32_t*)g.order,
+                                       (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
+                                       (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, (const float*)g.depths,
+                                       (uint32_t*)b.keys_unsorted, b.vals_unsorted);
+                }
+                LAUNCHCHK("k_emit_sorted");
+                {
+                    ProfScope ps(K_SORT, st);
+                    HIPCHK(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, (const uint32_t*)b.keys_unsorted, (uint32_t*)b.keys,
+                                                              (const uint32_t*)b.vals_unsorted, b.vals, R, 0, end_bit, st));
+                }
+                {
+                    ProfScope ps(K_RANGES, st);
+                    hipLaunchKernelGGL(k_ranges<uint32_t>, dim3(rblocks), dim3(GSR_BLOCK), 0, st, R, (const uint32_t*)b.keys, im.ranges);
+                }
+            } else {
+                {
+                    ProfScope ps(K_EMIT, st);
+                    hipLaunchKernelGGL(k_emit_sorted<uint16_t>, dim3(pblocks), dim3(GSR_BLOCK), zb_lds, st, P, (const uint32_t*)g.order,
+                                       (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
+                                       (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, (const float*)g.depths,
+                                       (uint16_t*)b.keys_unsorted, b.vals_unsorted);
+                }
+                LAUNCHCHK("k_emit_sorted");
+                {   // (3) stable sort on the tile bits only
+                    ProfScope ps(K_SORT, st);
+                    HIPCHK(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, (const uint16_t*)b.keys_unsorted, (uint16_t*)b.keys,
+                                                              (const uint32_t*)b.vals_unsorted, b.vals, R, 0, end_bit, st));
+                }
+                {
+                    ProfScope ps(K_RANGES, st);
+                    hipLaunchKernelGGL(k_ranges<uint16_t>, dim3(rblocks), dim3(GSR_BLOCK), 0, st, R, (const uint16_t*)b.keys, im.ranges);
+                }
+            }
+            LAUNCHCHK("k_ranges");
+        }
     }
     if (n_touched) HIPCHK(hipMemsetAsync(n_touched, 0, (size_t)P * sizeof(int), st));
     const float* feat = colors_precomp ? colors_precomp : g.rgb;
     if (side) HIPCHK(hipStreamWaitEvent(st, side->join, 0));
     ProfScope* psr = new ProfScope(K_RENDER_FWD, st);
-    if (n_touched)
-        hipLaunchKernelGGL(k_render_fwd<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
-                           (const uint32_t*)b.vals, width, height, gx, ntiles, (const float2*)g.xy, feat,
-                           (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha,
-                           im.n_contrib, n_touched, zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), im.fail,
-                           tl_spec.mul, tl_spec.add, zbc_next, (const uint32_t*)im.truncc, im.sbx);
-    else
-        hipLaunchKernelGGL(k_render_fwd<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, (const uint2*)im.ranges,
-                           (const uint32_t*)b.vals, width, height, gx, ntiles, (const float2*)g.xy, feat,
-                           (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha,
-                           im.n_contrib, (int*)nullptr, zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), im.fail,
-                           tl_spec.mul, tl_spec.add, zbc_next, (const uint32_t*)im.truncc, im.sbx);
+#define GSR_FWD_ARGS im.ranges, local_path ? bl.vals : b.vals, (const unsigned long long*)bl.bins, (const uint32_t*)im.tile_cursor, \
+                     width, height, gx, ntiles, (const float2*)g.xy, feat, \
+                     (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
+                     zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), im.fail, tl_spec.mul, tl_spec.add, zbc_next, \
+                     (const uint32_t*)im.truncc, im.sbx
+    if (local_path) {
+        if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+        else hipLaunchKernelGGL((k_render_fwd<false, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+    } else {
+        if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, false>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+        else hipLaunchKernelGGL((k_render_fwd<false, false>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+    }
     delete psr;
     LAUNCHCHK("k_render_fwd");
     return R;
@@ -672,7 +701,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     *converged = 0;
     h_f[0] = 0.f;
     struct FlagGuard { FlagGuard() { tl_native_loop = true; } ~FlagGuard() { tl_native_loop = false; tl_spec.mode = 0; } } guard;
-    int n_fallbacks = 0, last_R = 0;
+    int n_fallbacks = 0, last_R = 0, fail_streak = 0, spec_resume = 0;
+    bool last_local = false;
     {   // gradient tensors: zero-filled once per call, then maintained row by row (PreBwdArgs::dirty)
         const size_t Pn = (size_t)a->P;
         if (!a->dL_dmean2D || !a->dL_dconic || !a->dL_dopacity || !a->dL_dcolor)
@@ -701,26 +731,39 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         // Speculative binning: from the second iteration on, instances lying behind what their tile needed in
         // the previous iteration (x margin) are not binned; the compositing kernel verifies the speculation and
         // a failed one is redone with complete lists, so results never depend on it.
-        tl_spec.mode = a->speculative ? ((it == 0) ? 2 : 1) : 0;
+        tl_spec.mode = a->speculative ? ((it == 0 || it < spec_resume) ? 2 : 1) : 0;
         tl_spec.parity = it & 1;
         if (a->bound_margin_mul > 0.f) { tl_spec.mul = a->bound_margin_mul; tl_spec.add = a->bound_margin_add; }
         int R = fwd();
         if (R < 0) { tl_spec.mode = 0; return R; }
-        if (it > 0 && a->stop_on_converged && h_f[0] != 0.f) { *converged = 1; tl_spec.mode = 0; break; }   // reference: `if converged: break`
         if (tl_spec.mode == 1) {
+            // the bin-by-tile forward does not synchronise; this read-back does (and completes the flag copy above)
             Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
             uint32_t* h_fail = reinterpret_cast<uint32_t*>(h_flag) + 2;
             HIPCHK(hipMemcpyAsync(h_fail, imv.fail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             if (*h_fail != 0u) {
                 n_fallbacks++;
+                if (getenv("GSR_DEBUG_TILES")) {
+                    const int nt = ((a->width + 15) / 16) * ((a->height + 15) / 16);
+                    std::vector<uint32_t> tc((size_t)nt * GSR_CURSOR_STRIDE);
+                    (void)hipMemcpy(tc.data(), imv.tile_cursor, tc.size() * 4, hipMemcpyDeviceToHost);
+                    uint32_t mx = 0, over = 0; unsigned long long sum = 0;
+                    for (int i = 0; i < nt; i++) { const uint32_t c = tc[(size_t)i * GSR_CURSOR_STRIDE]; mx = c > mx ? c : mx; over += c > GSR_LSORT_CAP; sum += c; }
+                    fprintf(stderr, "[gsr] it %d fail=0x%x: bin fill max %u, over capacity %u of %d, sum %llu\n", it, *h_fail, mx, over, nt, sum);
+                }
                 tl_spec.mode = 2;
                 R = fwd();
                 if (R < 0) { tl_spec.mode = 0; return R; }
-            }
+                // back off: a scene whose lists stay long after culling would otherwise pay for both forwards every time
+                fail_streak++;
+                if (fail_streak >= 2) spec_resume = it + 1 + (1 << (fail_streak < 6 ? fail_streak : 6));
+            } else fail_streak = 0;
         }
+        if (it > 0 && a->stop_on_converged && h_f[0] != 0.f) { *converged = 1; tl_spec.mode = 0; break; }   // reference: `if converged: break`
         tl_spec.mode = 0;
         last_R = R;
+        last_local = (R == 0);      // the bin-by-tile forward does not bring its instance count to the host
         if (!dirty_cleared) {
             Geom gg; carve_geom((char*)gb.ptr, a->P, gg);
             HIPCHK(hipMemsetAsync(gg.dirty, 0, (size_t)a->P, st));
@@ -744,7 +787,19 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         }
         *iters_done = it + 1;
     }
-    if (a->stats_out) { a->stats_out[0] = n_fallbacks; a->stats_out[1] = last_R; }
+    if (a->stats_out) {
+        if (last_local && ib.ptr) {      // instances binned by the last forward = sum of the tile cursors
+            Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
+            const int nt = ((a->width + GSR_TILE - 1) / GSR_TILE) * ((a->height + GSR_TILE - 1) / GSR_TILE);
+            std::vector<uint32_t> tc((size_t)nt * GSR_CURSOR_STRIDE);
+            HIPCHK(hipMemcpyAsync(tc.data(), imv.tile_cursor, tc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            long long sum = 0;
+            for (int i = 0; i < nt; i++) sum += tc[(size_t)i * GSR_CURSOR_STRIDE];
+            last_R = (int)sum;
+        }
+        a->stats_out[0] = n_fallbacks; a->stats_out[1] = last_R;
+    }
     if (!*converged && a->stop_on_converged) {
         HIPCHK(hipMemcpyAsync(h_f, ps + GSR_PS_CONV, sizeof(float), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));

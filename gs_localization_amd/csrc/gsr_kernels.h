@@ -71,11 +71,26 @@ __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int 
     hi = min(x1 - 1, (int)floorf(pb * (1.f / GSR_TILE)));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Bin-by-tile path of the native loop.  Once the speculative depth bounds have cut the per-tile lists down to
+// a few hundred entries, neither global sort is needed: k_preprocess appends (depth bits << 32 | index) straight
+// into fixed-capacity per-tile bins (one returning atomic on the tile's cursor per instance), and the compositing
+// kernel sorts each tile's bin in LDS -- by (depth bits, index), the same total order as the reference's stable
+// radix sort of (tile | depth) keys (rasterizer_impl.cu:304-309).  No prefix sum, no host read of the instance
+// count.  A tile with more than GSR_LSORT_CAP entries reports failure and the host redoes the forward on the
+// global-sort path.
+// ---------------------------------------------------------------------------------------------
+#define GSR_LSORT_CAP 2048        // bin capacity = longest list the in-LDS sort takes
+#define GSR_CURSOR_STRIDE 16      // cursors sit 64 B apart: the atomics of neighbouring tiles go to different lines
+#define GSR_COOP_AREA 8           // rectangles with more tiles than this are walked by the whole wave
+
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
     uint32_t* depth_key; uint32_t* order_in;
     const float* zb; uint32_t* trunc;      // speculative per-tile depth bounds of the native loop (nullable)
     const float* zbc; uint32_t* truncc; int sbx;   // the same per 4x4-tile superblock (max of its tiles): quick reject
+    // bin-by-tile path (nullable): per-tile append cursors and fixed-capacity bins of (depth bits << 32 | index)
+    uint32_t* tile_cursor; unsigned long long* bins;
     const float* means; const float* scales; float mod; const float* rots; const float* opac;
     const float* shs; const float* cov3D_pre; const float* colors_pre;
     const float* view; const float* proj; const float* campos;
@@ -140,8 +155,12 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     }
     const int idx = blockIdx.x * GSR_BLOCK + tid;
     const bool live = idx < a.P;
-    bool vis = false;
+    bool vis = false, coop = false, dropped = false;
     float3 p = make_float3(0.f, 0.f, 0.f);
+    TileTest tt = {};
+    int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
+    float zv = 0.f;
+    uint32_t cnt = 0;
 
     if (live) {
         a.radii[idx] = 0;
@@ -189,8 +208,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                     a.conic_op[idx] = make_float4(conic.x, conic.y, conic.z, opacity);
                     a.rects[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
                     // exact count of tiles this splat can change
-                    const TileTest tt = make_tile_test(pix, conic, opacity);
-                    uint32_t cnt = 0;
+                    tt = make_tile_test(pix, conic, opacity);
+                    rx0 = x0; ry0 = y0; rx1 = x1; ry1 = y1; zv = pview.z;
                     bool far_everywhere = false;
                     if (a.zb != nullptr) {
                         // behind the bound of every superblock the rectangle overlaps => behind every tile's bound
@@ -198,32 +217,89 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                         for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
                             for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, a.zbc[sy * a.sbx + sx]);
                         far_everywhere = pview.z > zc;
-                        if (far_everywhere)
-                            for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
-                                for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++)
-                                    if (a.truncc[sy * a.sbx + sx] == 0u) a.truncc[sy * a.sbx + sx] = 1u;   // (test first: ~10^4 lanes per flag)
+                        if (far_everywhere) dropped = true;
                     }
                     if (!far_everywhere) {
-                        uint32_t full = 0;
-                        for (int y = y0; y < y1; y++) {
-                            int lo, hi;
-                            row_span(tt, y, x0, x1, lo, hi);
-                            full += (uint32_t)max(0, hi - lo + 1);
-                            if (a.zb == nullptr) continue;
-                            // behind everything this tile needed last iteration (+ margin): speculatively dropped
-                            for (int x = lo; x <= hi; x++) cnt += (pview.z <= s_zb[y * a.gx + x]) ? 1u : 0u;
+                        if (a.bins != nullptr && (x1 - x0) * (y1 - y0) > GSR_COOP_AREA) coop = true;      // whole wave helps below
+                        else {
+                            uint32_t full = 0;
+                            for (int y = y0; y < y1; y++) {
+                                int lo, hi;
+                                row_span(tt, y, x0, x1, lo, hi);
+                                full += (uint32_t)max(0, hi - lo + 1);
+                                if (a.zb == nullptr) continue;
+                                // behind everything this tile needed last iteration (+ margin): speculatively dropped
+                                for (int x = lo; x <= hi; x++)
+                                    if (pview.z <= s_zb[y * a.gx + x]) {
+                                        cnt++;
+                                        if (a.bins != nullptr) {
+                                            const int tile = y * a.gx + x;
+                                            const uint32_t pos = atomicAdd(&a.tile_cursor[tile * GSR_CURSOR_STRIDE], 1u);
+                                            if (pos < GSR_LSORT_CAP)
+                                                a.bins[(size_t)tile * GSR_LSORT_CAP + pos] =
+                                                    ((unsigned long long)__float_as_uint(pview.z) << 32) | (uint32_t)idx;
+                                        }
+                                    }
+                            }
+                            if (a.zb == nullptr) cnt = full;
+                            else if (cnt != full) dropped = true;
                         }
-                        if (a.zb == nullptr) cnt = full;
-                        else if (cnt != full)      // something was dropped: remember it per superblock (test first: many lanes per flag)
-                            for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
-                                for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++)
-                                    if (a.truncc[sy * a.sbx + sx] == 0u) a.truncc[sy * a.sbx + sx] = 1u;
                     }
-                    a.tiles_touched[idx] = cnt;
-                    if (cnt) a.depth_key[idx] = __float_as_uint(pview.z);
                 }
             }
         }
+    }
+    if (a.bins != nullptr) {
+        // Large footprints: the 64 lanes of the wave walk the rectangle together (one tile per lane), so no lane
+        // is left issuing hundreds of dependent atomics on its own.
+        const int lane = tid & 63;
+        unsigned long long todo = __ballot(coop);
+        while (todo != 0ull) {
+            const int src = (int)__builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            TileTest bt;
+#define GSR_BCAST_F(v) __uint_as_float(__builtin_amdgcn_readlane((int)__float_as_uint(v), src))
+            bt.mx = GSR_BCAST_F(tt.mx); bt.my = GSR_BCAST_F(tt.my); bt.A = GSR_BCAST_F(tt.A); bt.B = GSR_BCAST_F(tt.B);
+            bt.C = GSR_BCAST_F(tt.C); bt.det = GSR_BCAST_F(tt.det); bt.twoq = GSR_BCAST_F(tt.twoq);
+            bt.dxe = GSR_BCAST_F(tt.dxe); bt.dye = GSR_BCAST_F(tt.dye); bt.invA = GSR_BCAST_F(tt.invA);
+            bt.cull = __builtin_amdgcn_readlane((int)tt.cull, src) != 0;
+            bt.none = __builtin_amdgcn_readlane((int)tt.none, src) != 0;
+            const float bz = GSR_BCAST_F(zv);
+#undef GSR_BCAST_F
+            const int bx0 = __builtin_amdgcn_readlane(rx0, src), by0 = __builtin_amdgcn_readlane(ry0, src);
+            const int bx1 = __builtin_amdgcn_readlane(rx1, src), by1 = __builtin_amdgcn_readlane(ry1, src);
+            const uint32_t bidx = (uint32_t)(blockIdx.x * GSR_BLOCK + (tid & ~63) + src);
+            const int bw = bx1 - bx0, area = bw * (by1 - by0);
+            uint32_t c_full = 0, c_cnt = 0;
+            for (int t0 = 0; t0 < area; t0 += 64) {
+                const int t = t0 + lane;
+                bool in_span = false, pass = false;
+                if (t < area) {
+                    const int y = by0 + t / bw, x = bx0 + (t - (t / bw) * bw);
+                    int lo, hi;
+                    row_span(bt, y, bx0, bx1, lo, hi);
+                    in_span = x >= lo && x <= hi;
+                    pass = in_span && bz <= s_zb[y * a.gx + x];
+                    if (pass) {
+                        const int tile = y * a.gx + x;
+                        const uint32_t pos = atomicAdd(&a.tile_cursor[tile * GSR_CURSOR_STRIDE], 1u);
+                        if (pos < GSR_LSORT_CAP)
+                            a.bins[(size_t)tile * GSR_LSORT_CAP + pos] = ((unsigned long long)__float_as_uint(bz) << 32) | bidx;
+                    }
+                }
+                c_full += (uint32_t)__popcll(__ballot(in_span));
+                c_cnt += (uint32_t)__popcll(__ballot(pass));
+            }
+            if (lane == src) { cnt = c_cnt; if (c_cnt != c_full) dropped = true; }
+        }
+    }
+    if (vis) {
+        if (dropped)       // something was dropped: remember it per superblock (test first: ~10^4 lanes per flag)
+            for (int sy = ry0 >> 2; sy <= (ry1 - 1) >> 2; sy++)
+                for (int sx = rx0 >> 2; sx <= (rx1 - 1) >> 2; sx++)
+                    if (a.truncc[sy * a.sbx + sx] == 0u) a.truncc[sy * a.sbx + sx] = 1u;
+        a.tiles_touched[idx] = cnt;
+        if (cnt) a.depth_key[idx] = __float_as_uint(zv);
     }
 }
 
@@ -375,9 +451,12 @@ struct SplatLDS {
     uint8_t list[4][GSR_BLOCK];   // per wave: staged splats that can touch its 8x8 block, in list order
 };
 
-template <bool TOUCHED>
-__global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restrict__ ranges,
-                                                          const uint32_t* __restrict__ point_list, int W, int H, int gx,
+template <bool TOUCHED, bool LOCALSORT>
+__global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(uint2* __restrict__ ranges,
+                                                          uint32_t* __restrict__ point_list,
+                                                          const unsigned long long* __restrict__ bins,
+                                                          const uint32_t* __restrict__ tile_cursor,
+                                                          int W, int H, int gx,
                                                           int ntiles, const float2* __restrict__ xy,
                                                           const float* __restrict__ rgb, const float* __restrict__ depths,
                                                           const float4* __restrict__ conic_op, const float* __restrict__ bg,
@@ -399,10 +478,39 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
     const bool inside = px < W && py < H;
     const int pix_id = W * py + px;
     const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile];
+    uint2 range;
+    if (LOCALSORT) {
+        range.x = (uint32_t)tile * GSR_LSORT_CAP;
+        range.y = range.x + tile_cursor[tile * GSR_CURSOR_STRIDE];
+    } else range = ranges[tile];
     const int total = (int)(range.y - range.x);
 
     const int lane = tid & 63, wv = tid >> 6;
+    __shared__ unsigned long long s_keys[LOCALSORT ? GSR_LSORT_CAP : 1];
+    if (LOCALSORT) {
+        // this tile's bin arrives unsorted: order it by (depth bits, index) in LDS (bitonic network), keep it there
+        // for the staging below and write the sorted indices (and the tile's range) back for the backward pass
+        if (total > GSR_LSORT_CAP) {          // block-uniform: give up, the host redoes the forward with global sorts
+            if (tid == 0) atomicAdd(fail, 0x10000u);
+            return;
+        }
+        if (tid == 0) ranges[tile] = range;
+        int npow = 64;
+        while (npow < total) npow <<= 1;
+        for (int i = tid; i < npow; i += GSR_BLOCK) s_keys[i] = (i < total) ? bins[range.x + i] : ~0ull;
+        __syncthreads();
+        for (int k = 2; k <= npow; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int q = tid; q < (npow >> 1); q += GSR_BLOCK) {      // one compare-exchange per lane
+                    const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
+                    const unsigned long long a0 = s_keys[i], a1 = s_keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a0 > a1) == up) { s_keys[i] = a1; s_keys[l] = a0; }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < total; i += GSR_BLOCK) point_list[range.x + i] = (uint32_t)s_keys[i];
+    }
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f;
     uint32_t last_contributor = 0;
@@ -412,7 +520,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(const uint2* __restric
         if (__syncthreads_and(done)) break;
         const int n = min(GSR_BLOCK, total - base);
         if (tid < n) {
-            const uint32_t id = point_list[range.x + base + tid];
+            const uint32_t id = LOCALSORT ? (uint32_t)s_keys[base + tid] : point_list[range.x + base + tid];
             const float2 m = xy[id];
             const float4 co = conic_op[id];
             s.a[tid] = make_float4(m.x, m.y, co.x, co.y);

@@ -15,13 +15,18 @@ vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); v
 init = torch.tensor(S.se3_exp([0.01, 0.01, 0.01, 0.01, 0.0, 0.0]), dtype=torch.float32, device=dev)
 fr = PL.FusedRefiner(model, H, W, device=dev)
 nk = lib.gsr_profile_kernel_count(); names = [lib.gsr_profile_kernel_name(i).decode() for i in range(nk)]
+import time
 for ab, spec in [(0, False), (0, True), (0, False), (0, True)]:
     lib.gsr_debug_ablate(ab)
     fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False, speculative=spec)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=100, stop_on_converged=False, speculative=spec)
+    torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / 100
+    info = dict(fr.last_info)
     lib.gsr_profile_enable((1 << nk) - 1)
     fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=40, stop_on_converged=False, speculative=spec)
     torch.cuda.synchronize()
     ms = (C.c_double * nk)(); cnt = (C.c_longlong * nk)(); lib.gsr_profile_collect(ms, cnt); lib.gsr_profile_enable(0)
-    d = {names[i]: round(ms[i] / max(cnt[i], 1), 4) for i in range(nk)}
-    print("spec", spec, d, flush=True)
+    d = {names[i]: round(ms[i] / 40, 4) for i in range(nk)}        # ms per iteration (all launches of that kernel)
+    print("spec", spec, "wall ms/iter %.4f" % (wall * 1e3), info, d, "sum %.4f" % sum(d.values()), flush=True)
 lib.gsr_debug_ablate(0)
