@@ -23,6 +23,7 @@ SIGNATURES = {
     "gsr_forward_stats": (_i, [_i, _i, _i, _vp, _vp, _vp, C.POINTER(C.c_longlong), _vp]),
     "gsr_profile_enable": (_i, [C.c_uint]),
     "gsr_debug_ablate": (_i, [_i]),
+    "gsr_debug_timing": (_i, [C.POINTER(C.c_ulonglong)]),
     "gsr_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "gsr_profile_kernel_count": (_i, []),
     "gsr_profile_kernel_name": (C.c_char_p, [_i]),

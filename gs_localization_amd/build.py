@@ -25,6 +25,8 @@ def build(force=False, verbose=False):
            # its own (iterative) cross-lane reduction loop
            "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
            "-I" + os.path.join(_ROOT, "include"), "-o", OUT, SRC]
+    if os.environ.get("GSR_TIMING"):      # diagnostic build: per-phase clocks inside the compositing kernels
+        cmd.insert(1, "-DGSR_TIMING=1")
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -224,6 +224,8 @@ thread_local bool tl_native_loop = false;
 // iteration recorded and record new ones, 2 = bin everything but record bounds.  parity picks the buffer.
 struct SpecCtx { int mode = 0; int parity = 0; float mul = 1.05f, add = 0.05f; bool local_sort = true; };
 thread_local SpecCtx tl_spec;
+// device-side guards of the native loop (see LoopGuard); {nullptr, nullptr} outside gsr_refine
+thread_local gsr::LoopGuard tl_guard = {nullptr, nullptr};
 thread_local int g_dev = 0;      // device chosen by the last select_device_of on this thread
 
 // One side stream + a fork/join event pair per device: independent work (SH colours, zero fills) runs next to
@@ -269,6 +271,27 @@ extern "C" {
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
 int gsr_debug_ablate(int bits) { g_ablate = bits; return 0; }
+
+// diagnostic builds only (GSR_TIMING): copies the 32 phase counters out and clears them; -1 in product builds
+int gsr_debug_timing(unsigned long long* out32)
+{
+#if GSR_TIMING
+    static std::vector<unsigned long long> h((size_t)2 * GSR_TIM_WAVES * 12);
+    if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(gsr::g_tim), h.size() * 8) != hipSuccess) return -2;
+    for (int k = 0; k < 2; k++)
+        for (int q = 0; q < 12; q++) {
+            unsigned long long sum = 0;
+            for (size_t w = 0; w < GSR_TIM_WAVES; w++) sum += h[((size_t)k * GSR_TIM_WAVES + w) * 12 + q];
+            out32[k * 16 + q] = sum;
+        }
+    std::fill(h.begin(), h.end(), 0ull);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_tim), h.data(), h.size() * 8) != hipSuccess) return -2;
+    return 0;
+#else
+    (void)out32;
+    return -1;
+#endif
+}
 
 int gsr_profile_enable(unsigned mask)
 {
@@ -375,6 +398,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     pa.radii = radii; pa.xy = g.xy; pa.depths = g.depths; pa.cov3D = g.cov3D; pa.rgb = g.rgb; pa.conic_op = g.conic_op;
     pa.clamped = g.clamped; pa.tiles_touched = g.tiles_touched; pa.rects = g.rects;
     pa.depth_key = g.depth_key; pa.order_in = g.order_in;
+    pa.guard = tl_guard;
     const float* zb_prev = (tl_spec.mode == 1) ? im.zb[tl_spec.parity ^ 1] : nullptr;
     float* zb_next = (tl_spec.mode != 0) ? im.zb[tl_spec.parity] : nullptr;
     pa.zb = zb_prev; pa.trunc = zb_prev ? im.trunc : nullptr;
@@ -400,8 +424,10 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
         hipLaunchKernelGGL(k_preprocess, dim3(pblocks), dim3(GSR_BLOCK), zb_prev ? (size_t)ntiles * sizeof(float) : 0, st, pa);
     }
     LAUNCHCHK("k_preprocess");
-    // SH colours only feed the compositing kernel: fork them onto the side stream, join before K6
-    Side* side = (colors_precomp == nullptr && !debug) ? get_side() : nullptr;
+    // SH colours only feed the compositing kernel: fork them onto the side stream, join before K6.  (Not on the
+    // bin-by-tile path: without the sort chain there is nothing latency-bound to hide them under, and the
+    // fork/join costs more than it gains -- measured 0.466 vs 0.434 ms per iteration.)
+    Side* side = (colors_precomp == nullptr && !debug && !local_path) ? get_side() : nullptr;
     if (colors_precomp == nullptr) {
         if (side) {
             HIPCHK(hipEventRecord(side->fork, st));
@@ -494,8 +520,8 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
 #define GSR_FWD_ARGS im.ranges, local_path ? bl.vals : b.vals, (const unsigned long long*)bl.bins, (const uint32_t*)im.tile_cursor, \
                      width, height, gx, ntiles, (const float2*)g.xy, feat, \
                      (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
-                     zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), im.fail, tl_spec.mul, tl_spec.add, zbc_next, \
-                     (const uint32_t*)im.truncc, im.sbx
+                     zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), tl_guard.poison ? const_cast<uint32_t*>(tl_guard.poison) : im.fail, tl_spec.mul, tl_spec.add, zbc_next, \
+                     (const uint32_t*)im.truncc, im.sbx, (g_ablate >> 12) & 0xf
     if (local_path) {
         if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
         else hipLaunchKernelGGL((k_render_fwd<false, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
@@ -579,11 +605,11 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
                      (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas, (const uint32_t*)im.n_contrib, dL_dpix, \
                      dL_ddepths, dL_dalphas, g.acc
     if (bwd_variant == 1 && (g_ablate & 0xff) == 0) {
-        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS);
-        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS);
+        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, tl_guard);
+        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, tl_guard);
     } else {
-        if (pose_mode) hipLaunchKernelGGL(k_render_bwd<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, g_ablate & 0xff);
-        else hipLaunchKernelGGL(k_render_bwd<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, g_ablate & 0xff);
+        if (pose_mode) hipLaunchKernelGGL(k_render_bwd<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, g_ablate & 0xff, tl_guard);
+        else hipLaunchKernelGGL(k_render_bwd<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, g_ablate & 0xff, tl_guard);
     }
     delete psb;
     LAUNCHCHK("k_render_bwd");
@@ -601,6 +627,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale; pb.dL_drot = dL_drot;
     pb.pose = pose_mode ? 1 : 0; pb.tau_acc = g.tau_acc;
     pb.dirty = tl_native_loop ? g.dirty : nullptr;
+    pb.guard = tl_guard;
     {
         ProfScope ps(K_PREPROCESS_BWD, st);
         hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, pb);
@@ -627,8 +654,9 @@ int gsr_tracking_loss(int width, int height, const float* image, const float* de
         return fail(GSR_E_INVALID, "gsr_tracking_loss: NULL pointer%s", "");
     int rc = select_device_of(image);
     if (rc != GSR_OK) return rc;
-    HIPCHK(hipMemsetAsync(out, 0, 4 * sizeof(float), st));
+    if (!tl_native_loop) HIPCHK(hipMemsetAsync(out, 0, 4 * sizeof(float), st));      // (the native loop's pose step clears it)
     LossArgs la;
+    la.guard = tl_guard;
     la.W = width; la.H = height; la.image = image; la.depth = depth; la.opacity = opacity; la.gt_image = gt_image;
     la.gt_depth = gt_depth; la.grad_mask = grad_mask; la.exposure = exposure; la.opacity_thr = opacity_threshold;
     la.depth_w = depth_weight; la.monocular = monocular; la.dL_dimage = dL_dimage; la.dL_ddepth = dL_ddepth;
@@ -661,7 +689,8 @@ int gsr_pose_step(float* pose_state, const float* dL_dtau, const float* loss_out
     int rc = select_device_of(pose_state);
     if (rc != GSR_OK) return rc;
     hipLaunchKernelGGL(gsr::k_pose_step, dim3(1), dim3(64), 0, st, pose_state, dL_dtau, (const double*)nullptr,
-                       (float*)nullptr, loss_out, projmatrix_raw, lr, converged_threshold);
+                       (float*)nullptr, loss_out, projmatrix_raw, lr, converged_threshold, (float*)nullptr,
+                       gsr::LoopGuard{nullptr, nullptr});
     LAUNCHCHK("k_pose_step");
     return 0;
 }
@@ -691,16 +720,27 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     hipStream_t st = (hipStream_t)a->stream;
     int rc = select_device_of(a->pose_state);
     if (rc != GSR_OK) return rc;
-    static thread_local int* h_flag = nullptr;           // pinned: the convergence flag rides on forward's own sync
-    if (!h_flag) HIPCHK(hipHostMalloc((void**)&h_flag, 4 * sizeof(float)));
-    float* h_f = reinterpret_cast<float*>(h_flag);
+    // Pinned status slots (one per iteration parity): {converged, loss, |tau|, poison} copied out behind each
+    // iteration, and the events that say when a slot is valid.
+    static thread_local float* h_status = nullptr;
+    static thread_local hipEvent_t ev_status[2] = {nullptr, nullptr};
+    if (!h_status) {
+        HIPCHK(hipHostMalloc((void**)&h_status, 2 * 4 * sizeof(float)));
+        HIPCHK(hipEventCreateWithFlags(&ev_status[0], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_status[1], hipEventDisableTiming));
+    }
     CachedBuf gb{a->geometry_buffer, a->geometry_ctx, nullptr, 0}, bb{a->binning_buffer, a->binning_ctx, nullptr, 0},
         ib{a->image_buffer, a->image_ctx, nullptr, 0};
     float* ps = a->pose_state;
     *iters_done = 0;
     *converged = 0;
-    h_f[0] = 0.f;
-    struct FlagGuard { FlagGuard() { tl_native_loop = true; } ~FlagGuard() { tl_native_loop = false; tl_spec.mode = 0; } } guard;
+    struct FlagGuard {
+        FlagGuard() { tl_native_loop = true; }
+        ~FlagGuard() { tl_native_loop = false; tl_spec.mode = 0; tl_guard = LoopGuard{nullptr, nullptr}; }
+    } guard;
+    uint32_t* poison = reinterpret_cast<uint32_t*>(ps + GSR_PS_POISON);
+    tl_guard.poison = poison;
+    tl_guard.conv = a->stop_on_converged ? ps + GSR_PS_CONV : nullptr;
     int n_fallbacks = 0, last_R = 0, fail_streak = 0, spec_resume = 0;
     bool last_local = false;
     {   // gradient tensors: zero-filled once per call, then maintained row by row (PreBwdArgs::dirty)
@@ -716,77 +756,114 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (a->dL_dsh && a->M > 0) HIPCHK(hipMemsetAsync(a->dL_dsh, 0, Pn * a->M * 3 * sizeof(float), st));
         if (a->dL_dscale) HIPCHK(hipMemsetAsync(a->dL_dscale, 0, Pn * 3 * sizeof(float), st));
         if (a->dL_drot) HIPCHK(hipMemsetAsync(a->dL_drot, 0, Pn * 4 * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(ps + GSR_PS_CONV, 0, 4 * sizeof(float), st));      // converged, loss, |tau|, poison
+        HIPCHK(hipMemsetAsync(a->loss_out, 0, 4 * sizeof(float), st));
     }
+    static_assert(GSR_PS_POISON == GSR_PS_CONV + 3, "status words are copied out as one block");
     bool dirty_cleared = false;
     const int debug = 0;
-    for (int it = 0; it < a->max_iters; it++) {
-        // convergence flag of the previous iteration: async copy, completed by gsr_forward's num_rendered sync
-        HIPCHK(hipMemcpyAsync(h_f, ps + GSR_PS_CONV, sizeof(float), hipMemcpyDeviceToHost, st));
-        auto fwd = [&]() {
-            return gsr_forward(cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
-                               a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
-                               a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
-                               a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, a->n_touched, a->stream);
-        };
-        // Speculative binning: from the second iteration on, instances lying behind what their tile needed in
-        // the previous iteration (x margin) are not binned; the compositing kernel verifies the speculation and
-        // a failed one is redone with complete lists, so results never depend on it.
-        tl_spec.mode = a->speculative ? ((it == 0 || it < spec_resume) ? 2 : 1) : 0;
+    if (a->bound_margin_mul > 0.f) { tl_spec.mul = a->bound_margin_mul; tl_spec.add = a->bound_margin_add; }
+
+    // One iteration = forward, tracking loss, backward, Adam + update_pose, all enqueued without waiting for the
+    // device (the non-speculative forward still reads its instance count back, as the reference does).  Behind
+    // it, the status words are copied to the slot of the iteration's parity.
+    int slot_mode[2] = {0, 0};
+    auto enqueue = [&](int it, int mode) -> int {
+        slot_mode[it & 1] = mode;
+        tl_spec.mode = mode;
         tl_spec.parity = it & 1;
-        if (a->bound_margin_mul > 0.f) { tl_spec.mul = a->bound_margin_mul; tl_spec.add = a->bound_margin_add; }
-        int R = fwd();
-        if (R < 0) { tl_spec.mode = 0; return R; }
-        if (tl_spec.mode == 1) {
-            // the bin-by-tile forward does not synchronise; this read-back does (and completes the flag copy above)
-            Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
-            uint32_t* h_fail = reinterpret_cast<uint32_t*>(h_flag) + 2;
-            HIPCHK(hipMemcpyAsync(h_fail, imv.fail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
-            if (*h_fail != 0u) {
-                n_fallbacks++;
-                if (getenv("GSR_DEBUG_TILES")) {
-                    const int nt = ((a->width + 15) / 16) * ((a->height + 15) / 16);
-                    std::vector<uint32_t> tc((size_t)nt * GSR_CURSOR_STRIDE);
-                    (void)hipMemcpy(tc.data(), imv.tile_cursor, tc.size() * 4, hipMemcpyDeviceToHost);
-                    uint32_t mx = 0, over = 0; unsigned long long sum = 0;
-                    for (int i = 0; i < nt; i++) { const uint32_t c = tc[(size_t)i * GSR_CURSOR_STRIDE]; mx = c > mx ? c : mx; over += c > GSR_LSORT_CAP; sum += c; }
-                    fprintf(stderr, "[gsr] it %d fail=0x%x: bin fill max %u, over capacity %u of %d, sum %llu\n", it, *h_fail, mx, over, nt, sum);
-                }
-                tl_spec.mode = 2;
-                R = fwd();
-                if (R < 0) { tl_spec.mode = 0; return R; }
-                // back off: a scene whose lists stay long after culling would otherwise pay for both forwards every time
-                fail_streak++;
-                if (fail_streak >= 2) spec_resume = it + 1 + (1 << (fail_streak < 6 ? fail_streak : 6));
-            } else fail_streak = 0;
-        }
-        if (it > 0 && a->stop_on_converged && h_f[0] != 0.f) { *converged = 1; tl_spec.mode = 0; break; }   // reference: `if converged: break`
+        int R = gsr_forward(cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
+                            a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
+                            a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
+                            a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, a->n_touched, a->stream);
         tl_spec.mode = 0;
+        if (R < 0) return R;
         last_R = R;
-        last_local = (R == 0);      // the bin-by-tile forward does not bring its instance count to the host
+        last_local = (mode == 1);      // the bin-by-tile forward does not bring its instance count to the host
         if (!dirty_cleared) {
             Geom gg; carve_geom((char*)gb.ptr, a->P, gg);
             HIPCHK(hipMemsetAsync(gg.dirty, 0, (size_t)a->P, st));
             dirty_cleared = true;
         }
-        rc = gsr_tracking_loss(a->width, a->height, a->out_color, a->out_depth, a->out_alpha, a->gt_image, a->gt_depth,
-                               a->grad_mask, ps + GSR_PS_PARAM + 6, a->opacity_threshold, a->depth_weight, a->monocular,
-                               a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->loss_out, a->stream);
-        if (rc < 0) return rc;
-        rc = gsr_backward(a->P, a->D, a->M, R, a->background, a->width, a->height, a->means3D, a->shs, nullptr, a->out_alpha,
-                          a->scales, a->scale_modifier, a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ,
-                          ps + GSR_PS_CAMPOS, a->tan_fovx, a->tan_fovy, a->radii, (char*)gb.ptr, (char*)bb.ptr, (char*)ib.ptr,
-                          a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor,
-                          a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, 0, 1, a->dL_dtau, a->stream);
-        if (rc < 0) return rc;
+        int rc2 = gsr_tracking_loss(a->width, a->height, a->out_color, a->out_depth, a->out_alpha, a->gt_image, a->gt_depth,
+                                    a->grad_mask, ps + GSR_PS_PARAM + 6, a->opacity_threshold, a->depth_weight, a->monocular,
+                                    a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->loss_out, a->stream);
+        if (rc2 < 0) return rc2;
+        rc2 = gsr_backward(a->P, a->D, a->M, R, a->background, a->width, a->height, a->means3D, a->shs, nullptr, a->out_alpha,
+                           a->scales, a->scale_modifier, a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ,
+                           ps + GSR_PS_CAMPOS, a->tan_fovx, a->tan_fovy, a->radii, (char*)gb.ptr, (char*)bb.ptr, (char*)ib.ptr,
+                           a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor,
+                           a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, 0, 1, a->dL_dtau, a->stream);
+        if (rc2 < 0) return rc2;
         {   // Adam + update_pose; also finishes the fp64 dL/dtau reduction left open by the backward
             Geom gg; carve_geom((char*)gb.ptr, a->P, gg);
             hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(64), 0, st, ps, (const float*)a->dL_dtau, (const double*)gg.tau_acc,
-                               a->dL_dtau, (const float*)a->loss_out, a->projmatrix_raw, a->lr, a->converged_threshold);
+                               a->dL_dtau, (const float*)a->loss_out, a->projmatrix_raw, a->lr, a->converged_threshold,
+                               a->loss_out, tl_guard);
             LAUNCHCHK("k_pose_step");
         }
-        *iters_done = it + 1;
+        HIPCHK(hipMemcpyAsync(h_status + 4 * (it & 1), ps + GSR_PS_CONV, 4 * sizeof(float), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipEventRecord(ev_status[it & 1], st));
+        return 0;
+    };
+    // Wait for iteration `it`'s status.  A poisoned iteration (failed speculation: its loss, backward and pose step
+    // and everything enqueued behind it were skipped on the device) is redone here with complete lists.
+    auto settle = [&](int it, bool& conv_out) -> int {
+        HIPCHK(hipEventSynchronize(ev_status[it & 1]));
+        const float* hs = h_status + 4 * (it & 1);
+        uint32_t pz; memcpy(&pz, hs + 3, sizeof(pz));
+        if (pz != 0u) {
+            n_fallbacks++;
+            HIPCHK(hipStreamSynchronize(st));
+            if (getenv("GSR_DEBUG_TILES")) fprintf(stderr, "[gsr] iteration %d: speculation failed (0x%x), redone\n", it, pz);
+            HIPCHK(hipMemsetAsync(poison, 0, sizeof(uint32_t), st));
+            int rc2 = enqueue(it, 2);
+            if (rc2 < 0) return rc2;
+            HIPCHK(hipEventSynchronize(ev_status[it & 1]));
+            // back off: a scene whose lists stay long after culling would otherwise pay for both forwards every time
+            fail_streak++;
+            if (fail_streak >= 2) spec_resume = it + 1 + (1 << (fail_streak < 6 ? fail_streak : 6));
+            conv_out = hs[0] != 0.f;
+            return 1;       // redone: whatever was enqueued behind it was skipped and must be enqueued again
+        }
+        if (slot_mode[it & 1] == 1) fail_streak = 0;
+        conv_out = hs[0] != 0.f;
+        return 0;
+    };
+    // Speculative binning: from the second iteration on, instances lying behind what their tile needed in the
+    // previous iteration (x margin) are not binned; the compositing kernel verifies the speculation and a failed
+    // one is redone with complete lists, so results never depend on it.
+    auto mode_of = [&](int it) { return a->speculative ? ((it == 0 || it < spec_resume) ? 2 : 1) : 0; };
+    int it = 0, settled = -1;
+    bool prev_pending = false;
+    while (it < a->max_iters) {
+        rc = enqueue(it, mode_of(it));
+        if (rc < 0) return rc;
+        if (prev_pending && settled < it - 1) {
+            bool conv = false;
+            rc = settle(it - 1, conv);
+            if (rc < 0) return rc;
+            settled = it - 1;
+            if (a->stop_on_converged && conv) {
+                // reference: `if converged: break` -- the forward of iteration `it` has been rendered at the final
+                // pose; its update was frozen on the device.  (After a redo it was skipped: render it again.)
+                if (rc == 1) { rc = enqueue(it, mode_of(it)); if (rc < 0) return rc; }
+                *converged = 1;
+                break;
+            }
+            if (rc == 1) continue;      // iteration `it` was skipped on the device: enqueue it again
+        }
+        prev_pending = true;
+        it++;
+        *iters_done = it;
     }
+    if (!*converged && prev_pending && it > 0 && settled < it - 1) {      // the last iteration's status
+        bool conv = false;
+        rc = settle(it - 1, conv);
+        if (rc < 0) return rc;
+        if (a->stop_on_converged && conv) *converged = 1;
+    }
+    HIPCHK(hipStreamSynchronize(st));
     if (a->stats_out) {
         if (last_local && ib.ptr) {      // instances binned by the last forward = sum of the tile cursors
             Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
@@ -799,11 +876,6 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             last_R = (int)sum;
         }
         a->stats_out[0] = n_fallbacks; a->stats_out[1] = last_R;
-    }
-    if (!*converged && a->stop_on_converged) {
-        HIPCHK(hipMemcpyAsync(h_f, ps + GSR_PS_CONV, sizeof(float), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        *converged = h_f[0] != 0.f ? 1 : 0;
     }
     return 0;
 }

@@ -5,6 +5,38 @@
 
 namespace gsr {
 
+// Diagnostic builds (GSR_TIMING=1 python gs_localization_amd/build.py): per-phase shader-clock totals of the two
+// compositing kernels, summed over waves (lane 0 of each wave keeps the running totals in scalar registers and
+// flushes them once at the end).  Read back with gsr_debug_timing(); slots 0-15 = K6, 16-31 = K7.
+#ifndef GSR_TIMING
+#define GSR_TIMING 0
+#endif
+#if GSR_TIMING
+#define GSR_TIM_WAVES (16384 * 4)
+__device__ unsigned long long g_tim[2][GSR_TIM_WAVES][12];      // [kernel][wave][slot]: every wave owns its row, no atomics
+#define GSR_T_DECL long long t_prev_ = clock64(); const long long t_start_ = t_prev_; long long t_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+#define GSR_T_TICK(slot) { const long long now_ = clock64(); t_acc_[slot] += now_ - t_prev_; t_prev_ = now_; }
+#define GSR_T_COUNT(slot, v) { t_acc_[slot] += (v); }
+#define GSR_T_FLUSH(base) t_acc_[9] = clock64() - t_start_; if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < GSR_TIM_WAVES) { for (int q_ = 0; q_ < 12; q_++) g_tim[(base) / 16][blockIdx.x * 4 + (threadIdx.x >> 6)][q_] += (unsigned long long)t_acc_[q_]; }
+#else
+#define GSR_T_DECL
+#define GSR_T_TICK(slot)
+#define GSR_T_COUNT(slot, v)
+#define GSR_T_FLUSH(base)
+#endif
+
+// Device-side guards of the native refinement loop (gsr_refine).  The host enqueues iteration i+1 before it has
+// seen iteration i's flags, so every kernel of the loop checks them itself:
+//   poison != 0 : a speculative forward failed its verification; everything downstream is skipped until the
+//                 host has redone that iteration with complete lists,
+//   conv   != 0 : the pose update already converged; loss, backward and pose step are skipped (frozen).
+// Both pointers are NULL outside the native loop.
+struct LoopGuard {
+    const uint32_t* poison; const float* conv;
+    __device__ __forceinline__ bool poisoned() const { return poison != nullptr && *poison != 0u; }
+    __device__ __forceinline__ bool frozen() const { return poisoned() || (conv != nullptr && *conv != 0.f); }
+};
+
 // ---------------------------------------------------------------------------------------------
 // K1  per-Gaussian preprocess (replaces forward.cu:155-256 preprocessCUDA).
 // One lane per Gaussian; HBM-streaming: reads 44+12M B, writes <= 80 B per Gaussian.
@@ -91,6 +123,7 @@ struct PreArgs {
     const float* zbc; uint32_t* truncc; int sbx;   // the same per 4x4-tile superblock (max of its tiles): quick reject
     // bin-by-tile path (nullable): per-tile append cursors and fixed-capacity bins of (depth bits << 32 | index)
     uint32_t* tile_cursor; unsigned long long* bins;
+    LoopGuard guard;
     const float* means; const float* scales; float mod; const float* rots; const float* opac;
     const float* shs; const float* cov3D_pre; const float* colors_pre;
     const float* view; const float* proj; const float* campos;
@@ -149,6 +182,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 {
     extern __shared__ float s_zb[];      // native loop: the per-tile depth bounds (gx*gy floats), else unused
     const int tid = threadIdx.x;
+    if (a.guard.poisoned()) return;
     if (a.zb != nullptr) {
         for (int i = tid; i < a.gx * a.gy; i += GSR_BLOCK) s_zb[i] = a.zb[i];
         __syncthreads();
@@ -312,6 +346,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_sh_color(PreArgs a)
     __shared__ uint8_t s_vis[GSR_BLOCK];
     const int tid = threadIdx.x;
     const int idx = blockIdx.x * GSR_BLOCK + tid;
+    if (a.guard.poisoned()) return;
     // only splats that were binned into at least one tile can ever be composited (this also skips everything
     // the native loop's speculative depth bounds dropped)
     const bool vis = idx < a.P && a.tiles_touched[idx] > 0;
@@ -465,9 +500,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(uint2* __restrict__ ra
                                                           int* __restrict__ n_touched, float* __restrict__ zb_next,
                                                           const uint32_t* __restrict__ trunc, uint32_t* __restrict__ fail,
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
-                                                          const uint32_t* __restrict__ truncc, int sbx)
+                                                          const uint32_t* __restrict__ truncc, int sbx, int ablate)
 {
     __shared__ SplatLDS s;
+    GSR_T_DECL
     __shared__ float s_zmax[4];
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
@@ -499,7 +535,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(uint2* __restrict__ ra
         while (npow < total) npow <<= 1;
         for (int i = tid; i < npow; i += GSR_BLOCK) s_keys[i] = (i < total) ? bins[range.x + i] : ~0ull;
         __syncthreads();
-        for (int k = 2; k <= npow; k <<= 1)
+        GSR_T_TICK(0)
+        for (int k = 2; k <= npow && !(ablate & 2); k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int q = tid; q < (npow >> 1); q += GSR_BLOCK) {      // one compare-exchange per lane
                     const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
@@ -511,6 +548,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(uint2* __restrict__ ra
             }
         for (int i = tid; i < total; i += GSR_BLOCK) point_list[range.x + i] = (uint32_t)s_keys[i];
     }
+    GSR_T_TICK(1)
     bool done = !inside;
     float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f;
     uint32_t last_contributor = 0;
@@ -518,8 +556,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(uint2* __restrict__ ra
 
     for (int base = 0; base < total; base += GSR_BLOCK) {
         if (__syncthreads_and(done)) break;
+        GSR_T_TICK(2)
+        GSR_T_COUNT(10, 1)
         const int n = min(GSR_BLOCK, total - base);
-        if (tid < n) {
+        if (tid < n && !(ablate & 8)) {
             const uint32_t id = LOCALSORT ? (uint32_t)s_keys[base + tid] : point_list[range.x + base + tid];
             const float2 m = xy[id];
             const float4 co = conic_op[id];
@@ -529,6 +569,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(uint2* __restrict__ ra
             s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], __uint_as_float(qm));
         }
         __syncthreads();
+        GSR_T_TICK(3)
         // this wave's compacted list (order preserved)
         int cnt = 0;
         for (int c0 = 0; c0 < n; c0 += 64) {
@@ -538,8 +579,11 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(uint2* __restrict__ ra
             if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
             cnt += (int)__popcll(mk);
         }
+        if (ablate & 1) cnt = 0;
+        GSR_T_TICK(4)
         for (int k = 0; k < cnt; k++) {
             if (__all(done)) break;                // whole wave finished: stop early
+            GSR_T_COUNT(11, 1)
             const int j = __builtin_amdgcn_readfirstlane((int)s.list[wv][k]);
             const float4 A = s.a[j];
             const float4 B = s.b[j];
@@ -558,19 +602,22 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(uint2* __restrict__ ra
                 T = test_T;
                 last_contributor = (uint32_t)(base + j + 1);      // 1-based position in the tile list
             }
-            if (TOUCHED) {
+            if (TOUCHED && !(ablate & 4)) {
                 // pose package: count pixels where the splat was blended with T still > 0.5;
                 // one atomic per wave instead of one per pixel
                 const unsigned long long m = __ballot(valid && test_T > 0.5f);
                 if (m != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(B.w)], (int)__popcll(m));
             }
         }
+        GSR_T_TICK(5)
     }
+    GSR_T_TICK(6)
     if (zb_next != nullptr) {
         // Native loop bookkeeping: how deep did this tile have to look?  Next iteration's binning drops what
         // lies behind that (plus a margin); if a pixel is still unsaturated at the end of a list from which
         // entries were dropped, the speculation failed and the host redoes this forward with full lists.
         const int unfinished = __syncthreads_or(inside && !done);
+        GSR_T_TICK(8)
         float zm = inside ? zneed : 0.f;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) zm = fmaxf(zm, __shfl_xor(zm, off, 64));
@@ -582,7 +629,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(uint2* __restrict__ ra
             zb_next[tile] = bound;
             const int sb = (ty >> 2) * sbx + (tx >> 2);
             atomicMax(reinterpret_cast<int*>(zbc_next) + sb, __float_as_int(bound));     // bounds are >= 0: int order = float order
-            if (unfinished && trunc != nullptr && truncc[sb] != 0u) atomicAdd(fail, 1u);
+            if (unfinished && trunc != nullptr && truncc[sb] != 0u && !ablate) atomicAdd(fail, 1u);
         }
     }
     if (inside) {
@@ -594,6 +641,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(uint2* __restrict__ ra
         out_alpha[pix_id] = 1.f - T;
         out_depth[pix_id] = Dd;
     }
+    GSR_T_TICK(7)
+    GSR_T_FLUSH(0)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -626,9 +675,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
                                                           const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
                                                           const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
                                                           const float* __restrict__ dL_dalphas, float* __restrict__ acc,
-                                                          int ablate)
+                                                          int ablate, LoopGuard guard)
 {
     __shared__ BwdLDS s;
+    if (guard.frozen()) return;
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -786,16 +836,19 @@ struct BwdMfmaLDS {
 };
 
 template <bool POSE>
-__global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd_mfma(const uint2* __restrict__ ranges,
+__global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ point_list, int W, int H, int gx,
                                                                int ntiles, const float* __restrict__ bg,
                                                                const float2* __restrict__ xy, const float4* __restrict__ conic_op,
                                                                const float* __restrict__ rgb, const float* __restrict__ depths,
                                                                const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
                                                                const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
-                                                               const float* __restrict__ dL_dalphas, float* __restrict__ acc)
+                                                               const float* __restrict__ dL_dalphas, float* __restrict__ acc,
+                                                               LoopGuard guard)
 {
     __shared__ BwdMfmaLDS s;
+    if (guard.frozen()) return;
+    GSR_T_DECL
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -844,8 +897,11 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd_mfma(const uint2* __re
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const int arow = (lane >> 4), acol = (lane & 15);
 
+    GSR_T_TICK(0)
     for (int base = 0; base < total; base += GSR_BWD_BATCH) {
         __syncthreads();
+        GSR_T_TICK(1)
+        GSR_T_COUNT(10, 1)
         const int n = min(GSR_BWD_BATCH, total - base);
         if (tid < n) {
             const uint32_t id = point_list[range.x + (total - 1 - base - tid)];
@@ -861,6 +917,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd_mfma(const uint2* __re
             for (int q = 0; q < 10; q++) s.acc[tid][q] = 0.f;
         }
         __syncthreads();
+        GSR_T_TICK(2)
         int cnt = 0;
         for (int c0 = 0; c0 < n; c0 += 64) {
             const int jj = c0 + lane;
@@ -870,6 +927,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd_mfma(const uint2* __re
             if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
             cnt += (int)__popcll(mk);
         }
+        GSR_T_TICK(3)
+        GSR_T_COUNT(11, cnt)
         for (int g0 = 0; g0 < cnt; g0 += 8) {
             float* row = wt + lane * GSR_WT_STRIDE;
             // the 8 list entries of this group in one 8-byte LDS read -> scalar registers, so that the splat
@@ -914,6 +973,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd_mfma(const uint2* __re
             }
             // S[16 rows = {W1,W2} x 8 splats][16 cols] += W[rows][4 pixels] * g[4 pixels][cols], 16 steps
             // (two accumulators: the 16x16x4 f32 MFMA issues every 32 cycles but a dependent one waits 40)
+            GSR_T_TICK(4)
             gsr_f32x4 D = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {
@@ -933,8 +993,11 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd_mfma(const uint2* __re
                     if (g0 + sidx < cnt && D[r] != 0.f) atomicAdd(&s.acc[s.list[wv][g0 + sidx]][acol], D[r]);
                 }
             }
+            GSR_T_TICK(5)
         }
+        GSR_T_TICK(6)
         __syncthreads();
+        GSR_T_TICK(7)
         // per staged splat: recombine the moments into the nine (ten) gradient sums, one run of atomics each
         if (tid < n) {
             const float* q = s.acc[tid];
@@ -959,7 +1022,9 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd_mfma(const uint2* __re
                 if (POSE) atomicAdd(dst + 9, q[3]);
             }
         }
+        GSR_T_TICK(8)
     }
+    GSR_T_FLUSH(16)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -981,6 +1046,7 @@ struct PreBwdArgs {
     // iteration to the next: bit 0 = this Gaussian's small gradient rows hold values, bit 1 = its dL_dsh row does.
     // A row is re-zeroed only when it held values and gets none this time, instead of 300 MB of memsets per call.
     uint8_t* dirty;
+    LoopGuard guard;
 };
 
 __device__ __forceinline__ float3 dnormvdv3(float3 v, float3 dv)
@@ -1107,6 +1173,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
     const int tid = threadIdx.x;
     const int idx = blockIdx.x * GSR_BLOCK + tid;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (a.guard.frozen()) return;
     float tau[6] = {0, 0, 0, 0, 0, 0};
     const bool live = idx < a.P;
     const bool vis = live && a.radii[idx] > 0;
@@ -1379,12 +1446,14 @@ struct LossArgs {
     const float* image; const float* depth; const float* opacity; const float* gt_image; const float* gt_depth;
     const uint8_t* grad_mask; const float* exposure; float opacity_thr, depth_w; int monocular;
     float* dL_dimage; float* dL_ddepth; float* dL_dalpha; float* out;     // out[0]=loss, [1]=dL/da, [2]=dL/db
+    LoopGuard guard;
 };
 __device__ __forceinline__ float sgnf(float d) { return (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f); }
 
 __global__ void __launch_bounds__(GSR_BLOCK) k_tracking_loss(LossArgs a)
 {
     __shared__ float s_red[4][3];
+    if (a.guard.frozen()) return;
     const int n = a.W * a.H;
     const float ea = expf(a.exposure[0]), eb = a.exposure[1];
     const float inv3n = 1.f / (3.f * (float)n), invn = 1.f / (float)n;
@@ -1438,6 +1507,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_tracking_loss(LossArgs a)
 #define GSR_PS_CONV 37
 #define GSR_PS_LOSS 38
 #define GSR_PS_TAUN 39
+#define GSR_PS_POISON 40      // uint32 bits: set by the compositing kernel when a speculative forward fails (gsr_refine)
 #define GSR_PS_VIEW 48
 #define GSR_PS_PROJ 64
 #define GSR_PS_CAMPOS 80
@@ -1475,10 +1545,13 @@ __global__ void k_pose_init(float* st, const float* proj_raw)
 // T_w2c <- SE3_exp([trans, rot]) T_w2c, deltas <- 0, converged = |tau| < threshold.
 // tau_acc (nullable): the fp64 block sums of K8/K9; when given, this kernel also finishes the dL/dtau
 // reduction (writes dL_dtau_out) so that the separate k_tau_finish launch is not needed in the native loop.
+// loss_zero (nullable): the native loop's loss accumulator, cleared here for the next iteration once consumed.
 __global__ void k_pose_step(float* st, const float* dL_dtau, const double* tau_acc, float* dL_dtau_out,
-                            const float* loss_out, const float* proj_raw, float lr, float conv_thr)
+                            const float* loss_out, const float* proj_raw, float lr, float conv_thr, float* loss_zero,
+                            LoopGuard guard)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (guard.frozen()) return;
     float t6[6];
     for (int i = 0; i < 6; i++) t6[i] = tau_acc ? (float)tau_acc[i] : dL_dtau[i];
     if (tau_acc && dL_dtau_out) for (int i = 0; i < 6; i++) dL_dtau_out[i] = t6[i];
@@ -1533,6 +1606,7 @@ __global__ void k_pose_step(float* st, const float* dL_dtau, const double* tau_a
     st[GSR_PS_CONV] = (taun < conv_thr) ? 1.f : 0.f;
     st[GSR_PS_TAUN] = taun;
     st[GSR_PS_LOSS] = loss_out[0];
+    if (loss_zero != nullptr) { loss_zero[0] = 0.f; loss_zero[1] = 0.f; loss_zero[2] = 0.f; loss_zero[3] = 0.f; }
     pose_write_camera(st, proj_raw);
 }
 

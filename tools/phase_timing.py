@@ -1,0 +1,42 @@
+"""Diagnostic: per-phase shader-clock totals inside k_render_fwd / k_render_bwd_mfma on S-1M-640 (native loop).
+Needs the timing build:  GSR_TIMING=1 python gs_localization_amd/build.py && python tools/phase_timing.py"""
+import ctypes as C, sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from gs_localization_amd import _lib, scenes as S, pipelines as PL
+lib = _lib.load(); dev = torch.device("cuda:0")
+sc = S.s_1m_640(); H, W = sc.H, sc.W
+model = PL.GaussianMap.from_scene(sc, device=dev)
+bg = torch.zeros(3, device=dev)
+proj = PL.getProjectionMatrix2(0.01, 100.0, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, W=W, H=H).transpose(0, 1).to(dev)
+vp = PL.Camera(0, None, None, torch.eye(4, device=dev), proj, sc.fx, sc.fy, sc.cx, sc.cy, PL.focal2fov(sc.fx, W), PL.focal2fov(sc.fy, H), H, W, device=dev)
+with torch.no_grad():
+    pkg = PL.render(vp, model, PL.PipelineParams(), bg)
+vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=dev)
+init = torch.tensor(S.se3_exp([0.01, 0.01, 0.01, 0.01, 0.0, 0.0]), dtype=torch.float32, device=dev)
+fr = PL.FusedRefiner(model, H, W, device=dev)
+nk = lib.gsr_profile_kernel_count(); names = [lib.gsr_profile_kernel_name(i).decode() for i in range(nk)]
+ITERS = 40
+nk = lib.gsr_profile_kernel_count(); names = [lib.gsr_profile_kernel_name(i).decode() for i in range(nk)]
+fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False, speculative=True)
+torch.cuda.synchronize()
+out = (C.c_ulonglong * 32)()
+assert lib.gsr_debug_timing(out) == 0, "not a GSR_TIMING build"
+lib.gsr_profile_enable((1 << nk) - 1)
+fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=ITERS, stop_on_converged=False, speculative=True)
+torch.cuda.synchronize()
+ms = (C.c_double * nk)(); cnt = (C.c_longlong * nk)(); lib.gsr_profile_collect(ms, cnt); lib.gsr_profile_enable(0)
+print({names[i]: (round(ms[i] / max(cnt[i], 1), 4), cnt[i]) for i in range(nk)})
+lib.gsr_debug_timing(out)
+v = [int(x) for x in out]
+nw = 1200 * 4 * ITERS        # waves
+def show(name, base, labels):
+    print(name, "(cycles per wave, mean)")
+    tot = 0
+    for i, l in enumerate(labels):
+        if l: print("  %-28s %10.0f" % (l, v[base + i] / nw)); tot += v[base + i] / nw if i < 9 else 0
+    print("  %-28s %10.0f" % ("sum of phases", tot))
+show("k_render_fwd", 0, ["bins load", "sort + writeback", "batch top (barrier_and)", "staging gathers + barrier", "compaction", "compositing loop",
+                         "after loop", "epilogue after barrier_or", "barrier_or", "(wave lifetime)", "batches", "loop iterations"])
+show("k_render_bwd_mfma", 16, ["prologue", "batch top barrier", "staging + barrier", "compaction", "weights (8 splats)", "mfma + lds atomics",
+                               "(loop exit)", "barrier after groups", "recombine + global atomics", "(wave lifetime)", "batches", "list entries"])
