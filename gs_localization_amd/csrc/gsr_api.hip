@@ -131,7 +131,7 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.rects = c.take<ushort4>(n);
     g.acc = c.take<float>(GSR_ACC_STRIDE * n);
     g.dirty = c.take<uint8_t>(n);
-    g.tau_acc = c.take<double>(8);
+    g.tau_acc = c.take<double>(8 * GSR_TAU_SLOTS);
     g.depth_key = c.take<uint32_t>(n);
     g.depth_key_sorted = c.take<uint32_t>(n);
     g.order_in = c.take<uint32_t>(n);
@@ -433,12 +433,10 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
             HIPCHK(hipEventRecord(side->fork, st));
             HIPCHK(hipStreamWaitEvent(side->st, side->fork, 0));
             hipLaunchKernelGGL(k_sh_color, dim3(pblocks), dim3(GSR_BLOCK), 0, side->st, pa);
-            if (tl_native_loop) HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), side->st));
             HIPCHK(hipEventRecord(side->join, side->st));
         } else {
             ProfScope ps(K_SH_COLOR, st);
             hipLaunchKernelGGL(k_sh_color, dim3(pblocks), dim3(GSR_BLOCK), 0, st, pa);
-            if (tl_native_loop) HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
         }
         LAUNCHCHK("k_sh_color");
     }
@@ -594,7 +592,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     // accumulators of K7 (atomically summed)
     ProfScope* psz = new ProfScope(K_BWD_ZERO, st);
     if (!tl_native_loop) HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
-    if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * sizeof(double), st));
+    if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));
     delete psz;
     const float* color_ptr = colors_precomp ? colors_precomp : g.rgb;
     ProfScope* psb = new ProfScope(K_RENDER_BWD, st);
@@ -630,7 +628,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     pb.guard = tl_guard;
     {
         ProfScope ps(K_PREPROCESS_BWD, st);
-        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, pb);
+        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + GSR_K8_SPAN - 1) / GSR_K8_SPAN), dim3(64), 0, st, pb);
     }
     LAUNCHCHK("k_preprocess_bwd");
     if (pose_mode && !tl_native_loop) {
@@ -757,6 +755,12 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (a->dL_dscale) HIPCHK(hipMemsetAsync(a->dL_dscale, 0, Pn * 3 * sizeof(float), st));
         if (a->dL_drot) HIPCHK(hipMemsetAsync(a->dL_drot, 0, Pn * 4 * sizeof(float), st));
         HIPCHK(hipMemsetAsync(ps + GSR_PS_CONV, 0, 4 * sizeof(float), st));      // converged, loss, |tau|, poison
+        // K7's accumulator records: cleared once here, afterwards K8 clears every record it consumes
+        Geom gg;
+        char* gptr = (char*)cached_resize(&gb, carve_geom(nullptr, a->P, gg));
+        if (!gptr) return fail(GSR_E_ALLOC, "geometry buffer callback returned NULL%s", "");
+        carve_geom(gptr, a->P, gg);
+        HIPCHK(hipMemsetAsync(gg.acc, 0, Pn * GSR_ACC_STRIDE * sizeof(float), st));
         HIPCHK(hipMemsetAsync(a->loss_out, 0, 4 * sizeof(float), st));
     }
     static_assert(GSR_PS_POISON == GSR_PS_CONV + 3, "status words are copied out as one block");

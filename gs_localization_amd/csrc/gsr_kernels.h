@@ -1032,13 +1032,14 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
 // preprocessCUDA, fused into one pass) + the SE(3) pose-gradient reduction of the pose package.
 // One lane per Gaussian; HBM-streaming.  Every output element is written exactly once.
 // ---------------------------------------------------------------------------------------------
+#define GSR_TAU_SLOTS 64
 struct PreBwdArgs {
     int P, D, M;
     const float* means; const int* radii; const float* shs; const uint8_t* clamped;
     const float* scales; const float* rots; float mod; const float* cov3D;   // cov3D: precomp or geom state
     const float* view; const float* proj; const float* campos;
     float fx, fy, tanx, tany;
-    const float* acc;                                     // packed K7 sums, GSR_ACC_STRIDE floats per Gaussian
+    float* acc;                                           // packed K7 sums, GSR_ACC_STRIDE floats per Gaussian
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;      // unpacked here, written once
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
     int pose; double* tau_acc;
@@ -1165,272 +1166,308 @@ __device__ __forceinline__ void cov3d_backward(const float* s3, float mod, const
 #undef A
 }
 
-__global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_bwd(PreBwdArgs a)
+// One WAVE per GSR_K8_SPAN consecutive Gaussians (workgroup = 64 lanes, ~14 KB of LDS: 11 resident per CU, no
+// cross-wave barriers).  Pass 1 looks at every Gaussian of the span (4 per lane) and compacts the active ones;
+// pass 2 runs the chain rule on dense lanes, SH rows staged through LDS GSR_K8_ROWS at a time.
+#define GSR_K8_SPAN 256
+#define GSR_K8_ROWS 64
+__global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
 {
-    __shared__ float4 s_sh[GSR_BLOCK * GSR_SH16_LDS4];
-    __shared__ uint8_t s_vis[GSR_BLOCK];
-    __shared__ double s_tau[4][6];
-    const int tid = threadIdx.x;
-    const int idx = blockIdx.x * GSR_BLOCK + tid;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ float4 s_sh[GSR_K8_ROWS * GSR_SH16_LDS4];
+    __shared__ uint8_t s_list[GSR_K8_SPAN];      // active Gaussians of the span (index within the span), compacted
+    __shared__ uint8_t s_flag[GSR_K8_SPAN];      // per compacted entry: 1 = has a colour gradient (SH row needed)
+    const int lane = threadIdx.x;
+    const int base = blockIdx.x * GSR_K8_SPAN;
     if (a.guard.frozen()) return;
     float tau[6] = {0, 0, 0, 0, 0, 0};
-    const bool live = idx < a.P;
-    const bool vis = live && a.radii[idx] > 0;
-    // the packed sums of K7; a Gaussian nobody blended has an all-zero record
-    float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-    if (vis) {
-        const float4* rec = reinterpret_cast<const float4*>(a.acc + (size_t)idx * GSR_ACC_STRIDE);
-        r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
-    }
-    // Every gradient tensor was zero-filled by the host on a side stream while K7 ran, so only rows that can
-    // be non-zero are written here: the ones of visible Gaussians (and SH rows only where colour gradient exists).
-    if (vis) {
-        a.dL_dcolor[3 * (size_t)idx] = r0.x; a.dL_dcolor[3 * (size_t)idx + 1] = r0.y; a.dL_dcolor[3 * (size_t)idx + 2] = r0.z;
-        a.dL_dmean2D[3 * (size_t)idx] = r0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = r1.x;
-        reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(r1.y, r1.z, 0.f, r1.w);
-        a.dL_dopacity[idx] = r2.x;
-    }
-    // zero colour gradient => zero SH gradient whatever the coefficients are: their row is not even read
-    const bool has_col = vis && (r0.x != 0.f || r0.y != 0.f || r0.z != 0.f);
-    // SH rows in (and dL_dsh rows out) as coalesced block streams through LDS, see k_preprocess
+    // SH rows in (and dL_dsh rows out) as 16-B-per-lane streams of whole 192-B rows through LDS
     const bool staged = (a.shs != nullptr) && sh16_vector_ok(a.M, a.shs) &&
                         (a.dL_dsh == nullptr || (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u) == 0);
-    const uint8_t was = (a.dirty != nullptr && live) ? a.dirty[idx] : (uint8_t)0;
-    // (s_vis bit 0: fetch + compute the SH row, bit 1: store the LDS row -- computed or zeros)
-    const bool zero_sh_row = (was & 2) && !has_col;
-    if (a.dirty != nullptr && live) a.dirty[idx] = (uint8_t)((vis ? 1 : 0) | (has_col ? 2 : 0));
-    if (live && !vis && (was & 1)) {
-        // no longer visible: clear what the previous iteration left in its rows
-        a.dL_dcolor[3 * (size_t)idx] = 0.f; a.dL_dcolor[3 * (size_t)idx + 1] = 0.f; a.dL_dcolor[3 * (size_t)idx + 2] = 0.f;
-        a.dL_dmean2D[3 * (size_t)idx] = 0.f; a.dL_dmean2D[3 * (size_t)idx + 1] = 0.f;
-        reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-        a.dL_dopacity[idx] = 0.f;
-        if (a.dL_dmean3D) { a.dL_dmean3D[3 * (size_t)idx] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 1] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 2] = 0.f; }
-        if (a.dL_dcov3D) {
+    // ---- pass 1.  Reads the packed sums of K7 and decides who has work: a Gaussian nobody blended has an
+    // all-zero record and all-zero gradients, whatever its other parameters are, so only `active` ones (any
+    // non-zero sum) go through the chain rule below.
+    int nact = 0;
 #pragma unroll
-            for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
+    for (int q = 0; q < GSR_K8_SPAN / 64; q++) {
+        const int local = q * 64 + lane;
+        const int idx = base + local;
+        const bool live = idx < a.P;
+        const bool vis = live && a.radii[idx] > 0;
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+        if (vis) {
+            const float4* rec = reinterpret_cast<const float4*>(a.acc + (size_t)idx * GSR_ACC_STRIDE);
+            r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
         }
-        if (a.dL_dscale) { a.dL_dscale[3 * (size_t)idx] = 0.f; a.dL_dscale[3 * (size_t)idx + 1] = 0.f; a.dL_dscale[3 * (size_t)idx + 2] = 0.f; }
-        if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const bool active = vis && (r0.x != 0.f || r0.y != 0.f || r0.z != 0.f || r0.w != 0.f || r1.x != 0.f || r1.y != 0.f ||
+                                    r1.z != 0.f || r1.w != 0.f || r2.x != 0.f || r2.y != 0.f);
+        // zero colour gradient => zero SH gradient whatever the coefficients are: their row is not even read
+        const bool has_col = active && (r0.x != 0.f || r0.y != 0.f || r0.z != 0.f);
+        // The gradient tensors are zero wherever nothing is written: the host zero-fills them per call, or (native
+        // loop) once per frame, after which the dirty bits say which rows hold values from the iteration before.
+        const uint8_t was = (a.dirty != nullptr && live) ? a.dirty[idx] : (uint8_t)0;
+        if (a.dirty != nullptr && live) {
+            const uint8_t now = (uint8_t)((active ? 1 : 0) | (has_col ? 2 : 0));
+            if (now != was) a.dirty[idx] = now;
+        }
+        if (active) {
+            a.dL_dcolor[3 * (size_t)idx] = r0.x; a.dL_dcolor[3 * (size_t)idx + 1] = r0.y; a.dL_dcolor[3 * (size_t)idx + 2] = r0.z;
+            a.dL_dmean2D[3 * (size_t)idx] = r0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = r1.x;
+            reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(r1.y, r1.z, 0.f, r1.w);
+            a.dL_dopacity[idx] = r2.x;
+        } else if (was & 1) {
+            // no gradient any more: clear what the previous iteration left in its rows
+            a.dL_dcolor[3 * (size_t)idx] = 0.f; a.dL_dcolor[3 * (size_t)idx + 1] = 0.f; a.dL_dcolor[3 * (size_t)idx + 2] = 0.f;
+            a.dL_dmean2D[3 * (size_t)idx] = 0.f; a.dL_dmean2D[3 * (size_t)idx + 1] = 0.f;
+            reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+            a.dL_dopacity[idx] = 0.f;
+            if (a.dL_dmean3D) { a.dL_dmean3D[3 * (size_t)idx] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 1] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 2] = 0.f; }
+            if (a.dL_dcov3D) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
+            }
+            if (a.dL_dscale) { a.dL_dscale[3 * (size_t)idx] = 0.f; a.dL_dscale[3 * (size_t)idx + 1] = 0.f; a.dL_dscale[3 * (size_t)idx + 2] = 0.f; }
+            if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if ((was & 2) && !has_col && a.dL_dsh)       // had an SH gradient last iteration, has none now
+            for (int i = 0; i < a.M * 3; i++) a.dL_dsh[(size_t)idx * a.M * 3 + i] = 0.f;
+        // compact the active Gaussians: pass 2 runs on dense lanes (and re-reads their records, L2 hits)
+        const unsigned long long mk = __ballot(active);
+        if (active) {
+            const int pos = nact + (int)__popcll(mk & ((1ull << lane) - 1ull));
+            s_list[pos] = (uint8_t)local;
+            s_flag[pos] = has_col ? 1 : 0;
+        }
+        nact += (int)__popcll(mk);
     }
-    if (staged) {
-        s_vis[tid] = (uint8_t)((has_col ? 3 : 0) | (zero_sh_row ? 2 : 0));
-        __syncthreads();
-        const float4* src = reinterpret_cast<const float4*>(a.shs) + (size_t)blockIdx.x * GSR_BLOCK * GSR_SH16_ROW4;
-#pragma unroll
-        for (int i = 0; i < GSR_SH16_ROW4; i++) {
-            const int j = tid + GSR_BLOCK * i;
-            const int g = j / GSR_SH16_ROW4;
-            if (s_vis[g] & 1) s_sh[g * GSR_SH16_LDS4 + (j - g * GSR_SH16_ROW4)] = src[j];
-        }
-        __syncthreads();
-        if (zero_sh_row) {
-#pragma unroll
-            for (int i = 0; i < GSR_SH16_ROW4; i++) s_sh[tid * GSR_SH16_LDS4 + i] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-    } else if (zero_sh_row && a.dL_dsh) {
-        for (int i = 0; i < a.M * 3; i++) a.dL_dsh[(size_t)idx * a.M * 3 + i] = 0.f;
-    }
-    float* my_row = reinterpret_cast<float*>(&s_sh[tid * GSR_SH16_LDS4]);
+    __syncthreads();
 
-    if (vis) {
-        const float* cov3D = a.cov3D + 6 * (size_t)idx;
-        float cov6[6];
+    // ---- pass 2: lane k takes the k-th active Gaussian of the chunk
+    for (int c0 = 0; c0 < nact; c0 += GSR_K8_ROWS) {
+        const int nrow = min(GSR_K8_ROWS, nact - c0);
+        if (staged) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) cov6[i] = cov3D[i];
-        const float3 mean = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
-        const float dcx = r1.y, dcy = r1.z, dcz = r1.w;
-        Cov2DTerms ct;
-        cov2d_terms(mean, a.fx, a.fy, a.tanx, a.tany, cov6, a.view, ct);
-        const float limx = 1.3f * a.tanx, limy = 1.3f * a.tany;
-        const float x_grad_mul = (ct.txtz < -limx || ct.txtz > limx) ? 0.f : 1.f;
-        const float y_grad_mul = (ct.tytz < -limy || ct.tytz > limy) ? 0.f : 1.f;
-        const float ca = ct.cov.m[0][0] + 0.3f, cb = ct.cov.m[0][1], cc = ct.cov.m[1][1] + 0.3f;
-        const float denom = ca * cc - cb * cb;
-        float dL_da = 0, dL_db = 0, dL_dc = 0;
-        const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-        float dcov[6];
-        const M3& T = ct.T;
-        const M3& V = ct.Vrk;
-        const M3& Wm = ct.W;
-#define TT(i, j) T.m[i][j]
-#define VV(i, j) V.m[i][j]
-#define WW(i, j) Wm.m[i][j]
-        if (denom2inv != 0) {
-            dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
-            dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
-            dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
-            dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
-            dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
-            dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
-            dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
-            dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
-            dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
-        } else {
-#pragma unroll
-            for (int i = 0; i < 6; i++) dcov[i] = 0;
-        }
-        if (a.dL_dcov3D) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
-        }
-
-        const float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da + (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
-        const float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da + (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
-        const float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da + (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
-        const float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc + (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
-        const float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc + (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
-        const float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc + (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
-        const float dL_dJ00 = WW(0, 0) * dL_dT00 + WW(0, 1) * dL_dT01 + WW(0, 2) * dL_dT02;
-        const float dL_dJ02 = WW(2, 0) * dL_dT00 + WW(2, 1) * dL_dT01 + WW(2, 2) * dL_dT02;
-        const float dL_dJ11 = WW(1, 0) * dL_dT10 + WW(1, 1) * dL_dT11 + WW(1, 2) * dL_dT12;
-        const float dL_dJ12 = WW(2, 0) * dL_dT10 + WW(2, 1) * dL_dT11 + WW(2, 2) * dL_dT12;
-#undef TT
-#undef VV
-#undef WW
-        const float3 t = ct.t;
-        const float tz = 1.f / t.z;
-        const float tz2 = tz * tz;
-        const float tz3 = tz2 * tz;
-        const float dL_dtx = x_grad_mul * -a.fx * tz2 * dL_dJ02;
-        const float dL_dty = y_grad_mul * -a.fy * tz2 * dL_dJ12;
-        const float dL_dtz = -a.fx * tz2 * dL_dJ00 - a.fy * tz2 * dL_dJ11 + (2 * a.fx * t.x) * tz3 * dL_dJ02 + (2 * a.fy * t.y) * tz3 * dL_dJ12;
-        const float* vm = a.view;
-        const float3 g_cov = make_float3(vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz,
-                                         vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz,
-                                         vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz);
-        float dm0 = g_cov.x, dm1 = g_cov.y, dm2 = g_cov.z;
-
-        const float* proj = a.proj;
-        const float4 m_hom = xform4x4(mean, proj);
-        const float m_w = 1.0f / (m_hom.w + 0.0000001f);
-        const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
-        const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-        const float g2x = r0.w, g2y = r1.x;
-        float3 g_m2d;
-        g_m2d.x = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
-        g_m2d.y = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
-        g_m2d.z = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
-        dm0 += g_m2d.x; dm1 += g_m2d.y; dm2 += g_m2d.z;
-
-        float3 g_depth = make_float3(0.f, 0.f, 0.f);
-        if (a.pose) {
-            const float dz = r2.y;
-            g_depth = make_float3(vm[2] * dz, vm[6] * dz, vm[10] * dz);
-            dm0 += g_depth.x; dm1 += g_depth.y; dm2 += g_depth.z;
-        }
-        float3 g_sh = make_float3(0.f, 0.f, 0.f);
-        if (a.shs) {
-            if (has_col) {
-                const float3 dcol = make_float3(r0.x, r0.y, r0.z);
-                if (staged)
-                    g_sh = sh_backward(a.D, 16, mean, a.campos, my_row, a.clamped[idx], dcol, a.dL_dsh ? my_row : nullptr);
-                else
-                    g_sh = sh_backward(a.D, a.M, mean, a.campos, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dcol,
-                                       a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
-                dm0 += g_sh.x; dm1 += g_sh.y; dm2 += g_sh.z;
+            for (int i = 0; i < GSR_SH16_ROW4; i++) {
+                const int j = lane + 64 * i;
+                const int r = j / GSR_SH16_ROW4, part = j - r * GSR_SH16_ROW4;
+                if (r < nrow && s_flag[c0 + r])
+                    s_sh[r * GSR_SH16_LDS4 + part] =
+                        reinterpret_cast<const float4*>(a.shs)[(size_t)(base + s_list[c0 + r]) * GSR_SH16_ROW4 + part];
             }
         }
-        if (a.dL_dmean3D) {
-            a.dL_dmean3D[3 * (size_t)idx] = dm0;
-            a.dL_dmean3D[3 * (size_t)idx + 1] = dm1;
-            a.dL_dmean3D[3 * (size_t)idx + 2] = dm2;
-        }
-
-        if (a.scales && (a.dL_dscale || a.dL_drot)) {
-            float s3[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
-            const float4 q = reinterpret_cast<const float4*>(a.rots)[idx];
-            float q4[4] = {q.x, q.y, q.z, q.w};
-            float ds[3], dq[4];
-            cov3d_backward(s3, a.mod, q4, dcov, ds, dq);
-            if (a.dL_dscale) {
-                a.dL_dscale[3 * (size_t)idx] = ds[0]; a.dL_dscale[3 * (size_t)idx + 1] = ds[1]; a.dL_dscale[3 * (size_t)idx + 2] = ds[2];
-            }
-            if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
-        }
-
-        if (a.pose) {
-            // dL/dtau for T_w2c <- exp([rho,theta]) T_w2c at 0:
-            //   drho   = R g_geo + R g_sh
-            //   dtheta = p_C x (R g_geo) + axial(Sigma_C G_C^T - G_C^T Sigma_C)
-            // with R[r][c] = view[4c+r], Sigma_C = R Sigma_W R^T, G_C = R G_W R^T, G_W symmetric.
-            float Rm[3][3];
-#pragma unroll
-            for (int r = 0; r < 3; r++)
-#pragma unroll
-                for (int c = 0; c < 3; c++) Rm[r][c] = vm[c * 4 + r];
-            const float gg[3] = {g_cov.x + g_m2d.x + g_depth.x, g_cov.y + g_m2d.y + g_depth.y, g_cov.z + g_m2d.z + g_depth.z};
-            const float gs[3] = {g_sh.x, g_sh.y, g_sh.z};
-            const float mw[3] = {mean.x, mean.y, mean.z};
-            float pc[3], Rg[3], Rs[3];
-#pragma unroll
-            for (int r = 0; r < 3; r++) {
-                pc[r] = Rm[r][0] * mw[0] + Rm[r][1] * mw[1] + Rm[r][2] * mw[2] + vm[12 + r];
-                Rg[r] = Rm[r][0] * gg[0] + Rm[r][1] * gg[1] + Rm[r][2] * gg[2];
-                Rs[r] = Rm[r][0] * gs[0] + Rm[r][1] * gs[1] + Rm[r][2] * gs[2];
-            }
-            const float GW[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]}, {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
-            const float SW[3][3] = {{cov6[0], cov6[1], cov6[2]}, {cov6[1], cov6[3], cov6[4]}, {cov6[2], cov6[4], cov6[5]}};
-            float SC[3][3], GC[3][3], tmp[3][3];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) tmp[i][j] = Rm[i][0] * SW[0][j] + Rm[i][1] * SW[1][j] + Rm[i][2] * SW[2][j];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) SC[i][j] = tmp[i][0] * Rm[j][0] + tmp[i][1] * Rm[j][1] + tmp[i][2] * Rm[j][2];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) tmp[i][j] = Rm[i][0] * GW[0][j] + Rm[i][1] * GW[1][j] + Rm[i][2] * GW[2][j];
-#pragma unroll
-            for (int i = 0; i < 3; i++)
-#pragma unroll
-                for (int j = 0; j < 3; j++) GC[i][j] = tmp[i][0] * Rm[j][0] + tmp[i][1] * Rm[j][1] + tmp[i][2] * Rm[j][2];
-            // A = SC*GC^T - GC^T*SC ; only the three antisymmetric combinations are needed
-            auto Aij = [&](int i, int j) {
-                float v = 0.f;
-#pragma unroll
-                for (int k = 0; k < 3; k++) v += SC[i][k] * GC[j][k] - GC[k][i] * SC[k][j];
-                return v;
-            };
-            tau[0] = Rg[0] + Rs[0]; tau[1] = Rg[1] + Rs[1]; tau[2] = Rg[2] + Rs[2];
-            tau[3] = pc[1] * Rg[2] - pc[2] * Rg[1] + (Aij(1, 2) - Aij(2, 1));
-            tau[4] = pc[2] * Rg[0] - pc[0] * Rg[2] + (Aij(2, 0) - Aij(0, 2));
-            tau[5] = pc[0] * Rg[1] - pc[1] * Rg[0] + (Aij(0, 1) - Aij(1, 0));
-        }
-    }
-    if (staged && a.dL_dsh) {
         __syncthreads();
-        float4* dst = reinterpret_cast<float4*>(a.dL_dsh) + (size_t)blockIdx.x * GSR_BLOCK * GSR_SH16_ROW4;
-        const int nrows = min(GSR_BLOCK, a.P - blockIdx.x * GSR_BLOCK);
-#pragma unroll
-        for (int i = 0; i < GSR_SH16_ROW4; i++) {
-            const int j = tid + GSR_BLOCK * i;
-            const int g = j / GSR_SH16_ROW4;
-            if (g < nrows && (s_vis[g] & 2)) dst[j] = s_sh[g * GSR_SH16_LDS4 + (j - g * GSR_SH16_ROW4)];
+        const bool vis = lane < nrow;
+        const int idx = base + (vis ? (int)s_list[c0 + lane] : 0);
+        float* my_row = reinterpret_cast<float*>(&s_sh[lane * GSR_SH16_LDS4]);
+        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+        if (vis) {
+            float4* rec = reinterpret_cast<float4*>(a.acc + (size_t)idx * GSR_ACC_STRIDE);
+            r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+            if (a.dirty != nullptr) {      // native loop: leave the record clean for the next iteration's K7 (no 48 MB memset)
+                rec[0] = make_float4(0.f, 0.f, 0.f, 0.f); rec[1] = rec[0]; rec[2] = rec[0];
+            }
         }
+        const bool has_col = vis && s_flag[c0 + lane];
+        if (vis) {
+            const float* cov3D = a.cov3D + 6 * (size_t)idx;
+            float cov6[6];
+    #pragma unroll
+            for (int i = 0; i < 6; i++) cov6[i] = cov3D[i];
+            const float3 mean = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
+            const float dcx = r1.y, dcy = r1.z, dcz = r1.w;
+            Cov2DTerms ct;
+            cov2d_terms(mean, a.fx, a.fy, a.tanx, a.tany, cov6, a.view, ct);
+            const float limx = 1.3f * a.tanx, limy = 1.3f * a.tany;
+            const float x_grad_mul = (ct.txtz < -limx || ct.txtz > limx) ? 0.f : 1.f;
+            const float y_grad_mul = (ct.tytz < -limy || ct.tytz > limy) ? 0.f : 1.f;
+            const float ca = ct.cov.m[0][0] + 0.3f, cb = ct.cov.m[0][1], cc = ct.cov.m[1][1] + 0.3f;
+            const float denom = ca * cc - cb * cb;
+            float dL_da = 0, dL_db = 0, dL_dc = 0;
+            const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+            float dcov[6];
+            const M3& T = ct.T;
+            const M3& V = ct.Vrk;
+            const M3& Wm = ct.W;
+    #define TT(i, j) T.m[i][j]
+    #define VV(i, j) V.m[i][j]
+    #define WW(i, j) Wm.m[i][j]
+            if (denom2inv != 0) {
+                dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
+                dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
+                dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
+                dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
+                dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
+                dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
+                dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
+                dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
+                dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
+            } else {
+    #pragma unroll
+                for (int i = 0; i < 6; i++) dcov[i] = 0;
+            }
+            if (a.dL_dcov3D) {
+    #pragma unroll
+                for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
+            }
+
+            const float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da + (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
+            const float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da + (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
+            const float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da + (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
+            const float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc + (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
+            const float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc + (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
+            const float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc + (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
+            const float dL_dJ00 = WW(0, 0) * dL_dT00 + WW(0, 1) * dL_dT01 + WW(0, 2) * dL_dT02;
+            const float dL_dJ02 = WW(2, 0) * dL_dT00 + WW(2, 1) * dL_dT01 + WW(2, 2) * dL_dT02;
+            const float dL_dJ11 = WW(1, 0) * dL_dT10 + WW(1, 1) * dL_dT11 + WW(1, 2) * dL_dT12;
+            const float dL_dJ12 = WW(2, 0) * dL_dT10 + WW(2, 1) * dL_dT11 + WW(2, 2) * dL_dT12;
+    #undef TT
+    #undef VV
+    #undef WW
+            const float3 t = ct.t;
+            const float tz = 1.f / t.z;
+            const float tz2 = tz * tz;
+            const float tz3 = tz2 * tz;
+            const float dL_dtx = x_grad_mul * -a.fx * tz2 * dL_dJ02;
+            const float dL_dty = y_grad_mul * -a.fy * tz2 * dL_dJ12;
+            const float dL_dtz = -a.fx * tz2 * dL_dJ00 - a.fy * tz2 * dL_dJ11 + (2 * a.fx * t.x) * tz3 * dL_dJ02 + (2 * a.fy * t.y) * tz3 * dL_dJ12;
+            const float* vm = a.view;
+            const float3 g_cov = make_float3(vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz,
+                                             vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz,
+                                             vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz);
+            float dm0 = g_cov.x, dm1 = g_cov.y, dm2 = g_cov.z;
+
+            const float* proj = a.proj;
+            const float4 m_hom = xform4x4(mean, proj);
+            const float m_w = 1.0f / (m_hom.w + 0.0000001f);
+            const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
+            const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
+            const float g2x = r0.w, g2y = r1.x;
+            float3 g_m2d;
+            g_m2d.x = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
+            g_m2d.y = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
+            g_m2d.z = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
+            dm0 += g_m2d.x; dm1 += g_m2d.y; dm2 += g_m2d.z;
+
+            float3 g_depth = make_float3(0.f, 0.f, 0.f);
+            if (a.pose) {
+                const float dz = r2.y;
+                g_depth = make_float3(vm[2] * dz, vm[6] * dz, vm[10] * dz);
+                dm0 += g_depth.x; dm1 += g_depth.y; dm2 += g_depth.z;
+            }
+            float3 g_sh = make_float3(0.f, 0.f, 0.f);
+            if (a.shs) {
+                if (has_col) {
+                    const float3 dcol = make_float3(r0.x, r0.y, r0.z);
+                    if (staged)
+                        g_sh = sh_backward(a.D, 16, mean, a.campos, my_row, a.clamped[idx], dcol, a.dL_dsh ? my_row : nullptr);
+                    else
+                        g_sh = sh_backward(a.D, a.M, mean, a.campos, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dcol,
+                                           a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
+                    dm0 += g_sh.x; dm1 += g_sh.y; dm2 += g_sh.z;
+                }
+            }
+            if (a.dL_dmean3D) {
+                a.dL_dmean3D[3 * (size_t)idx] = dm0;
+                a.dL_dmean3D[3 * (size_t)idx + 1] = dm1;
+                a.dL_dmean3D[3 * (size_t)idx + 2] = dm2;
+            }
+
+            if (a.scales && (a.dL_dscale || a.dL_drot)) {
+                float s3[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+                const float4 q = reinterpret_cast<const float4*>(a.rots)[idx];
+                float q4[4] = {q.x, q.y, q.z, q.w};
+                float ds[3], dq[4];
+                cov3d_backward(s3, a.mod, q4, dcov, ds, dq);
+                if (a.dL_dscale) {
+                    a.dL_dscale[3 * (size_t)idx] = ds[0]; a.dL_dscale[3 * (size_t)idx + 1] = ds[1]; a.dL_dscale[3 * (size_t)idx + 2] = ds[2];
+                }
+                if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
+            }
+
+            if (a.pose) {
+                // dL/dtau for T_w2c <- exp([rho,theta]) T_w2c at 0:
+                //   drho   = R g_geo + R g_sh
+                //   dtheta = p_C x (R g_geo) + axial(Sigma_C G_C^T - G_C^T Sigma_C)
+                // with R[r][c] = view[4c+r], Sigma_C = R Sigma_W R^T, G_C = R G_W R^T, G_W symmetric.
+                float Rm[3][3];
+    #pragma unroll
+                for (int r = 0; r < 3; r++)
+    #pragma unroll
+                    for (int c = 0; c < 3; c++) Rm[r][c] = vm[c * 4 + r];
+                const float gg[3] = {g_cov.x + g_m2d.x + g_depth.x, g_cov.y + g_m2d.y + g_depth.y, g_cov.z + g_m2d.z + g_depth.z};
+                const float gs[3] = {g_sh.x, g_sh.y, g_sh.z};
+                const float mw[3] = {mean.x, mean.y, mean.z};
+                float pc[3], Rg[3], Rs[3];
+    #pragma unroll
+                for (int r = 0; r < 3; r++) {
+                    pc[r] = Rm[r][0] * mw[0] + Rm[r][1] * mw[1] + Rm[r][2] * mw[2] + vm[12 + r];
+                    Rg[r] = Rm[r][0] * gg[0] + Rm[r][1] * gg[1] + Rm[r][2] * gg[2];
+                    Rs[r] = Rm[r][0] * gs[0] + Rm[r][1] * gs[1] + Rm[r][2] * gs[2];
+                }
+                const float GW[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]}, {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+                const float SW[3][3] = {{cov6[0], cov6[1], cov6[2]}, {cov6[1], cov6[3], cov6[4]}, {cov6[2], cov6[4], cov6[5]}};
+                float SC[3][3], GC[3][3], tmp[3][3];
+    #pragma unroll
+                for (int i = 0; i < 3; i++)
+    #pragma unroll
+                    for (int j = 0; j < 3; j++) tmp[i][j] = Rm[i][0] * SW[0][j] + Rm[i][1] * SW[1][j] + Rm[i][2] * SW[2][j];
+    #pragma unroll
+                for (int i = 0; i < 3; i++)
+    #pragma unroll
+                    for (int j = 0; j < 3; j++) SC[i][j] = tmp[i][0] * Rm[j][0] + tmp[i][1] * Rm[j][1] + tmp[i][2] * Rm[j][2];
+    #pragma unroll
+                for (int i = 0; i < 3; i++)
+    #pragma unroll
+                    for (int j = 0; j < 3; j++) tmp[i][j] = Rm[i][0] * GW[0][j] + Rm[i][1] * GW[1][j] + Rm[i][2] * GW[2][j];
+    #pragma unroll
+                for (int i = 0; i < 3; i++)
+    #pragma unroll
+                    for (int j = 0; j < 3; j++) GC[i][j] = tmp[i][0] * Rm[j][0] + tmp[i][1] * Rm[j][1] + tmp[i][2] * Rm[j][2];
+                // A = SC*GC^T - GC^T*SC ; only the three antisymmetric combinations are needed
+                auto Aij = [&](int i, int j) {
+                    float v = 0.f;
+    #pragma unroll
+                    for (int k = 0; k < 3; k++) v += SC[i][k] * GC[j][k] - GC[k][i] * SC[k][j];
+                    return v;
+                };
+                tau[0] += Rg[0] + Rs[0]; tau[1] += Rg[1] + Rs[1]; tau[2] += Rg[2] + Rs[2];
+                tau[3] += pc[1] * Rg[2] - pc[2] * Rg[1] + (Aij(1, 2) - Aij(2, 1));
+                tau[4] += pc[2] * Rg[0] - pc[0] * Rg[2] + (Aij(2, 0) - Aij(0, 2));
+                tau[5] += pc[0] * Rg[1] - pc[1] * Rg[0] + (Aij(0, 1) - Aij(1, 0));
+            }
+        }
+        if (staged && a.dL_dsh) {
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < GSR_SH16_ROW4; i++) {
+                const int j = lane + 64 * i;
+                const int r = j / GSR_SH16_ROW4, part = j - r * GSR_SH16_ROW4;
+                if (r < nrow && s_flag[c0 + r])
+                    reinterpret_cast<float4*>(a.dL_dsh)[(size_t)(base + s_list[c0 + r]) * GSR_SH16_ROW4 + part] =
+                        s_sh[r * GSR_SH16_LDS4 + part];
+            }
+        }
+        __syncthreads();
     }
     if (a.pose) {
-        // block reduction in fp64, one fp64 atomic per block and component
+        // wave reduction in fp64, one fp64 atomic per wave and component into one of GSR_TAU_SLOTS partial sums
+        // (64 B apart: ~4000 waves adding into six words would queue up at the memory-side atomic unit)
 #pragma unroll
         for (int i = 0; i < 6; i++) {
             const double t = wave_sum_d((double)tau[i]);
-            if (lane == 0) s_tau[wv][i] = t;
-        }
-        __syncthreads();
-        if (threadIdx.x < 6) {
-            const double t = s_tau[0][threadIdx.x] + s_tau[1][threadIdx.x] + s_tau[2][threadIdx.x] + s_tau[3][threadIdx.x];
-            if (t != 0.0) atomicAdd(&a.tau_acc[threadIdx.x], t);
+            if (lane == 0 && t != 0.0) atomicAdd(&a.tau_acc[(blockIdx.x & (GSR_TAU_SLOTS - 1)) * 8 + i], t);
         }
     }
 }
 
+__device__ __forceinline__ double tau_total(const double* acc, int i)
+{
+    double t = 0.0;
+    for (int sl = 0; sl < GSR_TAU_SLOTS; sl++) t += acc[sl * 8 + i];
+    return t;
+}
 __global__ void k_tau_finish(const double* acc, float* out)
 {
-    if (threadIdx.x < 6) out[threadIdx.x] = (float)acc[threadIdx.x];
+    if (threadIdx.x < 6) out[threadIdx.x] = (float)tau_total(acc, threadIdx.x);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1553,7 +1590,7 @@ __global__ void k_pose_step(float* st, const float* dL_dtau, const double* tau_a
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     if (guard.frozen()) return;
     float t6[6];
-    for (int i = 0; i < 6; i++) t6[i] = tau_acc ? (float)tau_acc[i] : dL_dtau[i];
+    for (int i = 0; i < 6; i++) t6[i] = tau_acc ? (float)tau_total(tau_acc, i) : dL_dtau[i];
     if (tau_acc && dL_dtau_out) for (int i = 0; i < 6; i++) dL_dtau_out[i] = t6[i];
     float g[8] = {t6[3], t6[4], t6[5], t6[0], t6[1], t6[2], loss_out[1], loss_out[2]};
     const float step = st[GSR_PS_STEP] + 1.f;
