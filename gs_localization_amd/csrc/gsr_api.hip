@@ -432,11 +432,11 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
         if (side) {
             HIPCHK(hipEventRecord(side->fork, st));
             HIPCHK(hipStreamWaitEvent(side->st, side->fork, 0));
-            hipLaunchKernelGGL(k_sh_color, dim3(pblocks), dim3(GSR_BLOCK), 0, side->st, pa);
+            hipLaunchKernelGGL(k_sh_color, dim3((P + GSR_SHC_SPAN - 1) / GSR_SHC_SPAN), dim3(64), 0, side->st, pa);
             HIPCHK(hipEventRecord(side->join, side->st));
         } else {
             ProfScope ps(K_SH_COLOR, st);
-            hipLaunchKernelGGL(k_sh_color, dim3(pblocks), dim3(GSR_BLOCK), 0, st, pa);
+            hipLaunchKernelGGL(k_sh_color, dim3((P + GSR_SHC_SPAN - 1) / GSR_SHC_SPAN), dim3(64), 0, st, pa);
         }
         LAUNCHCHK("k_sh_color");
     }

@@ -340,40 +340,54 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 // SH -> RGB (forward.cu:20-71) as its own kernel: it only needs radii > 0 from the geometry pass, so the host
 // runs it on a side stream underneath the (latency-bound) sort chain and joins before compositing.
 // Summation order is the reference's; SH rows arrive as one coalesced stream per block (see above).
-__global__ void __launch_bounds__(GSR_BLOCK) k_sh_color(PreArgs a)
+#define GSR_SHC_SPAN 256
+#define GSR_SHC_ROWS 64
+__global__ void __launch_bounds__(64) k_sh_color(PreArgs a)
 {
-    __shared__ float4 s_sh[GSR_BLOCK * GSR_SH16_LDS4];
-    __shared__ uint8_t s_vis[GSR_BLOCK];
-    const int tid = threadIdx.x;
-    const int idx = blockIdx.x * GSR_BLOCK + tid;
+    // One wave per GSR_SHC_SPAN Gaussians: the ones that need a colour are compacted first (4 candidates per lane),
+    // then handled on dense lanes with their SH rows staged GSR_SHC_ROWS at a time (~14 KB of LDS per wave).
+    __shared__ float4 s_sh[GSR_SHC_ROWS * GSR_SH16_LDS4];
+    __shared__ uint8_t s_list[GSR_SHC_SPAN];
+    const int lane = threadIdx.x;
+    const int base = blockIdx.x * GSR_SHC_SPAN;
     if (a.guard.poisoned()) return;
     // only splats that were binned into at least one tile can ever be composited (this also skips everything
     // the native loop's speculative depth bounds dropped)
-    const bool vis = idx < a.P && a.tiles_touched[idx] > 0;
-    float3 p = make_float3(0.f, 0.f, 0.f);
-    if (vis) p = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
-    if (sh16_vector_ok(a.M, a.shs)) {
-        s_vis[tid] = vis ? 1 : 0;
-        __syncthreads();
-        const float4* src = reinterpret_cast<const float4*>(a.shs) + (size_t)blockIdx.x * GSR_BLOCK * GSR_SH16_ROW4;
+    int nact = 0;
 #pragma unroll
-        for (int i = 0; i < GSR_SH16_ROW4; i++) {
-            const int j = tid + GSR_BLOCK * i;              // float4 index inside the block's contiguous chunk
-            const int g = j / GSR_SH16_ROW4;
-            if (s_vis[g]) s_sh[g * GSR_SH16_LDS4 + (j - g * GSR_SH16_ROW4)] = src[j];
+    for (int q = 0; q < GSR_SHC_SPAN / 64; q++) {
+        const int local = q * 64 + lane;
+        const int idx = base + local;
+        const bool need = idx < a.P && a.tiles_touched[idx] > 0;
+        const unsigned long long mk = __ballot(need);
+        if (need) s_list[nact + (int)__popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)local;
+        nact += (int)__popcll(mk);
+    }
+    __syncthreads();
+    const bool staged = sh16_vector_ok(a.M, a.shs);
+    for (int c0 = 0; c0 < nact; c0 += GSR_SHC_ROWS) {
+        const int nrow = min(GSR_SHC_ROWS, nact - c0);
+        if (staged) {
+#pragma unroll
+            for (int i = 0; i < GSR_SH16_ROW4; i++) {
+                const int j = lane + 64 * i;
+                const int r = j / GSR_SH16_ROW4, part = j - r * GSR_SH16_ROW4;
+                if (r < nrow)
+                    s_sh[r * GSR_SH16_LDS4 + part] =
+                        reinterpret_cast<const float4*>(a.shs)[(size_t)(base + s_list[c0 + r]) * GSR_SH16_ROW4 + part];
+            }
         }
         __syncthreads();
-        if (vis) {
+        if (lane < nrow) {
+            const int idx = base + (int)s_list[c0 + lane];
+            const float3 p = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
             uint8_t cb;
-            const float3 c = sh_to_rgb(a.D, 16, p, a.campos, reinterpret_cast<const float*>(&s_sh[tid * GSR_SH16_LDS4]), cb);
+            const float3 c = staged ? sh_to_rgb(a.D, 16, p, a.campos, reinterpret_cast<const float*>(&s_sh[lane * GSR_SH16_LDS4]), cb)
+                                    : sh_to_rgb(a.D, a.M, p, a.campos, a.shs + (size_t)idx * a.M * 3, cb);
             a.rgb[3 * idx] = c.x; a.rgb[3 * idx + 1] = c.y; a.rgb[3 * idx + 2] = c.z;
             a.clamped[idx] = cb;
         }
-    } else if (vis) {
-        uint8_t cb;
-        const float3 c = sh_to_rgb(a.D, a.M, p, a.campos, a.shs + (size_t)idx * a.M * 3, cb);
-        a.rgb[3 * idx] = c.x; a.rgb[3 * idx + 1] = c.y; a.rgb[3 * idx + 2] = c.z;
-        a.clamped[idx] = cb;
+        __syncthreads();
     }
 }
 
