@@ -520,7 +520,30 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
                      (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
                      zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), tl_guard.poison ? const_cast<uint32_t*>(tl_guard.poison) : im.fail, tl_spec.mul, tl_spec.add, zbc_next, \
                      (const uint32_t*)im.truncc, im.sbx, (g_ablate >> 12) & 0xf
-    if (local_path) {
+#define GSR_FWD2_ARGS im.ranges, local_path ? bl.vals : b.vals, (const unsigned long long*)bl.bins, (const uint32_t*)im.tile_cursor, \
+                      width, height, gx, ntiles, (const float2*)g.xy, feat, \
+                      (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
+                      zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), tl_guard.poison ? const_cast<uint32_t*>(tl_guard.poison) : im.fail, \
+                      tl_spec.mul, tl_spec.add, zbc_next, (const uint32_t*)im.truncc, im.sbx
+    static const int fwd_v = getenv("GSR_FWD_V") ? atoi(getenv("GSR_FWD_V")) : 3;      // diagnostics: older kernel generations
+    const bool fwd_v1 = fwd_v == 1;
+    if (fwd_v == 3) {
+        if (local_path) {
+            if (n_touched) hipLaunchKernelGGL((k_render_fwd3<true, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD2_ARGS);
+            else hipLaunchKernelGGL((k_render_fwd3<false, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD2_ARGS);
+        } else {
+            if (n_touched) hipLaunchKernelGGL((k_render_fwd3<true, false>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD2_ARGS);
+            else hipLaunchKernelGGL((k_render_fwd3<false, false>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD2_ARGS);
+        }
+    } else if (!fwd_v1) {
+        if (local_path) {
+            if (n_touched) hipLaunchKernelGGL((k_render_fwd2<true, true>), dim3(ntiles), dim3(GSR_FWD2_THREADS), 0, st, GSR_FWD2_ARGS);
+            else hipLaunchKernelGGL((k_render_fwd2<false, true>), dim3(ntiles), dim3(GSR_FWD2_THREADS), 0, st, GSR_FWD2_ARGS);
+        } else {
+            if (n_touched) hipLaunchKernelGGL((k_render_fwd2<true, false>), dim3(ntiles), dim3(GSR_FWD2_THREADS), 0, st, GSR_FWD2_ARGS);
+            else hipLaunchKernelGGL((k_render_fwd2<false, false>), dim3(ntiles), dim3(GSR_FWD2_THREADS), 0, st, GSR_FWD2_ARGS);
+        }
+    } else if (local_path) {
         if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
         else hipLaunchKernelGGL((k_render_fwd<false, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
     } else {

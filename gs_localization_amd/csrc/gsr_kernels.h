@@ -660,6 +660,436 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(uint2* __restrict__ ra
 }
 
 // ---------------------------------------------------------------------------------------------
+// K6, packed form (the one the host launches).  Same walk and the same per-pixel recurrence as k_render_fwd, but
+//   * a workgroup is TWO waves per tile and every lane owns TWO pixels of one row, (x, y) and (x + 8, y): the
+//     per-pixel arithmetic then runs on the packed fp32 pipes (v_pk_fma/mul/add_f32: two pixels per instruction)
+//     and the splat record is read from LDS once per two pixels;
+//   * the conic is staged pre-multiplied, A2 = -a/2 log2e, B2 = -b log2e, C2 = -c/2 log2e, so that
+//         power log2e = dx (A2 dx + B2 dy) + C2 dy dy          (dy and B2 dy, C2 dy dy shared by the pair)
+//     takes two packed FMAs per pair and feeds v_exp_f32 directly.  k_render_bwd2 evaluates the identical
+//     expression, so both passes see the same alpha bits.
+// ---------------------------------------------------------------------------------------------
+typedef float gsr_v2f __attribute__((ext_vector_type(2)));
+#define GSR_LOG2E 1.4426950408889634f
+#define GSR_FWD2_THREADS 128
+#define GSR_FWD2_BATCH 256
+struct SplatLDS2 {
+    float4 a[GSR_FWD2_BATCH];   // x, y, A2, B2
+    float4 b[GSR_FWD2_BATCH];   // C2, opacity, depth, id (bits)
+    float4 c[GSR_FWD2_BATCH];   // r, g, b, half-tile mask (bits)
+    uint8_t list[2][GSR_FWD2_BATCH];   // per wave: staged splats that can touch its 16x8 half tile, in list order
+};
+// Which of the tile's two 16x8 halves (= waves) a staged splat can change; same ellipse bound and slack as
+// quadrant_mask.  Bit w set <=> wave w must look at the splat.  Not positive definite => both.
+__device__ __forceinline__ uint32_t half_mask(float my, float A, float B, float C, float opacity, int Y0)
+{
+    const float det = A * C - B * B;
+    if (!(A > 0.f && C > 0.f && det > 0.f)) return 0x3u;
+    const float qmax = (opacity > 0.f) ? (__logf(255.f * opacity) + 0.02f) : -1.f;
+    if (qmax < 0.f) return 0u;
+    const float hy = __builtin_amdgcn_sqrtf(2.f * qmax * __builtin_amdgcn_rcpf(det) * A) * 1.0001f + 0.01f;
+    const float yl = my - hy - (float)Y0, yh = my + hy - (float)Y0;
+    return ((yl <= 7.f && yh >= 0.f) ? 1u : 0u) | ((yl <= 15.f && yh >= 8.f) ? 2u : 0u);
+}
+// power * log2(e) for the pixel pair; see the header comment
+__device__ __forceinline__ gsr_v2f pair_power2(gsr_v2f dx, float dy, float A2, float B2, float C2)
+{
+    const float u = B2 * dy;
+    const float t = (C2 * dy) * dy;
+    const gsr_v2f uu = {u, u}, tt = {t, t}, aa = {A2, A2};
+    return __builtin_elementwise_fma(dx, __builtin_elementwise_fma(aa, dx, uu), tt);
+}
+
+template <bool TOUCHED, bool LOCALSORT>
+__global__ void __launch_bounds__(GSR_FWD2_THREADS) k_render_fwd2(uint2* __restrict__ ranges,
+                                                          uint32_t* __restrict__ point_list,
+                                                          const unsigned long long* __restrict__ bins,
+                                                          const uint32_t* __restrict__ tile_cursor,
+                                                          int W, int H, int gx,
+                                                          int ntiles, const float2* __restrict__ xy,
+                                                          const float* __restrict__ rgb, const float* __restrict__ depths,
+                                                          const float4* __restrict__ conic_op, const float* __restrict__ bg,
+                                                          float* __restrict__ out_color, float* __restrict__ out_depth,
+                                                          float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
+                                                          int* __restrict__ n_touched, float* __restrict__ zb_next,
+                                                          const uint32_t* __restrict__ trunc, uint32_t* __restrict__ fail,
+                                                          float margin_mul, float margin_add, float* __restrict__ zbc_next,
+                                                          const uint32_t* __restrict__ truncc, int sbx)
+{
+    __shared__ SplatLDS2 s;
+    GSR_T_DECL
+    __shared__ float s_zmax[2];
+    __shared__ unsigned long long s_keys[LOCALSORT ? GSR_LSORT_CAP : 1];
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int px0 = tx * GSR_TILE + (lane & 7), px1 = px0 + 8, py = ty * GSR_TILE + wv * 8 + (lane >> 3);
+    const bool in0 = px0 < W && py < H, in1 = px1 < W && py < H;
+    const gsr_v2f pxv = {(float)px0, (float)px1};
+    const float pyf = (float)py;
+    uint2 range;
+    if (LOCALSORT) {
+        range.x = (uint32_t)tile * GSR_LSORT_CAP;
+        range.y = range.x + tile_cursor[tile * GSR_CURSOR_STRIDE];
+    } else range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+
+    if (LOCALSORT) {
+        // this tile's bin arrives unsorted: order it by (depth bits, index) in LDS (bitonic network), keep it there
+        // for the staging below and write the sorted indices (and the tile's range) back for the backward pass
+        if (total > GSR_LSORT_CAP) {          // block-uniform: give up, the host redoes the forward with global sorts
+            if (tid == 0) atomicAdd(fail, 0x10000u);
+            return;
+        }
+        if (tid == 0) ranges[tile] = range;
+        int npow = 64;
+        while (npow < total) npow <<= 1;
+        for (int i = tid; i < npow; i += GSR_FWD2_THREADS) s_keys[i] = (i < total) ? bins[range.x + i] : ~0ull;
+        __syncthreads();
+        GSR_T_TICK(0)
+        for (int k = 2; k <= npow; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int q = tid; q < (npow >> 1); q += GSR_FWD2_THREADS) {      // one compare-exchange per lane and step
+                    const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
+                    const unsigned long long a0 = s_keys[i], a1 = s_keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a0 > a1) == up) { s_keys[i] = a1; s_keys[l] = a0; }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < total; i += GSR_FWD2_THREADS) point_list[range.x + i] = (uint32_t)s_keys[i];
+    }
+    GSR_T_TICK(1)
+    bool done0 = !in0, done1 = !in1;
+    gsr_v2f T = {1.f, 1.f}, C0 = {0.f, 0.f}, C1 = {0.f, 0.f}, C2 = {0.f, 0.f}, Dd = {0.f, 0.f};
+    uint32_t last0 = 0, last1 = 0;
+    float zneed = 0.f;        // depth of the last list entry one of this lane's pixels had to look at
+
+    for (int base = 0; base < total; base += GSR_FWD2_BATCH) {
+        if (__syncthreads_and(done0 && done1)) break;
+        GSR_T_TICK(2)
+        GSR_T_COUNT(10, 1)
+        const int n = min(GSR_FWD2_BATCH, total - base);
+        for (int t = tid; t < n; t += GSR_FWD2_THREADS) {
+            const uint32_t id = LOCALSORT ? (uint32_t)s_keys[base + t] : point_list[range.x + base + t];
+            const float2 m = xy[id];
+            const float4 co = conic_op[id];
+            s.a[t] = make_float4(m.x, m.y, (-0.5f * GSR_LOG2E) * co.x, (-GSR_LOG2E) * co.y);
+            s.b[t] = make_float4((-0.5f * GSR_LOG2E) * co.z, co.w, depths[id], __uint_as_float(id));
+            const uint32_t hm = half_mask(m.y, co.x, co.y, co.z, co.w, ty * GSR_TILE);
+            s.c[t] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], __uint_as_float(hm));
+        }
+        __syncthreads();
+        GSR_T_TICK(3)
+        // this wave's compacted list (order preserved)
+        int cnt = 0;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int jj = c0 + lane;
+            const bool hit = jj < n && ((__float_as_uint(s.c[min(jj, GSR_FWD2_BATCH - 1)].w) >> wv) & 1u);
+            const unsigned long long mk = __ballot(hit);
+            if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
+            cnt += (int)__popcll(mk);
+        }
+        GSR_T_TICK(4)
+        for (int k = 0; k < cnt; k++) {
+            if (__all(done0 && done1)) break;                // whole wave finished: stop early
+            GSR_T_COUNT(11, 1)
+            const int j = __builtin_amdgcn_readfirstlane((int)s.list[wv][k]);
+            const float4 A = s.a[j];
+            const float4 B = s.b[j];
+            if (!(done0 && done1)) zneed = B.z;
+            const gsr_v2f dx = A.x - pxv;
+            const float dy = A.y - pyf;
+            const gsr_v2f p2 = pair_power2(dx, dy, A.z, A.w, B.x);
+            gsr_v2f al = {B.y * __builtin_amdgcn_exp2f(p2.x), B.y * __builtin_amdgcn_exp2f(p2.y)};
+            al.x = fminf(0.99f, al.x); al.y = fminf(0.99f, al.y);
+            const gsr_v2f tT = T * (1.f - al);
+            bool v0 = !done0 && !(p2.x > 0.0f) && !(al.x < 1.0f / 255.0f);
+            bool v1 = !done1 && !(p2.y > 0.0f) && !(al.y < 1.0f / 255.0f);
+            if (v0 && tT.x < 0.0001f) { done0 = true; v0 = false; }
+            if (v1 && tT.y < 0.0001f) { done1 = true; v1 = false; }
+            if (v0 || v1) {
+                const float4 Cc = s.c[j];
+                gsr_v2f w = al * T;
+                w.x = v0 ? w.x : 0.f; w.y = v1 ? w.y : 0.f;
+                C0 = C0 + Cc.x * w; C1 = C1 + Cc.y * w; C2 = C2 + Cc.z * w;
+                Dd = Dd + B.z * w;
+                T.x = v0 ? tT.x : T.x; T.y = v1 ? tT.y : T.y;
+                const uint32_t pos = (uint32_t)(base + j + 1);      // 1-based position in the tile list
+                last0 = v0 ? pos : last0; last1 = v1 ? pos : last1;
+            }
+            if (TOUCHED) {
+                // pose package: count pixels where the splat was blended with T still > 0.5;
+                // one atomic per wave instead of one per pixel
+                const int c = (int)__popcll(__ballot(v0 && tT.x > 0.5f)) + (int)__popcll(__ballot(v1 && tT.y > 0.5f));
+                if (c != 0 && lane == 0) atomicAdd(&n_touched[__float_as_uint(B.w)], c);
+            }
+        }
+        GSR_T_TICK(5)
+    }
+    GSR_T_TICK(6)
+    if (zb_next != nullptr) {
+        // Native loop bookkeeping: how deep did this tile have to look?  Next iteration's binning drops what
+        // lies behind that (plus a margin); if a pixel is still unsaturated at the end of a list from which
+        // entries were dropped, the speculation failed and the host redoes this forward with full lists.
+        const int unfinished = __syncthreads_or((in0 && !done0) || (in1 && !done1));
+        float zm = (in0 || in1) ? zneed : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) zm = fmaxf(zm, __shfl_xor(zm, off, 64));
+        if (lane == 0) s_zmax[wv] = zm;
+        __syncthreads();
+        if (tid == 0) {
+            zm = fmaxf(s_zmax[0], s_zmax[1]);
+            const float bound = unfinished ? __builtin_huge_valf() : zm * margin_mul + margin_add;
+            zb_next[tile] = bound;
+            const int sb = (ty >> 2) * sbx + (tx >> 2);
+            atomicMax(reinterpret_cast<int*>(zbc_next) + sb, __float_as_int(bound));     // bounds are >= 0: int order = float order
+            if (unfinished && trunc != nullptr && truncc[sb] != 0u) atomicAdd(fail, 1u);
+        }
+    }
+    const size_t N = (size_t)W * H;
+    if (in0) {
+        const int pix = W * py + px0;
+        n_contrib[pix] = last0;
+        out_color[pix] = C0.x + T.x * bg[0]; out_color[N + pix] = C1.x + T.x * bg[1]; out_color[2 * N + pix] = C2.x + T.x * bg[2];
+        out_alpha[pix] = 1.f - T.x;
+        out_depth[pix] = Dd.x;
+    }
+    if (in1) {
+        const int pix = W * py + px1;
+        n_contrib[pix] = last1;
+        out_color[pix] = C0.y + T.y * bg[0]; out_color[N + pix] = C1.y + T.y * bg[1]; out_color[2 * N + pix] = C2.y + T.y * bg[2];
+        out_alpha[pix] = 1.f - T.y;
+        out_depth[pix] = Dd.y;
+    }
+    GSR_T_TICK(7)
+    GSR_T_FLUSH(0)
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6, lean form.  Same tile / lane mapping and per-pixel recurrence as k_render_fwd; what changes is the shape of
+// the inner loop, because a tile's walk is one long dependent chain and a wave issues at most one instruction
+// every four cycles, VALU or scalar: the kernel's duration is (list length) x (instructions per list entry).
+//   * the wave's list is consumed eight entries at a time: one 8-byte LDS read brings their indices into two
+//     scalar registers, the bodies are unrolled, branch-free and their LDS reads independent of each other;
+//     the last (fewer than eight) entries go through a plain tail loop;
+//   * termination is folded into T: a finished pixel has T = 0 (its true transmittance is parked in Tfin), so
+//     every later weight alpha*T vanishes by itself and no `done` flag has to be carried through the body;
+//   * power > 0 is folded into G (G = 0 => alpha = 0 => skipped by the 1/255 test);
+//   * the conic is staged pre-multiplied by -log2(e)/2 (see pair_power2), so the exponent feeds v_exp_f32;
+//   * n_touched: eight popcounts are parked in eight lanes and leave as ONE atomic instruction per group.
+// ---------------------------------------------------------------------------------------------
+struct SplatLDS3 {
+    float4 a[GSR_BLOCK];   // x, y, A2, B2
+    float4 b[GSR_BLOCK];   // C2, opacity, depth, id (bits)
+    float4 c[GSR_BLOCK];   // r, g, b, quadrant mask (bits)
+    alignas(8) uint8_t list[4][GSR_BLOCK];   // per wave: staged splats that can touch its 8x8 block, in list order
+};
+
+template <bool TOUCHED, bool LOCALSORT>
+__global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd3(uint2* __restrict__ ranges,
+                                                          uint32_t* __restrict__ point_list,
+                                                          const unsigned long long* __restrict__ bins,
+                                                          const uint32_t* __restrict__ tile_cursor,
+                                                          int W, int H, int gx,
+                                                          int ntiles, const float2* __restrict__ xy,
+                                                          const float* __restrict__ rgb, const float* __restrict__ depths,
+                                                          const float4* __restrict__ conic_op, const float* __restrict__ bg,
+                                                          float* __restrict__ out_color, float* __restrict__ out_depth,
+                                                          float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
+                                                          int* __restrict__ n_touched, float* __restrict__ zb_next,
+                                                          const uint32_t* __restrict__ trunc, uint32_t* __restrict__ fail,
+                                                          float margin_mul, float margin_add, float* __restrict__ zbc_next,
+                                                          const uint32_t* __restrict__ truncc, int sbx)
+{
+    __shared__ SplatLDS3 s;
+    __shared__ float s_zmax[4];
+    __shared__ unsigned long long s_keys[LOCALSORT ? GSR_LSORT_CAP : 1];
+    GSR_T_DECL
+    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tx = tile % gx, ty = tile / gx;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int px = tx * GSR_TILE + (wv & 1) * 8 + (tid & 7), py = ty * GSR_TILE + (wv >> 1) * 8 + ((tid >> 3) & 7);
+    const bool inside = px < W && py < H;
+    const int pix_id = W * py + px;
+    const float pxf = (float)px, pyf = (float)py;
+    uint2 range;
+    if (LOCALSORT) {
+        range.x = (uint32_t)tile * GSR_LSORT_CAP;
+        range.y = range.x + tile_cursor[tile * GSR_CURSOR_STRIDE];
+    } else range = ranges[tile];
+    const int total = (int)(range.y - range.x);
+
+    if (LOCALSORT) {
+        // this tile's bin arrives unsorted: order it by (depth bits, index) in LDS (bitonic network), keep it there
+        // for the staging below and write the sorted indices (and the tile's range) back for the backward pass
+        if (total > GSR_LSORT_CAP) {          // block-uniform: give up, the host redoes the forward with global sorts
+            if (tid == 0) atomicAdd(fail, 0x10000u);
+            return;
+        }
+        if (tid == 0) ranges[tile] = range;
+        int npow = 64;
+        while (npow < total) npow <<= 1;
+        for (int i = tid; i < npow; i += GSR_BLOCK) s_keys[i] = (i < total) ? bins[range.x + i] : ~0ull;
+        __syncthreads();
+        GSR_T_TICK(0)
+        for (int k = 2; k <= npow; k <<= 1)
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int q = tid; q < (npow >> 1); q += GSR_BLOCK) {      // one compare-exchange per lane
+                    const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
+                    const unsigned long long a0 = s_keys[i], a1 = s_keys[l];
+                    const bool up = (i & k) == 0;
+                    if ((a0 > a1) == up) { s_keys[i] = a1; s_keys[l] = a0; }
+                }
+                __syncthreads();
+            }
+        for (int i = tid; i < total; i += GSR_BLOCK) point_list[range.x + i] = (uint32_t)s_keys[i];
+    }
+    GSR_T_TICK(1)
+    // T > 0: still compositing.  T == 0: finished (or outside the image); the pixel's transmittance is in Tfin.
+    float T = inside ? 1.0f : 0.f, Tfin = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f;
+    uint32_t last_contributor = 0;
+    float zneed = 0.f;        // depth bound of what this pixel had to look at (rounded up to its group of eight)
+
+    for (int base = 0; base < total; base += GSR_BLOCK) {
+        if (__syncthreads_and(T == 0.f)) break;
+        GSR_T_TICK(2)
+        GSR_T_COUNT(10, 1)
+        const int n = min(GSR_BLOCK, total - base);
+        if (tid < n) {
+            const uint32_t id = LOCALSORT ? (uint32_t)s_keys[base + tid] : point_list[range.x + base + tid];
+            const float2 m = xy[id];
+            const float4 co = conic_op[id];
+            s.a[tid] = make_float4(m.x, m.y, (-0.5f * GSR_LOG2E) * co.x, (-GSR_LOG2E) * co.y);
+            s.b[tid] = make_float4((-0.5f * GSR_LOG2E) * co.z, co.w, depths[id], __uint_as_float(id));
+            const uint32_t qm = quadrant_mask(m.x, m.y, co.x, co.y, co.z, co.w, tx * GSR_TILE, ty * GSR_TILE);
+            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], __uint_as_float(qm));
+        }
+        __syncthreads();
+        GSR_T_TICK(3)
+        // this wave's compacted list (order preserved)
+        int cnt = 0;
+        for (int c0 = 0; c0 < n; c0 += 64) {
+            const int jj = c0 + lane;
+            const bool hit = jj < n && ((__float_as_uint(s.c[min(jj, GSR_BLOCK - 1)].w) >> wv) & 1u);
+            const unsigned long long mk = __ballot(hit);
+            if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
+            cnt += (int)__popcll(mk);
+        }
+        GSR_T_TICK(4)
+        const int full = cnt & ~7;
+        for (int g0 = 0; g0 < full; g0 += 8) {
+            if (__all(T == 0.f)) break;                // whole wave finished: stop early
+            GSR_T_COUNT(11, 8)
+            const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(&s.list[wv][g0]);
+            const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)packed);
+            const uint32_t phi = __builtin_amdgcn_readfirstlane((uint32_t)(packed >> 32));
+            const bool alive0 = T > 0.f;
+            float zlast = 0.f;
+            int tcnt = 0;              // n_touched: lane k of the wave ends up with the count of the group's k-th splat
+#pragma unroll
+            for (int sidx = 0; sidx < 8; sidx++) {
+                const int j = (int)(((sidx < 4 ? plo : phi) >> (8 * (sidx & 3))) & 0xFFu);
+                const float4 A = s.a[j];
+                const float4 B = s.b[j];
+                const float4 Cc = s.c[j];
+                const float dx = A.x - pxf, dy = A.y - pyf;
+                const float p2 = __builtin_fmaf(dx, __builtin_fmaf(A.z, dx, A.w * dy), (B.x * dy) * dy);
+                float G = __builtin_amdgcn_exp2f(p2);
+                G = (p2 > 0.0f) ? 0.f : G;
+                const float alpha = fminf(0.99f, B.y * G);
+                const float test_T = T * (1.f - alpha);
+                const bool valid = !(alpha < 1.0f / 255.0f);
+                const bool kill = valid && test_T < 0.0001f;
+                const bool blend = valid && !kill;
+                const float w = blend ? alpha * T : 0.f;
+                C0 = __builtin_fmaf(Cc.x, w, C0); C1 = __builtin_fmaf(Cc.y, w, C1); C2 = __builtin_fmaf(Cc.z, w, C2);
+                Dd = __builtin_fmaf(B.z, w, Dd);
+                Tfin = kill ? fmaxf(Tfin, T) : Tfin;
+                T = kill ? 0.f : (valid ? test_T : T);
+                last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;      // 1-based position in the tile list
+                if (TOUCHED) {
+                    // pose package: count pixels where the splat was blended with T still > 0.5
+                    const int c = (int)__popcll(__ballot(valid && test_T > 0.5f));
+                    asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(tcnt) : "s"(c), "i"(sidx));
+                }
+                if (sidx == 7) zlast = B.z;
+            }
+            zneed = alive0 ? zlast : zneed;
+            if (TOUCHED) {
+                if (lane < 8 && tcnt != 0) {
+                    const int j = (int)s.list[wv][g0 + lane];
+                    atomicAdd(&n_touched[__float_as_uint(s.b[j].w)], tcnt);
+                }
+            }
+        }
+        // tail: fewer than eight entries left in this wave's list
+        for (int k = full; k < cnt; k++) {
+            if (__all(T == 0.f)) break;
+            GSR_T_COUNT(11, 1)
+            const int j = __builtin_amdgcn_readfirstlane((int)s.list[wv][k]);
+            const float4 A = s.a[j];
+            const float4 B = s.b[j];
+            const float4 Cc = s.c[j];
+            if (T > 0.f) zneed = B.z;
+            const float dx = A.x - pxf, dy = A.y - pyf;
+            const float p2 = __builtin_fmaf(dx, __builtin_fmaf(A.z, dx, A.w * dy), (B.x * dy) * dy);
+            float G = __builtin_amdgcn_exp2f(p2);
+            G = (p2 > 0.0f) ? 0.f : G;
+            const float alpha = fminf(0.99f, B.y * G);
+            const float test_T = T * (1.f - alpha);
+            const bool valid = !(alpha < 1.0f / 255.0f);
+            const bool kill = valid && test_T < 0.0001f;
+            const bool blend = valid && !kill;
+            const float w = blend ? alpha * T : 0.f;
+            C0 = __builtin_fmaf(Cc.x, w, C0); C1 = __builtin_fmaf(Cc.y, w, C1); C2 = __builtin_fmaf(Cc.z, w, C2);
+            Dd = __builtin_fmaf(B.z, w, Dd);
+            Tfin = kill ? fmaxf(Tfin, T) : Tfin;
+            T = kill ? 0.f : (valid ? test_T : T);
+            last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;
+            if (TOUCHED) {
+                const int c = (int)__popcll(__ballot(valid && test_T > 0.5f));
+                if (c != 0 && lane == 0) atomicAdd(&n_touched[__float_as_uint(B.w)], c);
+            }
+        }
+        GSR_T_TICK(5)
+    }
+    GSR_T_TICK(6)
+    const bool done = (T == 0.f);
+    const float T_out = fmaxf(T, Tfin);
+    if (zb_next != nullptr) {
+        // Native loop bookkeeping: how deep did this tile have to look?  Next iteration's binning drops what
+        // lies behind that (plus a margin); if a pixel is still unsaturated at the end of a list from which
+        // entries were dropped, the speculation failed and the host redoes this forward with full lists.
+        const int unfinished = __syncthreads_or(inside && !done);
+        float zm = inside ? zneed : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) zm = fmaxf(zm, __shfl_xor(zm, off, 64));
+        if (lane == 0) s_zmax[wv] = zm;
+        __syncthreads();
+        if (tid == 0) {
+            zm = fmaxf(fmaxf(s_zmax[0], s_zmax[1]), fmaxf(s_zmax[2], s_zmax[3]));
+            const float bound = unfinished ? __builtin_huge_valf() : zm * margin_mul + margin_add;
+            zb_next[tile] = bound;
+            const int sb = (ty >> 2) * sbx + (tx >> 2);
+            atomicMax(reinterpret_cast<int*>(zbc_next) + sb, __float_as_int(bound));     // bounds are >= 0: int order = float order
+            if (unfinished && trunc != nullptr && truncc[sb] != 0u) atomicAdd(fail, 1u);
+        }
+    }
+    if (inside) {
+        n_contrib[pix_id] = last_contributor;
+        const size_t N = (size_t)W * H;
+        out_color[pix_id] = C0 + T_out * bg[0];
+        out_color[N + pix_id] = C1 + T_out * bg[1];
+        out_color[2 * N + pix_id] = C2 + T_out * bg[2];
+        out_alpha[pix_id] = 1.f - T_out;
+        out_depth[pix_id] = Dd;
+    }
+    GSR_T_TICK(7)
+    GSR_T_FLUSH(0)
+}
+
+// ---------------------------------------------------------------------------------------------
 // K7  per-tile back-to-front gradient (replaces backward.cu:399-581 renderCUDA).
 // Same tile/lane mapping as K6.  Differences from the reference's schedule (results identical up to
 // fp32 summation order):  (1) the walk starts at the tile's deepest contributor (max n_contrib),

@@ -29,14 +29,16 @@ ms = (C.c_double * nk)(); cnt = (C.c_longlong * nk)(); lib.gsr_profile_collect(m
 print({names[i]: (round(ms[i] / max(cnt[i], 1), 4), cnt[i]) for i in range(nk)})
 lib.gsr_debug_timing(out)
 v = [int(x) for x in out]
-nw = 1200 * 4 * ITERS        # waves
+nw = 1200 * 4 * ITERS        # waves (K7); the packed forward kernel has 2 per tile
 def show(name, base, labels):
     print(name, "(cycles per wave, mean)")
     tot = 0
     for i, l in enumerate(labels):
         if l: print("  %-28s %10.0f" % (l, v[base + i] / nw)); tot += v[base + i] / nw if i < 9 else 0
     print("  %-28s %10.0f" % ("sum of phases", tot))
-show("k_render_fwd", 0, ["bins load", "sort + writeback", "batch top (barrier_and)", "staging gathers + barrier", "compaction", "compositing loop",
+nw = 1200 * 2 * ITERS
+show("k_render_fwd2", 0, ["bins load", "sort + writeback", "batch top (barrier_and)", "staging gathers + barrier", "compaction", "compositing loop",
                          "after loop", "epilogue after barrier_or", "barrier_or", "(wave lifetime)", "batches", "loop iterations"])
+nw = 1200 * 4 * ITERS
 show("k_render_bwd_mfma", 16, ["prologue", "batch top barrier", "staging + barrier", "compaction", "weights (8 splats)", "mfma + lds atomics",
                                "(loop exit)", "barrier after groups", "recombine + global atomics", "(wave lifetime)", "batches", "list entries"])
