@@ -518,32 +518,9 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
 #define GSR_FWD_ARGS im.ranges, local_path ? bl.vals : b.vals, (const unsigned long long*)bl.bins, (const uint32_t*)im.tile_cursor, \
                      width, height, gx, ntiles, (const float2*)g.xy, feat, \
                      (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
-                     zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), tl_guard.poison ? const_cast<uint32_t*>(tl_guard.poison) : im.fail, tl_spec.mul, tl_spec.add, zbc_next, \
-                     (const uint32_t*)im.truncc, im.sbx, (g_ablate >> 12) & 0xf
-#define GSR_FWD2_ARGS im.ranges, local_path ? bl.vals : b.vals, (const unsigned long long*)bl.bins, (const uint32_t*)im.tile_cursor, \
-                      width, height, gx, ntiles, (const float2*)g.xy, feat, \
-                      (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
-                      zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), tl_guard.poison ? const_cast<uint32_t*>(tl_guard.poison) : im.fail, \
-                      tl_spec.mul, tl_spec.add, zbc_next, (const uint32_t*)im.truncc, im.sbx
-    static const int fwd_v = getenv("GSR_FWD_V") ? atoi(getenv("GSR_FWD_V")) : 3;      // diagnostics: older kernel generations
-    const bool fwd_v1 = fwd_v == 1;
-    if (fwd_v == 3) {
-        if (local_path) {
-            if (n_touched) hipLaunchKernelGGL((k_render_fwd3<true, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD2_ARGS);
-            else hipLaunchKernelGGL((k_render_fwd3<false, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD2_ARGS);
-        } else {
-            if (n_touched) hipLaunchKernelGGL((k_render_fwd3<true, false>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD2_ARGS);
-            else hipLaunchKernelGGL((k_render_fwd3<false, false>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD2_ARGS);
-        }
-    } else if (!fwd_v1) {
-        if (local_path) {
-            if (n_touched) hipLaunchKernelGGL((k_render_fwd2<true, true>), dim3(ntiles), dim3(GSR_FWD2_THREADS), 0, st, GSR_FWD2_ARGS);
-            else hipLaunchKernelGGL((k_render_fwd2<false, true>), dim3(ntiles), dim3(GSR_FWD2_THREADS), 0, st, GSR_FWD2_ARGS);
-        } else {
-            if (n_touched) hipLaunchKernelGGL((k_render_fwd2<true, false>), dim3(ntiles), dim3(GSR_FWD2_THREADS), 0, st, GSR_FWD2_ARGS);
-            else hipLaunchKernelGGL((k_render_fwd2<false, false>), dim3(ntiles), dim3(GSR_FWD2_THREADS), 0, st, GSR_FWD2_ARGS);
-        }
-    } else if (local_path) {
+                     zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), tl_guard.poison ? const_cast<uint32_t*>(tl_guard.poison) : im.fail, \
+                     tl_spec.mul, tl_spec.add, zbc_next, (const uint32_t*)im.truncc, im.sbx
+    if (local_path) {
         if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
         else hipLaunchKernelGGL((k_render_fwd<false, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
     } else {
@@ -619,19 +596,11 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     delete psz;
     const float* color_ptr = colors_precomp ? colors_precomp : g.rgb;
     ProfScope* psb = new ProfScope(K_RENDER_BWD, st);
-    // 0 = DPP/VALU reduction (k_render_bwd), 1 = matrix-core contraction (k_render_bwd_mfma, default)
-    static const int bwd_env = getenv("GSR_BWD_DPP") ? 0 : 1;
-    const int bwd_variant = (g_ablate & 0x100) ? 0 : bwd_env;
 #define GSR_BWD_ARGS (const uint2*)im.ranges, (const uint32_t*)b.vals, width, height, gx, ntiles, background, (const float2*)g.xy, \
                      (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas, (const uint32_t*)im.n_contrib, dL_dpix, \
                      dL_ddepths, dL_dalphas, g.acc
-    if (bwd_variant == 1 && (g_ablate & 0xff) == 0) {
-        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, tl_guard);
-        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, tl_guard);
-    } else {
-        if (pose_mode) hipLaunchKernelGGL(k_render_bwd<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, g_ablate & 0xff, tl_guard);
-        else hipLaunchKernelGGL(k_render_bwd<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, g_ablate & 0xff, tl_guard);
-    }
+    if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, tl_guard);
+    else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, tl_guard);
     delete psb;
     LAUNCHCHK("k_render_bwd");
 

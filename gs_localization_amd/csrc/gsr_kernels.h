@@ -493,393 +493,23 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
     return m;
 }
 
-struct SplatLDS {
-    float4 a[GSR_BLOCK];   // x, y, conic.x, conic.y
-    float4 b[GSR_BLOCK];   // conic.z, opacity, depth, id (bits)
-    float4 c[GSR_BLOCK];   // r, g, b, quadrant mask (bits)
-    uint8_t list[4][GSR_BLOCK];   // per wave: staged splats that can touch its 8x8 block, in list order
-};
-
-template <bool TOUCHED, bool LOCALSORT>
-__global__ void __launch_bounds__(GSR_BLOCK) k_render_fwd(uint2* __restrict__ ranges,
-                                                          uint32_t* __restrict__ point_list,
-                                                          const unsigned long long* __restrict__ bins,
-                                                          const uint32_t* __restrict__ tile_cursor,
-                                                          int W, int H, int gx,
-                                                          int ntiles, const float2* __restrict__ xy,
-                                                          const float* __restrict__ rgb, const float* __restrict__ depths,
-                                                          const float4* __restrict__ conic_op, const float* __restrict__ bg,
-                                                          float* __restrict__ out_color, float* __restrict__ out_depth,
-                                                          float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-                                                          int* __restrict__ n_touched, float* __restrict__ zb_next,
-                                                          const uint32_t* __restrict__ trunc, uint32_t* __restrict__ fail,
-                                                          float margin_mul, float margin_add, float* __restrict__ zbc_next,
-                                                          const uint32_t* __restrict__ truncc, int sbx, int ablate)
-{
-    __shared__ SplatLDS s;
-    GSR_T_DECL
-    __shared__ float s_zmax[4];
-    const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x;
-    // each wave owns an 8x8 pixel block of the tile (not a 16x4 strip): a splat's footprint then misses
-    // whole waves more often, which is what the wave-level skips below key on
-    const int px = tx * GSR_TILE + ((tid >> 6) & 1) * 8 + (tid & 7), py = ty * GSR_TILE + (tid >> 7) * 8 + ((tid >> 3) & 7);
-    const bool inside = px < W && py < H;
-    const int pix_id = W * py + px;
-    const float pxf = (float)px, pyf = (float)py;
-    uint2 range;
-    if (LOCALSORT) {
-        range.x = (uint32_t)tile * GSR_LSORT_CAP;
-        range.y = range.x + tile_cursor[tile * GSR_CURSOR_STRIDE];
-    } else range = ranges[tile];
-    const int total = (int)(range.y - range.x);
-
-    const int lane = tid & 63, wv = tid >> 6;
-    __shared__ unsigned long long s_keys[LOCALSORT ? GSR_LSORT_CAP : 1];
-    if (LOCALSORT) {
-        // this tile's bin arrives unsorted: order it by (depth bits, index) in LDS (bitonic network), keep it there
-        // for the staging below and write the sorted indices (and the tile's range) back for the backward pass
-        if (total > GSR_LSORT_CAP) {          // block-uniform: give up, the host redoes the forward with global sorts
-            if (tid == 0) atomicAdd(fail, 0x10000u);
-            return;
-        }
-        if (tid == 0) ranges[tile] = range;
-        int npow = 64;
-        while (npow < total) npow <<= 1;
-        for (int i = tid; i < npow; i += GSR_BLOCK) s_keys[i] = (i < total) ? bins[range.x + i] : ~0ull;
-        __syncthreads();
-        GSR_T_TICK(0)
-        for (int k = 2; k <= npow && !(ablate & 2); k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int q = tid; q < (npow >> 1); q += GSR_BLOCK) {      // one compare-exchange per lane
-                    const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
-                    const unsigned long long a0 = s_keys[i], a1 = s_keys[l];
-                    const bool up = (i & k) == 0;
-                    if ((a0 > a1) == up) { s_keys[i] = a1; s_keys[l] = a0; }
-                }
-                __syncthreads();
-            }
-        for (int i = tid; i < total; i += GSR_BLOCK) point_list[range.x + i] = (uint32_t)s_keys[i];
-    }
-    GSR_T_TICK(1)
-    bool done = !inside;
-    float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f;
-    uint32_t last_contributor = 0;
-    float zneed = 0.f;        // depth of the last list entry this pixel had to look at
-
-    for (int base = 0; base < total; base += GSR_BLOCK) {
-        if (__syncthreads_and(done)) break;
-        GSR_T_TICK(2)
-        GSR_T_COUNT(10, 1)
-        const int n = min(GSR_BLOCK, total - base);
-        if (tid < n && !(ablate & 8)) {
-            const uint32_t id = LOCALSORT ? (uint32_t)s_keys[base + tid] : point_list[range.x + base + tid];
-            const float2 m = xy[id];
-            const float4 co = conic_op[id];
-            s.a[tid] = make_float4(m.x, m.y, co.x, co.y);
-            s.b[tid] = make_float4(co.z, co.w, depths[id], __uint_as_float(id));
-            const uint32_t qm = quadrant_mask(m.x, m.y, co.x, co.y, co.z, co.w, tx * GSR_TILE, ty * GSR_TILE);
-            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], __uint_as_float(qm));
-        }
-        __syncthreads();
-        GSR_T_TICK(3)
-        // this wave's compacted list (order preserved)
-        int cnt = 0;
-        for (int c0 = 0; c0 < n; c0 += 64) {
-            const int jj = c0 + lane;
-            const bool hit = jj < n && ((__float_as_uint(s.c[min(jj, GSR_BLOCK - 1)].w) >> wv) & 1u);
-            const unsigned long long mk = __ballot(hit);
-            if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
-            cnt += (int)__popcll(mk);
-        }
-        if (ablate & 1) cnt = 0;
-        GSR_T_TICK(4)
-        for (int k = 0; k < cnt; k++) {
-            if (__all(done)) break;                // whole wave finished: stop early
-            GSR_T_COUNT(11, 1)
-            const int j = __builtin_amdgcn_readfirstlane((int)s.list[wv][k]);
-            const float4 A = s.a[j];
-            const float4 B = s.b[j];
-            if (!done) zneed = B.z;
-            const float dx = A.x - pxf, dy = A.y - pyf;
-            const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-            const float alpha = fminf(0.99f, B.y * __expf(power));
-            const float test_T = T * (1.f - alpha);
-            bool valid = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (valid && test_T < 0.0001f) { done = true; valid = false; }
-            if (valid) {
-                const float4 Cc = s.c[j];
-                const float w = alpha * T;
-                C0 += Cc.x * w; C1 += Cc.y * w; C2 += Cc.z * w;
-                Dd += B.z * w;
-                T = test_T;
-                last_contributor = (uint32_t)(base + j + 1);      // 1-based position in the tile list
-            }
-            if (TOUCHED && !(ablate & 4)) {
-                // pose package: count pixels where the splat was blended with T still > 0.5;
-                // one atomic per wave instead of one per pixel
-                const unsigned long long m = __ballot(valid && test_T > 0.5f);
-                if (m != 0ull && lane == 0) atomicAdd(&n_touched[__float_as_uint(B.w)], (int)__popcll(m));
-            }
-        }
-        GSR_T_TICK(5)
-    }
-    GSR_T_TICK(6)
-    if (zb_next != nullptr) {
-        // Native loop bookkeeping: how deep did this tile have to look?  Next iteration's binning drops what
-        // lies behind that (plus a margin); if a pixel is still unsaturated at the end of a list from which
-        // entries were dropped, the speculation failed and the host redoes this forward with full lists.
-        const int unfinished = __syncthreads_or(inside && !done);
-        GSR_T_TICK(8)
-        float zm = inside ? zneed : 0.f;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) zm = fmaxf(zm, __shfl_xor(zm, off, 64));
-        if (lane == 0) s_zmax[wv] = zm;
-        __syncthreads();
-        if (tid == 0) {
-            zm = fmaxf(fmaxf(s_zmax[0], s_zmax[1]), fmaxf(s_zmax[2], s_zmax[3]));
-            const float bound = unfinished ? __builtin_huge_valf() : zm * margin_mul + margin_add;
-            zb_next[tile] = bound;
-            const int sb = (ty >> 2) * sbx + (tx >> 2);
-            atomicMax(reinterpret_cast<int*>(zbc_next) + sb, __float_as_int(bound));     // bounds are >= 0: int order = float order
-            if (unfinished && trunc != nullptr && truncc[sb] != 0u && !ablate) atomicAdd(fail, 1u);
-        }
-    }
-    if (inside) {
-        n_contrib[pix_id] = last_contributor;
-        const size_t N = (size_t)W * H;
-        out_color[pix_id] = C0 + T * bg[0];
-        out_color[N + pix_id] = C1 + T * bg[1];
-        out_color[2 * N + pix_id] = C2 + T * bg[2];
-        out_alpha[pix_id] = 1.f - T;
-        out_depth[pix_id] = Dd;
-    }
-    GSR_T_TICK(7)
-    GSR_T_FLUSH(0)
-}
-
-// ---------------------------------------------------------------------------------------------
-// K6, packed form (the one the host launches).  Same walk and the same per-pixel recurrence as k_render_fwd, but
-//   * a workgroup is TWO waves per tile and every lane owns TWO pixels of one row, (x, y) and (x + 8, y): the
-//     per-pixel arithmetic then runs on the packed fp32 pipes (v_pk_fma/mul/add_f32: two pixels per instruction)
-//     and the splat record is read from LDS once per two pixels;
-//   * the conic is staged pre-multiplied, A2 = -a/2 log2e, B2 = -b log2e, C2 = -c/2 log2e, so that
-//         power log2e = dx (A2 dx + B2 dy) + C2 dy dy          (dy and B2 dy, C2 dy dy shared by the pair)
-//     takes two packed FMAs per pair and feeds v_exp_f32 directly.  k_render_bwd2 evaluates the identical
-//     expression, so both passes see the same alpha bits.
-// ---------------------------------------------------------------------------------------------
-typedef float gsr_v2f __attribute__((ext_vector_type(2)));
 #define GSR_LOG2E 1.4426950408889634f
-#define GSR_FWD2_THREADS 128
-#define GSR_FWD2_BATCH 256
-struct SplatLDS2 {
-    float4 a[GSR_FWD2_BATCH];   // x, y, A2, B2
-    float4 b[GSR_FWD2_BATCH];   // C2, opacity, depth, id (bits)
-    float4 c[GSR_FWD2_BATCH];   // r, g, b, half-tile mask (bits)
-    uint8_t list[2][GSR_FWD2_BATCH];   // per wave: staged splats that can touch its 16x8 half tile, in list order
-};
-// Which of the tile's two 16x8 halves (= waves) a staged splat can change; same ellipse bound and slack as
-// quadrant_mask.  Bit w set <=> wave w must look at the splat.  Not positive definite => both.
-__device__ __forceinline__ uint32_t half_mask(float my, float A, float B, float C, float opacity, int Y0)
-{
-    const float det = A * C - B * B;
-    if (!(A > 0.f && C > 0.f && det > 0.f)) return 0x3u;
-    const float qmax = (opacity > 0.f) ? (__logf(255.f * opacity) + 0.02f) : -1.f;
-    if (qmax < 0.f) return 0u;
-    const float hy = __builtin_amdgcn_sqrtf(2.f * qmax * __builtin_amdgcn_rcpf(det) * A) * 1.0001f + 0.01f;
-    const float yl = my - hy - (float)Y0, yh = my + hy - (float)Y0;
-    return ((yl <= 7.f && yh >= 0.f) ? 1u : 0u) | ((yl <= 15.f && yh >= 8.f) ? 2u : 0u);
-}
-// power * log2(e) for the pixel pair; see the header comment
-__device__ __forceinline__ gsr_v2f pair_power2(gsr_v2f dx, float dy, float A2, float B2, float C2)
-{
-    const float u = B2 * dy;
-    const float t = (C2 * dy) * dy;
-    const gsr_v2f uu = {u, u}, tt = {t, t}, aa = {A2, A2};
-    return __builtin_elementwise_fma(dx, __builtin_elementwise_fma(aa, dx, uu), tt);
-}
-
-template <bool TOUCHED, bool LOCALSORT>
-__global__ void __launch_bounds__(GSR_FWD2_THREADS) k_render_fwd2(uint2* __restrict__ ranges,
-                                                          uint32_t* __restrict__ point_list,
-                                                          const unsigned long long* __restrict__ bins,
-                                                          const uint32_t* __restrict__ tile_cursor,
-                                                          int W, int H, int gx,
-                                                          int ntiles, const float2* __restrict__ xy,
-                                                          const float* __restrict__ rgb, const float* __restrict__ depths,
-                                                          const float4* __restrict__ conic_op, const float* __restrict__ bg,
-                                                          float* __restrict__ out_color, float* __restrict__ out_depth,
-                                                          float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
-                                                          int* __restrict__ n_touched, float* __restrict__ zb_next,
-                                                          const uint32_t* __restrict__ trunc, uint32_t* __restrict__ fail,
-                                                          float margin_mul, float margin_add, float* __restrict__ zbc_next,
-                                                          const uint32_t* __restrict__ truncc, int sbx)
-{
-    __shared__ SplatLDS2 s;
-    GSR_T_DECL
-    __shared__ float s_zmax[2];
-    __shared__ unsigned long long s_keys[LOCALSORT ? GSR_LSORT_CAP : 1];
-    const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int px0 = tx * GSR_TILE + (lane & 7), px1 = px0 + 8, py = ty * GSR_TILE + wv * 8 + (lane >> 3);
-    const bool in0 = px0 < W && py < H, in1 = px1 < W && py < H;
-    const gsr_v2f pxv = {(float)px0, (float)px1};
-    const float pyf = (float)py;
-    uint2 range;
-    if (LOCALSORT) {
-        range.x = (uint32_t)tile * GSR_LSORT_CAP;
-        range.y = range.x + tile_cursor[tile * GSR_CURSOR_STRIDE];
-    } else range = ranges[tile];
-    const int total = (int)(range.y - range.x);
-
-    if (LOCALSORT) {
-        // this tile's bin arrives unsorted: order it by (depth bits, index) in LDS (bitonic network), keep it there
-        // for the staging below and write the sorted indices (and the tile's range) back for the backward pass
-        if (total > GSR_LSORT_CAP) {          // block-uniform: give up, the host redoes the forward with global sorts
-            if (tid == 0) atomicAdd(fail, 0x10000u);
-            return;
-        }
-        if (tid == 0) ranges[tile] = range;
-        int npow = 64;
-        while (npow < total) npow <<= 1;
-        for (int i = tid; i < npow; i += GSR_FWD2_THREADS) s_keys[i] = (i < total) ? bins[range.x + i] : ~0ull;
-        __syncthreads();
-        GSR_T_TICK(0)
-        for (int k = 2; k <= npow; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int q = tid; q < (npow >> 1); q += GSR_FWD2_THREADS) {      // one compare-exchange per lane and step
-                    const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
-                    const unsigned long long a0 = s_keys[i], a1 = s_keys[l];
-                    const bool up = (i & k) == 0;
-                    if ((a0 > a1) == up) { s_keys[i] = a1; s_keys[l] = a0; }
-                }
-                __syncthreads();
-            }
-        for (int i = tid; i < total; i += GSR_FWD2_THREADS) point_list[range.x + i] = (uint32_t)s_keys[i];
-    }
-    GSR_T_TICK(1)
-    bool done0 = !in0, done1 = !in1;
-    gsr_v2f T = {1.f, 1.f}, C0 = {0.f, 0.f}, C1 = {0.f, 0.f}, C2 = {0.f, 0.f}, Dd = {0.f, 0.f};
-    uint32_t last0 = 0, last1 = 0;
-    float zneed = 0.f;        // depth of the last list entry one of this lane's pixels had to look at
-
-    for (int base = 0; base < total; base += GSR_FWD2_BATCH) {
-        if (__syncthreads_and(done0 && done1)) break;
-        GSR_T_TICK(2)
-        GSR_T_COUNT(10, 1)
-        const int n = min(GSR_FWD2_BATCH, total - base);
-        for (int t = tid; t < n; t += GSR_FWD2_THREADS) {
-            const uint32_t id = LOCALSORT ? (uint32_t)s_keys[base + t] : point_list[range.x + base + t];
-            const float2 m = xy[id];
-            const float4 co = conic_op[id];
-            s.a[t] = make_float4(m.x, m.y, (-0.5f * GSR_LOG2E) * co.x, (-GSR_LOG2E) * co.y);
-            s.b[t] = make_float4((-0.5f * GSR_LOG2E) * co.z, co.w, depths[id], __uint_as_float(id));
-            const uint32_t hm = half_mask(m.y, co.x, co.y, co.z, co.w, ty * GSR_TILE);
-            s.c[t] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], __uint_as_float(hm));
-        }
-        __syncthreads();
-        GSR_T_TICK(3)
-        // this wave's compacted list (order preserved)
-        int cnt = 0;
-        for (int c0 = 0; c0 < n; c0 += 64) {
-            const int jj = c0 + lane;
-            const bool hit = jj < n && ((__float_as_uint(s.c[min(jj, GSR_FWD2_BATCH - 1)].w) >> wv) & 1u);
-            const unsigned long long mk = __ballot(hit);
-            if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
-            cnt += (int)__popcll(mk);
-        }
-        GSR_T_TICK(4)
-        for (int k = 0; k < cnt; k++) {
-            if (__all(done0 && done1)) break;                // whole wave finished: stop early
-            GSR_T_COUNT(11, 1)
-            const int j = __builtin_amdgcn_readfirstlane((int)s.list[wv][k]);
-            const float4 A = s.a[j];
-            const float4 B = s.b[j];
-            if (!(done0 && done1)) zneed = B.z;
-            const gsr_v2f dx = A.x - pxv;
-            const float dy = A.y - pyf;
-            const gsr_v2f p2 = pair_power2(dx, dy, A.z, A.w, B.x);
-            gsr_v2f al = {B.y * __builtin_amdgcn_exp2f(p2.x), B.y * __builtin_amdgcn_exp2f(p2.y)};
-            al.x = fminf(0.99f, al.x); al.y = fminf(0.99f, al.y);
-            const gsr_v2f tT = T * (1.f - al);
-            bool v0 = !done0 && !(p2.x > 0.0f) && !(al.x < 1.0f / 255.0f);
-            bool v1 = !done1 && !(p2.y > 0.0f) && !(al.y < 1.0f / 255.0f);
-            if (v0 && tT.x < 0.0001f) { done0 = true; v0 = false; }
-            if (v1 && tT.y < 0.0001f) { done1 = true; v1 = false; }
-            if (v0 || v1) {
-                const float4 Cc = s.c[j];
-                gsr_v2f w = al * T;
-                w.x = v0 ? w.x : 0.f; w.y = v1 ? w.y : 0.f;
-                C0 = C0 + Cc.x * w; C1 = C1 + Cc.y * w; C2 = C2 + Cc.z * w;
-                Dd = Dd + B.z * w;
-                T.x = v0 ? tT.x : T.x; T.y = v1 ? tT.y : T.y;
-                const uint32_t pos = (uint32_t)(base + j + 1);      // 1-based position in the tile list
-                last0 = v0 ? pos : last0; last1 = v1 ? pos : last1;
-            }
-            if (TOUCHED) {
-                // pose package: count pixels where the splat was blended with T still > 0.5;
-                // one atomic per wave instead of one per pixel
-                const int c = (int)__popcll(__ballot(v0 && tT.x > 0.5f)) + (int)__popcll(__ballot(v1 && tT.y > 0.5f));
-                if (c != 0 && lane == 0) atomicAdd(&n_touched[__float_as_uint(B.w)], c);
-            }
-        }
-        GSR_T_TICK(5)
-    }
-    GSR_T_TICK(6)
-    if (zb_next != nullptr) {
-        // Native loop bookkeeping: how deep did this tile have to look?  Next iteration's binning drops what
-        // lies behind that (plus a margin); if a pixel is still unsaturated at the end of a list from which
-        // entries were dropped, the speculation failed and the host redoes this forward with full lists.
-        const int unfinished = __syncthreads_or((in0 && !done0) || (in1 && !done1));
-        float zm = (in0 || in1) ? zneed : 0.f;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) zm = fmaxf(zm, __shfl_xor(zm, off, 64));
-        if (lane == 0) s_zmax[wv] = zm;
-        __syncthreads();
-        if (tid == 0) {
-            zm = fmaxf(s_zmax[0], s_zmax[1]);
-            const float bound = unfinished ? __builtin_huge_valf() : zm * margin_mul + margin_add;
-            zb_next[tile] = bound;
-            const int sb = (ty >> 2) * sbx + (tx >> 2);
-            atomicMax(reinterpret_cast<int*>(zbc_next) + sb, __float_as_int(bound));     // bounds are >= 0: int order = float order
-            if (unfinished && trunc != nullptr && truncc[sb] != 0u) atomicAdd(fail, 1u);
-        }
-    }
-    const size_t N = (size_t)W * H;
-    if (in0) {
-        const int pix = W * py + px0;
-        n_contrib[pix] = last0;
-        out_color[pix] = C0.x + T.x * bg[0]; out_color[N + pix] = C1.x + T.x * bg[1]; out_color[2 * N + pix] = C2.x + T.x * bg[2];
-        out_alpha[pix] = 1.f - T.x;
-        out_depth[pix] = Dd.x;
-    }
-    if (in1) {
-        const int pix = W * py + px1;
-        n_contrib[pix] = last1;
-        out_color[pix] = C0.y + T.y * bg[0]; out_color[N + pix] = C1.y + T.y * bg[1]; out_color[2 * N + pix] = C2.y + T.y * bg[2];
-        out_alpha[pix] = 1.f - T.y;
-        out_depth[pix] = Dd.y;
-    }
-    GSR_T_TICK(7)
-    GSR_T_FLUSH(0)
-}
-
-// ---------------------------------------------------------------------------------------------
-// K6, lean form.  Same tile / lane mapping and per-pixel recurrence as k_render_fwd; what changes is the shape of
-// the inner loop, because a tile's walk is one long dependent chain and a wave issues at most one instruction
-// every four cycles, VALU or scalar: the kernel's duration is (list length) x (instructions per list entry).
+// The inner loop is shaped by one fact: a tile's walk is a long dependent chain and a wave issues at most one
+// instruction every four cycles, VALU or scalar, so the kernel's duration is (list length) x (instructions per
+// list entry) -- not bytes, not flops.
 //   * the wave's list is consumed eight entries at a time: one 8-byte LDS read brings their indices into two
 //     scalar registers, the bodies are unrolled, branch-free and their LDS reads independent of each other;
 //     the last (fewer than eight) entries go through a plain tail loop;
 //   * termination is folded into T: a finished pixel has T = 0 (its true transmittance is parked in Tfin), so
 //     every later weight alpha*T vanishes by itself and no `done` flag has to be carried through the body;
-//   * power > 0 is folded into G (G = 0 => alpha = 0 => skipped by the 1/255 test);
-//   * the conic is staged pre-multiplied by -log2(e)/2 (see pair_power2), so the exponent feeds v_exp_f32;
+//   * power > 0 (forward.cu:342) is folded into G (G = 0 => alpha = 0 => skipped by the 1/255 test);
+//   * the conic is staged pre-multiplied, A2 = -a/2 log2e, B2 = -b log2e, C2 = -c/2 log2e, so that
+//         power log2e = dx (A2 dx + B2 dy) + C2 dy dy
+//     is two FMAs and three multiplies and feeds v_exp_f32 directly; K7 evaluates the identical expression, so
+//     both passes see the same alpha bits;
 //   * n_touched: eight popcounts are parked in eight lanes and leave as ONE atomic instruction per group.
 // ---------------------------------------------------------------------------------------------
-struct SplatLDS3 {
+struct SplatLDS {
     float4 a[GSR_BLOCK];   // x, y, A2, B2
     float4 b[GSR_BLOCK];   // C2, opacity, depth, id (bits)
     float4 c[GSR_BLOCK];   // r, g, b, quadrant mask (bits)
@@ -887,7 +517,7 @@ struct SplatLDS3 {
 };
 
 template <bool TOUCHED, bool LOCALSORT>
-__global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd3(uint2* __restrict__ ranges,
+__global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__ ranges,
                                                           uint32_t* __restrict__ point_list,
                                                           const unsigned long long* __restrict__ bins,
                                                           const uint32_t* __restrict__ tile_cursor,
@@ -902,7 +532,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd3(uint2* __restrict_
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
                                                           const uint32_t* __restrict__ truncc, int sbx)
 {
-    __shared__ SplatLDS3 s;
+    __shared__ SplatLDS s;
     __shared__ float s_zmax[4];
     __shared__ unsigned long long s_keys[LOCALSORT ? GSR_LSORT_CAP : 1];
     GSR_T_DECL
@@ -1091,167 +721,16 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd3(uint2* __restrict_
 
 // ---------------------------------------------------------------------------------------------
 // K7  per-tile back-to-front gradient (replaces backward.cu:399-581 renderCUDA).
-// Same tile/lane mapping as K6.  Differences from the reference's schedule (results identical up to
-// fp32 summation order):  (1) the walk starts at the tile's deepest contributor (max n_contrib),
-// not at the end of the tile list;  (2) the 9 (+1 for the pose package) per-splat sums are reduced
-// across the 64 lanes with DPP, across the 4 waves with LDS float atomics, and leave the workgroup
-// as ONE global atomic per (tile, splat, quantity) instead of one per (pixel, splat, quantity).
+// Same tile / lane mapping as K6.  Differences from the reference's schedule (results identical up to fp32
+// summation order):  (1) the walk starts at the tile's deepest contributor (max n_contrib), not at the end of
+// the tile list;  (2) the per-splat sums are contracted over the 64 pixels of a wave on the matrix cores, merged
+// across the 4 waves with LDS float atomics, and leave the workgroup as ONE global atomic per (tile, splat,
+// quantity) instead of one per (pixel, splat, quantity).
 // ---------------------------------------------------------------------------------------------
-#define GSR_NQ 10
 // packed per-Gaussian accumulator record of K7 (floats): 0-2 dL/dcolor, 3-4 dL/dmean2D, 5-7 dL/dconic (a,b,c),
 // 8 dL/dopacity, 9 dL/dz (pose package), 10-11 padding
 #define GSR_ACC_STRIDE 12
-struct BwdLDS {
-    float4 a[GSR_BLOCK];
-    float4 b[GSR_BLOCK];
-    float4 c[GSR_BLOCK];
-    float acc[GSR_BLOCK][GSR_NQ + 1];   // +1 pad: conflict-free column flush
-    int wmax[4];
-    uint8_t list[4][GSR_BLOCK];         // per wave: staged splats its 8x8 block can see, in walk order
-};
-
-template <bool POSE>
-__global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restrict__ ranges,
-                                                          const uint32_t* __restrict__ point_list, int W, int H, int gx,
-                                                          int ntiles, const float* __restrict__ bg,
-                                                          const float2* __restrict__ xy, const float4* __restrict__ conic_op,
-                                                          const float* __restrict__ rgb, const float* __restrict__ depths,
-                                                          const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
-                                                          const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
-                                                          const float* __restrict__ dL_dalphas, float* __restrict__ acc,
-                                                          int ablate, LoopGuard guard)
-{
-    __shared__ BwdLDS s;
-    if (guard.frozen()) return;
-    const int tile = xcd_remap(blockIdx.x, ntiles);
-    const int tx = tile % gx, ty = tile / gx;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int px = tx * GSR_TILE + (wv & 1) * 8 + (tid & 7), py = ty * GSR_TILE + (wv >> 1) * 8 + ((tid >> 3) & 7);
-    const bool inside = px < W && py < H;
-    const int pix_id = W * py + px;
-    const float pxf = (float)px, pyf = (float)py;
-    const uint2 range = ranges[tile];
-    const size_t N = (size_t)W * H;
-
-    const float T_final = inside ? (1.f - alphas[pix_id]) : 0.f;
-    float T = T_final;
-    const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
-    float dpx = 0.f, dpy = 0.f, dpz = 0.f, dLd = 0.f, dLa = 0.f;
-    if (inside) {
-        dpx = dL_dpix[pix_id]; dpy = dL_dpix[N + pix_id]; dpz = dL_dpix[2 * N + pix_id];
-        dLd = dL_ddepths[pix_id]; dLa = dL_dalphas[pix_id];
-    }
-    const float bg_dot = bg[0] * dpx + bg[1] * dpy + bg[2] * dpz;
-
-    // deepest contributor of the tile
-    int m = last_contributor;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
-    if (lane == 0) s.wmax[wv] = m;
-    __syncthreads();
-    const int total = max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3]));
-
-    const int wave_max = s.wmax[wv];            // deepest contributor among this wave's 64 pixels
-    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, adr = 0.f, aar = 0.f;
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
-    const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
-
-    for (int base = 0; base < total; base += GSR_BLOCK) {
-        __syncthreads();
-        const int n = min(GSR_BLOCK, total - base);
-        if (tid < n) {
-            const uint32_t id = point_list[range.x + (total - 1 - base - tid)];
-            const float2 mm = xy[id];
-            const float4 co = conic_op[id];
-            s.a[tid] = make_float4(mm.x, mm.y, co.x, co.y);
-            s.b[tid] = make_float4(co.z, co.w, depths[id], __uint_as_float(id));
-            const uint32_t qm = quadrant_mask(mm.x, mm.y, co.x, co.y, co.z, co.w, tx * GSR_TILE, ty * GSR_TILE);
-            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], __uint_as_float(qm));
-        }
-#pragma unroll
-        for (int q = 0; q < GSR_NQ + 1; q++) s.acc[tid][q] = 0.f;
-        __syncthreads();
-        // this wave's compacted list: splats whose footprint reaches its block and that are not deeper than
-        // the deepest contributor of its pixels.  Entry j of the batch is position total - base - j (1-based).
-        int cnt = 0;
-        for (int c0 = 0; c0 < n; c0 += 64) {
-            const int jj = c0 + lane;
-            const bool hit = jj < n && ((__float_as_uint(s.c[min(jj, GSR_BLOCK - 1)].w) >> wv) & 1u) &&
-                             (total - base - jj) <= wave_max;
-            const unsigned long long mk = __ballot(hit);
-            if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
-            cnt += (int)__popcll(mk);
-        }
-        if (ablate & 8) cnt = 0;
-        for (int k = 0; k < cnt; k++) {
-            const int j = __builtin_amdgcn_readfirstlane((int)s.list[wv][k]);
-            const int contributor = total - base - j;
-            const float4 A = s.a[j];
-            const float4 B = s.b[j];
-            const float dx = A.x - pxf, dy = A.y - pyf;
-            const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-            const float G = __expf(power);
-            const float alpha = fminf(0.99f, B.y * G);
-            const bool valid = (contributor <= last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-            if (__ballot(valid) == 0ull) continue;     // wave-uniform skip
-            float v[GSR_NQ];
-#pragma unroll
-            for (int q = 0; q < GSR_NQ; q++) v[q] = 0.f;
-            if (valid) {
-                const float4 Cc = s.c[j];
-                // one hardware reciprocal (1 ulp) serves both 1/(1-alpha) uses of backward.cu:516,558
-                const float r1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                T = T * r1ma;
-                const float dchannel_dcolor = alpha * T;
-                float dL_dopa = 0.f;
-                ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = Cc.x; dL_dopa += (Cc.x - ar0) * dpx;
-                ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = Cc.y; dL_dopa += (Cc.y - ar1) * dpy;
-                ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = Cc.z; dL_dopa += (Cc.z - ar2) * dpz;
-                v[0] = dchannel_dcolor * dpx; v[1] = dchannel_dcolor * dpy; v[2] = dchannel_dcolor * dpz;
-                adr = last_alpha * last_depth + (1.f - last_alpha) * adr; last_depth = B.z;
-                dL_dopa += (B.z - adr) * dLd;
-                if (POSE) v[9] = dchannel_dcolor * dLd;
-                aar = last_alpha + (1.f - last_alpha) * aar;
-                dL_dopa += -(alpha - aar) * dLa;
-                dL_dopa *= T;
-                last_alpha = alpha;
-                dL_dopa += (-T_final * r1ma) * bg_dot;
-                const float dL_dG = B.y * dL_dopa;
-                const float gdx = G * dx, gdy = G * dy;
-                const float dG_ddelx = -gdx * A.z - gdy * A.w;
-                const float dG_ddely = -gdy * B.x - gdx * A.w;
-                v[3] = dL_dG * dG_ddelx * ddelx_dx;
-                v[4] = dL_dG * dG_ddely * ddely_dy;
-                v[5] = -0.5f * gdx * dx * dL_dG;
-                v[6] = -0.5f * gdx * dy * dL_dG;
-                v[7] = -0.5f * gdy * dy * dL_dG;
-                v[8] = G * dL_dopa;
-            }
-            if (!(ablate & 2)) row_sum10_to_lane15(v);
-            else {
-#pragma unroll
-                for (int q = 0; q < GSR_NQ; q++) asm volatile("" ::"v"(v[q]));
-            }
-            if (!(ablate & 1) && (lane & 15) == 15) {
-#pragma unroll
-                for (int q = 0; q < (POSE ? GSR_NQ : GSR_NQ - 1); q++) atomicAdd(&s.acc[j][q], v[q]);
-            }
-        }
-        __syncthreads();
-        if (ablate & 4) continue;
-        // flush: one lane per (splat, quantity) so that a wave instruction adds runs of consecutive floats of
-        // the packed per-Gaussian records (GSR_ACC_STRIDE floats each) instead of 64 scattered rows
-        for (int e = tid; e < n * GSR_NQ; e += GSR_BLOCK) {
-            const int j = e / GSR_NQ, q = e - j * GSR_NQ;
-            const float val = s.acc[j][q];
-            if (val != 0.f) atomicAdd(&acc[(size_t)__float_as_uint(s.b[j].w) * GSR_ACC_STRIDE + q], val);
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K7, matrix-core form.  Same walk, same per-pixel recurrences as k_render_bwd, but each (pixel, splat) pair
-// only produces TWO weights,
+// Each (pixel, splat) pair only produces TWO weights,
 //     W1 = alpha * T                      (d pixel / d colour_i,  backward.cu:517)
 //     W2 = G * dL/d(alpha_i)              (backward.cu:549-578 before the per-quantity factors)
 // and every per-splat gradient sum is a pixel moment of them:
@@ -1263,16 +742,22 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_render_bwd(const uint2* __restric
 // A = 8 splats x {W1,W2} (16 rows) by 4 pixels, B = 4 pixels by 16 columns, 16 steps per 64-pixel wave.
 // The weights are transposed through a per-wave LDS buffer ([pixel][17] floats, conflict-free both ways);
 // the 16 B operands per lane are pixel constants and stay in registers for the whole kernel.
-// VALU work per pair drops from ~75 maths + 54 reduction instructions to ~60.
+//
+// Like K6 the walk is a dependent chain whose length is (entries) x (instructions per entry), so the per-entry
+// body is branch-free: a splat that is skipped for this pixel (behind its last contributor, alpha < 1/255 or
+// power > 0) is given alpha = 0, for which every recurrence below is the identity -- T/(1-0) = T, the
+// "colour behind" accumulators absorb the previous splat exactly as they would one step later -- instead of
+// being branched around.  alpha is recomputed with K6's expression (pre-scaled conic, v_exp_f32), bit for bit.
 // ---------------------------------------------------------------------------------------------
 typedef float gsr_f32x4 __attribute__((ext_vector_type(4)));
 #define GSR_WT_STRIDE 17
-// splats staged per batch: 128 keeps the workgroup at 32 KB of LDS = 4-5 workgroups per CU
+// splats staged per batch: 128 keeps the workgroup at ~31 KB of LDS = 5 workgroups per CU
 #define GSR_BWD_BATCH 128
 struct BwdMfmaLDS {
-    float4 a[GSR_BWD_BATCH];
-    float4 b[GSR_BWD_BATCH];
-    float4 c[GSR_BWD_BATCH];
+    float4 a[GSR_BWD_BATCH];            // x, y, A2, B2 (pre-scaled conic, see K6)
+    float4 b[GSR_BWD_BATCH];            // C2, opacity, depth, id (bits)
+    float4 c[GSR_BWD_BATCH];            // r, g, b, quadrant mask (bits)
+    float4 d[GSR_BWD_BATCH];            // conic a, b, c as stored (for the recombination), unused
     float acc[GSR_BWD_BATCH][10];       // per staged splat: 0-3 = sum W1 (dpx,dpy,dpz,dLd), 4-9 = W2 moments
     float wt[4][64 * GSR_WT_STRIDE];    // per wave: [pixel][0..7] = W1 of 8 splats, [8..15] = W2
     int wmax[4];
@@ -1314,6 +799,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         dLd = dL_ddepths[pix_id]; dLa = dL_dalphas[pix_id];
     }
     const float bg_dot = bg[0] * dpx + bg[1] * dpy + bg[2] * dpz;
+    const float nTf_bg = -T_final * bg_dot;
 
     // B operands: lane (k = lane>>4, j = lane&15) needs g[pixel 4t+k][column j] for t = 0..15
     float* wt = s.wt[wv];
@@ -1336,10 +822,12 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
     const int total = max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3]));
     const int wave_max = s.wmax[wv];
 
-    float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, adr = 0.f, aar = 0.f;
-    float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_depth = 0.f;
+    float av = 0.f, lv = 0.f, last_alpha = 0.f;      // the "composited behind me" recurrence, see the loop body
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const int arow = (lane >> 4), acol = (lane & 15);
+    // which (row, column) entries of the MFMA result this lane owns are meaningful: rows 0-7 (W1) x columns 0-3,
+    // rows 8-15 (W2) x columns 4-9
+    const bool owns = (arow < 2) ? (acol < 4) : (acol >= 4 && acol < 10);
 
     GSR_T_TICK(0)
     for (int base = 0; base < total; base += GSR_BWD_BATCH) {
@@ -1351,10 +839,11 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             const uint32_t id = point_list[range.x + (total - 1 - base - tid)];
             const float2 mm = xy[id];
             const float4 co = conic_op[id];
-            s.a[tid] = make_float4(mm.x, mm.y, co.x, co.y);
-            s.b[tid] = make_float4(co.z, co.w, depths[id], __uint_as_float(id));
+            s.a[tid] = make_float4(mm.x, mm.y, (-0.5f * GSR_LOG2E) * co.x, (-GSR_LOG2E) * co.y);
+            s.b[tid] = make_float4((-0.5f * GSR_LOG2E) * co.z, co.w, depths[id], __uint_as_float(id));
             const uint32_t qm = quadrant_mask(mm.x, mm.y, co.x, co.y, co.z, co.w, tx * GSR_TILE, ty * GSR_TILE);
             s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], __uint_as_float(qm));
+            s.d[tid] = make_float4(co.x, co.y, co.z, 0.f);
         }
         if (tid < GSR_BWD_BATCH) {
 #pragma unroll
@@ -1380,44 +869,45 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(&s.list[wv][g0]);
             const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)packed);
             const uint32_t phi = __builtin_amdgcn_readfirstlane((uint32_t)(packed >> 32));
+            const int gn = min(8, cnt - g0);          // wave-uniform
 #pragma unroll
             for (int sidx = 0; sidx < 8; sidx++) {
                 float w1 = 0.f, w2 = 0.f;
-                if (g0 + sidx < cnt) {          // wave-uniform
+                if (sidx < gn) {
                     const int j = (int)(((sidx < 4 ? plo : phi) >> (8 * (sidx & 3))) & 0xFFu);
                     const int contributor = total - base - j;
                     const float4 A = s.a[j];
                     const float4 B = s.b[j];
+                    const float4 Cc = s.c[j];
                     const float dx = A.x - pxf, dy = A.y - pyf;
-                    const float power = -0.5f * (A.z * dx * dx + B.x * dy * dy) - A.w * dx * dy;
-                    const float G = __expf(power);
+                    const float p2 = __builtin_fmaf(dx, __builtin_fmaf(A.z, dx, A.w * dy), (B.x * dy) * dy);
+                    float G = __builtin_amdgcn_exp2f(p2);
+                    G = (p2 > 0.0f) ? 0.f : G;
                     const float alpha = fminf(0.99f, B.y * G);
-                    const bool valid = (contributor <= last_contributor) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-                    if (valid) {
-                        const float4 Cc = s.c[j];
-                        const float r1ma = __builtin_amdgcn_rcpf(1.f - alpha);
-                        T = T * r1ma;
-                        w1 = alpha * T;
-                        float dL_dopa = 0.f;
-                        ar0 = last_alpha * lc0 + (1.f - last_alpha) * ar0; lc0 = Cc.x; dL_dopa += (Cc.x - ar0) * dpx;
-                        ar1 = last_alpha * lc1 + (1.f - last_alpha) * ar1; lc1 = Cc.y; dL_dopa += (Cc.y - ar1) * dpy;
-                        ar2 = last_alpha * lc2 + (1.f - last_alpha) * ar2; lc2 = Cc.z; dL_dopa += (Cc.z - ar2) * dpz;
-                        adr = last_alpha * last_depth + (1.f - last_alpha) * adr; last_depth = B.z;
-                        dL_dopa += (B.z - adr) * dLd;
-                        aar = last_alpha + (1.f - last_alpha) * aar;
-                        dL_dopa += -(alpha - aar) * dLa;
-                        dL_dopa *= T;
-                        last_alpha = alpha;
-                        dL_dopa += (-T_final * r1ma) * bg_dot;
-                        w2 = G * dL_dopa;
-                    }
+                    const bool valid = (contributor <= last_contributor) && !(alpha < 1.0f / 255.0f);
+                    const float ae = valid ? alpha : 0.f;          // skipped => transparent: every update below is the identity
+                    const float r1ma = __builtin_amdgcn_rcpf(1.f - ae);
+                    T = T * r1ma;
+                    w1 = ae * T;
+                    // backward.cu:520-547 keeps four "composited behind me" recurrences (r, g, b, depth) plus the
+                    // accumulated alpha, each of the form  X <- la * lastvalue + (1 - la) * X,  and then sums
+                    // (value - X) * dL/dchannel.  All of it is linear in the per-splat value, so ONE recurrence on
+                    //     v = c . dL/dpix + depth * dL/ddepth - dL/dalpha
+                    // carries the same information:  sum_ch (value_ch - X_ch) dL_ch - (alpha - A) dL/dalpha
+                    //                              = (v - V) + (1 - alpha) dL/dalpha
+                    const float v = __builtin_fmaf(B.z, dLd, __builtin_fmaf(Cc.z, dpz, __builtin_fmaf(Cc.y, dpy, Cc.x * dpx))) - dLa;
+                    av = __builtin_fmaf(last_alpha, lv, (1.f - last_alpha) * av);
+                    float dL_dopa = __builtin_fmaf(1.f - ae, dLa, v - av);
+                    dL_dopa = __builtin_fmaf(dL_dopa, T, nTf_bg * r1ma);
+                    w2 = valid ? G * dL_dopa : 0.f;
+                    lv = v; last_alpha = ae;
                 }
                 row[sidx] = w1;
                 row[8 + sidx] = w2;
             }
+            GSR_T_TICK(4)
             // S[16 rows = {W1,W2} x 8 splats][16 cols] += W[rows][4 pixels] * g[4 pixels][cols], 16 steps
             // (two accumulators: the 16x16x4 f32 MFMA issues every 32 cycles but a dependent one waits 40)
-            GSR_T_TICK(4)
             gsr_f32x4 D = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {
@@ -1427,14 +917,14 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                 D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop1, Breg[t + 1], D2, 0, 0, 0);
             }
             D = D + D2;
-            // D: lane holds column acol, rows 4*arow + r.  Rows 0-7 are W1 sums (columns 0-3 meaningful),
-            // rows 8-15 are W2 sums (columns 4-9 meaningful); merge the four waves in LDS.
-            const bool w1rows = arow < 2;
-            if ((w1rows && acol < 4) || (!w1rows && acol >= 4 && acol < 10)) {
+            // D: lane holds column acol, rows 4*arow + r, i.e. splat (arow & 1) * 4 + r of the group.  Merge the
+            // four waves in LDS (unconditional float atomics: adding 0 is harmless, a branch per value is not free).
+            if (owns) {
+                const uint32_t four = (arow & 1) ? phi : plo;
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
                     const int sidx = (arow & 1) * 4 + r;
-                    if (g0 + sidx < cnt && D[r] != 0.f) atomicAdd(&s.acc[s.list[wv][g0 + sidx]][acol], D[r]);
+                    if (sidx < gn) atomicAdd(&s.acc[(four >> (8 * r)) & 0xFFu][acol], D[r]);
                 }
             }
             GSR_T_TICK(5)
@@ -1442,29 +932,33 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         GSR_T_TICK(6)
         __syncthreads();
         GSR_T_TICK(7)
-        // per staged splat: recombine the moments into the nine (ten) gradient sums, one run of atomics each
+        // per staged splat: recombine the moments into the nine (ten) gradient sums (in place) ...
         if (tid < n) {
-            const float* q = s.acc[tid];
+            float* q = s.acc[tid];
             const float M0 = q[4], Mu = q[5], Mv = q[6], Muu = q[7], Muv = q[8], Mvv = q[9];
-            if (q[0] != 0.f || q[1] != 0.f || q[2] != 0.f || q[3] != 0.f || M0 != 0.f || Mu != 0.f || Mv != 0.f ||
-                Muu != 0.f || Muv != 0.f || Mvv != 0.f) {
-                const float4 A = s.a[tid];
-                const float4 B = s.b[tid];
-                const float mu = A.x - cx0, mv = A.y - cy0, ca = A.z, cb = A.w, cc = B.x, o = B.y;
-                const float sdx = mu * M0 - Mu, sdy = mv * M0 - Mv;
-                const float sxx = mu * mu * M0 - 2.f * mu * Mu + Muu;
-                const float sxy = mu * mv * M0 - mu * Mv - mv * Mu + Muv;
-                const float syy = mv * mv * M0 - 2.f * mv * Mv + Mvv;
-                float* dst = acc + (size_t)__float_as_uint(B.w) * GSR_ACC_STRIDE;
-                atomicAdd(dst + 0, q[0]); atomicAdd(dst + 1, q[1]); atomicAdd(dst + 2, q[2]);
-                atomicAdd(dst + 3, -o * ddelx_dx * (ca * sdx + cb * sdy));
-                atomicAdd(dst + 4, -o * ddely_dy * (cc * sdy + cb * sdx));
-                atomicAdd(dst + 5, -0.5f * o * sxx);
-                atomicAdd(dst + 6, -0.5f * o * sxy);
-                atomicAdd(dst + 7, -0.5f * o * syy);
-                atomicAdd(dst + 8, M0);
-                if (POSE) atomicAdd(dst + 9, q[3]);
-            }
+            const float dz = q[3];
+            const float4 A = s.a[tid];
+            const float4 Dc = s.d[tid];
+            const float mu = A.x - cx0, mv = A.y - cy0, ca = Dc.x, cb = Dc.y, cc = Dc.z, o = s.b[tid].y;
+            const float sdx = mu * M0 - Mu, sdy = mv * M0 - Mv;
+            const float sxx = mu * mu * M0 - 2.f * mu * Mu + Muu;
+            const float sxy = mu * mv * M0 - mu * Mv - mv * Mu + Muv;
+            const float syy = mv * mv * M0 - 2.f * mv * Mv + Mvv;
+            q[3] = -o * ddelx_dx * (ca * sdx + cb * sdy);
+            q[4] = -o * ddely_dy * (cc * sdy + cb * sdx);
+            q[5] = -0.5f * o * sxx;
+            q[6] = -0.5f * o * sxy;
+            q[7] = -0.5f * o * syy;
+            q[8] = M0;
+            q[9] = dz;
+        }
+        __syncthreads();
+        // ... and flush them: one lane per (splat, quantity), so that a wave instruction adds runs of consecutive
+        // floats of the packed per-Gaussian records instead of 64 scattered rows
+        for (int e = tid; e < n * 10; e += GSR_BLOCK) {
+            const int j = e / 10, q = e - j * 10;
+            const float val = s.acc[j][q];
+            if (val != 0.f && (POSE || q != 9)) atomicAdd(&acc[(size_t)__float_as_uint(s.b[j].w) * GSR_ACC_STRIDE + q], val);
         }
         GSR_T_TICK(8)
     }

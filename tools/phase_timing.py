@@ -36,8 +36,8 @@ def show(name, base, labels):
     for i, l in enumerate(labels):
         if l: print("  %-28s %10.0f" % (l, v[base + i] / nw)); tot += v[base + i] / nw if i < 9 else 0
     print("  %-28s %10.0f" % ("sum of phases", tot))
-nw = 1200 * 2 * ITERS
-show("k_render_fwd2", 0, ["bins load", "sort + writeback", "batch top (barrier_and)", "staging gathers + barrier", "compaction", "compositing loop",
+nw = 1200 * 4 * ITERS
+show("k_render_fwd", 0, ["bins load", "sort + writeback", "batch top (barrier_and)", "staging gathers + barrier", "compaction", "compositing loop",
                          "after loop", "epilogue after barrier_or", "barrier_or", "(wave lifetime)", "batches", "loop iterations"])
 nw = 1200 * 4 * ITERS
 show("k_render_bwd_mfma", 16, ["prologue", "batch top barrier", "staging + barrier", "compaction", "weights (8 splats)", "mfma + lds atomics",
