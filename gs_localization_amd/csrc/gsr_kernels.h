@@ -199,8 +199,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     if (live) {
         a.radii[idx] = 0;
         a.tiles_touched[idx] = 0;
-        a.depth_key[idx] = 0xFFFFFFFFu;     // culled Gaussians sort behind every visible one
-        a.order_in[idx] = (uint32_t)idx;
+        if (a.bins == nullptr) {            // (the bin-by-tile path has no depth sort)
+            a.depth_key[idx] = 0xFFFFFFFFu;     // culled Gaussians sort behind every visible one
+            a.order_in[idx] = (uint32_t)idx;
+        }
         p = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
         const float4 ph = xform4x4(p, a.proj);
         const float pw = 1.0f / (ph.w + 0.0000001f);
@@ -333,7 +335,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                 for (int sx = rx0 >> 2; sx <= (rx1 - 1) >> 2; sx++)
                     if (a.truncc[sy * a.sbx + sx] == 0u) a.truncc[sy * a.sbx + sx] = 1u;
         a.tiles_touched[idx] = cnt;
-        if (cnt) a.depth_key[idx] = __float_as_uint(zv);
+        if (cnt && a.bins == nullptr) a.depth_key[idx] = __float_as_uint(zv);
     }
 }
 
@@ -563,6 +565,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
         for (int i = tid; i < npow; i += GSR_BLOCK) s_keys[i] = (i < total) ? bins[range.x + i] : ~0ull;
         __syncthreads();
         GSR_T_TICK(0)
+        // (measured: a rank sort and a variant with wave-local steps and 3 barriers instead of 45 are no faster --
+        // with five workgroups per CU sorting at the same time the step is bound by its ~25 VALU instructions)
         for (int k = 2; k <= npow; k <<= 1)
             for (int j = k >> 1; j > 0; j >>= 1) {
                 for (int q = tid; q < (npow >> 1); q += GSR_BLOCK) {      // one compare-exchange per lane

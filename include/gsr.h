@@ -171,7 +171,7 @@ int gsr_tracking_loss(int width, int height, const float* image, const float* de
 /* Device-resident pose state: GSR_POSE_STATE_FLOATS floats, layout
  *   [0..8] R (row-major W2C rotation) [9..11] T [12..14] cam_rot_delta [15..17] cam_trans_delta
  *   [18] exposure_a [19] exposure_b [20..27] Adam exp_avg [28..35] Adam exp_avg_sq [36] Adam step
- *   [37] converged [38] last loss [39] |tau| [48..63] viewmatrix [64..79] projmatrix [80..82] campos
+ *   [37] converged [38] last loss [39] |tau| [40] poison word of gsr_refine (uint32) [48..63] viewmatrix [64..79] projmatrix [80..82] campos
  * (viewmatrix/projmatrix/campos are what gsr_forward / gsr_backward take).
  * gsr_pose_init fills [48..82] from R, T and projmatrix_raw (16 floats, P^T row-major), replacing
  * Camera.world_view_transform / full_proj_transform / camera_center (tools/camera_utils.py:144-158). */
@@ -187,7 +187,10 @@ int gsr_pose_step(float* pose_state, const float* dL_dtau, const float* loss_out
 /* The whole refinement loop of gradient_decent() (7scenes_localize_full_dslam.py:29-93) in one call:
  * up to max_iters x { gsr_forward (pose package) -> gsr_tracking_loss -> gsr_backward -> gsr_pose_step },
  * stopping like the reference when update_pose reports convergence.  Every pointer is a device pointer
- * owned by the caller; workspaces are requested through the resize callbacks only when they must grow. */
+ * owned by the caller; workspaces are requested through the resize callbacks only when they must grow.
+ * loss_out is scratch here (the last loss is pose_state[38]).  In the steady state no call inside blocks on the
+ * device: every kernel of the loop checks the converged / poison words itself and the host reads each
+ * iteration's 16-byte status one iteration late. */
 typedef struct gsr_refine_args {
     int P, D, M;
     const float* means3D; const float* shs; const float* opacities; const float* scales; const float* rotations;

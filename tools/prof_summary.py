@@ -82,15 +82,15 @@ def main():
             if k:
                 acc[k][0] += 1
                 acc[k][1] += float(r["Counter_Value"])
-        # per API call: forward kernels run once per render_fwd launch, backward ones once per render_bwd launch
-        n_fwd = max(acc["render_fwd"][0], 1)
-        n_bwd = max(acc["render_bwd"][0], 1)
+        # per LAUNCH of that kernel (the rocPRIM sort groups several kernels: per rocPRIM kernel launch)
         for k, (c, v) in acc.items():
-            traffic.setdefault(k, {})[which + "_KiB_per_iter"] = v / (n_bwd if k.endswith("_bwd") else n_fwd)
+            traffic.setdefault(k, {})[which + "_KiB_per_iter"] = v / max(c, 1)
+            traffic[k]["launches_" + which] = c
     out = {}
     for k, d in traffic.items():
         fe, wr = d.get("fetch_KiB_per_iter", 0.0) * 1024, d.get("write_KiB_per_iter", 0.0) * 1024
-        out[k] = {"fetch_raw_bytes": fe, "fetch_x2_bytes": 2 * fe, "write_bytes": wr, "hbm_bytes_corrected": 2 * fe + wr}
+        out[k] = {"per": "launch", "launches_profiled": d.get("launches_fetch", d.get("launches_write", 0)),
+                  "fetch_raw_bytes": fe, "fetch_x2_bytes": 2 * fe, "write_bytes": wr, "hbm_bytes_corrected": 2 * fe + wr}
     if out:
         json.dump(out, open(os.path.join(ROOT, "profiles", f"{a.tag}_traffic.json"), "w"), indent=1)
         json.dump({k: v["hbm_bytes_corrected"] for k, v in out.items()}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
