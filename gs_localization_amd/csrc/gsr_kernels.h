@@ -510,6 +510,9 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
 //     is two FMAs and three multiplies and feeds v_exp_f32 directly; K7 evaluates the identical expression, so
 //     both passes see the same alpha bits;
 //   * n_touched: eight popcounts are parked in eight lanes and leave as ONE atomic instruction per group.
+// Tried and dropped (measured slower, single frame and with four frames in flight): two pixels per lane on the
+// packed fp32 pipes with two waves per tile -- fewer VALU instructions per pixel, but half the waves to hide the
+// chain's latency and twice the per-lane predicate bookkeeping (80 vs 60 us, 5.0 vs 5.2 k it/s at 4 frames).
 // ---------------------------------------------------------------------------------------------
 struct SplatLDS {
     float4 a[GSR_BLOCK];   // x, y, A2, B2

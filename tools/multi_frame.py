@@ -15,7 +15,7 @@ def make_view():
     vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=dev)
     return vp
 K = 200
-for nf, spec in ((4, True), (6, True), (8, True)) * 3:
+for nf, spec in ((4, True), (6, True)) * 3:
     frs = [PL.FusedRefiner(model, H, W, device=dev) for _ in range(nf)]
     vps = [make_view() for _ in range(nf)]
     inits = [torch.tensor(S.se3_exp(np.r_[0.01 * (i + 1), 0.01, -0.01, 0.01, 0.0, 0.005 * i]), dtype=torch.float32, device=dev) for i in range(nf)]
