@@ -236,19 +236,67 @@ struct Side {
     hipStream_t st = nullptr;
     hipEvent_t fork = nullptr, join = nullptr;
 };
-thread_local Side g_side[64];      // per host thread: concurrent callers (one stream each) do not share events
-Side* get_side()
+// Side streams are pooled per device (host threads come and go -- one per frame in flight -- and creating a
+// stream costs milliseconds).  A Side is held for the duration of one API call; the next holder's work simply
+// queues behind whatever the previous one left on the stream.
+struct SidePool { std::mutex mu; std::vector<Side*> free_list[64]; };
+SidePool g_sides;
+Side* side_acquire()
 {
     static const bool disabled = getenv("GSR_NO_SIDE_STREAM") != nullptr;     // diagnostics
-    if (disabled) return nullptr;
-    if (g_dev < 0 || g_dev >= 64) return nullptr;
-    Side& sd = g_side[g_dev];
-    if (!sd.st) {
-        if (hipStreamCreateWithFlags(&sd.st, hipStreamNonBlocking) != hipSuccess) { sd.st = nullptr; (void)hipGetLastError(); return nullptr; }
-        if (hipEventCreateWithFlags(&sd.fork, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&sd.join, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    if (disabled || g_dev < 0 || g_dev >= 64) return nullptr;
+    {
+        std::lock_guard<std::mutex> l(g_sides.mu);
+        auto& fl = g_sides.free_list[g_dev];
+        if (!fl.empty()) { Side* sd = fl.back(); fl.pop_back(); return sd; }
     }
-    return &sd;
+    Side* sd = new Side();
+    if (hipStreamCreateWithFlags(&sd->st, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&sd->fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&sd->join, hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        delete sd;           // (whatever was created is leaked: this only happens when the runtime is out of resources)
+        return nullptr;
+    }
+    return sd;
+}
+struct SideLease {          // RAII: returns the Side to its device's pool
+    Side* sd; int dev;
+    explicit SideLease(bool want) : sd(want ? side_acquire() : nullptr), dev(g_dev) {}
+    ~SideLease()
+    {
+        if (!sd) return;
+        std::lock_guard<std::mutex> l(g_sides.mu);
+        g_sides.free_list[dev].push_back(sd);
+    }
+    SideLease(const SideLease&) = delete;
+    SideLease& operator=(const SideLease&) = delete;
+};
+
+// Pinned status slots + events of one gsr_refine call, pooled for the same reason.
+struct LoopCtx { float* h_status = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
+struct LoopCtxPool { std::mutex mu; std::vector<LoopCtx*> free_list; };
+LoopCtxPool g_loop_ctx;
+LoopCtx* loop_ctx_acquire()
+{
+    {
+        std::lock_guard<std::mutex> l(g_loop_ctx.mu);
+        if (!g_loop_ctx.free_list.empty()) { LoopCtx* c = g_loop_ctx.free_list.back(); g_loop_ctx.free_list.pop_back(); return c; }
+    }
+    LoopCtx* c = new LoopCtx();
+    if (hipHostMalloc((void**)&c->h_status, 2 * 4 * sizeof(float)) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->ev[1], hipEventDisableTiming) != hipSuccess) {
+        (void)hipGetLastError();
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+void loop_ctx_release(LoopCtx* c)
+{
+    std::lock_guard<std::mutex> l(g_loop_ctx.mu);
+    g_loop_ctx.free_list.push_back(c);
 }
 
 int select_device_of(const void* p)
@@ -427,7 +475,8 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     // SH colours only feed the compositing kernel: fork them onto the side stream, join before K6.  (Not on the
     // bin-by-tile path: without the sort chain there is nothing latency-bound to hide them under, and the
     // fork/join costs more than it gains -- measured 0.466 vs 0.434 ms per iteration.)
-    Side* side = (colors_precomp == nullptr && !debug && !local_path) ? get_side() : nullptr;
+    SideLease side_lease(colors_precomp == nullptr && !debug && !local_path);
+    Side* side = side_lease.sd;
     if (colors_precomp == nullptr) {
         if (side) {
             HIPCHK(hipEventRecord(side->fork, st));
@@ -570,7 +619,8 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
 
     // Gradient tensors are zero-filled on the side stream while K7 runs; K8/K9 then only writes non-zero rows.
     // (the native loop zero-fills once per frame and keeps the tensors consistent through the dirty bits)
-    Side* side = (debug || tl_native_loop) ? nullptr : get_side();
+    SideLease side_lease(!(debug || tl_native_loop));
+    Side* side = side_lease.sd;
     hipStream_t zs = side ? side->st : st;
     if (side) {
         HIPCHK(hipEventRecord(side->fork, st));
@@ -712,13 +762,14 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     if (rc != GSR_OK) return rc;
     // Pinned status slots (one per iteration parity): {converged, loss, |tau|, poison} copied out behind each
     // iteration, and the events that say when a slot is valid.
-    static thread_local float* h_status = nullptr;
-    static thread_local hipEvent_t ev_status[2] = {nullptr, nullptr};
-    if (!h_status) {
-        HIPCHK(hipHostMalloc((void**)&h_status, 2 * 4 * sizeof(float)));
-        HIPCHK(hipEventCreateWithFlags(&ev_status[0], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ev_status[1], hipEventDisableTiming));
-    }
+    struct CtxLease {
+        LoopCtx* c;
+        CtxLease() : c(loop_ctx_acquire()) {}
+        ~CtxLease() { if (c) loop_ctx_release(c); }
+    } ctx_lease;
+    if (!ctx_lease.c) return fail(GSR_E_HIP, "gsr_refine: could not create pinned status slots / events%s", "");
+    float* h_status = ctx_lease.c->h_status;
+    hipEvent_t* ev_status = ctx_lease.c->ev;
     CachedBuf gb{a->geometry_buffer, a->geometry_ctx, nullptr, 0}, bb{a->binning_buffer, a->binning_ctx, nullptr, 0},
         ib{a->image_buffer, a->image_ctx, nullptr, 0};
     float* ps = a->pose_state;
