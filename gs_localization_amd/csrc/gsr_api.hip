@@ -927,6 +927,43 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     return 0;
 }
 
+int gsr_map_from_ply_rows(int P, const float* rows, int row_floats, const int* cols, int n_rest, int activate,
+                          float* means3D, float* shs, float* opacities, float* scales, float* rotations, void* stream)
+{
+    using namespace gsr;
+    const int debug = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (P < 0 || row_floats <= 0) return fail(GSR_E_INVALID, "gsr_map_from_ply_rows: bad sizes%s", "");
+    if (n_rest < 0 || n_rest > GSR_PLY_MAX_REST || n_rest % 3 != 0)
+        return fail(GSR_E_INVALID, "gsr_map_from_ply_rows: n_rest must be a multiple of 3, at most 45%s", "");
+    if (P == 0) return 0;
+    if (!rows || !cols || !means3D || !shs || !opacities || !scales || !rotations)
+        return fail(GSR_E_INVALID, "gsr_map_from_ply_rows: NULL pointer%s", "");
+    for (int i = 0; i < 14 + n_rest; i++)
+        if (cols[i] < 0 || cols[i] >= row_floats) return fail(GSR_E_INVALID, "gsr_map_from_ply_rows: column index outside the row%s", "");
+    int rc = select_device_of(rows);
+    if (rc != GSR_OK) return rc;
+    PlyMapArgs a;
+    a.P = P; a.row_floats = row_floats; a.activate = activate ? 1 : 0; a.M = 1 + n_rest / 3;
+    a.rows = rows; a.means3D = means3D; a.shs = shs; a.opacities = opacities; a.scales = scales; a.rotations = rotations;
+    int k = 0;
+    for (int i = 0; i < 3; i++) a.c.xyz[i] = cols[k++];
+    for (int i = 0; i < 3; i++) a.c.f_dc[i] = cols[k++];
+    for (int i = 0; i < GSR_PLY_MAX_REST; i++) a.c.f_rest[i] = (i < n_rest) ? cols[k++] : 0;
+    a.c.opacity = cols[k++];
+    for (int i = 0; i < 3; i++) a.c.scale[i] = cols[k++];
+    for (int i = 0; i < 4; i++) a.c.rot[i] = cols[k++];
+    a.c.n_rest = n_rest;
+    const size_t lds = (size_t)64 * (row_floats | 1) * sizeof(float);
+    if (lds > 64 * 1024) return fail(GSR_E_INVALID, "gsr_map_from_ply_rows: rows of more than 255 floats are not supported%s", "");
+    if (row_floats == 62 && a.M == 16)        // what 3DGS writes for SH degree 3 (x y z nx ny nz + 56)
+        hipLaunchKernelGGL((k_map_from_ply_rows<62, 16>), dim3((P + 63) / 64), dim3(64), lds, st, a);
+    else
+        hipLaunchKernelGGL((k_map_from_ply_rows<0, 0>), dim3((P + 63) / 64), dim3(64), lds, st, a);
+    LAUNCHCHK("k_map_from_ply_rows");
+    return 0;
+}
+
 int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix, uint8_t* present,
                      void* stream)
 {

@@ -1416,6 +1416,115 @@ __global__ void k_tau_finish(const double* acc, float* out)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Map on-disk rows -> device layout.  Replaces the host-side column gathering of
+// load_ply (gs_localization/pipelines/tools/gaussian_model.py:377-467, gaussian_splatting/scene/
+// gaussian_model.py:215-256) and, for the read-only localisation map, the activation getters that the
+// reference re-evaluates in every render() (tools/gaussian_model.py:77-96: exp, sigmoid, normalize, cat).
+// Input: the P vertex rows exactly as stored in point_cloud.ply (row_floats f32 properties each), uploaded
+// as they are.  One wave per 64 rows: the rows arrive as one coalesced stream into LDS, each lane then
+// converts its own row.  HBM-bound byte work: 4*row_floats B in, (19 + 3M)*4 B out per Gaussian.
+// ---------------------------------------------------------------------------------------------
+#define GSR_PLY_MAX_REST 45
+struct PlyCols {             // float index of each property inside a row
+    int xyz[3], f_dc[3], f_rest[GSR_PLY_MAX_REST], opacity, scale[3], rot[4];
+    int n_rest;              // 3 * ((D + 1)^2 - 1)
+};
+struct PlyMapArgs {
+    int P, row_floats, activate, M;
+    const float* rows;
+    float* means3D; float* shs; float* opacities; float* scales; float* rotations;
+    PlyCols c;
+};
+// RF / MM: compile-time row length and SH coefficient count (the index arithmetic is all divisions by them);
+// 0 = take them from the arguments.
+template <int RF, int MM>
+__global__ void __launch_bounds__(64) k_map_from_ply_rows(PlyMapArgs a)
+{
+    const int rf = RF ? RF : a.row_floats, mm = RF ? MM : a.M;
+    extern __shared__ float s_rows[];            // 64 rows, odd row stride (conflict-free column reads)
+    __shared__ int s_col[3 * 16];                // source column of every element of one [M,3] feature row
+    __shared__ float s_qn[64];                   // per row: 1 / max(|q|, eps)   (F.normalize, eps 1e-12)
+    const int lane = threadIdx.x;
+    const int base = blockIdx.x * 64;
+    const int nrow = min(64, a.P - base);
+    const int rs = rf | 1;
+    const float* src = a.rows + (size_t)base * rf;
+    // the block's rows are contiguous in the file: one coalesced stream, 16 B per lane when the buffer allows
+    const int nfl = nrow * rf;
+    if ((reinterpret_cast<uintptr_t>(src) & 15u) == 0) {
+        const float4* src4 = reinterpret_cast<const float4*>(src);
+        for (int i4 = lane; i4 < (nfl >> 2); i4 += 64) {
+            const float4 v = src4[i4];
+            const float vv[4] = {v.x, v.y, v.z, v.w};
+            int r = (4 * i4) / rf, c = 4 * i4 - r * rf;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                s_rows[r * rs + c] = vv[k];
+                if (++c == rf) { c = 0; r++; }
+            }
+        }
+        for (int i = (nfl & ~3) + lane; i < nfl; i += 64) {
+            const int r = i / rf;
+            s_rows[r * rs + (i - r * rf)] = src[i];
+        }
+    } else {
+        for (int i = lane; i < nfl; i += 64) {
+            const int r = i / rf;
+            s_rows[r * rs + (i - r * rf)] = src[i];
+        }
+    }
+    // features: [P, M, 3], coefficient-major, RGB innermost = cat(features_dc, features_rest) after the
+    // reference's reshape (P, 3, M-1) + transpose(1, 2): f_rest_{c*(M-1)+k} is coefficient 1+k of channel c
+    const int nr = mm - 1;
+    if (lane < 3 * mm) {
+        const int kk = lane / 3, c = lane - kk * 3;
+        s_col[lane] = (kk == 0) ? a.c.f_dc[c] : a.c.f_rest[c * nr + (kk - 1)];
+    }
+    __syncthreads();
+    if (lane < nrow) {
+        const float* row = s_rows + lane * rs;
+        const float q0 = row[a.c.rot[0]], q1 = row[a.c.rot[1]], q2 = row[a.c.rot[2]], q3 = row[a.c.rot[3]];
+        s_qn[lane] = a.activate ? fmaxf(sqrtf(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3), 1e-12f) : 1.f;
+        const float o = row[a.c.opacity];
+        a.opacities[(size_t)base + lane] = a.activate ? 1.0f / (1.0f + expf(-o)) : o;          // torch.sigmoid
+    }
+    __syncthreads();
+    // every output tensor's slice of this block is contiguous: consecutive lanes write consecutive floats
+    const int w = 3 * mm;
+    float* shs = a.shs + (size_t)base * w;
+    if ((reinterpret_cast<uintptr_t>(shs) & 15u) == 0 && ((nrow * w) & 3) == 0) {
+        for (int e4 = lane; e4 < (nrow * w) >> 2; e4 += 64) {
+            int r = (4 * e4) / w, c = 4 * e4 - r * w;
+            float vv[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                vv[k] = s_rows[r * rs + s_col[c]];
+                if (++c == w) { c = 0; r++; }
+            }
+            reinterpret_cast<float4*>(shs)[e4] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        }
+    } else {
+        for (int e = lane; e < nrow * w; e += 64) {
+            const int r = e / w;
+            shs[e] = s_rows[r * rs + s_col[e - r * w]];
+        }
+    }
+    float* means = a.means3D + (size_t)base * 3;
+    float* scales = a.scales + (size_t)base * 3;
+    for (int e = lane; e < nrow * 3; e += 64) {
+        const int r = e / 3, c = e - r * 3;
+        means[e] = s_rows[r * rs + a.c.xyz[c]];
+        const float sv = s_rows[r * rs + a.c.scale[c]];
+        scales[e] = a.activate ? expf(sv) : sv;                                                  // torch.exp
+    }
+    float* rots = a.rotations + (size_t)base * 4;
+    for (int e = lane; e < nrow * 4; e += 64) {
+        const int r = e >> 2, c = e & 3;
+        rots[e] = s_rows[r * rs + a.c.rot[c]] / s_qn[r];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Pose-refinement epilogue: the ~130 tiny launches the reference's Python loop
 // issues per iteration for the tracking loss, its autograd backward, Adam and update_pose become two.
 // ---------------------------------------------------------------------------------------------

@@ -205,6 +205,14 @@ class GaussianMap:
         return GaussianMap(t(scene.means3D), t(scene.shs), t(scene.opacities), t(scene.scales), t(scene.rotations),
                            scene.sh_degree, requires_grad)
 
+    @staticmethod
+    def from_ply(path, device="cuda:0", requires_grad=True, max_sh_degree=None):
+        """load_ply (tools/gaussian_model.py:377-467) straight into the device layout: the file's vertex rows are
+        uploaded as stored and converted (column gather, SH layout, activations) by one HIP kernel."""
+        from . import map_io
+        xyz, shs, opac, scales, rots, deg = map_io.load_map_tensors(path, device, activate=True, max_sh_degree=max_sh_degree)
+        return GaussianMap(xyz, shs, opac, scales, rots, deg, requires_grad)
+
     get_xyz = property(lambda s: s._t[0])
     get_features = property(lambda s: s._t[1])
     get_opacity = property(lambda s: s._t[2])

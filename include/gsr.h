@@ -219,6 +219,20 @@ typedef struct gsr_refine_args {
 } gsr_refine_args;
 int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
 
+/* Map on-disk rows -> device layout.  Replaces the per-property column gathering of
+ * load_ply (gs_localization/pipelines/tools/gaussian_model.py:377-467; gaussian_splatting/scene/
+ * gaussian_model.py:215-256) and, with activate = 1, the activation getters the reference re-evaluates in every
+ * render() of a map that never changes during localisation (tools/gaussian_model.py:77-96).
+ *   rows        device, P * row_floats f32: the vertex rows exactly as stored in point_cloud.ply
+ *   cols        HOST array of 14 + n_rest ints: float index inside a row of
+ *               x, y, z, f_dc_0..2, f_rest_0..n_rest-1, opacity, scale_0..2, rot_0..3   (in this order)
+ *   n_rest      3 * ((sh_degree + 1)^2 - 1), at most 45
+ *   outputs     means3D [P,3], shs [P,M,3] with M = 1 + n_rest / 3 (coefficient-major, RGB innermost: what the
+ *               rasterizer takes), opacities [P], scales [P,3], rotations [P,4]
+ *   activate    1: sigmoid(opacity), exp(scale), normalize(rot) applied once here; 0: raw parameters */
+int gsr_map_from_ply_rows(int P, const float* rows, int row_floats, const int* cols, int n_rest, int activate,
+                          float* means3D, float* shs, float* opacities, float* scales, float* rotations, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the caller's stream around each kernel
  * (bench.py's roofline leg).  mask bit i enables kernel id i; 0 disables (the default, zero cost).
  * gsr_profile_collect waits for the recorded events, ADDS elapsed milliseconds / launch counts per
