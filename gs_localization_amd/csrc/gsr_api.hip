@@ -927,6 +927,75 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     return 0;
 }
 
+size_t gsr_training_loss_bytes(int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    return (size_t)width * height * 9 * sizeof(float) + 256;
+}
+
+int gsr_training_loss(int width, int height, const float* image, const float* gt_image, float lambda_dssim,
+                      const float* depth, const float* pseudo_depth, float depth_weight, float* dL_dimage,
+                      float* dL_ddepth, float* out, gsr_resize_fn workspace, void* workspace_ctx, void* stream)
+{
+    using namespace gsr;
+    const int debug = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (width <= 0 || height <= 0) return fail(GSR_E_INVALID, "positive image size required%s", "");
+    if (!image || !gt_image || !dL_dimage || !out || !workspace) return fail(GSR_E_INVALID, "gsr_training_loss: NULL pointer%s", "");
+    if ((depth == nullptr) != (pseudo_depth == nullptr)) return fail(GSR_E_INVALID, "gsr_training_loss: depth and pseudo_depth go together%s", "");
+    if (depth && !dL_ddepth) return fail(GSR_E_INVALID, "gsr_training_loss: dL_ddepth required with a depth term%s", "");
+    int rc = select_device_of(image);
+    if (rc != GSR_OK) return rc;
+    const size_t N = (size_t)width * height;
+    char* ws = (char*)workspace(workspace_ctx, gsr_training_loss_bytes(width, height));
+    if (!ws) return fail(GSR_E_ALLOC, "workspace callback returned NULL%s", "");
+    double* sums = reinterpret_cast<double*>(ws);                  // 10 doubles (256 B reserved)
+    float* maps = reinterpret_cast<float*>(ws + 256);
+    HIPCHK(hipMemsetAsync(sums, 0, 10 * sizeof(double), st));
+    SsimArgs sa;
+    sa.W = width; sa.H = height; sa.img = image; sa.gt = gt_image; sa.lambda_dssim = lambda_dssim; sa.maps = maps;
+    sa.sums = sums; sa.dL_dimage = dL_dimage;
+    {   // gaussian(11, 1.5) of loss_utils.py:23-25: float32 exp values, float32 sum, float32 division
+        float g[11], sum = 0.f;
+        for (int x = 0; x < 11; x++) { g[x] = (float)exp(-(double)((x - 5) * (x - 5)) / (2.0 * 1.5 * 1.5)); sum += g[x]; }
+        for (int x = 0; x < 11; x++) sa.w[x] = g[x] / sum;
+    }
+    const dim3 grid((width + GSR_SSIM_T - 1) / GSR_SSIM_T, (height + GSR_SSIM_T - 1) / GSR_SSIM_T, 3);
+    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(GSR_SSIM_T * GSR_SSIM_T), 0, st, sa);
+    LAUNCHCHK("k_ssim_fwd");
+    PearsonArgs pa;
+    pa.n = (int)N; pa.depth = depth; pa.pseudo = pseudo_depth; pa.sums = sums; pa.weight = depth_weight; pa.dL_ddepth = dL_ddepth;
+    pa.out = out; pa.lambda_dssim = lambda_dssim; pa.npix3 = (int)(3 * N);
+    const int eb = (int)((N + GSR_BLOCK - 1) / GSR_BLOCK);
+    if (depth) {
+        hipLaunchKernelGGL(k_pearson_sums, dim3(eb < 256 ? eb : 256), dim3(GSR_BLOCK), 0, st, pa);
+        LAUNCHCHK("k_pearson_sums");
+    }
+    hipLaunchKernelGGL(k_train_loss_finish, dim3(depth ? (eb < 1024 ? eb : 1024) : 1), dim3(GSR_BLOCK), 0, st, pa, (const double*)sums);
+    LAUNCHCHK("k_train_loss_finish");
+    hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(GSR_SSIM_T * GSR_SSIM_T), 0, st, sa);
+    LAUNCHCHK("k_ssim_bwd");
+    return 0;
+}
+
+int gsr_densification_stats(int P, const int* radii, const float* dL_dmean2D, float* max_radii2D,
+                            float* xyz_gradient_accum, float* denom, void* stream)
+{
+    using namespace gsr;
+    const int debug = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (P < 0) return fail(GSR_E_INVALID, "P >= 0 required%s", "");
+    if (P == 0) return 0;
+    if (!radii || !dL_dmean2D || !max_radii2D || !xyz_gradient_accum || !denom)
+        return fail(GSR_E_INVALID, "gsr_densification_stats: NULL pointer%s", "");
+    int rc = select_device_of(radii);
+    if (rc != GSR_OK) return rc;
+    hipLaunchKernelGGL(k_densification_stats, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, radii, dL_dmean2D,
+                       max_radii2D, xyz_gradient_accum, denom);
+    LAUNCHCHK("k_densification_stats");
+    return 0;
+}
+
 int gsr_map_from_ply_rows(int P, const float* rows, int row_floats, const int* cols, int n_rest, int activate,
                           float* means3D, float* shs, float* opacities, float* scales, float* rotations, void* stream)
 {

@@ -1416,6 +1416,227 @@ __global__ void k_tau_finish(const double* acc, float* out)
 }
 
 // ---------------------------------------------------------------------------------------------
+// Training-step loss epilogue: gaussian_splatting/train.py:92-108 with
+// utils/loss_utils.py:17-63 and their autograd backward, as four launches instead of ~60:
+//   loss = (1 - lambda) L1(image, gt) + lambda (1 - SSIM(image, gt)) + w_d min(1 - rho(-m, d), 1 - rho(1/(m+200), d))
+// SSIM: 11x11 Gaussian window (sigma 1.5), zero padding, per channel.  Every statistic of _ssim is a window
+// filter of x, y, xx, yy, xy, so the map is a function F(mu1, mu2, Exx, Eyy, Exy) per pixel and
+//   dSSIM/dx(q) = sum_p w(p - q) [ F_mu1(p) + 2 x(q) F_Exx(p) + y(q) F_Exy(p) ] / (3N):
+// pass 1 (k_ssim_fwd) filters the five inputs (separable, 26x26 halo tile in LDS), evaluates the map, sums it
+// and the L1 term, and stores the three partial-derivative maps; pass 2 (k_ssim_bwd) filters those maps with
+// the same (symmetric) window and assembles dL/dimage including the L1 sign term.  HBM traffic per pixel and
+// channel: 8 B in + 12 B out, then 12 B + 8 B in + 4 B out.
+// ---------------------------------------------------------------------------------------------
+#define GSR_SSIM_R 5
+#define GSR_SSIM_T 16
+#define GSR_SSIM_H (GSR_SSIM_T + 2 * GSR_SSIM_R)      // 26
+struct SsimArgs {
+    int W, H;
+    const float* img; const float* gt;       // [3, H, W]
+    float lambda_dssim;
+    float* maps;                             // workspace: [3 maps][3 channels][H][W]  (F_mu1, F_Exx, F_Exy)
+    double* sums;                            // [0] sum |x - y|, [1] sum ssim_map   (fp64 atomics)
+    float* dL_dimage;
+    float w[2 * GSR_SSIM_R + 1];             // gaussian(11, 1.5), normalised (loss_utils.py:23-25)
+};
+
+__global__ void __launch_bounds__(GSR_SSIM_T * GSR_SSIM_T) k_ssim_fwd(SsimArgs a)
+{
+    __shared__ float s_x[GSR_SSIM_H][GSR_SSIM_H + 1], s_y[GSR_SSIM_H][GSR_SSIM_H + 1];
+    __shared__ float s_h[5][GSR_SSIM_H][GSR_SSIM_T + 1];       // horizontally filtered x, y, xx, yy, xy
+    __shared__ double s_red[4][2];
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int ch = blockIdx.z;
+    const int x0 = blockIdx.x * GSR_SSIM_T, y0 = blockIdx.y * GSR_SSIM_T;
+    const size_t N = (size_t)a.W * a.H;
+    const float* img = a.img + ch * N;
+    const float* gt = a.gt + ch * N;
+    for (int i = tid; i < GSR_SSIM_H * GSR_SSIM_H; i += GSR_SSIM_T * GSR_SSIM_T) {
+        const int r = i / GSR_SSIM_H, c = i - r * GSR_SSIM_H;
+        const int gx = x0 + c - GSR_SSIM_R, gy = y0 + r - GSR_SSIM_R;
+        const bool in = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;          // zero padding (F.conv2d padding = 5)
+        s_x[r][c] = in ? img[(size_t)gy * a.W + gx] : 0.f;
+        s_y[r][c] = in ? gt[(size_t)gy * a.W + gx] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < GSR_SSIM_H * GSR_SSIM_T; i += GSR_SSIM_T * GSR_SSIM_T) {
+        const int r = i / GSR_SSIM_T, c = i - r * GSR_SSIM_T;
+        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * GSR_SSIM_R + 1; k++) {
+            const float wx = a.w[k], xv = s_x[r][c + k], yv = s_y[r][c + k];
+            sx += wx * xv; sy += wx * yv; sxx += wx * (xv * xv); syy += wx * (yv * yv); sxy += wx * (xv * yv);
+        }
+        s_h[0][r][c] = sx; s_h[1][r][c] = sy; s_h[2][r][c] = sxx; s_h[3][r][c] = syy; s_h[4][r][c] = sxy;
+    }
+    __syncthreads();
+    const int px = x0 + lx, py = y0 + ly;
+    const bool inside = px < a.W && py < a.H;
+    double l1 = 0.0, ss = 0.0;
+    if (inside) {
+        float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * GSR_SSIM_R + 1; k++) {
+            const float wy = a.w[k];
+            mu1 += wy * s_h[0][ly + k][lx]; mu2 += wy * s_h[1][ly + k][lx];
+            exx += wy * s_h[2][ly + k][lx]; eyy += wy * s_h[3][ly + k][lx]; exy += wy * s_h[4][ly + k][lx];
+        }
+        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
+        const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cd = mu1_sq + mu2_sq + C1, D = s1 + s2 + C2;
+        const float inv = 1.f / (Cd * D);
+        const float ssim = A * B * inv;
+        // F(mu1, mu2, Exx, Eyy, Exy) with s1 = Exx - mu1^2, s12 = Exy - mu1 mu2:
+        //   dF/dExx = -A B / (Cd D^2),  dF/dExy = 2 A / (Cd D),
+        //   dF/dmu1 = 2 mu2 B/(Cd D) - 2 mu2 A/(Cd D) ... collected below (chain through s1 and s12 included)
+        const float F_exx = -ssim / D;
+        const float F_exy = 2.f * A * inv;
+        const float F_mu1 = 2.f * mu2 * B * inv - 2.f * mu1 * ssim / Cd - 2.f * mu1 * F_exx - mu2 * F_exy;
+        const size_t o = ch * N + (size_t)py * a.W + px;
+        a.maps[o] = F_mu1; a.maps[3 * N + o] = F_exx; a.maps[6 * N + o] = F_exy;
+        ss = (double)ssim;
+        l1 = (double)fabsf(s_x[ly + GSR_SSIM_R][lx + GSR_SSIM_R] - s_y[ly + GSR_SSIM_R][lx + GSR_SSIM_R]);
+    }
+    l1 = wave_sum_d(l1); ss = wave_sum_d(ss);
+    if ((tid & 63) == 0) { s_red[tid >> 6][0] = l1; s_red[tid >> 6][1] = ss; }
+    __syncthreads();
+    if (tid < 2) {
+        const double t = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+        if (t != 0.0) atomicAdd(&a.sums[tid], t);
+    }
+}
+
+__global__ void __launch_bounds__(GSR_SSIM_T * GSR_SSIM_T) k_ssim_bwd(SsimArgs a)
+{
+    __shared__ float s_m[3][GSR_SSIM_H][GSR_SSIM_H + 1];
+    __shared__ float s_h[3][GSR_SSIM_H][GSR_SSIM_T + 1];
+    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int ch = blockIdx.z;
+    const int x0 = blockIdx.x * GSR_SSIM_T, y0 = blockIdx.y * GSR_SSIM_T;
+    const size_t N = (size_t)a.W * a.H;
+    for (int i = tid; i < GSR_SSIM_H * GSR_SSIM_H; i += GSR_SSIM_T * GSR_SSIM_T) {
+        const int r = i / GSR_SSIM_H, c = i - r * GSR_SSIM_H;
+        const int gx = x0 + c - GSR_SSIM_R, gy = y0 + r - GSR_SSIM_R;
+        const bool in = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;          // no output pixel outside the image
+        const size_t o = ch * N + (size_t)gy * a.W + gx;
+#pragma unroll
+        for (int m = 0; m < 3; m++) s_m[m][r][c] = in ? a.maps[3 * m * N + o] : 0.f;
+    }
+    __syncthreads();
+    for (int i = tid; i < GSR_SSIM_H * GSR_SSIM_T; i += GSR_SSIM_T * GSR_SSIM_T) {
+        const int r = i / GSR_SSIM_T, c = i - r * GSR_SSIM_T;
+        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < 2 * GSR_SSIM_R + 1; k++) {
+            const float wx = a.w[k];
+            t0 += wx * s_m[0][r][c + k]; t1 += wx * s_m[1][r][c + k]; t2 += wx * s_m[2][r][c + k];
+        }
+        s_h[0][r][c] = t0; s_h[1][r][c] = t1; s_h[2][r][c] = t2;
+    }
+    __syncthreads();
+    const int px = x0 + lx, py = y0 + ly;
+    if (px >= a.W || py >= a.H) return;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 2 * GSR_SSIM_R + 1; k++) {
+        const float wy = a.w[k];
+        g0 += wy * s_h[0][ly + k][lx]; g1 += wy * s_h[1][ly + k][lx]; g2 += wy * s_h[2][ly + k][lx];
+    }
+    const size_t o = ch * N + (size_t)py * a.W + px;
+    const float x = a.img[o], y = a.gt[o];
+    const float inv3n = 1.f / (3.f * (float)N);
+    const float d = x - y;
+    const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+    // loss = (1 - lambda) mean|x - y| + lambda (1 - mean ssim_map)
+    a.dL_dimage[o] = (1.f - a.lambda_dssim) * sgn * inv3n - a.lambda_dssim * inv3n * (g0 + 2.f * x * g1 + y * g2);
+}
+
+// Pseudo-depth term of train.py:96-108: w_d * min(1 - rho(-m, d), 1 - rho(1 / (m + 200), d)), rho = Pearson
+// correlation over all pixels (torchmetrics pearson_corrcoef: cov / sqrt(var_x var_y), clamped to [-1, 1]).
+struct PearsonArgs {
+    int n;
+    const float* depth; const float* pseudo;
+    double* sums;         // [2..9]: sum d, sum dd, sum a, sum aa, sum ad, sum b, sum bb, sum bd   (a = -m, b = 1/(m+200))
+    float weight;
+    float* dL_ddepth;
+    float* out;           // [0] loss, [1] Ll1, [2] ssim, [3] pseudo-depth loss
+    float lambda_dssim; int npix3;      // for the final scalar
+};
+__global__ void __launch_bounds__(GSR_BLOCK) k_pearson_sums(PearsonArgs a)
+{
+    __shared__ double s_red[4][8];
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int i = blockIdx.x * GSR_BLOCK + threadIdx.x; i < a.n; i += gridDim.x * GSR_BLOCK) {
+        const double d = (double)a.depth[i], m = (double)a.pseudo[i];
+        const double xa = -m, xb = (double)(1.0f / ((float)m + 200.f));
+        v[0] += d; v[1] += d * d; v[2] += xa; v[3] += xa * xa; v[4] += xa * d; v[5] += xb; v[6] += xb * xb; v[7] += xb * d;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+        const double t = wave_sum_d(v[q]);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6][q] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) {
+        const double t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
+        if (t != 0.0) atomicAdd(&a.sums[2 + threadIdx.x], t);
+    }
+}
+// rho and the coefficients of d(1 - rho)/dd_i = -(x_i - mx) / (n sx sd) + rho (d_i - md) / (n sd^2)
+__device__ __forceinline__ void pearson_terms(double n, double sx, double sxx, double sd, double sdd, double sxd, double& rho,
+                                              double& mx, double& md, double& cx, double& cd)
+{
+    mx = sx / n; md = sd / n;
+    const double vx = sxx / n - mx * mx, vd = sdd / n - md * md, cov = sxd / n - mx * md;
+    const double den = sqrt(vx * vd);
+    rho = cov / den;
+    const bool clamped = rho > 1.0 || rho < -1.0;       // torch.clamp: no gradient through a clamped value
+    rho = fmin(1.0, fmax(-1.0, rho));
+    cx = clamped ? 0.0 : -1.0 / (n * den);
+    cd = clamped ? 0.0 : rho / (n * vd);
+}
+__global__ void __launch_bounds__(GSR_BLOCK) k_train_loss_finish(PearsonArgs a, const double* ssim_sums)
+{
+    double rho_a = 0, rho_b = 0, mxa = 0, mxb = 0, md = 0, cxa = 0, cxb = 0, cda = 0, cdb = 0, md2 = 0;
+    float pd = 0.f;
+    bool use_a = true;
+    if (a.depth != nullptr) {
+        const double n = (double)a.n;
+        const double* s = a.sums + 2;
+        pearson_terms(n, s[2], s[3], s[0], s[1], s[4], rho_a, mxa, md, cxa, cda);
+        pearson_terms(n, s[5], s[6], s[0], s[1], s[7], rho_b, mxb, md2, cxb, cdb);
+        use_a = !((1.0 - rho_b) < (1.0 - rho_a));          // Python min(): the first argument wins ties
+        pd = (float)(use_a ? 1.0 - rho_a : 1.0 - rho_b);
+        for (int i = blockIdx.x * GSR_BLOCK + threadIdx.x; i < a.n; i += gridDim.x * GSR_BLOCK) {
+            const double d = (double)a.depth[i], m = (double)a.pseudo[i];
+            const double x = use_a ? -m : (double)(1.0f / ((float)m + 200.f));
+            const double g = use_a ? cxa * (x - mxa) + cda * (d - md) : cxb * (x - mxb) + cdb * (d - md);
+            a.dL_ddepth[i] = a.weight * (float)g;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const float l1 = (float)(ssim_sums[0] / (double)a.npix3), ss = (float)(ssim_sums[1] / (double)a.npix3);
+        a.out[1] = l1; a.out[2] = ss; a.out[3] = pd;
+        a.out[0] = (1.0f - a.lambda_dssim) * l1 + a.lambda_dssim * (1.0f - ss) + ((a.depth != nullptr) ? a.weight * pd : 0.f);
+    }
+}
+
+// Densification statistics of train.py:142-145 / gaussian_model.py:405-407 in one pass over the Gaussians.
+__global__ void __launch_bounds__(GSR_BLOCK) k_densification_stats(int P, const int* radii, const float* dL_dmean2D,
+                                                                   float* max_radii2D, float* xyz_gradient_accum, float* denom)
+{
+    const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    const int r = radii[i];
+    if (r <= 0) return;                                              // visibility_filter = radii > 0
+    max_radii2D[i] = fmaxf(max_radii2D[i], (float)r);
+    const float gx = dL_dmean2D[3 * i], gy = dL_dmean2D[3 * i + 1];
+    xyz_gradient_accum[i] += sqrtf(gx * gx + gy * gy);               // torch.norm(grad[:, :2], dim=-1)
+    denom[i] += 1.f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Map on-disk rows -> device layout.  Replaces the host-side column gathering of
 // load_ply (gs_localization/pipelines/tools/gaussian_model.py:377-467, gaussian_splatting/scene/
 // gaussian_model.py:215-256) and, for the read-only localisation map, the activation getters that the

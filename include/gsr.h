@@ -233,6 +233,23 @@ int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
 int gsr_map_from_ply_rows(int P, const float* rows, int row_floats, const int* cols, int n_rest, int activate,
                           float* means3D, float* shs, float* opacities, float* scales, float* rotations, void* stream);
 
+/* Training-step loss epilogue: gaussian_splatting/train.py:92-108 with
+ * utils/loss_utils.py:17-63 (l1_loss, ssim with the 11x11 Gaussian window) and their autograd backward:
+ *   loss = (1 - lambda_dssim) * L1(image, gt) + lambda_dssim * (1 - SSIM(image, gt))
+ *          + depth_weight * min(1 - pearson(-pseudo, depth), 1 - pearson(1 / (pseudo + 200), depth))
+ * image, gt_image: [3, H, W]; depth, pseudo_depth: [H, W] or both NULL (no depth term; dL_ddepth may then be NULL).
+ * Writes dL_dimage [3, H, W], dL_ddepth [H, W] and out[4] = {loss, Ll1, ssim, pseudo-depth loss} (device).
+ * workspace: resize callback for 36 * W * H + 256 bytes of scratch. */
+size_t gsr_training_loss_bytes(int width, int height);
+int gsr_training_loss(int width, int height, const float* image, const float* gt_image, float lambda_dssim,
+                      const float* depth, const float* pseudo_depth, float depth_weight, float* dL_dimage,
+                      float* dL_ddepth, float* out, gsr_resize_fn workspace, void* workspace_ctx, void* stream);
+/* Densification statistics of train.py:142-145 + GaussianModel.add_densification_stats (gaussian_model.py:405-407)
+ * for the Gaussians with radii > 0: max_radii2D = max(max_radii2D, radii), xyz_gradient_accum += |dL_dmean2D.xy|,
+ * denom += 1.  dL_dmean2D is the [P, 3] screen-space gradient the backward returns. */
+int gsr_densification_stats(int P, const int* radii, const float* dL_dmean2D, float* max_radii2D,
+                            float* xyz_gradient_accum, float* denom, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the caller's stream around each kernel
  * (bench.py's roofline leg).  mask bit i enables kernel id i; 0 disables (the default, zero cost).
  * gsr_profile_collect waits for the recorded events, ADDS elapsed milliseconds / launch counts per
