@@ -17,6 +17,8 @@ SIGNATURES = {
     "gsr_backward": (_i, [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "gsr_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "gsr_knn_bytes": (C.c_size_t, [_i]),
+    "gsr_dist2_knn3": (_i, [_i, _vp, _vp, RESIZE_FN, _vp, _vp]),
     "gsr_training_loss_bytes": (C.c_size_t, [_i, _i]),
     "gsr_training_loss": (_i, [_i, _i, _vp, _vp, _f, _vp, _vp, _f, _vp, _vp, _vp, RESIZE_FN, _vp, _vp]),
     "gsr_densification_stats": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),

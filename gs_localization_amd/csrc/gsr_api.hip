@@ -927,6 +927,65 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     return 0;
 }
 
+namespace {
+struct KnnWs { uint32_t* mm; uint32_t* codes; uint32_t* codes_sorted; uint32_t* idx; uint32_t* idx_sorted; float4* sorted; float* boxes;
+               char* sort_tmp; size_t sort_bytes; };
+size_t carve_knn(char* base, int P, KnnWs& w)
+{
+    Carver c(base);
+    const size_t n = P > 0 ? (size_t)P : 1;
+    w.mm = c.take<uint32_t>(8);
+    w.codes = c.take<uint32_t>(n); w.codes_sorted = c.take<uint32_t>(n);
+    w.idx = c.take<uint32_t>(n); w.idx_sorted = c.take<uint32_t>(n);
+    w.sorted = c.take<float4>(n);
+    w.boxes = c.take<float>(8 * ((n + GSR_KNN_BOX - 1) / GSR_KNN_BOX));
+    w.sort_bytes = 0;
+    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, w.sort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                             (uint32_t*)nullptr, (int)n);
+    w.sort_tmp = c.take<char>(w.sort_bytes);
+    return c.size();
+}
+}  // namespace
+
+size_t gsr_knn_bytes(int P) { KnnWs w; return carve_knn(nullptr, P, w); }
+
+int gsr_dist2_knn3(int P, const float* points, float* mean_dist2, gsr_resize_fn workspace, void* workspace_ctx, void* stream)
+{
+    using namespace gsr;
+    const int debug = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (P < 0) return fail(GSR_E_INVALID, "P >= 0 required%s", "");
+    if (P == 0) return 0;
+    if (!points || !mean_dist2 || !workspace) return fail(GSR_E_INVALID, "gsr_dist2_knn3: NULL pointer%s", "");
+    int rc = select_device_of(points);
+    if (rc != GSR_OK) return rc;
+    KnnWs w;
+    char* ws = (char*)workspace(workspace_ctx, carve_knn(nullptr, P, w));
+    if (!ws) return fail(GSR_E_ALLOC, "workspace callback returned NULL%s", "");
+    carve_knn(ws, P, w);
+    const int pblocks = (P + GSR_BLOCK - 1) / GSR_BLOCK;
+    {   // min / max seeded with the origin: encoded 0.0f
+        const uint32_t zero_enc = 0x80000000u;
+        const uint32_t init[8] = {zero_enc, zero_enc, zero_enc, zero_enc, zero_enc, zero_enc, 0, 0};
+        HIPCHK(hipMemcpyAsync(w.mm, init, sizeof(init), hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(k_knn_minmax, dim3(pblocks < 1024 ? pblocks : 1024), dim3(GSR_BLOCK), 0, st, P, points, w.mm);
+    LAUNCHCHK("k_knn_minmax");
+    hipLaunchKernelGGL(k_knn_morton, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, points, (const uint32_t*)w.mm, w.codes, w.idx);
+    LAUNCHCHK("k_knn_morton");
+    HIPCHK(hipcub::DeviceRadixSort::SortPairs(w.sort_tmp, w.sort_bytes, (const uint32_t*)w.codes, w.codes_sorted, (const uint32_t*)w.idx,
+                                              w.idx_sorted, P, 0, 30, st));
+    hipLaunchKernelGGL(k_knn_gather, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, points, (const uint32_t*)w.idx_sorted, w.sorted);
+    LAUNCHCHK("k_knn_gather");
+    const int nboxes = (P + GSR_KNN_BOX - 1) / GSR_KNN_BOX;
+    hipLaunchKernelGGL(k_knn_boxes, dim3(nboxes), dim3(GSR_KNN_BOX), 0, st, P, (const float4*)w.sorted, w.boxes);
+    LAUNCHCHK("k_knn_boxes");
+    hipLaunchKernelGGL(k_knn_search, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const float4*)w.sorted, (const float*)w.boxes, nboxes,
+                       mean_dist2);
+    LAUNCHCHK("k_knn_search");
+    return 0;
+}
+
 size_t gsr_training_loss_bytes(int width, int height)
 {
     if (width <= 0 || height <= 0) return 0;

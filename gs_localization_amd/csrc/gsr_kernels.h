@@ -1416,6 +1416,147 @@ __global__ void k_tau_finish(const double* acc, float* out)
 }
 
 // ---------------------------------------------------------------------------------------------
+// distCUDA2: mean squared distance of every point to its three nearest neighbours,
+// gaussian_splatting/submodules/simple-knn/simple_knn.cu:45-220 (the only native dependency of create_from_pcd).
+// Same plan as the reference -- Morton order, axis-aligned boxes over runs of 1024 sorted points, exact search
+// with box pruning -- re-cut for wave64: the points are first GATHERED into Morton order (float4, original index
+// in .w) so that a wave's 64 points are spatial neighbours; the wave tests each box ONCE against its own bounding
+// box and current search radius, and a surviving box's points are read at wave-uniform addresses (scalar loads,
+// broadcast to all lanes), each lane keeping its own three best.  The pruning is conservative at both levels,
+// so the result is the exact 3-NN mean like the reference's.
+// ---------------------------------------------------------------------------------------------
+#define GSR_KNN_BOX 1024
+__device__ __forceinline__ uint32_t knn_prep_morton(uint32_t x)
+{
+    x = (x | (x << 16)) & 0x030000FFu;
+    x = (x | (x << 8)) & 0x0300F00Fu;
+    x = (x | (x << 4)) & 0x030C30C3u;
+    x = (x | (x << 2)) & 0x09249249u;
+    return x;
+}
+// min / max over all points, seeded with the origin like the reference's reductions (simple_knn.cu:184-194,
+// init = {0,0,0}); floats are compared through an order-preserving integer encoding
+__device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t b = __float_as_uint(f); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+__device__ __forceinline__ float ord2f(uint32_t u) { return __uint_as_float((u & 0x80000000u) ? (u & 0x7FFFFFFFu) : ~u); }
+__global__ void __launch_bounds__(GSR_BLOCK) k_knn_minmax(int P, const float* __restrict__ pts, uint32_t* __restrict__ mm /*[6]: min xyz, max xyz (encoded)*/)
+{
+    float lo[3] = {0.f, 0.f, 0.f}, hi[3] = {0.f, 0.f, 0.f};
+    for (int i = blockIdx.x * GSR_BLOCK + threadIdx.x; i < P; i += gridDim.x * GSR_BLOCK)
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const float v = pts[3 * (size_t)i + c]; lo[c] = fminf(lo[c], v); hi[c] = fmaxf(hi[c], v); }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], off, 64)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], off, 64)); }
+        if ((threadIdx.x & 63) == 0) { atomicMin(&mm[c], f2ord(lo[c])); atomicMax(&mm[3 + c], f2ord(hi[c])); }
+    }
+}
+__global__ void __launch_bounds__(GSR_BLOCK) k_knn_morton(int P, const float* __restrict__ pts, const uint32_t* __restrict__ mm,
+                                                          uint32_t* __restrict__ codes, uint32_t* __restrict__ idx)
+{
+    const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    uint32_t code = 0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const float lo = ord2f(mm[c]), hi = ord2f(mm[3 + c]);
+        const float t = ((pts[3 * (size_t)i + c] - lo) / (hi - lo)) * (float)((1 << 10) - 1);      // simple_knn.cu:57-66
+        code |= knn_prep_morton((uint32_t)t) << c;
+    }
+    codes[i] = code;
+    idx[i] = (uint32_t)i;
+}
+__global__ void __launch_bounds__(GSR_BLOCK) k_knn_gather(int P, const float* __restrict__ pts, const uint32_t* __restrict__ idx_sorted,
+                                                          float4* __restrict__ sorted)
+{
+    const int i = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    if (i >= P) return;
+    const uint32_t j = idx_sorted[i];
+    sorted[i] = make_float4(pts[3 * (size_t)j], pts[3 * (size_t)j + 1], pts[3 * (size_t)j + 2], __uint_as_float(j));
+}
+// one workgroup of 1024 lanes per box (simple_knn.cu:83-123)
+__global__ void __launch_bounds__(GSR_KNN_BOX) k_knn_boxes(int P, const float4* __restrict__ sorted, float* __restrict__ boxes /*[nb][8]*/)
+{
+    __shared__ float s_lo[16][3], s_hi[16][3];
+    const int i = blockIdx.x * GSR_KNN_BOX + threadIdx.x;
+    float lo[3] = {3.402823466e38f, 3.402823466e38f, 3.402823466e38f}, hi[3] = {-3.402823466e38f, -3.402823466e38f, -3.402823466e38f};
+    if (i < P) { const float4 p = sorted[i]; lo[0] = hi[0] = p.x; lo[1] = hi[1] = p.y; lo[2] = hi[2] = p.z; }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], off, 64)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], off, 64)); }
+        if ((threadIdx.x & 63) == 0) { s_lo[threadIdx.x >> 6][c] = lo[c]; s_hi[threadIdx.x >> 6][c] = hi[c]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        float l = s_lo[0][threadIdx.x], h = s_hi[0][threadIdx.x];
+        for (int w = 1; w < 16; w++) { l = fminf(l, s_lo[w][threadIdx.x]); h = fmaxf(h, s_hi[w][threadIdx.x]); }
+        boxes[blockIdx.x * 8 + threadIdx.x] = l; boxes[blockIdx.x * 8 + 4 + threadIdx.x] = h;
+    }
+}
+__device__ __forceinline__ void knn_update3(float dist, float* best)      // simple_knn.cu:137-151
+{
+#pragma unroll
+    for (int j = 0; j < 3; j++)
+        if (best[j] > dist) { const float t = best[j]; best[j] = dist; dist = t; }
+}
+__device__ __forceinline__ float knn_dist2(float4 a, float4 b)
+{
+    const float dx = b.x - a.x, dy = b.y - a.y, dz = b.z - a.z;
+    return dx * dx + dy * dy + dz * dz;
+}
+__global__ void __launch_bounds__(GSR_BLOCK) k_knn_search(int P, const float4* __restrict__ sorted, const float* __restrict__ boxes,
+                                                          int nboxes, float* __restrict__ dists)
+{
+    const int lane = threadIdx.x & 63;
+    const int w0 = (blockIdx.x * GSR_BLOCK + (threadIdx.x & ~63));        // first sorted index of this wave
+    if (w0 >= P) return;
+    const int i = w0 + lane;
+    const bool live = i < P;
+    const float4 me = sorted[live ? i : P - 1];
+    const float FMAX = 3.402823466e38f;
+    float best[3] = {FMAX, FMAX, FMAX};
+    if (live)
+        for (int k = max(0, i - 3); k <= min(P - 1, i + 3); k++)
+            if (k != i) knn_update3(knn_dist2(me, sorted[k]), best);
+    const float reject = best[2];                          // an upper bound of the third-nearest distance
+    best[0] = FMAX; best[1] = FMAX; best[2] = FMAX;
+    // the wave's own bounding box
+    float lo[3] = {live ? me.x : FMAX, live ? me.y : FMAX, live ? me.z : FMAX}, hi[3] = {live ? me.x : -FMAX, live ? me.y : -FMAX, live ? me.z : -FMAX};
+#pragma unroll
+    for (int c = 0; c < 3; c++)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { lo[c] = fminf(lo[c], __shfl_xor(lo[c], off, 64)); hi[c] = fmaxf(hi[c], __shfl_xor(hi[c], off, 64)); }
+    for (int b = 0; b < nboxes; b++) {
+        const float bl[3] = {boxes[b * 8], boxes[b * 8 + 1], boxes[b * 8 + 2]}, bh[3] = {boxes[b * 8 + 4], boxes[b * 8 + 5], boxes[b * 8 + 6]};
+        // wave level: squared gap between the two boxes against the largest radius any lane still searches
+        float rad = live ? fminf(reject, best[2]) : 0.f;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) rad = fmaxf(rad, __shfl_xor(rad, off, 64));
+        float gap = 0.f;
+#pragma unroll
+        for (int c = 0; c < 3; c++) { const float g = fmaxf(0.f, fmaxf(bl[c] - hi[c], lo[c] - bh[c])); gap += g * g; }
+        if (gap > rad) continue;                           // wave-uniform
+        // lane level: the reference's own test (simple_knn.cu:125-135, 177-180)
+        float d2 = 0.f;
+        {
+            const float p3[3] = {me.x, me.y, me.z};
+#pragma unroll
+            for (int c = 0; c < 3; c++)
+                if (p3[c] < bl[c] || p3[c] > bh[c]) { const float g = fminf(fabsf(p3[c] - bl[c]), fabsf(p3[c] - bh[c])); d2 += g * g; }
+        }
+        const bool want = live && !(d2 > reject || d2 > best[2]);
+        if (__ballot(want) == 0ull) continue;
+        const int e = min(P, (b + 1) * GSR_KNN_BOX);
+        for (int k = b * GSR_KNN_BOX; k < e; k++) {
+            const float4 q = sorted[k];                    // wave-uniform address: one scalar load for all lanes
+            if (want && k != i) knn_update3(knn_dist2(me, q), best);
+        }
+    }
+    if (live) dists[__float_as_uint(me.w)] = (best[0] + best[1] + best[2]) / 3.0f;
+}
+
+// ---------------------------------------------------------------------------------------------
 // Training-step loss epilogue: gaussian_splatting/train.py:92-108 with
 // utils/loss_utils.py:17-63 and their autograd backward, as four launches instead of ~60:
 //   loss = (1 - lambda) L1(image, gt) + lambda (1 - SSIM(image, gt)) + w_d min(1 - rho(-m, d), 1 - rho(1/(m+200), d))

@@ -250,6 +250,12 @@ int gsr_training_loss(int width, int height, const float* image, const float* gt
 int gsr_densification_stats(int P, const int* radii, const float* dL_dmean2D, float* max_radii2D,
                             float* xyz_gradient_accum, float* denom, void* stream);
 
+/* distCUDA2 (gaussian_splatting/submodules/simple-knn/simple_knn.cu:183-220 behind
+ * spatial.cu:15-26): mean_dist2[i] = mean squared distance from point i to its three nearest OTHER points.
+ * points [P,3], mean_dist2 [P] on the device; workspace: resize callback for gsr_knn_bytes(P) bytes. */
+size_t gsr_knn_bytes(int P);
+int gsr_dist2_knn3(int P, const float* points, float* mean_dist2, gsr_resize_fn workspace, void* workspace_ctx, void* stream);
+
 /* Optional per-kernel timing with HIP events recorded on the caller's stream around each kernel
  * (bench.py's roofline leg).  mask bit i enables kernel id i; 0 disables (the default, zero cost).
  * gsr_profile_collect waits for the recorded events, ADDS elapsed milliseconds / launch counts per
