@@ -226,6 +226,9 @@ struct SpecCtx { int mode = 0; int parity = 0; float mul = 1.05f, add = 0.05f; b
 thread_local SpecCtx tl_spec;
 // device-side guards of the native loop (see LoopGuard); {nullptr, nullptr} outside gsr_refine
 thread_local gsr::LoopGuard tl_guard = {nullptr, nullptr};
+// set by gsr_refine per iteration: what the loss kernel clears for the next iteration (see LossArgs)
+struct LoopClear { uint32_t* a = nullptr; float* b = nullptr; int n = 0; };
+thread_local LoopClear tl_clear;
 thread_local int g_dev = 0;      // device chosen by the last select_device_of on this thread
 
 // One side stream + a fork/join event pair per device: independent work (SH colours, zero fills) runs next to
@@ -447,6 +450,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     pa.clamped = g.clamped; pa.tiles_touched = g.tiles_touched; pa.rects = g.rects;
     pa.depth_key = g.depth_key; pa.order_in = g.order_in;
     pa.guard = tl_guard;
+    pa.n_touched = n_touched;
     const float* zb_prev = (tl_spec.mode == 1) ? im.zb[tl_spec.parity ^ 1] : nullptr;
     float* zb_next = (tl_spec.mode != 0) ? im.zb[tl_spec.parity] : nullptr;
     pa.zb = zb_prev; pa.trunc = zb_prev ? im.trunc : nullptr;
@@ -463,7 +467,9 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     }
     pa.tile_cursor = local_path ? im.tile_cursor : nullptr;
     pa.bins = bl.bins;
-    if (tl_spec.mode != 0) {
+    // (on the by-tile path inside gsr_refine these words are cleared by the kernels that consume them: the tile cursors
+    // by the compositing kernel, the superblock flags / bounds by the loss kernel)
+    if (tl_spec.mode != 0 && !(local_path && tl_native_loop)) {
         HIPCHK(hipMemsetAsync(im.trunc, 0, im.clear_words * sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(zbc_next, 0, (size_t)im.nsb * sizeof(float), st));
     }
@@ -560,11 +566,10 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
             LAUNCHCHK("k_ranges");
         }
     }
-    if (n_touched) HIPCHK(hipMemsetAsync(n_touched, 0, (size_t)P * sizeof(int), st));
     const float* feat = colors_precomp ? colors_precomp : g.rgb;
     if (side) HIPCHK(hipStreamWaitEvent(st, side->join, 0));
     ProfScope* psr = new ProfScope(K_RENDER_FWD, st);
-#define GSR_FWD_ARGS im.ranges, local_path ? bl.vals : b.vals, (const unsigned long long*)bl.bins, (const uint32_t*)im.tile_cursor, \
+#define GSR_FWD_ARGS im.ranges, local_path ? bl.vals : b.vals, (const unsigned long long*)bl.bins, im.tile_cursor, \
                      width, height, gx, ntiles, (const float2*)g.xy, feat, \
                      (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
                      zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), tl_guard.poison ? const_cast<uint32_t*>(tl_guard.poison) : im.fail, \
@@ -642,7 +647,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     // accumulators of K7 (atomically summed)
     ProfScope* psz = new ProfScope(K_BWD_ZERO, st);
     if (!tl_native_loop) HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
-    if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));
+    if (pose_mode && !tl_native_loop) HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));
     delete psz;
     const float* color_ptr = colors_precomp ? colors_precomp : g.rgb;
     ProfScope* psb = new ProfScope(K_RENDER_BWD, st);
@@ -697,6 +702,7 @@ int gsr_tracking_loss(int width, int height, const float* image, const float* de
     if (!tl_native_loop) HIPCHK(hipMemsetAsync(out, 0, 4 * sizeof(float), st));      // (the native loop's pose step clears it)
     LossArgs la;
     la.guard = tl_guard;
+    la.clear_a = tl_clear.a; la.clear_b = tl_clear.b; la.clear_n = tl_clear.n;
     la.W = width; la.H = height; la.image = image; la.depth = depth; la.opacity = opacity; la.gt_image = gt_image;
     la.gt_depth = gt_depth; la.grad_mask = grad_mask; la.exposure = exposure; la.opacity_thr = opacity_threshold;
     la.depth_w = depth_weight; la.monocular = monocular; la.dL_dimage = dL_dimage; la.dL_ddepth = dL_ddepth;
@@ -777,7 +783,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     *converged = 0;
     struct FlagGuard {
         FlagGuard() { tl_native_loop = true; }
-        ~FlagGuard() { tl_native_loop = false; tl_spec.mode = 0; tl_guard = LoopGuard{nullptr, nullptr}; }
+        ~FlagGuard() { tl_native_loop = false; tl_spec.mode = 0; tl_guard = LoopGuard{nullptr, nullptr}; tl_clear = LoopClear{}; }
     } guard;
     uint32_t* poison = reinterpret_cast<uint32_t*>(ps + GSR_PS_POISON);
     tl_guard.poison = poison;
@@ -804,6 +810,15 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (!gptr) return fail(GSR_E_ALLOC, "geometry buffer callback returned NULL%s", "");
         carve_geom(gptr, a->P, gg);
         HIPCHK(hipMemsetAsync(gg.acc, 0, Pn * GSR_ACC_STRIDE * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(gg.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));      // then kept clean by the pose step
+        // image workspace: flags, cursors and both bound buffers start from zero; afterwards the kernels keep them so
+        Img im0;
+        char* iptr = (char*)cached_resize(&ib, carve_img(nullptr, a->width, a->height, im0));
+        if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
+        carve_img(iptr, a->width, a->height, im0);
+        HIPCHK(hipMemsetAsync(im0.trunc, 0, im0.clear_words * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(im0.zbc[0], 0, (size_t)im0.nsb * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(im0.zbc[1], 0, (size_t)im0.nsb * sizeof(float), st));
         HIPCHK(hipMemsetAsync(a->loss_out, 0, 4 * sizeof(float), st));
     }
     static_assert(GSR_PS_POISON == GSR_PS_CONV + 3, "status words are copied out as one block");
@@ -819,6 +834,12 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         slot_mode[it & 1] = mode;
         tl_spec.mode = mode;
         tl_spec.parity = it & 1;
+        {   // the loss kernel of this iteration clears the dropped-here flags and the bounds buffer iteration it+1 writes
+            Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
+            tl_clear.a = (mode != 0) ? imv.truncc : nullptr;
+            tl_clear.b = imv.zbc[(it & 1) ^ 1];
+            tl_clear.n = imv.nsb;
+        }
         int R = gsr_forward(cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
                             a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
                             a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
@@ -912,14 +933,14 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     }
     HIPCHK(hipStreamSynchronize(st));
     if (a->stats_out) {
-        if (last_local && ib.ptr) {      // instances binned by the last forward = sum of the tile cursors
+        if (last_local && ib.ptr) {      // instances binned by the last forward = sum of the tile list lengths
             Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
             const int nt = ((a->width + GSR_TILE - 1) / GSR_TILE) * ((a->height + GSR_TILE - 1) / GSR_TILE);
-            std::vector<uint32_t> tc((size_t)nt * GSR_CURSOR_STRIDE);
-            HIPCHK(hipMemcpyAsync(tc.data(), imv.tile_cursor, tc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            std::vector<uint2> rg((size_t)nt);
+            HIPCHK(hipMemcpyAsync(rg.data(), imv.ranges, rg.size() * sizeof(uint2), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
             long long sum = 0;
-            for (int i = 0; i < nt; i++) sum += tc[(size_t)i * GSR_CURSOR_STRIDE];
+            for (int i = 0; i < nt; i++) sum += (long long)(rg[i].y - rg[i].x);
             last_R = (int)sum;
         }
         a->stats_out[0] = n_fallbacks; a->stats_out[1] = last_R;

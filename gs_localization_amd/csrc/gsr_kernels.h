@@ -123,6 +123,7 @@ struct PreArgs {
     const float* zbc; uint32_t* truncc; int sbx;   // the same per 4x4-tile superblock (max of its tiles): quick reject
     // bin-by-tile path (nullable): per-tile append cursors and fixed-capacity bins of (depth bits << 32 | index)
     uint32_t* tile_cursor; unsigned long long* bins;
+    int* n_touched;          // nullable: cleared here (one 4-B store per Gaussian) instead of by a separate memset
     LoopGuard guard;
     const float* means; const float* scales; float mod; const float* rots; const float* opac;
     const float* shs; const float* cov3D_pre; const float* colors_pre;
@@ -199,6 +200,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     if (live) {
         a.radii[idx] = 0;
         a.tiles_touched[idx] = 0;
+        if (a.n_touched != nullptr) a.n_touched[idx] = 0;
         if (a.bins == nullptr) {            // (the bin-by-tile path has no depth sort)
             a.depth_key[idx] = 0xFFFFFFFFu;     // culled Gaussians sort behind every visible one
             a.order_in[idx] = (uint32_t)idx;
@@ -525,7 +527,7 @@ template <bool TOUCHED, bool LOCALSORT>
 __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__ ranges,
                                                           uint32_t* __restrict__ point_list,
                                                           const unsigned long long* __restrict__ bins,
-                                                          const uint32_t* __restrict__ tile_cursor,
+                                                          uint32_t* __restrict__ tile_cursor,
                                                           int W, int H, int gx,
                                                           int ntiles, const float2* __restrict__ xy,
                                                           const float* __restrict__ rgb, const float* __restrict__ depths,
@@ -550,8 +552,13 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
     const float pxf = (float)px, pyf = (float)py;
     uint2 range;
     if (LOCALSORT) {
+        // one lane reads the tile's cursor and clears it for the next iteration's appends (no memset); everybody else
+        // gets the count through LDS
+        __shared__ uint32_t s_cursor;
+        if (tid == 0) { s_cursor = tile_cursor[tile * GSR_CURSOR_STRIDE]; tile_cursor[tile * GSR_CURSOR_STRIDE] = 0u; }
+        __syncthreads();
         range.x = (uint32_t)tile * GSR_LSORT_CAP;
-        range.y = range.x + tile_cursor[tile * GSR_CURSOR_STRIDE];
+        range.y = range.x + s_cursor;
     } else range = ranges[tile];
     const int total = (int)(range.y - range.x);
 
@@ -1899,6 +1906,9 @@ struct LossArgs {
     const float* image; const float* depth; const float* opacity; const float* gt_image; const float* gt_depth;
     const uint8_t* grad_mask; const float* exposure; float opacity_thr, depth_w; int monocular;
     float* dL_dimage; float* dL_ddepth; float* dL_dalpha; float* out;     // out[0]=loss, [1]=dL/da, [2]=dL/db
+    // native loop (nullable): per-superblock words that this iteration's forward has consumed and the next one
+    // starts from zero -- cleared here instead of by two memsets per iteration
+    uint32_t* clear_a; float* clear_b; int clear_n;
     LoopGuard guard;
 };
 __device__ __forceinline__ float sgnf(float d) { return (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f); }
@@ -1907,6 +1917,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_tracking_loss(LossArgs a)
 {
     __shared__ float s_red[4][3];
     if (a.guard.frozen()) return;
+    if (blockIdx.x == 0 && a.clear_a != nullptr)
+        for (int i = threadIdx.x; i < a.clear_n; i += GSR_BLOCK) { a.clear_a[i] = 0u; a.clear_b[i] = 0.f; }
     const int n = a.W * a.H;
     const float ea = expf(a.exposure[0]), eb = a.exposure[1];
     const float inv3n = 1.f / (3.f * (float)n), invn = 1.f / (float)n;
@@ -2003,10 +2015,16 @@ __global__ void k_pose_step(float* st, const float* dL_dtau, const double* tau_a
                             const float* loss_out, const float* proj_raw, float lr, float conv_thr, float* loss_zero,
                             LoopGuard guard)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    if (blockIdx.x != 0) return;
     if (guard.frozen()) return;
+    __shared__ float s_t6[6];
+    if (threadIdx.x < 6) s_t6[threadIdx.x] = tau_acc ? (float)tau_total(tau_acc, threadIdx.x) : dL_dtau[threadIdx.x];
+    __syncthreads();
+    if (tau_acc != nullptr && loss_zero != nullptr)        // native loop: leave the partial sums clean for the next backward
+        for (int i = threadIdx.x; i < 8 * GSR_TAU_SLOTS; i += blockDim.x) const_cast<double*>(tau_acc)[i] = 0.0;
+    if (threadIdx.x != 0) return;
     float t6[6];
-    for (int i = 0; i < 6; i++) t6[i] = tau_acc ? (float)tau_total(tau_acc, i) : dL_dtau[i];
+    for (int i = 0; i < 6; i++) t6[i] = s_t6[i];
     if (tau_acc && dL_dtau_out) for (int i = 0; i < 6; i++) dL_dtau_out[i] = t6[i];
     float g[8] = {t6[3], t6[4], t6[5], t6[0], t6[1], t6[2], loss_out[1], loss_out[2]};
     const float step = st[GSR_PS_STEP] + 1.f;
