@@ -10,6 +10,7 @@
 #include <string>
 #include <vector>
 #include <mutex>
+#include <atomic>
 
 #include "gsr.h"
 #include "gsr_kernels.h"
@@ -277,7 +278,7 @@ struct SideLease {          // RAII: returns the Side to its device's pool
 };
 
 // Pinned status slots + events of one gsr_refine call, pooled for the same reason.
-struct LoopCtx { float* h_status = nullptr; hipEvent_t ev[2] = {nullptr, nullptr}; };
+struct LoopCtx { float* h_status = nullptr; };      // 2 slots x 8 floats of pinned, device-visible host memory
 struct LoopCtxPool { std::mutex mu; std::vector<LoopCtx*> free_list; };
 LoopCtxPool g_loop_ctx;
 LoopCtx* loop_ctx_acquire()
@@ -287,9 +288,7 @@ LoopCtx* loop_ctx_acquire()
         if (!g_loop_ctx.free_list.empty()) { LoopCtx* c = g_loop_ctx.free_list.back(); g_loop_ctx.free_list.pop_back(); return c; }
     }
     LoopCtx* c = new LoopCtx();
-    if (hipHostMalloc((void**)&c->h_status, 2 * 4 * sizeof(float)) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev[0], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->ev[1], hipEventDisableTiming) != hipSuccess) {
+    if (hipHostMalloc((void**)&c->h_status, 2 * 8 * sizeof(float)) != hipSuccess) {
         (void)hipGetLastError();
         delete c;
         return nullptr;
@@ -736,7 +735,7 @@ int gsr_pose_step(float* pose_state, const float* dL_dtau, const float* loss_out
     if (rc != GSR_OK) return rc;
     hipLaunchKernelGGL(gsr::k_pose_step, dim3(1), dim3(64), 0, st, pose_state, dL_dtau, (const double*)nullptr,
                        (float*)nullptr, loss_out, projmatrix_raw, lr, converged_threshold, (float*)nullptr,
-                       gsr::LoopGuard{nullptr, nullptr});
+                       gsr::LoopGuard{nullptr, nullptr}, (float*)nullptr, 0);
     LAUNCHCHK("k_pose_step");
     return 0;
 }
@@ -773,9 +772,26 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         CtxLease() : c(loop_ctx_acquire()) {}
         ~CtxLease() { if (c) loop_ctx_release(c); }
     } ctx_lease;
-    if (!ctx_lease.c) return fail(GSR_E_HIP, "gsr_refine: could not create pinned status slots / events%s", "");
+    if (!ctx_lease.c) return fail(GSR_E_HIP, "gsr_refine: could not create the pinned status slots%s", "");
     float* h_status = ctx_lease.c->h_status;
-    hipEvent_t* ev_status = ctx_lease.c->ev;
+    for (int i = 0; i < 16; i++) h_status[i] = 0.f;          // sequence words of both slots start at 0
+    // Waits until the pose step of iteration `it` has published its status (sequence word == it + 1).  The kernel
+    // writes the slot itself (k_pose_step), so there is no copy and no event; the stream is queried now and then so
+    // that a failed launch cannot turn this into an endless wait.
+    auto wait_status = [&](int it) -> int {
+        volatile int* seqw = reinterpret_cast<volatile int*>(h_status + 8 * (it & 1)) + 4;
+        for (unsigned spins = 0;; spins++) {
+            if (*seqw == it + 1) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
+            if ((spins & 0x3FFFu) == 0x3FFFu) {
+                const hipError_t q = hipStreamQuery(st);
+                if (q == hipSuccess) {          // everything enqueued has run: one last look, then give up
+                    if (*seqw == it + 1) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
+                    return fail(GSR_E_HIP, "gsr_refine: the iteration finished without publishing its status%s", "");
+                }
+                if (q != hipErrorNotReady) return fail(GSR_E_HIP, "gsr_refine: %s", hipGetErrorString(q));
+            }
+        }
+    };
     CachedBuf gb{a->geometry_buffer, a->geometry_ctx, nullptr, 0}, bb{a->binning_buffer, a->binning_ctx, nullptr, 0},
         ib{a->image_buffer, a->image_ctx, nullptr, 0};
     float* ps = a->pose_state;
@@ -832,6 +848,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     int slot_mode[2] = {0, 0};
     auto enqueue = [&](int it, int mode) -> int {
         slot_mode[it & 1] = mode;
+        reinterpret_cast<volatile int*>(h_status + 8 * (it & 1))[4] = 0;      // (nothing in flight writes this slot any more)
         tl_spec.mode = mode;
         tl_spec.parity = it & 1;
         {   // the loss kernel of this iteration clears the dropped-here flags and the bounds buffer iteration it+1 writes
@@ -867,18 +884,16 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             Geom gg; carve_geom((char*)gb.ptr, a->P, gg);
             hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(64), 0, st, ps, (const float*)a->dL_dtau, (const double*)gg.tau_acc,
                                a->dL_dtau, (const float*)a->loss_out, a->projmatrix_raw, a->lr, a->converged_threshold,
-                               a->loss_out, tl_guard);
+                               a->loss_out, tl_guard, h_status + 8 * (it & 1), it + 1);
             LAUNCHCHK("k_pose_step");
         }
-        HIPCHK(hipMemcpyAsync(h_status + 4 * (it & 1), ps + GSR_PS_CONV, 4 * sizeof(float), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipEventRecord(ev_status[it & 1], st));
         return 0;
     };
     // Wait for iteration `it`'s status.  A poisoned iteration (failed speculation: its loss, backward and pose step
     // and everything enqueued behind it were skipped on the device) is redone here with complete lists.
     auto settle = [&](int it, bool& conv_out) -> int {
-        HIPCHK(hipEventSynchronize(ev_status[it & 1]));
-        const float* hs = h_status + 4 * (it & 1);
+        { const int wrc = wait_status(it); if (wrc < 0) return wrc; }
+        const float* hs = h_status + 8 * (it & 1);
         uint32_t pz; memcpy(&pz, hs + 3, sizeof(pz));
         if (pz != 0u) {
             n_fallbacks++;
@@ -887,7 +902,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             HIPCHK(hipMemsetAsync(poison, 0, sizeof(uint32_t), st));
             int rc2 = enqueue(it, 2);
             if (rc2 < 0) return rc2;
-            HIPCHK(hipEventSynchronize(ev_status[it & 1]));
+            { const int wrc = wait_status(it); if (wrc < 0) return wrc; }
             // back off: a scene whose lists stay long after culling would otherwise pay for both forwards every time
             fail_streak++;
             if (fail_streak >= 2) spec_resume = it + 1 + (1 << (fail_streak < 6 ? fail_streak : 6));

@@ -2011,21 +2011,12 @@ __global__ void k_pose_init(float* st, const float* proj_raw)
 // tau_acc (nullable): the fp64 block sums of K8/K9; when given, this kernel also finishes the dL/dtau
 // reduction (writes dL_dtau_out) so that the separate k_tau_finish launch is not needed in the native loop.
 // loss_zero (nullable): the native loop's loss accumulator, cleared here for the next iteration once consumed.
-__global__ void k_pose_step(float* st, const float* dL_dtau, const double* tau_acc, float* dL_dtau_out,
-                            const float* loss_out, const float* proj_raw, float lr, float conv_thr, float* loss_zero,
-                            LoopGuard guard)
+__device__ __forceinline__ void pose_step_body(float* st, const float* s_t6, bool have_tau_acc, float* dL_dtau_out, const float* loss_out,
+                                               const float* proj_raw, float lr, float conv_thr, float* loss_zero)
 {
-    if (blockIdx.x != 0) return;
-    if (guard.frozen()) return;
-    __shared__ float s_t6[6];
-    if (threadIdx.x < 6) s_t6[threadIdx.x] = tau_acc ? (float)tau_total(tau_acc, threadIdx.x) : dL_dtau[threadIdx.x];
-    __syncthreads();
-    if (tau_acc != nullptr && loss_zero != nullptr)        // native loop: leave the partial sums clean for the next backward
-        for (int i = threadIdx.x; i < 8 * GSR_TAU_SLOTS; i += blockDim.x) const_cast<double*>(tau_acc)[i] = 0.0;
-    if (threadIdx.x != 0) return;
     float t6[6];
     for (int i = 0; i < 6; i++) t6[i] = s_t6[i];
-    if (tau_acc && dL_dtau_out) for (int i = 0; i < 6; i++) dL_dtau_out[i] = t6[i];
+    if (have_tau_acc && dL_dtau_out) for (int i = 0; i < 6; i++) dL_dtau_out[i] = t6[i];
     float g[8] = {t6[3], t6[4], t6[5], t6[0], t6[1], t6[2], loss_out[1], loss_out[2]};
     const float step = st[GSR_PS_STEP] + 1.f;
     st[GSR_PS_STEP] = step;
@@ -2080,6 +2071,34 @@ __global__ void k_pose_step(float* st, const float* dL_dtau, const double* tau_a
     if (loss_zero != nullptr) { loss_zero[0] = 0.f; loss_zero[1] = 0.f; loss_zero[2] = 0.f; loss_zero[3] = 0.f; }
     pose_write_camera(st, proj_raw);
 }
+
+
+// host_status (nullable, pinned host memory, 8 floats): the native loop's per-iteration status {converged, loss,
+// |tau|, poison bits} followed by the sequence number `seq`, written by this kernel itself on every exit path --
+// no copy kernel, no event: the host polls the sequence word.
+__global__ void k_pose_step(float* st, const float* dL_dtau, const double* tau_acc, float* dL_dtau_out,
+                            const float* loss_out, const float* proj_raw, float lr, float conv_thr, float* loss_zero,
+                            LoopGuard guard, float* host_status, int seq)
+{
+    if (blockIdx.x != 0) return;
+    const bool run = !guard.frozen();          // block-uniform
+    __shared__ float s_t6[6];
+    if (run) {
+        if (threadIdx.x < 6) s_t6[threadIdx.x] = tau_acc ? (float)tau_total(tau_acc, threadIdx.x) : dL_dtau[threadIdx.x];
+        __syncthreads();
+        if (tau_acc != nullptr && loss_zero != nullptr)        // native loop: leave the partial sums clean for the next backward
+            for (int i = threadIdx.x; i < 8 * GSR_TAU_SLOTS; i += blockDim.x) const_cast<double*>(tau_acc)[i] = 0.0;
+    }
+    if (threadIdx.x != 0) return;
+    if (run) pose_step_body(st, s_t6, tau_acc != nullptr, dL_dtau_out, loss_out, proj_raw, lr, conv_thr, loss_zero);
+    if (host_status != nullptr) {
+        host_status[0] = st[GSR_PS_CONV]; host_status[1] = st[GSR_PS_LOSS]; host_status[2] = st[GSR_PS_TAUN];
+        host_status[3] = __uint_as_float(guard.poison ? *guard.poison : 0u);
+        __threadfence_system();
+        reinterpret_cast<volatile int*>(host_status)[4] = seq;
+    }
+}
+
 
 // K10  near-plane visibility (replaces rasterizer_impl.cu:54-66 checkFrustum)
 __global__ void __launch_bounds__(GSR_BLOCK) k_mark_visible(int P, const float* means, const float* view, uint8_t* present)
