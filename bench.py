@@ -58,7 +58,7 @@ def algorithmic_bytes(P, V, R, R_eff, N, M, ntiles):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--frames-in-flight", type=int, default=4, help="query frames refined concurrently per GPU")
