@@ -62,7 +62,6 @@ struct Profiler {
     }
 };
 Profiler g_prof;
-int g_ablate = 0;      // diagnostic builds only (gsr_debug_ablate): switches parts of k_render_bwd off
 struct ProfScope {
     int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
     ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on((g_prof.mask >> id_) & 1u)
@@ -319,8 +318,6 @@ int select_device_of(const void* p)
 extern "C" {
 
 const char* gsr_last_error(void) { return g_err.c_str(); }
-
-int gsr_debug_ablate(int bits) { g_ablate = bits; return 0; }
 
 // diagnostic builds only (GSR_TIMING): copies the 32 phase counters out and clears them; -1 in product builds
 int gsr_debug_timing(unsigned long long* out32)

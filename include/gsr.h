@@ -261,9 +261,6 @@ int gsr_dist2_knn3(int P, const float* points, float* mean_dist2, gsr_resize_fn 
  * gsr_profile_collect waits for the recorded events, ADDS elapsed milliseconds / launch counts per
  * kernel id into ms[] / launches[] (arrays of gsr_profile_kernel_count() entries) and forgets them. */
 int gsr_profile_enable(unsigned mask);
-/* Diagnostics only (ablation timing, results become wrong): bit0 no LDS accumulation, bit1 no DPP
- * reduction, bit2 no global flush, bit3 no splat loop in the backward compositing kernel.  0 = normal. */
-int gsr_debug_ablate(int bits);
 /* Diagnostic builds only (compiled with -DGSR_TIMING=1): copies out and clears 32 shader-clock phase totals of
  * the two compositing kernels (slots 0-15 forward, 16-31 backward).  Returns -1 in product builds. */
 int gsr_debug_timing(unsigned long long* out32);

@@ -1,4 +1,5 @@
-"""Diagnostic: time k_render_bwd on S-1M-640 with parts switched off (gsr_debug_ablate)."""
+"""Native loop on S-1M-640, single frame, plain vs speculative: wall time per iteration and the per-kernel HIP-event
+times (ms per iteration) from the library's own profiler."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -16,8 +17,7 @@ init = torch.tensor(S.se3_exp([0.01, 0.01, 0.01, 0.01, 0.0, 0.0]), dtype=torch.f
 fr = PL.FusedRefiner(model, H, W, device=dev)
 nk = lib.gsr_profile_kernel_count(); names = [lib.gsr_profile_kernel_name(i).decode() for i in range(nk)]
 import time
-for ab, spec in [(0, False), (0, True), (0, False), (0, True)]:
-    lib.gsr_debug_ablate(ab)
+for spec in [False, True, False, True]:
     fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False, speculative=spec)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=100, stop_on_converged=False, speculative=spec)
@@ -29,4 +29,3 @@ for ab, spec in [(0, False), (0, True), (0, False), (0, True)]:
     ms = (C.c_double * nk)(); cnt = (C.c_longlong * nk)(); lib.gsr_profile_collect(ms, cnt); lib.gsr_profile_enable(0)
     d = {names[i]: round(ms[i] / 40, 4) for i in range(nk)}        # ms per iteration (all launches of that kernel)
     print("spec", spec, "wall ms/iter %.4f" % (wall * 1e3), info, d, "sum %.4f" % sum(d.values()), flush=True)
-lib.gsr_debug_ablate(0)
