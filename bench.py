@@ -225,6 +225,9 @@ def main():
                 raise e
     run_all(Wm)
     torch.cuda.synchronize()
+    # one launch in 16 is bracketed: an event pair around every launch keeps the kernel from overlapping its neighbours
+    # of the other frames in flight (measured: -5 % on `value`)
+    lib.gsr_profile_sampling(16)
     lib.gsr_profile_enable(1 << names.index(dominant))
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -233,6 +236,7 @@ def main():
     elapsed = time.perf_counter() - t0
     dom_ms, dom_n = collect()[dominant]
     lib.gsr_profile_enable(0)
+    lib.gsr_profile_sampling(1)
     if world > 1:
         t = torch.tensor([elapsed, elapsed_py, elapsed_single], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -293,6 +297,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_kernel_bytes[dominant], "avg_launch_ms": dom_avg_ms,
+                         "launches_timed": int(dom_n),
                          "avg_launch_ms_single_frame": native_ms[dominant],
                          # the reference algorithm's bytes per iteration (all kernels) x measured
                          # iterations/s, against the HBM peak: > 1 means the loop runs faster than the reference's

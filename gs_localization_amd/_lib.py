@@ -28,6 +28,7 @@ SIGNATURES = {
     "gsr_binning_bytes": (C.c_size_t, [_i]),
     "gsr_forward_stats": (_i, [_i, _i, _i, _vp, _vp, _vp, C.POINTER(C.c_longlong), _vp]),
     "gsr_profile_enable": (_i, [C.c_uint]),
+    "gsr_profile_sampling": (_i, [C.c_uint]),
     "gsr_debug_timing": (_i, [C.POINTER(C.c_ulonglong)]),
     "gsr_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "gsr_profile_kernel_count": (_i, []),

@@ -50,6 +50,8 @@ const char* const kKernelNames[K_COUNT] = {"preprocess_fwd", "scan", "emit", "so
 struct Profiler {
     std::mutex mu;
     unsigned mask = 0;
+    unsigned every = 1;                         // bracket one launch in `every` (gsr_profile_sampling)
+    std::atomic<unsigned> seen[K_COUNT];
     std::vector<hipEvent_t> pool;
     struct Pending { int id; hipEvent_t a, b; };
     std::vector<Pending> pending;
@@ -66,6 +68,7 @@ struct ProfScope {
     int id; hipStream_t st; hipEvent_t a = nullptr, b = nullptr; bool on;
     ProfScope(int id_, hipStream_t st_) : id(id_), st(st_), on((g_prof.mask >> id_) & 1u)
     {
+        if (on && g_prof.every > 1) on = (g_prof.seen[id_].fetch_add(1u, std::memory_order_relaxed) % g_prof.every) == 0u;
         if (!on) return;
         std::lock_guard<std::mutex> l(g_prof.mu);
         a = g_prof.get(); b = g_prof.get();
@@ -344,6 +347,12 @@ int gsr_profile_enable(unsigned mask)
 {
     std::lock_guard<std::mutex> l(g_prof.mu);
     g_prof.mask = mask;
+    return 0;
+}
+int gsr_profile_sampling(unsigned every)
+{
+    std::lock_guard<std::mutex> l(g_prof.mu);
+    g_prof.every = every ? every : 1u;
     return 0;
 }
 int gsr_profile_kernel_count(void) { return K_COUNT; }

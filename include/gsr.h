@@ -261,6 +261,9 @@ int gsr_dist2_knn3(int P, const float* points, float* mean_dist2, gsr_resize_fn 
  * gsr_profile_collect waits for the recorded events, ADDS elapsed milliseconds / launch counts per
  * kernel id into ms[] / launches[] (arrays of gsr_profile_kernel_count() entries) and forgets them. */
 int gsr_profile_enable(unsigned mask);
+/* Bracket only one launch in `every` of each enabled kernel (default 1 = all): an event pair around a kernel keeps it
+ * from overlapping its neighbours, which costs ~5 % with several frames in flight. */
+int gsr_profile_sampling(unsigned every);
 /* Diagnostic builds only (compiled with -DGSR_TIMING=1): copies out and clears 32 shader-clock phase totals of
  * the two compositing kernels (slots 0-15 forward, 16-31 backward).  Returns -1 in product builds. */
 int gsr_debug_timing(unsigned long long* out32);
