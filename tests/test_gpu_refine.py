@@ -257,3 +257,38 @@ def test_native_loop_gradient_tensors_stay_consistent():
         zero_rows = np.all(b.reshape(b.shape[0], -1) == 0, axis=1)
         assert zero_rows.sum() > 1000
         assert np.all(a.reshape(a.shape[0], -1)[zero_rows] == 0), k
+
+
+@pytest.mark.parametrize("W,H,mono,conv_thr", [(150, 100, False, 1e-4), (96, 70, True, 3e-3)])
+def test_final_state_equals_fresh_render_at_returned_pose(W, H, mono, conv_thr):
+    """Whatever the loop did internally (speculation, frozen iterations after convergence, in-kernel clears), what it
+    leaves behind -- image, depth, opacity, n_touched, radii -- must be the render of the pose it reports as the last
+    forward's, like the reference's last render_pkg.  Odd image sizes, monocular config, early exit."""
+    from gs_localization_amd import pipelines as PL
+    sc = S.small(P=12000, W=W, H=H, sh_degree=2, seed=21, scale_med=0.04)
+    model, bg, view, init = _setup(sc, seed=4)
+    cfg = {"Training": dict(PL.TRACKING_CONFIG["Training"], monocular=mono)}
+    fr = PL.FusedRefiner(model, H, W, device=DEV)
+    for stop in (True, False):
+        vp = view()
+        R, T, info = fr.refine(vp, cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=40, converged_threshold=conv_thr,
+                               stop_on_converged=stop)
+        torch.cuda.synchronize()
+        if stop and conv_thr > 1e-3:
+            assert info["converged"] and info["iters"] < 40        # this configuration must take the early exit
+        if stop and info["converged"]:
+            Rl, Tl = R, T                                  # converged: the last forward was rendered at the final pose
+        else:
+            continue                                       # (not converged: the last forward precedes the last update)
+        chk = view()
+        chk.update_RT(Rl.clone(), Tl.clone())
+        with torch.no_grad():
+            pkg = PL.render(chk, model, PL.PipelineParams(), bg)
+        # the native state keeps R, T in fp32 on the device; the camera rebuilt on the host agrees to ~1e-7
+        assert torch.allclose(fr.color, pkg["render"], atol=2e-4), float((fr.color - pkg["render"]).abs().max())
+        assert torch.allclose(fr.depth, pkg["depth"], atol=2e-3)
+        assert torch.allclose(fr.alpha, pkg["opacity"], atol=2e-4)
+        assert int((fr.radii != pkg["radii"]).sum()) <= 2
+        nt = pkg["n_touched"]
+        assert int((fr.n_touched - nt).abs().sum()) <= max(4, int(2e-3 * int(nt.sum())))
+    assert info["iters"] == 40
