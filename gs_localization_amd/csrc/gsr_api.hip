@@ -810,6 +810,10 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     uint32_t* poison = reinterpret_cast<uint32_t*>(ps + GSR_PS_POISON);
     tl_guard.poison = poison;
     tl_guard.conv = a->stop_on_converged ? ps + GSR_PS_CONV : nullptr;
+    // warm start: the previous call on this workspace left its last bounds in buffer warm_buf (0 / 1); iteration 0 must
+    // READ that buffer, i.e. write the other one
+    const int warm_buf = (a->speculative && a->warm_state && (*a->warm_state == 1 || *a->warm_state == 2)) ? *a->warm_state - 1 : -1;
+    const int poff = (warm_buf >= 0) ? (warm_buf ^ 1) : 0;
     int n_fallbacks = 0, last_R = 0, fail_streak = 0, spec_resume = 0;
     bool last_local = false;
     {   // gradient tensors: zero-filled once per call, then maintained row by row (PreBwdArgs::dirty)
@@ -839,28 +843,32 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
         carve_img(iptr, a->width, a->height, im0);
         HIPCHK(hipMemsetAsync(im0.trunc, 0, im0.clear_words * sizeof(uint32_t), st));
-        HIPCHK(hipMemsetAsync(im0.zbc[0], 0, (size_t)im0.nsb * sizeof(float), st));
-        HIPCHK(hipMemsetAsync(im0.zbc[1], 0, (size_t)im0.nsb * sizeof(float), st));
+        // (a warm start keeps the bounds the previous call recorded in buffer `warm_buf`)
+        if (warm_buf != 0) HIPCHK(hipMemsetAsync(im0.zbc[0], 0, (size_t)im0.nsb * sizeof(float), st));
+        if (warm_buf != 1) HIPCHK(hipMemsetAsync(im0.zbc[1], 0, (size_t)im0.nsb * sizeof(float), st));
         HIPCHK(hipMemsetAsync(a->loss_out, 0, 4 * sizeof(float), st));
     }
     static_assert(GSR_PS_POISON == GSR_PS_CONV + 3, "status words are copied out as one block");
     bool dirty_cleared = false;
     const int debug = 0;
+    auto par = [&](int it) { return (it + poff) & 1; };      // which of the two bound buffers iteration `it` WRITES
     if (a->bound_margin_mul > 0.f) { tl_spec.mul = a->bound_margin_mul; tl_spec.add = a->bound_margin_add; }
 
     // One iteration = forward, tracking loss, backward, Adam + update_pose, all enqueued without waiting for the
     // device (the non-speculative forward still reads its instance count back, as the reference does).  Behind
     // it, the status words are copied to the slot of the iteration's parity.
     int slot_mode[2] = {0, 0};
+    int last_enq = -1;            // last iteration whose forward was enqueued: its bounds are the newest
     auto enqueue = [&](int it, int mode) -> int {
         slot_mode[it & 1] = mode;
+        last_enq = it;
         reinterpret_cast<volatile int*>(h_status + 8 * (it & 1))[4] = 0;      // (nothing in flight writes this slot any more)
         tl_spec.mode = mode;
-        tl_spec.parity = it & 1;
+        tl_spec.parity = par(it);
         {   // the loss kernel of this iteration clears the dropped-here flags and the bounds buffer iteration it+1 writes
             Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
             tl_clear.a = (mode != 0) ? imv.truncc : nullptr;
-            tl_clear.b = imv.zbc[(it & 1) ^ 1];
+            tl_clear.b = imv.zbc[par(it) ^ 1];
             tl_clear.n = imv.nsb;
         }
         int R = gsr_forward(cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
@@ -922,7 +930,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     // Speculative binning: from the second iteration on, instances lying behind what their tile needed in the
     // previous iteration (x margin) are not binned; the compositing kernel verifies the speculation and a failed
     // one is redone with complete lists, so results never depend on it.
-    auto mode_of = [&](int it) { return a->speculative ? ((it == 0 || it < spec_resume) ? 2 : 1) : 0; };
+    auto mode_of = [&](int it) { return a->speculative ? (((it == 0 && warm_buf < 0) || it < spec_resume) ? 2 : 1) : 0; };
     int it = 0, settled = -1;
     bool prev_pending = false;
     while (it < a->max_iters) {
@@ -953,6 +961,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (a->stop_on_converged && conv) *converged = 1;
     }
     HIPCHK(hipStreamSynchronize(st));
+    if (a->warm_state) *a->warm_state = (a->speculative && last_enq >= 0) ? (par(last_enq) + 1) : 0;
     if (a->stats_out) {
         if (last_local && ib.ptr) {      // instances binned by the last forward = sum of the tile list lengths
             Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);

@@ -346,9 +346,10 @@ class FusedRefiner:
         self.g_tau, self.loss_out = e(6), e(4)
         self.state = torch.zeros(_lib.POSE_STATE_FLOATS, dtype=torch.float32, device=dev)
         self.ws = [_Workspace(dev), _Workspace(dev), _Workspace(dev)]
+        self._warm = C.c_int(0)          # gsr_refine_args.warm_state of this refiner's image workspace
 
     def refine(self, viewpoint, config, initial_R, initial_T, background, iters=50, lr=0.001, converged_threshold=1e-4,
-               stop_on_converged=True, speculative=True, bound_margin=(1.05, 0.05)):
+               stop_on_converged=True, speculative=True, bound_margin=(1.05, 0.05), warm_start=False):
         C, _lib = self._C, self._lib_mod
         dev = self.dev
         # speculative=True: exact optimisation (include/gsr.h, gsr_refine_args.speculative): ~9x fewer binned
@@ -378,6 +379,11 @@ class FusedRefiner:
         a.P, a.D, a.M = self.P, int(self.model.active_sh_degree), self.M
         a.means3D, a.shs, a.opacities, a.scales, a.rotations = map(p, (self.means3D, self.shs, self.opac, self.scales, self.rots))
         a.scale_modifier = 1.0
+        # warm_start=True: frame sequences -- start speculating from the depth bounds the previous refine() of this
+        # refiner left behind instead of binning the first iteration with the global sorts (still verified, still exact)
+        if not warm_start:
+            self._warm.value = 0
+        a.warm_state = C.pointer(self._warm)
         a.width, a.height = self.W, self.H
         a.tan_fovx, a.tan_fovy = math.tan(viewpoint.FoVx * 0.5), math.tan(viewpoint.FoVy * 0.5)
         a.background, a.projmatrix_raw = p(bg), p(proj_raw)

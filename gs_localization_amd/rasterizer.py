@@ -83,7 +83,8 @@ class _Workspace:
 
     def _resize(self, _ctx, nbytes):
         try:
-            self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            if self.t.numel() < int(nbytes):      # a workspace that is kept (FusedRefiner) keeps its contents and its address
+                self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
             return self.t.data_ptr()
         except Exception:      # surfaces as GSR_E_ALLOC
             return 0

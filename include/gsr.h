@@ -215,6 +215,12 @@ typedef struct gsr_refine_args {
      * depth the tile had to look at in the previous iteration, are not binned.  0 disables. */
     int speculative; float bound_margin_mul, bound_margin_add;     /* margins <= 0: defaults 1.05, 0.05 */
     int* stats_out;             /* nullable host int[2]: number of redone forwards, last num_rendered */
+    /* Nullable HOST int, in/out: warm start of the speculation for frame sequences.  0 on input = the image workspace
+     * holds no depth bounds (the first iteration bins with the global sorts).  Pass the value the previous call on the
+     * SAME image workspace (same size) left here to start speculating from that frame's bounds at once -- consecutive
+     * frames of a sequence see almost the same depths.  As always the speculation is verified and redone if it
+     * fails, so a stale or unrelated set of bounds costs time, never exactness. */
+    int* warm_state;
     void* stream;
 } gsr_refine_args;
 int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);

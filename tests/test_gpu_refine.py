@@ -292,3 +292,41 @@ def test_final_state_equals_fresh_render_at_returned_pose(W, H, mono, conv_thr):
         nt = pkg["n_touched"]
         assert int((fr.n_touched - nt).abs().sum()) <= max(4, int(2e-3 * int(nt.sum())))
     assert info["iters"] == 40
+
+
+def test_warm_start_of_the_speculation_is_exact():
+    """Frame sequences: refine() can start speculating from the bounds the previous call left in the workspace.
+    Same result as a cold start -- from the same frame, from a neighbouring pose, and from an unrelated one (where
+    the verification has to catch the stale bounds)."""
+    from gs_localization_amd import pipelines as PL
+    sc = S.small(P=40000, W=160, H=128, sh_degree=2, seed=13, scale_med=0.04)
+    model, bg, view, init = _setup(sc, seed=3)
+    cfg = PL.TRACKING_CONFIG
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+
+    def run(start, warm):
+        vp = view()
+        R, T, info = fr.refine(vp, cfg, start[:3, :3].clone(), start[:3, 3].clone(), bg, iters=10, stop_on_converged=False, warm_start=warm)
+        return R.clone(), T.clone(), dict(info), fr.color.clone()
+    cold = run(init, False)
+    assert fr._warm.value in (1, 2)
+    warm_same = run(init, True)                        # bounds of the same frame
+    near = torch.tensor(S.se3_exp([0.004, -0.003, 0.002, 0.002, -0.001, 0.001]), dtype=torch.float32, device=DEV) @ init
+    cold_near = run(near, False)
+    run(init, False)
+    warm_near = run(near, True)                        # bounds of a neighbouring frame
+    far = torch.tensor(S.se3_exp([0.3, 0.2, -0.4, 0.25, -0.2, 0.1]), dtype=torch.float32, device=DEV)
+    cold_far = run(far, False)
+    run(init, False)
+    warm_far = run(far, True)                          # unrelated bounds: must still be exact
+    for a, b, name in ((cold, warm_same, "same"), (cold_near, warm_near, "near"), (cold_far, warm_far, "far")):
+        assert torch.allclose(a[0], b[0], atol=2e-6) and torch.allclose(a[1], b[1], atol=2e-6), name
+        # (far from the map's sweet spot a 3e-7 pose difference -- fp32 atomics reorder the gradient sums -- already
+        # moves single pixels by 1e-3)
+        assert torch.allclose(a[3], b[3], atol=5e-3 if name == "far" else 5e-4), name
+    assert warm_same[2]["fallbacks"] == 0
+    # a cold start bins its first iteration completely, a warm one does not: fewer instances in a 1-iteration call
+    fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=1, stop_on_converged=False)
+    n_cold = fr.last_info["num_rendered"]
+    fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=1, stop_on_converged=False, warm_start=True)
+    assert fr.last_info["num_rendered"] < 0.6 * n_cold
