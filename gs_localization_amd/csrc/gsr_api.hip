@@ -154,6 +154,7 @@ struct Img {
     float* zb[2]; uint32_t* trunc; uint32_t* fail;      // speculative depth bounds of the native loop
     float* zbc[2]; uint32_t* truncc; int sbx, nsb;       // per 4x4-tile superblock
     uint32_t* tile_cursor; size_t clear_words;           // bin-by-tile path: per-tile append cursors (GSR_CURSOR_STRIDE apart)
+    float* loss_shards;                                   // native loop: GSR_LOSS_SHARDS x 16 floats (fused tracking loss)
 };
 size_t carve_img(char* base, int W, int H, Img& im)
 {
@@ -173,6 +174,7 @@ size_t carve_img(char* base, int W, int H, Img& im)
     im.truncc = base ? im.trunc + (size_t)gx * gy : nullptr;
     im.fail = base ? im.truncc + im.nsb : nullptr;
     im.tile_cursor = base ? im.trunc + (((size_t)gx * gy + im.nsb + 1 + 15) & ~(size_t)15) : nullptr;
+    im.loss_shards = c.take<float>(GSR_LOSS_SHARDS * 16);
     return c.size();
 }
 
@@ -232,6 +234,8 @@ thread_local gsr::LoopGuard tl_guard = {nullptr, nullptr};
 // set by gsr_refine per iteration: what the loss kernel clears for the next iteration (see LossArgs)
 struct LoopClear { uint32_t* a = nullptr; float* b = nullptr; int n = 0; };
 thread_local LoopClear tl_clear;
+// set by gsr_refine: the tracking loss evaluated in the compositing kernel's epilogue (FusedLoss); out == nullptr otherwise
+thread_local gsr::FusedLoss tl_floss = {};
 thread_local int g_dev = 0;      // device chosen by the last select_device_of on this thread
 
 // One side stream + a fork/join event pair per device: independent work (SH colours, zero fills) runs next to
@@ -578,7 +582,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
                      width, height, gx, ntiles, (const float2*)g.xy, feat, \
                      (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
                      zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), tl_guard.poison ? const_cast<uint32_t*>(tl_guard.poison) : im.fail, \
-                     tl_spec.mul, tl_spec.add, zbc_next, (const uint32_t*)im.truncc, im.sbx
+                     tl_spec.mul, tl_spec.add, zbc_next, (const uint32_t*)im.truncc, im.sbx, tl_floss
     if (local_path) {
         if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
         else hipLaunchKernelGGL((k_render_fwd<false, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
@@ -741,7 +745,7 @@ int gsr_pose_step(float* pose_state, const float* dL_dtau, const float* loss_out
     if (rc != GSR_OK) return rc;
     hipLaunchKernelGGL(gsr::k_pose_step, dim3(1), dim3(64), 0, st, pose_state, dL_dtau, (const double*)nullptr,
                        (float*)nullptr, loss_out, projmatrix_raw, lr, converged_threshold, (float*)nullptr,
-                       gsr::LoopGuard{nullptr, nullptr}, (float*)nullptr, 0);
+                       gsr::LoopGuard{nullptr, nullptr}, (float*)nullptr, 0, (float*)nullptr, (uint32_t*)nullptr, (float*)nullptr, 0);
     LAUNCHCHK("k_pose_step");
     return 0;
 }
@@ -805,7 +809,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     *converged = 0;
     struct FlagGuard {
         FlagGuard() { tl_native_loop = true; }
-        ~FlagGuard() { tl_native_loop = false; tl_spec.mode = 0; tl_guard = LoopGuard{nullptr, nullptr}; tl_clear = LoopClear{}; }
+        ~FlagGuard() { tl_native_loop = false; tl_spec.mode = 0; tl_guard = LoopGuard{nullptr, nullptr}; tl_clear = LoopClear{}; tl_floss = FusedLoss{}; }
     } guard;
     uint32_t* poison = reinterpret_cast<uint32_t*>(ps + GSR_PS_POISON);
     tl_guard.poison = poison;
@@ -843,6 +847,12 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
         carve_img(iptr, a->width, a->height, im0);
         HIPCHK(hipMemsetAsync(im0.trunc, 0, im0.clear_words * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(im0.loss_shards, 0, GSR_LOSS_SHARDS * 16 * sizeof(float), st));
+        HIPCHK(hipMemsetAsync(a->dL_dalpha, 0, (size_t)a->width * a->height * sizeof(float), st));      // no gradient flows into opacity
+        tl_floss.gt_image = a->gt_image; tl_floss.gt_depth = a->gt_depth; tl_floss.grad_mask = a->grad_mask;
+        tl_floss.exposure = ps + GSR_PS_PARAM + 6; tl_floss.opacity_thr = a->opacity_threshold; tl_floss.depth_w = a->depth_weight;
+        tl_floss.monocular = a->monocular; tl_floss.dL_dimage = a->dL_dimage; tl_floss.dL_ddepth = a->dL_ddepth;
+        tl_floss.out = im0.loss_shards; tl_floss.conv = a->stop_on_converged ? ps + GSR_PS_CONV : nullptr;
         // (a warm start keeps the bounds the previous call recorded in buffer `warm_buf`)
         if (warm_buf != 0) HIPCHK(hipMemsetAsync(im0.zbc[0], 0, (size_t)im0.nsb * sizeof(float), st));
         if (warm_buf != 1) HIPCHK(hipMemsetAsync(im0.zbc[1], 0, (size_t)im0.nsb * sizeof(float), st));
@@ -857,6 +867,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     // One iteration = forward, tracking loss, backward, Adam + update_pose, all enqueued without waiting for the
     // device (the non-speculative forward still reads its instance count back, as the reference does).  Behind
     // it, the status words are copied to the slot of the iteration's parity.
+    Img imv_loop{};                // the image workspace's carving (for the pose step launch)
     int slot_mode[2] = {0, 0};
     int last_enq = -1;            // last iteration whose forward was enqueued: its bounds are the newest
     auto enqueue = [&](int it, int mode) -> int {
@@ -870,6 +881,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             tl_clear.a = (mode != 0) ? imv.truncc : nullptr;
             tl_clear.b = imv.zbc[par(it) ^ 1];
             tl_clear.n = imv.nsb;
+            imv_loop = imv;
         }
         int R = gsr_forward(cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
                             a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
@@ -884,10 +896,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             HIPCHK(hipMemsetAsync(gg.dirty, 0, (size_t)a->P, st));
             dirty_cleared = true;
         }
-        int rc2 = gsr_tracking_loss(a->width, a->height, a->out_color, a->out_depth, a->out_alpha, a->gt_image, a->gt_depth,
-                                    a->grad_mask, ps + GSR_PS_PARAM + 6, a->opacity_threshold, a->depth_weight, a->monocular,
-                                    a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->loss_out, a->stream);
-        if (rc2 < 0) return rc2;
+        int rc2 = 0;      // (the tracking loss was evaluated in the compositing kernel's epilogue: tl_floss)
         rc2 = gsr_backward(a->P, a->D, a->M, R, a->background, a->width, a->height, a->means3D, a->shs, nullptr, a->out_alpha,
                            a->scales, a->scale_modifier, a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ,
                            ps + GSR_PS_CAMPOS, a->tan_fovx, a->tan_fovy, a->radii, (char*)gb.ptr, (char*)bb.ptr, (char*)ib.ptr,
@@ -898,7 +907,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             Geom gg; carve_geom((char*)gb.ptr, a->P, gg);
             hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(64), 0, st, ps, (const float*)a->dL_dtau, (const double*)gg.tau_acc,
                                a->dL_dtau, (const float*)a->loss_out, a->projmatrix_raw, a->lr, a->converged_threshold,
-                               a->loss_out, tl_guard, h_status + 8 * (it & 1), it + 1);
+                               a->loss_out, tl_guard, h_status + 8 * (it & 1), it + 1, imv_loop.loss_shards, tl_clear.a, tl_clear.b,
+                               tl_clear.n);
             LAUNCHCHK("k_pose_step");
         }
         return 0;
@@ -914,6 +924,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             HIPCHK(hipStreamSynchronize(st));
             if (getenv("GSR_DEBUG_TILES")) fprintf(stderr, "[gsr] iteration %d: speculation failed (0x%x), redone\n", it, pz);
             HIPCHK(hipMemsetAsync(poison, 0, sizeof(uint32_t), st));
+            HIPCHK(hipMemsetAsync(imv_loop.loss_shards, 0, GSR_LOSS_SHARDS * 16 * sizeof(float), st));      // the failed forward added to them
             int rc2 = enqueue(it, 2);
             if (rc2 < 0) return rc2;
             { const int wrc = wait_status(it); if (wrc < 0) return wrc; }

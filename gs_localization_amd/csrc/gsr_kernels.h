@@ -516,6 +516,19 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
 // packed fp32 pipes with two waves per tile -- fewer VALU instructions per pixel, but half the waves to hide the
 // chain's latency and twice the per-lane predicate bookkeeping (80 vs 60 us, 5.0 vs 5.2 k it/s at 4 frames).
 // ---------------------------------------------------------------------------------------------
+// Native loop: the tracking loss (descent_utils.py:85-123) and its pixel gradients are evaluated in the compositing
+// kernel's epilogue, where the pixel's colour, depth and opacity are still in registers -- one launch and one pass over
+// the images less per iteration.  Partial sums go to GSR_LOSS_SHARDS x {loss, dL/da, dL/db} accumulators (64 B apart),
+// which the pose step adds up and clears.  out == nullptr: not fused (drop-in packages, gsr_tracking_loss).
+#define GSR_LOSS_SHARDS 16
+struct FusedLoss {
+    const float* gt_image; const float* gt_depth; const uint8_t* grad_mask; const float* exposure;
+    float opacity_thr, depth_w; int monocular;
+    float* dL_dimage; float* dL_ddepth; float* out;         // out: [GSR_LOSS_SHARDS][16] floats
+    const float* conv;                                        // frozen after convergence, like k_tracking_loss
+};
+__device__ __forceinline__ float sgnf(float d) { return (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f); }
+
 struct SplatLDS {
     float4 a[GSR_BLOCK];   // x, y, A2, B2
     float4 b[GSR_BLOCK];   // C2, opacity, depth, id (bits)
@@ -537,7 +550,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
                                                           int* __restrict__ n_touched, float* __restrict__ zb_next,
                                                           const uint32_t* __restrict__ trunc, uint32_t* __restrict__ fail,
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
-                                                          const uint32_t* __restrict__ truncc, int sbx)
+                                                          const uint32_t* __restrict__ truncc, int sbx, FusedLoss fl)
 {
     __shared__ SplatLDS s;
     __shared__ float s_zmax[4];
@@ -720,14 +733,53 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
             if (unfinished && trunc != nullptr && truncc[sb] != 0u) atomicAdd(fail, 1u);
         }
     }
+    const size_t N = (size_t)W * H;
+    const float img3[3] = {C0 + T_out * bg[0], C1 + T_out * bg[1], C2 + T_out * bg[2]};
     if (inside) {
         n_contrib[pix_id] = last_contributor;
-        const size_t N = (size_t)W * H;
-        out_color[pix_id] = C0 + T_out * bg[0];
-        out_color[N + pix_id] = C1 + T_out * bg[1];
-        out_color[2 * N + pix_id] = C2 + T_out * bg[2];
+        out_color[pix_id] = img3[0];
+        out_color[N + pix_id] = img3[1];
+        out_color[2 * N + pix_id] = img3[2];
         out_alpha[pix_id] = 1.f - T_out;
         out_depth[pix_id] = Dd;
+    }
+    if (fl.out != nullptr && !(fl.conv != nullptr && *fl.conv != 0.f)) {
+        // fused tracking loss: same arithmetic as k_tracking_loss, on the values just written
+        __shared__ float s_red[4][3];
+        const float ea = expf(fl.exposure[0]), eb = fl.exposure[1];
+        const float inv3n = 1.f / (3.f * (float)N), invn = 1.f / (float)N;
+        float l = 0.f, da = 0.f, db = 0.f;
+        if (inside) {
+            const bool om = (1.f - T_out) > fl.opacity_thr;
+            const float gm = fl.grad_mask[pix_id] ? 1.f : 0.f;
+            const float w = om ? gm : 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; c++) {
+                const float img = img3[c];
+                const float d = (ea * img + eb) * gm - fl.gt_image[(size_t)c * N + pix_id] * gm;
+                if (om) l += fabsf(d) * inv3n;
+                const float g = w * sgnf(d) * inv3n;
+                fl.dL_dimage[(size_t)c * N + pix_id] = g * ea;
+                da += g * ea * img;
+                db += g;
+            }
+            float gdp = 0.f;
+            if (!fl.monocular) {
+                const float gd = fl.gt_depth[pix_id];
+                const float dm = (gd > 0.01f && om) ? gm : 0.f;
+                const float dd = Dd * dm - gd * dm;
+                l += fl.depth_w * fabsf(dd) * invn;
+                gdp = fl.depth_w * dm * sgnf(dd) * invn;
+            }
+            fl.dL_ddepth[pix_id] = gdp;
+        }
+        l = wave_sum(l); da = wave_sum(da); db = wave_sum(db);
+        if (lane == 0) { s_red[wv][0] = l; s_red[wv][1] = da; s_red[wv][2] = db; }
+        __syncthreads();
+        if (tid < 3) {
+            const float t = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
+            if (t != 0.f) atomicAdd(&fl.out[(blockIdx.x & (GSR_LOSS_SHARDS - 1)) * 16 + tid], t);
+        }
     }
     GSR_T_TICK(7)
     GSR_T_FLUSH(0)
@@ -1911,8 +1963,6 @@ struct LossArgs {
     uint32_t* clear_a; float* clear_b; int clear_n;
     LoopGuard guard;
 };
-__device__ __forceinline__ float sgnf(float d) { return (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f); }
-
 __global__ void __launch_bounds__(GSR_BLOCK) k_tracking_loss(LossArgs a)
 {
     __shared__ float s_red[4][3];
@@ -2078,27 +2128,46 @@ __device__ __forceinline__ void pose_step_body(float* st, const float* s_t6, boo
 // no copy kernel, no event: the host polls the sequence word.
 __global__ void k_pose_step(float* st, const float* dL_dtau, const double* tau_acc, float* dL_dtau_out,
                             const float* loss_out, const float* proj_raw, float lr, float conv_thr, float* loss_zero,
-                            LoopGuard guard, float* host_status, int seq)
+                            LoopGuard guard, float* host_status, int seq, float* loss_shards, uint32_t* clear_a, float* clear_b,
+                            int clear_n)
 {
     if (blockIdx.x != 0) return;
     const bool run = !guard.frozen();          // block-uniform
-    __shared__ float s_t6[6];
+    // The update itself is one lane's work, but as a chain of ~130 dependent global accesses it took 11 us: the state,
+    // the loss terms and the projection matrix are brought into LDS by the whole wave first and written back at the end.
+    __shared__ float s_st[GSR_PS_SIZE], s_t6[6], s_loss[4], s_proj[16];
+    const int tid = threadIdx.x;
     if (run) {
-        if (threadIdx.x < 6) s_t6[threadIdx.x] = tau_acc ? (float)tau_total(tau_acc, threadIdx.x) : dL_dtau[threadIdx.x];
+        for (int i = tid; i < GSR_PS_SIZE; i += blockDim.x) s_st[i] = st[i];
+        if (tid < 6) s_t6[tid] = tau_acc ? (float)tau_total(tau_acc, tid) : dL_dtau[tid];
+        if (tid >= 8 && tid < 12) {
+            float v = loss_out[tid - 8];
+            if (loss_shards != nullptr) {          // fused loss: add up (and clear) the shards the compositing kernel filled
+                v = 0.f;
+                for (int sh = 0; sh < GSR_LOSS_SHARDS; sh++) { v += loss_shards[sh * 16 + (tid - 8)]; loss_shards[sh * 16 + (tid - 8)] = 0.f; }
+            }
+            s_loss[tid - 8] = v;
+        }
+        if (clear_a != nullptr)                    // per-superblock words the forward has consumed (see LossArgs)
+            for (int i = tid; i < clear_n; i += blockDim.x) { clear_a[i] = 0u; clear_b[i] = 0.f; }
+        if (tid >= 16 && tid < 32) s_proj[tid - 16] = proj_raw[tid - 16];
         __syncthreads();
         if (tau_acc != nullptr && loss_zero != nullptr)        // native loop: leave the partial sums clean for the next backward
-            for (int i = threadIdx.x; i < 8 * GSR_TAU_SLOTS; i += blockDim.x) const_cast<double*>(tau_acc)[i] = 0.0;
+            for (int i = tid; i < 8 * GSR_TAU_SLOTS; i += blockDim.x) const_cast<double*>(tau_acc)[i] = 0.0;
+        if (tid == 0) pose_step_body(s_st, s_t6, tau_acc != nullptr, dL_dtau_out, s_loss, s_proj, lr, conv_thr, nullptr);
+        __syncthreads();
+        for (int i = tid; i < GSR_PS_SIZE; i += blockDim.x)
+            if (i != GSR_PS_POISON) st[i] = s_st[i];           // (the poison word belongs to the compositing kernel and the host)
+        if (loss_zero != nullptr && tid < 4) loss_zero[tid] = 0.f;
     }
-    if (threadIdx.x != 0) return;
-    if (run) pose_step_body(st, s_t6, tau_acc != nullptr, dL_dtau_out, loss_out, proj_raw, lr, conv_thr, loss_zero);
-    if (host_status != nullptr) {
-        host_status[0] = st[GSR_PS_CONV]; host_status[1] = st[GSR_PS_LOSS]; host_status[2] = st[GSR_PS_TAUN];
+    if (tid == 0 && host_status != nullptr) {
+        const float* cur = run ? s_st : st;
+        host_status[0] = cur[GSR_PS_CONV]; host_status[1] = cur[GSR_PS_LOSS]; host_status[2] = cur[GSR_PS_TAUN];
         host_status[3] = __uint_as_float(guard.poison ? *guard.poison : 0u);
         __threadfence_system();
         reinterpret_cast<volatile int*>(host_status)[4] = seq;
     }
 }
-
 
 // K10  near-plane visibility (replaces rasterizer_impl.cu:54-66 checkFrustum)
 __global__ void __launch_bounds__(GSR_BLOCK) k_mark_visible(int P, const float* means, const float* view, uint8_t* present)
