@@ -160,3 +160,26 @@ def test_headline_scene_counts_and_image():
     _check_forward(o, f, True)
     o2, _ = U.hip_run(sc, cam, pose=True)
     assert np.array_equal(o["color"], o2["color"]) and np.array_equal(o["depth"], o2["depth"])
+
+
+def test_headline_scene_backward_is_linear_in_the_incoming_gradients():
+    """Full BASELINE size, size-independent property of the backward pass: every output gradient (all Gaussian
+    parameters and dL/dtau) is linear in (dL/dcolor, dL/ddepth, dL/dalpha):  B(2 g1 - 3 g2) = 2 B(g1) - 3 B(g2),
+    up to the fp32 reordering of the atomically accumulated sums."""
+    sc = S.s_1m_640()
+    cam = U.scene_inputs(sc)
+    rng = np.random.default_rng(11)
+    shp = [(3, sc.H, sc.W), (1, sc.H, sc.W), (1, sc.H, sc.W)]
+    g1 = [rng.normal(size=s).astype(np.float32) for s in shp]
+    g2 = [rng.normal(size=s).astype(np.float32) for s in shp]
+    g3 = [2.0 * a - 3.0 * b for a, b in zip(g1, g2)]
+    _, b1 = U.hip_run(sc, cam, grads=g1, pose=True)
+    _, b2 = U.hip_run(sc, cam, grads=g2, pose=True)
+    _, b3 = U.hip_run(sc, cam, grads=g3, pose=True)
+    for k in ("means3D", "means2D", "opacities", "sh", "scales", "rotations", "tau"):
+        want = 2.0 * b1[k].astype(np.float64) - 3.0 * b2[k].astype(np.float64)
+        assert U.rel_l1(b3[k], want) <= 2e-5, k
+    # and zero incoming gradients give exactly zero everywhere (no stale accumulator state between calls)
+    _, b0 = U.hip_run(sc, cam, grads=[np.zeros(s, np.float32) for s in shp], pose=True)
+    for k in ("means3D", "means2D", "opacities", "sh", "scales", "rotations", "tau"):
+        assert not np.any(b0[k]), k
