@@ -463,6 +463,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     const float* zb_prev = (tl_spec.mode == 1) ? im.zb[tl_spec.parity ^ 1] : nullptr;
     float* zb_next = (tl_spec.mode != 0) ? im.zb[tl_spec.parity] : nullptr;
     pa.zb = zb_prev; pa.trunc = zb_prev ? im.trunc : nullptr;
+    pa.zb_mul = tl_spec.mul; pa.zb_add = tl_spec.add;
     pa.zbc = zb_prev ? im.zbc[tl_spec.parity ^ 1] : nullptr; pa.truncc = zb_prev ? im.truncc : nullptr; pa.sbx = im.sbx;
     float* zbc_next = (tl_spec.mode != 0) ? im.zbc[tl_spec.parity] : nullptr;
     // bin-by-tile + in-kernel sort instead of the two global sorts: only with speculative bounds (short lists)
@@ -540,7 +541,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
                     ProfScope ps(K_EMIT, st);
                     hipLaunchKernelGGL(k_emit_sorted<uint32_t>, dim3(pblocks), dim3(GSR_BLOCK), zb_lds, st, P, (const uint32_t*)g.order,
                                        (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
-                                       (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, (const float*)g.depths,
+                                       (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, tl_spec.mul, tl_spec.add, (const float*)g.depths,
                                        (uint32_t*)b.keys_unsorted, b.vals_unsorted);
                 }
                 LAUNCHCHK("k_emit_sorted");
@@ -558,7 +559,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
                     ProfScope ps(K_EMIT, st);
                     hipLaunchKernelGGL(k_emit_sorted<uint16_t>, dim3(pblocks), dim3(GSR_BLOCK), zb_lds, st, P, (const uint32_t*)g.order,
                                        (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
-                                       (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, (const float*)g.depths,
+                                       (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, tl_spec.mul, tl_spec.add, (const float*)g.depths,
                                        (uint16_t*)b.keys_unsorted, b.vals_unsorted);
                 }
                 LAUNCHCHK("k_emit_sorted");
@@ -862,7 +863,14 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     bool dirty_cleared = false;
     const int debug = 0;
     auto par = [&](int it) { return (it + poff) & 1; };      // which of the two bound buffers iteration `it` WRITES
-    if (a->bound_margin_mul > 0.f) { tl_spec.mul = a->bound_margin_mul; tl_spec.add = a->bound_margin_add; }
+    // Margin of the speculative bounds.  Given by the caller: fixed.  Otherwise adaptive: bound = (1 + m) z + m metres
+    // with m between 0.01 and 0.05 -- tightened by a fifth after eight verified iterations in a row, doubled when a
+    // speculation fails (tight bounds mean shorter lists; a failure costs one forward with the global sorts).
+    const bool adaptive_margin = !(a->bound_margin_mul > 0.f);
+    float margin_m = 0.02f;
+    int margin_streak = 0;
+    if (!adaptive_margin) { tl_spec.mul = a->bound_margin_mul; tl_spec.add = a->bound_margin_add; }
+    else { tl_spec.mul = 1.f + margin_m; tl_spec.add = margin_m; }
 
     // One iteration = forward, tracking loss, backward, Adam + update_pose, all enqueued without waiting for the
     // device (the non-speculative forward still reads its instance count back, as the reference does).  Behind
@@ -873,6 +881,10 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     auto enqueue = [&](int it, int mode) -> int {
         slot_mode[it & 1] = mode;
         last_enq = it;
+        if (adaptive_margin) {
+            const float m = (it == 0 && warm_buf >= 0) ? 0.05f : margin_m;      // (bounds recorded for another frame: be generous)
+            tl_spec.mul = 1.f + m; tl_spec.add = m;
+        }
         reinterpret_cast<volatile int*>(h_status + 8 * (it & 1))[4] = 0;      // (nothing in flight writes this slot any more)
         tl_spec.mode = mode;
         tl_spec.parity = par(it);
@@ -931,10 +943,14 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             // back off: a scene whose lists stay long after culling would otherwise pay for both forwards every time
             fail_streak++;
             if (fail_streak >= 2) spec_resume = it + 1 + (1 << (fail_streak < 6 ? fail_streak : 6));
+            if (adaptive_margin) { margin_m = fminf(0.05f, margin_m * 2.f); margin_streak = 0; }
             conv_out = hs[0] != 0.f;
             return 1;       // redone: whatever was enqueued behind it was skipped and must be enqueued again
         }
-        if (slot_mode[it & 1] == 1) fail_streak = 0;
+        if (slot_mode[it & 1] == 1) {
+            fail_streak = 0;
+            if (adaptive_margin && ++margin_streak >= 8) { margin_m = fmaxf(0.01f, margin_m * 0.8f); margin_streak = 0; }
+        }
         conv_out = hs[0] != 0.f;
         return 0;
     };

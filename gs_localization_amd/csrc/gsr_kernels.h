@@ -119,7 +119,8 @@ __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int 
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
     uint32_t* depth_key; uint32_t* order_in;
-    const float* zb; uint32_t* trunc;      // speculative per-tile depth bounds of the native loop (nullable)
+    const float* zb; uint32_t* trunc;      // speculative per-tile depth bounds of the native loop (nullable): the depth each
+    float zb_mul, zb_add;                  // tile had to look at; an instance is kept if z <= zb * zb_mul + zb_add
     const float* zbc; uint32_t* truncc; int sbx;   // the same per 4x4-tile superblock (max of its tiles): quick reject
     // bin-by-tile path (nullable): per-tile append cursors and fixed-capacity bins of (depth bits << 32 | index)
     uint32_t* tile_cursor; unsigned long long* bins;
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     const int tid = threadIdx.x;
     if (a.guard.poisoned()) return;
     if (a.zb != nullptr) {
-        for (int i = tid; i < a.gx * a.gy; i += GSR_BLOCK) s_zb[i] = a.zb[i];
+        for (int i = tid; i < a.gx * a.gy; i += GSR_BLOCK) s_zb[i] = a.zb[i] * a.zb_mul + a.zb_add;
         __syncthreads();
     }
     const int idx = blockIdx.x * GSR_BLOCK + tid;
@@ -254,7 +255,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                         float zc = 0.f;
                         for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
                             for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, a.zbc[sy * a.sbx + sx]);
-                        far_everywhere = pview.z > zc;
+                        far_everywhere = pview.z > zc * a.zb_mul + a.zb_add;
                         if (far_everywhere) dropped = true;
                     }
                     if (!far_everywhere) {
@@ -424,12 +425,12 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t
                                                            const uint32_t* __restrict__ tt_sorted,
                                                            const ushort4* __restrict__ rects, const float2* __restrict__ xy,
                                                            const float4* __restrict__ conic_op, int gx, int gy_tiles,
-                                                           const float* __restrict__ zb, const float* __restrict__ depths,
+                                                           const float* __restrict__ zb, float zb_mul, float zb_add, const float* __restrict__ depths,
                                                            KeyT* __restrict__ keys, uint32_t* __restrict__ vals)
 {
     extern __shared__ float s_zb[];      // per-tile depth bounds (native loop), see k_preprocess
     if (zb != nullptr) {
-        for (int i = threadIdx.x; i < gx * gy_tiles; i += GSR_BLOCK) s_zb[i] = zb[i];
+        for (int i = threadIdx.x; i < gx * gy_tiles; i += GSR_BLOCK) s_zb[i] = zb[i] * zb_mul + zb_add;
         __syncthreads();
     }
     const int run = (threadIdx.x >> 4) * gridDim.x + blockIdx.x;       // which run of 16 consecutive Gaussians
@@ -726,7 +727,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
         __syncthreads();
         if (tid == 0) {
             zm = fmaxf(fmaxf(s_zmax[0], s_zmax[1]), fmaxf(s_zmax[2], s_zmax[3]));
-            const float bound = unfinished ? __builtin_huge_valf() : zm * margin_mul + margin_add;
+            const float bound = unfinished ? __builtin_huge_valf() : zm;      // (the margin is applied where the bound is used)
             zb_next[tile] = bound;
             const int sb = (ty >> 2) * sbx + (tx >> 2);
             atomicMax(reinterpret_cast<int*>(zbc_next) + sb, __float_as_int(bound));     // bounds are >= 0: int order = float order

@@ -349,7 +349,7 @@ class FusedRefiner:
         self._warm = C.c_int(0)          # gsr_refine_args.warm_state of this refiner's image workspace
 
     def refine(self, viewpoint, config, initial_R, initial_T, background, iters=50, lr=0.001, converged_threshold=1e-4,
-               stop_on_converged=True, speculative=True, bound_margin=(1.05, 0.05), warm_start=False):
+               stop_on_converged=True, speculative=True, bound_margin=None, warm_start=False):
         C, _lib = self._C, self._lib_mod
         dev = self.dev
         # speculative=True: exact optimisation (include/gsr.h, gsr_refine_args.speculative): ~9x fewer binned
@@ -401,7 +401,8 @@ class FusedRefiner:
         a.lr, a.converged_threshold, a.max_iters = float(lr), float(converged_threshold), int(iters)
         a.stop_on_converged = int(bool(stop_on_converged))
         a.speculative = int(bool(speculative))
-        a.bound_margin_mul, a.bound_margin_add = float(bound_margin[0]), float(bound_margin[1])
+        # bound_margin=None: adaptive margin of the speculative depth bounds (include/gsr.h); (mul, add) fixes it
+        a.bound_margin_mul, a.bound_margin_add = (0.0, 0.0) if bound_margin is None else (float(bound_margin[0]), float(bound_margin[1]))
         stats = (C.c_int * 2)()
         a.stats_out = stats
         a.stream = stream

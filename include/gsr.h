@@ -213,7 +213,7 @@ typedef struct gsr_refine_args {
     /* Speculative binning (exact: verified on the device, a failed speculation is redone with full lists):
      * from the 2nd iteration on, tile instances deeper than bound_margin_mul * z + bound_margin_add, z = the
      * depth the tile had to look at in the previous iteration, are not binned.  0 disables. */
-    int speculative; float bound_margin_mul, bound_margin_add;     /* margins <= 0: defaults 1.05, 0.05 */
+    int speculative; float bound_margin_mul, bound_margin_add;     /* mul <= 0: adaptive, (1+m) z + m with m in [0.01, 0.05] */
     int* stats_out;             /* nullable host int[2]: number of redone forwards, last num_rendered */
     /* Nullable HOST int, in/out: warm start of the speculation for frame sequences.  0 on input = the image workspace
      * holds no depth bounds (the first iteration bins with the global sorts).  Pass the value the previous call on the
