@@ -776,8 +776,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     hipStream_t st = (hipStream_t)a->stream;
     int rc = select_device_of(a->pose_state);
     if (rc != GSR_OK) return rc;
-    // Pinned status slots (one per iteration parity): {converged, loss, |tau|, poison} copied out behind each
-    // iteration, and the events that say when a slot is valid.
+    // Pinned status slots (one per iteration parity): {converged, loss, |tau|, poison, sequence number}, written by the
+    // pose-step kernel of each iteration.
     struct CtxLease {
         LoopCtx* c;
         CtxLease() : c(loop_ctx_acquire()) {}
@@ -859,7 +859,6 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (warm_buf != 1) HIPCHK(hipMemsetAsync(im0.zbc[1], 0, (size_t)im0.nsb * sizeof(float), st));
         HIPCHK(hipMemsetAsync(a->loss_out, 0, 4 * sizeof(float), st));
     }
-    static_assert(GSR_PS_POISON == GSR_PS_CONV + 3, "status words are copied out as one block");
     bool dirty_cleared = false;
     const int debug = 0;
     auto par = [&](int it) { return (it + poff) & 1; };      // which of the two bound buffers iteration `it` WRITES
@@ -872,9 +871,9 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     if (!adaptive_margin) { tl_spec.mul = a->bound_margin_mul; tl_spec.add = a->bound_margin_add; }
     else { tl_spec.mul = 1.f + margin_m; tl_spec.add = margin_m; }
 
-    // One iteration = forward, tracking loss, backward, Adam + update_pose, all enqueued without waiting for the
-    // device (the non-speculative forward still reads its instance count back, as the reference does).  Behind
-    // it, the status words are copied to the slot of the iteration's parity.
+    // One iteration = forward (with the tracking loss in its compositing epilogue), backward, Adam + update_pose, all
+    // enqueued without waiting for the device (the non-speculative forward still reads its instance count back, as
+    // the reference does).  The pose step publishes the status words to the slot of the iteration's parity.
     Img imv_loop{};                // the image workspace's carving (for the pose step launch)
     int slot_mode[2] = {0, 0};
     int last_enq = -1;            // last iteration whose forward was enqueued: its bounds are the newest
@@ -888,7 +887,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         reinterpret_cast<volatile int*>(h_status + 8 * (it & 1))[4] = 0;      // (nothing in flight writes this slot any more)
         tl_spec.mode = mode;
         tl_spec.parity = par(it);
-        {   // the loss kernel of this iteration clears the dropped-here flags and the bounds buffer iteration it+1 writes
+        {   // the pose step of this iteration clears the dropped-here flags and the bounds buffer iteration it+1 writes
             Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
             tl_clear.a = (mode != 0) ? imv.truncc : nullptr;
             tl_clear.b = imv.zbc[par(it) ^ 1];
