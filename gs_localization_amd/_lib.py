@@ -14,6 +14,9 @@ _vp, _i, _f = C.c_void_p, C.c_int, C.c_float
 SIGNATURES = {
     "gsr_forward": (_i, [RESIZE_FN, _vp, RESIZE_FN, _vp, RESIZE_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp,
                          _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "gsr_spec_state_bytes": (C.c_size_t, [_i, _i]),
+    "gsr_forward_speculative": (_i, [_vp, RESIZE_FN, _vp, RESIZE_FN, _vp, RESIZE_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
+                                     _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "gsr_backward": (_i, [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp,
                           _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "gsr_mark_visible": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
@@ -37,6 +40,12 @@ SIGNATURES = {
     "gsr_abi_version": (_i, []),
     "gsr_device_ok": (_i, []),
 }
+
+class SpecState(C.Structure):
+    """mirror of `gsr_spec_state` (include/gsr.h)"""
+    _fields_ = [("device_buffer", _vp), ("width", _i), ("height", _i), ("valid", _i), ("parity", _i), ("fail_streak", _i),
+                ("skip", _i), ("last_speculative", _i), ("n_speculative", _i), ("n_failed", _i)]
+
 
 class RefineArgs(C.Structure):
     """mirror of `gsr_refine_args` (include/gsr.h)"""

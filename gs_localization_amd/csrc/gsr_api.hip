@@ -227,8 +227,29 @@ int bits_for(uint32_t n)
 thread_local bool tl_native_loop = false;
 // Speculative per-tile depth bounds (native loop only): mode 0 = off, 1 = bin with the bounds the previous
 // iteration recorded and record new ones, 2 = bin everything but record bounds.  parity picks the buffer.
-struct SpecCtx { int mode = 0; int parity = 0; float mul = 1.05f, add = 0.05f; bool local_sort = true; };
+struct SpecCtx { int mode = 0; int parity = 0; float mul = 1.05f, add = 0.05f; bool local_sort = true; char* state = nullptr; };
 thread_local SpecCtx tl_spec;
+// gsr_forward_speculative: bounds, flags, cursors and the unsorted bins live in the caller's persistent state buffer
+// instead of the per-call image / binning buffers (which then only hold what the backward reads)
+size_t carve_spec(char* base, int W, int H, Img& im, unsigned long long** bins)
+{
+    Carver c(base);
+    const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
+    im.zb[0] = c.take<float>((size_t)gx * gy);
+    im.zb[1] = c.take<float>((size_t)gx * gy);
+    im.sbx = (gx + 3) / 4;
+    im.nsb = im.sbx * ((gy + 3) / 4);
+    im.zbc[0] = c.take<float>((size_t)im.nsb);
+    im.zbc[1] = c.take<float>((size_t)im.nsb);
+    im.clear_words = (size_t)gx * gy + im.nsb + 16 + (size_t)gx * gy * GSR_CURSOR_STRIDE;
+    im.trunc = c.take<uint32_t>(im.clear_words);
+    im.truncc = base ? im.trunc + (size_t)gx * gy : nullptr;
+    im.fail = base ? im.truncc + im.nsb : nullptr;
+    im.tile_cursor = base ? im.trunc + (((size_t)gx * gy + im.nsb + 1 + 15) & ~(size_t)15) : nullptr;
+    unsigned long long* b = c.take<unsigned long long>((size_t)gx * gy * GSR_LSORT_CAP);
+    if (bins) *bins = b;
+    return c.size();
+}
 // device-side guards of the native loop (see LoopGuard); {nullptr, nullptr} outside gsr_refine
 thread_local gsr::LoopGuard tl_guard = {nullptr, nullptr};
 // set by gsr_refine per iteration: what the loss kernel clears for the next iteration (see LossArgs)
@@ -447,6 +468,8 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     char* iptr = (char*)image_buffer(image_ctx, ibytes);
     if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
     carve_img(iptr, width, height, im);
+    unsigned long long* state_bins = nullptr;
+    if (tl_spec.state) carve_spec(tl_spec.state, width, height, im, &state_bins);
 
     const int pblocks = (P + GSR_BLOCK - 1) / GSR_BLOCK;
     PreArgs pa;
@@ -470,10 +493,12 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     const bool local_path = zb_prev != nullptr && tl_spec.local_sort && ntiles <= 65536;
     BinLocal bl{nullptr, nullptr};
     if (local_path) {
-        const size_t lbytes = carve_bin_local(nullptr, ntiles, bl);
+        // (with a state buffer the unsorted bins live there and the per-call buffer only holds the sorted lists)
+        const size_t lbytes = state_bins ? (size_t)ntiles * GSR_LSORT_CAP * sizeof(uint32_t) : carve_bin_local(nullptr, ntiles, bl);
         char* lptr = (char*)binning_buffer(binning_ctx, lbytes);
         if (!lptr) return fail(GSR_E_ALLOC, "binning buffer callback returned NULL%s", "");
-        carve_bin_local(lptr, ntiles, bl);
+        if (state_bins) { bl.vals = reinterpret_cast<uint32_t*>(lptr); bl.bins = state_bins; }
+        else carve_bin_local(lptr, ntiles, bl);
     }
     pa.tile_cursor = local_path ? im.tile_cursor : nullptr;
     pa.bins = bl.bins;
@@ -594,6 +619,61 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     delete psr;
     LAUNCHCHK("k_render_fwd");
     return R;
+}
+
+size_t gsr_spec_state_bytes(int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    Img im; return carve_spec(nullptr, width, height, im, nullptr);
+}
+
+int gsr_forward_speculative(gsr_spec_state* s, gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn binning_buffer,
+                            void* binning_ctx, gsr_resize_fn image_buffer, void* image_ctx, int P, int D, int M,
+                            const float* background, int width, int height, const float* means3D, const float* shs,
+                            const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
+                            const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
+                            const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
+                            float* out_depth, float* out_alpha, int* radii, int debug, int* n_touched, void* stream)
+{
+    using namespace gsr;
+#define GSR_FWD_PASS geometry_buffer, geometry_ctx, binning_buffer, binning_ctx, image_buffer, image_ctx, P, D, M, background, width, \
+                     height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, \
+                     projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii, debug, n_touched, stream
+    if (tl_native_loop) return fail(GSR_E_INVALID, "gsr_forward_speculative: not callable from inside gsr_refine%s", "");
+    if (!s || !s->device_buffer || P <= 0 || width <= 0 || height <= 0) {
+        if (s) { s->valid = 0; s->last_speculative = 0; }
+        return gsr_forward(GSR_FWD_PASS);
+    }
+    if (s->width == 0 && s->height == 0) { s->width = width; s->height = height; }
+    if (s->width != width || s->height != height)
+        return fail(GSR_E_INVALID, "gsr_forward_speculative: the state was sized for another image size%s", "");
+    hipStream_t st = (hipStream_t)stream;
+    struct Reset { ~Reset() { tl_spec = SpecCtx{}; } } reset;
+    tl_spec = SpecCtx{};
+    tl_spec.state = static_cast<char*>(s->device_buffer);
+    s->last_speculative = 0;
+    const int next = (s->parity ^ 1) & 1;          // the bound buffer this forward writes
+    if (s->valid && s->skip == 0) {
+        tl_spec.mode = 1; tl_spec.parity = next;
+        const int R = gsr_forward(GSR_FWD_PASS);
+        if (R < 0) { s->valid = 0; return R; }
+        Img im; carve_spec(tl_spec.state, width, height, im, nullptr);
+        uint32_t failed = 0;      // the one blocking read of this forward
+        HIPCHK(hipMemcpyAsync(&failed, im.fail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (failed == 0u) {
+            s->parity = next; s->fail_streak = 0; s->n_speculative++; s->last_speculative = 1;
+            return R;
+        }
+        s->n_failed++; s->fail_streak++;
+        if (s->fail_streak >= 2) s->skip = 1 << (s->fail_streak < 7 ? s->fail_streak - 1 : 6);      // 2, 4, ... 64
+    } else if (s->skip > 0) s->skip--;
+    tl_spec.mode = 2; tl_spec.parity = next;         // complete lists through the global sorts; records the bounds
+    const int R = gsr_forward(GSR_FWD_PASS);
+    if (R < 0) { s->valid = 0; return R; }
+    s->parity = next; s->valid = 1;
+    return R;
+#undef GSR_FWD_PASS
 }
 
 int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,

@@ -14,6 +14,8 @@ the HIP kernels behind gsr_forward / gsr_backward.  There is no CPU path.
 """
 from typing import NamedTuple
 import ctypes as C
+import os
+import threading
 
 import torch
 import torch.nn as nn
@@ -90,6 +92,46 @@ class _Workspace:
             return 0
 
 
+class _SpecCache(threading.local):
+    """Per thread: the `gsr_spec_state` of each (device, stream, image size) the drop-in packages have rendered -- what lets
+    the fifty render() calls of a refinement (7scenes_localize_full_dslam.py:66-91) skip the global sorts.  Purely a
+    matter of speed: every speculative forward is verified on the device and redone if it missed (include/gsr.h)."""
+    MAX = 4
+
+    def __init__(self):
+        self.states = {}      # key -> (SpecState, device tensor); insertion order = age
+
+    def get(self, lib, dev, stream, W, H):
+        key = (dev.index, stream, W, H)
+        hit = self.states.pop(key, None)
+        if hit is None:
+            if len(self.states) >= self.MAX:
+                self.states.pop(next(iter(self.states)))
+            buf = torch.empty(int(lib.gsr_spec_state_bytes(W, H)), dtype=torch.uint8, device=dev)
+            st = _lib.SpecState()
+            st.device_buffer = buf.data_ptr()
+            hit = (st, buf)
+        self.states[key] = hit
+        return hit[0]
+
+
+_spec_cache = _SpecCache()
+
+
+def speculation_enabled():
+    """GSR_SPECULATION=0 makes the drop-in packages call the plain gsr_forward every time."""
+    return os.environ.get("GSR_SPECULATION", "1") != "0"
+
+
+def speculation_counters(device=None):
+    """(verified, missed) speculative forwards of this thread's states -- for tests and tools."""
+    v = m = 0
+    for (di, _, _, _), (st, _) in _spec_cache.states.items():
+        if device is None or torch.device(device).index in (None, di):
+            v += st.n_speculative; m += st.n_failed
+    return v, m
+
+
 def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, want_touched):
     lib = _lib.load()
     _require_gpu(means3D)
@@ -109,13 +151,14 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     M = sh.size(1) if sh.numel() != 0 else 0
     geom, binning, img = _Workspace(dev), _Workspace(dev), _Workspace(dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
+    spec = C.byref(_spec_cache.get(lib, dev, stream, W, H)) if (P > 0 and speculation_enabled()) else None
     with torch.cuda.device(dev):
-        rc = lib.gsr_forward(geom.fn, None, binning.fn, None, img.fn, None, P, int(rs.sh_degree), M, _ptr(bg), W, H,
-                             _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
-                             float(rs.scale_modifier), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(view), _ptr(proj),
-                             _ptr(campos), float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)),
-                             color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), _ptr(radii), int(bool(rs.debug)),
-                             _ptr(n_touched), stream)
+        rc = lib.gsr_forward_speculative(spec, geom.fn, None, binning.fn, None, img.fn, None, P, int(rs.sh_degree), M, _ptr(bg),
+                                         W, H, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
+                                         float(rs.scale_modifier), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(view),
+                                         _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
+                                         int(bool(rs.prefiltered)), color.data_ptr(), depth.data_ptr(), alpha.data_ptr(),
+                                         _ptr(radii), int(bool(rs.debug)), _ptr(n_touched), stream)
     num_rendered = _lib.check(rc)
     saved = (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom.t, binning.t, img.t, alpha,
              opacities)

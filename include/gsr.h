@@ -83,6 +83,42 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx,
                 int* n_touched,
                 void* stream);
 
+/* gsr_forward for callers that render a sequence of nearby views through the stateless boundary (the reference's
+ * own loops: 7scenes_localize_full_dslam.py:66-91 calls render() fifty times per frame, a few millimetres apart).
+ * `state` carries, from one call to the next, how deep every 16x16 tile had to look before all its pixels had
+ * terminated.  The next call bins only what lies in front of those depths (x1.05 + 5 cm) -- per tile, without the
+ * two global sorts -- and the compositing kernel VERIFIES the guess: a tile that reaches the end of a shortened
+ * list with an unsaturated pixel raises a flag, and the forward is redone with complete lists before this function
+ * returns.  Outputs are therefore always those of gsr_forward (same lists up to each pixel's termination, same
+ * summation order); a wrong guess (a new frame, another map) only costs time, and after repeated misses the guess
+ * is tried less often (2, 4, ... 64 calls apart).  One blocking device->host read per forward, as gsr_forward.
+ * The saved buffers feed gsr_backward unchanged; the return value is what gsr_backward expects as R (0 when the
+ * lists were binned by tile: the backward then finds them through the image buffer).
+ *   state->device_buffer: gsr_spec_state_bytes(width, height) bytes on the GPU, owned by the caller, contents opaque,
+ *   need not be initialised; all other fields zero before the first call.  One state per (thread, stream, image size).
+ *   state == NULL or device_buffer == NULL: plain gsr_forward. */
+typedef struct gsr_spec_state {
+    void* device_buffer;
+    int width, height;          /* set by the first call; later calls must match */
+    int valid;                  /* bounds of a previous call are recorded (write 0 to drop them) */
+    int parity;                 /* which of the two bound buffers is current */
+    int fail_streak, skip;      /* back-off after misses */
+    int last_speculative;       /* out: 1 if the last forward was composed from speculative bins */
+    int n_speculative, n_failed;/* counters: verified / missed guesses */
+} gsr_spec_state;
+size_t gsr_spec_state_bytes(int width, int height);
+int gsr_forward_speculative(gsr_spec_state* state,
+                            gsr_resize_fn geometry_buffer, void* geometry_ctx,
+                            gsr_resize_fn binning_buffer, void* binning_ctx,
+                            gsr_resize_fn image_buffer, void* image_ctx,
+                            int P, int D, int M, const float* background, int width, int height,
+                            const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
+                            const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
+                            const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                            float tan_fovx, float tan_fovy, int prefiltered,
+                            float* out_color, float* out_depth, float* out_alpha, int* radii, int debug,
+                            int* n_touched, void* stream);
+
 /* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:62-89, rasterizer_impl.cu:343-444).
  *   R = value returned by gsr_forward; geom/binning/img buffers = the ones it filled.
  *   dL_dpix [3,H,W], dL_ddepths [1,H,W], dL_dalphas [1,H,W].

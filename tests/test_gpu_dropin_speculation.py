@@ -1,0 +1,128 @@
+"""-m gpu : the drop-in packages call gsr_forward_speculative (include/gsr.h): a render that follows a nearby render
+reuses that one's per-tile depth bounds and skips the global sorts.  The speculation is verified on the device, so the
+outputs must be those of the plain forward -- bit for bit for the images, radii and n_touched (same lists up to each
+pixel's termination, same summation order), to summation-order noise for the gradients -- whether the guess holds
+(nearby pose), misses (far pose, other scene) or is switched off."""
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gs_localization_amd import scenes as S, rasterizer as RZ
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def _w2c(tau):
+    return S.se3_exp(np.asarray(tau, np.float64))
+
+
+def _run(sc, w2c, pose, spec, grads):
+    old = os.environ.get("GSR_SPECULATION")
+    os.environ["GSR_SPECULATION"] = "1" if spec else "0"
+    try:
+        return U.hip_run(sc, U.scene_inputs(sc, w2c), grads, pose=pose)
+    finally:
+        if old is None:
+            del os.environ["GSR_SPECULATION"]
+        else:
+            os.environ["GSR_SPECULATION"] = old
+
+
+def _same(a, b, pose):
+    for k in ("color", "depth", "alpha", "radii"):
+        assert np.array_equal(a[k], b[k]), k
+    if pose:
+        assert np.array_equal(a["n_touched"], b["n_touched"])
+
+
+def _close_grads(ga, gb, pose):
+    for k in ("means3D", "means2D", "opacities", "sh", "scales", "rotations"):
+        assert U.rel_l1(ga[k], gb[k]) <= 2e-6, k
+    if pose:
+        assert U.rel_l1(ga["tau"], gb["tau"]) <= 2e-6
+
+
+@pytest.mark.parametrize("pose", [False, True])
+def test_nearby_render_is_speculative_and_identical(pose):
+    sc = S.small(P=30000, W=160, H=128, sh_degree=3, seed=21, scale_med=0.04)
+    grads = U.random_grads(sc, seed=3)
+    RZ._spec_cache.states.clear()
+    first = _w2c([0, 0, 0, 0, 0, 0])
+    near = _w2c([0.004, -0.003, 0.002, 0.002, -0.001, 0.0015])
+    _run(sc, first, pose, True, grads)                       # no bounds yet: complete lists, records the bounds
+    assert RZ.speculation_counters() == (0, 0)
+    o_s, g_s = _run(sc, near, pose, True, grads)             # guess from the first render
+    assert RZ.speculation_counters() == (1, 0)
+    o_p, g_p = _run(sc, near, pose, False, grads)            # plain gsr_forward
+    _same(o_s, o_p, pose)
+    _close_grads(g_s, g_p, pose)
+    o_s2, _ = _run(sc, near, pose, True, grads)              # and again, now from the bounds a speculative render recorded
+    assert RZ.speculation_counters() == (2, 0)
+    _same(o_s2, o_p, pose)
+
+
+def test_missed_guess_is_redone_and_backs_off():
+    sc = S.small(P=30000, W=160, H=128, sh_degree=2, seed=22, scale_med=0.04)
+    other = S.small(P=30000, W=160, H=128, sh_degree=2, seed=23, scale_med=0.04)       # same image size, other map,
+    other.means3D *= np.float32(1.5); other.scales *= np.float32(1.5)                   # 1.5x further away: the bounds are useless
+    grads = U.random_grads(sc, seed=4)
+    RZ._spec_cache.states.clear()
+    _run(sc, _w2c([0] * 6), True, True, grads)
+    o_s, g_s = _run(other, _w2c([0] * 6), True, True, grads)
+    v, m = RZ.speculation_counters()
+    assert (v, m) == (0, 1)
+    o_p, g_p = _run(other, _w2c([0] * 6), True, False, grads)
+    _same(o_s, o_p, True)
+    _close_grads(g_s, g_p, True)
+    # ever deeper maps (scaled about the camera): every guess misses; after two misses in a row the guess is tried less and less often
+    import copy
+    for i in range(12):
+        deeper = copy.deepcopy(other)
+        deeper.means3D *= np.float32(1.2 ** (i + 1))          # the same picture, everything 1.2x further away each time
+        deeper.scales *= np.float32(1.2 ** (i + 1))
+        _run(deeper, _w2c([0] * 6), True, True, None)
+    v, m = RZ.speculation_counters()
+    assert v == 0 and 3 <= m <= 5, (v, m)
+    other = deeper
+    # a nearby render still succeeds as soon as it is tried again
+    for _ in range(10):
+        o, _ = _run(other, _w2c([0.002, 0, 0, 0, 0.001, 0]), True, True, None)
+    assert RZ.speculation_counters()[0] >= 1
+    o_p, _ = _run(other, _w2c([0.002, 0, 0, 0, 0.001, 0]), True, False, None)
+    _same(o, o_p, True)
+
+
+def test_python_loop_uses_the_speculation_and_matches_the_plain_loop():
+    """The reference-style loop on the drop-in package: same poses with and without the speculation."""
+    from gs_localization_amd import pipelines as PL
+    sc = S.small(P=30000, W=160, H=128, sh_degree=3, seed=11, scale_med=0.04)
+    dev = torch.device("cuda:0")
+    model = PL.GaussianMap.from_scene(sc, device=dev)
+    bg = torch.zeros(3, device=dev)
+    proj = PL.getProjectionMatrix2(0.01, 100.0, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, W=sc.W, H=sc.H).transpose(0, 1).to(dev)
+
+    def view():
+        vp = PL.Camera(0, None, None, torch.eye(4, device=dev), proj, sc.fx, sc.fy, sc.cx, sc.cy, PL.focal2fov(sc.fx, sc.W),
+                       PL.focal2fov(sc.fy, sc.H), sc.H, sc.W, device=dev)
+        return vp
+    vp0 = view()
+    with torch.no_grad():
+        pkg = PL.render(vp0, model, PL.PipelineParams(), bg)
+    init = torch.tensor(S.se3_exp(np.array([0.01, -0.008, 0.006, 0.004, -0.003, 0.005])), dtype=torch.float32, device=dev)
+    res = {}
+    for spec in (False, True):
+        os.environ["GSR_SPECULATION"] = "1" if spec else "0"
+        RZ._spec_cache.states.clear()
+        vp = view()
+        vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone()
+        vp.grad_mask = torch.ones((1, sc.H, sc.W), dtype=torch.bool, device=dev)
+        R, T, _ = PL.gradient_decent(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), model, PL.PipelineParams(), bg, iters=12)
+        res[spec] = (R.detach().clone(), T.detach().clone(), RZ.speculation_counters())
+    os.environ.pop("GSR_SPECULATION", None)
+    assert res[False][2] == (0, 0)
+    assert res[True][2][0] >= 10 and res[True][2][1] == 0
+    assert torch.allclose(res[True][0], res[False][0], atol=2e-6) and torch.allclose(res[True][1], res[False][1], atol=2e-6)

@@ -2,11 +2,13 @@
 activations -> diff_gaussian_rasterization forward -> L1 + SSIM + Pearson depth loss -> backward with gradients
 for every Gaussian parameter -> densification statistics -> Adam on the six parameter groups.
 Scene: S-train-garden-like: SH degree 1, white background, P = 0.2 M ... 1.5 M, grad_depth != 0.
+Like train.py:71-75 every step renders another, randomly picked training camera (16 views, up to 0.4 m / 12 deg apart), so
+the drop-in's depth speculation (gsr_forward_speculative) mostly misses and backs off; the counters are printed.
 Prints ms per step and where it goes (rasterizer forward / loss / backward / optimizer)."""
 import sys, os, time, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gs_localization_amd import scenes as S, train_epilogue as TE
+from gs_localization_amd import scenes as S, train_epilogue as TE, rasterizer as RZ
 from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
 
 dev = torch.device("cuda:0")
@@ -16,16 +18,21 @@ FX = 0.9 * W
 
 def build(P):
     sc = S._draw("S-train-garden", P, W, H, FX, FX, 0.5, 6.0, 0.012, 0.6, 1, 0)
-    view, proj, _, campos = S.camera_matrices(sc)
     t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=dev)
+    rng = np.random.default_rng(5)
+    rasts = []
+    for v in range(16):
+        tau = np.concatenate([rng.uniform(-0.4, 0.4, 3), np.radians(rng.uniform(-12, 12, 3))]) if v else np.zeros(6)
+        view, proj, _, campos = S.camera_matrices(sc, S.se3_exp(tau))
+        rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=sc.tanfovx, tanfovy=sc.tanfovy,
+                                           bg=torch.ones(3, device=dev), scale_modifier=1.0, viewmatrix=t(view), projmatrix=t(proj),
+                                           sh_degree=1, campos=t(campos), prefiltered=False, debug=False)
+        rasts.append(GaussianRasterizer(rs))
     par = dict(xyz=t(sc.means3D), f_dc=t(sc.shs[:, :1]), f_rest=t(sc.shs[:, 1:]),
                scaling=torch.log(t(sc.scales)), rotation=t(sc.rotations), opacity=torch.logit(t(sc.opacities).clamp(1e-4, 1 - 1e-4)))
     for v in par.values():
         v.requires_grad_(True)
-    rs = GaussianRasterizationSettings(image_height=H, image_width=W, tanfovx=sc.tanfovx, tanfovy=sc.tanfovy,
-                                       bg=torch.ones(3, device=dev), scale_modifier=1.0, viewmatrix=t(view), projmatrix=t(proj),
-                                       sh_degree=1, campos=t(campos), prefiltered=False, debug=False)
-    return sc, par, GaussianRasterizer(rs)
+    return sc, par, rasts
 
 
 def render(par, rast):
@@ -41,11 +48,14 @@ def render(par, rast):
 
 def main():
     for P in (200_000, 800_000, 1_500_000):
-        sc, par, rast = build(P)
+        sc, par, rasts = build(P)
+        gts = []
         with torch.no_grad():
-            gt, _, d0, _ = render(par, rast)
-            gt = (gt + 0.03 * torch.randn_like(gt)).clamp(0, 1)
-            pseudo = 100.0 / (d0[0] + 0.5) + torch.randn_like(d0[0])
+            for rast in rasts:
+                gt, _, d0, _ = render(par, rast)
+                gts.append(((gt + 0.03 * torch.randn_like(gt)).clamp(0, 1), 100.0 / (d0[0] + 0.5) + torch.randn_like(d0[0])))
+        pick = np.random.default_rng(9)
+        RZ._spec_cache.states.clear()
         opt = torch.optim.Adam([{"params": [v], "lr": lr} for v, lr in zip(par.values(), (1.6e-4, 2.5e-3, 1.25e-4, 5e-3, 1e-3, 5e-2))], eps=1e-15)
         max_radii = torch.zeros(P, device=dev); accum = torch.zeros(P, 1, device=dev); denom = torch.zeros(P, 1, device=dev)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
@@ -54,7 +64,9 @@ def main():
         def step(timed):
             nonlocal n
             if timed: ev[0].record()
-            img, radii, depth, ss = render(par, rast)
+            v = int(pick.integers(len(rasts)))
+            gt, pseudo = gts[v]
+            img, radii, depth, ss = render(par, rasts[v])
             if timed: ev[1].record()
             loss = TE.training_loss(img, gt, 0.2, depth[0], pseudo, 0.1)
             if timed: ev[2].record()
@@ -77,8 +89,9 @@ def main():
         for _ in range(10): step(True)
         a = acc / n
         print(f"train step {W}x{H} P={P:8d} SH1: {el * 1e3:6.2f} ms/step ({1 / el:6.1f} it/s); rasterizer fwd (+activations) {a[0]:.2f} ms, "
-              f"loss epilogue {a[1]:.2f} ms, backward {a[2]:.2f} ms, densification stats + Adam {a[3]:.2f} ms; loss {float(l.detach()):.4f}", flush=True)
-        del par, rast, opt
+              f"loss epilogue {a[1]:.2f} ms, backward {a[2]:.2f} ms, densification stats + Adam {a[3]:.2f} ms; loss {float(l.detach()):.4f}; "
+              f"speculative forwards verified/missed {RZ.speculation_counters()}", flush=True)
+        del par, rasts, opt, gts
         torch.cuda.empty_cache()
 
 
