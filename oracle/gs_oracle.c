@@ -494,6 +494,17 @@ static inline void atomic_addf(float* p, float v)
 #pragma omp atomic
     *p += v;
 }
+/* Checker option (not reference behaviour): accumulate the per-Gaussian sums of the compositing backward in double
+ * shadow arrays and round once.  The reference adds fp32 atomics in arbitrary order (cr/backward.cu:556-574); for a
+ * splat that covers 1e5 pixels that order noise alone reaches 1e-4 relative, which is what a parity test would then
+ * measure.  Off by default. */
+static int g_acc64 = 0;
+void gso_set_accumulate_double(int on) { g_acc64 = on ? 1 : 0; }
+static inline void atomic_addd(double* p, double v)
+{
+#pragma omp atomic
+    *p += v;
+}
 
 /* cr/auxiliary.h:101-112 */
 static vec3 dnormvdv3(vec3 v, vec3 dv)
@@ -629,6 +640,10 @@ void gso_backward(const gso_state* s, int D, int M, const float* background, con
     const float* colors = colors_precomp != NULL ? colors_precomp : s->rgb;
     float* dL_dz = NULL;
     if (pose_mode) dL_dz = (float*)calloc(P > 0 ? (size_t)P : 1, sizeof(float));
+    /* double shadows (gso_set_accumulate_double): colour 3, mean2D 2, conic 3, opacity 1, z 1 = 10 per Gaussian */
+    double* sh64 = g_acc64 ? (double*)calloc((P > 0 ? (size_t)P : 1) * 10, sizeof(double)) : NULL;
+#define ACC(farr, fidx, slot, val) do { if (sh64) atomic_addd(&sh64[(size_t)id * 10 + (slot)], (double)(val)); \
+                                        else atomic_addf(&(farr)[fidx], (val)); } while (0)
 
     /* ---- K7 render backward, cr/backward.cu:399-581 ---- */
     const float ddelx_dx = (float)(0.5 * W);
@@ -673,13 +688,13 @@ void gso_backward(const gso_state* s, int D, int M, const float* background, con
                         last_color[ch] = c;
                         const float dL_dchannel = dL_dpixel[ch];
                         dL_dopa += (c - accum_rec[ch]) * dL_dchannel;
-                        atomic_addf(&dL_dcolor[id * 3 + ch], dchannel_dcolor * dL_dchannel);
+                        ACC(dL_dcolor, id * 3 + ch, ch, dchannel_dcolor * dL_dchannel);
                     }
                     const float c_d = s->depths[id];
                     accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
                     last_depth = c_d;
                     dL_dopa += (c_d - accum_depth_rec) * dL_ddepth;
-                    if (pose_mode) atomic_addf(&dL_dz[id], dchannel_dcolor * dL_ddepth);
+                    if (pose_mode) ACC(dL_dz, id, 9, dchannel_dcolor * dL_ddepth);
                     accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
                     dL_dopa += -(alpha - accum_alpha_rec) * dL_dalpha;   /* cr/backward.cu:545-547 quirk */
                     dL_dopa *= T;
@@ -692,14 +707,27 @@ void gso_backward(const gso_state* s, int D, int M, const float* background, con
                     const float gdy = G * dy;
                     const float dG_ddelx = -gdx * co[0] - gdy * co[1];
                     const float dG_ddely = -gdy * co[2] - gdx * co[1];
-                    atomic_addf(&dL_dmean2D[3 * id], dL_dG * dG_ddelx * ddelx_dx);
-                    atomic_addf(&dL_dmean2D[3 * id + 1], dL_dG * dG_ddely * ddely_dy);
-                    atomic_addf(&dL_dconic[4 * id], -0.5f * gdx * dx * dL_dG);
-                    atomic_addf(&dL_dconic[4 * id + 1], -0.5f * gdx * dy * dL_dG);
-                    atomic_addf(&dL_dconic[4 * id + 3], -0.5f * gdy * dy * dL_dG);
-                    atomic_addf(&dL_dopacity[id], G * dL_dopa);
+                    ACC(dL_dmean2D, 3 * id, 3, dL_dG * dG_ddelx * ddelx_dx);
+                    ACC(dL_dmean2D, 3 * id + 1, 4, dL_dG * dG_ddely * ddely_dy);
+                    ACC(dL_dconic, 4 * id, 5, -0.5f * gdx * dx * dL_dG);
+                    ACC(dL_dconic, 4 * id + 1, 6, -0.5f * gdx * dy * dL_dG);
+                    ACC(dL_dconic, 4 * id + 3, 7, -0.5f * gdy * dy * dL_dG);
+                    ACC(dL_dopacity, id, 8, G * dL_dopa);
                 }
             }
+    }
+
+#undef ACC
+    if (sh64) {
+        for (int i = 0; i < P; i++) {
+            const double* q = sh64 + (size_t)i * 10;
+            for (int c = 0; c < 3; c++) dL_dcolor[3 * i + c] += (float)q[c];
+            dL_dmean2D[3 * i] += (float)q[3]; dL_dmean2D[3 * i + 1] += (float)q[4];
+            dL_dconic[4 * i] += (float)q[5]; dL_dconic[4 * i + 1] += (float)q[6]; dL_dconic[4 * i + 3] += (float)q[7];
+            dL_dopacity[i] += (float)q[8];
+            if (pose_mode) dL_dz[i] += (float)q[9];
+        }
+        free(sh64);
     }
 
     /* per-thread tau partials are summed in fp64 then cast (deterministic enough for a checker) */

@@ -45,6 +45,11 @@ def set_threads(n):
     lib().gso_set_threads(int(n))
 
 
+def set_accumulate_double(on):
+    """Checker option: the compositing backward sums its per-Gaussian atomics in double and rounds once (see gs_oracle.c)."""
+    lib().gso_set_accumulate_double(int(bool(on)))
+
+
 class Forward:
     """Result of one oracle forward; owns the opaque state needed by backward()."""
 

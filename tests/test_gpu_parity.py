@@ -183,3 +183,32 @@ def test_headline_scene_backward_is_linear_in_the_incoming_gradients():
     _, b0 = U.hip_run(sc, cam, grads=[np.zeros(s, np.float32) for s in shp], pose=True)
     for k in ("means3D", "means2D", "opacities", "sh", "scales", "rotations", "tau"):
         assert not np.any(b0[k]), k
+
+
+@pytest.mark.parametrize("W,H,P", [(1920, 1080, 4000),       # 8 160 tiles: the bounds of the native loop still fit in LDS
+                                   (4112, 4096, 3000)])      # 65 792 tiles: 32-bit tile keys (rasterizer_impl.cu:35-50 sizes
+def test_large_images(W, H, P):                              # the key by the tile count) and no bin-by-tile path
+    """Maximum sizes: image parity and gradients at full-HD and at more than 65 536 tiles, both packages; the drop-in
+    speculation and the native loop must fall back to paths that can hold that many tiles."""
+    import os
+    from oracle import oracle as O
+    O.set_threads(min(32, os.cpu_count() or 1))
+    sc = S.small(P=P, W=W, H=H, sh_degree=1, seed=31, scale_med=0.03)
+    cam = U.scene_inputs(sc, W2C)
+    grads = U.random_grads(sc, seed=1)
+    # Splats here cover up to 1e5 pixels: the order noise of fp32 atomics (which the oracle reproduces faithfully) would
+    # dominate the comparison, so the oracle sums its per-Gaussian atomics in double for this test.
+    O.set_accumulate_double(True)
+    try:
+        for pose in (False, True):
+            f, go = U.oracle_run(sc, cam, grads, pose=pose)
+            o, g = U.hip_run(sc, cam, grads, pose=pose)
+            _check_forward(o, f, pose)
+            _check_grads(g, go, pose, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
+    finally:
+        O.set_accumulate_double(False)
+    for pose in (False, True):
+        o, _ = U.hip_run(sc, cam, grads, pose=pose)
+        o2, _ = U.hip_run(sc, cam, grads, pose=pose)         # second render: speculative where the size allows it
+        for k in ("color", "depth", "alpha", "radii"):
+            assert np.array_equal(o[k], o2[k]), k
