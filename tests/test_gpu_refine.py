@@ -330,3 +330,19 @@ def test_warm_start_of_the_speculation_is_exact():
     n_cold = fr.last_info["num_rendered"]
     fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=1, stop_on_converged=False, warm_start=True)
     assert fr.last_info["num_rendered"] < 0.6 * n_cold
+
+
+@pytest.mark.parametrize("W,H", [(1920, 1080),       # 8 160 tiles: per-tile bounds staged in LDS, bin-by-tile path
+                                 (2576, 1616)])      # 16 261 tiles: the bounds no longer fit in LDS, the loop keeps the global sorts
+def test_native_loop_on_large_images_matches_python_loop(W, H):
+    from gs_localization_amd import pipelines as PL
+    sc = S.small(P=30000, W=W, H=H, sh_degree=2, seed=8, scale_med=0.03)
+    model, bg, view, init = _setup(sc)
+    cfg = PL.TRACKING_CONFIG
+    vp1, vp2 = view(), view()
+    R1, T1, _ = PL.gradient_decent(vp1, cfg, init[:3, :3].clone(), init[:3, 3].clone(), model, PL.PipelineParams(), bg, iters=6)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    R2, T2, info = fr.refine(vp2, cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=6)
+    assert info["iters"] == 6
+    assert torch.allclose(R1, R2, atol=2e-5), (R1 - R2).abs().max()
+    assert torch.allclose(T1, T2, atol=2e-5), (T1 - T2).abs().max()
