@@ -666,6 +666,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
                 Tfin = kill ? fmaxf(Tfin, T) : Tfin;
                 T = kill ? 0.f : (valid ? test_T : T);
                 last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;      // 1-based position in the tile list
+#if GSR_TIMING
+                if (__ballot(valid && alive0) == 0ull) GSR_T_COUNT(8, 1)      // entry that no live pixel of this wave could use
+#endif
                 if (TOUCHED) {
                     // pose package: count pixels where the splat was blended with T still > 0.5
                     const int c = (int)__popcll(__ballot(valid && test_T > 0.5f));
