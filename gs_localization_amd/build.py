@@ -27,6 +27,9 @@ def build(force=False, verbose=False):
            "-I" + os.path.join(_ROOT, "include"), "-o", OUT, SRC]
     if os.environ.get("GSR_TIMING"):      # diagnostic build: per-phase clocks inside the compositing kernels
         cmd.insert(1, "-DGSR_TIMING=1")
+    if os.environ.get("GSR_DEFS"):        # experiments: extra -D switches, e.g. GSR_DEFS="-DGSR_K8_SPAN=384"
+        for d in os.environ["GSR_DEFS"].split():
+            cmd.insert(1, d)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

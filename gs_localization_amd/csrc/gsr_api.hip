@@ -483,6 +483,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     pa.depth_key = g.depth_key; pa.order_in = g.order_in;
     pa.guard = tl_guard;
     pa.n_touched = n_touched;
+    pa.shc_span = shc_span(P);
     const float* zb_prev = (tl_spec.mode == 1) ? im.zb[tl_spec.parity ^ 1] : nullptr;
     float* zb_next = (tl_spec.mode != 0) ? im.zb[tl_spec.parity] : nullptr;
     pa.zb = zb_prev; pa.trunc = zb_prev ? im.trunc : nullptr;
@@ -522,11 +523,11 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
         if (side) {
             HIPCHK(hipEventRecord(side->fork, st));
             HIPCHK(hipStreamWaitEvent(side->st, side->fork, 0));
-            hipLaunchKernelGGL(k_sh_color, dim3((P + GSR_SHC_SPAN - 1) / GSR_SHC_SPAN), dim3(64), 0, side->st, pa);
+            hipLaunchKernelGGL(k_sh_color, dim3((P + pa.shc_span - 1) / pa.shc_span), dim3(64), 0, side->st, pa);
             HIPCHK(hipEventRecord(side->join, side->st));
         } else {
             ProfScope ps(K_SH_COLOR, st);
-            hipLaunchKernelGGL(k_sh_color, dim3((P + GSR_SHC_SPAN - 1) / GSR_SHC_SPAN), dim3(64), 0, st, pa);
+            hipLaunchKernelGGL(k_sh_color, dim3((P + pa.shc_span - 1) / pa.shc_span), dim3(64), 0, st, pa);
         }
         LAUNCHCHK("k_sh_color");
     }
@@ -765,7 +766,8 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     pb.guard = tl_guard;
     {
         ProfScope ps(K_PREPROCESS_BWD, st);
-        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + GSR_K8_SPAN - 1) / GSR_K8_SPAN), dim3(64), 0, st, pb);
+        pb.span = k8_span(P);
+        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + pb.span - 1) / pb.span), dim3(64), 0, st, pb);
     }
     LAUNCHCHK("k_preprocess_bwd");
     if (pose_mode && !tl_native_loop) {

@@ -132,6 +132,7 @@ struct PreArgs {
     float tanx, tany, fx, fy;
     int* radii; float2* xy; float* depths; float* cov3D; float* rgb; float4* conic_op;
     uint8_t* clamped; uint32_t* tiles_touched; ushort4* rects;
+    int shc_span;            // k_sh_color: Gaussians per wave (shc_span())
 };
 
 __device__ __forceinline__ float3 sh_to_rgb(int deg, int M, float3 pos, const float* campos, const float* sh,
@@ -346,26 +347,38 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 // runs it on a side stream underneath the (latency-bound) sort chain and joins before compositing.
 // Summation order is the reference's; SH rows arrive as one coalesced stream per block (see above).
 #define GSR_SHC_SPAN 256
+#define GSR_SHC_SPAN_MAX 2048
 #define GSR_SHC_ROWS 64
+// Gaussians per wave: like K8 (k8_span) the kernel is a chain of dependent memory phases per wave, so the span is
+// chosen to make every wave resident at once (129 registers, ~18 KB of LDS: 8 waves per CU)
+static inline int shc_span(int P)
+{
+    const int resident = 256 * 8;
+    int span = ((P + resident - 1) / resident + GSR_SHC_SPAN - 1) / GSR_SHC_SPAN * GSR_SHC_SPAN;
+    if (span < GSR_SHC_SPAN) span = GSR_SHC_SPAN;
+    if (span > GSR_SHC_SPAN_MAX) span = GSR_SHC_SPAN_MAX;
+    return span;
+}
 __global__ void __launch_bounds__(64) k_sh_color(PreArgs a)
 {
-    // One wave per GSR_SHC_SPAN Gaussians: the ones that need a colour are compacted first (4 candidates per lane),
-    // then handled on dense lanes with their SH rows staged GSR_SHC_ROWS at a time (~14 KB of LDS per wave).
+    // One wave per a.shc_span Gaussians: the ones that need a colour are compacted first (4 candidates per lane at a
+    // time), then handled on dense lanes with their SH rows staged GSR_SHC_ROWS at a time through LDS.
     __shared__ float4 s_sh[GSR_SHC_ROWS * GSR_SH16_LDS4];
-    __shared__ uint8_t s_list[GSR_SHC_SPAN];
+    __shared__ uint16_t s_list[GSR_SHC_SPAN_MAX];
     const int lane = threadIdx.x;
-    const int base = blockIdx.x * GSR_SHC_SPAN;
+    const int base = blockIdx.x * a.shc_span;
     if (a.guard.poisoned()) return;
     // only splats that were binned into at least one tile can ever be composited (this also skips everything
     // the native loop's speculative depth bounds dropped)
     int nact = 0;
+    for (int q0 = 0; q0 < a.shc_span / 64; q0 += GSR_SHC_SPAN / 64)
 #pragma unroll
-    for (int q = 0; q < GSR_SHC_SPAN / 64; q++) {
-        const int local = q * 64 + lane;
+    for (int qq = 0; qq < GSR_SHC_SPAN / 64; qq++) {
+        const int local = (q0 + qq) * 64 + lane;
         const int idx = base + local;
         const bool need = idx < a.P && a.tiles_touched[idx] > 0;
         const unsigned long long mk = __ballot(need);
-        if (need) s_list[nact + (int)__popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)local;
+        if (need) s_list[nact + (int)__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)local;
         nact += (int)__popcll(mk);
     }
     __syncthreads();
@@ -1056,6 +1069,7 @@ struct PreBwdArgs {
     // A row is re-zeroed only when it held values and gets none this time, instead of 300 MB of memsets per call.
     uint8_t* dirty;
     LoopGuard guard;
+    int span;       // Gaussians per wave: a multiple of GSR_K8_SPAN, at most GSR_K8_SPAN_MAX (k8_span)
 };
 
 __device__ __forceinline__ float3 dnormvdv3(float3 v, float3 dv)
@@ -1174,18 +1188,31 @@ __device__ __forceinline__ void cov3d_backward(const float* s3, float mod, const
 #undef A
 }
 
-// One WAVE per GSR_K8_SPAN consecutive Gaussians (workgroup = 64 lanes, ~14 KB of LDS: 11 resident per CU, no
-// cross-wave barriers).  Pass 1 looks at every Gaussian of the span (4 per lane) and compacts the active ones;
-// pass 2 runs the chain rule on dense lanes, SH rows staged through LDS GSR_K8_ROWS at a time.
+// One WAVE per `span` consecutive Gaussians (workgroup = 64 lanes, ~19 KB of LDS, no cross-wave barriers).  Pass 1
+// looks at every Gaussian of the span (GSR_K8_SPAN = 4 per lane at a time) and compacts the active ones; pass 2 runs
+// the chain rule on dense lanes, SH rows staged through LDS GSR_K8_ROWS at a time.
+// The kernel is bound by the latency of a wave's dependent phases (records -> compaction -> parameter gathers -> chain
+// rule -> stores) at the 2 waves per SIMD its 242 registers allow, so its duration is (rounds of resident waves) x
+// (one wave's latency): the host picks the span that lets all waves be resident at once (k8_span) -- 35 -> 27 us at
+// 1 M Gaussians (span 512 instead of 256), and the heavier second pass runs on fuller lanes.
 #define GSR_K8_SPAN 256
+#define GSR_K8_SPAN_MAX 2048
 #define GSR_K8_ROWS 64
+static inline int k8_span(int P)
+{
+    const int resident = 256 * 4 * 2;                       // CUs x SIMDs x waves per SIMD at this register count
+    int span = ((P + resident - 1) / resident + GSR_K8_SPAN - 1) / GSR_K8_SPAN * GSR_K8_SPAN;
+    if (span < GSR_K8_SPAN) span = GSR_K8_SPAN;
+    if (span > GSR_K8_SPAN_MAX) span = GSR_K8_SPAN_MAX;
+    return span;
+}
 __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
 {
     __shared__ float4 s_sh[GSR_K8_ROWS * GSR_SH16_LDS4];
-    __shared__ uint8_t s_list[GSR_K8_SPAN];      // active Gaussians of the span (index within the span), compacted
-    __shared__ uint8_t s_flag[GSR_K8_SPAN];      // per compacted entry: 1 = has a colour gradient (SH row needed)
+    __shared__ uint16_t s_list[GSR_K8_SPAN_MAX];      // active Gaussians of the span (index within the span), compacted
+    __shared__ uint8_t s_flag[GSR_K8_SPAN_MAX];       // per compacted entry: 1 = has a colour gradient (SH row needed)
     const int lane = threadIdx.x;
-    const int base = blockIdx.x * GSR_K8_SPAN;
+    const int base = blockIdx.x * a.span;
     if (a.guard.frozen()) return;
     float tau[6] = {0, 0, 0, 0, 0, 0};
     // SH rows in (and dL_dsh rows out) as 16-B-per-lane streams of whole 192-B rows through LDS
@@ -1195,9 +1222,10 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     // all-zero record and all-zero gradients, whatever its other parameters are, so only `active` ones (any
     // non-zero sum) go through the chain rule below.
     int nact = 0;
+    for (int q0 = 0; q0 < a.span / 64; q0 += GSR_K8_SPAN / 64)
 #pragma unroll
-    for (int q = 0; q < GSR_K8_SPAN / 64; q++) {
-        const int local = q * 64 + lane;
+    for (int qq = 0; qq < GSR_K8_SPAN / 64; qq++) {
+        const int local = (q0 + qq) * 64 + lane;
         const int idx = base + local;
         const bool live = idx < a.P;
         const bool vis = live && a.radii[idx] > 0;
@@ -1242,7 +1270,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         const unsigned long long mk = __ballot(active);
         if (active) {
             const int pos = nact + (int)__popcll(mk & ((1ull << lane) - 1ull));
-            s_list[pos] = (uint8_t)local;
+            s_list[pos] = (uint16_t)local;
             s_flag[pos] = has_col ? 1 : 0;
         }
         nact += (int)__popcll(mk);
