@@ -257,6 +257,9 @@ struct LoopClear { uint32_t* a = nullptr; float* b = nullptr; int n = 0; };
 thread_local LoopClear tl_clear;
 // set by gsr_refine: the tracking loss evaluated in the compositing kernel's epilogue (FusedLoss); out == nullptr otherwise
 thread_local gsr::FusedLoss tl_floss = {};
+// set by gsr_refine: 1 = this forward computes the 3D covariances of all Gaussians into the geometry buffer,
+// 2 = this forward reads them from there (the map is constant during a refinement), 0 = neither
+thread_local int tl_cov_cache = 0;
 thread_local int g_dev = 0;      // device chosen by the last select_device_of on this thread
 
 // One side stream + a fork/join event pair per device: independent work (SH colours, zero fills) runs next to
@@ -476,6 +479,8 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.gx = gx; pa.gy = gy;
     pa.means = means3D; pa.scales = scales; pa.mod = scale_modifier; pa.rots = rotations; pa.opac = opacities;
     pa.shs = shs; pa.cov3D_pre = cov3D_precomp; pa.colors_pre = colors_precomp;
+    pa.cov_all = (tl_cov_cache == 1 && cov3D_precomp == nullptr) ? 1 : 0;
+    if (tl_cov_cache == 2 && cov3D_precomp == nullptr) pa.cov3D_pre = g.cov3D;
     pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos;
     pa.tanx = tan_fovx; pa.tany = tan_fovy; pa.fx = focal_x; pa.fy = focal_y;
     pa.radii = radii; pa.xy = g.xy; pa.depths = g.depths; pa.cov3D = g.cov3D; pa.rgb = g.rgb; pa.conic_op = g.conic_op;
@@ -892,7 +897,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     *converged = 0;
     struct FlagGuard {
         FlagGuard() { tl_native_loop = true; }
-        ~FlagGuard() { tl_native_loop = false; tl_spec.mode = 0; tl_guard = LoopGuard{nullptr, nullptr}; tl_clear = LoopClear{}; tl_floss = FusedLoss{}; }
+        ~FlagGuard() { tl_native_loop = false; tl_cov_cache = 0; tl_spec.mode = 0; tl_guard = LoopGuard{nullptr, nullptr}; tl_clear = LoopClear{}; tl_floss = FusedLoss{}; }
     } guard;
     uint32_t* poison = reinterpret_cast<uint32_t*>(ps + GSR_PS_POISON);
     tl_guard.poison = poison;
@@ -942,6 +947,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         HIPCHK(hipMemsetAsync(a->loss_out, 0, 4 * sizeof(float), st));
     }
     bool dirty_cleared = false;
+    bool cov_cached = false;        // the first forward stores every Gaussian's 3D covariance, the others reuse it
     const int debug = 0;
     auto par = [&](int it) { return (it + poff) & 1; };      // which of the two bound buffers iteration `it` WRITES
     // Margin of the speculative bounds.  Given by the caller: fixed.  Otherwise adaptive: bound = (1 + m) z + m metres
@@ -969,6 +975,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         reinterpret_cast<volatile int*>(h_status + 8 * (it & 1))[4] = 0;      // (nothing in flight writes this slot any more)
         tl_spec.mode = mode;
         tl_spec.parity = par(it);
+        tl_cov_cache = cov_cached ? 2 : 1;
+        cov_cached = true;
         {   // the pose step of this iteration clears the dropped-here flags and the bounds buffer iteration it+1 writes
             Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
             tl_clear.a = (mode != 0) ? imv.truncc : nullptr;

@@ -133,6 +133,7 @@ struct PreArgs {
     int* radii; float2* xy; float* depths; float* cov3D; float* rgb; float4* conic_op;
     uint8_t* clamped; uint32_t* tiles_touched; ushort4* rects;
     int shc_span;            // k_sh_color: Gaussians per wave (shc_span())
+    int cov_all;             // k_preprocess: compute and store cov3D for every Gaussian, culled or not (see there)
 };
 
 __device__ __forceinline__ float3 sh_to_rgb(int deg, int M, float3 pos, const float* campos, const float* sh,
@@ -212,9 +213,21 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
         const float pw = 1.0f / (ph.w + 0.0000001f);
         const float3 pproj = make_float3(ph.x * pw, ph.y * pw, ph.z * pw);
         const float3 pview = xform4x3(p, a.view);
+        float cov6[6];
+        if (a.cov_all) {
+            // native loop, first forward of a refinement: the map does not change while the pose is refined, so the
+            // 3D covariances are computed for EVERY Gaussian now (also the ones culled at this pose) and the later
+            // iterations read them back (cov3D_pre = this buffer) instead of rebuilding them from scale and rotation
+            float s3[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
+            const float4 q = reinterpret_cast<const float4*>(a.rots)[idx];
+            float q4[4] = {q.x, q.y, q.z, q.w};
+            cov3d_from_scale_rot(s3, a.mod, q4, cov6);
+#pragma unroll
+            for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov6[i];
+        }
         if (pview.z > 0.2f) {     // near cull (auxiliary.h:150)
-            float cov6[6];
-            if (a.cov3D_pre != nullptr) {
+            if (a.cov_all) {
+            } else if (a.cov3D_pre != nullptr) {
 #pragma unroll
                 for (int i = 0; i < 6; i++) cov6[i] = a.cov3D_pre[6 * (size_t)idx + i];
             } else {
