@@ -24,11 +24,14 @@ def build(force=False, verbose=False):
            # one lane already holds the wave total when we issue an atomic: keep hipcc from wrapping it in
            # its own (iterative) cross-lane reduction loop
            "-mllvm", "-amdgpu-atomic-optimizer-strategy=None",
+           # the SLP vectorizer pairs neighbouring list entries of the unrolled compositing bodies on the packed-fp32
+           # instructions; building the register pairs costs more v_mov than the packed maths saves (K6 55 -> 50 us)
+           "-fno-slp-vectorize",
            "-I" + os.path.join(_ROOT, "include"), "-o", OUT, SRC]
     if os.environ.get("GSR_TIMING"):      # diagnostic build: per-phase clocks inside the compositing kernels
         cmd.insert(1, "-DGSR_TIMING=1")
     if os.environ.get("GSR_DEFS"):        # experiments: extra -D switches, e.g. GSR_DEFS="-DGSR_K8_SPAN=384"
-        for d in os.environ["GSR_DEFS"].split():
+        for d in reversed(os.environ["GSR_DEFS"].split()):
             cmd.insert(1, d)
     if verbose:
         print(" ".join(cmd))

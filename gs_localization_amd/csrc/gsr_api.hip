@@ -987,7 +987,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         int R = gsr_forward(cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
                             a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
                             a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
-                            a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, a->n_touched, a->stream);
+                            a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, /*n_touched: see the end*/ nullptr, a->stream);
         tl_spec.mode = 0;
         if (R < 0) return R;
         last_R = R;
@@ -1075,6 +1075,23 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         rc = settle(it - 1, conv);
         if (rc < 0) return rc;
         if (a->stop_on_converged && conv) *converged = 1;
+    }
+    if (last_enq >= 0 && gb.ptr && bb.ptr && ib.ptr) {
+        // n_touched (fifth output of the pose package's forward) is only wanted for the LAST forward, and counting it
+        // costs every iteration's compositing kernel an eighth of its instructions: the loop runs the variant
+        // without it and the lists of the last forward are composited once more here, with the counters.  Same
+        // lists, same geometry, same order: the images it rewrites are bit-identical.
+        const int gx = (a->width + GSR_TILE - 1) / GSR_TILE, gy = (a->height + GSR_TILE - 1) / GSR_TILE;
+        Geom g; carve_geom((char*)gb.ptr, a->P, g);
+        Img im; carve_img((char*)ib.ptr, a->width, a->height, im);
+        HIPCHK(hipMemsetAsync(a->n_touched, 0, (size_t)a->P * sizeof(int), st));
+        hipLaunchKernelGGL((k_render_fwd<true, false>), dim3(gx * gy), dim3(GSR_BLOCK), 0, st, im.ranges,
+                           reinterpret_cast<uint32_t*>(bb.ptr), (const unsigned long long*)nullptr, (uint32_t*)nullptr, a->width,
+                           a->height, gx, gx * gy, (const float2*)g.xy, (const float*)g.rgb, (const float*)g.depths,
+                           (const float4*)g.conic_op, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
+                           a->n_touched, (float*)nullptr, (const uint32_t*)nullptr, im.fail, 1.f, 0.f, (float*)nullptr,
+                           (const uint32_t*)im.truncc, im.sbx, FusedLoss{});
+        LAUNCHCHK("k_render_fwd (n_touched)");
     }
     HIPCHK(hipStreamSynchronize(st));
     if (a->warm_state) *a->warm_state = (a->speculative && last_enq >= 0) ? (par(last_enq) + 1) : 0;
