@@ -151,8 +151,8 @@ size_t carve_geom(char* base, int P, Geom& g)
 
 struct Img {
     uint32_t* n_contrib; uint2* ranges;
-    float* zb[2]; uint32_t* trunc; uint32_t* fail;      // speculative depth bounds of the native loop
-    float* zbc[2]; uint32_t* truncc; int sbx, nsb;       // per 4x4-tile superblock
+    float* zb[2]; uint32_t* fail;                       // speculative depth bounds of the native loop, verification flag
+    float* zbc[2]; int sbx, nsb;                         // bounds per 4x4-tile superblock
     uint32_t* tile_cursor; size_t clear_words;           // bin-by-tile path: per-tile append cursors (GSR_CURSOR_STRIDE apart)
     float* loss_shards;                                   // native loop: GSR_LOSS_SHARDS x 16 floats (fused tracking loss)
 };
@@ -168,12 +168,10 @@ size_t carve_img(char* base, int W, int H, Img& im)
     im.nsb = im.sbx * ((gy + 3) / 4);
     im.zbc[0] = c.take<float>((size_t)im.nsb);
     im.zbc[1] = c.take<float>((size_t)im.nsb);
-    // trunc | truncc | fail | tile_cursor are contiguous: one memset clears them
-    im.clear_words = (size_t)gx * gy + im.nsb + 16 + (size_t)gx * gy * GSR_CURSOR_STRIDE;
-    im.trunc = c.take<uint32_t>(im.clear_words);
-    im.truncc = base ? im.trunc + (size_t)gx * gy : nullptr;
-    im.fail = base ? im.truncc + im.nsb : nullptr;
-    im.tile_cursor = base ? im.trunc + (((size_t)gx * gy + im.nsb + 1 + 15) & ~(size_t)15) : nullptr;
+    // fail | tile_cursor are contiguous: one memset clears them
+    im.clear_words = 16 + (size_t)gx * gy * GSR_CURSOR_STRIDE;
+    im.fail = c.take<uint32_t>(im.clear_words);
+    im.tile_cursor = base ? im.fail + 16 : nullptr;
     im.loss_shards = c.take<float>(GSR_LOSS_SHARDS * 16);
     return c.size();
 }
@@ -241,11 +239,9 @@ size_t carve_spec(char* base, int W, int H, Img& im, unsigned long long** bins)
     im.nsb = im.sbx * ((gy + 3) / 4);
     im.zbc[0] = c.take<float>((size_t)im.nsb);
     im.zbc[1] = c.take<float>((size_t)im.nsb);
-    im.clear_words = (size_t)gx * gy + im.nsb + 16 + (size_t)gx * gy * GSR_CURSOR_STRIDE;
-    im.trunc = c.take<uint32_t>(im.clear_words);
-    im.truncc = base ? im.trunc + (size_t)gx * gy : nullptr;
-    im.fail = base ? im.truncc + im.nsb : nullptr;
-    im.tile_cursor = base ? im.trunc + (((size_t)gx * gy + im.nsb + 1 + 15) & ~(size_t)15) : nullptr;
+    im.clear_words = 16 + (size_t)gx * gy * GSR_CURSOR_STRIDE;
+    im.fail = c.take<uint32_t>(im.clear_words);
+    im.tile_cursor = base ? im.fail + 16 : nullptr;
     unsigned long long* b = c.take<unsigned long long>((size_t)gx * gy * GSR_LSORT_CAP);
     if (bins) *bins = b;
     return c.size();
@@ -351,22 +347,22 @@ extern "C" {
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
 // diagnostic builds only (GSR_TIMING): copies the 32 phase counters out and clears them; -1 in product builds
-int gsr_debug_timing(unsigned long long* out32)
+int gsr_debug_timing(unsigned long long* out48)
 {
 #if GSR_TIMING
-    static std::vector<unsigned long long> h((size_t)2 * GSR_TIM_WAVES * 12);
+    static std::vector<unsigned long long> h((size_t)3 * GSR_TIM_WAVES * 12);
     if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(gsr::g_tim), h.size() * 8) != hipSuccess) return -2;
-    for (int k = 0; k < 2; k++)
+    for (int k = 0; k < 3; k++)
         for (int q = 0; q < 12; q++) {
             unsigned long long sum = 0;
             for (size_t w = 0; w < GSR_TIM_WAVES; w++) sum += h[((size_t)k * GSR_TIM_WAVES + w) * 12 + q];
-            out32[k * 16 + q] = sum;
+            out48[k * 16 + q] = sum;
         }
     std::fill(h.begin(), h.end(), 0ull);
     if (hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_tim), h.data(), h.size() * 8) != hipSuccess) return -2;
     return 0;
 #else
-    (void)out32;
+    (void)out48;
     return -1;
 #endif
 }
@@ -491,9 +487,9 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     pa.shc_span = shc_span(P);
     const float* zb_prev = (tl_spec.mode == 1) ? im.zb[tl_spec.parity ^ 1] : nullptr;
     float* zb_next = (tl_spec.mode != 0) ? im.zb[tl_spec.parity] : nullptr;
-    pa.zb = zb_prev; pa.trunc = zb_prev ? im.trunc : nullptr;
+    pa.zb = zb_prev;
     pa.zb_mul = tl_spec.mul; pa.zb_add = tl_spec.add;
-    pa.zbc = zb_prev ? im.zbc[tl_spec.parity ^ 1] : nullptr; pa.truncc = zb_prev ? im.truncc : nullptr; pa.sbx = im.sbx;
+    pa.zbc = zb_prev ? im.zbc[tl_spec.parity ^ 1] : nullptr; pa.sbx = im.sbx;
     float* zbc_next = (tl_spec.mode != 0) ? im.zbc[tl_spec.parity] : nullptr;
     // bin-by-tile + in-kernel sort instead of the two global sorts: only with speculative bounds (short lists)
     const bool local_path = zb_prev != nullptr && tl_spec.local_sort && ntiles <= 65536;
@@ -509,9 +505,9 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     pa.tile_cursor = local_path ? im.tile_cursor : nullptr;
     pa.bins = bl.bins;
     // (on the by-tile path inside gsr_refine these words are cleared by the kernels that consume them: the tile cursors
-    // by the compositing kernel, the superblock flags / bounds by the loss kernel)
+    // by the compositing kernel, the superblock bounds by the pose step)
     if (tl_spec.mode != 0 && !(local_path && tl_native_loop)) {
-        HIPCHK(hipMemsetAsync(im.trunc, 0, im.clear_words * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(im.fail, 0, im.clear_words * sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(zbc_next, 0, (size_t)im.nsb * sizeof(float), st));
     }
     {
@@ -613,8 +609,8 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
 #define GSR_FWD_ARGS im.ranges, local_path ? bl.vals : b.vals, (const unsigned long long*)bl.bins, im.tile_cursor, \
                      width, height, gx, ntiles, (const float2*)g.xy, feat, \
                      (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
-                     zb_next, (const uint32_t*)(zb_prev ? im.trunc : nullptr), tl_guard.poison ? const_cast<uint32_t*>(tl_guard.poison) : im.fail, \
-                     tl_spec.mul, tl_spec.add, zbc_next, (const uint32_t*)im.truncc, im.sbx, tl_floss
+                     zb_next, zb_prev, tl_guard.poison ? const_cast<uint32_t*>(tl_guard.poison) : im.fail, \
+                     tl_spec.mul, tl_spec.add, zbc_next, im.sbx, tl_floss
     if (local_path) {
         if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
         else hipLaunchKernelGGL((k_render_fwd<false, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
@@ -934,7 +930,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         char* iptr = (char*)cached_resize(&ib, carve_img(nullptr, a->width, a->height, im0));
         if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
         carve_img(iptr, a->width, a->height, im0);
-        HIPCHK(hipMemsetAsync(im0.trunc, 0, im0.clear_words * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(im0.fail, 0, im0.clear_words * sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(im0.loss_shards, 0, GSR_LOSS_SHARDS * 16 * sizeof(float), st));
         HIPCHK(hipMemsetAsync(a->dL_dalpha, 0, (size_t)a->width * a->height * sizeof(float), st));      // no gradient flows into opacity
         tl_floss.gt_image = a->gt_image; tl_floss.gt_depth = a->gt_depth; tl_floss.grad_mask = a->grad_mask;
@@ -977,10 +973,10 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         tl_spec.parity = par(it);
         tl_cov_cache = cov_cached ? 2 : 1;
         cov_cached = true;
-        {   // the pose step of this iteration clears the dropped-here flags and the bounds buffer iteration it+1 writes
+        {   // the pose step of this iteration clears the superblock bounds buffer iteration it+1 accumulates into
             Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
-            tl_clear.a = (mode != 0) ? imv.truncc : nullptr;
-            tl_clear.b = imv.zbc[par(it) ^ 1];
+            tl_clear.a = nullptr;
+            tl_clear.b = (mode != 0) ? imv.zbc[par(it) ^ 1] : nullptr;
             tl_clear.n = imv.nsb;
             imv_loop = imv;
         }
@@ -1089,8 +1085,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                            reinterpret_cast<uint32_t*>(bb.ptr), (const unsigned long long*)nullptr, (uint32_t*)nullptr, a->width,
                            a->height, gx, gx * gy, (const float2*)g.xy, (const float*)g.rgb, (const float*)g.depths,
                            (const float4*)g.conic_op, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
-                           a->n_touched, (float*)nullptr, (const uint32_t*)nullptr, im.fail, 1.f, 0.f, (float*)nullptr,
-                           (const uint32_t*)im.truncc, im.sbx, FusedLoss{});
+                           a->n_touched, (float*)nullptr, (const float*)nullptr, im.fail, 1.f, 0.f, (float*)nullptr,
+                           im.sbx, FusedLoss{});
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
     HIPCHK(hipStreamSynchronize(st));

@@ -13,7 +13,7 @@ namespace gsr {
 #endif
 #if GSR_TIMING
 #define GSR_TIM_WAVES (16384 * 4)
-__device__ unsigned long long g_tim[2][GSR_TIM_WAVES][12];      // [kernel][wave][slot]: every wave owns its row, no atomics
+__device__ unsigned long long g_tim[3][GSR_TIM_WAVES][12];      // [kernel][wave][slot]: every wave owns its row, no atomics
 #define GSR_T_DECL long long t_prev_ = clock64(); const long long t_start_ = t_prev_; long long t_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
 #define GSR_T_TICK(slot) { const long long now_ = clock64(); t_acc_[slot] += now_ - t_prev_; t_prev_ = now_; }
 #define GSR_T_COUNT(slot, v) { t_acc_[slot] += (v); }
@@ -114,14 +114,16 @@ __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int 
 // ---------------------------------------------------------------------------------------------
 #define GSR_LSORT_CAP 2048        // bin capacity = longest list the in-LDS sort takes
 #define GSR_CURSOR_STRIDE 16      // cursors sit 64 B apart: the atomics of neighbouring tiles go to different lines
+#ifndef GSR_COOP_AREA
 #define GSR_COOP_AREA 8           // rectangles with more tiles than this are walked by the whole wave
+#endif
 
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
     uint32_t* depth_key; uint32_t* order_in;
-    const float* zb; uint32_t* trunc;      // speculative per-tile depth bounds of the native loop (nullable): the depth each
+    const float* zb;                       // speculative per-tile depth bounds of the native loop (nullable): the depth each
     float zb_mul, zb_add;                  // tile had to look at; an instance is kept if z <= zb * zb_mul + zb_add
-    const float* zbc; uint32_t* truncc; int sbx;   // the same per 4x4-tile superblock (max of its tiles): quick reject
+    const float* zbc; int sbx;             // the same per 4x4-tile superblock (max of its tiles): quick reject
     // bin-by-tile path (nullable): per-tile append cursors and fixed-capacity bins of (depth bits << 32 | index)
     uint32_t* tile_cursor; unsigned long long* bins;
     int* n_touched;          // nullable: cleared here (one 4-B store per Gaussian) instead of by a separate memset
@@ -187,13 +189,15 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     extern __shared__ float s_zb[];      // native loop: the per-tile depth bounds (gx*gy floats), else unused
     const int tid = threadIdx.x;
     if (a.guard.poisoned()) return;
+    GSR_T_DECL
     if (a.zb != nullptr) {
         for (int i = tid; i < a.gx * a.gy; i += GSR_BLOCK) s_zb[i] = a.zb[i] * a.zb_mul + a.zb_add;
         __syncthreads();
     }
+    GSR_T_TICK(0)
     const int idx = blockIdx.x * GSR_BLOCK + tid;
     const bool live = idx < a.P;
-    bool vis = false, coop = false, dropped = false;
+    bool vis = false, coop = false, own = false;
     float3 p = make_float3(0.f, 0.f, 0.f);
     TileTest tt = {};
     int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
@@ -270,38 +274,38 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                         for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
                             for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, a.zbc[sy * a.sbx + sx]);
                         far_everywhere = pview.z > zc * a.zb_mul + a.zb_add;
-                        if (far_everywhere) dropped = true;
                     }
                     if (!far_everywhere) {
                         if (a.bins != nullptr && (x1 - x0) * (y1 - y0) > GSR_COOP_AREA) coop = true;      // whole wave helps below
-                        else {
-                            uint32_t full = 0;
-                            for (int y = y0; y < y1; y++) {
-                                int lo, hi;
-                                row_span(tt, y, x0, x1, lo, hi);
-                                full += (uint32_t)max(0, hi - lo + 1);
-                                if (a.zb == nullptr) continue;
-                                // behind everything this tile needed last iteration (+ margin): speculatively dropped
-                                for (int x = lo; x <= hi; x++)
-                                    if (pview.z <= s_zb[y * a.gx + x]) {
-                                        cnt++;
-                                        if (a.bins != nullptr) {
-                                            const int tile = y * a.gx + x;
-                                            const uint32_t pos = atomicAdd(&a.tile_cursor[tile * GSR_CURSOR_STRIDE], 1u);
-                                            if (pos < GSR_LSORT_CAP)
-                                                a.bins[(size_t)tile * GSR_LSORT_CAP + pos] =
-                                                    ((unsigned long long)__float_as_uint(pview.z) << 32) | (uint32_t)idx;
-                                        }
-                                    }
-                            }
-                            if (a.zb == nullptr) cnt = full;
-                            else if (cnt != full) dropped = true;
-                        }
+                        else own = true;
                     }
                 }
             }
         }
     }
+    GSR_T_TICK(1)
+    if (own) {      // small footprint: the lane walks its own rectangle
+        uint32_t full = 0;
+        for (int y = ry0; y < ry1; y++) {
+            int lo, hi;
+            row_span(tt, y, rx0, rx1, lo, hi);
+            full += (uint32_t)max(0, hi - lo + 1);
+            if (a.zb == nullptr) continue;
+            // behind everything this tile needed last iteration (+ margin): speculatively dropped
+            for (int x = lo; x <= hi; x++)
+                if (zv <= s_zb[y * a.gx + x]) {
+                    cnt++;
+                    if (a.bins != nullptr) {
+                        const int tile = y * a.gx + x;
+                        const uint32_t pos = atomicAdd(&a.tile_cursor[tile * GSR_CURSOR_STRIDE], 1u);
+                        if (pos < GSR_LSORT_CAP)
+                            a.bins[(size_t)tile * GSR_LSORT_CAP + pos] = ((unsigned long long)__float_as_uint(zv) << 32) | (uint32_t)idx;
+                    }
+                }
+        }
+        if (a.zb == nullptr) cnt = full;
+    }
+    GSR_T_TICK(2)
     if (a.bins != nullptr) {
         // Large footprints: the 64 lanes of the wave walk the rectangle together (one tile per lane), so no lane
         // is left issuing hundreds of dependent atomics on its own.
@@ -323,7 +327,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
             const int bx1 = __builtin_amdgcn_readlane(rx1, src), by1 = __builtin_amdgcn_readlane(ry1, src);
             const uint32_t bidx = (uint32_t)(blockIdx.x * GSR_BLOCK + (tid & ~63) + src);
             const int bw = bx1 - bx0, area = bw * (by1 - by0);
-            uint32_t c_full = 0, c_cnt = 0;
+            uint32_t c_cnt = 0;
             for (int t0 = 0; t0 < area; t0 += 64) {
                 const int t = t0 + lane;
                 bool in_span = false, pass = false;
@@ -340,20 +344,20 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                             a.bins[(size_t)tile * GSR_LSORT_CAP + pos] = ((unsigned long long)__float_as_uint(bz) << 32) | bidx;
                     }
                 }
-                c_full += (uint32_t)__popcll(__ballot(in_span));
                 c_cnt += (uint32_t)__popcll(__ballot(pass));
             }
-            if (lane == src) { cnt = c_cnt; if (c_cnt != c_full) dropped = true; }
+            if (lane == src) cnt = c_cnt;
         }
     }
+    GSR_T_TICK(3)
     if (vis) {
-        if (dropped)       // something was dropped: remember it per superblock (test first: ~10^4 lanes per flag)
-            for (int sy = ry0 >> 2; sy <= (ry1 - 1) >> 2; sy++)
-                for (int sx = rx0 >> 2; sx <= (rx1 - 1) >> 2; sx++)
-                    if (a.truncc[sy * a.sbx + sx] == 0u) a.truncc[sy * a.sbx + sx] = 1u;
+        // (what was dropped is not recorded: an instance can only be dropped from a tile whose bound is finite, and the
+        // compositing kernel treats every such tile that ends unsaturated as a failed speculation)
         a.tiles_touched[idx] = cnt;
         if (cnt && a.bins == nullptr) a.depth_key[idx] = __float_as_uint(zv);
     }
+    GSR_T_TICK(4)
+    GSR_T_FLUSH(32)
 }
 
 // SH -> RGB (forward.cu:20-71) as its own kernel: it only needs radii > 0 from the geometry pass, so the host
@@ -575,9 +579,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
                                                           float* __restrict__ out_color, float* __restrict__ out_depth,
                                                           float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
                                                           int* __restrict__ n_touched, float* __restrict__ zb_next,
-                                                          const uint32_t* __restrict__ trunc, uint32_t* __restrict__ fail,
+                                                          const float* __restrict__ zb_used, uint32_t* __restrict__ fail,
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
-                                                          const uint32_t* __restrict__ truncc, int sbx, FusedLoss fl)
+                                                          int sbx, FusedLoss fl)
 {
     __shared__ SplatLDS s;
     __shared__ float s_zmax[4];
@@ -760,7 +764,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
             zb_next[tile] = bound;
             const int sb = (ty >> 2) * sbx + (tx >> 2);
             atomicMax(reinterpret_cast<int*>(zbc_next) + sb, __float_as_int(bound));     // bounds are >= 0: int order = float order
-            if (unfinished && trunc != nullptr && truncc[sb] != 0u) atomicAdd(fail, 1u);
+            // zb_used: the bounds this forward was binned with.  Instances can only have been dropped from a tile whose
+            // bound was finite; if such a tile ends with an unsaturated pixel, a dropped instance may be missing.
+            if (unfinished && zb_used != nullptr && zb_used[tile] < __builtin_huge_valf()) atomicAdd(fail, 1u);
         }
     }
     const size_t N = (size_t)W * H;
@@ -2012,8 +2018,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_tracking_loss(LossArgs a)
 {
     __shared__ float s_red[4][3];
     if (a.guard.frozen()) return;
-    if (blockIdx.x == 0 && a.clear_a != nullptr)
-        for (int i = threadIdx.x; i < a.clear_n; i += GSR_BLOCK) { a.clear_a[i] = 0u; a.clear_b[i] = 0.f; }
+    if (blockIdx.x == 0 && a.clear_b != nullptr)
+        for (int i = threadIdx.x; i < a.clear_n; i += GSR_BLOCK) { if (a.clear_a != nullptr) a.clear_a[i] = 0u; a.clear_b[i] = 0.f; }
     const int n = a.W * a.H;
     const float ea = expf(a.exposure[0]), eb = a.exposure[1];
     const float inv3n = 1.f / (3.f * (float)n), invn = 1.f / (float)n;
@@ -2193,8 +2199,8 @@ __global__ void k_pose_step(float* st, const float* dL_dtau, const double* tau_a
             }
             s_loss[tid - 8] = v;
         }
-        if (clear_a != nullptr)                    // per-superblock words the forward has consumed (see LossArgs)
-            for (int i = tid; i < clear_n; i += blockDim.x) { clear_a[i] = 0u; clear_b[i] = 0.f; }
+        if (clear_b != nullptr)                    // per-superblock bounds the next forward accumulates into (see LossArgs)
+            for (int i = tid; i < clear_n; i += blockDim.x) { if (clear_a != nullptr) clear_a[i] = 0u; clear_b[i] = 0.f; }
         if (tid >= 16 && tid < 32) s_proj[tid - 16] = proj_raw[tid - 16];
         __syncthreads();
         if (tau_acc != nullptr && loss_zero != nullptr)        // native loop: leave the partial sums clean for the next backward

@@ -306,9 +306,9 @@ int gsr_profile_enable(unsigned mask);
 /* Bracket only one launch in `every` of each enabled kernel (default 1 = all): an event pair around a kernel keeps it
  * from overlapping its neighbours, which costs ~5 % with several frames in flight. */
 int gsr_profile_sampling(unsigned every);
-/* Diagnostic builds only (compiled with -DGSR_TIMING=1): copies out and clears 32 shader-clock phase totals of
- * the two compositing kernels (slots 0-15 forward, 16-31 backward).  Returns -1 in product builds. */
-int gsr_debug_timing(unsigned long long* out32);
+/* Diagnostic builds only (compiled with -DGSR_TIMING=1): copies out and clears 48 shader-clock phase totals
+ * (slots 0-15 compositing forward, 16-31 compositing backward, 32-47 preprocess).  Returns -1 in product builds. */
+int gsr_debug_timing(unsigned long long* out48);
 int gsr_profile_collect(double* ms, long long* launches);
 int gsr_profile_kernel_count(void);
 const char* gsr_profile_kernel_name(int id);

@@ -346,3 +346,30 @@ def test_native_loop_on_large_images_matches_python_loop(W, H):
     assert info["iters"] == 6
     assert torch.allclose(R1, R2, atol=2e-5), (R1 - R2).abs().max()
     assert torch.allclose(T1, T2, atol=2e-5), (T1 - T2).abs().max()
+
+
+def test_speculation_on_a_half_empty_scene():
+    """Tiles that never saturate (sky, holes in the map) have no finite depth bound: nothing is ever dropped from them,
+    so an unsaturated pixel there is not a failed speculation.  Half of this image is dense, the other half sparse and
+    faint; the loop must speculate without a single redone forward and agree with complete lists."""
+    from gs_localization_amd import pipelines as PL
+    sc = S.small(P=60000, W=160, H=128, sh_degree=1, seed=14, scale_med=0.04)
+    right = sc.means3D[:, 0] > 0
+    keep = ~right | (np.arange(sc.P) % 40 == 0)            # thin the right half out
+    sc.means3D, sc.scales, sc.rotations, sc.opacities, sc.shs = (np.ascontiguousarray(x[keep]) for x in
+                                                                   (sc.means3D, sc.scales, sc.rotations, sc.opacities, sc.shs))
+    sc.opacities[sc.means3D[:, 0] > 0] *= 0.2               # and make it faint
+    model, bg, view, init = _setup(sc, seed=3)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    out = {}
+    for spec in (False, True):
+        vp = view()
+        R, T, info = fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=12, stop_on_converged=False,
+                               speculative=spec)
+        out[spec] = (R.clone(), T.clone(), info, fr.alpha.clone())
+    a = out[False][3]
+    assert float((a[..., sc.W // 2 + 16:] < 0.9).float().mean()) > 0.5       # the right half really is unsaturated
+    assert float((a[..., :sc.W // 2 - 16] > 0.999).float().mean()) > 0.9     # and the left half saturated
+    assert out[True][2]["fallbacks"] == 0
+    assert out[True][2]["num_rendered"] < 0.8 * out[False][2]["num_rendered"]
+    assert torch.allclose(out[True][0], out[False][0], atol=2e-6) and torch.allclose(out[True][1], out[False][1], atol=2e-6)

@@ -20,7 +20,7 @@ ITERS = 40
 nk = lib.gsr_profile_kernel_count(); names = [lib.gsr_profile_kernel_name(i).decode() for i in range(nk)]
 fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False, speculative=True)
 torch.cuda.synchronize()
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 48)()
 assert lib.gsr_debug_timing(out) == 0, "not a GSR_TIMING build"
 lib.gsr_profile_enable((1 << nk) - 1)
 fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=ITERS, stop_on_converged=False, speculative=True)
@@ -42,3 +42,6 @@ show("k_render_fwd", 0, ["bins load", "sort + writeback", "batch top (barrier_an
 nw = 1200 * 4 * ITERS
 show("k_render_bwd_mfma", 16, ["prologue", "batch top barrier", "staging + barrier", "compaction", "weights (8 splats)", "mfma + lds atomics",
                                "(loop exit)", "barrier after groups", "recombine + global atomics", "(wave lifetime)", "batches", "list entries"])
+nw = (sc.P + 255) // 256 * 4 * ITERS
+show("k_preprocess", 32, ["bounds -> LDS + barrier", "geometry, bound test", "own rectangle walk (divergent)", "cooperative walks", "flags, counts",
+                          "", "", "", "", "(wave lifetime)", "", ""])
