@@ -452,7 +452,6 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
 
     const int gx = (width + GSR_TILE - 1) / GSR_TILE, gy = (height + GSR_TILE - 1) / GSR_TILE;
     if (gx > 65535 || gy > 65535) return fail(GSR_E_INVALID, "image too large%s", "");
-    if (tl_spec.mode == 1 && (size_t)gx * gy * sizeof(float) > 60 * 1024) tl_spec.mode = 2;   // bounds must fit in LDS
     const int ntiles = gx * gy;
     const float focal_y = height / (2.0f * tan_fovy);
     const float focal_x = width / (2.0f * tan_fovx);
@@ -512,7 +511,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     }
     {
         ProfScope ps(K_PREPROCESS, st);
-        hipLaunchKernelGGL(k_preprocess, dim3(pblocks), dim3(GSR_BLOCK), zb_prev ? (size_t)ntiles * sizeof(float) : 0, st, pa);
+        hipLaunchKernelGGL(k_preprocess, dim3(pblocks), dim3(GSR_BLOCK), 0, st, pa);
     }
     LAUNCHCHK("k_preprocess");
     // SH colours only feed the compositing kernel: fork them onto the side stream, join before K6.  (Not on the
@@ -562,11 +561,10 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
         if (R > 0) {
             const int end_bit = bits_for((uint32_t)(ntiles - 1)) > 0 ? bits_for((uint32_t)(ntiles - 1)) : 1;
             const int rblocks = (R + GSR_BLOCK - 1) / GSR_BLOCK;
-            const size_t zb_lds = zb_prev ? (size_t)ntiles * sizeof(float) : 0;
             if (wide) {
                 {
                     ProfScope ps(K_EMIT, st);
-                    hipLaunchKernelGGL(k_emit_sorted<uint32_t>, dim3(pblocks), dim3(GSR_BLOCK), zb_lds, st, P, (const uint32_t*)g.order,
+                    hipLaunchKernelGGL(k_emit_sorted<uint32_t>, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
                                        (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
                                        (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, tl_spec.mul, tl_spec.add, (const float*)g.depths,
                                        (uint32_t*)b.keys_unsorted, b.vals_unsorted);
@@ -584,7 +582,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
             } else {
                 {
                     ProfScope ps(K_EMIT, st);
-                    hipLaunchKernelGGL(k_emit_sorted<uint16_t>, dim3(pblocks), dim3(GSR_BLOCK), zb_lds, st, P, (const uint32_t*)g.order,
+                    hipLaunchKernelGGL(k_emit_sorted<uint16_t>, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
                                        (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
                                        (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, tl_spec.mul, tl_spec.add, (const float*)g.depths,
                                        (uint16_t*)b.keys_unsorted, b.vals_unsorted);

@@ -186,14 +186,12 @@ __device__ __forceinline__ bool sh16_vector_ok(int M, const float* shs)
 
 __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 {
-    extern __shared__ float s_zb[];      // native loop: the per-tile depth bounds (gx*gy floats), else unused
+    // (the per-tile bounds are read straight from global memory: only the few lanes of a wave whose splat survives
+    // the superblock test look at them, a dozen reads per wave that hit in L1/L2, against 1 200 loads + LDS stores and
+    // a barrier per workgroup for a staged copy -- an eighth of the kernel's time, and a limit on the tile count)
     const int tid = threadIdx.x;
     if (a.guard.poisoned()) return;
     GSR_T_DECL
-    if (a.zb != nullptr) {
-        for (int i = tid; i < a.gx * a.gy; i += GSR_BLOCK) s_zb[i] = a.zb[i] * a.zb_mul + a.zb_add;
-        __syncthreads();
-    }
     GSR_T_TICK(0)
     const int idx = blockIdx.x * GSR_BLOCK + tid;
     const bool live = idx < a.P;
@@ -293,7 +291,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
             if (a.zb == nullptr) continue;
             // behind everything this tile needed last iteration (+ margin): speculatively dropped
             for (int x = lo; x <= hi; x++)
-                if (zv <= s_zb[y * a.gx + x]) {
+                if (zv <= a.zb[y * a.gx + x] * a.zb_mul + a.zb_add) {
                     cnt++;
                     if (a.bins != nullptr) {
                         const int tile = y * a.gx + x;
@@ -336,7 +334,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                     int lo, hi;
                     row_span(bt, y, bx0, bx1, lo, hi);
                     in_span = x >= lo && x <= hi;
-                    pass = in_span && bz <= s_zb[y * a.gx + x];
+                    pass = in_span && bz <= a.zb[y * a.gx + x] * a.zb_mul + a.zb_add;
                     if (pass) {
                         const int tile = y * a.gx + x;
                         const uint32_t pos = atomicAdd(&a.tile_cursor[tile * GSR_CURSOR_STRIDE], 1u);
@@ -458,11 +456,6 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t
                                                            const float* __restrict__ zb, float zb_mul, float zb_add, const float* __restrict__ depths,
                                                            KeyT* __restrict__ keys, uint32_t* __restrict__ vals)
 {
-    extern __shared__ float s_zb[];      // per-tile depth bounds (native loop), see k_preprocess
-    if (zb != nullptr) {
-        for (int i = threadIdx.x; i < gx * gy_tiles; i += GSR_BLOCK) s_zb[i] = zb[i] * zb_mul + zb_add;
-        __syncthreads();
-    }
     const int run = (threadIdx.x >> 4) * gridDim.x + blockIdx.x;       // which run of 16 consecutive Gaussians
     const int k = run * 16 + (threadIdx.x & 15);
     if (k >= P || tt_sorted[k] == 0) return;
@@ -476,7 +469,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t
         int lo, hi;
         row_span(tt, y, r.x, r.z, lo, hi);
         for (int x = lo; x <= hi; x++) {
-            if (zb && !(z <= s_zb[y * gx + x])) continue;      // same test as the count in k_preprocess
+            if (zb && !(z <= zb[y * gx + x] * zb_mul + zb_add)) continue;      // same test as the count in k_preprocess
             keys[off] = (KeyT)(y * gx + x);
             vals[off] = idx;
             off++;

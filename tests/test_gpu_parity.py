@@ -185,7 +185,7 @@ def test_headline_scene_backward_is_linear_in_the_incoming_gradients():
         assert not np.any(b0[k]), k
 
 
-@pytest.mark.parametrize("W,H,P", [(1920, 1080, 4000),       # 8 160 tiles: the bounds of the native loop still fit in LDS
+@pytest.mark.parametrize("W,H,P", [(1920, 1080, 4000),       # 8 160 tiles
                                    (4112, 4096, 3000)])      # 65 792 tiles: 32-bit tile keys (rasterizer_impl.cu:35-50 sizes
 def test_large_images(W, H, P):                              # the key by the tile count) and no bin-by-tile path
     """Maximum sizes: image parity and gradients at full-HD and at more than 65 536 tiles, both packages; the drop-in

@@ -332,8 +332,8 @@ def test_warm_start_of_the_speculation_is_exact():
     assert fr.last_info["num_rendered"] < 0.6 * n_cold
 
 
-@pytest.mark.parametrize("W,H", [(1920, 1080),       # 8 160 tiles: per-tile bounds staged in LDS, bin-by-tile path
-                                 (2576, 1616)])      # 16 261 tiles: the bounds no longer fit in LDS, the loop keeps the global sorts
+@pytest.mark.parametrize("W,H", [(1920, 1080),       # 8 160 tiles
+                                 (2576, 1616)])      # 16 261 tiles (more than a workgroup's LDS could hold bounds for)
 def test_native_loop_on_large_images_matches_python_loop(W, H):
     from gs_localization_amd import pipelines as PL
     sc = S.small(P=30000, W=W, H=H, sh_degree=2, seed=8, scale_med=0.03)
