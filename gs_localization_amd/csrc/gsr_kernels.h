@@ -124,6 +124,7 @@ struct PreArgs {
     const float* zb;                       // speculative per-tile depth bounds of the native loop (nullable): the depth each
     float zb_mul, zb_add;                  // tile had to look at; an instance is kept if z <= zb * zb_mul + zb_add
     const float* zbc; int sbx;             // the same per 4x4-tile superblock (max of its tiles): quick reject
+    int zbc_lds;                           // k_preprocess: number of superblock bounds staged in LDS (0: read from global)
     // bin-by-tile path (nullable): per-tile append cursors and fixed-capacity bins of (depth bits << 32 | index)
     uint32_t* tile_cursor; unsigned long long* bins;
     int* n_touched;          // nullable: cleared here (one 4-B store per Gaussian) instead of by a separate memset
@@ -189,9 +190,14 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     // (the per-tile bounds are read straight from global memory: only the few lanes of a wave whose splat survives
     // the superblock test look at them, a dozen reads per wave that hit in L1/L2, against 1 200 loads + LDS stores and
     // a barrier per workgroup for a staged copy -- an eighth of the kernel's time, and a limit on the tile count)
+    extern __shared__ float s_zbc[];      // a.zbc_lds floats: the superblock bounds (0: read them from global memory)
     const int tid = threadIdx.x;
     if (a.guard.poisoned()) return;
     GSR_T_DECL
+    if (a.zbc_lds > 0) {
+        for (int i = tid; i < a.zbc_lds; i += GSR_BLOCK) s_zbc[i] = a.zbc[i];
+        __syncthreads();
+    }
     GSR_T_TICK(0)
     const int idx = blockIdx.x * GSR_BLOCK + tid;
     const bool live = idx < a.P;
@@ -269,8 +275,13 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                     if (a.zb != nullptr) {
                         // behind the bound of every superblock the rectangle overlaps => behind every tile's bound
                         float zc = 0.f;
-                        for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
-                            for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, a.zbc[sy * a.sbx + sx]);
+                        if (a.zbc_lds > 0) {
+                            for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
+                                for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, s_zbc[sy * a.sbx + sx]);
+                        } else {
+                            for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
+                                for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, a.zbc[sy * a.sbx + sx]);
+                        }
                         far_everywhere = pview.z > zc * a.zb_mul + a.zb_add;
                     }
                     if (!far_everywhere) {
