@@ -1332,6 +1332,14 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     #pragma unroll
             for (int i = 0; i < 6; i++) cov6[i] = cov3D[i];
             const float3 mean = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
+            // (scale and rotation are only needed at the very end; requested here, their latency is hidden by the chain rule)
+            const bool want_sr = a.scales && (a.dL_dscale || a.dL_drot);
+            float s3[3] = {0.f, 0.f, 0.f};
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (want_sr) {
+                s3[0] = a.scales[3 * idx]; s3[1] = a.scales[3 * idx + 1]; s3[2] = a.scales[3 * idx + 2];
+                q = reinterpret_cast<const float4*>(a.rots)[idx];
+            }
             const float dcx = r1.y, dcy = r1.z, dcz = r1.w;
             Cov2DTerms ct;
             cov2d_terms(mean, a.fx, a.fy, a.tanx, a.tany, cov6, a.view, ct);
@@ -1430,9 +1438,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
                 a.dL_dmean3D[3 * (size_t)idx + 2] = dm2;
             }
 
-            if (a.scales && (a.dL_dscale || a.dL_drot)) {
-                float s3[3] = {a.scales[3 * idx], a.scales[3 * idx + 1], a.scales[3 * idx + 2]};
-                const float4 q = reinterpret_cast<const float4*>(a.rots)[idx];
+            if (want_sr) {
                 float q4[4] = {q.x, q.y, q.z, q.w};
                 float ds[3], dq[4];
                 cov3d_backward(s3, a.mod, q4, dcov, ds, dq);
