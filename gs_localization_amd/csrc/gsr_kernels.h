@@ -541,7 +541,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
 //     the last (fewer than eight) entries go through a plain tail loop;
 //   * termination is folded into T: a finished pixel has T = 0 (its true transmittance is parked in Tfin), so
 //     every later weight alpha*T vanishes by itself and no `done` flag has to be carried through the body;
-//   * power > 0 (forward.cu:342) is folded into G (G = 0 => alpha = 0 => skipped by the 1/255 test);
+//   * power > 0 (forward.cu:342) is folded into the `valid` predicate (a scalar AND, not a select on G);
 //   * the conic is staged pre-multiplied, A2 = -a/2 log2e, B2 = -b log2e, C2 = -c/2 log2e, so that
 //         power log2e = dx (A2 dx + B2 dy) + C2 dy dy
 //     is two FMAs and three multiplies and feeds v_exp_f32 directly; K7 evaluates the identical expression, so
@@ -687,17 +687,16 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
                 const float4 Cc = s.c[j];
                 const float dx = A.x - pxf, dy = A.y - pyf;
                 const float p2 = __builtin_fmaf(dx, __builtin_fmaf(A.z, dx, A.w * dy), (B.x * dy) * dy);
-                float G = __builtin_amdgcn_exp2f(p2);
-                G = (p2 > 0.0f) ? 0.f : G;
+                const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, B.y * G);
                 const float test_T = T * (1.f - alpha);
-                const bool valid = !(alpha < 1.0f / 255.0f);
+                const bool valid = !(alpha < 1.0f / 255.0f) && !(p2 > 0.0f);      // power > 0: skipped (forward.cu:342)
                 const bool kill = valid && test_T < 0.0001f;
                 const bool blend = valid && !kill;
                 const float w = blend ? alpha * T : 0.f;
                 C0 = __builtin_fmaf(Cc.x, w, C0); C1 = __builtin_fmaf(Cc.y, w, C1); C2 = __builtin_fmaf(Cc.z, w, C2);
                 Dd = __builtin_fmaf(B.z, w, Dd);
-                Tfin = kill ? fmaxf(Tfin, T) : Tfin;
+                Tfin += kill ? T : 0.f;          // (T is 0 after the first kill: later ones add nothing)
                 T = kill ? 0.f : (valid ? test_T : T);
                 last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;      // 1-based position in the tile list
 #if GSR_TIMING
@@ -729,17 +728,16 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
             if (T > 0.f) zneed = B.z;
             const float dx = A.x - pxf, dy = A.y - pyf;
             const float p2 = __builtin_fmaf(dx, __builtin_fmaf(A.z, dx, A.w * dy), (B.x * dy) * dy);
-            float G = __builtin_amdgcn_exp2f(p2);
-            G = (p2 > 0.0f) ? 0.f : G;
+            const float G = __builtin_amdgcn_exp2f(p2);
             const float alpha = fminf(0.99f, B.y * G);
             const float test_T = T * (1.f - alpha);
-            const bool valid = !(alpha < 1.0f / 255.0f);
+            const bool valid = !(alpha < 1.0f / 255.0f) && !(p2 > 0.0f);
             const bool kill = valid && test_T < 0.0001f;
             const bool blend = valid && !kill;
             const float w = blend ? alpha * T : 0.f;
             C0 = __builtin_fmaf(Cc.x, w, C0); C1 = __builtin_fmaf(Cc.y, w, C1); C2 = __builtin_fmaf(Cc.z, w, C2);
             Dd = __builtin_fmaf(B.z, w, Dd);
-            Tfin = kill ? fmaxf(Tfin, T) : Tfin;
+            Tfin += kill ? T : 0.f;
             T = kill ? 0.f : (valid ? test_T : T);
             last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;
             if (TOUCHED) {
@@ -987,10 +985,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                     const float4 Cc = s.c[j];
                     const float dx = A.x - pxf, dy = A.y - pyf;
                     const float p2 = __builtin_fmaf(dx, __builtin_fmaf(A.z, dx, A.w * dy), (B.x * dy) * dy);
-                    float G = __builtin_amdgcn_exp2f(p2);
-                    G = (p2 > 0.0f) ? 0.f : G;
+                    const float G = __builtin_amdgcn_exp2f(p2);
                     const float alpha = fminf(0.99f, B.y * G);
-                    const bool valid = (contributor <= last_contributor) && !(alpha < 1.0f / 255.0f);
+                    const bool valid = (contributor <= last_contributor) && !(alpha < 1.0f / 255.0f) && !(p2 > 0.0f);
                     const float ae = valid ? alpha : 0.f;          // skipped => transparent: every update below is the identity
                     const float r1ma = __builtin_amdgcn_rcpf(1.f - ae);
                     T = T * r1ma;
