@@ -126,3 +126,15 @@ def test_python_loop_uses_the_speculation_and_matches_the_plain_loop():
     assert res[False][2] == (0, 0)
     assert res[True][2][0] >= 10 and res[True][2][1] == 0
     assert torch.allclose(res[True][0], res[False][0], atol=2e-6) and torch.allclose(res[True][1], res[False][1], atol=2e-6)
+
+
+def test_randomised_scenes_and_pose_walks():
+    """tools/fuzz_speculation.py on 40 random cases: odd image sizes, sparse / faint / half-empty scenes, pose walks with
+    jumps, both packages, and the native loop with and without speculation."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, CASES="40", SEED="11")
+    env.pop("GSR_SPECULATION", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_speculation.py")], env=env, cwd=root, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "40 cases ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
