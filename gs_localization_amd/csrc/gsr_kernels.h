@@ -63,6 +63,9 @@ __device__ __forceinline__ TileTest make_tile_test(float2 m, float3 conic, float
     t.mx = m.x; t.my = m.y; t.A = conic.x; t.B = conic.y; t.C = conic.z;
     t.det = conic.x * conic.z - conic.y * conic.y;
     t.cull = (conic.x > 0.f) && (conic.z > 0.f) && (t.det > 0.f);
+#ifdef GSR_NO_CULL      // diagnostic build (tools/cull_check.py): every tile of the reference rectangle, every quadrant
+    t.cull = false;
+#endif
     // q <= ln(255 o) + slack.  The slack (0.02 in q, i.e. 2 % in alpha) covers the fp32 rounding of q in
     // the compositing kernels, also for strongly correlated conics where q is a difference of large terms.
     const float qmax = (opacity > 0.f) ? (__logf(255.f * opacity) + 0.02f) : -1.f;
@@ -515,6 +518,9 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
 {
     const float det = A * C - B * B;
     if (!(A > 0.f && C > 0.f && det > 0.f)) return 0xFu;
+#ifdef GSR_NO_CULL
+    return 0xFu;
+#endif
     const float qmax = (opacity > 0.f) ? (__logf(255.f * opacity) + 0.02f) : -1.f;
     if (qmax < 0.f) return 0u;
     const float s2 = 2.f * qmax * __builtin_amdgcn_rcpf(det);
