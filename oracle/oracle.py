@@ -58,7 +58,10 @@ class Forward:
 
     def __del__(self):
         if getattr(self, "_state", None):
-            lib().gso_free(C.c_void_p(self._state))
+            try:
+                lib().gso_free(C.c_void_p(self._state))
+            except TypeError:          # interpreter shutdown: the module globals are already gone
+                pass
             self._state = None
 
     def state(self):
