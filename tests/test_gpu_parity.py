@@ -212,3 +212,23 @@ def test_large_images(W, H, P):                              # the key by the ti
         o2, _ = U.hip_run(sc, cam, grads, pose=pose)         # second render: speculative where the size allows it
         for k in ("color", "depth", "alpha", "radii"):
             assert np.array_equal(o[k], o2[k]), k
+
+
+def test_headline_scene_gradients_under_the_tracking_loss():
+    """Full BASELINE size with the gradients the refinement actually sends in: L1 tracking loss (colour / 3N, depth
+    weighted, descent_utils.py:85-123) between the render at a pose 1.2 cm / 0.9 deg off and the render at the true
+    pose.  BASELINE.json's bar: pose gradient within 1e-5 of the reference algorithm (the CPU oracle)."""
+    import os
+    from oracle import oracle as O
+    O.set_threads(min(64, os.cpu_count() or 1))
+    sc = S.s_1m_640()
+    o_gt, _ = U.hip_run(sc, U.scene_inputs(sc), pose=True)
+    cam = U.scene_inputs(sc, S.se3_exp([0.012, -0.009, 0.011, 0.008, -0.01, 0.009]))
+    o, _ = U.hip_run(sc, cam, pose=True)
+    N = sc.W * sc.H
+    grads = ((np.sign(o["color"] - o_gt["color"]) / (3 * N)).astype(np.float32),
+             (0.5 * np.sign(o["depth"] - o_gt["depth"]) / N).astype(np.float32), np.zeros((1, sc.H, sc.W), np.float32))
+    f, go = U.oracle_run(sc, cam, grads, pose=True)
+    _, g = U.hip_run(sc, cam, grads, pose=True)
+    assert U.rel_l1(g["tau"], go["tau"]) <= TAU_TOL
+    _check_grads(g, go, False, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
