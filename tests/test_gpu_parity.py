@@ -232,3 +232,27 @@ def test_headline_scene_gradients_under_the_tracking_loss():
     _, g = U.hip_run(sc, cam, grads, pose=True)
     assert U.rel_l1(g["tau"], go["tau"]) <= TAU_TOL
     _check_grads(g, go, False, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
+
+
+@pytest.mark.parametrize("make", [S.s_50k_fern, S.s_800k_chess, S.s_3m_cam], ids=["S-50k-fern", "S-800k-chess", "S-3M-cam"])
+def test_other_baseline_configs_at_full_size(make):
+    """BASELINE.json configs 0, 1/2 and 3 at their full sizes: radii exact, images and n_touched against the oracle, and the
+    backward under the tracking loss's gradients (as test_headline_scene_gradients_under_the_tracking_loss)."""
+    import os
+    from oracle import oracle as O
+    O.set_threads(min(64, os.cpu_count() or 1))
+    sc = make()
+    o_gt, _ = U.hip_run(sc, U.scene_inputs(sc), pose=True)
+    cam = U.scene_inputs(sc, S.se3_exp([0.01, -0.008, 0.012, 0.006, -0.009, 0.007]))
+    o, _ = U.hip_run(sc, cam, pose=True)
+    N = sc.W * sc.H
+    grads = ((np.sign(o["color"] - o_gt["color"]) / (3 * N)).astype(np.float32),
+             (0.5 * np.sign(o["depth"] - o_gt["depth"]) / N).astype(np.float32), np.zeros((1, sc.H, sc.W), np.float32))
+    O.set_accumulate_double(True)      # S-50k-fern's splats cover thousands of pixels: keep the order noise of the oracle's own
+    try:                               # fp32 atomics (2e-5 from run to run) out of the comparison, as in test_large_images
+        f, go = U.oracle_run(sc, cam, grads, pose=True)
+    finally:
+        O.set_accumulate_double(False)
+    o, g = U.hip_run(sc, cam, grads, pose=True)
+    _check_forward(o, f, True)
+    _check_grads(g, go, True, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
