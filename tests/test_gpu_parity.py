@@ -256,3 +256,28 @@ def test_other_baseline_configs_at_full_size(make):
     o, g = U.hip_run(sc, cam, grads, pose=True)
     _check_forward(o, f, True)
     _check_grads(g, go, True, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
+
+
+def test_training_config_package_a_at_size():
+    """BASELINE.json config 4's shape (train.py through package (A)): 1296x840, SH degree 1, white background, 200 k
+    Gaussians, gradients of an L1 image loss plus a depth and an opacity term (train.py:92-108 feeds all three)."""
+    import os
+    from oracle import oracle as O
+    O.set_threads(min(64, os.cpu_count() or 1))
+    sc = S._draw("S-train-garden", 200_000, 1296, 840, 0.9 * 1296, 0.9 * 1296, 0.5, 6.0, 0.012, 0.6, 1, 0)
+    sc.bg[:] = 1.0
+    o_gt, _ = U.hip_run(sc, U.scene_inputs(sc), pose=False)
+    cam = U.scene_inputs(sc, S.se3_exp([0.02, -0.01, 0.015, 0.01, -0.012, 0.008]))
+    o, _ = U.hip_run(sc, cam, pose=False)
+    N = sc.W * sc.H
+    grads = ((np.sign(o["color"] - o_gt["color"]) / (3 * N)).astype(np.float32),
+             (0.1 * np.sign(o["depth"] - o_gt["depth"]) / N).astype(np.float32),
+             (0.05 * np.sign(o["alpha"] - o_gt["alpha"] + 1e-9) / N).astype(np.float32))
+    O.set_accumulate_double(True)
+    try:
+        f, go = U.oracle_run(sc, cam, grads, pose=False)
+    finally:
+        O.set_accumulate_double(False)
+    o, g = U.hip_run(sc, cam, grads, pose=False)
+    _check_forward(o, f, False)
+    _check_grads(g, go, False, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
