@@ -256,6 +256,9 @@ thread_local gsr::FusedLoss tl_floss = {};
 // set by gsr_refine: 1 = this forward computes the 3D covariances of all Gaussians into the geometry buffer,
 // 2 = this forward reads them from there (the map is constant during a refinement), 0 = neither
 thread_local int tl_cov_cache = 0;
+// set by gsr_refine: this forward's `radii` cannot be the ones the caller gets (not the last iteration; convergence is
+// checked on the device), so the speculative preprocess may settle most Gaussians with a conservative test
+thread_local bool tl_lean = false;
 thread_local int g_dev = 0;      // device chosen by the last select_device_of on this thread
 
 // One side stream + a fork/join event pair per device: independent work (SH colours, zero fills) runs next to
@@ -512,6 +515,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     {
         ProfScope ps(K_PREPROCESS, st);
         pa.zbc_lds = (pa.zbc != nullptr && im.nsb <= 4096) ? im.nsb : 0;
+        pa.lean = (tl_lean && tl_native_loop && local_path && pa.cov_all == 0) ? 1 : 0;
         hipLaunchKernelGGL(k_preprocess, dim3(pblocks), dim3(GSR_BLOCK), (size_t)pa.zbc_lds * sizeof(float), st, pa);
     }
     LAUNCHCHK("k_preprocess");
@@ -892,7 +896,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     *converged = 0;
     struct FlagGuard {
         FlagGuard() { tl_native_loop = true; }
-        ~FlagGuard() { tl_native_loop = false; tl_cov_cache = 0; tl_spec.mode = 0; tl_guard = LoopGuard{nullptr, nullptr}; tl_clear = LoopClear{}; tl_floss = FusedLoss{}; }
+        ~FlagGuard() { tl_native_loop = false; tl_cov_cache = 0; tl_lean = false; tl_spec.mode = 0; tl_guard = LoopGuard{nullptr, nullptr}; tl_clear = LoopClear{}; tl_floss = FusedLoss{}; }
     } guard;
     uint32_t* poison = reinterpret_cast<uint32_t*>(ps + GSR_PS_POISON);
     tl_guard.poison = poison;
@@ -972,6 +976,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         tl_spec.parity = par(it);
         tl_cov_cache = cov_cached ? 2 : 1;
         cov_cached = true;
+        tl_lean = (mode == 1) && (it != a->max_iters - 1);
         {   // the pose step of this iteration clears the superblock bounds buffer iteration it+1 accumulates into
             Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
             tl_clear.a = nullptr;

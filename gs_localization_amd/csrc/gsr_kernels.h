@@ -128,6 +128,7 @@ struct PreArgs {
     float zb_mul, zb_add;                  // tile had to look at; an instance is kept if z <= zb * zb_mul + zb_add
     const float* zbc; int sbx;             // the same per 4x4-tile superblock (max of its tiles): quick reject
     int zbc_lds;                           // k_preprocess: number of superblock bounds staged in LDS (0: read from global)
+    int lean;                              // k_preprocess: radii of this forward are not an output (see the kernel)
     // bin-by-tile path (nullable): per-tile append cursors and fixed-capacity bins of (depth bits << 32 | index)
     uint32_t* tile_cursor; unsigned long long* bins;
     int* n_touched;          // nullable: cleared here (one 4-B store per Gaussian) instead of by a separate memset
@@ -202,6 +203,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
         __syncthreads();
     }
     GSR_T_TICK(0)
+    const bool lean = a.lean != 0 && a.zbc_lds > 0 && a.scales != nullptr && !a.guard.frozen();
     const int idx = blockIdx.x * GSR_BLOCK + tid;
     const bool live = idx < a.P;
     bool vis = false, coop = false, own = false;
@@ -224,6 +226,36 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
         const float pw = 1.0f / (ph.w + 0.0000001f);
         const float3 pproj = make_float3(ph.x * pw, ph.y * pw, ph.z * pw);
         const float3 pview = xform4x3(p, a.view);
+        // Native loop, iterations whose `radii` the caller cannot get (a.lean: not the last one; not after convergence):
+        // 98 % of the Gaussians in front of the camera lie behind the bound of every tile they could touch and leave with
+        // tiles_touched = 0 -- after 600 instructions of exact geometry.  A radius bound from the largest scale,
+        //     lambda_max(cov2D + 0.3 I) <= |J|_F^2 s_max^2 + 0.92    (J: the perspective Jacobian with the clamped x/z, y/z of
+        //     forward.cu:90-96; the reference's radius formula mid + sqrt(max(0.1, mid^2 - det)) <= trace + 0.32),
+        // gives a larger rectangle; behind all of ITS superblocks => behind all of the exact rectangle's.  Such a lane skips
+        // the geometry (its radius stays 0: only this differs from the exact path), and a wave whose 64 lanes all do -- a
+        // third of them on S-1M-640 -- skips it altogether.  No compaction, no barrier (DESIGN.md section 8 has the
+        // versions with them: slower).
+        bool settled = false;
+        if (lean && pview.z > 0.2f) {
+            const float smax = a.mod * fmaxf(a.scales[3 * idx], fmaxf(a.scales[3 * idx + 1], a.scales[3 * idx + 2]));
+            const float rz = 1.0f / pview.z;
+            const float ccx = fminf(1.3f * a.tanx, fmaxf(-1.3f * a.tanx, pview.x * rz));
+            const float ccy = fminf(1.3f * a.tany, fmaxf(-1.3f * a.tany, pview.y * rz));
+            const float jx = a.fx * rz, jy = a.fy * rz;
+            const float jn2 = jx * jx * (1.f + ccx * ccx) + jy * jy * (1.f + ccy * ccy);
+            const float rb = fminf(1.0e6f, ceilf(3.f * __builtin_amdgcn_sqrtf((jn2 * smax) * smax * 1.001f + 0.95f) * 1.001f) + 1.f);
+            if (rb == rb) {          // (NaN: the exact code decides)
+                int x0, y0, x1, y1;
+                get_rect(ndc2pix(pproj.x, a.W), ndc2pix(pproj.y, a.H), (int)rb, a.gx, a.gy, x0, y0, x1, y1);
+                if ((x1 - x0) * (y1 - y0) == 0) settled = true;
+                else {
+                    float zc = 0.f;
+                    for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
+                        for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, s_zbc[sy * a.sbx + sx]);
+                    settled = pview.z > zc * a.zb_mul + a.zb_add;
+                }
+            }
+        }
         float cov6[6];
         if (a.cov_all) {
             // native loop, first forward of a refinement: the map does not change while the pose is refined, so the
@@ -236,7 +268,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 #pragma unroll
             for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov6[i];
         }
-        if (pview.z > 0.2f) {     // near cull (auxiliary.h:150)
+        if (pview.z > 0.2f && !settled) {     // near cull (auxiliary.h:150)
             if (a.cov_all) {
             } else if (a.cov3D_pre != nullptr) {
 #pragma unroll
