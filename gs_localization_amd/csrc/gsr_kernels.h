@@ -577,7 +577,7 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
 //   * the wave's list is consumed eight entries at a time: one 8-byte LDS read brings their indices into two
 //     scalar registers, the bodies are unrolled, branch-free and their LDS reads independent of each other;
 //     the last (fewer than eight) entries go through a plain tail loop;
-//   * termination is folded into T: a finished pixel has T = 0 (its true transmittance is parked in Tfin), so
+//   * termination is folded into T: a finished pixel has T <= 0 (its true transmittance is -T), so
 //     every later weight alpha*T vanishes by itself and no `done` flag has to be carried through the body;
 //   * power > 0 (forward.cu:342) is folded into the `valid` predicate (a scalar AND, not a select on G);
 //   * the conic is staged pre-multiplied, A2 = -a/2 log2e, B2 = -b log2e, C2 = -c/2 log2e, so that
@@ -676,13 +676,15 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
         for (int i = tid; i < total; i += GSR_BLOCK) point_list[range.x + i] = (uint32_t)s_keys[i];
     }
     GSR_T_TICK(1)
-    // T > 0: still compositing.  T == 0: finished (or outside the image); the pixel's transmittance is in Tfin.
-    float T = inside ? 1.0f : 0.f, Tfin = 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f;
+    // T > 0: still compositing.  T <= 0: finished (or outside the image); the pixel's transmittance is -T.  With a
+    // negative T every later test_T = T (1 - alpha) is negative, i.e. "below 1e-4": the splat is neither blended nor
+    // counted, and the kill branch keeps T where it is -- no flag and no second register to carry.
+    float T = inside ? 1.0f : 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f;
     uint32_t last_contributor = 0;
     float zneed = 0.f;        // depth bound of what this pixel had to look at (rounded up to its group of eight)
 
     for (int base = 0; base < total; base += GSR_BLOCK) {
-        if (__syncthreads_and(T == 0.f)) break;
+        if (__syncthreads_and(T <= 0.f)) break;
         GSR_T_TICK(2)
         GSR_T_COUNT(10, 1)
         const int n = min(GSR_BLOCK, total - base);
@@ -709,7 +711,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
         GSR_T_TICK(4)
         const int full = cnt & ~7;
         for (int g0 = 0; g0 < full; g0 += 8) {
-            if (__all(T == 0.f)) break;                // whole wave finished: stop early
+            if (__all(T <= 0.f)) break;                // whole wave finished: stop early
             GSR_T_COUNT(11, 8)
             const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(&s.list[wv][g0]);
             const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)packed);
@@ -734,8 +736,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
                 const float w = blend ? alpha * T : 0.f;
                 C0 = __builtin_fmaf(Cc.x, w, C0); C1 = __builtin_fmaf(Cc.y, w, C1); C2 = __builtin_fmaf(Cc.z, w, C2);
                 Dd = __builtin_fmaf(B.z, w, Dd);
-                Tfin += kill ? T : 0.f;          // (T is 0 after the first kill: later ones add nothing)
-                T = kill ? 0.f : (valid ? test_T : T);
+                T = kill ? __uint_as_float(__float_as_uint(T) | 0x80000000u) : (valid ? test_T : T);      // kill: T -> -|T|
                 last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;      // 1-based position in the tile list
 #if GSR_TIMING
                 if (__ballot(valid && alive0) == 0ull) GSR_T_COUNT(8, 1)      // entry that no live pixel of this wave could use
@@ -757,7 +758,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
         }
         // tail: fewer than eight entries left in this wave's list
         for (int k = full; k < cnt; k++) {
-            if (__all(T == 0.f)) break;
+            if (__all(T <= 0.f)) break;
             GSR_T_COUNT(11, 1)
             const int j = __builtin_amdgcn_readfirstlane((int)s.list[wv][k]);
             const float4 A = s.a[j];
@@ -775,8 +776,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
             const float w = blend ? alpha * T : 0.f;
             C0 = __builtin_fmaf(Cc.x, w, C0); C1 = __builtin_fmaf(Cc.y, w, C1); C2 = __builtin_fmaf(Cc.z, w, C2);
             Dd = __builtin_fmaf(B.z, w, Dd);
-            Tfin += kill ? T : 0.f;
-            T = kill ? 0.f : (valid ? test_T : T);
+            T = kill ? __uint_as_float(__float_as_uint(T) | 0x80000000u) : (valid ? test_T : T);
             last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;
             if (TOUCHED) {
                 const int c = (int)__popcll(__ballot(valid && test_T > 0.5f));
@@ -786,8 +786,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
         GSR_T_TICK(5)
     }
     GSR_T_TICK(6)
-    const bool done = (T == 0.f);
-    const float T_out = fmaxf(T, Tfin);
+    const bool done = (T <= 0.f);
+    const float T_out = fabsf(T);
     if (zb_next != nullptr) {
         // Native loop bookkeeping: how deep did this tile have to look?  Next iteration's binning drops what
         // lies behind that (plus a margin); if a pixel is still unsaturated at the end of a list from which
