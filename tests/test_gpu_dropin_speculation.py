@@ -138,3 +138,40 @@ def test_randomised_scenes_and_pose_walks():
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_speculation.py")], env=env, cwd=root, capture_output=True, text=True,
                        timeout=600)
     assert r.returncode == 0 and "40 cases ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+def test_spec_state_contract_through_the_c_abi():
+    """gsr_forward_speculative with state == NULL is gsr_forward; a state sized for one image size is refused for another
+    (GSR_E_INVALID + message) instead of being read out of bounds."""
+    import ctypes as C
+    from gs_localization_amd import _lib
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    sc = S.small(P=2000, W=64, H=48, sh_degree=1, seed=31)
+    cam = U.scene_inputs(sc)
+    t = lambda a: torch.tensor(np.ascontiguousarray(a, np.float32), device=dev)
+    means, opac, shs, scales, rots = t(sc.means3D), t(sc.opacities), t(sc.shs), t(sc.scales), t(sc.rotations)
+    bg, view, proj, campos = t(sc.bg), t(cam["view"]), t(cam["proj"]), t(cam["campos"])
+
+    def call(state, W, H):
+        bufs = [RZ._Workspace(dev) for _ in range(3)]
+        color = torch.empty((3, H, W), device=dev); depth = torch.empty((1, H, W), device=dev); alpha = torch.empty((1, H, W), device=dev)
+        radii = torch.empty(sc.P, dtype=torch.int32, device=dev)
+        rc = lib.gsr_forward_speculative(state, bufs[0].fn, None, bufs[1].fn, None, bufs[2].fn, None, sc.P, 1, 4, bg.data_ptr(), W, H,
+                                         means.data_ptr(), shs.data_ptr(), None, opac.data_ptr(), scales.data_ptr(), 1.0, rots.data_ptr(),
+                                         None, view.data_ptr(), proj.data_ptr(), campos.data_ptr(), sc.tanfovx, sc.tanfovy, 0,
+                                         color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), radii.data_ptr(), 0, None,
+                                         torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        return rc, color
+    rc0, c0 = call(None, sc.W, sc.H)
+    assert rc0 > 0
+    st = _lib.SpecState()
+    buf = torch.empty(int(lib.gsr_spec_state_bytes(sc.W, sc.H)), dtype=torch.uint8, device=dev)
+    st.device_buffer = buf.data_ptr()
+    rc1, c1 = call(C.byref(st), sc.W, sc.H)
+    rc2, c2 = call(C.byref(st), sc.W, sc.H)
+    assert rc1 == rc0 and st.valid == 1 and st.last_speculative == 1 and st.n_speculative == 1
+    assert torch.equal(c0, c1) and torch.equal(c0, c2)
+    rc3, _ = call(C.byref(st), sc.W + 16, sc.H)
+    assert rc3 < 0 and b"another image size" in lib.gsr_last_error()
