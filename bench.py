@@ -77,7 +77,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    from gs_localization_amd import _lib, scenes as S, pipelines as PL, shard
+    from gs_localization_amd import _lib, scenes as S, shard
+    from tests import replay as PL      # the reference-style Python loop on the drop-in packages (test infrastructure)
     lib = _lib.load()
     assert lib.gsr_device_ok() == 1, "no gfx950 device"
 
@@ -86,23 +87,12 @@ def main():
     W, H, M = sc.W, sc.H, sc.shs.shape[1]
     N, ntiles = W * H, ((W + 15) // 16) * ((H + 15) // 16)
     model = PL.GaussianMap.from_scene(sc, device=dev, requires_grad=not args.pose_only)
-    pipe = PL.PipelineParams()
     background = torch.zeros(3, dtype=torch.float32, device=dev)
-    proj = PL.getProjectionMatrix2(znear=0.01, zfar=100.0, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, W=W, H=H).transpose(0, 1).to(dev)
-    fovx, fovy = PL.focal2fov(sc.fx, W), PL.focal2fov(sc.fy, H)
     config = PL.TRACKING_CONFIG
     w2c_gt = np.eye(4)
 
     def make_view(uid):
-        gt = torch.tensor(w2c_gt, dtype=torch.float32, device=dev)
-        vp = PL.Camera(uid, None, None, gt, proj, sc.fx, sc.fy, sc.cx, sc.cy, fovx, fovy, H, W, device=dev)
-        vp.update_RT(gt[:3, :3].clone(), gt[:3, 3].clone())
-        with torch.no_grad():
-            pkg = PL.render(vp, model, pipe, background)
-        vp.original_image = pkg["render"].detach().clone()
-        vp.depth = pkg["depth"].detach()[0].clone()
-        vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=dev)
-        return vp
+        return PL.make_frame(sc, model, dev, background, uid=uid)
 
     # query frames of this rank (global ids rank*F .. rank*F+F-1): GT pose = identity, start pose off by
     # (2 cm, 1 deg) in a per-frame random direction (SURVEY 8(c) fixture 9)
@@ -121,7 +111,7 @@ def main():
         v.update_RT(i0[:3, :3].clone(), i0[:3, 3].clone())
         for p_ in (v.cam_rot_delta, v.cam_trans_delta, v.exposure_a, v.exposure_b):
             p_.data.zero_()
-        return PL.make_pose_optimizer(v)
+        return PL.pose_adam(v)
 
     def barrier():
         if world > 1:
@@ -140,7 +130,7 @@ def main():
     opt = reset()
     lib.gsr_profile_enable((1 << nk) - 1)
     for _ in range(Wm):
-        conv, _pkg = PL.refine_iteration(vp, config, model, pipe, background, opt)
+        conv, _pkg = PL.loop_iteration(vp, config, model, background, opt)
         bool(conv)
     torch.cuda.synchronize()
     kernels_ms = {k: (v[0] / v[1] if v[1] else 0.0) for k, v in collect().items()}
@@ -150,7 +140,7 @@ def main():
     # scene statistics at the start pose (V, R under the reference rule, R' emitted, R_eff of own binning)
     stats = (C.c_longlong * 4)()
     reset()
-    pkg = PL.render(vp, model, pipe, background)          # fresh graph: saved tensors still alive
+    pkg = PL.render(vp, model, background)          # fresh graph: saved tensors still alive
     sv = pkg["render"].grad_fn.saved_tensors
     _lib.check(lib.gsr_forward_stats(sc.P, W, H, sv[5].data_ptr(), sv[7].data_ptr(), sv[9].data_ptr(), stats,
                                      torch.cuda.current_stream().cuda_stream))
@@ -175,7 +165,7 @@ def main():
     barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(K):
-        conv, _pkg = PL.refine_iteration(vp, config, model, pipe, background, opt)
+        conv, _pkg = PL.loop_iteration(vp, config, model, background, opt)
         bool(conv)          # the reference's `if converged: break` forces this host sync every iteration
     torch.cuda.synchronize(); barrier()
     elapsed_py = time.perf_counter() - t0

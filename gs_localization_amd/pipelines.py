@@ -1,188 +1,19 @@
-"""Host-side mirror of the pose-refinement loop that the metric times.
+"""Native pose refinement of one query frame: the device-resident map container and the host wrapper of `gsr_refine`.
 
-Same names / argument meaning as the reference callers (paths relative to /root/reference):
-  render()             gs_localization/pipelines/tools/__init__.py:24-153
-  Camera               gs_localization/pipelines/tools/camera_utils.py:38-205
-  get_loss_tracking*   gs_localization/pipelines/tools/descent_utils.py:85-123
-  SO3_exp/V/SE3_exp, update_pose   gs_localization/pipelines/tools/pose_utils.py:54-122
-  gradient_decent      gs_localization/pipelines/7scenes_localize_full_dslam.py:29-93
-  getProjectionMatrix2, getWorld2View2   gs_localization/pipelines/tools/graphics_utils.py:38-98
-  pose errors          gs_localization/pipelines/7scenes_localize_full_dslam.py:368-377
+What the reference does per frame in Python -- `gradient_decent()`,
+gs_localization/pipelines/7scenes_localize_full_dslam.py:29-93: up to fifty times { render through the pose rasterizer,
+tracking loss, backward, Adam step, update_pose, convergence test } -- runs here as ONE C-ABI call (include/gsr.h,
+`gsr_refine`).  The caller's camera object is used as it is (duck-typed: R, T, exposure_a/b, projection_matrix, FoVx/FoVy,
+original_image, depth, grad_mask, update_RT -- the attributes of tools/camera_utils.py:38-158), so a script written against the
+reference's `Camera` can hand its viewpoint straight to `FusedRefiner.refine`.
 
-The reference scripts themselves cannot run here (hard-coded D:/ paths, h5py/cv2/munch/plyfile
-missing, no datasets -- SURVEY.md section 0 fact 5); this module replays their call sequence so that the
-drop-in packages are exercised exactly as those scripts would exercise them.
+The reference-style Python loop on the drop-in packages (what the unchanged scripts would execute) is test infrastructure
+and lives in tests/replay.py.
 """
 import math
 
 import numpy as np
 import torch
-from torch import nn
-
-from diff_gaussian_rasterization_pose import GaussianRasterizationSettings, GaussianRasterizer
-
-
-# ------------------------------------------------------------------ graphics_utils
-def getWorld2View2(R, t, translate=None, scale=1.0):
-    Rt = torch.zeros((4, 4), device=R.device, dtype=R.dtype)
-    Rt[:3, :3] = R
-    Rt[:3, 3] = t
-    Rt[3, 3] = 1.0
-    if translate is None and scale == 1.0:
-        return Rt      # inverse(inverse(Rt)) of graphics_utils.py:38-51 with the default arguments
-    C2W = torch.linalg.inv(Rt)
-    C2W[:3, 3] = (C2W[:3, 3] + translate.to(R.device)) * scale
-    return torch.linalg.inv(C2W)
-
-
-def getProjectionMatrix2(znear, zfar, cx, cy, fx, fy, W, H):
-    left = ((2 * cx - W) / W - 1.0) * W / 2.0
-    right = ((2 * cx - W) / W + 1.0) * W / 2.0
-    top = ((2 * cy - H) / H + 1.0) * H / 2.0
-    bottom = ((2 * cy - H) / H - 1.0) * H / 2.0
-    left = znear / fx * left
-    right = znear / fx * right
-    top = znear / fy * top
-    bottom = znear / fy * bottom
-    P = torch.zeros(4, 4)
-    z_sign = 1.0
-    P[0, 0] = 2.0 * znear / (right - left)
-    P[1, 1] = 2.0 * znear / (top - bottom)
-    P[0, 2] = (right + left) / (right - left)
-    P[1, 2] = (top + bottom) / (top - bottom)
-    P[3, 2] = z_sign
-    P[2, 2] = z_sign * zfar / (zfar - znear)
-    P[2, 3] = -(zfar * znear) / (zfar - znear)
-    return P
-
-
-def focal2fov(focal, pixels):
-    return 2 * math.atan(pixels / (2 * focal))
-
-
-# ------------------------------------------------------------------ pose_utils
-def skew_sym_mat(x):
-    ssm = torch.zeros(3, 3, device=x.device, dtype=x.dtype)
-    ssm[0, 1] = -x[2]
-    ssm[0, 2] = x[1]
-    ssm[1, 0] = x[2]
-    ssm[1, 2] = -x[0]
-    ssm[2, 0] = -x[1]
-    ssm[2, 1] = x[0]
-    return ssm
-
-
-def SO3_exp(theta):
-    W = skew_sym_mat(theta)
-    W2 = W @ W
-    angle = torch.norm(theta)
-    I = torch.eye(3, device=theta.device, dtype=theta.dtype)
-    if angle < 1e-5:
-        return I + W + 0.5 * W2
-    return I + (torch.sin(angle) / angle) * W + ((1 - torch.cos(angle)) / (angle**2)) * W2
-
-
-def V(theta):
-    I = torch.eye(3, device=theta.device, dtype=theta.dtype)
-    W = skew_sym_mat(theta)
-    W2 = W @ W
-    angle = torch.norm(theta)
-    if angle < 1e-5:
-        return I + 0.5 * W + (1.0 / 6.0) * W2
-    return I + W * ((1.0 - torch.cos(angle)) / (angle**2)) + W2 * ((angle - torch.sin(angle)) / (angle**3))
-
-
-def SE3_exp(tau):
-    rho = tau[:3]
-    theta = tau[3:]
-    T = torch.eye(4, device=tau.device, dtype=tau.dtype)
-    T[:3, :3] = SO3_exp(theta)
-    T[:3, 3] = V(theta) @ rho
-    return T
-
-
-def update_pose(camera, converged_threshold=1e-4):
-    tau = torch.cat([camera.cam_trans_delta, camera.cam_rot_delta], axis=0)
-    T_w2c = torch.eye(4, device=tau.device)
-    T_w2c[0:3, 0:3] = camera.R
-    T_w2c[0:3, 3] = camera.T
-    new_w2c = SE3_exp(tau) @ T_w2c
-    converged = tau.norm() < converged_threshold
-    camera.update_RT(new_w2c[0:3, 0:3], new_w2c[0:3, 3])
-    camera.cam_rot_delta.data.fill_(0)
-    camera.cam_trans_delta.data.fill_(0)
-    return converged
-
-
-# ------------------------------------------------------------------ camera_utils
-class Camera(nn.Module):
-    def __init__(self, uid, color, depth, gt_T, projection_matrix, fx, fy, cx, cy, fovx, fovy, image_height,
-                 image_width, device="cuda:0"):
-        super().__init__()
-        self.uid = uid
-        self.device = device
-        T = torch.eye(4, device=device)
-        self.R = T[:3, :3]
-        self.T = T[:3, 3]
-        self.R_gt = gt_T[:3, :3]
-        self.T_gt = gt_T[:3, 3]
-        self.original_image = color
-        self.depth = depth
-        self.grad_mask = None
-        self.fx, self.fy, self.cx, self.cy = fx, fy, cx, cy
-        self.FoVx, self.FoVy = fovx, fovy
-        self.image_height, self.image_width = image_height, image_width
-        self.cam_rot_delta = nn.Parameter(torch.zeros(3, requires_grad=True, device=device))
-        self.cam_trans_delta = nn.Parameter(torch.zeros(3, requires_grad=True, device=device))
-        self.exposure_a = nn.Parameter(torch.tensor([0.0], requires_grad=True, device=device))
-        self.exposure_b = nn.Parameter(torch.tensor([0.0], requires_grad=True, device=device))
-        self.projection_matrix = projection_matrix.to(device=device)
-
-    @property
-    def world_view_transform(self):
-        return getWorld2View2(self.R, self.T).transpose(0, 1)
-
-    @property
-    def full_proj_transform(self):
-        return (self.world_view_transform.unsqueeze(0).bmm(self.projection_matrix.unsqueeze(0))).squeeze(0)
-
-    @property
-    def camera_center(self):
-        # = world_view_transform.inverse()[3, :3] of camera_utils.py:156-158 for a rigid W2C
-        return -(self.R.transpose(0, 1) @ self.T)
-
-    def update_RT(self, R, t):
-        self.R = R.to(device=self.device)
-        self.T = t.to(device=self.device)
-
-
-# ------------------------------------------------------------------ descent_utils
-def get_loss_tracking(config, image, depth, opacity, viewpoint, initialization=False):
-    image_ab = (torch.exp(viewpoint.exposure_a)) * image + viewpoint.exposure_b
-    if config["Training"]["monocular"]:
-        return get_loss_tracking_rgb(config, image_ab, depth, opacity, viewpoint)
-    return get_loss_tracking_rgbd(config, image_ab, depth, opacity, viewpoint)
-
-
-def get_loss_tracking_rgb(config, image, depth, opacity, viewpoint):
-    gt_image = viewpoint.original_image.to(image.device)
-    opacity_mask = (opacity > config["Training"]["opacity_threshold"]).view(*depth.shape)
-    l1 = opacity_mask * torch.abs(image * viewpoint.grad_mask - gt_image * viewpoint.grad_mask)
-    return l1.mean()
-
-
-def get_loss_tracking_rgbd(config, image, depth, opacity, viewpoint, initialization=False):
-    alpha = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.98
-    gt_depth = viewpoint.depth
-    if not torch.is_tensor(gt_depth):
-        gt_depth = torch.from_numpy(gt_depth)
-    gt_depth = gt_depth.to(dtype=torch.float32, device=image.device)[None]
-    depth_pixel_mask = (gt_depth > 0.01).view(*depth.shape)
-    opacity_mask = (opacity > config["Training"]["opacity_threshold"]).view(*depth.shape)
-    l1_rgb = get_loss_tracking_rgb(config, image, depth, opacity, viewpoint)
-    depth_mask = depth_pixel_mask * opacity_mask * viewpoint.grad_mask
-    l1_depth = torch.abs(depth * depth_mask - gt_depth * depth_mask)
-    return l1_rgb + (1 - alpha) * l1_depth.mean()
 
 
 # ------------------------------------------------------------------ map container
@@ -220,100 +51,19 @@ class GaussianMap:
     get_rotation = property(lambda s: s._t[4])
 
 
-class PipelineParams:
-    convert_SHs_python = False
-    compute_cov3D_python = False
-    debug = False
-
-
-# ------------------------------------------------------------------ tools/__init__.py render()
-def render(viewpoint_camera, pc, pipe, bg_color, scaling_modifier=1.0, override_color=None, mask=None):
-    if pc.get_xyz.shape[0] == 0:
-        return None
-    screenspace_points = torch.zeros_like(pc.get_xyz, dtype=pc.get_xyz.dtype, requires_grad=True) + 0
-    try:
-        screenspace_points.retain_grad()
-    except Exception:
-        pass
-    tanfovx = math.tan(viewpoint_camera.FoVx * 0.5)
-    tanfovy = math.tan(viewpoint_camera.FoVy * 0.5)
-    raster_settings = GaussianRasterizationSettings(
-        image_height=int(viewpoint_camera.image_height),
-        image_width=int(viewpoint_camera.image_width),
-        tanfovx=tanfovx,
-        tanfovy=tanfovy,
-        bg=bg_color,
-        scale_modifier=scaling_modifier,
-        viewmatrix=viewpoint_camera.world_view_transform,
-        projmatrix=viewpoint_camera.full_proj_transform,
-        projmatrix_raw=viewpoint_camera.projection_matrix,
-        sh_degree=pc.active_sh_degree,
-        campos=viewpoint_camera.camera_center,
-        prefiltered=False,
-        debug=False,
-    )
-    rasterizer = GaussianRasterizer(raster_settings=raster_settings)
-    means3D = pc.get_xyz
-    means2D = screenspace_points
-    opacity = pc.get_opacity
-    if pc.get_scaling.shape[-1] == 1:
-        scales = pc.get_scaling.repeat(1, 3)
-    else:
-        scales = pc.get_scaling
-    rotations = pc.get_rotation
-    shs = pc.get_features if override_color is None else None
-    rendered_image, radii, depth, opacity, n_touched = rasterizer(
-        means3D=means3D, means2D=means2D, shs=shs, colors_precomp=override_color, opacities=opacity, scales=scales,
-        rotations=rotations, cov3D_precomp=None, theta=viewpoint_camera.cam_rot_delta,
-        rho=viewpoint_camera.cam_trans_delta)
-    return {"render": rendered_image, "viewspace_points": screenspace_points, "visibility_filter": radii > 0,
-            "radii": radii, "depth": depth, "opacity": opacity, "n_touched": n_touched}
-
-
-# ------------------------------------------------------------------ the timed loop
-def make_pose_optimizer(viewpoint):
-    """Adam groups of 7scenes_localize_full_dslam.py:33-64"""
-    return torch.optim.Adam([
-        {"params": [viewpoint.cam_rot_delta], "lr": 0.001, "name": "rot_{}".format(viewpoint.uid)},
-        {"params": [viewpoint.cam_trans_delta], "lr": 0.001, "name": "trans_{}".format(viewpoint.uid)},
-        {"params": [viewpoint.exposure_a], "lr": 0.001, "name": "exposure_a_{}".format(viewpoint.uid)},
-        {"params": [viewpoint.exposure_b], "lr": 0.001, "name": "exposure_b_{}".format(viewpoint.uid)},
-    ])
-
-
-def refine_iteration(viewpoint, config, Model, pipeline_params, background, pose_optimizer):
-    """One body of the loop at 7scenes_localize_full_dslam.py:66-91.  Returns (converged, render_pkg)."""
-    render_pkg = render(viewpoint, Model, pipeline_params, background)
-    image, depth, opacity = render_pkg["render"], render_pkg["depth"], render_pkg["opacity"]
-    pose_optimizer.zero_grad()
-    loss_tracking = get_loss_tracking(config, image, depth, opacity, viewpoint)
-    loss_tracking.backward()
-    with torch.no_grad():
-        pose_optimizer.step()
-        converged = update_pose(viewpoint, converged_threshold=1e-4)
-    return converged, render_pkg
-
-
-def gradient_decent(viewpoint, config, initial_R, initial_T, Model, pipeline_params, background, iters=50):
-    viewpoint.update_RT(initial_R, initial_T)
-    pose_optimizer = make_pose_optimizer(viewpoint)
-    render_pkg = None
-    for _ in range(iters):
-        converged, render_pkg = refine_iteration(viewpoint, config, Model, pipeline_params, background, pose_optimizer)
-        if converged:
-            break
-    return viewpoint.R, viewpoint.T, render_pkg
-
-
 class FusedRefiner:
     """gradient_decent() with the whole loop on the device.
 
-    Same inputs, same hyper-parameters and the same result as `gradient_decent` above -- render (B),
-    tracking loss, backward, Adam step, update_pose, early exit on convergence -- but each iteration is
-    the four native calls of `gsr_refine` (include/gsr.h) instead of ~130 torch launches, and autograd is
-    not involved.  `gaussian_grads=True` keeps computing every Gaussian-parameter gradient like the
-    reference does (its map tensors require grad, tools/gaussian_model.py:437-462) although nothing
-    consumes them; `False` is the pose-only fast path."""
+    Same inputs, same hyper-parameters and the same pose trajectory as the reference's loop -- render (B), tracking loss,
+    backward, Adam step, update_pose, early exit on convergence -- but each iteration is a handful of kernels enqueued by
+    `gsr_refine` (include/gsr.h) instead of ~130 torch launches, and autograd is not involved.  `gaussian_grads=True` keeps
+    computing every Gaussian-parameter gradient like the reference does (its map tensors require grad,
+    tools/gaussian_model.py:437-462) although nothing consumes them; `False` is the pose-only fast path.
+
+    One documented difference in what is RETURNED next to the pose: the reference hands back the render_pkg of its last
+    loop body, i.e. the render at the pose BEFORE the last update (7scenes_localize_full_dslam.py:66-93).  `refine` does the
+    same when max_iters is reached; on early convergence its images (render / depth / opacity, radii, n_touched) are those
+    of one more forward at the FINAL pose -- the converged update is below 1e-4, so the two differ by less than that step."""
 
     def __init__(self, Model, image_height, image_width, device="cuda:0", gaussian_grads=True):
         import ctypes as C

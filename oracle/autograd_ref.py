@@ -66,15 +66,17 @@ def eval_sh_deg(deg, sh, d):
 
 def render_autograd(fwd_state, radii, means3D, opacities, w2c, P_raw, W, H, tanfovx, tanfovy, bg, sh_degree=0,
                     shs=None, colors_precomp=None, scales=None, rotations=None, cov3D_precomp=None,
-                    scale_modifier=1.0, tau=None, depth_to_mean=False):
+                    scale_modifier=1.0, tau=None, depth_to_mean=False, se3_exp=None):
     """All tensor inputs are float64 torch tensors (leaf tensors may require grad).
     fwd_state / radii come from an fp32 oracle forward of the same inputs (frozen decisions).
     w2c: 4x4 world-to-camera; P_raw: 4x4 intrinsics projection (not transposed).
     tau: optional 6-vector [rho, theta] (zeros, requires_grad) applied as exp(tau) @ w2c.
+    se3_exp: the exponential to use for that (tests/golden/make_pose_golden.py passes the reference's own SE3_exp,
+    imported from pose_utils.py); default: the restatement above.
     Returns color[3,H,W], depth[H,W], alpha[H,W], aux dict."""
     dt = torch.float64
     Pn = means3D.shape[0]
-    T_w2c = w2c if tau is None else se3_exp_first_order_safe(tau) @ w2c
+    T_w2c = w2c if tau is None else (se3_exp or se3_exp_first_order_safe)(tau) @ w2c
     Rm, tv = T_w2c[:3, :3], T_w2c[:3, 3]
     p_view = means3D @ Rm.T + tv
     full = P_raw @ T_w2c

@@ -98,29 +98,18 @@ def test_missed_guess_is_redone_and_backs_off():
 
 def test_python_loop_uses_the_speculation_and_matches_the_plain_loop():
     """The reference-style loop on the drop-in package: same poses with and without the speculation."""
-    from gs_localization_amd import pipelines as PL
+    from tests import replay as PL
     sc = S.small(P=30000, W=160, H=128, sh_degree=3, seed=11, scale_med=0.04)
     dev = torch.device("cuda:0")
     model = PL.GaussianMap.from_scene(sc, device=dev)
     bg = torch.zeros(3, device=dev)
-    proj = PL.getProjectionMatrix2(0.01, 100.0, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, W=sc.W, H=sc.H).transpose(0, 1).to(dev)
-
-    def view():
-        vp = PL.Camera(0, None, None, torch.eye(4, device=dev), proj, sc.fx, sc.fy, sc.cx, sc.cy, PL.focal2fov(sc.fx, sc.W),
-                       PL.focal2fov(sc.fy, sc.H), sc.H, sc.W, device=dev)
-        return vp
-    vp0 = view()
-    with torch.no_grad():
-        pkg = PL.render(vp0, model, PL.PipelineParams(), bg)
     init = torch.tensor(S.se3_exp(np.array([0.01, -0.008, 0.006, 0.004, -0.003, 0.005])), dtype=torch.float32, device=dev)
     res = {}
     for spec in (False, True):
         os.environ["GSR_SPECULATION"] = "1" if spec else "0"
         RZ._spec_cache.states.clear()
-        vp = view()
-        vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone()
-        vp.grad_mask = torch.ones((1, sc.H, sc.W), dtype=torch.bool, device=dev)
-        R, T, _ = PL.gradient_decent(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), model, PL.PipelineParams(), bg, iters=12)
+        vp = PL.make_frame(sc, model, dev, bg)
+        R, T, _ = PL.python_loop(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), model, bg, iters=12)
         res[spec] = (R.detach().clone(), T.detach().clone(), RZ.speculation_counters())
     os.environ.pop("GSR_SPECULATION", None)
     assert res[False][2] == (0, 0)

@@ -1,7 +1,9 @@
-"""-m gpu : the fused pose-refinement epilogue against plain PyTorch fp32 references of
-the same ops: tracking loss + gradient (torch autograd of the mirror of descent_utils.py, itself pinned to
-the reference by tests/golden), Adam + update_pose (torch.optim.Adam + the mirror of pose_utils.py), and
-the whole native loop against the reference-style Python loop on the same rasterizer."""
+"""-m gpu : the fused pose-refinement epilogue.
+
+Pinned to the reference's own Python through committed fixtures (tests/golden/pose_loop_vectors.npz, produced by
+tests/golden/make_pose_golden.py which imports pose_utils.py / descent_utils.py / camera_utils.py and torch.optim.Adam):
+tracking loss + gradients, Adam + update_pose trajectories, camera matrices, float64 dL/dtau, and an 8-iteration refinement.
+The remaining tests compare the native loop with the reference-style Python loop of tests/replay.py on the same rasterizer."""
 import ctypes as C
 import math
 
@@ -19,121 +21,128 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-@pytest.mark.parametrize("mono", [False, True])
-def test_tracking_loss_kernel_matches_torch_autograd(mono):
-    from gs_localization_amd import _lib, pipelines as PL
-    lib = _lib.load()
-    torch.manual_seed(0)
-    H, W = 37, 53
-    image = torch.rand(3, H, W, device=DEV, requires_grad=True)
-    depth = (torch.rand(1, H, W, device=DEV) * 4 + 0.5).requires_grad_(True)
-    opacity = torch.rand(1, H, W, device=DEV) * 0.1 + 0.93
-    gt = torch.rand(3, H, W, device=DEV)
-    gt_depth = torch.rand(H, W, device=DEV) * 4
-    gt_depth[torch.rand(H, W, device=DEV) < 0.2] = 0
-    mask = torch.rand(1, H, W, device=DEV) < 0.7
+@pytest.fixture(scope="module")
+def pose_golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_loop_vectors.npz"))
 
-    class VP:
-        pass
-    vp = VP()
-    vp.exposure_a = torch.tensor([0.07], device=DEV, requires_grad=True)
-    vp.exposure_b = torch.tensor([-0.03], device=DEV, requires_grad=True)
-    vp.original_image, vp.depth, vp.grad_mask = gt, gt_depth, mask
-    cfg = {"Training": {"monocular": mono, "alpha": 0.99, "opacity_threshold": 0.99}}
-    loss = PL.get_loss_tracking(cfg, image, depth, opacity, vp)
-    loss.backward()
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+@pytest.mark.parametrize("mono", [0, 1])
+def test_tracking_loss_kernel_matches_reference_fixture(pose_golden, tag, mono):
+    """k_tracking_loss against get_loss_tracking + torch autograd of the reference (descent_utils.py:85-123)"""
+    from gs_localization_amd import _lib
+    lib, g = _lib.load(), pose_golden
+    k = f"track_{tag}_"
+    t = lambda a: torch.tensor(np.ascontiguousarray(a), device=DEV)
+    image, depth, opacity, gt, gt_depth = (t(g[k + n]) for n in ("image", "depth", "opacity", "gt", "gt_depth"))
+    H, W = gt_depth.shape
+    m8 = t(g[k + "mask"].reshape(H, W).astype(np.uint8))
+    expo = t(g[k + "exposure"])
     gi, gd, ga = torch.empty_like(image), torch.empty(1, H, W, device=DEV), torch.empty(1, H, W, device=DEV)
     out = torch.empty(4, device=DEV)
-    expo = torch.tensor([0.07, -0.03], device=DEV)
-    m8 = mask.reshape(H, W).to(torch.uint8).contiguous()
-    _lib.check(lib.gsr_tracking_loss(W, H, _p(image.detach()), _p(depth.detach()), _p(opacity), _p(gt), _p(gt_depth), _p(m8),
-                                     _p(expo), 0.99, 0.01, int(mono), _p(gi), _p(gd), _p(ga), _p(out),
-                                     torch.cuda.current_stream().cuda_stream))
+    _lib.check(lib.gsr_tracking_loss(W, H, _p(image), _p(depth), _p(opacity), _p(gt), _p(gt_depth), _p(m8), _p(expo), 0.99, 0.01,
+                                     int(mono), _p(gi), _p(gd), _p(ga), _p(out), torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
-    assert abs(out[0].item() - loss.item()) <= 1e-6 * max(1.0, abs(loss.item()))
-    assert torch.allclose(gi, image.grad, rtol=1e-5, atol=1e-9)
-    dref = depth.grad if depth.grad is not None else torch.zeros_like(gd)
-    assert torch.allclose(gd, dref, rtol=1e-5, atol=1e-9)
+    r = f"track_{tag}_mono{mono}_"
+    loss = float(g[r + "loss"])
+    assert abs(out[0].item() - loss) <= 1e-6 * max(1.0, abs(loss))
+    assert torch.allclose(gi.cpu(), torch.tensor(g[r + "dimage"]), rtol=1e-5, atol=1e-9)
+    assert torch.allclose(gd.cpu(), torch.tensor(g[r + "ddepth"]), rtol=1e-5, atol=1e-9)
     assert float(ga.abs().sum()) == 0.0
-    assert abs(out[1].item() - vp.exposure_a.grad.item()) <= 2e-5 * abs(vp.exposure_a.grad.item()) + 1e-8
-    assert abs(out[2].item() - vp.exposure_b.grad.item()) <= 2e-5 * abs(vp.exposure_b.grad.item()) + 1e-8
+    da, db = g[r + "dexposure"]
+    assert abs(out[1].item() - da) <= 2e-5 * abs(da) + 1e-8
+    assert abs(out[2].item() - db) <= 2e-5 * abs(db) + 1e-8
 
 
-def test_pose_step_matches_torch_adam_and_update_pose():
-    from gs_localization_amd import _lib, pipelines as PL
-    lib = _lib.load()
-    rng = np.random.default_rng(3)
-    proj = PL.getProjectionMatrix2(0.01, 100.0, 320, 240, 525, 525, 640, 480).transpose(0, 1).contiguous()
-    T0 = torch.tensor(S.se3_exp([0.3, -0.2, 0.5, 0.1, -0.3, 0.2]), dtype=torch.float32)
-    cam = PL.Camera(0, None, None, torch.eye(4), proj, 525, 525, 320, 240, 1.0, 1.0, 480, 640, device="cpu")
-    cam.update_RT(T0[:3, :3].clone(), T0[:3, 3].clone())
-    opt = PL.make_pose_optimizer(cam)
+def test_pose_step_matches_reference_adam_and_update_pose_fixture(pose_golden):
+    """k_pose_init / k_pose_step against the reference's Camera, torch.optim.Adam (four groups) and update_pose
+    (camera_utils.py:144-158, 7scenes_localize_full_dslam.py:33-64, pose_utils.py:105-122): 16 recorded steps"""
+    from gs_localization_amd import _lib
+    lib, g = _lib.load(), pose_golden
     st = torch.zeros(_lib.POSE_STATE_FLOATS)
-    st[0:9] = T0[:3, :3].reshape(-1)
-    st[9:12] = T0[:3, 3]
+    st[0:9] = torch.tensor(g["traj_R0"]).reshape(-1)
+    st[9:12] = torch.tensor(g["traj_T0"])
     state = st.to(DEV)
-    proj_d = proj.to(DEV)
+    proj_d = torch.tensor(g["cam_proj_raw_T"]).contiguous().to(DEV)
     stream = torch.cuda.current_stream().cuda_stream
     _lib.check(lib.gsr_pose_init(_p(state), _p(proj_d), stream))
     torch.cuda.synchronize()
-    assert torch.allclose(state[48:64].cpu().reshape(4, 4), cam.world_view_transform, atol=1e-7)
-    assert torch.allclose(state[64:80].cpu().reshape(4, 4), cam.full_proj_transform, rtol=1e-5, atol=1e-6)
-    assert torch.allclose(state[80:83].cpu(), cam.camera_center, atol=1e-6)
-    for it in range(12):
-        scale = 10.0 ** rng.uniform(-6, 1)           # also drives |tau| below the 1e-4 threshold sometimes
-        g = (rng.normal(size=8) * scale).astype(np.float32)
-        cam.cam_rot_delta.grad = torch.tensor(g[0:3])
-        cam.cam_trans_delta.grad = torch.tensor(g[3:6])
-        cam.exposure_a.grad = torch.tensor(g[6:7])
-        cam.exposure_b.grad = torch.tensor(g[7:8])
-        with torch.no_grad():
-            opt.step()
-            conv = bool(PL.update_pose(cam, 1e-4))
-        dtau = torch.tensor(np.concatenate([g[3:6], g[0:3]]), device=DEV)          # [rho, theta]
-        lo = torch.tensor([0.5, g[6], g[7], 0.0], device=DEV)
+    assert torch.allclose(state[48:64].cpu().reshape(4, 4), torch.tensor(g["cam_view"]), atol=1e-7)
+    assert torch.allclose(state[64:80].cpu().reshape(4, 4), torch.tensor(g["cam_fullproj"]), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(state[80:83].cpu(), torch.tensor(g["cam_center"]), atol=1e-6)
+    assert g["traj_converged"].any() and not g["traj_converged"].all()
+    for it, gr in enumerate(g["traj_grads"]):
+        dtau = torch.tensor(np.concatenate([gr[3:6], gr[0:3]]), device=DEV)          # [rho, theta]
+        lo = torch.tensor([0.5, gr[6], gr[7], 0.0], device=DEV)
         _lib.check(lib.gsr_pose_step(_p(state), _p(dtau), _p(lo), _p(proj_d), 0.001, 1e-4, stream))
         torch.cuda.synchronize()
         s = state.cpu()
-        assert torch.allclose(s[0:9].reshape(3, 3), cam.R, atol=2e-6), it
-        assert torch.allclose(s[9:12], cam.T, atol=2e-6), it
-        assert abs(s[18].item() - cam.exposure_a.item()) < 1e-6 and abs(s[19].item() - cam.exposure_b.item()) < 1e-6
-        assert bool(s[37].item()) == conv, it
+        assert torch.allclose(s[0:9].reshape(3, 3), torch.tensor(g["traj_R"][it]), atol=2e-6), it
+        assert torch.allclose(s[9:12], torch.tensor(g["traj_T"][it]), atol=2e-6), it
+        ea, eb = g["traj_exposure"][it]
+        assert abs(s[18].item() - ea) < 1e-6 and abs(s[19].item() - eb) < 1e-6
+        assert bool(s[37].item()) == bool(g["traj_converged"][it]), it
         assert float(s[12:18].abs().sum()) == 0.0
-        assert torch.allclose(s[48:64].reshape(4, 4), cam.world_view_transform, atol=2e-6)
+        assert torch.allclose(s[48:64].reshape(4, 4), torch.tensor(g["traj_view"][it]), atol=2e-6)
+
+
+@pytest.mark.parametrize("name", ["sh3", "offcentre_white", "partial_tiles"])
+def test_pose_gradient_matches_float64_fixture(pose_golden, name):
+    """dL/dtau of the HIP path against float64 autograd through the REFERENCE's SE3_exp (SURVEY.md 8(c) fixture 8)"""
+    from tests import util as U
+    g = pose_golden
+    P, W, H, deg, seed = (int(x) for x in g[f"tau_{name}_scene"])
+    sc = S.small(P=P, W=W, H=H, sh_degree=deg, seed=seed)
+    cx, cy, bg = g[f"tau_{name}_cxcy_bg"]
+    sc.cx, sc.cy = float(cx), float(cy)
+    sc.bg[:] = bg
+    cam = U.scene_inputs(sc, g["tau_w2c"])
+    grads = (g[f"tau_{name}_gc"], g[f"tau_{name}_gd"], np.zeros((1, H, W), np.float32))
+    _, got = U.hip_run(sc, cam, grads, pose=True)
+    assert U.rel_l1(got["tau"], g[f"tau_{name}_expected"]) <= 1e-5
+
+
+def test_native_loop_follows_the_recorded_reference_loop(pose_golden):
+    """gsr_refine, k iterations, against the pose after k bodies of the reference's loop (its get_loss_tracking, Adam and
+    update_pose around the CPU oracle's render / backward; SURVEY.md 8(c) fixture 9).  Each iteration moves every pose
+    component by ~lr = 1e-3, so agreement to 2e-5 after 8 iterations means every step took the same direction."""
+    from tests import replay as PL
+    g = pose_golden
+    P, W, H, deg, seed = (int(x) for x in g["loop_scene"])
+    sc = S.small(P=P, W=W, H=H, sh_degree=deg, seed=seed, scale_med=float(g["loop_scale_med"]))
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    init = torch.tensor(g["loop_init"], device=DEV)
+    for k in (1, 4, 8):
+        vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, DEV), sc, DEV)
+        vp.original_image = torch.tensor(g["loop_gt_image"], device=DEV)
+        vp.depth = torch.tensor(g["loop_gt_depth"], device=DEV)
+        vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=DEV)
+        for spec in (False, True):
+            fr = PL.FusedRefiner(model, H, W, device=DEV)
+            R, T, info = fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=k, speculative=spec)
+            assert info["iters"] == k
+            assert torch.allclose(R.cpu(), torch.tensor(g["loop_R"][k - 1]), atol=2e-5), (k, spec)
+            assert torch.allclose(T.cpu(), torch.tensor(g["loop_T"][k - 1]), atol=2e-5), (k, spec)
+        assert abs(info["loss"] - float(g["loop_loss"][k - 1])) <= 2e-4 * float(g["loop_loss"][k - 1])
 
 
 def _setup(sc, seed=0):
-    from gs_localization_amd import pipelines as PL
-    W, H = sc.W, sc.H
+    from tests import replay as PL
     model = PL.GaussianMap.from_scene(sc, device=DEV)
     bg = torch.zeros(3, device=DEV)
-    proj = PL.getProjectionMatrix2(0.01, 100.0, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, W=W, H=H).transpose(0, 1).to(DEV)
-    fovx, fovy = PL.focal2fov(sc.fx, W), PL.focal2fov(sc.fy, H)
-    gt = torch.eye(4, device=DEV)
-
-    def view():
-        vp = PL.Camera(0, None, None, gt, proj, sc.fx, sc.fy, sc.cx, sc.cy, fovx, fovy, H, W, device=DEV)
-        with torch.no_grad():
-            pkg = PL.render(vp, model, PL.PipelineParams(), bg)
-        vp.original_image = pkg["render"].detach().clone()
-        vp.depth = pkg["depth"].detach()[0].clone()
-        vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=DEV)
-        return vp
-    rng = np.random.default_rng(seed)
-    dt = rng.normal(size=3); dt *= 0.02 / np.linalg.norm(dt)
-    dr = rng.normal(size=3); dr *= math.radians(1.0) / np.linalg.norm(dr)
-    init = torch.tensor(S.se3_exp(np.concatenate([dt, dr])), dtype=torch.float32, device=DEV)
-    return model, bg, view, init
+    return model, bg, (lambda: PL.make_frame(sc, model, DEV, bg)), PL.perturbed_start(seed, device=DEV)
 
 
 def test_native_loop_matches_python_loop_and_converges():
-    from gs_localization_amd import pipelines as PL
+    from tests import replay as PL
     sc = S.small(P=20000, W=160, H=120, sh_degree=3, seed=5, scale_med=0.03)
     model, bg, view, init = _setup(sc)
     cfg = PL.TRACKING_CONFIG
     for iters in (1, 8):
         vp1, vp2 = view(), view()
-        R1, T1, _ = PL.gradient_decent(vp1, cfg, init[:3, :3].clone(), init[:3, 3].clone(), model, PL.PipelineParams(), bg, iters=iters)
+        R1, T1, _ = PL.python_loop(vp1, cfg, init[:3, :3].clone(), init[:3, 3].clone(), model, bg, iters=iters)
         fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
         R2, T2, info = fr.refine(vp2, cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=iters)
         assert info["iters"] == iters
@@ -151,7 +160,7 @@ def test_native_loop_matches_python_loop_and_converges():
 
 
 def test_native_loop_stops_on_convergence_like_reference():
-    from gs_localization_amd import pipelines as PL
+    from tests import replay as PL
     sc = S.small(P=5000, W=96, H=64, sh_degree=1, seed=6, scale_med=0.05)
     model, bg, view, init = _setup(sc)
     vp = view()
@@ -161,7 +170,7 @@ def test_native_loop_stops_on_convergence_like_reference():
     R, T, info = fr.refine(vp, PL.TRACKING_CONFIG, eye[:3, :3].clone(), eye[:3, 3].clone(), bg, iters=20, converged_threshold=1.0)
     assert info["converged"] and info["iters"] == 1
     vp2 = view()
-    R2, T2, _ = PL.gradient_decent(vp2, PL.TRACKING_CONFIG, eye[:3, :3].clone(), eye[:3, 3].clone(), model, PL.PipelineParams(), bg, iters=20)
+    R2, T2, _ = PL.python_loop(vp2, PL.TRACKING_CONFIG, eye[:3, :3].clone(), eye[:3, 3].clone(), model, bg, iters=20)
     R3, T3, info3 = fr.refine(view(), PL.TRACKING_CONFIG, eye[:3, :3].clone(), eye[:3, 3].clone(), bg, iters=20, stop_on_converged=False)
     assert info3["iters"] == 20
 
@@ -170,7 +179,7 @@ def test_speculative_binning_is_exact_and_falls_back():
     """The native loop drops tile instances behind the depth each tile needed one iteration earlier.  The
     result must not depend on it: same pose as with complete lists, also when the bounds are made
     absurdly tight so that the device-side check fails and forwards are redone."""
-    from gs_localization_amd import pipelines as PL
+    from tests import replay as PL
     sc = S.small(P=60000, W=160, H=128, sh_degree=2, seed=9, scale_med=0.04)
     model, bg, view, init = _setup(sc, seed=2)
     cfg = PL.TRACKING_CONFIG
@@ -197,7 +206,7 @@ def test_concurrent_frames_on_one_gpu_match_sequential():
     """bench.py keeps several frames in flight per GPU (one host thread + one stream each): the library must be
     re-entrant -- same poses as refining the frames one after the other."""
     import threading
-    from gs_localization_amd import pipelines as PL
+    from tests import replay as PL
     sc = S.small(P=30000, W=160, H=128, sh_degree=3, seed=11, scale_med=0.04)
     model, bg, view, _ = _setup(sc)
     cfg = PL.TRACKING_CONFIG
@@ -231,7 +240,7 @@ def test_native_loop_gradient_tensors_stay_consistent():
     """The native loop zero-fills the Gaussian-gradient tensors once and then only touches rows that change
     (dirty bits).  After several iterations they must equal what a fresh autograd backward gives at the
     same pose -- including exact zeros in rows that dropped out of view."""
-    from gs_localization_amd import pipelines as PL
+    from tests import replay as PL
     from tests.util import rel_l1
     sc = S.small(P=40000, W=160, H=128, sh_degree=3, seed=21, scale_med=0.04)
     # make visibility change between iterations: a thick shell of splats right at the near plane
@@ -245,8 +254,8 @@ def test_native_loop_gradient_tensors_stay_consistent():
     frB.refine(vpB, cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=5, stop_on_converged=False)
     for t in (model.get_xyz, model.get_features, model.get_opacity, model.get_scaling, model.get_rotation):
         t.grad = None
-    pkg = PL.render(vpB, model, PL.PipelineParams(), bg)
-    PL.get_loss_tracking(cfg, pkg["render"], pkg["depth"], pkg["opacity"], vpB).backward()
+    pkg = PL.render(vpB, model, bg)
+    PL.tracking_loss(cfg, pkg["render"], pkg["depth"], pkg["opacity"], vpB).backward()
     ref = dict(m3d=model.get_xyz.grad, sh=model.get_features.grad, opac=model.get_opacity.grad,
                scale=model.get_scaling.grad, rot=model.get_rotation.grad)
     got = dict(m3d=frA.g_m3d, sh=frA.g_sh, opac=frA.g_opac, scale=frA.g_scale, rot=frA.g_rot)
@@ -264,7 +273,7 @@ def test_final_state_equals_fresh_render_at_returned_pose(W, H, mono, conv_thr):
     """Whatever the loop did internally (speculation, frozen iterations after convergence, in-kernel clears), what it
     leaves behind -- image, depth, opacity, n_touched, radii -- must be the render of the pose it reports as the last
     forward's, like the reference's last render_pkg.  Odd image sizes, monocular config, early exit."""
-    from gs_localization_amd import pipelines as PL
+    from tests import replay as PL
     sc = S.small(P=12000, W=W, H=H, sh_degree=2, seed=21, scale_med=0.04)
     model, bg, view, init = _setup(sc, seed=4)
     cfg = {"Training": dict(PL.TRACKING_CONFIG["Training"], monocular=mono)}
@@ -283,7 +292,7 @@ def test_final_state_equals_fresh_render_at_returned_pose(W, H, mono, conv_thr):
         chk = view()
         chk.update_RT(Rl.clone(), Tl.clone())
         with torch.no_grad():
-            pkg = PL.render(chk, model, PL.PipelineParams(), bg)
+            pkg = PL.render(chk, model, bg)
         # the native state keeps R, T in fp32 on the device; the camera rebuilt on the host agrees to ~1e-7
         assert torch.allclose(fr.color, pkg["render"], atol=2e-4), float((fr.color - pkg["render"]).abs().max())
         assert torch.allclose(fr.depth, pkg["depth"], atol=2e-3)
@@ -298,7 +307,7 @@ def test_warm_start_of_the_speculation_is_exact():
     """Frame sequences: refine() can start speculating from the bounds the previous call left in the workspace.
     Same result as a cold start -- from the same frame, from a neighbouring pose, and from an unrelated one (where
     the verification has to catch the stale bounds)."""
-    from gs_localization_amd import pipelines as PL
+    from tests import replay as PL
     sc = S.small(P=40000, W=160, H=128, sh_degree=2, seed=13, scale_med=0.04)
     model, bg, view, init = _setup(sc, seed=3)
     cfg = PL.TRACKING_CONFIG
@@ -335,12 +344,12 @@ def test_warm_start_of_the_speculation_is_exact():
 @pytest.mark.parametrize("W,H", [(1920, 1080),       # 8 160 tiles
                                  (2576, 1616)])      # 16 261 tiles (more than a workgroup's LDS could hold bounds for)
 def test_native_loop_on_large_images_matches_python_loop(W, H):
-    from gs_localization_amd import pipelines as PL
+    from tests import replay as PL
     sc = S.small(P=30000, W=W, H=H, sh_degree=2, seed=8, scale_med=0.03)
     model, bg, view, init = _setup(sc)
     cfg = PL.TRACKING_CONFIG
     vp1, vp2 = view(), view()
-    R1, T1, _ = PL.gradient_decent(vp1, cfg, init[:3, :3].clone(), init[:3, 3].clone(), model, PL.PipelineParams(), bg, iters=6)
+    R1, T1, _ = PL.python_loop(vp1, cfg, init[:3, :3].clone(), init[:3, 3].clone(), model, bg, iters=6)
     fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
     R2, T2, info = fr.refine(vp2, cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=6)
     assert info["iters"] == 6
@@ -352,7 +361,7 @@ def test_speculation_on_a_half_empty_scene():
     """Tiles that never saturate (sky, holes in the map) have no finite depth bound: nothing is ever dropped from them,
     so an unsaturated pixel there is not a failed speculation.  Half of this image is dense, the other half sparse and
     faint; the loop must speculate without a single redone forward and agree with complete lists."""
-    from gs_localization_amd import pipelines as PL
+    from tests import replay as PL
     sc = S.small(P=60000, W=160, H=128, sh_degree=1, seed=14, scale_med=0.04)
     right = sc.means3D[:, 0] > 0
     keep = ~right | (np.arange(sc.P) % 40 == 0)            # thin the right half out

@@ -102,53 +102,14 @@ def test_product_never_imports_the_oracle():
         assert "oracle" not in open(os.path.join(ROOT, pkg, "__init__.py")).read()
 
 
-def test_host_maths_against_reference_python_golden(golden):
-    from gs_localization_amd import pipelines as PL, scenes as S
-    for c, Pref in zip(golden["proj_intr"], golden["proj_P"]):
-        fx, fy, cx, cy, W, H = c
-        P = PL.getProjectionMatrix2(0.01, 100.0, cx=cx, cy=cy, fx=fx, fy=fy, W=int(W), H=int(H)).numpy()
-        assert np.allclose(P, Pref, rtol=1e-6, atol=1e-7)
-        assert np.allclose(S.projection_matrix(0.01, 100.0, fx, fy, cx, cy, int(W), int(H)), Pref, rtol=1e-6, atol=1e-7)
-    for tau, Tref in zip(golden["se3_tau"], golden["se3_T"]):
-        assert np.allclose(PL.SE3_exp(torch.tensor(tau)).numpy(), Tref, atol=1e-12)
-        assert np.allclose(S.se3_exp(tau), Tref, atol=1e-12)
-    Rt = torch.tensor(golden["w2v_in"])
-    assert np.allclose(PL.getWorld2View2(Rt[:3, :3], Rt[:3, 3]).numpy(), golden["w2v_out"], atol=1e-12)
-
-
-def test_tracking_loss_against_reference_python_golden(golden):
-    from gs_localization_amd import pipelines as PL
-
-    class VP:
-        pass
-    vp = VP()
-    vp.exposure_a = torch.tensor([float(golden["loss_exposure"][0])])
-    vp.exposure_b = torch.tensor([float(golden["loss_exposure"][1])])
-    vp.original_image = torch.tensor(golden["loss_gt"])
-    vp.depth = golden["loss_gt_depth"]
-    vp.grad_mask = torch.tensor(golden["loss_grad_mask"])
-    for mono in (True, False):
-        cfg = {"Training": {"monocular": mono, "alpha": 0.99, "opacity_threshold": 0.99}}
-        loss = PL.get_loss_tracking(cfg, torch.tensor(golden["loss_image"]), torch.tensor(golden["loss_depth"]),
-                                    torch.tensor(golden["loss_opacity"]), vp)
-        assert abs(loss.item() - float(golden[f"loss_mono{int(mono)}"])) < 1e-7
-
-
-def test_update_pose_semantics():
-    from gs_localization_amd import pipelines as PL
-    proj = PL.getProjectionMatrix2(0.01, 100.0, 320, 240, 525, 525, 640, 480).transpose(0, 1)
-    cam = PL.Camera(0, None, None, torch.eye(4), proj, 525, 525, 320, 240, 1.0, 1.0, 480, 640, device="cpu")
-    with torch.no_grad():
-        cam.cam_trans_delta.copy_(torch.tensor([0.01, 0.0, -0.02]))
-        cam.cam_rot_delta.copy_(torch.tensor([0.0, 0.01, 0.0]))
-        conv = PL.update_pose(cam, 1e-4)
-    assert not bool(conv)
-    assert float(cam.cam_rot_delta.abs().sum()) == 0 and float(cam.cam_trans_delta.abs().sum()) == 0
-    T = PL.SE3_exp(torch.tensor([0.01, 0.0, -0.02, 0.0, 0.01, 0.0]))
-    assert torch.allclose(cam.R, T[:3, :3], atol=1e-7) and torch.allclose(cam.T, T[:3, 3], atol=1e-7)
-    with torch.no_grad():
-        assert bool(PL.update_pose(cam, 1e-4))          # zero delta => converged
-    # camera_center equals the reference's world_view_transform.inverse()[3,:3]
-    assert torch.allclose(cam.camera_center, cam.world_view_transform.inverse()[3, :3], atol=1e-6)
-    te, re = PL.pose_errors(np.eye(3), np.zeros(3), cam.R.numpy(), cam.T.numpy())
-    assert te > 0.02 and 0.5 < re < 0.6
+def test_product_holds_no_restated_reference_python():
+    """The reference-style loop (render / loss / Adam / pose update as the scripts issue them) is test infrastructure
+    (tests/replay.py); the product package offers the native loop only and never imports from tests/."""
+    import gs_localization_amd.pipelines as P
+    for name in ("SE3_exp", "SO3_exp", "update_pose", "get_loss_tracking", "gradient_decent", "render", "Camera", "getProjectionMatrix2"):
+        assert not hasattr(P, name), name
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "gs_localization_amd")):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "from tests" not in src and "import tests" not in src, fn

@@ -149,7 +149,8 @@ def test_render_from_ply_equals_render_from_tensors(tmp_path):
     """The whole route: raw parameters -> point_cloud.ply -> GaussianMap.from_ply -> render, against the same map
     built from torch-activated tensors."""
     import torch
-    from gs_localization_amd import scenes as S, pipelines as PL
+    from gs_localization_amd import scenes as S
+    from tests import replay as PL
     sc = S.small(P=3000, W=96, H=64, sh_degree=3, seed=5)
     raw = dict(xyz=sc.means3D, features_dc=sc.shs[:, :1], features_rest=sc.shs[:, 1:],
                opacity=np.log(sc.opacities / (1 - sc.opacities)).reshape(-1, 1), scaling=np.log(sc.scales),
@@ -162,12 +163,11 @@ def test_render_from_ply_equals_render_from_tensors(tmp_path):
                            torch.exp(t(raw["scaling"])), torch.nn.functional.normalize(t(raw["rotation"])), 3)
     assert m_ply.active_sh_degree == 3
     H, W = sc.H, sc.W
-    proj = PL.getProjectionMatrix2(0.01, 100.0, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, W=W, H=H).transpose(0, 1).to(dev)
-    vp = PL.Camera(0, None, None, torch.eye(4, device=dev), proj, sc.fx, sc.fy, sc.cx, sc.cy, PL.focal2fov(sc.fx, W), PL.focal2fov(sc.fy, H), H, W, device=dev)
+    vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, dev), sc, dev)
     bg = torch.zeros(3, device=dev)
     with torch.no_grad():
-        a = PL.render(vp, m_ply, PL.PipelineParams(), bg)
-        b = PL.render(vp, m_ref, PL.PipelineParams(), bg)
+        a = PL.render(vp, m_ply, bg)
+        b = PL.render(vp, m_ref, bg)
     for k in ("render", "depth", "opacity"):
         d = (a[k] - b[k]).abs().sum() / b[k].abs().sum().clamp_min(1e-12)
         assert float(d) <= 1e-5, k

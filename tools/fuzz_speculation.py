@@ -5,7 +5,8 @@ with and without speculation -- same poses.  Prints the number of cases, verifie
 import sys, os, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gs_localization_amd import scenes as S, rasterizer as RZ, pipelines as PL
+from gs_localization_amd import scenes as S, rasterizer as RZ
+from tests import replay as PL
 from tests import util as U
 dev = torch.device("cuda:0")
 N = int(os.environ.get("CASES", 120))
@@ -45,11 +46,10 @@ for case in range(N):
     if case % 3 == 0:
         model = PL.GaussianMap.from_scene(sc, device=dev)
         bg = torch.zeros(3, device=dev)
-        proj = PL.getProjectionMatrix2(0.01, 100.0, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, W=W, H=H).transpose(0, 1).to(dev)
         def view():
-            vp = PL.Camera(0, None, None, torch.eye(4, device=dev), proj, sc.fx, sc.fy, sc.cx, sc.cy, PL.focal2fov(sc.fx, W), PL.focal2fov(sc.fy, H), H, W, device=dev)
+            vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, dev), sc, dev)
             with torch.no_grad():
-                pkg = PL.render(vp, model, PL.PipelineParams(), bg)
+                pkg = PL.render(vp, model, bg)
             vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=dev)
             return vp
         init = torch.tensor(S.se3_exp(rng.normal(size=6) * 0.01), dtype=torch.float32, device=dev)

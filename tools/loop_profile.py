@@ -3,15 +3,15 @@ times (ms per iteration) from the library's own profiler."""
 import ctypes as C, sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gs_localization_amd import _lib, scenes as S, pipelines as PL
+from gs_localization_amd import _lib, scenes as S
+from tests import replay as PL
 lib = _lib.load(); dev = torch.device("cuda:0")
 sc = S.s_1m_640(); H, W = sc.H, sc.W
 model = PL.GaussianMap.from_scene(sc, device=dev)
 bg = torch.zeros(3, device=dev)
-proj = PL.getProjectionMatrix2(0.01, 100.0, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, W=W, H=H).transpose(0, 1).to(dev)
-vp = PL.Camera(0, None, None, torch.eye(4, device=dev), proj, sc.fx, sc.fy, sc.cx, sc.cy, PL.focal2fov(sc.fx, W), PL.focal2fov(sc.fy, H), H, W, device=dev)
+vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, dev), sc, dev)
 with torch.no_grad():
-    pkg = PL.render(vp, model, PL.PipelineParams(), bg)
+    pkg = PL.render(vp, model, bg)
 vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=dev)
 init = torch.tensor(S.se3_exp([0.01, 0.01, 0.01, 0.01, 0.0, 0.0]), dtype=torch.float32, device=dev)
 fr = PL.FusedRefiner(model, H, W, device=dev)

@@ -1,39 +1,39 @@
-"""Where the reference-style Python loop (pipelines.refine_iteration on the drop-in package (B)) spends its time on
+"""Where the reference-style Python loop (tests/replay.py loop_iteration on the drop-in package (B)) spends its time on
 S-1M-640: per-phase wall time with a device sync after each phase, next to the unsynchronised loop rate."""
 import sys, os, time, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gs_localization_amd import scenes as S, pipelines as PL
+from gs_localization_amd import scenes as S
+from tests import replay as PL
 dev = torch.device("cuda:0")
 sc = S.s_1m_640(); H, W = sc.H, sc.W
 model = PL.GaussianMap.from_scene(sc, device=dev)
 bg = torch.zeros(3, device=dev)
-proj = PL.getProjectionMatrix2(0.01, 100.0, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, W=W, H=H).transpose(0, 1).to(dev)
-vp = PL.Camera(0, None, None, torch.eye(4, device=dev), proj, sc.fx, sc.fy, sc.cx, sc.cy, PL.focal2fov(sc.fx, W), PL.focal2fov(sc.fy, H), H, W, device=dev)
+vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, dev), sc, dev)
 with torch.no_grad():
-    pkg = PL.render(vp, model, PL.PipelineParams(), bg)
+    pkg = PL.render(vp, model, bg)
 vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=dev)
 rng = np.random.default_rng(7)
 d_t = rng.normal(size=3); d_t *= 0.02 / np.linalg.norm(d_t)
 d_r = rng.normal(size=3); d_r *= math.radians(1.0) / np.linalg.norm(d_r)
 init = torch.tensor(S.se3_exp(np.concatenate([d_t, d_r])), dtype=torch.float32, device=dev)
-pp = PL.PipelineParams(); cfg = PL.TRACKING_CONFIG
+cfg = PL.TRACKING_CONFIG
 
 def loop(K, synced):
     vp.update_RT(init[:3, :3].clone(), init[:3, 3].clone())
-    opt = PL.make_pose_optimizer(vp)
+    opt = PL.pose_adam(vp)
     acc = np.zeros(5)
     sync = torch.cuda.synchronize if synced else (lambda: None)
     torch.cuda.synchronize(); t_all = time.perf_counter()
     for _ in range(K):
         t0 = time.perf_counter()
-        rp = PL.render(vp, model, pp, bg); sync(); t1 = time.perf_counter()
+        rp = PL.render(vp, model, bg); sync(); t1 = time.perf_counter()
         opt.zero_grad()
-        loss = PL.get_loss_tracking(cfg, rp["render"], rp["depth"], rp["opacity"], vp); sync(); t2 = time.perf_counter()
+        loss = PL.tracking_loss(cfg, rp["render"], rp["depth"], rp["opacity"], vp); sync(); t2 = time.perf_counter()
         loss.backward(); sync(); t3 = time.perf_counter()
         with torch.no_grad():
             opt.step(); sync(); t4 = time.perf_counter()
-            conv = PL.update_pose(vp, converged_threshold=1e-4); bool(conv); sync(); t5 = time.perf_counter()      # `if converged: break` reads it back
+            conv = PL.apply_pose_delta(vp, converged_threshold=1e-4); bool(conv); sync(); t5 = time.perf_counter()      # `if converged: break` reads it back
         acc += [t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4]
     torch.cuda.synchronize()
     return (time.perf_counter() - t_all) / K, acc / K

@@ -3,16 +3,16 @@ the number of redone (failed speculative) forwards and the pose error after 50 i
 import sys, os, time, math
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gs_localization_amd import _lib, scenes as S, pipelines as PL
+from gs_localization_amd import _lib, scenes as S
+from tests import replay as PL
 lib = _lib.load(); dev = torch.device("cuda:0")
 for make in (S.s_50k_fern, S.s_800k_chess, S.s_1m_640, S.s_3m_cam):
     sc = make(); H, W = sc.H, sc.W
     model = PL.GaussianMap.from_scene(sc, device=dev)
     bg = torch.zeros(3, device=dev)
-    proj = PL.getProjectionMatrix2(0.01, 100.0, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, W=W, H=H).transpose(0, 1).to(dev)
-    vp = PL.Camera(0, None, None, torch.eye(4, device=dev), proj, sc.fx, sc.fy, sc.cx, sc.cy, PL.focal2fov(sc.fx, W), PL.focal2fov(sc.fy, H), H, W, device=dev)
+    vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, dev), sc, dev)
     with torch.no_grad():
-        pkg = PL.render(vp, model, PL.PipelineParams(), bg)
+        pkg = PL.render(vp, model, bg)
     vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=dev)
     rng = np.random.default_rng(7)
     d_t = rng.normal(size=3); d_t *= 0.02 / np.linalg.norm(d_t)
