@@ -118,9 +118,13 @@ class _SpecCache(threading.local):
 _spec_cache = _SpecCache()
 
 
-def speculation_enabled():
-    """GSR_SPECULATION=0 makes the drop-in packages call the plain gsr_forward every time."""
-    return os.environ.get("GSR_SPECULATION", "1") != "0"
+def speculation_enabled(pose_package):
+    """Whether a drop-in forward carries depth bounds from one call to the next (gsr_forward_speculative).
+    Default: on for the pose package (its caller renders the same frame fifty times, a few millimetres apart), off for
+    package (A) (train.py picks a random camera every step: every guess would miss, and each cached state pins
+    ~17 KB per tile of device memory).  GSR_SPECULATION=1 / 0 forces it on / off for both."""
+    v = os.environ.get("GSR_SPECULATION")
+    return bool(pose_package) if v is None else v != "0"
 
 
 def speculation_counters(device=None):
@@ -151,7 +155,7 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     M = sh.size(1) if sh.numel() != 0 else 0
     geom, binning, img = _Workspace(dev), _Workspace(dev), _Workspace(dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
-    spec = C.byref(_spec_cache.get(lib, dev, stream, W, H)) if (P > 0 and speculation_enabled()) else None
+    spec = C.byref(_spec_cache.get(lib, dev, stream, W, H)) if (P > 0 and speculation_enabled(want_touched)) else None
     with torch.cuda.device(dev):
         rc = lib.gsr_forward_speculative(spec, geom.fn, None, binning.fn, None, img.fn, None, P, int(rs.sh_degree), M, _ptr(bg),
                                          W, H, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),

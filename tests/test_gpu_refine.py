@@ -75,7 +75,7 @@ def test_pose_step_matches_reference_adam_and_update_pose_fixture(pose_golden):
     for it, gr in enumerate(g["traj_grads"]):
         dtau = torch.tensor(np.concatenate([gr[3:6], gr[0:3]]), device=DEV)          # [rho, theta]
         lo = torch.tensor([0.5, gr[6], gr[7], 0.0], device=DEV)
-        _lib.check(lib.gsr_pose_step(_p(state), _p(dtau), _p(lo), _p(proj_d), 0.001, 1e-4, stream))
+        _lib.check(lib.gsr_pose_step(_p(state), _p(dtau), _p(lo), _p(proj_d), 0.001, float(g["traj_threshold"]), stream))
         torch.cuda.synchronize()
         s = state.cpu()
         assert torch.allclose(s[0:9].reshape(3, 3), torch.tensor(g["traj_R"][it]), atol=2e-6), it
@@ -106,8 +106,8 @@ def test_pose_gradient_matches_float64_fixture(pose_golden, name):
 def test_native_loop_follows_the_recorded_reference_loop(pose_golden):
     """gsr_refine, k iterations, against the pose after k bodies of the reference's loop (its get_loss_tracking, Adam and
     update_pose around the CPU oracle's render / backward; SURVEY.md 8(c) fixture 9).  Each iteration moves every pose
-    component by ~lr = 1e-3, so agreement to 2e-5 after 8 iterations means every step took the same direction."""
-    from tests import replay as PL
+    component by ~lr = 1e-3; the poses agree to 2e-6 and the last iteration's dL/dtau to 1e-5."""
+    from tests import replay as PL, util as U
     g = pose_golden
     P, W, H, deg, seed = (int(x) for x in g["loop_scene"])
     sc = S.small(P=P, W=W, H=H, sh_degree=deg, seed=seed, scale_med=float(g["loop_scale_med"]))
@@ -115,17 +115,20 @@ def test_native_loop_follows_the_recorded_reference_loop(pose_golden):
     bg = torch.zeros(3, device=DEV)
     init = torch.tensor(g["loop_init"], device=DEV)
     for k in (1, 4, 8):
-        vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, DEV), sc, DEV)
-        vp.original_image = torch.tensor(g["loop_gt_image"], device=DEV)
-        vp.depth = torch.tensor(g["loop_gt_depth"], device=DEV)
-        vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=DEV)
         for spec in (False, True):
+            vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, DEV), sc, DEV)
+            vp.original_image = torch.tensor(g["loop_gt_image"], device=DEV)
+            vp.depth = torch.tensor(g["loop_gt_depth"], device=DEV)
+            vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=DEV)
             fr = PL.FusedRefiner(model, H, W, device=DEV)
             R, T, info = fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=k, speculative=spec)
             assert info["iters"] == k
-            assert torch.allclose(R.cpu(), torch.tensor(g["loop_R"][k - 1]), atol=2e-5), (k, spec)
-            assert torch.allclose(T.cpu(), torch.tensor(g["loop_T"][k - 1]), atol=2e-5), (k, spec)
-        assert abs(info["loss"] - float(g["loop_loss"][k - 1])) <= 2e-4 * float(g["loop_loss"][k - 1])
+            assert torch.allclose(R.cpu(), torch.tensor(g["loop_R"][k - 1]), atol=2e-6), (k, spec)
+            assert torch.allclose(T.cpu(), torch.tensor(g["loop_T"][k - 1]), atol=2e-6), (k, spec)
+            assert U.rel_l1(fr.g_tau.cpu().numpy(), g["loop_tau"][k - 1]) <= 1e-5, (k, spec)
+        # (the loss is a mean of |render - observation| of a few 1e-2 per pixel, masked by opacity > 0.99: the rasterizers'
+        # 1e-4 image differences and a handful of pixels on the other side of the mask move it by a fraction of a percent)
+        assert abs(info["loss"] - float(g["loop_loss"][k - 1])) <= 2e-2 * float(g["loop_loss"][k - 1])
 
 
 def _setup(sc, seed=0):

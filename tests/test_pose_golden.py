@@ -75,7 +75,7 @@ def test_replay_adam_and_pose_update_against_reference_trajectory(pg):
         fr.exposure_a.grad, fr.exposure_b.grad = torch.tensor(g[6:7]), torch.tensor(g[7:8])
         with torch.no_grad():
             opt.step()
-            conv = bool(RP.apply_pose_delta(fr, 1e-4))
+            conv = bool(RP.apply_pose_delta(fr, float(pg["traj_threshold"])))
         assert conv == bool(pg["traj_converged"][it]), it
         assert torch.allclose(fr.R, torch.tensor(pg["traj_R"][it]), atol=1e-6), it
         assert torch.allclose(fr.T, torch.tensor(pg["traj_T"][it]), atol=1e-6), it

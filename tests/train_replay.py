@@ -1,0 +1,217 @@
+"""TEST INFRASTRUCTURE: BASELINE.json config 4 ("S-train-garden") as a loop.
+
+Replays the call sequence of gaussian_splatting/train.py:71-161 on the drop-in package (A) and the fused epilogue:
+  per iteration   random training camera (:71-75) -> activations + render (gaussian_renderer/__init__.py:18-104) ->
+                  L1 + SSIM + Pearson pseudo-depth loss (:92-108) -> backward with gradients for EVERY Gaussian parameter ->
+                  max_radii2D / add_densification_stats (:142-145) -> Adam on the six parameter groups (:157-158)
+  on the cadence  `iteration > densify_from and iteration % densification_interval == 0` (:147-149): the number of
+                  Gaussians changes.  `GaussianModel.densify_and_prune` itself is out of scope, so the
+                  change is synthetic but consumes the same statistics: prune transparent / oversized splats, then duplicate the
+                  splats with the largest mean screen-space gradient (a sample of the parent's own Gaussian, both shrunk) until
+                  P follows a geometric schedule P0 -> P1; optimizer moments are kept for survivors and zero for newcomers
+                  (cat_tensors_to_optimizer semantics, scene/gaussian_model.py:307-328), the statistics restart from zero.
+What this exercises in the product: workspaces that must regrow, the per-thread speculation state of the drop-in package
+after P changed, random cameras (every speculation misses), white background, SH degree 1, grad_depth != 0.
+Used by tests/test_gpu_train_replay.py (parity at several P against the oracle) and by bench.py's `train_step` leg.
+"""
+import math
+
+import numpy as np
+import torch
+
+from diff_gaussian_rasterization import GaussianRasterizationSettings, GaussianRasterizer
+from gs_localization_amd import scenes as S, train_epilogue as TE
+
+LRS = dict(xyz=1.6e-4, f_dc=2.5e-3, f_rest=2.5e-3 / 20.0, opacity=5e-2, scaling=5e-3, rotation=1e-3)      # arguments/__init__.py:75-82
+
+
+def garden_scene(P, W=1296, H=840, seed=0):
+    sc = S._draw("S-train-garden", P, W, H, 0.9 * W, 0.9 * W, 0.5, 6.0, 0.012, 0.6, 1, seed)
+    sc.bg[:] = 1.0
+    return sc
+
+
+class TrainReplay:
+    def __init__(self, P0=200_000, P1=1_500_000, W=1296, H=840, device="cuda:0", n_views=16, seed=0, densify_from=500,
+                 densification_interval=100, densify_until=7000, lambda_dssim=0.2, depth_weight=0.1):
+        self.dev = torch.device(device)
+        self.W, self.H = W, H
+        self.P0, self.P1 = P0, P1
+        self.densify_from, self.interval, self.densify_until = densify_from, densification_interval, densify_until
+        self.lambda_dssim, self.depth_weight = lambda_dssim, depth_weight
+        self.scene = garden_scene(P0, W, H, seed)
+        sc = self.scene
+        t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=self.dev)
+        self.par = dict(xyz=t(sc.means3D), f_dc=t(sc.shs[:, :1]), f_rest=t(sc.shs[:, 1:]),
+                        opacity=torch.logit(t(sc.opacities).clamp(1e-4, 1 - 1e-4)), scaling=torch.log(t(sc.scales)),
+                        rotation=t(sc.rotations))
+        for v in self.par.values():
+            v.requires_grad_(True)
+        self.opt = torch.optim.Adam([{"params": [self.par[k]], "lr": LRS[k], "name": k} for k in LRS], lr=0.0, eps=1e-15)
+        self._reset_stats()
+        self.rng = np.random.default_rng(seed + 5)
+        self.gen = torch.Generator(device=self.dev); self.gen.manual_seed(seed + 7)
+        self.bg = torch.ones(3, device=self.dev)
+        self.views = []
+        for v in range(n_views):
+            tau = np.concatenate([self.rng.uniform(-0.4, 0.4, 3), np.radians(self.rng.uniform(-12, 12, 3))]) if v else np.zeros(6)
+            w2c = S.se3_exp(tau)
+            view, proj, _, campos = S.camera_matrices(sc, w2c)
+            self.views.append(dict(w2c=w2c, view=t(view), proj=t(proj), campos=t(campos)))
+        with torch.no_grad():        # observations: renders of the initial model plus noise; pseudo depth ~ inverse depth
+            for vw in self.views:
+                out = self.render(vw)
+                vw["gt"] = (out["image"] + 0.03 * torch.randn(out["image"].shape, device=self.dev, generator=self.gen)).clamp(0, 1)
+                d0 = out["depth"][0]
+                vw["pseudo"] = 100.0 / (d0 + 0.5) + torch.randn(d0.shape, device=self.dev, generator=self.gen)
+        n_events = len([i for i in range(1, densify_until) if i > densify_from and i % densification_interval == 0])
+        self.growth = (P1 / P0) ** (1.0 / max(n_events, 1))
+        self.events = 0
+        self.last = None
+
+    # ------------------------------------------------------------------------------------------------
+    @property
+    def P(self):
+        return self.par["xyz"].shape[0]
+
+    def _reset_stats(self):
+        P = self.par["xyz"].shape[0]
+        self.max_radii2D = torch.zeros(P, device=self.dev)
+        self.xyz_gradient_accum = torch.zeros(P, 1, device=self.dev)
+        self.denom = torch.zeros(P, 1, device=self.dev)
+
+    def rasterizer(self, vw):
+        sc = self.scene
+        return GaussianRasterizer(GaussianRasterizationSettings(
+            image_height=self.H, image_width=self.W, tanfovx=sc.tanfovx, tanfovy=sc.tanfovy, bg=self.bg, scale_modifier=1.0,
+            viewmatrix=vw["view"], projmatrix=vw["proj"], sh_degree=1, campos=vw["campos"], prefiltered=False, debug=False))
+
+    def render(self, vw):
+        p = self.par
+        act = dict(means3D=p["xyz"], shs=torch.cat((p["f_dc"], p["f_rest"]), dim=1), opacities=torch.sigmoid(p["opacity"]),
+                   scales=torch.exp(p["scaling"]), rotations=torch.nn.functional.normalize(p["rotation"]))
+        means2D = torch.zeros_like(p["xyz"], requires_grad=True)
+        image, radii, depth, alpha = self.rasterizer(vw)(means2D=means2D, colors_precomp=None, cov3D_precomp=None, **act)
+        return dict(image=image, radii=radii, depth=depth, alpha=alpha, means2D=means2D, act=act)
+
+    def step(self, iteration, events=None, keep=False):
+        """One body of train.py's loop.  events: optional list of 5 torch.cuda.Event to record the phase boundaries
+        (render | loss | backward | statistics + densification + Adam).  keep: retain the rasterizer-boundary tensors and their
+        gradients in self.last (for the parity test)."""
+        rec = (lambda i: events[i].record()) if events else (lambda i: None)
+        rec(0)
+        vi = int(self.rng.integers(len(self.views)))
+        vw = self.views[vi]
+        out = self.render(vw)
+        if keep:
+            for tname in ("opacities", "scales", "rotations", "shs"):
+                out["act"][tname].retain_grad()
+            out["image"].retain_grad(); out["depth"].retain_grad(); out["alpha"].retain_grad()
+        rec(1)
+        loss = TE.training_loss(out["image"], vw["gt"], self.lambda_dssim, out["depth"][0], vw["pseudo"], self.depth_weight)
+        rec(2)
+        loss.backward()
+        rec(3)
+        changed = False
+        if keep:      # gradients at the rasterizer boundary, before the optimizer consumes and clears them
+            a = out["act"]
+            out["act"] = dict(a, means3D=self.par["xyz"].detach().clone())      # (the parameter itself is about to be stepped in place)
+            z = lambda t, like: torch.zeros_like(like) if t is None else t.detach().clone()
+            self.last = dict(view=vw, view_index=vi, loss=float(loss.detach()), **out,
+                             pix_grads=(z(out["image"].grad, out["image"]), z(out["depth"].grad, out["depth"]), z(out["alpha"].grad, out["alpha"])),
+                             grads=dict(means3D=self.par["xyz"].grad.detach().clone(), means2D=out["means2D"].grad.detach().clone(),
+                                        opacities=a["opacities"].grad.detach().clone(), sh=a["shs"].grad.detach().clone(),
+                                        scales=a["scales"].grad.detach().clone(), rotations=a["rotations"].grad.detach().clone()))
+        with torch.no_grad():
+            if iteration < self.densify_until:
+                TE.add_densification_stats(out["radii"], out["means2D"].grad, self.max_radii2D, self.xyz_gradient_accum, self.denom)
+                if iteration > self.densify_from and iteration % self.interval == 0:
+                    self.events += 1
+                    self.densify(int(round(self.P0 * self.growth ** self.events)), size_threshold=20 if iteration > 3000 else None)
+                    changed = True
+            if not changed:           # (after a densification the gradients belong to tensors that no longer exist)
+                self.opt.step()
+            self.opt.zero_grad(set_to_none=True)
+        rec(4)
+        return loss.detach()
+
+    # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def densify(self, target_P, size_threshold=None):
+        p = self.par
+        P = self.P
+        grads = (self.xyz_gradient_accum / self.denom).squeeze(1)
+        grads[grads.isnan()] = 0.0
+        prune = torch.sigmoid(p["opacity"]).squeeze(1) < 0.005
+        if size_threshold:
+            prune |= self.max_radii2D > size_threshold
+        if int(prune.sum()) > P // 20:        # keep the schedule: never more than 5 % at once
+            prune &= torch.rand(P, device=self.dev, generator=self.gen) < (P / 20) / float(prune.sum())
+        keep_idx = torch.nonzero(~prune).squeeze(1)
+        n_new = max(0, min(target_P, self.P1) - keep_idx.numel())
+        grads[prune] = -1.0
+        src = torch.topk(grads, min(n_new, P)).indices if n_new else keep_idx[:0]
+        while src.numel() < n_new:            # more newcomers than parents: take the best again
+            src = torch.cat((src, src[: n_new - src.numel()]))
+        sc_src = torch.exp(p["scaling"][src])
+        q = torch.nn.functional.normalize(p["rotation"][src])
+        r, x, y, z = q.unbind(1)
+        Rm = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                          2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+        offs = torch.bmm(Rm, (sc_src * torch.randn(sc_src.shape, device=self.dev, generator=self.gen)).unsqueeze(-1)).squeeze(-1)
+        shrink = math.log(1.6)
+        new = dict(xyz=p["xyz"][src] + offs, f_dc=p["f_dc"][src], f_rest=p["f_rest"][src], opacity=p["opacity"][src],
+                   scaling=p["scaling"][src] - shrink, rotation=p["rotation"][src])
+        parent = torch.zeros(P, dtype=torch.bool, device=self.dev)
+        parent[src] = True
+        for group in self.opt.param_groups:
+            name = group["name"]
+            old = group["params"][0]
+            st = self.opt.state.pop(old, None)
+            kept = old.detach()[keep_idx]
+            if name == "scaling":
+                kept = kept - shrink * parent[keep_idx].unsqueeze(1).float()
+            fresh = torch.nn.Parameter(torch.cat((kept, new[name]), dim=0).contiguous().requires_grad_(True))
+            if st is not None:
+                for k in ("exp_avg", "exp_avg_sq"):
+                    st[k] = torch.cat((st[k][keep_idx], torch.zeros_like(new[name])), dim=0)
+                self.opt.state[fresh] = st
+            group["params"][0] = fresh
+            p[name] = fresh
+        self._reset_stats()
+
+    # ------------------------------------------------------------------------------------------------
+    def as_scene(self, act=None):
+        """The model at the rasterizer boundary (post-activation, numpy) as a scenes.Scene, for the CPU oracle."""
+        if act is None:
+            with torch.no_grad():
+                act = self.render(self.views[0])["act"]
+        n = lambda t: np.ascontiguousarray(t.detach().cpu().numpy(), np.float32)
+        sc = self.scene
+        return S.Scene(name=f"S-train-garden@{self.P}", W=self.W, H=self.H, fx=sc.fx, fy=sc.fy, cx=sc.cx, cy=sc.cy, znear=sc.znear,
+                       zfar=sc.zfar, sh_degree=1, means3D=n(act["means3D"]), scales=n(act["scales"]), rotations=n(act["rotations"]),
+                       opacities=n(act["opacities"]), shs=n(act["shs"]), bg=np.ones(3, np.float32))
+
+
+def time_steps(tr, first_iteration, n, warm=3):
+    """ms per step and per phase over n steps (no densification inside: the caller picks the window)."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    it = first_iteration
+    for _ in range(warm):
+        tr.step(it); it += 1
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tr.step(it); it += 1
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / n
+    acc = np.zeros(4)
+    m = min(n, 10)
+    for _ in range(m):
+        tr.step(it, events=ev); it += 1
+        torch.cuda.synchronize()
+        acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+    acc /= m
+    return dict(P=tr.P, ms_per_step=1e3 * wall, render_fwd_ms=acc[0], loss_epilogue_ms=acc[1], backward_ms=acc[2],
+                stats_and_adam_ms=acc[3]), it
