@@ -2,8 +2,7 @@
 // Replaces CudaRasterizer::Rasterizer::{forward,backward,markVisible}
 // (reference: cuda_rasterizer/rasterizer_impl.cu:141-153,197-339,343-444).
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
-#include <rocprim/device/device_radix_sort.hpp>
+#include <hipcub/hipcub.hpp>          // distCUDA2 only (Morton sort); the rasterizer itself uses no library kernels
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,6 +10,7 @@
 #include <vector>
 #include <mutex>
 #include <atomic>
+#include <thread>
 
 #include "gsr.h"
 #include "gsr_kernels.h"
@@ -44,9 +44,10 @@ int fail(int code, const char* fmt, const char* a = "", const char* b = "")
     } while (0)
 
 // ---- optional per-kernel HIP-event timing (gsr_profile_*) ----
-enum KernelId { K_PREPROCESS = 0, K_SCAN, K_EMIT, K_SORT, K_RANGES, K_RENDER_FWD, K_BWD_ZERO, K_RENDER_BWD, K_PREPROCESS_BWD, K_DEPTH_SORT, K_SH_COLOR, K_COUNT };
-const char* const kKernelNames[K_COUNT] = {"preprocess_fwd", "scan", "emit", "sort", "ranges", "render_fwd",
-                                           "bwd_zero", "render_bwd", "preprocess_bwd", "depth_sort", "sh_color"};
+enum KernelId { K_PREPROCESS = 0, K_SH_COLOR, K_TILE_COUNT, K_TILE_SCAN, K_TILE_EMIT, K_RENDER_FWD, K_BWD_ZERO, K_RENDER_BWD, K_PREPROCESS_BWD,
+                K_POSE_STEP, K_COUNT };
+const char* const kKernelNames[K_COUNT] = {"preprocess_fwd", "sh_color", "tile_count", "tile_scan", "tile_emit", "render_fwd",
+                                           "bwd_zero", "render_bwd", "preprocess_bwd", "pose_step"};
 struct Profiler {
     std::mutex mu;
     unsigned mask = 0;
@@ -83,20 +84,6 @@ struct ProfScope {
     }
 };
 
-// Depth sort of the P Gaussians (32-bit key, 32-bit index).  rocPRIM's default picks a merge sort below 2^20
-// items (1 block sort + 10 merge passes, ~160 us at P = 1 M on MI355X); Onesweep with 512x16-item blocks and
-// wave-match ranking measured 115 us (tools/micro/sort_bench2.hip), so that configuration is pinned here.
-using DepthSortConfig = rocprim::radix_sort_config<
-    rocprim::default_config, rocprim::default_config,
-    rocprim::radix_sort_onesweep_config<rocprim::kernel_config<512, 16>, rocprim::kernel_config<512, 16>, 8,
-                                        rocprim::block_radix_rank_algorithm::match>,
-    64 * 1024>;
-inline hipError_t depth_sort(void* tmp, size_t& bytes, const uint32_t* kin, uint32_t* kout, const uint32_t* vin,
-                             uint32_t* vout, unsigned n, hipStream_t st)
-{
-    return rocprim::radix_sort_pairs<DepthSortConfig>(tmp, bytes, kin, kout, vin, vout, n, 0, 32, st);
-}
-
 // 256-byte aligned carving of an opaque workspace; with base == nullptr it only measures.
 struct Carver {
     char* base;
@@ -115,9 +102,7 @@ struct Carver {
 
 struct Geom {   // per-Gaussian state carried from forward to backward
     float* depths; float2* xy; float4* conic_op; float* rgb; float* cov3D; uint8_t* clamped;
-    uint32_t* tiles_touched; uint32_t* offsets; ushort4* rects; float* acc; double* tau_acc; uint8_t* dirty;
-    uint32_t* depth_key; uint32_t* depth_key_sorted; uint32_t* order_in; uint32_t* order; uint32_t* tt_sorted;
-    char* scan_tmp; size_t scan_bytes; char* dsort_tmp; size_t dsort_bytes;
+    uint32_t* tiles_touched; ushort4* rects; float* acc; double* tau_acc; uint8_t* dirty;
 };
 size_t carve_geom(char* base, int P, Geom& g)
 {
@@ -130,27 +115,23 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.cov3D = c.take<float>(6 * n);
     g.clamped = c.take<uint8_t>(n);
     g.tiles_touched = c.take<uint32_t>(n);
-    g.offsets = c.take<uint32_t>(n);
     g.rects = c.take<ushort4>(n);
     g.acc = c.take<float>(GSR_ACC_STRIDE * n);
     g.dirty = c.take<uint8_t>(n);
     g.tau_acc = c.take<double>(8 * GSR_TAU_SLOTS);
-    g.depth_key = c.take<uint32_t>(n);
-    g.depth_key_sorted = c.take<uint32_t>(n);
-    g.order_in = c.take<uint32_t>(n);
-    g.order = c.take<uint32_t>(n);
-    g.tt_sorted = c.take<uint32_t>(n);
-    g.dsort_bytes = 0;
-    (void)depth_sort(nullptr, g.dsort_bytes, nullptr, nullptr, nullptr, nullptr, (unsigned)n, nullptr);
-    g.dsort_tmp = c.take<char>(g.dsort_bytes);
-    g.scan_bytes = 0;
-    (void)hipcub::DeviceScan::InclusiveSum(nullptr, g.scan_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-    g.scan_tmp = c.take<char>(g.scan_bytes);
     return c.size();
 }
 
+// The aggregated binning kernels keep one (count) or two (emit) LDS words per tile; images with more tiles than this fall
+// back to per-instance atomics in HBM.  At most kTileBinMaxGroups workgroups share the Gaussians (tile_bin_gpb).
+constexpr int kTileBinLdsTiles = 16 * 1024;
+constexpr int kTileBinMaxGroups = 2048;
+
 struct Img {
     uint32_t* n_contrib; uint2* ranges;
+    // exact bins: instances per tile, their exclusive prefix sum (ntiles + 1), how much of each segment has been handed out,
+    // and the total (one word)
+    uint32_t* tile_count; uint32_t* tile_offset; uint32_t* tile_fill; uint32_t* total; uint16_t* block_counts; int copies;
     float* zb[2]; uint32_t* fail;                       // speculative depth bounds of the native loop, verification flag
     float* zbc[2]; int sbx, nsb;                         // bounds per 4x4-tile superblock
     uint32_t* tile_cursor; size_t clear_words;           // bin-by-tile path: per-tile append cursors (GSR_CURSOR_STRIDE apart)
@@ -162,6 +143,14 @@ size_t carve_img(char* base, int W, int H, Img& im)
     const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
     im.n_contrib = c.take<uint32_t>((size_t)W * H);
     im.ranges = c.take<uint2>((size_t)gx * gy);
+    // (counter copies and the per-workgroup count rows only exist on the LDS-aggregated path: up to kTileBinLdsTiles tiles)
+    const size_t nt = (size_t)gx * gy;
+    im.copies = (nt <= (size_t)kTileBinLdsTiles) ? GSR_TBIN_COPIES : 1;
+    im.tile_count = c.take<uint32_t>(nt * im.copies);
+    im.tile_offset = c.take<uint32_t>(nt + 1);
+    im.tile_fill = c.take<uint32_t>(nt * im.copies);
+    im.total = c.take<uint32_t>(1);
+    im.block_counts = c.take<uint16_t>(nt <= (size_t)kTileBinLdsTiles ? nt * kTileBinMaxGroups : 1);
     im.zb[0] = c.take<float>((size_t)gx * gy);
     im.zb[1] = c.take<float>((size_t)gx * gy);
     im.sbx = (gx + 3) / 4;
@@ -176,29 +165,15 @@ size_t carve_img(char* base, int W, int H, Img& im)
     return c.size();
 }
 
-struct Bin {      // per tile instance: tile key (16 bit when the tile count allows, else 32) + Gaussian index
-    void* keys_unsorted; void* keys; uint32_t* vals_unsorted; uint32_t* vals;
-    char* sort_tmp; size_t sort_bytes;
+struct Bin {      // exact bins, per tile instance: the ordered index lists (what the backward reads) + the unordered keys
+    uint32_t* vals; unsigned long long* keys;
 };
-size_t carve_bin(char* base, int R, bool wide_keys, Bin& b)
+size_t carve_bin(char* base, int R, Bin& b)
 {
     Carver c(base);
     const size_t n = R > 0 ? (size_t)R : 1;
     b.vals = c.take<uint32_t>(n);
-    b.vals_unsorted = c.take<uint32_t>(n);
-    b.sort_bytes = 0;
-    if (wide_keys) {
-        b.keys = c.take<uint32_t>(n);
-        b.keys_unsorted = c.take<uint32_t>(n);
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b.sort_bytes, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                                 (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-    } else {
-        b.keys = c.take<uint16_t>(n);
-        b.keys_unsorted = c.take<uint16_t>(n);
-        (void)hipcub::DeviceRadixSort::SortPairs(nullptr, b.sort_bytes, (uint16_t*)nullptr, (uint16_t*)nullptr,
-                                                 (uint32_t*)nullptr, (uint32_t*)nullptr, (int)n);
-    }
-    b.sort_tmp = c.take<char>(b.sort_bytes);
+    b.keys = c.take<unsigned long long>(n);
     return c.size();
 }
 
@@ -212,21 +187,21 @@ size_t carve_bin_local(char* base, int ntiles, BinLocal& b)
     return c.size();
 }
 
-// number of bits needed to hold values < n  (same result as rasterizer_impl.cu:35-50 for n >= 1)
-int bits_for(uint32_t n)
-{
-    int b = 0;
-    while ((n >> b) != 0u) b++;
-    return b;
-}
-
-// set by gsr_refine around its calls: the forward zero-fills the K7 accumulators on the side stream (so the
-// backward need not), and the backward leaves the final dL/dtau conversion to the fused pose step
-thread_local bool tl_native_loop = false;
-// Speculative per-tile depth bounds (native loop only): mode 0 = off, 1 = bin with the bounds the previous
-// iteration recorded and record new ones, 2 = bin everything but record bounds.  parity picks the buffer.
-struct SpecCtx { int mode = 0; int parity = 0; float mul = 1.05f, add = 0.05f; bool local_sort = true; char* state = nullptr; };
-thread_local SpecCtx tl_spec;
+// What the callers inside this library add to a forward / backward pass.  The public gsr_forward / gsr_backward run with a
+// default-constructed context; gsr_forward_speculative fills `spec`; gsr_refine fills everything, per iteration.  (Passed
+// explicitly: the backward may run on another host thread than the forward -- PyTorch's autograd worker -- and a re-entrant
+// caller must never inherit a previous call's settings.)
+// Speculative per-tile depth bounds: mode 0 = off, 1 = bin with the bounds the previous forward recorded and record new
+// ones, 2 = bin everything but record bounds.  parity picks the buffer that is written.
+struct SpecCtx { int mode = 0; int parity = 0; float mul = 1.05f, add = 0.05f; char* state = nullptr; };
+struct PassCtx {
+    bool native_loop = false;      // gsr_refine: gradient tensors and accumulators are maintained by the kernels, not re-zeroed here
+    SpecCtx spec;
+    gsr::LoopGuard guard = {nullptr, nullptr};      // device-side poison / converged words (see LoopGuard)
+    gsr::FusedLoss floss = {};     // tracking loss evaluated in the compositing kernel's epilogue (out == nullptr: not fused)
+    int cov_cache = 0;             // 1 = this forward stores every Gaussian's 3D covariance in the geometry buffer, 2 = reads them back
+    bool lean = false;             // this forward's radii are not an output (see k_preprocess)
+};
 // gsr_forward_speculative: bounds, flags, cursors and the unsorted bins live in the caller's persistent state buffer
 // instead of the per-call image / binning buffers (which then only hold what the backward reads)
 size_t carve_spec(char* base, int W, int H, Img& im, unsigned long long** bins)
@@ -246,20 +221,6 @@ size_t carve_spec(char* base, int W, int H, Img& im, unsigned long long** bins)
     if (bins) *bins = b;
     return c.size();
 }
-// device-side guards of the native loop (see LoopGuard); {nullptr, nullptr} outside gsr_refine
-thread_local gsr::LoopGuard tl_guard = {nullptr, nullptr};
-// set by gsr_refine per iteration: what the loss kernel clears for the next iteration (see LossArgs)
-struct LoopClear { uint32_t* a = nullptr; float* b = nullptr; int n = 0; };
-thread_local LoopClear tl_clear;
-// set by gsr_refine: the tracking loss evaluated in the compositing kernel's epilogue (FusedLoss); out == nullptr otherwise
-thread_local gsr::FusedLoss tl_floss = {};
-// set by gsr_refine: 1 = this forward computes the 3D covariances of all Gaussians into the geometry buffer,
-// 2 = this forward reads them from there (the map is constant during a refinement), 0 = neither
-thread_local int tl_cov_cache = 0;
-// set by gsr_refine: this forward's `radii` cannot be the ones the caller gets (not the last iteration; convergence is
-// checked on the device), so the speculative preprocess may settle most Gaussians with a conservative test
-thread_local bool tl_lean = false;
-thread_local int g_dev = 0;      // device chosen by the last select_device_of on this thread
 
 // One side stream + a fork/join event pair per device: independent work (SH colours, zero fills) runs next to
 // the latency-bound sort chain / the VALU-bound backward compositing instead of in front of them.
@@ -274,13 +235,13 @@ struct Side {
 // queues behind whatever the previous one left on the stream.
 struct SidePool { std::mutex mu; std::vector<Side*> free_list[64]; };
 SidePool g_sides;
-Side* side_acquire()
+Side* side_acquire(int dev)
 {
     static const bool disabled = getenv("GSR_NO_SIDE_STREAM") != nullptr;     // diagnostics
-    if (disabled || g_dev < 0 || g_dev >= 64) return nullptr;
+    if (disabled || dev < 0 || dev >= 64) return nullptr;
     {
         std::lock_guard<std::mutex> l(g_sides.mu);
-        auto& fl = g_sides.free_list[g_dev];
+        auto& fl = g_sides.free_list[dev];
         if (!fl.empty()) { Side* sd = fl.back(); fl.pop_back(); return sd; }
     }
     Side* sd = new Side();
@@ -295,7 +256,7 @@ Side* side_acquire()
 }
 struct SideLease {          // RAII: returns the Side to its device's pool
     Side* sd; int dev;
-    explicit SideLease(bool want) : sd(want ? side_acquire() : nullptr), dev(g_dev) {}
+    SideLease(bool want, int dev_) : sd(want ? side_acquire(dev_) : nullptr), dev(dev_) {}
     ~SideLease()
     {
         if (!sd) return;
@@ -330,7 +291,7 @@ void loop_ctx_release(LoopCtx* c)
     g_loop_ctx.free_list.push_back(c);
 }
 
-int select_device_of(const void* p)
+int select_device_of(const void* p, int* dev_out = nullptr)
 {
     hipPointerAttribute_t attr;
     hipError_t e = hipPointerGetAttributes(&attr, p);
@@ -339,7 +300,7 @@ int select_device_of(const void* p)
         return fail(GSR_E_NODEVICE, "means3D must live in device memory%s", "");
     e = hipSetDevice(attr.device);
     if (e != hipSuccess) return fail(GSR_E_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
-    g_dev = attr.device;
+    if (dev_out) *dev_out = attr.device;
     return GSR_OK;
 }
 
@@ -415,15 +376,47 @@ int gsr_device_ok(void)
 
 size_t gsr_geometry_bytes(int P) { Geom g; return carve_geom(nullptr, P, g); }
 size_t gsr_image_bytes(int width, int height) { Img im; return carve_img(nullptr, width, height, im); }
-size_t gsr_binning_bytes(int num_rendered) { Bin b; return carve_bin(nullptr, num_rendered, true, b); }
+size_t gsr_binning_bytes(int num_rendered) { Bin b; return carve_bin(nullptr, num_rendered, b); }
 
-int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn binning_buffer, void* binning_ctx,
-                gsr_resize_fn image_buffer, void* image_ctx, int P, int D, int M, const float* background, int width,
-                int height, const float* means3D, const float* shs, const float* colors_precomp, const float* opacities,
-                const float* scales, float scale_modifier, const float* rotations, const float* cov3D_precomp,
-                const float* viewmatrix, const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy,
-                int prefiltered, float* out_color, float* out_depth, float* out_alpha, int* radii, int debug,
-                int* n_touched, void* stream)
+namespace {
+
+// Gaussians per workgroup of k_tile_count / k_tile_emit: 2 per lane (2048) aggregate enough in LDS (one add to a tile's counter
+// in HBM per workgroup instead of one per instance) and leave every CU a workgroup or two; more per lane only when the
+// workgroup count would exceed kTileBinMaxGroups (the rows of per-workgroup counts are sized for that many).
+int tile_bin_gpb(int P)
+{
+    int k = (P + kTileBinMaxGroups * GSR_TBIN_THREADS - 1) / (kTileBinMaxGroups * GSR_TBIN_THREADS);
+    if (k < 2) k = 2;
+    return k * GSR_TBIN_THREADS;
+}
+// 16 K tiles = 128 KB of the CU's 160 KB in k_tile_emit: beyond HIP's default 64 KB of dynamic LDS, so the limit is raised
+// once per device.
+int allow_large_lds(int dev)
+{
+    static std::mutex mu;
+    static bool done[64] = {};
+    if (dev < 0 || dev >= 64) return GSR_OK;
+    std::lock_guard<std::mutex> l(mu);
+    if (done[dev]) return GSR_OK;
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gsr::k_tile_count<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gsr::k_tile_count<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gsr::k_tile_emit<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gsr::k_tile_emit<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    done[dev] = true;
+    return GSR_OK;
+}
+
+#define GSR_FWD_PARAMS gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn binning_buffer, void* binning_ctx,                 \
+                       gsr_resize_fn image_buffer, void* image_ctx, int P, int D, int M, const float* background, int width, int height,    \
+                       const float* means3D, const float* shs, const float* colors_precomp, const float* opacities, const float* scales,    \
+                       float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,                   \
+                       const float* projmatrix, const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,    \
+                       float* out_depth, float* out_alpha, int* radii, int debug, int* n_touched, void* stream
+#define GSR_FWD_PASS geometry_buffer, geometry_ctx, binning_buffer, binning_ctx, image_buffer, image_ctx, P, D, M, background, width, \
+                     height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, \
+                     projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii, debug, n_touched, stream
+
+int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
 {
     (void)prefiltered;   // the reference only uses it to trap on a culled point (auxiliary.h:152-156)
     using namespace gsr;
@@ -434,8 +427,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     const size_t N = (size_t)width * height;
     if (P == 0) {
         // rasterize_points.cu:81 skips the rasterizer entirely: outputs stay at their zero fill
-        void* probe = out_color;
-        int rc = select_device_of(probe);
+        int rc = select_device_of(out_color);
         if (rc != GSR_OK) return rc;
         HIPCHK(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), st));
         HIPCHK(hipMemsetAsync(out_depth, 0, N * sizeof(float), st));
@@ -450,7 +442,8 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
         return fail(GSR_E_INVALID, "provide exactly one of (scales, rotations) / cov3D_precomp%s", "");
     if (shs && (M <= 0 || (D + 1) * (D + 1) > M || D < 0 || D > 3))
         return fail(GSR_E_INVALID, "SH degree / coefficient count mismatch%s", "");
-    int rc = select_device_of(means3D);
+    int dev = 0;
+    int rc = select_device_of(means3D, &dev);
     if (rc != GSR_OK) return rc;
 
     const int gx = (width + GSR_TILE - 1) / GSR_TILE, gy = (height + GSR_TILE - 1) / GSR_TILE;
@@ -458,6 +451,7 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     const int ntiles = gx * gy;
     const float focal_y = height / (2.0f * tan_fovy);
     const float focal_x = width / (2.0f * tan_fovx);
+    const SpecCtx& sp = cx.spec;
 
     Geom g;
     const size_t gbytes = carve_geom(nullptr, P, g);
@@ -470,33 +464,35 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
     if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
     carve_img(iptr, width, height, im);
     unsigned long long* state_bins = nullptr;
-    if (tl_spec.state) carve_spec(tl_spec.state, width, height, im, &state_bins);
+    if (sp.state) carve_spec(sp.state, width, height, im, &state_bins);
 
     const int pblocks = (P + GSR_BLOCK - 1) / GSR_BLOCK;
     PreArgs pa;
     pa.P = P; pa.D = D; pa.M = M; pa.W = width; pa.H = height; pa.gx = gx; pa.gy = gy;
     pa.means = means3D; pa.scales = scales; pa.mod = scale_modifier; pa.rots = rotations; pa.opac = opacities;
     pa.shs = shs; pa.cov3D_pre = cov3D_precomp; pa.colors_pre = colors_precomp;
-    pa.cov_all = (tl_cov_cache == 1 && cov3D_precomp == nullptr) ? 1 : 0;
-    if (tl_cov_cache == 2 && cov3D_precomp == nullptr) pa.cov3D_pre = g.cov3D;
+    pa.cov_all = (cx.cov_cache == 1 && cov3D_precomp == nullptr) ? 1 : 0;
+    if (cx.cov_cache == 2 && cov3D_precomp == nullptr) pa.cov3D_pre = g.cov3D;
     pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos;
     pa.tanx = tan_fovx; pa.tany = tan_fovy; pa.fx = focal_x; pa.fy = focal_y;
     pa.radii = radii; pa.xy = g.xy; pa.depths = g.depths; pa.cov3D = g.cov3D; pa.rgb = g.rgb; pa.conic_op = g.conic_op;
     pa.clamped = g.clamped; pa.tiles_touched = g.tiles_touched; pa.rects = g.rects;
-    pa.depth_key = g.depth_key; pa.order_in = g.order_in;
-    pa.guard = tl_guard;
+    pa.guard = cx.guard;
     pa.n_touched = n_touched;
     pa.shc_span = shc_span(P);
-    const float* zb_prev = (tl_spec.mode == 1) ? im.zb[tl_spec.parity ^ 1] : nullptr;
-    float* zb_next = (tl_spec.mode != 0) ? im.zb[tl_spec.parity] : nullptr;
+    // Two ways to a tile's list.  With depth bounds from a previous forward (speculation) the few surviving instances are
+    // appended to fixed-capacity per-tile bins by the preprocess itself; without them every instance is binned exactly
+    // (count -> scan -> emit) and the compositing kernel orders each tile's segment lazily.  (More than 65 536 tiles: the
+    // fixed-capacity bins would not fit; such a forward bins exactly and only records bounds.)
+    const bool by_tile = sp.mode == 1 && ntiles <= 65536;
+    const float* zb_prev = by_tile ? im.zb[sp.parity ^ 1] : nullptr;
+    float* zb_next = (sp.mode != 0) ? im.zb[sp.parity] : nullptr;
     pa.zb = zb_prev;
-    pa.zb_mul = tl_spec.mul; pa.zb_add = tl_spec.add;
-    pa.zbc = zb_prev ? im.zbc[tl_spec.parity ^ 1] : nullptr; pa.sbx = im.sbx;
-    float* zbc_next = (tl_spec.mode != 0) ? im.zbc[tl_spec.parity] : nullptr;
-    // bin-by-tile + in-kernel sort instead of the two global sorts: only with speculative bounds (short lists)
-    const bool local_path = zb_prev != nullptr && tl_spec.local_sort && ntiles <= 65536;
+    pa.zb_mul = sp.mul; pa.zb_add = sp.add;
+    pa.zbc = zb_prev ? im.zbc[sp.parity ^ 1] : nullptr; pa.sbx = im.sbx;
+    float* zbc_next = (sp.mode != 0) ? im.zbc[sp.parity] : nullptr;
     BinLocal bl{nullptr, nullptr};
-    if (local_path) {
+    if (by_tile) {
         // (with a state buffer the unsorted bins live there and the per-call buffer only holds the sorted lists)
         const size_t lbytes = state_bins ? (size_t)ntiles * GSR_LSORT_CAP * sizeof(uint32_t) : carve_bin_local(nullptr, ntiles, bl);
         char* lptr = (char*)binning_buffer(binning_ctx, lbytes);
@@ -504,25 +500,30 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
         if (state_bins) { bl.vals = reinterpret_cast<uint32_t*>(lptr); bl.bins = state_bins; }
         else carve_bin_local(lptr, ntiles, bl);
     }
-    pa.tile_cursor = local_path ? im.tile_cursor : nullptr;
+    pa.tile_cursor = by_tile ? im.tile_cursor : nullptr;
     pa.bins = bl.bins;
+    pa.tile_count = by_tile ? nullptr : im.tile_count;
+    pa.ntiles = ntiles;
     // (on the by-tile path inside gsr_refine these words are cleared by the kernels that consume them: the tile cursors
     // by the compositing kernel, the superblock bounds by the pose step)
-    if (tl_spec.mode != 0 && !(local_path && tl_native_loop)) {
+    if (sp.mode != 0 && !(by_tile && cx.native_loop)) {
         HIPCHK(hipMemsetAsync(im.fail, 0, im.clear_words * sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(zbc_next, 0, (size_t)im.nsb * sizeof(float), st));
     }
     {
         ProfScope ps(K_PREPROCESS, st);
         pa.zbc_lds = (pa.zbc != nullptr && im.nsb <= 4096) ? im.nsb : 0;
-        pa.lean = (tl_lean && tl_native_loop && local_path && pa.cov_all == 0) ? 1 : 0;
-        hipLaunchKernelGGL(k_preprocess, dim3(pblocks), dim3(GSR_BLOCK), (size_t)pa.zbc_lds * sizeof(float), st, pa);
+        pa.lean = (cx.lean && cx.native_loop && by_tile && pa.cov_all == 0) ? 1 : 0;
+        // (the exact-bin path has the preprocess zero the per-tile counters, all copies: at least that many threads)
+        pa.ntiles = ntiles * im.copies;
+        const int blocks = by_tile ? pblocks : std::max(pblocks, (pa.ntiles + GSR_BLOCK - 1) / GSR_BLOCK);
+        hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(GSR_BLOCK), (size_t)pa.zbc_lds * sizeof(float), st, pa);
     }
     LAUNCHCHK("k_preprocess");
     // SH colours only feed the compositing kernel: fork them onto the side stream, join before K6.  (Not on the
-    // bin-by-tile path: without the sort chain there is nothing latency-bound to hide them under, and the
+    // by-tile path: without the binning chain there is nothing latency-bound to hide them under, and the
     // fork/join costs more than it gains -- measured 0.466 vs 0.434 ms per iteration.)
-    SideLease side_lease(colors_precomp == nullptr && !debug && !local_path);
+    SideLease side_lease(colors_precomp == nullptr && !debug && !by_tile, dev);
     Side* side = side_lease.sd;
     if (colors_precomp == nullptr) {
         if (side) {
@@ -537,158 +538,89 @@ int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn
         LAUNCHCHK("k_sh_color");
     }
     int R = 0;
-    Bin b{};
-    if (!local_path) {
-        {   // (1) Gaussians in (depth bits, index) order; culled ones carry key 0xFFFFFFFF and end up last
-            ProfScope ps(K_DEPTH_SORT, st);
-            HIPCHK(depth_sort(g.dsort_tmp, g.dsort_bytes, g.depth_key, g.depth_key_sorted, g.order_in, g.order, (unsigned)P, st));
-        }
+    Bin b{nullptr, nullptr};
+    if (!by_tile) {
+        TileBinArgs ta;
+        ta.P = P; ta.gx = gx; ta.gy = gy; ta.ntiles = ntiles; ta.gpb = tile_bin_gpb(P);
+        ta.tiles_touched = g.tiles_touched; ta.rects = g.rects; ta.xy = g.xy; ta.conic_op = g.conic_op; ta.depths = g.depths;
+        ta.tile_count = im.tile_count; ta.tile_offset = im.tile_offset; ta.tile_fill = im.tile_fill; ta.keys = nullptr;
+        ta.block_counts = im.block_counts; ta.copies = im.copies;
+        const int tblocks = (P + ta.gpb - 1) / ta.gpb;
+        // (LDS aggregation: counters for every tile fit, and a lane keeps its 2 or 4 Gaussians in registers)
+        const int kpt = ta.gpb / GSR_TBIN_THREADS;
+        const bool agg = ntiles <= kTileBinLdsTiles && kpt <= 4;
+        if (agg && ntiles > 8 * 1024) { rc = allow_large_lds(dev); if (rc != GSR_OK) return rc; }
         {
-            ProfScope ps(K_SCAN, st);
-            hipLaunchKernelGGL(k_gather_counts, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
-                               (const uint32_t*)g.tiles_touched, g.tt_sorted);
-            HIPCHK(hipcub::DeviceScan::InclusiveSum(g.scan_tmp, g.scan_bytes, g.tt_sorted, g.offsets, P, st));
+            ProfScope ps(K_TILE_COUNT, st);
+            const size_t lds = (size_t)ntiles * sizeof(uint32_t);
+            if (agg && kpt <= 2) hipLaunchKernelGGL((k_tile_count<true, 2>), dim3(tblocks), dim3(GSR_TBIN_THREADS), lds, st, ta);
+            else if (agg) hipLaunchKernelGGL((k_tile_count<true, 4>), dim3(tblocks), dim3(GSR_TBIN_THREADS), lds, st, ta);
+            else hipLaunchKernelGGL((k_tile_count<false, 2>), dim3(tblocks), dim3(GSR_TBIN_THREADS), 0, st, ta);
         }
-        // one blocking 4-byte read, as rasterizer_impl.cu:282
+        LAUNCHCHK("k_tile_count");
+        {
+            ProfScope ps(K_TILE_SCAN, st);
+            hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, ntiles, agg ? im.copies : 1, im.tile_count, im.tile_offset, im.tile_fill, im.total);
+        }
+        LAUNCHCHK("k_tile_scan");
+        // one blocking 4-byte read, as rasterizer_impl.cu:282: the instance arrays are sized by it
         uint32_t num_rendered_u = 0;
-        HIPCHK(hipMemcpyAsync(&num_rendered_u, g.offsets + (P - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&num_rendered_u, im.total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         if (num_rendered_u > 0x7fffffffu) return fail(GSR_E_INVALID, "more than 2^31 tile instances%s", "");
         R = (int)num_rendered_u;
-
-        const bool wide = ntiles > 65536;
-        const size_t bbytes = carve_bin(nullptr, R, wide, b);
+        const size_t bbytes = carve_bin(nullptr, R, b);
         char* bptr = (char*)binning_buffer(binning_ctx, bbytes);
         if (!bptr) return fail(GSR_E_ALLOC, "binning buffer callback returned NULL%s", "");
-        carve_bin(bptr, R, wide, b);
-
-        HIPCHK(hipMemsetAsync(im.ranges, 0, (size_t)ntiles * sizeof(uint2), st));
+        carve_bin(bptr, R, b);
         if (R > 0) {
-            const int end_bit = bits_for((uint32_t)(ntiles - 1)) > 0 ? bits_for((uint32_t)(ntiles - 1)) : 1;
-            const int rblocks = (R + GSR_BLOCK - 1) / GSR_BLOCK;
-            if (wide) {
-                {
-                    ProfScope ps(K_EMIT, st);
-                    hipLaunchKernelGGL(k_emit_sorted<uint32_t>, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
-                                       (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
-                                       (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, tl_spec.mul, tl_spec.add, (const float*)g.depths,
-                                       (uint32_t*)b.keys_unsorted, b.vals_unsorted);
-                }
-                LAUNCHCHK("k_emit_sorted");
-                {
-                    ProfScope ps(K_SORT, st);
-                    HIPCHK(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, (const uint32_t*)b.keys_unsorted, (uint32_t*)b.keys,
-                                                              (const uint32_t*)b.vals_unsorted, b.vals, R, 0, end_bit, st));
-                }
-                {
-                    ProfScope ps(K_RANGES, st);
-                    hipLaunchKernelGGL(k_ranges<uint32_t>, dim3(rblocks), dim3(GSR_BLOCK), 0, st, R, (const uint32_t*)b.keys, im.ranges);
-                }
-            } else {
-                {
-                    ProfScope ps(K_EMIT, st);
-                    hipLaunchKernelGGL(k_emit_sorted<uint16_t>, dim3(pblocks), dim3(GSR_BLOCK), 0, st, P, (const uint32_t*)g.order,
-                                       (const uint32_t*)g.offsets, (const uint32_t*)g.tt_sorted, (const ushort4*)g.rects,
-                                       (const float2*)g.xy, (const float4*)g.conic_op, gx, gy, zb_prev, tl_spec.mul, tl_spec.add, (const float*)g.depths,
-                                       (uint16_t*)b.keys_unsorted, b.vals_unsorted);
-                }
-                LAUNCHCHK("k_emit_sorted");
-                {   // (3) stable sort on the tile bits only
-                    ProfScope ps(K_SORT, st);
-                    HIPCHK(hipcub::DeviceRadixSort::SortPairs(b.sort_tmp, b.sort_bytes, (const uint16_t*)b.keys_unsorted, (uint16_t*)b.keys,
-                                                              (const uint32_t*)b.vals_unsorted, b.vals, R, 0, end_bit, st));
-                }
-                {
-                    ProfScope ps(K_RANGES, st);
-                    hipLaunchKernelGGL(k_ranges<uint16_t>, dim3(rblocks), dim3(GSR_BLOCK), 0, st, R, (const uint16_t*)b.keys, im.ranges);
-                }
-            }
-            LAUNCHCHK("k_ranges");
+            ta.keys = b.keys;
+            // bands: each band's share of the key array should fit the L2s (8 x 4 MB) with room to spare
+            int bands = (int)(((size_t)R * 8 + (12u << 20) - 1) / (12u << 20));
+            bands = std::max(1, std::min(bands, std::min(gy, 16)));
+            ProfScope ps(K_TILE_EMIT, st);
+            const size_t lds = (size_t)2 * ntiles * sizeof(uint32_t);
+            if (agg && kpt <= 2) hipLaunchKernelGGL((k_tile_emit<true, 2>), dim3(tblocks), dim3(GSR_TBIN_THREADS), lds, st, ta, bands);
+            else if (agg) hipLaunchKernelGGL((k_tile_emit<true, 4>), dim3(tblocks), dim3(GSR_TBIN_THREADS), lds, st, ta, bands);
+            else hipLaunchKernelGGL((k_tile_emit<false, 2>), dim3(tblocks), dim3(GSR_TBIN_THREADS), 0, st, ta, 1);
         }
+        LAUNCHCHK("k_tile_emit");
     }
     const float* feat = colors_precomp ? colors_precomp : g.rgb;
     if (side) HIPCHK(hipStreamWaitEvent(st, side->join, 0));
-    ProfScope* psr = new ProfScope(K_RENDER_FWD, st);
-#define GSR_FWD_ARGS im.ranges, local_path ? bl.vals : b.vals, (const unsigned long long*)bl.bins, im.tile_cursor, \
-                     width, height, gx, ntiles, (const float2*)g.xy, feat, \
+    {
+        ProfScope psr(K_RENDER_FWD, st);
+#define GSR_FWD_ARGS im.ranges, by_tile ? bl.vals : b.vals, by_tile ? (const unsigned long long*)bl.bins : (const unsigned long long*)b.keys, \
+                     by_tile ? im.tile_cursor : im.tile_offset, width, height, gx, ntiles, (const float2*)g.xy, feat, \
                      (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
-                     zb_next, zb_prev, tl_guard.poison ? const_cast<uint32_t*>(tl_guard.poison) : im.fail, \
-                     tl_spec.mul, tl_spec.add, zbc_next, im.sbx, tl_floss
-    if (local_path) {
-        if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
-        else hipLaunchKernelGGL((k_render_fwd<false, true>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
-    } else {
-        if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, false>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
-        else hipLaunchKernelGGL((k_render_fwd<false, false>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+                     zb_next, zb_prev, cx.guard.poison ? const_cast<uint32_t*>(cx.guard.poison) : im.fail, \
+                     sp.mul, sp.add, zbc_next, im.sbx, cx.floss
+        if (by_tile) {
+            if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+            else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+        } else {
+            if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_EXACT>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+            else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_EXACT>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+        }
+#undef GSR_FWD_ARGS
     }
-    delete psr;
     LAUNCHCHK("k_render_fwd");
     return R;
 }
 
-size_t gsr_spec_state_bytes(int width, int height)
-{
-    if (width <= 0 || height <= 0) return 0;
-    Img im; return carve_spec(nullptr, width, height, im, nullptr);
-}
+#define GSR_BWD_PARAMS int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,                    \
+                       const float* shs, const float* colors_precomp, const float* alphas, const float* scales, float scale_modifier,       \
+                       const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,                \
+                       const float* campos, float tan_fovx, float tan_fovy, const int* radii, char* geom_buffer, char* binning_buffer,      \
+                       char* img_buffer, const float* dL_dpix, const float* dL_ddepths, const float* dL_dalphas, float* dL_dmean2D,         \
+                       float* dL_dconic, float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh,          \
+                       float* dL_dscale, float* dL_drot, int debug, int pose_mode, float* dL_dtau, void* stream
+#define GSR_BWD_PASS P, D, M, R, background, width, height, means3D, shs, colors_precomp, alphas, scales, scale_modifier, rotations,        \
+                     cov3D_precomp, viewmatrix, projmatrix, campos, tan_fovx, tan_fovy, radii, geom_buffer, binning_buffer, img_buffer,     \
+                     dL_dpix, dL_ddepths, dL_dalphas, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh,         \
+                     dL_dscale, dL_drot, debug, pose_mode, dL_dtau, stream
 
-int gsr_forward_speculative(gsr_spec_state* s, gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn binning_buffer,
-                            void* binning_ctx, gsr_resize_fn image_buffer, void* image_ctx, int P, int D, int M,
-                            const float* background, int width, int height, const float* means3D, const float* shs,
-                            const float* colors_precomp, const float* opacities, const float* scales, float scale_modifier,
-                            const float* rotations, const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix,
-                            const float* cam_pos, float tan_fovx, float tan_fovy, int prefiltered, float* out_color,
-                            float* out_depth, float* out_alpha, int* radii, int debug, int* n_touched, void* stream)
-{
-    using namespace gsr;
-#define GSR_FWD_PASS geometry_buffer, geometry_ctx, binning_buffer, binning_ctx, image_buffer, image_ctx, P, D, M, background, width, \
-                     height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, \
-                     projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii, debug, n_touched, stream
-    if (tl_native_loop) return fail(GSR_E_INVALID, "gsr_forward_speculative: not callable from inside gsr_refine%s", "");
-    if (!s || !s->device_buffer || P <= 0 || width <= 0 || height <= 0) {
-        if (s) { s->valid = 0; s->last_speculative = 0; }
-        return gsr_forward(GSR_FWD_PASS);
-    }
-    if (s->width == 0 && s->height == 0) { s->width = width; s->height = height; }
-    if (s->width != width || s->height != height)
-        return fail(GSR_E_INVALID, "gsr_forward_speculative: the state was sized for another image size%s", "");
-    hipStream_t st = (hipStream_t)stream;
-    struct Reset { ~Reset() { tl_spec = SpecCtx{}; } } reset;
-    tl_spec = SpecCtx{};
-    tl_spec.state = static_cast<char*>(s->device_buffer);
-    s->last_speculative = 0;
-    const int next = (s->parity ^ 1) & 1;          // the bound buffer this forward writes
-    if (s->valid && s->skip == 0) {
-        tl_spec.mode = 1; tl_spec.parity = next;
-        const int R = gsr_forward(GSR_FWD_PASS);
-        if (R < 0) { s->valid = 0; return R; }
-        Img im; carve_spec(tl_spec.state, width, height, im, nullptr);
-        uint32_t failed = 0;      // the one blocking read of this forward
-        HIPCHK(hipMemcpyAsync(&failed, im.fail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipStreamSynchronize(st));
-        if (failed == 0u) {
-            s->parity = next; s->fail_streak = 0; s->n_speculative++; s->last_speculative = 1;
-            return R;
-        }
-        s->n_failed++; s->fail_streak++;
-        if (s->fail_streak >= 2) s->skip = 1 << (s->fail_streak < 7 ? s->fail_streak - 1 : 6);      // 2, 4, ... 64
-    } else if (s->skip > 0) s->skip--;
-    tl_spec.mode = 2; tl_spec.parity = next;         // complete lists through the global sorts; records the bounds
-    const int R = gsr_forward(GSR_FWD_PASS);
-    if (R < 0) { s->valid = 0; return R; }
-    s->parity = next; s->valid = 1;
-    return R;
-#undef GSR_FWD_PASS
-}
-
-int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
-                 const float* shs, const float* colors_precomp, const float* alphas, const float* scales,
-                 float scale_modifier, const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
-                 const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
-                 char* geom_buffer, char* binning_buffer, char* img_buffer, const float* dL_dpix, const float* dL_ddepths,
-                 const float* dL_dalphas, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
-                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
-                 int pose_mode, float* dL_dtau, void* stream)
+int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
 {
     // dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot may be NULL: that gradient is then not written
     using namespace gsr;
@@ -706,7 +638,8 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
         !dL_dalphas || !dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor)
         return fail(GSR_E_INVALID, "a required backward pointer is NULL%s", "");
     if (pose_mode && !dL_dtau) return fail(GSR_E_INVALID, "pose_mode needs dL_dtau%s", "");
-    int rc = select_device_of(means3D);
+    int dev = 0;
+    int rc = select_device_of(means3D, &dev);
     if (rc != GSR_OK) return rc;
 
     const int gx = (width + GSR_TILE - 1) / GSR_TILE, gy = (height + GSR_TILE - 1) / GSR_TILE;
@@ -714,19 +647,20 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     const float focal_y = height / (2.0f * tan_fovy);
     const float focal_x = width / (2.0f * tan_fovx);
     Geom g; carve_geom(geom_buffer, P, g);
-    Bin b; carve_bin(binning_buffer, R, ntiles > 65536, b);
+    // (the ordered index lists sit at the start of the binning buffer on both binning paths; ranges[] says where)
+    const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer);
     Img im; carve_img(img_buffer, width, height, im);
 
     // Gradient tensors are zero-filled on the side stream while K7 runs; K8/K9 then only writes non-zero rows.
     // (the native loop zero-fills once per frame and keeps the tensors consistent through the dirty bits)
-    SideLease side_lease(!(debug || tl_native_loop));
+    SideLease side_lease(!(debug || cx.native_loop), dev);
     Side* side = side_lease.sd;
     hipStream_t zs = side ? side->st : st;
     if (side) {
         HIPCHK(hipEventRecord(side->fork, st));
         HIPCHK(hipStreamWaitEvent(side->st, side->fork, 0));
     }
-    if (!tl_native_loop) {
+    if (!cx.native_loop) {
         const size_t Pn = (size_t)P;
         HIPCHK(hipMemsetAsync(dL_dmean2D, 0, Pn * 3 * sizeof(float), zs));
         HIPCHK(hipMemsetAsync(dL_dconic, 0, Pn * 4 * sizeof(float), zs));
@@ -739,19 +673,21 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
         if (dL_drot) HIPCHK(hipMemsetAsync(dL_drot, 0, Pn * 4 * sizeof(float), zs));
     }
     if (side) HIPCHK(hipEventRecord(side->join, side->st));
-    // accumulators of K7 (atomically summed)
-    ProfScope* psz = new ProfScope(K_BWD_ZERO, st);
-    if (!tl_native_loop) HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
-    if (pose_mode && !tl_native_loop) HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));
-    delete psz;
+    if (!cx.native_loop) {      // accumulators of K7 (atomically summed)
+        ProfScope psz(K_BWD_ZERO, st);
+        HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
+        if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));
+    }
     const float* color_ptr = colors_precomp ? colors_precomp : g.rgb;
-    ProfScope* psb = new ProfScope(K_RENDER_BWD, st);
-#define GSR_BWD_ARGS (const uint2*)im.ranges, (const uint32_t*)b.vals, width, height, gx, ntiles, background, (const float2*)g.xy, \
+    {
+        ProfScope psb(K_RENDER_BWD, st);
+#define GSR_BWD_ARGS (const uint2*)im.ranges, point_list, width, height, gx, ntiles, background, (const float2*)g.xy, \
                      (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas, (const uint32_t*)im.n_contrib, dL_dpix, \
                      dL_ddepths, dL_dalphas, g.acc
-    if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, tl_guard);
-    else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, tl_guard);
-    delete psb;
+        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard);
+        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard);
+#undef GSR_BWD_ARGS
+    }
     LAUNCHCHK("k_render_bwd");
 
     if (side) HIPCHK(hipStreamWaitEvent(st, side->join, 0));
@@ -766,20 +702,70 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     pb.dL_dmean2D = dL_dmean2D; pb.dL_dconic = dL_dconic; pb.dL_dopacity = dL_dopacity; pb.dL_dcolor = dL_dcolor;
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale; pb.dL_drot = dL_drot;
     pb.pose = pose_mode ? 1 : 0; pb.tau_acc = g.tau_acc;
-    pb.dirty = tl_native_loop ? g.dirty : nullptr;
-    pb.guard = tl_guard;
+    pb.dirty = cx.native_loop ? g.dirty : nullptr;
+    pb.guard = cx.guard;
     {
         ProfScope ps(K_PREPROCESS_BWD, st);
         pb.span = k8_span(P);
         hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + pb.span - 1) / pb.span), dim3(64), 0, st, pb);
     }
     LAUNCHCHK("k_preprocess_bwd");
-    if (pose_mode && !tl_native_loop) {
+    if (pose_mode && !cx.native_loop) {
         hipLaunchKernelGGL(k_tau_finish, dim3(1), dim3(64), 0, st, (const double*)g.tau_acc, dL_dtau);
         LAUNCHCHK("k_tau_finish");
     }
     return 0;
 }
+
+}  // namespace
+
+int gsr_forward(GSR_FWD_PARAMS) { return forward_impl(PassCtx{}, GSR_FWD_PASS); }
+
+size_t gsr_spec_state_bytes(int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    Img im; return carve_spec(nullptr, width, height, im, nullptr);
+}
+
+int gsr_forward_speculative(gsr_spec_state* s, GSR_FWD_PARAMS)
+{
+    using namespace gsr;
+    if (!s || !s->device_buffer || P <= 0 || width <= 0 || height <= 0) {
+        if (s) { s->valid = 0; s->last_speculative = 0; }
+        return forward_impl(PassCtx{}, GSR_FWD_PASS);
+    }
+    if (s->width == 0 && s->height == 0) { s->width = width; s->height = height; }
+    if (s->width != width || s->height != height)
+        return fail(GSR_E_INVALID, "gsr_forward_speculative: the state was sized for another image size%s", "");
+    hipStream_t st = (hipStream_t)stream;
+    PassCtx cx;
+    cx.spec.state = static_cast<char*>(s->device_buffer);
+    s->last_speculative = 0;
+    const int next = (s->parity ^ 1) & 1;          // the bound buffer this forward writes
+    const int ntiles = ((width + GSR_TILE - 1) / GSR_TILE) * ((height + GSR_TILE - 1) / GSR_TILE);
+    if (s->valid && s->skip == 0 && ntiles <= 65536) {
+        cx.spec.mode = 1; cx.spec.parity = next;
+        const int R = forward_impl(cx, GSR_FWD_PASS);
+        if (R < 0) { s->valid = 0; return R; }
+        Img im; carve_spec(cx.spec.state, width, height, im, nullptr);
+        uint32_t failed = 0;      // the one blocking read of this forward
+        HIPCHK(hipMemcpyAsync(&failed, im.fail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (failed == 0u) {
+            s->parity = next; s->fail_streak = 0; s->n_speculative++; s->last_speculative = 1;
+            return R;
+        }
+        s->n_failed++; s->fail_streak++;
+        if (s->fail_streak >= 2) s->skip = 1 << (s->fail_streak < 7 ? s->fail_streak - 1 : 6);      // 2, 4, ... 64
+    } else if (s->skip > 0) s->skip--;
+    cx.spec.mode = 2; cx.spec.parity = next;         // complete lists (exact bins); records the bounds
+    const int R = forward_impl(cx, GSR_FWD_PASS);
+    if (R < 0) { s->valid = 0; return R; }
+    s->parity = next; s->valid = 1;
+    return R;
+}
+
+int gsr_backward(GSR_BWD_PARAMS) { return backward_impl(PassCtx{}, GSR_BWD_PASS); }
 
 int gsr_tracking_loss(int width, int height, const float* image, const float* depth, const float* opacity,
                       const float* gt_image, const float* gt_depth, const uint8_t* grad_mask, const float* exposure,
@@ -795,10 +781,10 @@ int gsr_tracking_loss(int width, int height, const float* image, const float* de
         return fail(GSR_E_INVALID, "gsr_tracking_loss: NULL pointer%s", "");
     int rc = select_device_of(image);
     if (rc != GSR_OK) return rc;
-    if (!tl_native_loop) HIPCHK(hipMemsetAsync(out, 0, 4 * sizeof(float), st));      // (the native loop's pose step clears it)
+    HIPCHK(hipMemsetAsync(out, 0, 4 * sizeof(float), st));
     LossArgs la;
-    la.guard = tl_guard;
-    la.clear_a = tl_clear.a; la.clear_b = tl_clear.b; la.clear_n = tl_clear.n;
+    la.guard = LoopGuard{nullptr, nullptr};
+    la.clear_a = nullptr; la.clear_b = nullptr; la.clear_n = 0;
     la.W = width; la.H = height; la.image = image; la.depth = depth; la.opacity = opacity; la.gt_image = gt_image;
     la.gt_depth = gt_depth; la.grad_mask = grad_mask; la.exposure = exposure; la.opacity_thr = opacity_threshold;
     la.depth_w = depth_weight; la.monocular = monocular; la.dL_dimage = dL_dimage; la.dL_ddepth = dL_ddepth;
@@ -859,26 +845,37 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     if (!a->pose_state || !a->projmatrix_raw || !a->gt_image || !a->grad_mask || !a->dL_dimage || !a->dL_ddepth ||
         !a->dL_dalpha || !a->dL_dtau || !a->loss_out || !a->n_touched)
         return fail(GSR_E_INVALID, "gsr_refine: a required pointer is NULL%s", "");
+    if (!a->dL_dmean2D || !a->dL_dconic || !a->dL_dopacity || !a->dL_dcolor)
+        return fail(GSR_E_INVALID, "gsr_refine: dL_dmean2D/dL_dconic/dL_dopacity/dL_dcolor are required%s", "");
     hipStream_t st = (hipStream_t)a->stream;
     int rc = select_device_of(a->pose_state);
     if (rc != GSR_OK) return rc;
     // Pinned status slots (one per iteration parity): {converged, loss, |tau|, poison, sequence number}, written by the
-    // pose-step kernel of each iteration.
+    // pose-step kernel of each iteration.  On an error return kernels that write these slots may still be in flight: the
+    // stream is drained before the slots go back to the pool, so that the next holder never sees a stale word.
     struct CtxLease {
-        LoopCtx* c;
-        CtxLease() : c(loop_ctx_acquire()) {}
-        ~CtxLease() { if (c) loop_ctx_release(c); }
-    } ctx_lease;
+        LoopCtx* c; hipStream_t st; bool clean = false;
+        explicit CtxLease(hipStream_t s_) : c(loop_ctx_acquire()), st(s_) {}
+        ~CtxLease()
+        {
+            if (!c) return;
+            if (!clean) { (void)hipStreamSynchronize(st); (void)hipGetLastError(); }
+            loop_ctx_release(c);
+        }
+    } ctx_lease(st);
     if (!ctx_lease.c) return fail(GSR_E_HIP, "gsr_refine: could not create the pinned status slots%s", "");
     float* h_status = ctx_lease.c->h_status;
     for (int i = 0; i < 16; i++) h_status[i] = 0.f;          // sequence words of both slots start at 0
     // Waits until the pose step of iteration `it` has published its status (sequence word == it + 1).  The kernel
-    // writes the slot itself (k_pose_step), so there is no copy and no event; the stream is queried now and then so
-    // that a failed launch cannot turn this into an endless wait.
+    // writes the slot itself (k_pose_step), so there is no copy and no event.  A few thousand polls cover the common case
+    // (the status is at most one iteration away); after that the thread yields between polls -- with several frames in
+    // flight per GPU and eight GPUs per node, dozens of these loops share the host's cores -- and the stream is queried
+    // now and then so that a failed launch cannot turn this into an endless wait.
     auto wait_status = [&](int it) -> int {
         volatile int* seqw = reinterpret_cast<volatile int*>(h_status + 8 * (it & 1)) + 4;
         for (unsigned spins = 0;; spins++) {
             if (*seqw == it + 1) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
+            if (spins > 4096u) std::this_thread::yield();
             if ((spins & 0x3FFFu) == 0x3FFFu) {
                 const hipError_t q = hipStreamQuery(st);
                 if (q == hipSuccess) {          // everything enqueued has run: one last look, then give up
@@ -894,13 +891,11 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     float* ps = a->pose_state;
     *iters_done = 0;
     *converged = 0;
-    struct FlagGuard {
-        FlagGuard() { tl_native_loop = true; }
-        ~FlagGuard() { tl_native_loop = false; tl_cov_cache = 0; tl_lean = false; tl_spec.mode = 0; tl_guard = LoopGuard{nullptr, nullptr}; tl_clear = LoopClear{}; tl_floss = FusedLoss{}; }
-    } guard;
     uint32_t* poison = reinterpret_cast<uint32_t*>(ps + GSR_PS_POISON);
-    tl_guard.poison = poison;
-    tl_guard.conv = a->stop_on_converged ? ps + GSR_PS_CONV : nullptr;
+    PassCtx cx;                    // what every forward / backward of this call runs with; spec / cov_cache / lean change per iteration
+    cx.native_loop = true;
+    cx.guard.poison = poison;
+    cx.guard.conv = a->stop_on_converged ? ps + GSR_PS_CONV : nullptr;
     // warm start: the previous call on this workspace left its last bounds in buffer warm_buf (0 / 1); iteration 0 must
     // READ that buffer, i.e. write the other one
     const int warm_buf = (a->speculative && a->warm_state && (*a->warm_state == 1 || *a->warm_state == 2)) ? *a->warm_state - 1 : -1;
@@ -909,8 +904,6 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     bool last_local = false;
     {   // gradient tensors: zero-filled once per call, then maintained row by row (PreBwdArgs::dirty)
         const size_t Pn = (size_t)a->P;
-        if (!a->dL_dmean2D || !a->dL_dconic || !a->dL_dopacity || !a->dL_dcolor)
-            return fail(GSR_E_INVALID, "gsr_refine: dL_dmean2D/dL_dconic/dL_dopacity/dL_dcolor are required%s", "");
         HIPCHK(hipMemsetAsync(a->dL_dmean2D, 0, Pn * 3 * sizeof(float), st));
         HIPCHK(hipMemsetAsync(a->dL_dconic, 0, Pn * 4 * sizeof(float), st));
         HIPCHK(hipMemsetAsync(a->dL_dopacity, 0, Pn * sizeof(float), st));
@@ -928,6 +921,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         carve_geom(gptr, a->P, gg);
         HIPCHK(hipMemsetAsync(gg.acc, 0, Pn * GSR_ACC_STRIDE * sizeof(float), st));
         HIPCHK(hipMemsetAsync(gg.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));      // then kept clean by the pose step
+        HIPCHK(hipMemsetAsync(gg.dirty, 0, Pn, st));
         // image workspace: flags, cursors and both bound buffers start from zero; afterwards the kernels keep them so
         Img im0;
         char* iptr = (char*)cached_resize(&ib, carve_img(nullptr, a->width, a->height, im0));
@@ -936,30 +930,28 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         HIPCHK(hipMemsetAsync(im0.fail, 0, im0.clear_words * sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(im0.loss_shards, 0, GSR_LOSS_SHARDS * 16 * sizeof(float), st));
         HIPCHK(hipMemsetAsync(a->dL_dalpha, 0, (size_t)a->width * a->height * sizeof(float), st));      // no gradient flows into opacity
-        tl_floss.gt_image = a->gt_image; tl_floss.gt_depth = a->gt_depth; tl_floss.grad_mask = a->grad_mask;
-        tl_floss.exposure = ps + GSR_PS_PARAM + 6; tl_floss.opacity_thr = a->opacity_threshold; tl_floss.depth_w = a->depth_weight;
-        tl_floss.monocular = a->monocular; tl_floss.dL_dimage = a->dL_dimage; tl_floss.dL_ddepth = a->dL_ddepth;
-        tl_floss.out = im0.loss_shards; tl_floss.conv = a->stop_on_converged ? ps + GSR_PS_CONV : nullptr;
+        cx.floss.gt_image = a->gt_image; cx.floss.gt_depth = a->gt_depth; cx.floss.grad_mask = a->grad_mask;
+        cx.floss.exposure = ps + GSR_PS_PARAM + 6; cx.floss.opacity_thr = a->opacity_threshold; cx.floss.depth_w = a->depth_weight;
+        cx.floss.monocular = a->monocular; cx.floss.dL_dimage = a->dL_dimage; cx.floss.dL_ddepth = a->dL_ddepth;
+        cx.floss.out = im0.loss_shards; cx.floss.conv = a->stop_on_converged ? ps + GSR_PS_CONV : nullptr;
         // (a warm start keeps the bounds the previous call recorded in buffer `warm_buf`)
         if (warm_buf != 0) HIPCHK(hipMemsetAsync(im0.zbc[0], 0, (size_t)im0.nsb * sizeof(float), st));
         if (warm_buf != 1) HIPCHK(hipMemsetAsync(im0.zbc[1], 0, (size_t)im0.nsb * sizeof(float), st));
         HIPCHK(hipMemsetAsync(a->loss_out, 0, 4 * sizeof(float), st));
     }
-    bool dirty_cleared = false;
     bool cov_cached = false;        // the first forward stores every Gaussian's 3D covariance, the others reuse it
     const int debug = 0;
     auto par = [&](int it) { return (it + poff) & 1; };      // which of the two bound buffers iteration `it` WRITES
     // Margin of the speculative bounds.  Given by the caller: fixed.  Otherwise adaptive: bound = (1 + m) z + m metres
     // with m between 0.01 and 0.05 -- tightened by a fifth after eight verified iterations in a row, doubled when a
-    // speculation fails (tight bounds mean shorter lists; a failure costs one forward with the global sorts).
+    // speculation fails (tight bounds mean shorter lists; a failure costs one forward with complete lists).
     const bool adaptive_margin = !(a->bound_margin_mul > 0.f);
     float margin_m = 0.02f;
     int margin_streak = 0;
-    if (!adaptive_margin) { tl_spec.mul = a->bound_margin_mul; tl_spec.add = a->bound_margin_add; }
-    else { tl_spec.mul = 1.f + margin_m; tl_spec.add = margin_m; }
+    if (!adaptive_margin) { cx.spec.mul = a->bound_margin_mul; cx.spec.add = a->bound_margin_add; }
 
     // One iteration = forward (with the tracking loss in its compositing epilogue), backward, Adam + update_pose, all
-    // enqueued without waiting for the device (the non-speculative forward still reads its instance count back, as
+    // enqueued without waiting for the device (a forward with complete lists still reads its instance count back, as
     // the reference does).  The pose step publishes the status words to the slot of the iteration's parity.
     Img imv_loop{};                // the image workspace's carving (for the pose step launch)
     int slot_mode[2] = {0, 0};
@@ -969,49 +961,43 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         last_enq = it;
         if (adaptive_margin) {
             const float m = (it == 0 && warm_buf >= 0) ? 0.05f : margin_m;      // (bounds recorded for another frame: be generous)
-            tl_spec.mul = 1.f + m; tl_spec.add = m;
+            cx.spec.mul = 1.f + m; cx.spec.add = m;
         }
         reinterpret_cast<volatile int*>(h_status + 8 * (it & 1))[4] = 0;      // (nothing in flight writes this slot any more)
-        tl_spec.mode = mode;
-        tl_spec.parity = par(it);
-        tl_cov_cache = cov_cached ? 2 : 1;
+        cx.spec.mode = mode;
+        cx.spec.parity = par(it);
+        cx.cov_cache = cov_cached ? 2 : 1;
         cov_cached = true;
-        tl_lean = (mode == 1) && (it != a->max_iters - 1);
-        {   // the pose step of this iteration clears the superblock bounds buffer iteration it+1 accumulates into
+        cx.lean = (mode == 1) && (it != a->max_iters - 1);
+        float* clear_b = nullptr;      // the pose step of this iteration clears the superblock bounds buffer iteration it+1 accumulates into
+        {
             Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
-            tl_clear.a = nullptr;
-            tl_clear.b = (mode != 0) ? imv.zbc[par(it) ^ 1] : nullptr;
-            tl_clear.n = imv.nsb;
+            clear_b = (mode != 0) ? imv.zbc[par(it) ^ 1] : nullptr;
             imv_loop = imv;
         }
-        int R = gsr_forward(cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
-                            a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
-                            a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
-                            a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, /*n_touched: see the end*/ nullptr, a->stream);
-        tl_spec.mode = 0;
+        int R = forward_impl(cx, cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
+                             a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
+                             a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
+                             a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, /*n_touched: see the end*/ nullptr, a->stream);
         if (R < 0) return R;
         last_R = R;
         last_local = (mode == 1);      // the bin-by-tile forward does not bring its instance count to the host
-        if (!dirty_cleared) {
-            Geom gg; carve_geom((char*)gb.ptr, a->P, gg);
-            HIPCHK(hipMemsetAsync(gg.dirty, 0, (size_t)a->P, st));
-            dirty_cleared = true;
-        }
-        int rc2 = 0;      // (the tracking loss was evaluated in the compositing kernel's epilogue: tl_floss)
-        rc2 = gsr_backward(a->P, a->D, a->M, R, a->background, a->width, a->height, a->means3D, a->shs, nullptr, a->out_alpha,
-                           a->scales, a->scale_modifier, a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ,
-                           ps + GSR_PS_CAMPOS, a->tan_fovx, a->tan_fovy, a->radii, (char*)gb.ptr, (char*)bb.ptr, (char*)ib.ptr,
-                           a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor,
-                           a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, 0, 1, a->dL_dtau, a->stream);
+        // (the tracking loss was evaluated in the compositing kernel's epilogue: cx.floss)
+        int rc2 = backward_impl(cx, a->P, a->D, a->M, R, a->background, a->width, a->height, a->means3D, a->shs, nullptr, a->out_alpha,
+                                a->scales, a->scale_modifier, a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ,
+                                ps + GSR_PS_CAMPOS, a->tan_fovx, a->tan_fovy, a->radii, (char*)gb.ptr, (char*)bb.ptr, (char*)ib.ptr,
+                                a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor,
+                                a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, 0, 1, a->dL_dtau, a->stream);
         if (rc2 < 0) return rc2;
         {   // Adam + update_pose; also finishes the fp64 dL/dtau reduction left open by the backward
             Geom gg; carve_geom((char*)gb.ptr, a->P, gg);
+            ProfScope pp(K_POSE_STEP, st);
             hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(64), 0, st, ps, (const float*)a->dL_dtau, (const double*)gg.tau_acc,
                                a->dL_dtau, (const float*)a->loss_out, a->projmatrix_raw, a->lr, a->converged_threshold,
-                               a->loss_out, tl_guard, h_status + 8 * (it & 1), it + 1, imv_loop.loss_shards, tl_clear.a, tl_clear.b,
-                               tl_clear.n);
-            LAUNCHCHK("k_pose_step");
+                               a->loss_out, cx.guard, h_status + 8 * (it & 1), it + 1, imv_loop.loss_shards, (uint32_t*)nullptr, clear_b,
+                               imv_loop.nsb);
         }
+        LAUNCHCHK("k_pose_step");
         return 0;
     };
     // Wait for iteration `it`'s status.  A poisoned iteration (failed speculation: its loss, backward and pose step
@@ -1058,9 +1044,14 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             if (rc < 0) return rc;
             settled = it - 1;
             if (a->stop_on_converged && conv) {
-                // reference: `if converged: break` -- the forward of iteration `it` has been rendered at the final
-                // pose; its update was frozen on the device.  (After a redo it was skipped: render it again.)
+                // reference: `if converged: break` -- the forward of iteration `it` is the render at the final pose; its
+                // update is frozen on the device.  (After a redo it was skipped: render it again.)  That forward is what the
+                // caller gets back, so its speculation must be verified like any other: its (frozen) pose step still
+                // publishes the poison word, and a failed one is rendered once more with complete lists.
                 if (rc == 1) { rc = enqueue(it, mode_of(it)); if (rc < 0) return rc; }
+                bool ignored = false;
+                rc = settle(it, ignored);
+                if (rc < 0) return rc;
                 *converged = 1;
                 break;
             }
@@ -1080,12 +1071,13 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         // n_touched (fifth output of the pose package's forward) is only wanted for the LAST forward, and counting it
         // costs every iteration's compositing kernel an eighth of its instructions: the loop runs the variant
         // without it and the lists of the last forward are composited once more here, with the counters.  Same
-        // lists, same geometry, same order: the images it rewrites are bit-identical.
+        // lists, same geometry, same order: the images it rewrites are bit-identical.  (The last forward ordered its
+        // lists as far as its pixels needed them, which is as far as this pass walks.)
         const int gx = (a->width + GSR_TILE - 1) / GSR_TILE, gy = (a->height + GSR_TILE - 1) / GSR_TILE;
         Geom g; carve_geom((char*)gb.ptr, a->P, g);
         Img im; carve_img((char*)ib.ptr, a->width, a->height, im);
         HIPCHK(hipMemsetAsync(a->n_touched, 0, (size_t)a->P * sizeof(int), st));
-        hipLaunchKernelGGL((k_render_fwd<true, false>), dim3(gx * gy), dim3(GSR_BLOCK), 0, st, im.ranges,
+        hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_SORTED>), dim3(gx * gy), dim3(GSR_BLOCK), 0, st, im.ranges,
                            reinterpret_cast<uint32_t*>(bb.ptr), (const unsigned long long*)nullptr, (uint32_t*)nullptr, a->width,
                            a->height, gx, gx * gy, (const float2*)g.xy, (const float*)g.rgb, (const float*)g.depths,
                            (const float4*)g.conic_op, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
@@ -1094,6 +1086,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
     HIPCHK(hipStreamSynchronize(st));
+    ctx_lease.clean = true;
     if (a->warm_state) *a->warm_state = (a->speculative && last_enq >= 0) ? (par(last_enq) + 1) : 0;
     if (a->stats_out) {
         if (last_local && ib.ptr) {      // instances binned by the last forward = sum of the tile list lengths
@@ -1305,22 +1298,19 @@ int gsr_forward_stats(int P, int width, int height, const int* radii, const char
     Geom g; carve_geom(const_cast<char*>(geom_buffer), P, g);
     Img im; carve_img(const_cast<char*>(img_buffer), width, height, im);
     const int gx = (width + GSR_TILE - 1) / GSR_TILE, gy = (height + GSR_TILE - 1) / GSR_TILE;
-    unsigned long long* d = nullptr;
-    HIPCHK(hipMalloc(&d, 4 * sizeof(unsigned long long)));
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(im.loss_shards);      // scratch (only the native loop uses these words)
     HIPCHK(hipMemsetAsync(d, 0, 4 * sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(k_stats_gauss, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, radii,
-                       (const uint32_t*)g.tiles_touched, (const ushort4*)g.rects, d);
+    hipLaunchKernelGGL(k_stats_gauss, dim3((P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, P, radii, (const ushort4*)g.rects, d);
     LAUNCHCHK("k_stats_gauss");
     hipLaunchKernelGGL(k_stats_tiles, dim3(gx * gy), dim3(GSR_BLOCK), 0, st, width, height, gx,
-                       (const uint32_t*)im.n_contrib, d);
+                       (const uint32_t*)im.n_contrib, (const uint2*)im.ranges, d);
     LAUNCHCHK("k_stats_tiles");
     unsigned long long h[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    HIPCHK(hipFree(d));
     stats[0] = (long long)h[0];
     stats[1] = (long long)h[1];   // R under the reference's bounding rule
-    stats[2] = (long long)h[3];   // instances actually emitted after exact tile culling
+    stats[2] = (long long)h[3];   // instances binned: sum of the tiles' list lengths (after exact tile culling / depth speculation)
     stats[3] = (long long)h[2];   // R_eff of THIS binning (max per-pixel n_contrib summed over tiles)
     return 0;
 }

@@ -53,7 +53,7 @@ struct LoopGuard {
 // reference's value.
 // ---------------------------------------------------------------------------------------------
 struct TileTest {
-    float mx, my, A, B, C, det, twoq, dxe, dye, invA;
+    float mx, my, A, B, C, det, twoq, dxe, dye, invA, dyext;
     bool cull;       // false: conic not positive definite -> keep every tile of the rectangle
     bool none;       // opacity so low that alpha < 1/255 everywhere
 };
@@ -71,36 +71,45 @@ __device__ __forceinline__ TileTest make_tile_test(float2 m, float3 conic, float
     const float qmax = (opacity > 0.f) ? (__logf(255.f * opacity) + 0.02f) : -1.f;
     t.none = t.cull && (qmax < 0.f);
     t.twoq = 2.f * fmaxf(qmax, 0.f);
-    // extreme points of the ellipse q = qmax in x: dx = +-dxe at dy = -+B dxe / C
+    // extreme points of the ellipse q = qmax (d = mean - pixel): dx = +-dxe at dy = -+B dxe / C, and |dy| <= dyext
     // (hardware rcp / sqrt, ~1 ulp: the spans are widened by 0.01 px, exact rounding is not needed here)
+    const float rdet = t.cull ? __builtin_amdgcn_rcpf(t.det) : 0.f;
     t.invA = t.cull ? __builtin_amdgcn_rcpf(t.A) : 0.f;
-    t.dxe = t.cull ? __builtin_amdgcn_sqrtf(t.twoq * t.C * __builtin_amdgcn_rcpf(t.det)) : 0.f;
+    t.dxe = t.cull ? __builtin_amdgcn_sqrtf(t.twoq * t.C * rdet) : 0.f;
     t.dye = t.cull ? (-t.B * t.dxe * __builtin_amdgcn_rcpf(t.C)) : 0.f;
+    t.dyext = t.cull ? __builtin_amdgcn_sqrtf(t.twoq * t.A * rdet) : 0.f;
     return t;
 }
+// Shrinks the reference's tile rectangle [x0, x1) x [y0, y1) to the tiles the bounding box of the ellipse q <= qmax reaches
+// (the rows and columns cut off have empty spans); widened by 0.01 px like the spans.  May come out empty.
+__device__ __forceinline__ void clip_rect(const TileTest& t, int& x0, int& y0, int& x1, int& y1)
+{
+    if (!t.cull) return;
+    if (t.none) { x1 = x0; y1 = y0; return; }
+    const float ex = t.dxe * 1.0001f + 0.01f, ey = t.dyext * 1.0001f + 0.01f;      // pixels mx - ex ... mx + ex, my - ey ... my + ey
+    x0 = max(x0, (int)ceilf((t.mx - ex - (float)(GSR_TILE - 1)) * (1.f / GSR_TILE)));
+    x1 = max(x0, min(x1, (int)floorf((t.mx + ex) * (1.f / GSR_TILE)) + 1));
+    y0 = max(y0, (int)ceilf((t.my - ey - (float)(GSR_TILE - 1)) * (1.f / GSR_TILE)));
+    y1 = max(y0, min(y1, (int)floorf((t.my + ey) * (1.f / GSR_TILE)) + 1));
+}
 // Tiles [lo, hi] (inclusive, within [x0, x1)) of tile row ty that the ellipse q <= qmax can reach; empty if lo > hi.
-// Exact x-extent of (ellipse ∩ row band): attained either at the ellipse's x-extreme points (if they lie in
-// the band) or where the ellipse crosses the band's two boundary lines.  Widened by 0.01 px.
+// For a fixed dy the ellipse spans dx in [(-B dy - s) / A, (-B dy + s) / A] with s = sqrt(A twoq - det dy^2).  The upper end
+// is a concave function of dy that peaks at the ellipse's +x extreme point (dy = dye), the lower end a convex one with its
+// minimum at the -x extreme point (dy = -dye): over the row's band of pixel rows each is extremal at that dy clamped into
+// the band -- one evaluation (one sqrt) per end, no case distinction.  Exact; widened by 0.01 px.
 __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int x1, int& lo, int& hi)
 {
     if (!t.cull) { lo = x0; hi = x1 - 1; return; }
     lo = 1; hi = 0;
     if (t.none) return;
     const float dyh = t.my - (float)(ty * GSR_TILE), dyl = dyh - (float)(GSR_TILE - 1);   // d = mean - pixel
-    float dmin = 3.0e38f, dmax = -3.0e38f;
-    const float disc_l = t.A * t.twoq - t.det * dyl * dyl;
-    if (disc_l >= 0.f) {
-        const float sq = __builtin_amdgcn_sqrtf(disc_l), c = -t.B * dyl;
-        dmin = fminf(dmin, (c - sq) * t.invA); dmax = fmaxf(dmax, (c + sq) * t.invA);
-    }
-    const float disc_h = t.A * t.twoq - t.det * dyh * dyh;
-    if (disc_h >= 0.f) {
-        const float sq = __builtin_amdgcn_sqrtf(disc_h), c = -t.B * dyh;
-        dmin = fminf(dmin, (c - sq) * t.invA); dmax = fmaxf(dmax, (c + sq) * t.invA);
-    }
-    if (t.dye >= dyl - 0.01f && t.dye <= dyh + 0.01f) dmax = fmaxf(dmax, t.dxe);
-    if (-t.dye >= dyl - 0.01f && -t.dye <= dyh + 0.01f) dmin = fminf(dmin, -t.dxe);
-    if (dmin > dmax) return;
+    const float dy1 = fminf(dyh, fmaxf(dyl, t.dye)), dy2 = fminf(dyh, fmaxf(dyl, -t.dye));
+    const float at = t.A * t.twoq;
+    const float disc1 = at - t.det * dy1 * dy1, disc2 = at - t.det * dy2 * dy2;
+    // (a clamped dy lies outside the ellipse's y-extent only if the whole band does; a hair of negative rounding is let through)
+    if (fminf(disc1, disc2) < -1e-3f * at) return;
+    const float dmax = (__builtin_amdgcn_sqrtf(fmaxf(disc1, 0.f)) - t.B * dy1) * t.invA;
+    const float dmin = (-__builtin_amdgcn_sqrtf(fmaxf(disc2, 0.f)) - t.B * dy2) * t.invA;
     const float pa = t.mx - dmax - 0.01f, pb = t.mx - dmin + 0.01f;        // pixel x-interval
     lo = max(x0, (int)ceilf((pa - (float)(GSR_TILE - 1)) * (1.f / GSR_TILE)));
     hi = min(x1 - 1, (int)floorf(pb * (1.f / GSR_TILE)));
@@ -123,7 +132,7 @@ __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int 
 
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
-    uint32_t* depth_key; uint32_t* order_in;
+    uint32_t* tile_count; int ntiles;      // exact-bin path: ntiles counter words (all copies) zeroed here for k_tile_count (nullable)
     const float* zb;                       // speculative per-tile depth bounds of the native loop (nullable): the depth each
     float zb_mul, zb_add;                  // tile had to look at; an instance is kept if z <= zb * zb_mul + zb_add
     const float* zbc; int sbx;             // the same per 4x4-tile superblock (max of its tiles): quick reject
@@ -205,6 +214,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     GSR_T_TICK(0)
     const bool lean = a.lean != 0 && a.zbc_lds > 0 && a.scales != nullptr && !a.guard.frozen();
     const int idx = blockIdx.x * GSR_BLOCK + tid;
+    if (a.tile_count != nullptr && idx < a.ntiles) a.tile_count[idx] = 0u;      // (k_tile_count adds into them next)
     const bool live = idx < a.P;
     bool vis = false, coop = false, own = false;
     float3 p = make_float3(0.f, 0.f, 0.f);
@@ -217,10 +227,6 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
         a.radii[idx] = 0;
         a.tiles_touched[idx] = 0;
         if (a.n_touched != nullptr) a.n_touched[idx] = 0;
-        if (a.bins == nullptr) {            // (the bin-by-tile path has no depth sort)
-            a.depth_key[idx] = 0xFFFFFFFFu;     // culled Gaussians sort behind every visible one
-            a.order_in[idx] = (uint32_t)idx;
-        }
         p = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
         const float4 ph = xform4x4(p, a.proj);
         const float pw = 1.0f / (ph.w + 0.0000001f);
@@ -306,6 +312,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                     // exact count of tiles this splat can change
                     tt = make_tile_test(pix, conic, opacity);
                     rx0 = x0; ry0 = y0; rx1 = x1; ry1 = y1; zv = pview.z;
+                    clip_rect(tt, rx0, ry0, rx1, ry1);      // (walked below; the stored rectangle stays the reference's)
                     bool far_everywhere = false;
                     if (a.zb != nullptr) {
                         // behind the bound of every superblock the rectangle overlaps => behind every tile's bound
@@ -319,8 +326,11 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                         }
                         far_everywhere = pview.z > zc * a.zb_mul + a.zb_add;
                     }
-                    if (!far_everywhere) {
-                        if (a.bins != nullptr && (x1 - x0) * (y1 - y0) > GSR_COOP_AREA) coop = true;      // whole wave helps below
+                    if (a.bins == nullptr) {
+                        // exact-bin path: k_tile_count / k_tile_emit walk the tiles; here only "can this splat reach any pixel"
+                        cnt = tt.none ? 0u : 1u;
+                    } else if (!far_everywhere) {
+                        if ((rx1 - rx0) * (ry1 - ry0) > GSR_COOP_AREA) coop = true;      // whole wave helps below
                         else own = true;
                     }
                 }
@@ -329,25 +339,19 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     }
     GSR_T_TICK(1)
     if (own) {      // small footprint: the lane walks its own rectangle
-        uint32_t full = 0;
         for (int y = ry0; y < ry1; y++) {
             int lo, hi;
             row_span(tt, y, rx0, rx1, lo, hi);
-            full += (uint32_t)max(0, hi - lo + 1);
-            if (a.zb == nullptr) continue;
             // behind everything this tile needed last iteration (+ margin): speculatively dropped
             for (int x = lo; x <= hi; x++)
                 if (zv <= a.zb[y * a.gx + x] * a.zb_mul + a.zb_add) {
                     cnt++;
-                    if (a.bins != nullptr) {
-                        const int tile = y * a.gx + x;
-                        const uint32_t pos = atomicAdd(&a.tile_cursor[tile * GSR_CURSOR_STRIDE], 1u);
-                        if (pos < GSR_LSORT_CAP)
-                            a.bins[(size_t)tile * GSR_LSORT_CAP + pos] = ((unsigned long long)__float_as_uint(zv) << 32) | (uint32_t)idx;
-                    }
+                    const int tile = y * a.gx + x;
+                    const uint32_t pos = atomicAdd(&a.tile_cursor[tile * GSR_CURSOR_STRIDE], 1u);
+                    if (pos < GSR_LSORT_CAP)
+                        a.bins[(size_t)tile * GSR_LSORT_CAP + pos] = ((unsigned long long)__float_as_uint(zv) << 32) | (uint32_t)idx;
                 }
         }
-        if (a.zb == nullptr) cnt = full;
     }
     GSR_T_TICK(2)
     if (a.bins != nullptr) {
@@ -398,7 +402,6 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
         // (what was dropped is not recorded: an instance can only be dropped from a tile whose bound is finite, and the
         // compositing kernel treats every such tile that ends unsaturated as a failed speculation)
         a.tiles_touched[idx] = cnt;
-        if (cnt && a.bins == nullptr) a.depth_key[idx] = __float_as_uint(zv);
     }
     GSR_T_TICK(4)
     GSR_T_FLUSH(32)
@@ -471,71 +474,258 @@ __global__ void __launch_bounds__(64) k_sh_color(PreArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------
-// Binning.  The reference sorts R (tile<<32 | depth) 64-bit keys (rasterizer_impl.cu:70-111,304-309:
-// 6 radix passes over R pairs).  Same final order, far fewer bytes:
-//   (1) the P Gaussians are sorted ONCE by (depth bits, index)            -- 4 passes over P pairs
-//   (2) instances are emitted in that order with a 16-bit tile key        -- k_emit_sorted
-//   (3) a STABLE radix sort on the tile bits only brings tiles together   -- 2 passes over R pairs
-// Stability keeps (depth, index) order inside each tile, which is exactly the order a stable sort of
-// the reference's 64-bit keys produces (ties in depth resolved by Gaussian index).
+// Binning with complete lists ("exact bins"; every forward that has no depth bounds to speculate with).
+// The reference duplicates every Gaussian into R (tile<<32 | depth) keys and radix-sorts all of them
+// (rasterizer_impl.cu:70-111, 278-315: 6 passes over R pairs).  95 % of that sorted list is never looked at: a tile's
+// pixels saturate after the first few hundred entries.  Here nothing is sorted globally:
+//   k_tile_count   every (Gaussian, tile) pair that survives the exact ellipse test is counted per tile -- in LDS, per
+//                  workgroup of a few thousand Gaussians, so that the tile counters in HBM see one add per
+//                  (workgroup, tile) instead of one per instance (memory-side atomics: ~18 per ns);
+//   k_tile_scan    exclusive prefix sum over the tile counts = every tile's segment of the instance arrays (and the
+//                  total, which the host reads to size them: the reference's one blocking read, rasterizer_impl.cu:282);
+//   k_tile_emit    the same walk again: a workgroup reserves its share of each tile's segment with one returning atomic
+//                  per (workgroup, tile) and scatters its (depth bits << 32 | index) keys there, in no particular order;
+//   compositing    k_render_fwd<.., 2> orders a tile's segment lazily, front to back: it SELECTS the nearest few
+//                  hundred keys (radix histogram over the key bits, in LDS), sorts those (bitonic, in LDS), composites
+//                  them, and only goes back for the next slice while some pixel of the tile is still unsaturated.
+// The order inside a tile is (depth bits, index) -- what the reference's stable sort of (tile | depth) keys gives -- as
+// far as the walk gets; the sorted prefix is written out for the backward pass, which never reads beyond the deepest
+// contributor.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GSR_BLOCK) k_gather_counts(int P, const uint32_t* __restrict__ order,
-                                                             const uint32_t* __restrict__ tiles_touched,
-                                                             uint32_t* __restrict__ tt_sorted)
+#define GSR_TBIN_COOP 32          // rectangles with more tiles than this are walked by the whole wave
+// Every workgroup adds its per-tile counts into the tile counters in HBM; with all of them hammering the same few KB the
+// memory-side atomic unit serialises (MI355X_MICROARCH.md, "Global float atomics": everybody into one row = 14x slower).
+// The counters are therefore kept in GSR_TBIN_COPIES private copies (workgroup b uses copy b mod copies); k_tile_scan adds
+// the copies up and gives every copy its own sub-range of the tile's segment.
+#define GSR_TBIN_COPIES 16
+// Workgroups of 1024 lanes: the walk is a short chain of dependent loads per Gaussian, so what counts is how many of them
+// are in flight -- 16 waves per workgroup, two workgroups per CU -- while the LDS counters still aggregate a few thousand
+// Gaussians.
+#define GSR_TBIN_THREADS 1024
+struct TileBinArgs {
+    int P, gx, gy, ntiles, gpb;                    // gpb: Gaussians per workgroup (multiple of GSR_TBIN_THREADS)
+    int copies;                                    // private copies of the per-tile counters (1 ... GSR_TBIN_COPIES)
+    const uint32_t* tiles_touched; const ushort4* rects; const float2* xy; const float4* conic_op; const float* depths;
+    uint32_t* tile_count;                          // [copies][ntiles]: count kernel adds; the scan turns them into sub-range starts
+    const uint32_t* tile_offset;                   // [ntiles + 1]   (emit)
+    uint32_t* tile_fill;                           // [copies][ntiles]: how much of each sub-range has been handed out (emit)
+    uint16_t* block_counts;                        // [workgroups][ntiles]: what each workgroup counted (count writes, emit reads); LDSAGG only
+    unsigned long long* keys;                      // [R] (emit)
+};
+
+// What the walk keeps per Gaussian between its passes over the image (registers): the span test without the terms only
+// needed once, the clipped rectangle, the key.
+struct WalkItem {
+    float mx, my, at, B, det, dye, invA;           // at = A * twoq
+    int x0, y0, x1, y1;                            // clipped tile rectangle; x1 == x0: nothing to do
+    unsigned long long key;
+    bool all;                                      // conic not positive definite: every tile of the rectangle
+};
+__device__ __forceinline__ void item_span(const WalkItem& t, int ty, int& lo, int& hi)      // row_span on the cached terms
 {
-    const int k = blockIdx.x * GSR_BLOCK + threadIdx.x;
-    if (k < P) tt_sorted[k] = tiles_touched[order[k]];
+    if (t.all) { lo = t.x0; hi = t.x1 - 1; return; }
+    lo = 1; hi = 0;
+    const float dyh = t.my - (float)(ty * GSR_TILE), dyl = dyh - (float)(GSR_TILE - 1);
+    const float dy1 = fminf(dyh, fmaxf(dyl, t.dye)), dy2 = fminf(dyh, fmaxf(dyl, -t.dye));
+    const float disc1 = t.at - t.det * dy1 * dy1, disc2 = t.at - t.det * dy2 * dy2;
+    if (fminf(disc1, disc2) < -1e-3f * t.at) return;
+    const float dmax = (__builtin_amdgcn_sqrtf(fmaxf(disc1, 0.f)) - t.B * dy1) * t.invA;
+    const float dmin = (-__builtin_amdgcn_sqrtf(fmaxf(disc2, 0.f)) - t.B * dy2) * t.invA;
+    const float pa = t.mx - dmax - 0.01f, pb = t.mx - dmin + 0.01f;
+    lo = max(t.x0, (int)ceilf((pa - (float)(GSR_TILE - 1)) * (1.f / GSR_TILE)));
+    hi = min(t.x1 - 1, (int)floorf(pb * (1.f / GSR_TILE)));
+}
+// (g0: offset of the KPT x 1024 window inside the workgroup's gpb Gaussians)
+template <int KPT>
+__device__ __forceinline__ void walk_load(const TileBinArgs& a, int g0, WalkItem (&it)[KPT])
+{
+    const int base = blockIdx.x * a.gpb + g0;
+#pragma unroll
+    for (int k = 0; k < KPT; k++) {
+        const int idx = base + k * GSR_TBIN_THREADS + (int)threadIdx.x;
+        WalkItem w = {};
+        if (g0 + k * GSR_TBIN_THREADS < a.gpb && idx < a.P && a.tiles_touched[idx] != 0u) {
+            const ushort4 r = a.rects[idx];
+            const float4 co = a.conic_op[idx];
+            const TileTest tt = make_tile_test(a.xy[idx], make_float3(co.x, co.y, co.z), co.w);
+            w.x0 = r.x; w.y0 = r.y; w.x1 = r.z; w.y1 = r.w;
+            clip_rect(tt, w.x0, w.y0, w.x1, w.y1);
+            w.mx = tt.mx; w.my = tt.my; w.at = tt.A * tt.twoq; w.B = tt.B; w.det = tt.det; w.dye = tt.dye; w.invA = tt.invA;
+            w.all = !tt.cull;
+            w.key = ((unsigned long long)__float_as_uint(a.depths[idx]) << 32) | (uint32_t)idx;
+        }
+        it[k] = w;
+    }
+}
+// Calls visit(tile, key) for every tile instance of the cached Gaussians in tile rows [b0, b1).
+// Footprints differ by two orders of magnitude (1 ... hundreds of tiles), so the unit of work handed to a lane is not a
+// Gaussian but one ROW of one Gaussian's rectangle: the wave lays the rows of its 64 Gaussians end to end (prefix sum of
+// the row counts), takes them 64 at a time, and each lane looks up whose row it got (binary search in the wave's prefix
+// array, in LDS), fetches that Gaussian's span terms from the owning lane (ds_bpermute) and walks the row's span.
+// s_pref: 64 words of LDS per wave.
+template <int KPT, class Visit>
+__device__ __forceinline__ void walk_rows(const TileBinArgs& a, const WalkItem (&it)[KPT], int b0, int b1, uint32_t* s_pref, Visit&& visit)
+{
+    const int lane = threadIdx.x & 63;
+    uint32_t* pref = s_pref + (threadIdx.x >> 6) * 64;
+#define GSR_PERM_F(v, src) __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((src) << 2, (int)__float_as_uint(v)))
+#define GSR_PERM_I(v, src) __builtin_amdgcn_ds_bpermute((src) << 2, (int)(v))
+#pragma unroll
+    for (int k = 0; k < KPT; k++) {
+        const WalkItem& w = it[k];
+        const int y0 = max(w.y0, b0), y1 = min(w.y1, b1);
+        const int nrows = (w.x1 > w.x0 && y1 > y0) ? (y1 - y0) : 0;
+        int incl = nrows;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        if (total == 0) continue;                  // wave-uniform
+        pref[lane] = (uint32_t)(incl - nrows);     // first row slot of lane's Gaussian (same-wave LDS traffic is in order: no barrier)
+        __builtin_amdgcn_wave_barrier();
+        for (int p0 = 0; p0 < total; p0 += 64) {
+            const int p = p0 + lane;
+            const bool act = p < total;
+            int src = 0;
+            if (act) {                             // largest lane s with pref[s] <= p (lanes with no rows share their successor's start:
+#pragma unroll                                     //  the largest one is the owner)
+                for (int step = 32; step > 0; step >>= 1)
+                    if (pref[src + step] <= (uint32_t)p) src += step;
+            }
+            WalkItem r;
+            r.mx = GSR_PERM_F(w.mx, src); r.my = GSR_PERM_F(w.my, src); r.at = GSR_PERM_F(w.at, src); r.B = GSR_PERM_F(w.B, src);
+            r.det = GSR_PERM_F(w.det, src); r.dye = GSR_PERM_F(w.dye, src); r.invA = GSR_PERM_F(w.invA, src);
+            r.x0 = GSR_PERM_I(w.x0, src); r.x1 = GSR_PERM_I(w.x1, src);
+            r.all = GSR_PERM_I((int)w.all, src) != 0;
+            const uint32_t klo = (uint32_t)GSR_PERM_I((uint32_t)w.key, src), khi = (uint32_t)GSR_PERM_I((uint32_t)(w.key >> 32), src);
+            const int sy0 = GSR_PERM_I(y0, src);
+            const int sfirst = GSR_PERM_I(incl - nrows, src);
+            if (act) {
+                const unsigned long long key = ((unsigned long long)khi << 32) | klo;
+                const int y = sy0 + (p - sfirst);
+                int lo, hi;
+                item_span(r, y, lo, hi);
+                for (int x = lo; x <= hi; x++) visit(y * a.gx + x, key);
+            }
+        }
+    }
+#undef GSR_PERM_F
+#undef GSR_PERM_I
 }
 
-// Each lane expands its Gaussian into (tile key, index) instances.  A block's output range is contiguous
-// (the offsets are a prefix sum in block order), so the instances are first laid out in LDS and then leave
-// the block as coalesced stores; a block with more than GSR_EMIT_CAP instances writes directly.
-// Lane -> Gaussian assignment is interleaved in runs of 16 across the whole depth order: the nearest (largest,
-// most tiles) splats sit at the front of that order, and a contiguous assignment would leave them all to the
-// first few workgroups.  Runs of 16 keep the index / offset reads in whole 64-B lines.
-template <typename KeyT>
-__global__ void __launch_bounds__(GSR_BLOCK) k_emit_sorted(int P, const uint32_t* __restrict__ order,
-                                                           const uint32_t* __restrict__ offsets,
-                                                           const uint32_t* __restrict__ tt_sorted,
-                                                           const ushort4* __restrict__ rects, const float2* __restrict__ xy,
-                                                           const float4* __restrict__ conic_op, int gx, int gy_tiles,
-                                                           const float* __restrict__ zb, float zb_mul, float zb_add, const float* __restrict__ depths,
-                                                           KeyT* __restrict__ keys, uint32_t* __restrict__ vals)
+// LDSAGG: the workgroup's per-tile counters live in LDS (a.ntiles words of dynamic shared memory); false: images with more
+// tiles than LDS can hold counters for, or more Gaussians per workgroup than KPT x 1024 -- every instance adds to the
+// counters in HBM directly (one copy).
+template <bool LDSAGG, int KPT>
+__global__ void __launch_bounds__(GSR_TBIN_THREADS) k_tile_count(TileBinArgs a)
 {
-    const int run = (threadIdx.x >> 4) * gridDim.x + blockIdx.x;       // which run of 16 consecutive Gaussians
-    const int k = run * 16 + (threadIdx.x & 15);
-    if (k >= P || tt_sorted[k] == 0) return;
-    const uint32_t idx = order[k];
-    uint32_t off = (k == 0) ? 0u : offsets[k - 1];
-    const ushort4 r = rects[idx];
-    const float4 co = conic_op[idx];
-    const TileTest tt = make_tile_test(xy[idx], make_float3(co.x, co.y, co.z), co.w);
-    const float z = zb ? depths[idx] : 0.f;
-    for (int y = r.y; y < r.w; y++) {
-        int lo, hi;
-        row_span(tt, y, r.x, r.z, lo, hi);
-        for (int x = lo; x <= hi; x++) {
-            if (zb && !(z <= zb[y * gx + x] * zb_mul + zb_add)) continue;      // same test as the count in k_preprocess
-            keys[off] = (KeyT)(y * gx + x);
-            vals[off] = idx;
-            off++;
+    extern __shared__ uint32_t s_tb[];
+    __shared__ uint32_t s_pref[GSR_TBIN_THREADS];
+    WalkItem it[KPT];
+    if (LDSAGG) {
+        for (int t = threadIdx.x; t < a.ntiles; t += GSR_TBIN_THREADS) s_tb[t] = 0u;
+        walk_load<KPT>(a, 0, it);
+        __syncthreads();
+        walk_rows<KPT>(a, it, 0, a.gy, s_pref, [&](int tile, unsigned long long) { atomicAdd(&s_tb[tile], 1u); });
+        __syncthreads();
+        uint32_t* mine = a.tile_count + (size_t)(blockIdx.x % a.copies) * a.ntiles;
+        uint16_t* row = a.block_counts + (size_t)blockIdx.x * a.ntiles;
+        for (int t = threadIdx.x; t < a.ntiles; t += GSR_TBIN_THREADS) {      // consecutive lanes -> consecutive counters: 256-B atomic bursts
+            const uint32_t c = s_tb[t];
+            row[t] = (uint16_t)c;                                      // (at most one instance per Gaussian and tile: c <= gpb <= 8192)
+            if (c != 0u) atomicAdd(&mine[t], c);
+        }
+    } else {
+        for (int g0 = 0; g0 < a.gpb; g0 += KPT * GSR_TBIN_THREADS) {
+            WalkItem jt[KPT];
+            walk_load<KPT>(a, g0, jt);
+            walk_rows<KPT>(a, jt, 0, a.gy, s_pref, [&](int tile, unsigned long long) { atomicAdd(&a.tile_count[tile], 1u); });
         }
     }
 }
 
-// per-tile [start,end) in the tile-sorted list (replaces rasterizer_impl.cu:116-138)
-template <typename KeyT>
-__global__ void __launch_bounds__(GSR_BLOCK) k_ranges(int L, const KeyT* __restrict__ keys, uint2* __restrict__ ranges)
+// One workgroup.  Per tile: total over the counter copies; tile_offset = exclusive prefix sum of the totals (ntiles + 1
+// entries); every copy's counter becomes the start of that copy's sub-range inside the tile's segment; tile_fill = 0;
+// the grand total goes to *total_out.
+__global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, int copies, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
+                                                     uint32_t* __restrict__ tile_fill, uint32_t* __restrict__ total_out)
 {
-    const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
-    if (idx >= L) return;
-    const uint32_t cur = (uint32_t)keys[idx];
-    if (idx == 0) ranges[cur].x = 0;
-    else {
-        const uint32_t prev = (uint32_t)keys[idx - 1];
-        if (cur != prev) { ranges[prev].y = idx; ranges[cur].x = idx; }
+    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_carry = 0u;
+    __syncthreads();
+    for (int t0 = 0; t0 < ntiles; t0 += 1024) {
+        const int t = t0 + tid;
+        uint32_t c = 0u;
+        if (t < ntiles) {
+            uint32_t v[GSR_TBIN_COPIES];          // all copies first: independent loads, one round trip
+#pragma unroll
+            for (int k = 0; k < GSR_TBIN_COPIES; k++) v[k] = (k < copies) ? tile_count[(size_t)k * ntiles + t] : 0u;
+#pragma unroll
+            for (int k = 0; k < GSR_TBIN_COPIES; k++)
+                if (k < copies) {
+                    tile_count[(size_t)k * ntiles + t] = c;          // start of copy k's sub-range, relative to the tile's segment
+                    tile_fill[(size_t)k * ntiles + t] = 0u;
+                    c += v[k];
+                }
+        }
+        uint32_t incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_wave[wv] = incl;
+        __syncthreads();
+        uint32_t before = s_carry;
+        for (int w = 0; w < wv; w++) before += s_wave[w];
+        if (t < ntiles) tile_offset[t] = before + incl - c;
+        __syncthreads();
+        if (tid == 1023) s_carry = before + incl;
+        __syncthreads();
     }
-    if (idx == L - 1) ranges[cur].y = L;
+    if (tid == 0) { tile_offset[ntiles] = s_carry; *total_out = s_carry; }
+}
+
+// The emit makes `bands` passes over the image, a band of tile rows at a time: every workgroup writes its keys of band 0,
+// then of band 1, ...  All workgroups are resident and move at about the same pace, so at any moment the scattered 8-byte
+// stores of the whole chip fall into one band's share of the key array -- small enough to sit in the L2s until its 64-byte
+// lines are complete (measured without bands at 1.5 M Gaussians / 4 293 tiles: 230-610 MB written for 96 MB of keys).
+// The per-Gaussian terms are computed once and kept in registers across the passes.
+template <bool LDSAGG, int KPT>
+__global__ void __launch_bounds__(GSR_TBIN_THREADS) k_tile_emit(TileBinArgs a, int bands)
+{
+    extern __shared__ uint32_t s_tb[];        // LDSAGG: [0, ntiles) running count, [ntiles, 2 ntiles) where this workgroup's keys of the tile start
+    __shared__ uint32_t s_pref[GSR_TBIN_THREADS];
+    if (LDSAGG) {
+        uint32_t* s_cnt = s_tb;
+        uint32_t* s_base = s_tb + a.ntiles;
+        const size_t copy = (size_t)(blockIdx.x % a.copies) * a.ntiles;
+        const uint16_t* row = a.block_counts + (size_t)blockIdx.x * a.ntiles;
+        for (int t = threadIdx.x; t < a.ntiles; t += GSR_TBIN_THREADS) {
+            const uint32_t c = row[t];          // what this workgroup counted for the tile (k_tile_count): reserve that much
+            s_base[t] = (c != 0u) ? a.tile_offset[t] + a.tile_count[copy + t] + atomicAdd(&a.tile_fill[copy + t], c) : 0u;
+            s_cnt[t] = 0u;
+        }
+        WalkItem it[KPT];
+        walk_load<KPT>(a, 0, it);
+        const int bh = (a.gy + bands - 1) / bands;
+        for (int b0 = 0; b0 < a.gy; b0 += bh) {
+            __syncthreads();
+            walk_rows<KPT>(a, it, b0, min(a.gy, b0 + bh), s_pref,
+                           [&](int tile, unsigned long long key) { a.keys[s_base[tile] + atomicAdd(&s_cnt[tile], 1u)] = key; });
+        }
+    } else {
+        for (int g0 = 0; g0 < a.gpb; g0 += KPT * GSR_TBIN_THREADS) {
+            WalkItem jt[KPT];
+            walk_load<KPT>(a, g0, jt);
+            walk_rows<KPT>(a, jt, 0, a.gy, s_pref,
+                           [&](int tile, unsigned long long key) { a.keys[a.tile_offset[tile] + atomicAdd(&a.tile_fill[tile], 1u)] = key; });
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -609,8 +799,106 @@ struct SplatLDS {
     alignas(8) uint8_t list[4][GSR_BLOCK];   // per wave: staged splats that can touch its 8x8 block, in list order
 };
 
-template <bool TOUCHED, bool LOCALSORT>
-__global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__ ranges,
+// Where the tile's list comes from:
+//   GSR_LIST_SORTED  point_list[ranges[tile]] is already in (depth, index) order (re-compositing a forward's lists);
+//   GSR_LIST_BINS    fixed-capacity bin of the native loop's speculative iterations (<= GSR_LSORT_CAP keys, appended by
+//                    k_preprocess): sorted here in LDS in one go;
+//   GSR_LIST_EXACT   the tile's segment of the exact bins (k_tile_emit), any length: ordered lazily, slice by slice.
+#define GSR_LIST_SORTED 0
+#define GSR_LIST_BINS 1
+#define GSR_LIST_EXACT 2
+#define GSR_SLICE_FIRST 512        // GSR_LIST_EXACT: the first slice aims at this many keys (most tiles saturate within it),
+#define GSR_SLICE_ALL 1024         // unless the whole segment is no longer than this; later slices take up to GSR_LSORT_CAP
+#define GSR_SEL_BITS 11            // radix of the selection histogram (2048 counters, aliased onto the key buffer)
+
+// Bitonic sort of s_keys[0, npow) (npow a power of two >= 64), ascending; all GSR_BLOCK threads.
+// (measured: a rank sort and a variant with wave-local steps and 3 barriers instead of 45 are no faster --
+// with five workgroups per CU sorting at the same time the step is bound by its ~25 VALU instructions)
+__device__ __forceinline__ void lds_bitonic_sort(unsigned long long* s_keys, int npow)
+{
+    const int tid = threadIdx.x;
+    for (int k = 2; k <= npow; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int q = tid; q < (npow >> 1); q += GSR_BLOCK) {      // one compare-exchange per lane
+                const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
+                const unsigned long long a0 = s_keys[i], a1 = s_keys[l];
+                const bool up = (i & k) == 0;
+                if ((a0 > a1) == up) { s_keys[i] = a1; s_keys[l] = a0; }
+            }
+            __syncthreads();
+        }
+}
+
+// GSR_LIST_EXACT: picks the next slice of a tile's unordered segment keys[0, total).  Keys are unique (the index is part
+// of them).  Among the keys above `lo` (all of them when `first`) finds a threshold `hi` such that the number m of keys in
+// (lo, hi] satisfies 1 <= m <= limit and, unless the keys run out of distinguishing bits earlier, m >= limit / 4:
+// most-significant-digit radix selection, GSR_SEL_BITS bits per pass over the segment (two or three passes for depths a
+// few octaves apart).  Block-uniform result; s_hist: 2^GSR_SEL_BITS counters; all threads must call.
+__device__ __forceinline__ void select_slice(const unsigned long long* __restrict__ keys, int total, bool first, unsigned long long lo,
+                                             int limit, uint32_t* s_hist, unsigned long long& hi, int& m)
+{
+    __shared__ uint32_t s_part[4];
+    __shared__ int s_best[2];            // largest digit that still fits, and the count accepted through it
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int minimum = limit >> 2;
+    unsigned long long prefix = 0ull;
+    int prefix_bits = 0, accepted = 0;
+    for (;;) {
+        const int dbits = min(GSR_SEL_BITS, 64 - prefix_bits), shift = 64 - prefix_bits - dbits;
+        const int nbins = 1 << dbits;
+        for (int i = tid; i < (1 << GSR_SEL_BITS); i += GSR_BLOCK) s_hist[i] = 0u;
+        if (tid == 0) { s_best[0] = -1; s_best[1] = accepted; }
+        __syncthreads();
+        for (int i = tid; i < total; i += GSR_BLOCK) {
+            const unsigned long long k = keys[i];
+            const bool in = (first || k > lo) && (prefix_bits == 0 || (k >> (64 - prefix_bits)) == prefix);
+            if (in) atomicAdd(&s_hist[(uint32_t)(k >> shift) & (uint32_t)(nbins - 1)], 1u);
+        }
+        __syncthreads();
+        // thread t owns bins [8 t, 8 t + 8): exclusive prefix of the per-thread sums, then a local walk
+        uint32_t c[8], mine = 0u;
+#pragma unroll
+        for (int q = 0; q < 8; q++) { c[q] = s_hist[8 * tid + q]; mine += c[q]; }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_part[wv] = incl;
+        __syncthreads();
+        uint32_t run = (uint32_t)accepted + incl - mine;
+        for (int w = 0; w < wv; w++) run += s_part[w];
+        int best = -1, best_cnt = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            run += c[q];
+            if (8 * tid + q < nbins && run <= (uint32_t)limit) { best = 8 * tid + q; best_cnt = (int)run; }
+        }
+        // cumulative counts are monotone, so the qualifying digits form a prefix: the largest one wins
+        if (best >= 0) atomicMax(&s_best[0], best);
+        __syncthreads();
+        if (best >= 0 && best == s_best[0]) s_best[1] = best_cnt;
+        __syncthreads();
+        const int d = s_best[0], acc = s_best[1];
+        __syncthreads();
+        if (acc >= minimum || shift == 0) {
+            // everything below the current prefix's digit d + 1
+            const unsigned long long top = ((prefix << dbits) + (unsigned long long)(d + 1)) << shift;      // first key NOT taken
+            hi = top - 1ull;
+            m = acc;
+            return;
+        }
+        accepted = acc;
+        prefix = (prefix << dbits) | (unsigned long long)(d + 1);
+        prefix_bits += dbits;
+    }
+}
+
+// (5 workgroups per CU keep every tile of a 640x480 image resident in one round: 96 registers.  The slice-ordering variant
+// with the n_touched counters needs a few more and gets 4 per CU rather than spilling.)
+template <bool TOUCHED, int LIST>
+__global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT) ? 4 : 5) k_render_fwd(uint2* __restrict__ ranges,
                                                           uint32_t* __restrict__ point_list,
                                                           const unsigned long long* __restrict__ bins,
                                                           uint32_t* __restrict__ tile_cursor,
@@ -625,9 +913,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
                                                           int sbx, FusedLoss fl)
 {
+    // (tile_cursor: GSR_LIST_BINS the per-tile append cursors; GSR_LIST_EXACT the tile_offset array of k_tile_scan)
     __shared__ SplatLDS s;
     __shared__ float s_zmax[4];
-    __shared__ unsigned long long s_keys[LOCALSORT ? GSR_LSORT_CAP : 1];
+    __shared__ unsigned long long s_keys[LIST != GSR_LIST_SORTED ? GSR_LSORT_CAP : 1];
     GSR_T_DECL
     const int tile = xcd_remap(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
@@ -637,7 +926,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
     const int pix_id = W * py + px;
     const float pxf = (float)px, pyf = (float)py;
     uint2 range;
-    if (LOCALSORT) {
+    if (LIST == GSR_LIST_BINS) {
         // one lane reads the tile's cursor and clears it for the next iteration's appends (no memset); everybody else
         // gets the count through LDS
         __shared__ uint32_t s_cursor;
@@ -645,13 +934,16 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
         __syncthreads();
         range.x = (uint32_t)tile * GSR_LSORT_CAP;
         range.y = range.x + s_cursor;
+    } else if (LIST == GSR_LIST_EXACT) {
+        range.x = tile_cursor[tile];
+        range.y = tile_cursor[tile + 1];
     } else range = ranges[tile];
     const int total = (int)(range.y - range.x);
 
-    if (LOCALSORT) {
+    if (LIST == GSR_LIST_BINS) {
         // this tile's bin arrives unsorted: order it by (depth bits, index) in LDS (bitonic network), keep it there
         // for the staging below and write the sorted indices (and the tile's range) back for the backward pass
-        if (total > GSR_LSORT_CAP) {          // block-uniform: give up, the host redoes the forward with global sorts
+        if (total > GSR_LSORT_CAP) {          // block-uniform: give up, the host redoes the forward with complete lists
             if (tid == 0) atomicAdd(fail, 0x10000u);
             return;
         }
@@ -661,18 +953,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
         for (int i = tid; i < npow; i += GSR_BLOCK) s_keys[i] = (i < total) ? bins[range.x + i] : ~0ull;
         __syncthreads();
         GSR_T_TICK(0)
-        // (measured: a rank sort and a variant with wave-local steps and 3 barriers instead of 45 are no faster --
-        // with five workgroups per CU sorting at the same time the step is bound by its ~25 VALU instructions)
-        for (int k = 2; k <= npow; k <<= 1)
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                for (int q = tid; q < (npow >> 1); q += GSR_BLOCK) {      // one compare-exchange per lane
-                    const int i = ((q & ~(j - 1)) << 1) | (q & (j - 1)), l = i | j;
-                    const unsigned long long a0 = s_keys[i], a1 = s_keys[l];
-                    const bool up = (i & k) == 0;
-                    if ((a0 > a1) == up) { s_keys[i] = a1; s_keys[l] = a0; }
-                }
-                __syncthreads();
-            }
+        lds_bitonic_sort(s_keys, npow);
         for (int i = tid; i < total; i += GSR_BLOCK) point_list[range.x + i] = (uint32_t)s_keys[i];
     }
     GSR_T_TICK(1)
@@ -683,13 +964,47 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
     uint32_t last_contributor = 0;
     float zneed = 0.f;        // depth bound of what this pixel had to look at (rounded up to its group of eight)
 
-    for (int base = 0; base < total; base += GSR_BLOCK) {
+    // GSR_LIST_EXACT: `consumed` entries of the segment are ordered (and written to point_list) so far; the keys of the
+    // current slice sit in s_keys[0, m).  The other modes make one pass with m = total.
+    int consumed = 0, m = total;
+    unsigned long long slice_lo = 0ull;
+  for (bool first_slice = true;; first_slice = false) {
+    if (LIST == GSR_LIST_EXACT) {
+        if (consumed >= total) break;
+        if (__syncthreads_and(T <= 0.f)) break;          // every pixel of the tile has terminated: the rest is never ordered
+        const unsigned long long* seg = bins + range.x;
+        const int remaining = total - consumed;
+        unsigned long long slice_hi = ~0ull;
+        m = remaining;
+        if (remaining > (first_slice ? GSR_SLICE_ALL : GSR_LSORT_CAP))
+            select_slice(seg, total, first_slice, slice_lo, first_slice ? GSR_SLICE_FIRST : GSR_LSORT_CAP,
+                         reinterpret_cast<uint32_t*>(s_keys), slice_hi, m);
+        if (m <= 0) {          // cannot happen with distinct keys (the index is part of them): corrupted bins -- fail loudly, never spin
+            if (tid == 0) atomicAdd(fail, 0x10000u);
+            break;
+        }
+        __shared__ uint32_t s_fill;
+        if (tid == 0) s_fill = 0u;
+        int npow = 64;
+        while (npow < m) npow <<= 1;
+        __syncthreads();
+        for (int i = tid; i < total; i += GSR_BLOCK) {
+            const unsigned long long k = seg[i];
+            if ((first_slice || k > slice_lo) && k <= slice_hi) s_keys[atomicAdd(&s_fill, 1u)] = k;
+        }
+        for (int i = m + tid; i < npow; i += GSR_BLOCK) s_keys[i] = ~0ull;
+        __syncthreads();
+        lds_bitonic_sort(s_keys, npow);
+        for (int i = tid; i < m; i += GSR_BLOCK) point_list[range.x + consumed + i] = (uint32_t)s_keys[i];
+        slice_lo = slice_hi;
+    }
+    for (int base = 0; base < m; base += GSR_BLOCK) {
         if (__syncthreads_and(T <= 0.f)) break;
         GSR_T_TICK(2)
         GSR_T_COUNT(10, 1)
-        const int n = min(GSR_BLOCK, total - base);
+        const int n = min(GSR_BLOCK, m - base);
         if (tid < n) {
-            const uint32_t id = LOCALSORT ? (uint32_t)s_keys[base + tid] : point_list[range.x + base + tid];
+            const uint32_t id = (LIST != GSR_LIST_SORTED) ? (uint32_t)s_keys[base + tid] : point_list[range.x + base + tid];
             const float2 m = xy[id];
             const float4 co = conic_op[id];
             s.a[tid] = make_float4(m.x, m.y, (-0.5f * GSR_LOG2E) * co.x, (-GSR_LOG2E) * co.y);
@@ -737,7 +1052,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
                 C0 = __builtin_fmaf(Cc.x, w, C0); C1 = __builtin_fmaf(Cc.y, w, C1); C2 = __builtin_fmaf(Cc.z, w, C2);
                 Dd = __builtin_fmaf(B.z, w, Dd);
                 T = kill ? __uint_as_float(__float_as_uint(T) | 0x80000000u) : (valid ? test_T : T);      // kill: T -> -|T|
-                last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;      // 1-based position in the tile list
+                last_contributor = blend ? (uint32_t)(consumed + base + j + 1) : last_contributor;      // 1-based position in the tile list
 #if GSR_TIMING
                 if (__ballot(valid && alive0) == 0ull) GSR_T_COUNT(8, 1)      // entry that no live pixel of this wave could use
 #endif
@@ -777,7 +1092,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
             C0 = __builtin_fmaf(Cc.x, w, C0); C1 = __builtin_fmaf(Cc.y, w, C1); C2 = __builtin_fmaf(Cc.z, w, C2);
             Dd = __builtin_fmaf(B.z, w, Dd);
             T = kill ? __uint_as_float(__float_as_uint(T) | 0x80000000u) : (valid ? test_T : T);
-            last_contributor = blend ? (uint32_t)(base + j + 1) : last_contributor;
+            last_contributor = blend ? (uint32_t)(consumed + base + j + 1) : last_contributor;
             if (TOUCHED) {
                 const int c = (int)__popcll(__ballot(valid && test_T > 0.5f));
                 if (c != 0 && lane == 0) atomicAdd(&n_touched[__float_as_uint(B.w)], c);
@@ -785,6 +1100,13 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_fwd(uint2* __restrict__
         }
         GSR_T_TICK(5)
     }
+    if (LIST != GSR_LIST_EXACT) break;
+    consumed += m;
+    __syncthreads();          // (the next slice overwrites s_keys and the staging buffers)
+  }
+    // GSR_LIST_EXACT: the tile's range is what has been ORDERED -- all that the backward pass and a re-compositing of
+    // these lists (n_touched) can need: no pixel looks beyond the slice in which the last one terminated
+    if (LIST == GSR_LIST_EXACT && tid == 0) ranges[tile] = make_uint2(range.x, range.x + (uint32_t)min(consumed, total));
     GSR_T_TICK(6)
     const bool done = (T <= 0.f);
     const float T_out = fabsf(T);
@@ -2274,24 +2596,24 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_mark_visible(int P, const float* 
     present[idx] = xform4x3(p, view).z > 0.2f ? 1 : 0;
 }
 
-// bench-only statistics: V, sum of tiles_touched, R_eff
-__global__ void __launch_bounds__(GSR_BLOCK) k_stats_gauss(int P, const int* radii, const uint32_t* tiles_touched,
-                                                           const ushort4* rects, unsigned long long* out)
+// bench-only statistics: V, R under the reference's bounding rule, instances binned, R_eff
+__global__ void __launch_bounds__(GSR_BLOCK) k_stats_gauss(int P, const int* radii, const ushort4* rects, unsigned long long* out)
 {
     const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
-    unsigned long long v = 0, t = 0, r = 0;
+    unsigned long long v = 0, r = 0;
     if (idx < P && radii[idx] > 0) {
-        v = 1; t = tiles_touched[idx];
+        v = 1;
         const ushort4 rc = rects[idx];
         r = (unsigned long long)(rc.z - rc.x) * (rc.w - rc.y);      // the reference's bounding-square count
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); t += __shfl_xor(t, off, 64); r += __shfl_xor(r, off, 64); }
-    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], v); atomicAdd(&out[1], r); atomicAdd(&out[3], t); }
+    for (int off = 32; off > 0; off >>= 1) { v += __shfl_xor(v, off, 64); r += __shfl_xor(r, off, 64); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(&out[0], v); atomicAdd(&out[1], r); }
 }
-__global__ void __launch_bounds__(GSR_BLOCK) k_stats_tiles(int W, int H, int gx, const uint32_t* n_contrib,
+__global__ void __launch_bounds__(GSR_BLOCK) k_stats_tiles(int W, int H, int gx, const uint32_t* n_contrib, const uint2* ranges,
                                                            unsigned long long* out)
 {
+    if (threadIdx.x == 0) { const uint2 rg = ranges[blockIdx.x]; atomicAdd(&out[3], (unsigned long long)(rg.y - rg.x)); }
     __shared__ int wm[4];
     const int tx = blockIdx.x % gx, ty = blockIdx.x / gx;
     const int px = tx * GSR_TILE + (threadIdx.x & 15), py = ty * GSR_TILE + (threadIdx.x >> 4);

@@ -159,7 +159,9 @@ class FusedRefiner:
         n_done, conv = C.c_int(0), C.c_int(0)
         with torch.cuda.device(dev):
             _lib.check(self.lib.gsr_pose_init(p(self.state), p(proj_raw), stream))
-            _lib.check(self.lib.gsr_refine(C.byref(a), C.byref(n_done), C.byref(conv)))
+            rc = self.lib.gsr_refine(C.byref(a), C.byref(n_done), C.byref(conv))
+            type(self.ws[0]).raise_pending(*self.ws)
+            _lib.check(rc)
         self._keep = (proj_raw, gt_image, gt_depth, mask, bg)        # alive until the stream has drained
         s = self.state.cpu()
         viewpoint.update_RT(s[0:9].reshape(3, 3).clone(), s[9:12].clone())

@@ -82,14 +82,23 @@ class _Workspace:
         self.device = device
         self.t = torch.empty(0, dtype=torch.uint8, device=device)
         self.fn = _lib.RESIZE_FN(self._resize)
+        self.error = None
 
     def _resize(self, _ctx, nbytes):
         try:
             if self.t.numel() < int(nbytes):      # a workspace that is kept (FusedRefiner) keeps its contents and its address
                 self.t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
             return self.t.data_ptr()
-        except Exception:      # surfaces as GSR_E_ALLOC
+        except Exception as ex:      # an exception cannot cross the C frame: the library sees NULL (GSR_E_ALLOC) and the
+            self.error = ex          # caller re-raises the original one (raise_pending)
             return 0
+
+    @staticmethod
+    def raise_pending(*workspaces):
+        for w in workspaces:
+            if w.error is not None:
+                ex, w.error = w.error, None
+                raise ex
 
 
 class _SpecCache(threading.local):
@@ -163,6 +172,7 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
                                          _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
                                          int(bool(rs.prefiltered)), color.data_ptr(), depth.data_ptr(), alpha.data_ptr(),
                                          _ptr(radii), int(bool(rs.debug)), _ptr(n_touched), stream)
+    _Workspace.raise_pending(geom, binning, img)          # e.g. torch's out-of-memory error, not a bare GSR_E_ALLOC
     num_rendered = _lib.check(rc)
     saved = (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom.t, binning.t, img.t, alpha,
              opacities)
