@@ -201,6 +201,8 @@ struct PassCtx {
     gsr::FusedLoss floss = {};     // tracking loss evaluated in the compositing kernel's epilogue (out == nullptr: not fused)
     int cov_cache = 0;             // 1 = this forward stores every Gaussian's 3D covariance in the geometry buffer, 2 = reads them back
     bool lean = false;             // this forward's radii are not an output (see k_preprocess)
+    uint32_t* ticket = nullptr;    // backward: the chain-rule kernel's last workgroup runs the pose step `fold` (see PreBwdArgs)
+    gsr::PoseStepArgs fold = {};
 };
 // gsr_forward_speculative: bounds, flags, cursors and the unsorted bins live in the caller's persistent state buffer
 // instead of the per-call image / binning buffers (which then only hold what the backward reads)
@@ -704,6 +706,8 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     pb.pose = pose_mode ? 1 : 0; pb.tau_acc = g.tau_acc;
     pb.dirty = cx.native_loop ? g.dirty : nullptr;
     pb.guard = cx.guard;
+    pb.ticket = cx.ticket; pb.fold = cx.fold;
+    if (pb.ticket) pb.fold.tau_acc = g.tau_acc;
     {
         ProfScope ps(K_PREPROCESS_BWD, st);
         pb.span = k8_span(P);
@@ -816,9 +820,9 @@ int gsr_pose_step(float* pose_state, const float* dL_dtau, const float* loss_out
     if (!pose_state || !dL_dtau || !loss_out || !projmatrix_raw) return fail(GSR_E_INVALID, "gsr_pose_step: NULL pointer%s", "");
     int rc = select_device_of(pose_state);
     if (rc != GSR_OK) return rc;
-    hipLaunchKernelGGL(gsr::k_pose_step, dim3(1), dim3(64), 0, st, pose_state, dL_dtau, (const double*)nullptr,
-                       (float*)nullptr, loss_out, projmatrix_raw, lr, converged_threshold, (float*)nullptr,
-                       gsr::LoopGuard{nullptr, nullptr}, (float*)nullptr, 0, (float*)nullptr, (uint32_t*)nullptr, (float*)nullptr, 0);
+    gsr::PoseStepArgs q = {};
+    q.st = pose_state; q.dL_dtau = dL_dtau; q.loss_out = loss_out; q.proj_raw = projmatrix_raw; q.lr = lr; q.conv_thr = converged_threshold;
+    hipLaunchKernelGGL(gsr::k_pose_step, dim3(1), dim3(64), 0, st, q, gsr::LoopGuard{nullptr, nullptr});
     LAUNCHCHK("k_pose_step");
     return 0;
 }
@@ -913,7 +917,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (a->dL_dsh && a->M > 0) HIPCHK(hipMemsetAsync(a->dL_dsh, 0, Pn * a->M * 3 * sizeof(float), st));
         if (a->dL_dscale) HIPCHK(hipMemsetAsync(a->dL_dscale, 0, Pn * 3 * sizeof(float), st));
         if (a->dL_drot) HIPCHK(hipMemsetAsync(a->dL_drot, 0, Pn * 4 * sizeof(float), st));
-        HIPCHK(hipMemsetAsync(ps + GSR_PS_CONV, 0, 4 * sizeof(float), st));      // converged, loss, |tau|, poison
+        HIPCHK(hipMemsetAsync(ps + GSR_PS_CONV, 0, 5 * sizeof(float), st));      // converged, loss, |tau|, poison, ticket
         // K7's accumulator records: cleared once here, afterwards K8 clears every record it consumes
         Geom gg;
         char* gptr = (char*)cached_resize(&gb, carve_geom(nullptr, a->P, gg));
@@ -969,12 +973,16 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         cx.cov_cache = cov_cached ? 2 : 1;
         cov_cached = true;
         cx.lean = (mode == 1) && (it != a->max_iters - 1);
-        float* clear_b = nullptr;      // the pose step of this iteration clears the superblock bounds buffer iteration it+1 accumulates into
-        {
-            Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
-            clear_b = (mode != 0) ? imv.zbc[par(it) ^ 1] : nullptr;
-            imv_loop = imv;
-        }
+        Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
+        imv_loop = imv;
+        // Adam + update_pose run in the chain-rule kernel's last workgroup (no launch of their own); they also finish the fp64
+        // dL/dtau reduction, clear the superblock bounds buffer iteration it+1 accumulates into and publish the status
+        cx.ticket = reinterpret_cast<uint32_t*>(ps + GSR_PS_TICKET);
+        cx.fold = PoseStepArgs{};
+        cx.fold.st = ps; cx.fold.dL_dtau = a->dL_dtau; cx.fold.dL_dtau_out = a->dL_dtau; cx.fold.loss_out = a->loss_out;
+        cx.fold.proj_raw = a->projmatrix_raw; cx.fold.lr = a->lr; cx.fold.conv_thr = a->converged_threshold; cx.fold.loss_zero = a->loss_out;
+        cx.fold.host_status = h_status + 8 * (it & 1); cx.fold.seq = it + 1; cx.fold.loss_shards = imv.loss_shards;
+        cx.fold.clear_b = (mode != 0) ? imv.zbc[par(it) ^ 1] : nullptr; cx.fold.clear_n = imv.nsb;
         int R = forward_impl(cx, cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
                              a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
                              a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
@@ -989,15 +997,6 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                                 a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor,
                                 a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, 0, 1, a->dL_dtau, a->stream);
         if (rc2 < 0) return rc2;
-        {   // Adam + update_pose; also finishes the fp64 dL/dtau reduction left open by the backward
-            Geom gg; carve_geom((char*)gb.ptr, a->P, gg);
-            ProfScope pp(K_POSE_STEP, st);
-            hipLaunchKernelGGL(k_pose_step, dim3(1), dim3(64), 0, st, ps, (const float*)a->dL_dtau, (const double*)gg.tau_acc,
-                               a->dL_dtau, (const float*)a->loss_out, a->projmatrix_raw, a->lr, a->converged_threshold,
-                               a->loss_out, cx.guard, h_status + 8 * (it & 1), it + 1, imv_loop.loss_shards, (uint32_t*)nullptr, clear_b,
-                               imv_loop.nsb);
-        }
-        LAUNCHCHK("k_pose_step");
         return 0;
     };
     // Wait for iteration `it`'s status.  A poisoned iteration (failed speculation: its loss, backward and pose step

@@ -1429,6 +1429,231 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
 }
 
 // ---------------------------------------------------------------------------------------------
+// Pose-refinement epilogue, pose state and optimiser step.
+// ---------------------------------------------------------------------------------------------
+// Device-resident state of one query frame's refinement (floats):
+//   [0..8] R (row-major W2C rotation)  [9..11] T   [12..14] cam_rot_delta  [15..17] cam_trans_delta
+//   [18] exposure_a  [19] exposure_b   [20..27] Adam exp_avg   [28..35] Adam exp_avg_sq   [36] Adam step
+//   [37] converged (0/1)  [38] last loss  [39] |tau|   [48..63] viewmatrix  [64..79] projmatrix  [80..82] campos
+#define GSR_PS_R 0
+#define GSR_PS_T 9
+#define GSR_PS_PARAM 12
+#define GSR_PS_M 20
+#define GSR_PS_V 28
+#define GSR_PS_STEP 36
+#define GSR_PS_CONV 37
+#define GSR_PS_LOSS 38
+#define GSR_PS_TAUN 39
+#define GSR_PS_POISON 40      // uint32 bits: set by the compositing kernel when a speculative forward fails (gsr_refine)
+#define GSR_PS_TICKET 41      // uint32: workgroups of the fused chain-rule kernel that have finished (native loop; returns to 0)
+#define GSR_PS_BETA 84        // two doubles (floats 84-87): beta1^step, beta2^step of Adam's bias corrections
+#define GSR_PS_VIEW 48
+#define GSR_PS_PROJ 64
+#define GSR_PS_CAMPOS 80
+#define GSR_PS_SIZE 96
+
+// view / proj / campos from (R, T): world_view_transform, full_proj_transform, camera_center of
+// gs_localization/pipelines/tools/camera_utils.py:144-158 without the two 4x4 inversions.  Everything is read into
+// registers first and written out at the end: one lane works here, and a chain of dependent LDS / global round trips (one
+// per element) is what the earlier versions of the pose step spent their time on.
+__device__ __forceinline__ void pose_write_camera(float* st, const float* R, const float* T, const float* proj_raw)
+{
+    float P[16], view[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) P[i] = proj_raw[i];
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+#pragma unroll
+        for (int r = 0; r < 3; r++) view[c * 4 + r] = R[r * 3 + c];
+        view[c * 4 + 3] = 0.f;
+    }
+    view[12] = T[0]; view[13] = T[1]; view[14] = T[2]; view[15] = 1.f;
+#pragma unroll
+    for (int i = 0; i < 16; i++) st[GSR_PS_VIEW + i] = view[i];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) acc += view[i * 4 + k] * P[k * 4 + j];
+            st[GSR_PS_PROJ + i * 4 + j] = acc;
+        }
+#pragma unroll
+    for (int c = 0; c < 3; c++) st[GSR_PS_CAMPOS + c] = -(R[0 * 3 + c] * T[0] + R[1 * 3 + c] * T[1] + R[2 * 3 + c] * T[2]);
+}
+
+__global__ void k_pose_init(float* st, const float* proj_raw)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float R[9], T[3];
+        for (int i = 0; i < 9; i++) R[i] = st[GSR_PS_R + i];
+        for (int i = 0; i < 3; i++) T[i] = st[GSR_PS_T + i];
+        pose_write_camera(st, R, T, proj_raw);
+    }
+}
+
+// Adam (torch.optim.Adam defaults, one lr for the four groups of 7scenes_localize_full_dslam.py:33-64) on
+// [rot(3), trans(3), exposure_a, exposure_b], then update_pose (tools/pose_utils.py:54-122):
+// T_w2c <- SE3_exp([trans, rot]) T_w2c, deltas <- 0, converged = |tau| < threshold.
+// tau_acc (nullable): the fp64 block sums of K8/K9; when given, this kernel also finishes the dL/dtau
+// reduction (writes dL_dtau_out) so that the separate k_tau_finish launch is not needed in the native loop.
+// loss_zero (nullable): the native loop's loss accumulator, cleared here for the next iteration once consumed.
+__device__ __forceinline__ void pose_step_body(float* st, const float* s_t6, bool have_tau_acc, float* dL_dtau_out, const float* loss_out,
+                                               const float* proj_raw, float lr, float conv_thr, float* loss_zero)
+{
+    // inputs -> registers (independent reads, one wait), see pose_write_camera
+    float t6[6], m[8], v[8], par[8], R[9], T[3], lo[3];
+#pragma unroll
+    for (int i = 0; i < 6; i++) t6[i] = s_t6[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { m[i] = st[GSR_PS_M + i]; v[i] = st[GSR_PS_V + i]; par[i] = st[GSR_PS_PARAM + i]; }
+#pragma unroll
+    for (int i = 0; i < 9; i++) R[i] = st[GSR_PS_R + i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) { T[i] = st[GSR_PS_T + i]; lo[i] = loss_out[i]; }
+    const float step = st[GSR_PS_STEP] + 1.f;
+    double* beta = reinterpret_cast<double*>(st + GSR_PS_BETA);
+    const double b1p = beta[0], b2p = beta[1];
+    if (have_tau_acc && dL_dtau_out) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) dL_dtau_out[i] = t6[i];
+    }
+    const float g[8] = {t6[3], t6[4], t6[5], t6[0], t6[1], t6[2], lo[1], lo[2]};
+    // beta^step as running products in double (torch evaluates beta ** step in double too; one multiplication per step
+    // instead of two software pow() calls on a single lane)
+    const double b1t = (step == 1.f ? 1.0 : b1p) * 0.9, b2t = (step == 1.f ? 1.0 : b2p) * 0.999;
+    const double bc1 = 1.0 - b1t, bc2 = 1.0 - b2t;
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    const float w1 = (float)(1.0 - 0.9), w2 = (float)(1.0 - 0.999);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        m[i] = m[i] + w1 * (g[i] - m[i]);                      // exp_avg.lerp_(grad, 1 - beta1)
+        v[i] = v[i] * 0.999f + w2 * (g[i] * g[i]);             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+        const float denom = sqrtf(v[i]) / bc2_sqrt + 1e-8f;
+        par[i] = par[i] + (-step_size) * (m[i] / denom);
+    }
+    // update_pose
+    const float th[3] = {par[0], par[1], par[2]};
+    const float rho[3] = {par[3], par[4], par[5]};
+    const float Wm[9] = {0.f, -th[2], th[1], th[2], 0.f, -th[0], -th[1], th[0], 0.f};
+    float W2[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) W2[i * 3 + j] = Wm[i * 3] * Wm[j] + Wm[i * 3 + 1] * Wm[3 + j] + Wm[i * 3 + 2] * Wm[6 + j];
+    const float angle = sqrtf(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
+    float cW, cW2, vW, vW2;
+    if (angle < 1e-5f) { cW = 1.f; cW2 = 0.5f; vW = 0.5f; vW2 = 1.0f / 6.0f; }
+    else {
+        cW = sinf(angle) / angle; cW2 = (1.f - cosf(angle)) / (angle * angle);
+        vW = (1.0f - cosf(angle)) / (angle * angle); vW2 = (angle - sinf(angle)) / (angle * angle * angle);
+    }
+    float Re[9], Vm[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const float I = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+        Re[i] = I + cW * Wm[i] + cW2 * W2[i];
+        Vm[i] = I + Wm[i] * vW + W2[i] * vW2;
+    }
+    float te[3], Rn[9], Tn[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) te[i] = Vm[i * 3] * rho[0] + Vm[i * 3 + 1] * rho[1] + Vm[i * 3 + 2] * rho[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) Rn[i * 3 + j] = Re[i * 3] * R[j] + Re[i * 3 + 1] * R[3 + j] + Re[i * 3 + 2] * R[6 + j];
+        Tn[i] = Re[i * 3] * T[0] + Re[i * 3 + 1] * T[1] + Re[i * 3 + 2] * T[2] + te[i];
+    }
+    const float taun = sqrtf(rho[0] * rho[0] + rho[1] * rho[1] + rho[2] * rho[2] + th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
+    // results
+    st[GSR_PS_STEP] = step;
+    beta[0] = b1t; beta[1] = b2t;
+#pragma unroll
+    for (int i = 0; i < 8; i++) { st[GSR_PS_M + i] = m[i]; st[GSR_PS_V + i] = v[i]; }
+    st[GSR_PS_PARAM + 6] = par[6]; st[GSR_PS_PARAM + 7] = par[7];
+#pragma unroll
+    for (int i = 0; i < 9; i++) st[GSR_PS_R + i] = Rn[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) st[GSR_PS_T + i] = Tn[i];
+#pragma unroll
+    for (int i = 0; i < 6; i++) st[GSR_PS_PARAM + i] = 0.f;          // cam_rot_delta / cam_trans_delta .fill_(0)
+    st[GSR_PS_CONV] = (taun < conv_thr) ? 1.f : 0.f;
+    st[GSR_PS_TAUN] = taun;
+    st[GSR_PS_LOSS] = lo[0];
+    if (loss_zero != nullptr) { loss_zero[0] = 0.f; loss_zero[1] = 0.f; loss_zero[2] = 0.f; loss_zero[3] = 0.f; }
+    pose_write_camera(st, Rn, Tn, proj_raw);
+}
+
+// The whole pose step on one wave (64 lanes; called by k_pose_step and, in the native loop, by the last workgroup of the
+// chain-rule kernel).  The update itself is one lane's work, but as a chain of ~130 dependent global accesses it took 11 us:
+// the state, the loss terms and the projection matrix are brought into LDS by the whole wave first and written back at the end.
+// host_status (nullable, pinned host memory, 8 floats): the native loop's per-iteration status {converged, loss, |tau|,
+// poison bits} followed by the sequence number `seq`, written on every path -- no copy kernel, no event: the host polls
+// the sequence word.  tau_acc is read with agent-scope atomic loads (other workgroups of the same launch added to it).
+struct PoseStepArgs {
+    float* st; const float* dL_dtau; double* tau_acc; float* dL_dtau_out; const float* loss_out; const float* proj_raw;
+    float lr, conv_thr; float* loss_zero; float* host_status; int seq; float* loss_shards; float* clear_b; int clear_n;
+};
+struct alignas(16) PoseStepLDS { float st[GSR_PS_SIZE]; float t6[8]; float loss[4]; float proj[16]; };
+__device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard guard, PoseStepLDS& s)
+{
+    const bool run = !guard.frozen();          // wave-uniform
+    const int lane = threadIdx.x & 63;
+    float* st = q.st;
+    if (run) {
+        for (int i = lane; i < GSR_PS_SIZE; i += 64) s.st[i] = st[i];
+        if (q.tau_acc != nullptr) {            // lane = slot: 64 partial sums per component -> fp64 wave reduction
+            double v[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                v[i] = __hip_atomic_load(&q.tau_acc[lane * 8 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int i = 0; i < 6; i++) {
+                const double t = wave_sum_d(v[i]);
+                if (lane == 0) s.t6[i] = (float)t;
+            }
+            if (q.loss_zero != nullptr) {      // native loop: leave the partial sums clean for the next backward
+#pragma unroll
+                for (int i = 0; i < 8; i++) q.tau_acc[lane * 8 + i] = 0.0;
+            }
+        } else if (lane < 6) s.t6[lane] = q.dL_dtau[lane];
+        if (q.loss_shards != nullptr) {
+            // fused loss: lane = shard * 4 + component -- one load per lane (sixteen load -> store round trips on four lanes
+            // were most of this step's time), summed over the shards by shuffles, shards cleared for the next iteration
+            const int c = lane & 3, sh = lane >> 2;
+            float v = q.loss_shards[sh * 16 + c];
+            q.loss_shards[sh * 16 + c] = 0.f;
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+            if (lane < 4) s.loss[lane] = v;
+        } else if (lane < 4) s.loss[lane] = q.loss_out[lane];
+        if (q.clear_b != nullptr)                    // per-superblock bounds the next forward accumulates into
+            for (int i = lane; i < q.clear_n; i += 64) q.clear_b[i] = 0.f;
+        if (lane >= 16 && lane < 32) s.proj[lane - 16] = q.proj_raw[lane - 16];
+        __builtin_amdgcn_wave_barrier();
+        if (lane == 0) pose_step_body(s.st, s.t6, q.tau_acc != nullptr, q.dL_dtau_out, s.loss, s.proj, q.lr, q.conv_thr, nullptr);
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < GSR_PS_SIZE; i += 64)
+            if (i != GSR_PS_POISON && i != GSR_PS_TICKET) st[i] = s.st[i];           // (those two words belong to other kernels and the host)
+        if (q.loss_zero != nullptr && lane < 4) q.loss_zero[lane] = 0.f;
+    }
+    if (lane == 0 && q.host_status != nullptr) {
+        const float* cur = run ? s.st : st;
+        q.host_status[0] = cur[GSR_PS_CONV]; q.host_status[1] = cur[GSR_PS_LOSS]; q.host_status[2] = cur[GSR_PS_TAUN];
+        q.host_status[3] = __uint_as_float(guard.poison ? *guard.poison : 0u);
+        __threadfence_system();
+        reinterpret_cast<volatile int*>(q.host_status)[4] = q.seq;
+    }
+}
+__global__ void __launch_bounds__(64) k_pose_step(PoseStepArgs q, LoopGuard guard)
+{
+    __shared__ PoseStepLDS s;
+    if (blockIdx.x == 0) pose_step_wave(q, guard, s);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K8+K9  per-Gaussian chain rule (replaces backward.cu:144-274 computeCov2DCUDA and :346-396
 // preprocessCUDA, fused into one pass) + the SE(3) pose-gradient reduction of the pose package.
 // One lane per Gaussian; HBM-streaming.  Every output element is written exactly once.
@@ -1450,6 +1675,10 @@ struct PreBwdArgs {
     uint8_t* dirty;
     LoopGuard guard;
     int span;       // Gaussians per wave: a multiple of GSR_K8_SPAN, at most GSR_K8_SPAN_MAX (k8_span)
+    // Native loop only (ticket nullable): the workgroup that finishes LAST runs the pose step (Adam, update_pose, camera
+    // matrices, status for the host) right here instead of in a launch of its own: every workgroup bumps the ticket once its
+    // dL/dtau sums are out; whoever draws the last number sees all of them.
+    uint32_t* ticket; PoseStepArgs fold;
 };
 
 __device__ __forceinline__ float3 dnormvdv3(float3 v, float3 dv)
@@ -1591,10 +1820,13 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     __shared__ float4 s_sh[GSR_K8_ROWS * GSR_SH16_LDS4];
     __shared__ uint16_t s_list[GSR_K8_SPAN_MAX];      // active Gaussians of the span (index within the span), compacted
     __shared__ uint8_t s_flag[GSR_K8_SPAN_MAX];       // per compacted entry: 1 = has a colour gradient (SH row needed)
+    __shared__ PoseStepLDS s_pose;
     const int lane = threadIdx.x;
     const int base = blockIdx.x * a.span;
-    if (a.guard.frozen()) return;
+    const bool frozen = a.guard.frozen();      // (a frozen iteration still takes its ticket: the last workgroup publishes the status)
+    if (frozen && a.ticket == nullptr) return;
     float tau[6] = {0, 0, 0, 0, 0, 0};
+  if (!frozen) {
     // SH rows in (and dL_dsh rows out) as 16-B-per-lane streams of whole 192-B rows through LDS
     const bool staged = (a.shs != nullptr) && sh16_vector_ok(a.M, a.shs) &&
                         (a.dL_dsh == nullptr || (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u) == 0);
@@ -1877,6 +2109,30 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         for (int i = 0; i < 6; i++) {
             const double t = wave_sum_d((double)tau[i]);
             if (lane == 0 && t != 0.0) atomicAdd(&a.tau_acc[(blockIdx.x & (GSR_TAU_SLOTS - 1)) * 8 + i], t);
+        }
+    }
+  }
+    if (a.ticket != nullptr) {
+        // Two levels: ~2000 workgroups drawing from ONE counter would queue up at the memory-side atomic unit for longer
+        // than the kernel runs (measured: +54 us).  Workgroups sharing a dL/dtau slot (blockIdx mod 64) count in the unused
+        // words of that slot; the last of each group draws from the main ticket.  (The pose step zeroes the slots.)
+        const uint32_t grp = blockIdx.x & (GSR_TAU_SLOTS - 1);
+        const uint32_t in_grp = (gridDim.x - grp + GSR_TAU_SLOTS - 1) / GSR_TAU_SLOTS;
+        const uint32_t ngrp = min((uint32_t)GSR_TAU_SLOTS, gridDim.x);
+        // The dL/dtau sums are memory-side atomics: once they have completed (vmcnt drained) every later reader sees them --
+        // no release fence, which at agent scope would write this XCD's whole L2 back (measured: +50 us on this kernel).
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t t = 0u;
+        if (lane == 0) {
+            t = atomicAdd(reinterpret_cast<uint32_t*>(&a.tau_acc[grp * 8 + 6]), 1u);
+            if (t == in_grp - 1u) t = atomicAdd(a.ticket, 1u) + 0x10000u;
+        }
+        t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        if (t == 0x10000u + ngrp - 1u) {
+            // last of all: everybody's sums are in (read below with agent-scope atomic loads, past this CU's L1)
+            if (lane == 0) *a.ticket = 0u;             // (the next launch starts counting from zero)
+            reinterpret_cast<uint32_t*>(&a.tau_acc[lane * 8 + 6])[0] = 0u;      // the group counters too, also on a frozen iteration
+            pose_step_wave(a.fold, a.guard, s_pose);
         }
     }
 }
@@ -2424,166 +2680,6 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_tracking_loss(LossArgs a)
     if (threadIdx.x < 3) {
         const float t = s_red[0][threadIdx.x] + s_red[1][threadIdx.x] + s_red[2][threadIdx.x] + s_red[3][threadIdx.x];
         if (t != 0.f) atomicAdd(&a.out[threadIdx.x], t);
-    }
-}
-
-// Device-resident state of one query frame's refinement (floats):
-//   [0..8] R (row-major W2C rotation)  [9..11] T   [12..14] cam_rot_delta  [15..17] cam_trans_delta
-//   [18] exposure_a  [19] exposure_b   [20..27] Adam exp_avg   [28..35] Adam exp_avg_sq   [36] Adam step
-//   [37] converged (0/1)  [38] last loss  [39] |tau|   [48..63] viewmatrix  [64..79] projmatrix  [80..82] campos
-#define GSR_PS_R 0
-#define GSR_PS_T 9
-#define GSR_PS_PARAM 12
-#define GSR_PS_M 20
-#define GSR_PS_V 28
-#define GSR_PS_STEP 36
-#define GSR_PS_CONV 37
-#define GSR_PS_LOSS 38
-#define GSR_PS_TAUN 39
-#define GSR_PS_POISON 40      // uint32 bits: set by the compositing kernel when a speculative forward fails (gsr_refine)
-#define GSR_PS_VIEW 48
-#define GSR_PS_PROJ 64
-#define GSR_PS_CAMPOS 80
-#define GSR_PS_SIZE 96
-
-// view / proj / campos from (R, T): world_view_transform, full_proj_transform, camera_center of
-// gs_localization/pipelines/tools/camera_utils.py:144-158 without the two 4x4 inversions
-__device__ __forceinline__ void pose_write_camera(float* st, const float* proj_raw)
-{
-    const float* R = st + GSR_PS_R;
-    const float* T = st + GSR_PS_T;
-    float* view = st + GSR_PS_VIEW;
-    for (int c = 0; c < 3; c++) {
-        for (int r = 0; r < 3; r++) view[c * 4 + r] = R[r * 3 + c];
-        view[c * 4 + 3] = 0.f;
-    }
-    view[12] = T[0]; view[13] = T[1]; view[14] = T[2]; view[15] = 1.f;
-    float* proj = st + GSR_PS_PROJ;
-    for (int i = 0; i < 4; i++)
-        for (int j = 0; j < 4; j++) {
-            float acc = 0.f;
-            for (int k = 0; k < 4; k++) acc += view[i * 4 + k] * proj_raw[k * 4 + j];
-            proj[i * 4 + j] = acc;
-        }
-    for (int c = 0; c < 3; c++) st[GSR_PS_CAMPOS + c] = -(R[0 * 3 + c] * T[0] + R[1 * 3 + c] * T[1] + R[2 * 3 + c] * T[2]);
-}
-
-__global__ void k_pose_init(float* st, const float* proj_raw)
-{
-    if (threadIdx.x == 0 && blockIdx.x == 0) pose_write_camera(st, proj_raw);
-}
-
-// Adam (torch.optim.Adam defaults, one lr for the four groups of 7scenes_localize_full_dslam.py:33-64) on
-// [rot(3), trans(3), exposure_a, exposure_b], then update_pose (tools/pose_utils.py:54-122):
-// T_w2c <- SE3_exp([trans, rot]) T_w2c, deltas <- 0, converged = |tau| < threshold.
-// tau_acc (nullable): the fp64 block sums of K8/K9; when given, this kernel also finishes the dL/dtau
-// reduction (writes dL_dtau_out) so that the separate k_tau_finish launch is not needed in the native loop.
-// loss_zero (nullable): the native loop's loss accumulator, cleared here for the next iteration once consumed.
-__device__ __forceinline__ void pose_step_body(float* st, const float* s_t6, bool have_tau_acc, float* dL_dtau_out, const float* loss_out,
-                                               const float* proj_raw, float lr, float conv_thr, float* loss_zero)
-{
-    float t6[6];
-    for (int i = 0; i < 6; i++) t6[i] = s_t6[i];
-    if (have_tau_acc && dL_dtau_out) for (int i = 0; i < 6; i++) dL_dtau_out[i] = t6[i];
-    float g[8] = {t6[3], t6[4], t6[5], t6[0], t6[1], t6[2], loss_out[1], loss_out[2]};
-    const float step = st[GSR_PS_STEP] + 1.f;
-    st[GSR_PS_STEP] = step;
-    const double bc1 = 1.0 - pow(0.9, (double)step), bc2 = 1.0 - pow(0.999, (double)step);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    const float w1 = (float)(1.0 - 0.9), w2 = (float)(1.0 - 0.999);
-    for (int i = 0; i < 8; i++) {
-        float m = st[GSR_PS_M + i], v = st[GSR_PS_V + i];
-        m = m + w1 * (g[i] - m);                         // exp_avg.lerp_(grad, 1 - beta1)
-        v = v * 0.999f + w2 * (g[i] * g[i]);             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        st[GSR_PS_M + i] = m; st[GSR_PS_V + i] = v;
-        const float denom = sqrtf(v) / bc2_sqrt + 1e-8f;
-        st[GSR_PS_PARAM + i] = st[GSR_PS_PARAM + i] + (-step_size) * (m / denom);
-    }
-    // update_pose
-    const float th[3] = {st[GSR_PS_PARAM + 0], st[GSR_PS_PARAM + 1], st[GSR_PS_PARAM + 2]};
-    const float rho[3] = {st[GSR_PS_PARAM + 3], st[GSR_PS_PARAM + 4], st[GSR_PS_PARAM + 5]};
-    const float Wm[9] = {0.f, -th[2], th[1], th[2], 0.f, -th[0], -th[1], th[0], 0.f};
-    float W2[9];
-    for (int i = 0; i < 3; i++)
-        for (int j = 0; j < 3; j++) W2[i * 3 + j] = Wm[i * 3] * Wm[j] + Wm[i * 3 + 1] * Wm[3 + j] + Wm[i * 3 + 2] * Wm[6 + j];
-    const float angle = sqrtf(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
-    float cW, cW2, vW, vW2;
-    if (angle < 1e-5f) { cW = 1.f; cW2 = 0.5f; vW = 0.5f; vW2 = 1.0f / 6.0f; }
-    else {
-        cW = sinf(angle) / angle; cW2 = (1.f - cosf(angle)) / (angle * angle);
-        vW = (1.0f - cosf(angle)) / (angle * angle); vW2 = (angle - sinf(angle)) / (angle * angle * angle);
-    }
-    float Re[9], Vm[9];
-    for (int i = 0; i < 9; i++) {
-        const float I = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
-        Re[i] = I + cW * Wm[i] + cW2 * W2[i];
-        Vm[i] = I + Wm[i] * vW + W2[i] * vW2;
-    }
-    float te[3];
-    for (int i = 0; i < 3; i++) te[i] = Vm[i * 3] * rho[0] + Vm[i * 3 + 1] * rho[1] + Vm[i * 3 + 2] * rho[2];
-    float Rn[9], Tn[3];
-    const float* R = st + GSR_PS_R;
-    const float* T = st + GSR_PS_T;
-    for (int i = 0; i < 3; i++) {
-        for (int j = 0; j < 3; j++) Rn[i * 3 + j] = Re[i * 3] * R[j] + Re[i * 3 + 1] * R[3 + j] + Re[i * 3 + 2] * R[6 + j];
-        Tn[i] = Re[i * 3] * T[0] + Re[i * 3 + 1] * T[1] + Re[i * 3 + 2] * T[2] + te[i];
-    }
-    const float taun = sqrtf(rho[0] * rho[0] + rho[1] * rho[1] + rho[2] * rho[2] + th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
-    for (int i = 0; i < 9; i++) st[GSR_PS_R + i] = Rn[i];
-    for (int i = 0; i < 3; i++) st[GSR_PS_T + i] = Tn[i];
-    for (int i = 0; i < 6; i++) st[GSR_PS_PARAM + i] = 0.f;          // cam_rot_delta / cam_trans_delta .fill_(0)
-    st[GSR_PS_CONV] = (taun < conv_thr) ? 1.f : 0.f;
-    st[GSR_PS_TAUN] = taun;
-    st[GSR_PS_LOSS] = loss_out[0];
-    if (loss_zero != nullptr) { loss_zero[0] = 0.f; loss_zero[1] = 0.f; loss_zero[2] = 0.f; loss_zero[3] = 0.f; }
-    pose_write_camera(st, proj_raw);
-}
-
-
-// host_status (nullable, pinned host memory, 8 floats): the native loop's per-iteration status {converged, loss,
-// |tau|, poison bits} followed by the sequence number `seq`, written by this kernel itself on every exit path --
-// no copy kernel, no event: the host polls the sequence word.
-__global__ void k_pose_step(float* st, const float* dL_dtau, const double* tau_acc, float* dL_dtau_out,
-                            const float* loss_out, const float* proj_raw, float lr, float conv_thr, float* loss_zero,
-                            LoopGuard guard, float* host_status, int seq, float* loss_shards, uint32_t* clear_a, float* clear_b,
-                            int clear_n)
-{
-    if (blockIdx.x != 0) return;
-    const bool run = !guard.frozen();          // block-uniform
-    // The update itself is one lane's work, but as a chain of ~130 dependent global accesses it took 11 us: the state,
-    // the loss terms and the projection matrix are brought into LDS by the whole wave first and written back at the end.
-    __shared__ float s_st[GSR_PS_SIZE], s_t6[6], s_loss[4], s_proj[16];
-    const int tid = threadIdx.x;
-    if (run) {
-        for (int i = tid; i < GSR_PS_SIZE; i += blockDim.x) s_st[i] = st[i];
-        if (tid < 6) s_t6[tid] = tau_acc ? (float)tau_total(tau_acc, tid) : dL_dtau[tid];
-        if (tid >= 8 && tid < 12) {
-            float v = loss_out[tid - 8];
-            if (loss_shards != nullptr) {          // fused loss: add up (and clear) the shards the compositing kernel filled
-                v = 0.f;
-                for (int sh = 0; sh < GSR_LOSS_SHARDS; sh++) { v += loss_shards[sh * 16 + (tid - 8)]; loss_shards[sh * 16 + (tid - 8)] = 0.f; }
-            }
-            s_loss[tid - 8] = v;
-        }
-        if (clear_b != nullptr)                    // per-superblock bounds the next forward accumulates into (see LossArgs)
-            for (int i = tid; i < clear_n; i += blockDim.x) { if (clear_a != nullptr) clear_a[i] = 0u; clear_b[i] = 0.f; }
-        if (tid >= 16 && tid < 32) s_proj[tid - 16] = proj_raw[tid - 16];
-        __syncthreads();
-        if (tau_acc != nullptr && loss_zero != nullptr)        // native loop: leave the partial sums clean for the next backward
-            for (int i = tid; i < 8 * GSR_TAU_SLOTS; i += blockDim.x) const_cast<double*>(tau_acc)[i] = 0.0;
-        if (tid == 0) pose_step_body(s_st, s_t6, tau_acc != nullptr, dL_dtau_out, s_loss, s_proj, lr, conv_thr, nullptr);
-        __syncthreads();
-        for (int i = tid; i < GSR_PS_SIZE; i += blockDim.x)
-            if (i != GSR_PS_POISON) st[i] = s_st[i];           // (the poison word belongs to the compositing kernel and the host)
-        if (loss_zero != nullptr && tid < 4) loss_zero[tid] = 0.f;
-    }
-    if (tid == 0 && host_status != nullptr) {
-        const float* cur = run ? s_st : st;
-        host_status[0] = cur[GSR_PS_CONV]; host_status[1] = cur[GSR_PS_LOSS]; host_status[2] = cur[GSR_PS_TAUN];
-        host_status[3] = __uint_as_float(guard.poison ? *guard.poison : 0u);
-        __threadfence_system();
-        reinterpret_cast<volatile int*>(host_status)[4] = seq;
     }
 }
 

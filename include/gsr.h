@@ -207,7 +207,9 @@ int gsr_tracking_loss(int width, int height, const float* image, const float* de
 /* Device-resident pose state: GSR_POSE_STATE_FLOATS floats, layout
  *   [0..8] R (row-major W2C rotation) [9..11] T [12..14] cam_rot_delta [15..17] cam_trans_delta
  *   [18] exposure_a [19] exposure_b [20..27] Adam exp_avg [28..35] Adam exp_avg_sq [36] Adam step
- *   [37] converged [38] last loss [39] |tau| [40] poison word of gsr_refine (uint32) [48..63] viewmatrix [64..79] projmatrix [80..82] campos
+ *   [37] converged [38] last loss [39] |tau| [40] poison word of gsr_refine (uint32) [41] workgroup ticket of gsr_refine (uint32)
+ *   [48..63] viewmatrix [64..79] projmatrix [80..82] campos [84..87] beta1^step, beta2^step as two doubles (Adam's bias corrections)
+ * All zeros + R, T (+ exposure) is a valid initial state.
  * (viewmatrix/projmatrix/campos are what gsr_forward / gsr_backward take).
  * gsr_pose_init fills [48..82] from R, T and projmatrix_raw (16 floats, P^T row-major), replacing
  * Camera.world_view_transform / full_proj_transform / camera_center (tools/camera_utils.py:144-158). */
