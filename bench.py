@@ -11,11 +11,16 @@ and keeps F frames in flight (one host thread + one HIP stream each): the compos
 dependent per-wave work, so a second frame's kernels fill the issue slots the first one leaves empty.
 
 A "step" is one iteration of every frame in flight on a rank; `value` = world * F * K / time.
-Also reported: the single-frame native loop, and the reference-style Python loop on the same kernels.
+Reported next to it, first-class: `single_frame_iters_per_s` (one frame alone on the native loop: the number comparable with
+the reference's one-frame-at-a-time loop), `plain_loop_iters_per_s` (native loop without depth speculation: complete lists
+every iteration) and `python_loop_iters_per_s` (the reference-style Python loop on the drop-in packages: what the unchanged
+scripts would run).
 
-Prints ONE JSON line on rank 0 with two extra objects:
-  roofline     -- dominant kernel's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak
-  cpu_baseline -- the CPU oracle (a port, oracle/gs_oracle.c, OpenMP) on the same scene, rank 0, N=1
+Prints ONE JSON line on rank 0 with extra objects:
+  roofline     -- dominant kernel's algorithmic bytes / its HIP-event duration vs the 8 TB/s HBM peak; whole-iteration
+                  traffic and issue-slot utilisation from the committed rocprofv3 counter passes (profiles/)
+  cpu_baseline -- the CPU oracle (a port, oracle/gs_oracle.c, OpenMP) on the same scene, rank 0, N=1 (+ other scenes / 1 thread)
+  train_step   -- BASELINE.json config 4: ms per train.py-style step at P = 0.2 / 0.8 / 1.5 M (rank 0, N=1)
 """
 import argparse
 import ctypes as C
@@ -37,20 +42,20 @@ HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md, "HBM3E peak 
 
 
 def algorithmic_bytes(P, V, R, R_eff, N, M, ntiles):
-    """SURVEY.md section 8(d) 'Algorithmic bytes per fwd+bwd iteration', split per kernel."""
+    """SURVEY.md section 8(d) 'Algorithmic bytes per fwd+bwd iteration' -- the REFERENCE algorithm's bytes, attributed to the
+    kernels here that do that work (the three binning kernels stand for the reference's emit + 64-bit key sort + ranges)."""
     passes = math.ceil((32 + math.ceil(math.log2(ntiles))) / 8)
     per = {
         "preprocess_fwd": P * 44 + V * 48,
         "sh_color": P * 12 * M,
-        "scan": 0,
-        "emit": R * 12,
-        "sort": passes * R * 24,
-        "ranges": R * 8,
+        "tile_count": 0,
+        "tile_scan": R * 8,
+        "tile_emit": R * 12 + passes * R * 24,
         "render_fwd": R_eff * 44 + N * 24,
         "bwd_zero": 0,
         "render_bwd": N * 24 + R_eff * 44 + R_eff * 36,
         "preprocess_bwd": V * (48 + 36) + P * (44 + 12 * M) + P * (40 + 12 * M),
-        "depth_sort": 0,    # our own extra pass (sorting P Gaussians by depth); not part of the reference's byte model
+        "pose_step": 0,
     }
     return per, passes
 
@@ -62,7 +67,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--frames-in-flight", type=int, default=4, help="query frames refined concurrently per GPU")
+    ap.add_argument("--repeats", type=int, default=3, help="the timed region is run this many times; `value` is the first, the rest show the spread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the CPU port on one thread on S-800k-chess (minutes)")
+    ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--pose-only", action="store_true", help="skip the Gaussian-parameter gradients (not the headline)")
     args = ap.parse_args()
 
@@ -91,21 +99,13 @@ def main():
     config = PL.TRACKING_CONFIG
     w2c_gt = np.eye(4)
 
-    def make_view(uid):
-        return PL.make_frame(sc, model, dev, background, uid=uid)
-
     # query frames of this rank (global ids rank*F .. rank*F+F-1): GT pose = identity, start pose off by
     # (2 cm, 1 deg) in a per-frame random direction (SURVEY 8(c) fixture 9)
     frame_ids = [rank * F + f for f in range(F)]
-    w2c_inits, inits, vps = [], [], []
-    for fid in frame_ids:
-        rng = np.random.default_rng(1000 + fid)
-        d_t = rng.normal(size=3); d_t *= 0.02 / np.linalg.norm(d_t)
-        d_r = rng.normal(size=3); d_r *= math.radians(1.0) / np.linalg.norm(d_r)
-        w2c_inits.append(S.se3_exp(np.concatenate([d_t, d_r])) @ w2c_gt)
-        inits.append(torch.tensor(w2c_inits[-1], dtype=torch.float32, device=dev))
-        vps.append(make_view(fid))
-    vp, init, w2c_init = vps[0], inits[0], w2c_inits[0]
+    inits = [PL.perturbed_start(1000 + fid, device=dev) for fid in frame_ids]
+    vps = [PL.make_frame(sc, model, dev, background, uid=fid) for fid in frame_ids]
+    vp, init = vps[0], inits[0]
+    w2c_init = init.cpu().numpy().astype(np.float64)
 
     def reset(v=vp, i0=init):
         v.update_RT(i0[:3, :3].clone(), i0[:3, 3].clone())
@@ -137,19 +137,19 @@ def main():
     lib.gsr_profile_enable(0)
     del _pkg
 
-    # scene statistics at the start pose (V, R under the reference rule, R' emitted, R_eff of own binning)
+    # scene statistics at the start pose (V, R under the reference rule, list entries ordered, R_eff of own binning)
     stats = (C.c_longlong * 4)()
     reset()
     pkg = PL.render(vp, model, background)          # fresh graph: saved tensors still alive
     sv = pkg["render"].grad_fn.saved_tensors
     _lib.check(lib.gsr_forward_stats(sc.P, W, H, sv[5].data_ptr(), sv[7].data_ptr(), sv[9].data_ptr(), stats,
                                      torch.cuda.current_stream().cuda_stream))
-    V, R, R_emit, R_eff_culled = (int(stats[i]) for i in range(4))
+    V, R, R_ordered, R_eff_culled = (int(stats[i]) for i in range(4))
     del pkg, sv
     # the byte model is defined on the REFERENCE's binning (bounding-square rule), whatever the
     # implementation emits.  V and R under that rule come from the GPU stats; R_eff under that rule needs the
     # reference lists, so it is taken from the CPU oracle's forward at this pose (cpu_baseline leg).
-    cpu = None
+    cpu, cpu_more = None, None
     R_eff, R_eff_src = R_eff_culled, "own culled binning (no CPU oracle run)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu, ref_counts = cpu_baseline(sc, w2c_init)
@@ -157,6 +157,7 @@ def main():
         # of Gaussians on the cull boundaries may differ)
         if abs(ref_counts["V"] - V) <= 1e-3 * V and abs(ref_counts["R"] - R) <= 1e-3 * R:
             R_eff, R_eff_src = ref_counts["R_eff"], "reference bounding rule (CPU oracle at the same pose)"
+        cpu_more = cpu_baseline_other_scenes(args.cpu_baseline_full)
     per_kernel_bytes, passes = algorithmic_bytes(sc.P, V, R, R_eff, N, M, ntiles)
     total_bytes = sum(per_kernel_bytes.values())
 
@@ -174,25 +175,30 @@ def main():
     # ---- (b) the native loop (gsr_refine), one frame at a time; per-kernel breakdown from a separate short run
     frs = [PL.FusedRefiner(model, H, W, device=dev, gaussian_grads=not args.pose_only) for _ in range(F)]
 
-    def native(f, iters, stop=False):
+    def native(f, iters, stop=False, speculative=True):
         return frs[f].refine(vps[f], config, inits[f][:3, :3].clone(), inits[f][:3, 3].clone(), background, iters=iters,
-                             stop_on_converged=stop)
-    native(0, Wm)
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    native(0, K)
-    torch.cuda.synchronize(); barrier()
-    elapsed_single = time.perf_counter() - t0
+                             stop_on_converged=stop, speculative=speculative)
+
+    def timed_single(spec):
+        native(0, Wm, speculative=spec)
+        barrier(); torch.cuda.synchronize()
+        t = time.perf_counter()
+        native(0, K, speculative=spec)
+        torch.cuda.synchronize(); barrier()
+        return time.perf_counter() - t
+    elapsed_single = timed_single(True)
+    elapsed_plain = timed_single(False)
     PROF_ITERS = 40
-    lib.gsr_profile_enable((1 << nk) - 1)
-    native(0, PROF_ITERS)
-    torch.cuda.synchronize()
-    prof = collect()
-    lib.gsr_profile_enable(0)
-    # ms per ITERATION (all launches of that kernel; the first iteration of a frame bins with the global sorts, the
-    # others by tile) and the kernel the loop spends most time in
-    native_ms = {k: v[0] / PROF_ITERS for k, v in prof.items()}
-    dominant = max(native_ms, key=native_ms.get)
+    native_ms = {}
+    for spec in (True, False):
+        lib.gsr_profile_enable((1 << nk) - 1)
+        native(0, PROF_ITERS, speculative=spec)
+        torch.cuda.synchronize()
+        prof = collect()
+        lib.gsr_profile_enable(0)
+        # ms per ITERATION (all launches of that kernel; the first iteration of a speculative frame bins completely, the others by tile)
+        native_ms[spec] = {k: v[0] / PROF_ITERS for k, v in prof.items()}
+    dominant = max(native_ms[True], key=native_ms[True].get)
 
     # ---- (c) TIMED REGION of `value`: F frames in flight per rank, K iterations each, native loop.
     # Only the dominant kernel is bracketed by HIP events (on the stream it is launched on).
@@ -219,18 +225,24 @@ def main():
     # of the other frames in flight (measured: -5 % on `value`)
     lib.gsr_profile_sampling(16)
     lib.gsr_profile_enable(1 << names.index(dominant))
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run_all(K)
-    torch.cuda.synchronize(); barrier()
-    elapsed = time.perf_counter() - t0
-    dom_ms, dom_n = collect()[dominant]
-    lib.gsr_profile_enable(0)
-    lib.gsr_profile_sampling(1)
+    elapsed_runs = []
+    dom_ms, dom_n = 0.0, 0
+    for rep in range(max(1, args.repeats)):
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_all(K)
+        torch.cuda.synchronize(); barrier()
+        elapsed_runs.append(time.perf_counter() - t0)
+        if rep == 0:
+            dom_ms, dom_n = collect()[dominant]
+            lib.gsr_profile_enable(0)
+            lib.gsr_profile_sampling(1)
+    elapsed = elapsed_runs[0]
     if world > 1:
-        t = torch.tensor([elapsed, elapsed_py, elapsed_single], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, elapsed_py, elapsed_single, elapsed_plain] + elapsed_runs, dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed, elapsed_py, elapsed_single = (float(x) for x in t.tolist())
+        vals = [float(x) for x in t.tolist()]
+        elapsed, elapsed_py, elapsed_single, elapsed_plain, elapsed_runs = vals[0], vals[1], vals[2], vals[3], vals[4:]
 
     # ---- pose error of full 50-iteration refinements with the reference's early exit (untimed), all frames gathered
     run_all(50, stop=True)
@@ -243,18 +255,31 @@ def main():
     te0, re0 = PL.pose_errors(w2c_gt[:3, :3], w2c_gt[:3, 3], w2c_init[:3, :3], w2c_init[:3, 3])
     res = shard.gather_results(torch.tensor(rows, dtype=torch.float64, device=dev), world * F, rank, world)
 
+    train = None
+    if rank == 0 and world == 1 and not args.no_train_leg:
+        del frs, vps, model
+        torch.cuda.empty_cache()
+        train = train_step_leg()
+
     if rank == 0:
         res = res.cpu().numpy()
         dom_avg_ms = dom_ms / max(dom_n, 1)
         achieved = per_kernel_bytes[dominant] / (dom_avg_ms * 1e-3) / 1e9 if dom_avg_ms > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get(dominant)
-            except Exception:
-                traffic = None
+        traffic, iter_traffic, issue = None, None, None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            traffic = tj.get(dominant)
+            loop_kernels = ("preprocess_fwd", "sh_color", "render_fwd", "render_bwd", "preprocess_bwd")
+            if all(k in tj for k in loop_kernels):
+                iter_traffic = sum(tj[k] for k in loop_kernels)
+        except Exception:
+            pass
+        try:
+            issue = json.load(open(os.path.join(ROOT, "profiles", "issue.json"))).get(dominant)
+        except Exception:
+            pass
         iters_total = world * F * K
+        single = world * K / elapsed_single
         out = {
             "metric": "render+backward iters/sec @640x480, 1M Gaussians; median pose err (cm/deg)",
             "value": iters_total / elapsed,
@@ -270,45 +295,53 @@ def main():
             "data": "synthetic",
             "config": {"workload": "S-1M-640 pose refinement (BASELINE.json configs[1] shape at 1M Gaussians)",
                        "width": W, "height": H, "gaussians": sc.P, "sh_degree": sc.sh_degree,
-                       "V": V, "R": R, "R_emitted": R_emit, "R_eff": R_eff, "R_eff_source": R_eff_src,
-                       "R_eff_own_binning": R_eff_culled, "sort_passes": passes,
+                       "V": V, "R": R, "R_eff": R_eff, "R_eff_source": R_eff_src,
+                       "list_entries_ordered_own_binning": R_ordered, "R_eff_own_binning": R_eff_culled, "sort_passes_reference": passes,
                        "algorithmic_bytes_per_iter": total_bytes, "frames_in_flight_per_gpu": F,
                        "iterations_per_step": F, "gaussian_grads": not args.pose_only,
                        "parallelism": f"frames: {world} GPU x {F} in flight",
                        "loop": "native gsr_refine (render, tracking loss, backward, Adam, update_pose per iteration)"},
-            "single_frame_iters_per_s": world * K / elapsed_single,
+            "value_repeats": [iters_total / e for e in elapsed_runs],
+            "single_frame_iters_per_s": single,
+            "plain_loop_iters_per_s": world * K / elapsed_plain,
             "python_loop_iters_per_s": world * K / elapsed_py,
             "pose_err_cm_median": 100.0 * float(np.median(res[:, 1])),
             "pose_err_deg_median": float(np.median(res[:, 2])),
             "pose_err_init_cm_deg": [100.0 * te0, re0],
             "refine_iters_median": float(np.median(res[:, 3])),
             "kernels_ms_python_loop": {k: round(v, 4) for k, v in kernels_ms.items()},
-            "kernels_ms_per_iter_native_single_frame": {k: round(v, 4) for k, v in native_ms.items()},
+            "kernels_ms_per_iter_native_single_frame": {k: round(v, 4) for k, v in native_ms[True].items()},
+            "kernels_ms_per_iter_native_plain_loop": {k: round(v, 4) for k, v in native_ms[False].items()},
             "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": per_kernel_bytes[dominant], "avg_launch_ms": dom_avg_ms,
                          "launches_timed": int(dom_n),
-                         "avg_launch_ms_single_frame": native_ms[dominant],
-                         # the reference algorithm's bytes per iteration (all kernels) x measured
-                         # iterations/s, against the HBM peak: > 1 means the loop runs faster than the reference's
-                         # traffic could even be streamed
+                         "avg_launch_ms_single_frame": native_ms[True][dominant],
+                         # what the kernel is actually bound by: vector + matrix issue slots (rocprofv3 SQ pass, profiles/issue.json)
+                         "issue_frac": issue,
+                         # whole iteration: HBM bytes per steady-state iteration (sum of the loop's kernels, profiles/traffic.json)
+                         # and that traffic at the measured single-frame / in-flight rates against the HBM peak
+                         "iter_traffic_bytes": iter_traffic,
+                         "iter_traffic_frac_single_frame": (iter_traffic * single / 1e9 / HBM_PEAK_GBS) if iter_traffic else None,
+                         "iter_traffic_frac_at_value": (iter_traffic * iters_total / elapsed / 1e9 / HBM_PEAK_GBS / world) if iter_traffic else None,
+                         # the reference algorithm's bytes per iteration (all kernels) x measured iterations/s against the
+                         # HBM peak: > 1 means the loop runs faster than the reference's traffic could even be streamed
                          "reference_bytes_rate_frac": total_bytes * iters_total / elapsed / 1e9 / HBM_PEAK_GBS / world},
         }
         if cpu is not None:
             out["cpu_baseline"] = cpu
+            out["cpu_baseline_other_scenes"] = cpu_more
+        if train is not None:
+            out["train_step"] = train
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
 
-def cpu_baseline(sc, w2c):
-    """The oracle (a port of the reference algorithm, not the reference itself) on the host cores:
-    fwd+bwd of the rasterizer with pose gradients on the same scene and pose; bounded to ~10-30 s.
-    Also returns the reference-rule counts (V, R, R_eff) of that forward."""
+def _cpu_time(sc, w2c, threads, backward, budget_s, max_n):
     from oracle import oracle as O
     from gs_localization_amd import scenes as S
-    cores = os.cpu_count() or 1
-    O.set_threads(cores)
+    O.set_threads(threads)
     view, proj, _, campos = S.camera_matrices(sc, w2c)
     rng = np.random.default_rng(0)
     gc = rng.normal(size=(3, sc.H, sc.W)).astype(np.float32)
@@ -318,15 +351,59 @@ def cpu_baseline(sc, w2c):
     while True:
         f = O.forward(sc.means3D, sc.opacities, view, proj, campos, sc.W, sc.H, sc.tanfovx, sc.tanfovy, sc.bg,
                       sh_degree=sc.sh_degree, shs=sc.shs, scales=sc.scales, rotations=sc.rotations, want_n_touched=True)
-        O.backward(f, gc, gd, ga, pose_mode=True)
+        if backward:
+            O.backward(f, gc, gd, ga, pose_mode=True)
         n += 1
         el = time.perf_counter() - t0
-        if el > 12.0 or n >= 20:
+        if el > budget_s or n >= max_n:
             break
+    return n, el, f
+
+
+def cpu_baseline(sc, w2c):
+    """The oracle (a port of the reference algorithm, not the reference itself) on the host cores:
+    fwd+bwd of the rasterizer with pose gradients on the same scene and pose; bounded to ~10-30 s.
+    Also returns the reference-rule counts (V, R, R_eff) of that forward."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    n, el, f = _cpu_time(sc, w2c, cores, True, 12.0, 20)
     counts = {"V": int((f.radii > 0).sum()), "R": int(f.num_rendered), "R_eff": O.r_eff(f)}
     return ({"value": n / el, "unit": "iters/s", "cores": cores, "kind": "port",
              "sample": f"{n} rasterizer fwd+bwd iterations (pose gradients) of the same S-1M-640 scene and pose, "
                        "OpenMP over tiles/Gaussians; excludes loss/Adam/update_pose (negligible on the CPU)"}, counts)
+
+
+def cpu_baseline_other_scenes(full):
+    """the CPU port at 1 thread and on all cores, on S-50k-fern (forward only: BASELINE.json config 0, the
+    reference's CPU-runnable case) and S-800k-chess (fwd+bwd, config 1).  Bounded: a few seconds each; the one-thread run
+    of S-800k-chess takes minutes and only runs with --cpu-baseline-full."""
+    from gs_localization_amd import scenes as S
+    cores = os.cpu_count() or 1
+    out = []
+    fern, chess = S.s_50k_fern(), S.s_800k_chess()
+    plan = [(fern, "S-50k-fern", False, 1, 8.0, 3), (fern, "S-50k-fern", False, cores, 4.0, 20), (chess, "S-800k-chess", True, cores, 8.0, 10)]
+    if full:
+        plan.append((chess, "S-800k-chess", True, 1, 1.0, 1))
+    for sc, name, bwd, thr, budget, max_n in plan:
+        n, el, _ = _cpu_time(sc, np.eye(4), thr, bwd, budget, max_n)
+        out.append({"scene": name, "pass": "fwd+bwd" if bwd else "fwd", "cores": thr, "value": n / el, "unit": "iters/s", "kind": "port",
+                    "sample": f"{n} iterations in {el:.1f} s"})
+    return out
+
+
+def train_step_leg():
+    """BASELINE.json config 4 (train.py, S-train-garden): ms per step through package (A) + the fused loss epilogue + torch Adam,
+    at three sizes of the model (1296x840, SH degree 1, white background, random camera per step)."""
+    from tests.train_replay import TrainReplay, time_steps
+    rows = []
+    for P in (200_000, 800_000, 1_500_000):
+        tr = TrainReplay(P0=P, P1=P, densify_from=10**9)
+        r, _ = time_steps(tr, 1, 30, warm=5)
+        rows.append({k: (round(float(v), 4) if not isinstance(v, int) else v) for k, v in r.items()})
+        del tr
+        torch.cuda.empty_cache()
+    return {"workload": "train.py step, 1296x840, SH1, white background, random camera per step, grad_depth != 0 (tests/train_replay.py)",
+            "per_P": rows}
 
 
 if __name__ == "__main__":

@@ -1,35 +1,73 @@
-"""CPU: the N>1 path (frames sharded over ranks, one gather at the end) on gloo, world_size 2."""
+"""CPU: the N>1 path on gloo, world_size 2 and 3 -- frames handed out from the shared counter (or round-robin), refined by a
+stub whose cost varies per frame like the early-exit refinement's does, results gathered once and ordered by frame id."""
 import os
+import time
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
 
-def _worker(rank, world, port, n_frames, out):
+def _cost_units(frame, world):
+    return 8 if frame % world == 0 else 1          # adversarial for round-robin: rank 0 would own every expensive frame
+
+
+def _worker(rank, world, port, n_frames, assign, slots, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from gs_localization_amd import shard
-    mine = shard.shard_frames(n_frames, rank, world)
-    local = torch.tensor([[float(f), 0.001 * f, 0.1 * f, float(rank)] for f in mine], dtype=torch.float64).reshape(-1, 4)
+
+    def refine(slot, f):            # stands in for FusedRefiner.refine: (trans err, rot err, iterations)
+        time.sleep(0.004 * _cost_units(f, world))
+        return 0.001 * f, 0.1 * f, float(_cost_units(f, world))
+    dist.barrier()
+    t0 = time.perf_counter()
+    local, busy = shard.run_split(n_frames, refine, rank, world, slots=slots, assign=assign, chunk=1, key=f"q{port}")
+    wall = time.perf_counter() - t0
+    t = torch.tensor([wall, sum(busy)], dtype=torch.float64)
+    walls = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]
+    dist.all_gather(walls, t)
     res = shard.gather_results(local, n_frames, rank, world)
     if rank == 0:
-        torch.save(res, out)
+        torch.save({"res": res, "walls": torch.stack(walls)}, out)
     else:
         assert res is None
     dist.destroy_process_group()
 
 
-def test_shard_and_gather_world2(tmp_path):
-    for n_frames in (7, 4, 1):
-        out = str(tmp_path / f"res{n_frames}.pt")
-        mp.spawn(_worker, args=(2, 29500 + n_frames, n_frames, out), nprocs=2, join=True)
-        res = torch.load(out)
-        assert res.shape == (n_frames, 4)
-        assert torch.equal(res[:, 0], torch.arange(n_frames, dtype=torch.float64))
-        assert torch.equal(res[:, 3], torch.arange(n_frames, dtype=torch.float64) % 2)   # round-robin owner
+@pytest.mark.parametrize("world", [2, 3])
+def test_queue_and_static_split_process_every_frame_once_in_order(tmp_path, world):
+    n_frames = 36
+    got = {}
+    for k, assign in enumerate(("queue", "static")):
+        out = str(tmp_path / f"res_{assign}.pt")
+        mp.spawn(_worker, args=(world, 29610 + 10 * world + k, n_frames, assign, 2, out), nprocs=world, join=True)
+        d = torch.load(out)
+        res = d["res"]
+        assert res.shape == (n_frames, 5)
+        assert torch.equal(res[:, 0], torch.arange(n_frames, dtype=torch.float64))          # every frame once, ordered by id
         assert torch.allclose(res[:, 1], 0.001 * torch.arange(n_frames, dtype=torch.float64))
+        got[assign] = (res, d["walls"])
+    # static = round-robin owners; with this cost pattern rank 0 does all the expensive frames
+    assert torch.equal(got["static"][0][:, 4], torch.arange(n_frames, dtype=torch.float64) % world)
+    busy_static = got["static"][1][:, 1]
+    assert busy_static[0] > 2.0 * busy_static[1:].max()
+    # the shared counter evens it out: every rank is busy for about the same time and the job finishes sooner
+    busy_q, wall_q = got["queue"][1][:, 1], got["queue"][1][:, 0]
+    assert busy_q.max() <= 1.4 * busy_q.mean(), busy_q
+    assert wall_q.max() < 0.8 * got["static"][1][:, 0].max()
+    owners = got["queue"][0][:, 4]
+    assert len(set(owners.tolist())) == world            # everybody took part
+
+
+def test_ragged_and_tiny_splits(tmp_path):
+    for n_frames in (7, 1):
+        out = str(tmp_path / f"r{n_frames}.pt")
+        mp.spawn(_worker, args=(2, 29700 + n_frames, n_frames, "queue", 1, out), nprocs=2, join=True)
+        res = torch.load(out)["res"]
+        assert res.shape == (n_frames, 5) and torch.equal(res[:, 0], torch.arange(n_frames, dtype=torch.float64))
 
 
 def test_shard_is_a_partition():
@@ -38,6 +76,15 @@ def test_shard_is_a_partition():
         for w in (1, 2, 3, 8):
             allf = sorted(f for r in range(w) for f in shard.shard_frames(n, r, w))
             assert allf == list(range(n))
+            for assign in ("static", "queue"):
+                if assign == "queue" and w > 1:
+                    continue              # (the shared counter needs a process group: covered above)
+                seen = []
+                for r in range(w):
+                    q = shard.FrameQueue(n, r, w, assign, chunk=3)
+                    while (f := q.claim()) is not None:
+                        seen.append(f)
+                assert sorted(seen) == list(range(n)), (n, w, assign)
 
 
 def test_median_errors_table():
@@ -46,3 +93,5 @@ def test_median_errors_table():
     m = shard.median_errors(res)
     assert m["median_t_m"] == 0.02 and m["median_R_deg"] == 0.8
     assert abs(m["recall"]["1cm,1deg"] - 1 / 3) < 1e-12 and m["recall"]["500cm,10deg"] == 1.0
+    even = torch.tensor([[0, 0.01, 1.0], [1, 0.03, 3.0]], dtype=torch.float64)          # numpy's median: mean of the two middle values
+    assert abs(shard.median_errors(even)["median_t_m"] - 0.02) < 1e-15

@@ -1,0 +1,119 @@
+#!/usr/bin/env python3
+"""BASELINE.json config 2: a whole test split of query frames refined on the GPUs of one node.
+
+The reference's driver (gs_localization/pipelines/7scenes_localize_full_dslam.py:352-389) walks the test images one by one
+on one GPU: initial pose from the feature-matching stage, `gradient_decent` (up to 50 iterations, early exit on convergence),
+pose errors, medians and the recall table.  Here: one process per GPU (torchrun), the map replicated on every rank, frames
+handed out on demand from a shared counter (gs_localization_amd/shard.py -- a frame costs 1 ... 50 iterations), F frames in
+flight per GPU on the native loop (`FusedRefiner`), ONE gather of the result rows at the end (RCCL over xGMI).
+
+No dataset exists here: the split is synthetic -- a map of --gaussians Gaussians (S-800k-chess by default), --frames query
+poses scattered 0.3 m / 10 deg around the map's reference view, each observed as the map's own render at that pose, each
+started from an initial pose up to 5 cm / 3 deg off (a different amount per frame, so that iteration counts differ).
+
+  python tools/localize_split.py --frames 64                                   # one GPU
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 --master-port 29511 \\
+      tools/localize_split.py --frames 2000                                     # one node
+Prints one JSON line on rank 0: frames/s, medians, recall, per-rank balance.  Scaling numbers need a multi-GPU node."""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=64)
+    ap.add_argument("--gaussians", type=int, default=800_000)
+    ap.add_argument("--in-flight", type=int, default=4, help="frames refined concurrently per GPU")
+    ap.add_argument("--assign", choices=("queue", "static"), default="queue")
+    ap.add_argument("--chunk", type=int, default=1, help="frames claimed per trip to the shared counter")
+    ap.add_argument("--iters", type=int, default=50)
+    args = ap.parse_args()
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from gs_localization_amd import scenes as S, shard
+    from tests import replay as RP
+
+    sc = S._draw("S-chess-split", args.gaussians, 640, 480, 525.0, 525.0, 0.5, 6.0, 0.01, 0.6, 3, 0)
+    gmap = RP.GaussianMap.from_scene(sc, device=dev)
+    bg = torch.zeros(3, device=dev)
+    proj = RP.intrinsics_projection(sc, dev)
+    F = max(1, args.in_flight)
+    refiners = [RP.FusedRefiner(gmap, sc.H, sc.W, device=dev) for _ in range(F)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
+
+    def frame_setup(f):
+        """ground-truth pose, observation and initial pose of query frame f (the same on whichever rank draws it)"""
+        rng = np.random.default_rng(7000 + f)
+        gt = S.se3_exp(np.concatenate([rng.uniform(-0.3, 0.3, 3), np.radians(rng.uniform(-10, 10, 3))]))
+        off = rng.uniform(0.1, 1.0)                 # 0.5 ... 5 cm and 0.3 ... 3 deg: some frames converge early, some never
+        dt = rng.normal(size=3); dt *= 0.05 * off / np.linalg.norm(dt)
+        dr = rng.normal(size=3); dr *= math.radians(3.0 * off) / np.linalg.norm(dr)
+        init = S.se3_exp(np.concatenate([dt, dr])) @ gt
+        return gt, init
+
+    def refine(slot, f):
+        gt, init = frame_setup(f)
+        with torch.cuda.stream(streams[slot]):
+            fr = RP.QueryFrame(f, proj, sc, dev, gt_w2c=torch.tensor(gt, dtype=torch.float32, device=dev))
+            g = torch.tensor(gt, dtype=torch.float32, device=dev)
+            fr.update_RT(g[:3, :3].clone(), g[:3, 3].clone())
+            with torch.no_grad():
+                obs = RP.render(fr, gmap, bg)
+            fr.original_image, fr.depth = obs["render"].detach().clone(), obs["depth"].detach()[0].clone()
+            fr.grad_mask = torch.ones((1, sc.H, sc.W), dtype=torch.bool, device=dev)
+            i0 = torch.tensor(init, dtype=torch.float32, device=dev)
+            R, T, info = refiners[slot].refine(fr, RP.TRACKING_CONFIG, i0[:3, :3].clone(), i0[:3, 3].clone(), bg, iters=args.iters)
+            te, re = RP.pose_errors(gt[:3, :3], gt[:3, 3], R.detach().cpu().numpy(), T.detach().cpu().numpy())
+        return te, re, float(info["iters"])
+
+    refine(0, 0)                                    # warm-up (allocations, first-touch), untimed
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    local, busy = shard.run_split(args.frames, refine, rank, world, slots=F, assign=args.assign, chunk=args.chunk)
+    torch.cuda.synchronize()
+    t_rank = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    wall = time.perf_counter() - t0
+    res = shard.gather_results(local.to(dev), args.frames, rank, world)
+    stats = torch.tensor([t_rank, sum(busy) / F, float(local.shape[0]), float(local[:, 3].sum()) if local.numel() else 0.0],
+                         dtype=torch.float64, device=dev)
+    per_rank = [torch.zeros_like(stats) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(per_rank, stats)
+    else:
+        per_rank = [stats]
+    if rank == 0:
+        res = res.cpu()
+        m = shard.median_errors(res)
+        pr = torch.stack(per_rank).cpu().numpy()
+        out = {"workload": f"synthetic test split: {args.frames} query frames, {args.gaussians} Gaussians, 640x480, up to {args.iters} iterations each",
+               "n_gpus": world, "frames_in_flight_per_gpu": F, "assign": args.assign, "frames_per_s": args.frames / wall,
+               "iterations_per_s": float(res[:, 3].sum()) / wall, "wall_s": wall,
+               "median_trans_err_cm": 100.0 * m["median_t_m"], "median_rot_err_deg": m["median_R_deg"], "recall": m["recall"],
+               "iterations_per_frame": {"min": float(res[:, 3].min()), "median": float(res[:, 3].median()), "max": float(res[:, 3].max())},
+               "per_rank": {"seconds_until_idle": [round(float(x), 3) for x in pr[:, 0]], "frames": [int(x) for x in pr[:, 2]],
+                            "iterations": [int(x) for x in pr[:, 3]]},
+               "balance_max_over_mean_idle_time": float(pr[:, 0].max() / pr[:, 0].mean())}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

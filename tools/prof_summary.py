@@ -21,10 +21,9 @@ from collections import defaultdict
 csv.field_size_limit(sys.maxsize)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-OURS = {"k_preprocess(": "preprocess_fwd", "k_sh_color": "sh_color", "k_gather_counts": "scan", "k_tracking_loss": "tracking_loss",
-        "k_pose_step": "pose_step", "k_tau_finish": "pose_step", "k_preprocess_bwd": "preprocess_bwd", "k_emit": "emit", "k_ranges": "ranges",
-        "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd", "radix_sort": "sort(rocPRIM: depth + tile)", "lookback_scan": "scan", "scan": "scan",
-        "k_tile_": "tile_sort", "k_bin": "bin", "k_loss": "loss", "k_pose": "pose_step"}
+OURS = {"k_preprocess(": "preprocess_fwd", "k_sh_color": "sh_color", "k_tile_count": "tile_count", "k_tile_scan": "tile_scan",
+        "k_tile_emit": "tile_emit", "k_tracking_loss": "tracking_loss", "k_pose_step": "pose_step", "k_pose_init": "pose_step",
+        "k_tau_finish": "pose_step", "k_preprocess_bwd": "preprocess_bwd", "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd"}
 
 
 def short(name):
@@ -53,6 +52,7 @@ def main():
     ap.add_argument("--kt", required=True)
     ap.add_argument("--fetch")
     ap.add_argument("--write")
+    ap.add_argument("--sq", help="counter_collection.csv of an SQ pass: SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAVES")
     ap.add_argument("--iters", type=int, default=0, help="refinement iterations under the profiler (default: k_render_bwd launches)")
     ap.add_argument("--cmd", default="")
     a = ap.parse_args()
@@ -94,6 +94,30 @@ def main():
     if out:
         json.dump(out, open(os.path.join(ROOT, "profiles", f"{a.tag}_traffic.json"), "w"), indent=1)
         json.dump({k: v["hbm_bytes_corrected"] for k, v in out.items()}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+    if a.sq:
+        # Issue-slot utilisation per kernel: a CU issues at most one VALU instruction per cycle (4 SIMDs x one wave64 instruction
+        # per 4 cycles) -> valu = SQ_INSTS_VALU / SQ_BUSY_CU_CYCLES; the fp32 MFMA occupies its SIMD's pipe for
+        # SQ_VALU_MFMA_BUSY_CYCLES (SIMD cycles: / 4 for CU cycles) -> mfma = that / 4 / SQ_BUSY_CU_CYCLES.
+        acc = defaultdict(lambda: defaultdict(float)); cnt = defaultdict(lambda: defaultdict(int))
+        for r in csv.DictReader(open(a.sq)):
+            k = ours(r["Kernel_Name"])
+            if k:
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"]); cnt[k][r["Counter_Name"]] += 1
+        issue = {}
+        with open(os.path.join(ROOT, "profiles", f"{a.tag}_issue_utilisation.md"), "w") as f:
+            f.write(f"# Issue-slot counters of the hot kernels ({a.tag})\n\ncommand: `{a.cmd}` under `rocprofv3 --pmc SQ_WAVES SQ_BUSY_CU_CYCLES "
+                    "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS` (counters only); per-launch averages.\n\n"
+                    "| kernel | launches | waves | VALU insts | MFMA insts | LDS insts | busy CU cycles | VALU issue | MFMA pipe | VALU insts / wave |\n|---|---|---|---|---|---|---|---|---|---|\n")
+            for k, d in acc.items():
+                g = lambda n: d.get(n, 0.0) / max(cnt[k].get(n, 1), 1)
+                busy = max(g("SQ_BUSY_CU_CYCLES"), 1.0)
+                valu, mfma = g("SQ_INSTS_VALU") / busy, g("SQ_VALU_MFMA_BUSY_CYCLES") / 4.0 / busy
+                issue[k] = {"valu_issue_frac": valu, "mfma_pipe_frac": mfma, "sum": valu + mfma, "valu_insts_per_wave": g("SQ_INSTS_VALU") / max(g("SQ_WAVES"), 1.0),
+                            "lds_insts_per_wave": g("SQ_INSTS_LDS") / max(g("SQ_WAVES"), 1.0), "mfma_insts_per_wave": g("SQ_INSTS_MFMA") / max(g("SQ_WAVES"), 1.0)}
+                f.write(f"| {k} | {cnt[k].get('SQ_WAVES', 0)} | {g('SQ_WAVES'):.0f} | {g('SQ_INSTS_VALU') / 1e6:.2f} M | {g('SQ_INSTS_MFMA') / 1e6:.2f} M | "
+                        f"{g('SQ_INSTS_LDS') / 1e6:.2f} M | {busy / 1e6:.1f} M | {valu:.2f} | {mfma:.2f} | {issue[k]['valu_insts_per_wave']:.0f} |\n")
+        json.dump(issue, open(os.path.join(ROOT, "profiles", "issue.json"), "w"), indent=1)
+        print(json.dumps(issue, indent=1))
     print(open(os.path.join(ROOT, "profiles", f"{a.tag}_kernel_stats.md")).read())
     print(json.dumps(out, indent=1))
 
