@@ -698,6 +698,7 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     pb.means = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = g.clamped;
     pb.scales = scales; pb.rots = rotations; pb.mod = scale_modifier;
     pb.cov3D = cov3D_precomp ? cov3D_precomp : g.cov3D;
+    pb.conic_op = g.conic_op;
     pb.view = viewmatrix; pb.proj = projmatrix; pb.campos = campos;
     pb.fx = focal_x; pb.fy = focal_y; pb.tanx = tan_fovx; pb.tany = tan_fovy;
     pb.acc = g.acc;

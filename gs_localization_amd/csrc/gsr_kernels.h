@@ -152,38 +152,39 @@ struct PreArgs {
     int cov_all;             // k_preprocess: compute and store cov3D for every Gaussian, culled or not (see there)
 };
 
+// Real spherical-harmonics basis of the 3DGS convention (signs and constants as forward.cu:20-71 / sh_utils.py), degree <= 3:
+// B[k](d) for the unit direction d = (x, y, z); entries above the active degree are left untouched.
+__device__ __forceinline__ void sh_basis(int deg, float x, float y, float z, float* B)
+{
+    B[0] = kSH_C0;
+    if (deg < 1) return;
+    B[1] = -kSH_C1 * y; B[2] = kSH_C1 * z; B[3] = -kSH_C1 * x;
+    if (deg < 2) return;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    B[4] = kSH_C2[0] * xy; B[5] = kSH_C2[1] * yz; B[6] = kSH_C2[2] * (2.0f * zz - xx - yy); B[7] = kSH_C2[3] * xz; B[8] = kSH_C2[4] * (xx - yy);
+    if (deg < 3) return;
+    B[9] = kSH_C3[0] * y * (3.0f * xx - yy); B[10] = kSH_C3[1] * xy * z; B[11] = kSH_C3[2] * y * (4.0f * zz - xx - yy);
+    B[12] = kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy); B[13] = kSH_C3[4] * x * (4.0f * zz - xx - yy);
+    B[14] = kSH_C3[5] * z * (xx - yy); B[15] = kSH_C3[6] * x * (xx - 3.0f * yy);
+}
+// View-dependent colour of one Gaussian: max(0, sum_k B_k(d) sh[k] + 0.5) per channel, d the unit vector from the camera
+// centre to the mean; clamp_bits records which channels were cut at zero (their gradient is masked in the backward pass).
 __device__ __forceinline__ float3 sh_to_rgb(int deg, int M, float3 pos, const float* campos, const float* sh,
                                             uint8_t& clamp_bits)
 {
-    float3 dir = make_float3(pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]);
-    float len = sqrtf(dir.x * dir.x + dir.y * dir.y + dir.z * dir.z);
-    float x = dir.x / len, y = dir.y / len, z = dir.z / len;
-    float res[3];
+    (void)M;
+    const float vx = pos.x - campos[0], vy = pos.y - campos[1], vz = pos.z - campos[2];
+    const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+    float B[16];
+    sh_basis(deg, vx / len, vy / len, vz / len, B);
+    const int nk = (deg + 1) * (deg + 1);
+    float c0 = 0.f, c1 = 0.f, c2 = 0.f;
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
-#define S(k) sh[(k) * 3 + c]
-        float r = kSH_C0 * S(0);
-        if (deg > 0) {
-            r = r - kSH_C1 * y * S(1) + kSH_C1 * z * S(2) - kSH_C1 * x * S(3);
-            if (deg > 1) {
-                float xx = x * x, yy = y * y, zz = z * z;
-                float xy = x * y, yz = y * z, xz = x * z;
-                r = r + kSH_C2[0] * xy * S(4) + kSH_C2[1] * yz * S(5) + kSH_C2[2] * (2.0f * zz - xx - yy) * S(6)
-                      + kSH_C2[3] * xz * S(7) + kSH_C2[4] * (xx - yy) * S(8);
-                if (deg > 2) {
-                    r = r + kSH_C3[0] * y * (3.0f * xx - yy) * S(9) + kSH_C3[1] * xy * z * S(10)
-                          + kSH_C3[2] * y * (4.0f * zz - xx - yy) * S(11)
-                          + kSH_C3[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * S(12)
-                          + kSH_C3[4] * x * (4.0f * zz - xx - yy) * S(13) + kSH_C3[5] * z * (xx - yy) * S(14)
-                          + kSH_C3[6] * x * (xx - 3.0f * yy) * S(15);
-                }
-            }
-        }
-#undef S
-        res[c] = r + 0.5f;
-    }
-    clamp_bits = (uint8_t)((res[0] < 0 ? 1 : 0) | (res[1] < 0 ? 2 : 0) | (res[2] < 0 ? 4 : 0));
-    return make_float3(fmaxf(res[0], 0.0f), fmaxf(res[1], 0.0f), fmaxf(res[2], 0.0f));
+    for (int k = 0; k < 16; k++)
+        if (k < nk) { c0 += B[k] * sh[k * 3]; c1 += B[k] * sh[k * 3 + 1]; c2 += B[k] * sh[k * 3 + 2]; }
+    c0 += 0.5f; c1 += 0.5f; c2 += 0.5f;
+    clamp_bits = (uint8_t)((c0 < 0 ? 1 : 0) | (c1 < 0 ? 2 : 0) | (c2 < 0 ? 4 : 0));
+    return make_float3(fmaxf(c0, 0.0f), fmaxf(c1, 0.0f), fmaxf(c2, 0.0f));
 }
 
 // SH rows of one block staged through LDS: the 256 x M x 3 floats of a block are contiguous in HBM, so
@@ -1663,6 +1664,7 @@ struct PreBwdArgs {
     int P, D, M;
     const float* means; const int* radii; const float* shs; const uint8_t* clamped;
     const float* scales; const float* rots; float mod; const float* cov3D;   // cov3D: precomp or geom state
+    const float4* conic_op;                               // the conic (and opacity) the forward stored
     const float* view; const float* proj; const float* campos;
     float fx, fy, tanx, tany;
     float* acc;                                           // packed K7 sums, GSR_ACC_STRIDE floats per Gaussian
@@ -1681,120 +1683,135 @@ struct PreBwdArgs {
     uint32_t* ticket; PoseStepArgs fold;
 };
 
-__device__ __forceinline__ float3 dnormvdv3(float3 v, float3 dv)
-{
-    const float sum2 = v.x * v.x + v.y * v.y + v.z * v.z;
-    const float invsum32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
-    float3 r;
-    r.x = ((+sum2 - v.x * v.x) * dv.x - v.y * v.x * dv.y - v.z * v.x * dv.z) * invsum32;
-    r.y = (-v.x * v.y * dv.x + (sum2 - v.y * v.y) * dv.y - v.z * v.y * dv.z) * invsum32;
-    r.z = (-v.x * v.z * dv.x - v.y * v.z * dv.y + (sum2 - v.z * v.z) * dv.z) * invsum32;
-    return r;
-}
+// ---- chain rule of one Gaussian, written from the maths rather than from the reference's expression trees -------------
+// Notation: p world mean, t = Wc p + trans its camera-space position (Wc[r][c] = view[4 c + r]), J the 2x3 perspective
+// Jacobian (backward.cu:166-199 keeps the clamped x/z, y/z in it as constants), M = J Wc (2x3), C = M Sigma M^T + 0.3 I the
+// screen-space covariance and Q = C^-1 the conic.  All gradient matrices below are the SYMMETRIC ones (an off-diagonal
+// parameter that appears twice gets half of its total derivative in each place).
 
-// SH backward (backward.cu:20-139); returns the mean-gradient part and, if dsh is non-null, writes
-// dL_dsh.  All reads of `sh` happen before the first write of `dsh`, so dsh may alias sh (in-place in LDS).
-__device__ __forceinline__ float3 sh_backward(int deg, int M, float3 pos, const float* campos, const float* sh,
-                                              uint8_t cb, float3 dcol, float* dsh)
+// Colour gradient -> SH coefficient gradients and the gradient w.r.t. the mean through the view direction
+// (what backward.cu:20-139 computes).  colour_c = max(0, sum_k B_k(d) sh[k][c] + 0.5), d = (p - campos) / |p - campos|:
+//   dL/dsh[k][c] = B_k(d) g_c                      g = dL/dcolour with the clamped channels masked
+//   dL/dd        = sum_k (sh[k] . g) grad B_k(d)   (x, y, z treated as independent, then projected through the
+//   dL/dp        = (dL/dd - d (d . dL/dd)) / |p - campos|                                  normalisation)
+// dsh may alias sh: row k is read before it is written.
+__device__ __forceinline__ float3 sh_color_backward(int deg, int M, float3 pos, const float* campos, const float* sh, uint8_t clamp_bits,
+                                                    float3 dcol, float* dsh)
 {
-    const float3 dir_orig = make_float3(pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]);
-    const float len = sqrtf(dir_orig.x * dir_orig.x + dir_orig.y * dir_orig.y + dir_orig.z * dir_orig.z);
-    const float x = dir_orig.x / len, y = dir_orig.y / len, z = dir_orig.z / len;
-    const float xx = x * x, yy = y * y, zz = z * z;
-    const float xy = x * y, yz = y * z, xz = x * z;
-    float dRGB[3] = {dcol.x * ((cb & 1) ? 0.f : 1.f), dcol.y * ((cb & 2) ? 0.f : 1.f), dcol.z * ((cb & 4) ? 0.f : 1.f)};
-    float dx[3] = {0, 0, 0}, dy[3] = {0, 0, 0}, dz[3] = {0, 0, 0};
-#define SH(k, c) sh[(k) * 3 + (c)]
+    const float3 v = make_float3(pos.x - campos[0], pos.y - campos[1], pos.z - campos[2]);
+    const float rlen = 1.0f / sqrtf(v.x * v.x + v.y * v.y + v.z * v.z);
+    const float x = v.x * rlen, y = v.y * rlen, z = v.z * rlen;
+    const float g0 = (clamp_bits & 1) ? 0.f : dcol.x, g1 = (clamp_bits & 2) ? 0.f : dcol.y, g2 = (clamp_bits & 4) ? 0.f : dcol.z;
+    float dx = 0.f, dy = 0.f, dz = 0.f;
+    // one term of the expansion: basis value b, basis gradient (bx, by, bz)
+#define GSR_SH_TERM(k, b, bx, by, bz)                                                                         \
+    {                                                                                                         \
+        const float c_ = sh[(k) * 3] * g0 + sh[(k) * 3 + 1] * g1 + sh[(k) * 3 + 2] * g2;                      \
+        dx += c_ * (bx); dy += c_ * (by); dz += c_ * (bz);                                                    \
+        if (dsh) { const float b_ = (b); dsh[(k) * 3] = b_ * g0; dsh[(k) * 3 + 1] = b_ * g1; dsh[(k) * 3 + 2] = b_ * g2; } \
+    }
+    if (dsh) { dsh[0] = kSH_C0 * g0; dsh[1] = kSH_C0 * g1; dsh[2] = kSH_C0 * g2; }
     if (deg > 0) {
-#pragma unroll
-        for (int c = 0; c < 3; c++) {
-            dx[c] = -kSH_C1 * SH(3, c);
-            dy[c] = -kSH_C1 * SH(1, c);
-            dz[c] = kSH_C1 * SH(2, c);
-        }
+        GSR_SH_TERM(1, -kSH_C1 * y, 0.f, -kSH_C1, 0.f)
+        GSR_SH_TERM(2, kSH_C1 * z, 0.f, 0.f, kSH_C1)
+        GSR_SH_TERM(3, -kSH_C1 * x, -kSH_C1, 0.f, 0.f)
         if (deg > 1) {
-#pragma unroll
-            for (int c = 0; c < 3; c++) {
-                dx[c] += kSH_C2[0] * y * SH(4, c) + kSH_C2[2] * 2.f * -x * SH(6, c) + kSH_C2[3] * z * SH(7, c) + kSH_C2[4] * 2.f * x * SH(8, c);
-                dy[c] += kSH_C2[0] * x * SH(4, c) + kSH_C2[1] * z * SH(5, c) + kSH_C2[2] * 2.f * -y * SH(6, c) + kSH_C2[4] * 2.f * -y * SH(8, c);
-                dz[c] += kSH_C2[1] * y * SH(5, c) + kSH_C2[2] * 2.f * 2.f * z * SH(6, c) + kSH_C2[3] * x * SH(7, c);
-            }
+            const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+            GSR_SH_TERM(4, kSH_C2[0] * xy, kSH_C2[0] * y, kSH_C2[0] * x, 0.f)
+            GSR_SH_TERM(5, kSH_C2[1] * yz, 0.f, kSH_C2[1] * z, kSH_C2[1] * y)
+            GSR_SH_TERM(6, kSH_C2[2] * (2.f * zz - xx - yy), kSH_C2[2] * (-2.f * x), kSH_C2[2] * (-2.f * y), kSH_C2[2] * (4.f * z))
+            GSR_SH_TERM(7, kSH_C2[3] * xz, kSH_C2[3] * z, 0.f, kSH_C2[3] * x)
+            GSR_SH_TERM(8, kSH_C2[4] * (xx - yy), kSH_C2[4] * (2.f * x), kSH_C2[4] * (-2.f * y), 0.f)
             if (deg > 2) {
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    dx[c] += (kSH_C3[0] * SH(9, c) * 3.f * 2.f * xy + kSH_C3[1] * SH(10, c) * yz + kSH_C3[2] * SH(11, c) * -2.f * xy
-                              + kSH_C3[3] * SH(12, c) * -3.f * 2.f * xz + kSH_C3[4] * SH(13, c) * (-3.f * xx + 4.f * zz - yy)
-                              + kSH_C3[5] * SH(14, c) * 2.f * xz + kSH_C3[6] * SH(15, c) * 3.f * (xx - yy));
-                    dy[c] += (kSH_C3[0] * SH(9, c) * 3.f * (xx - yy) + kSH_C3[1] * SH(10, c) * xz
-                              + kSH_C3[2] * SH(11, c) * (-3.f * yy + 4.f * zz - xx) + kSH_C3[3] * SH(12, c) * -3.f * 2.f * yz
-                              + kSH_C3[4] * SH(13, c) * -2.f * xy + kSH_C3[5] * SH(14, c) * -2.f * yz
-                              + kSH_C3[6] * SH(15, c) * -3.f * 2.f * xy);
-                    dz[c] += (kSH_C3[1] * SH(10, c) * xy + kSH_C3[2] * SH(11, c) * 4.f * 2.f * yz
-                              + kSH_C3[3] * SH(12, c) * 3.f * (2.f * zz - xx - yy) + kSH_C3[4] * SH(13, c) * 4.f * 2.f * xz
-                              + kSH_C3[5] * SH(14, c) * (xx - yy));
-                }
+                GSR_SH_TERM(9, kSH_C3[0] * y * (3.f * xx - yy), kSH_C3[0] * (6.f * xy), kSH_C3[0] * (3.f * xx - 3.f * yy), 0.f)
+                GSR_SH_TERM(10, kSH_C3[1] * xy * z, kSH_C3[1] * yz, kSH_C3[1] * xz, kSH_C3[1] * xy)
+                GSR_SH_TERM(11, kSH_C3[2] * y * (4.f * zz - xx - yy), kSH_C3[2] * (-2.f * xy), kSH_C3[2] * (4.f * zz - xx - 3.f * yy), kSH_C3[2] * (8.f * yz))
+                GSR_SH_TERM(12, kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy), kSH_C3[3] * (-6.f * xz), kSH_C3[3] * (-6.f * yz),
+                            kSH_C3[3] * (6.f * zz - 3.f * xx - 3.f * yy))
+                GSR_SH_TERM(13, kSH_C3[4] * x * (4.f * zz - xx - yy), kSH_C3[4] * (4.f * zz - 3.f * xx - yy), kSH_C3[4] * (-2.f * xy), kSH_C3[4] * (8.f * xz))
+                GSR_SH_TERM(14, kSH_C3[5] * z * (xx - yy), kSH_C3[5] * (2.f * xz), kSH_C3[5] * (-2.f * yz), kSH_C3[5] * (xx - yy))
+                GSR_SH_TERM(15, kSH_C3[6] * x * (xx - 3.f * yy), kSH_C3[6] * (3.f * xx - 3.f * yy), kSH_C3[6] * (-6.f * xy), 0.f)
             }
         }
     }
-#undef SH
-    if (dsh) {
-#define DSH(k, w) { const float w_ = (w); _Pragma("unroll") for (int c = 0; c < 3; c++) dsh[(k) * 3 + c] = w_ * dRGB[c]; }
-        DSH(0, kSH_C0);
-        if (deg > 0) {
-            DSH(1, -kSH_C1 * y); DSH(2, kSH_C1 * z); DSH(3, -kSH_C1 * x);
-            if (deg > 1) {
-                DSH(4, kSH_C2[0] * xy); DSH(5, kSH_C2[1] * yz); DSH(6, kSH_C2[2] * (2.f * zz - xx - yy));
-                DSH(7, kSH_C2[3] * xz); DSH(8, kSH_C2[4] * (xx - yy));
-                if (deg > 2) {
-                    DSH(9, kSH_C3[0] * y * (3.f * xx - yy)); DSH(10, kSH_C3[1] * xy * z);
-                    DSH(11, kSH_C3[2] * y * (4.f * zz - xx - yy)); DSH(12, kSH_C3[3] * z * (2.f * zz - 3.f * xx - 3.f * yy));
-                    DSH(13, kSH_C3[4] * x * (4.f * zz - xx - yy)); DSH(14, kSH_C3[5] * z * (xx - yy));
-                    DSH(15, kSH_C3[6] * x * (xx - 3.f * yy));
-                }
-            }
-        }
-        // coefficients above the active degree receive zero gradient (the reference's buffer is pre-zeroed)
+#undef GSR_SH_TERM
+    if (dsh)      // coefficients above the active degree receive zero gradient (the reference's buffer is pre-zeroed)
         for (int k = (deg + 1) * (deg + 1); k < M; k++) { dsh[k * 3] = 0.f; dsh[k * 3 + 1] = 0.f; dsh[k * 3 + 2] = 0.f; }
-#undef DSH
-    }
-    const float3 dL_ddir = make_float3(dx[0] * dRGB[0] + dx[1] * dRGB[1] + dx[2] * dRGB[2],
-                                       dy[0] * dRGB[0] + dy[1] * dRGB[1] + dy[2] * dRGB[2],
-                                       dz[0] * dRGB[0] + dz[1] * dRGB[1] + dz[2] * dRGB[2]);
-    return dnormvdv3(dir_orig, dL_ddir);
+    const float along = x * dx + y * dy + z * dz;
+    return make_float3((dx - x * along) * rlen, (dy - y * along) * rlen, (dz - z * along) * rlen);
 }
 
-// scale / quaternion gradient from dL/dSigma (backward.cu:278-341)
-__device__ __forceinline__ void cov3d_backward(const float* s3, float mod, const float* q4, const float* d, float* ds,
-                                               float* dq)
+// Screen-space gradients of one Gaussian -> gradient of its 3D covariance and of its mean through the projection of the
+// covariance (what backward.cu:144-274 computes).  Inputs: the conic Q the forward stored, gq = dL/d(Qa, Qb, Qc) as the
+// compositing backward sums them (Qb appears once in the exponent).
+//   H  = dL/dC = -Q Gq Q,  Gq = [[gq.x, gq.y], [gq.y, gq.z]]          (derivative of the matrix inverse)
+//   G3 = dL/dSigma = M^T H M                                           (6 unique entries; out_G)
+//   D  = dL/dM = 2 H M Sigma = 2 N Sigma with N = H M
+//   dL/dJ = D Wc^T restricted to J's four non-constant entries, then dL/dt through J(t), then dL/dp = Wc^T dL/dt.
+__device__ __forceinline__ float3 covariance_chain(float3 p, const float* cov6, float3 Q, float3 gq, const float* view, float fx, float fy,
+                                                   float tanx, float tany, float* out_G)
 {
-    const float r = q4[0], x = q4[1], y = q4[2], z = q4[3];
-    M3 R = m3_cols(1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y),
-                   2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x),
-                   2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y));
-    M3 S = m3_cols(1, 0, 0, 0, 1, 0, 0, 0, 1);
-    const float sx = mod * s3[0], sy = mod * s3[1], sz = mod * s3[2];
-    S.m[0][0] = sx; S.m[1][1] = sy; S.m[2][2] = sz;
-    const M3 Mm = m3_mul(S, R);
-    const M3 dSig = m3_cols(d[0], 0.5f * d[1], 0.5f * d[2], 0.5f * d[1], d[3], 0.5f * d[4], 0.5f * d[2], 0.5f * d[4], d[5]);
-    const M3 MdS = m3_mul(Mm, dSig);
-    M3 dL_dM;
+    const float W00 = view[0], W01 = view[4], W02 = view[8], W10 = view[1], W11 = view[5], W12 = view[9], W20 = view[2], W21 = view[6],
+                W22 = view[10];
+    const float tx = W00 * p.x + W01 * p.y + W02 * p.z + view[12], ty = W10 * p.x + W11 * p.y + W12 * p.z + view[13],
+                tz = W20 * p.x + W21 * p.y + W22 * p.z + view[14];
+    const float rz = 1.0f / tz, rz2 = rz * rz;
+    const float limx = 1.3f * tanx, limy = 1.3f * tany;
+    const float ux = tx * rz, uy = ty * rz;
+    const bool in_x = !(ux < -limx || ux > limx), in_y = !(uy < -limy || uy > limy);
+    const float cx = fminf(limx, fmaxf(-limx, ux)) * tz, cy = fminf(limy, fmaxf(-limy, uy)) * tz;      // the clamped t.x, t.y of the forward
+    const float j00 = fx * rz, j02 = -fx * cx * rz2, j11 = fy * rz, j12 = -fy * cy * rz2;
+    const float m0[3] = {j00 * W00 + j02 * W20, j00 * W01 + j02 * W21, j00 * W02 + j02 * W22};
+    const float m1[3] = {j11 * W10 + j12 * W20, j11 * W11 + j12 * W21, j11 * W12 + j12 * W22};
+    const float u00 = Q.x * gq.x + Q.y * gq.y, u01 = Q.x * gq.y + Q.y * gq.z, u10 = Q.y * gq.x + Q.z * gq.y, u11 = Q.y * gq.y + Q.z * gq.z;
+    const float h00 = -(u00 * Q.x + u01 * Q.y), h01 = -(u00 * Q.y + u01 * Q.z), h11 = -(u10 * Q.y + u11 * Q.z);
+    float n0[3], n1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { n0[k] = h00 * m0[k] + h01 * m1[k]; n1[k] = h01 * m0[k] + h11 * m1[k]; }
+    out_G[0] = m0[0] * n0[0] + m1[0] * n1[0]; out_G[1] = m0[0] * n0[1] + m1[0] * n1[1]; out_G[2] = m0[0] * n0[2] + m1[0] * n1[2];
+    out_G[3] = m0[1] * n0[1] + m1[1] * n1[1]; out_G[4] = m0[1] * n0[2] + m1[1] * n1[2]; out_G[5] = m0[2] * n0[2] + m1[2] * n1[2];
+    const float S[3][3] = {{cov6[0], cov6[1], cov6[2]}, {cov6[1], cov6[3], cov6[4]}, {cov6[2], cov6[4], cov6[5]}};
+    float d0[3], d1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        d0[k] = 2.f * (n0[0] * S[0][k] + n0[1] * S[1][k] + n0[2] * S[2][k]);
+        d1[k] = 2.f * (n1[0] * S[0][k] + n1[1] * S[1][k] + n1[2] * S[2][k]);
+    }
+    const float e00 = d0[0] * W00 + d0[1] * W01 + d0[2] * W02, e02 = d0[0] * W20 + d0[1] * W21 + d0[2] * W22;
+    const float e11 = d1[0] * W10 + d1[1] * W11 + d1[2] * W12, e12 = d1[0] * W20 + d1[1] * W21 + d1[2] * W22;
+    const float dtx = in_x ? -fx * rz2 * e02 : 0.f, dty = in_y ? -fy * rz2 * e12 : 0.f;
+    const float dtz = -rz2 * (fx * e00 + fy * e11) + 2.f * rz2 * rz * (fx * cx * e02 + fy * cy * e12);
+    return make_float3(W00 * dtx + W10 * dty + W20 * dtz, W01 * dtx + W11 * dty + W21 * dtz, W02 * dtx + W12 * dty + W22 * dtz);
+}
+
+// dL/dSigma (symmetric, G = G00 G01 G02 G11 G12 G22) -> gradients of the scale and of the quaternion used AS GIVEN
+// (what backward.cu:278-341 computes).  Sigma = R S^2 R^T, S = diag(mod * scale), R the rotation of q = (r, x, y, z):
+//   dL/ds_j = 2 s_j (R^T G R)_jj,   dL/dR = 2 G R S^2 =: E,   dL/dq = sum_ij E_ij dR_ij/dq.
+__device__ __forceinline__ void covariance_param_grads(const float* scale3, float mod, float4 q, const float* G, float* dscale, float* dq)
+{
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    const float R[3][3] = {{1.f - 2.f * (y * y + z * z), 2.f * (x * y - r * z), 2.f * (x * z + r * y)},
+                           {2.f * (x * y + r * z), 1.f - 2.f * (x * x + z * z), 2.f * (y * z - r * x)},
+                           {2.f * (x * z - r * y), 2.f * (y * z + r * x), 1.f - 2.f * (x * x + y * y)}};
+    const float Gm[3][3] = {{G[0], G[1], G[2]}, {G[1], G[3], G[4]}, {G[2], G[4], G[5]}};
+    float A[3][3];
 #pragma unroll
     for (int i = 0; i < 3; i++)
 #pragma unroll
-        for (int j = 0; j < 3; j++) dL_dM.m[i][j] = 2.0f * MdS.m[i][j];
-    const M3 Rt = m3_T(R);
-    M3 dMt = m3_T(dL_dM);
-    ds[0] = Rt.m[0][0] * dMt.m[0][0] + Rt.m[0][1] * dMt.m[0][1] + Rt.m[0][2] * dMt.m[0][2];
-    ds[1] = Rt.m[1][0] * dMt.m[1][0] + Rt.m[1][1] * dMt.m[1][1] + Rt.m[1][2] * dMt.m[1][2];
-    ds[2] = Rt.m[2][0] * dMt.m[2][0] + Rt.m[2][1] * dMt.m[2][1] + Rt.m[2][2] * dMt.m[2][2];
+        for (int j = 0; j < 3; j++) A[i][j] = Gm[i][0] * R[0][j] + Gm[i][1] * R[1][j] + Gm[i][2] * R[2][j];
+    float E[3][3];
 #pragma unroll
-    for (int j = 0; j < 3; j++) { dMt.m[0][j] *= sx; dMt.m[1][j] *= sy; dMt.m[2][j] *= sz; }
-#define A(i, j) dMt.m[i][j]
-    dq[0] = 2 * z * (A(0, 1) - A(1, 0)) + 2 * y * (A(2, 0) - A(0, 2)) + 2 * x * (A(1, 2) - A(2, 1));
-    dq[1] = 2 * y * (A(1, 0) + A(0, 1)) + 2 * z * (A(2, 0) + A(0, 2)) + 2 * r * (A(1, 2) - A(2, 1)) - 4 * x * (A(2, 2) + A(1, 1));
-    dq[2] = 2 * x * (A(1, 0) + A(0, 1)) + 2 * r * (A(2, 0) - A(0, 2)) + 2 * z * (A(1, 2) + A(2, 1)) - 4 * y * (A(2, 2) + A(0, 0));
-    dq[3] = 2 * r * (A(0, 1) - A(1, 0)) + 2 * x * (A(2, 0) + A(0, 2)) + 2 * y * (A(1, 2) + A(2, 1)) - 4 * z * (A(1, 1) + A(0, 0));
-#undef A
+    for (int j = 0; j < 3; j++) {
+        const float sj = mod * scale3[j];
+        dscale[j] = mod * 2.f * sj * (R[0][j] * A[0][j] + R[1][j] * A[1][j] + R[2][j] * A[2][j]);
+        const float w = 2.f * sj * sj;
+#pragma unroll
+        for (int i = 0; i < 3; i++) E[i][j] = w * A[i][j];
+    }
+    dq[0] = 2.f * (z * (E[1][0] - E[0][1]) + y * (E[0][2] - E[2][0]) + x * (E[2][1] - E[1][2]));
+    dq[1] = 2.f * (y * (E[0][1] + E[1][0]) + z * (E[0][2] + E[2][0]) + r * (E[2][1] - E[1][2])) - 4.f * x * (E[1][1] + E[2][2]);
+    dq[2] = 2.f * (x * (E[0][1] + E[1][0]) + r * (E[0][2] - E[2][0]) + z * (E[1][2] + E[2][1])) - 4.f * y * (E[0][0] + E[2][2]);
+    dq[3] = 2.f * (r * (E[1][0] - E[0][1]) + x * (E[0][2] + E[2][0]) + y * (E[1][2] + E[2][1])) - 4.f * z * (E[0][0] + E[1][1]);
 }
 
 // One WAVE per `span` consecutive Gaussians (workgroup = 64 lanes, ~19 KB of LDS, no cross-wave barriers).  Pass 1
@@ -1825,7 +1842,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     const int base = blockIdx.x * a.span;
     const bool frozen = a.guard.frozen();      // (a frozen iteration still takes its ticket: the last workgroup publishes the status)
     if (frozen && a.ticket == nullptr) return;
-    float tau[6] = {0, 0, 0, 0, 0, 0};
+    float tw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // world-frame sums behind dL/dtau, see (6) below
   if (!frozen) {
     // SH rows in (and dL_dsh rows out) as 16-B-per-lane streams of whole 192-B rows through LDS
     const bool staged = (a.shs != nullptr) && sh16_vector_ok(a.M, a.shs) &&
@@ -1916,11 +1933,11 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         }
         const bool has_col = vis && s_flag[c0 + lane];
         if (vis) {
-            const float* cov3D = a.cov3D + 6 * (size_t)idx;
             float cov6[6];
-    #pragma unroll
-            for (int i = 0; i < 6; i++) cov6[i] = cov3D[i];
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov6[i] = a.cov3D[6 * (size_t)idx + i];
             const float3 mean = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
+            const float4 co = a.conic_op[idx];
             // (scale and rotation are only needed at the very end; requested here, their latency is hidden by the chain rule)
             const bool want_sr = a.scales && (a.dL_dscale || a.dL_drot);
             float s3[3] = {0.f, 0.f, 0.f};
@@ -1929,164 +1946,67 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
                 s3[0] = a.scales[3 * idx]; s3[1] = a.scales[3 * idx + 1]; s3[2] = a.scales[3 * idx + 2];
                 q = reinterpret_cast<const float4*>(a.rots)[idx];
             }
-            const float dcx = r1.y, dcy = r1.z, dcz = r1.w;
-            Cov2DTerms ct;
-            cov2d_terms(mean, a.fx, a.fy, a.tanx, a.tany, cov6, a.view, ct);
-            const float limx = 1.3f * a.tanx, limy = 1.3f * a.tany;
-            const float x_grad_mul = (ct.txtz < -limx || ct.txtz > limx) ? 0.f : 1.f;
-            const float y_grad_mul = (ct.tytz < -limy || ct.tytz > limy) ? 0.f : 1.f;
-            const float ca = ct.cov.m[0][0] + 0.3f, cb = ct.cov.m[0][1], cc = ct.cov.m[1][1] + 0.3f;
-            const float denom = ca * cc - cb * cb;
-            float dL_da = 0, dL_db = 0, dL_dc = 0;
-            const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
-            float dcov[6];
-            const M3& T = ct.T;
-            const M3& V = ct.Vrk;
-            const M3& Wm = ct.W;
-    #define TT(i, j) T.m[i][j]
-    #define VV(i, j) V.m[i][j]
-    #define WW(i, j) Wm.m[i][j]
-            if (denom2inv != 0) {
-                dL_da = denom2inv * (-cc * cc * dcx + 2 * cb * cc * dcy + (denom - ca * cc) * dcz);
-                dL_dc = denom2inv * (-ca * ca * dcz + 2 * ca * cb * dcy + (denom - ca * cc) * dcx);
-                dL_db = denom2inv * 2 * (cb * cc * dcx - (denom + 2 * cb * cb) * dcy + ca * cb * dcz);
-                dcov[0] = (TT(0, 0) * TT(0, 0) * dL_da + TT(0, 0) * TT(1, 0) * dL_db + TT(1, 0) * TT(1, 0) * dL_dc);
-                dcov[3] = (TT(0, 1) * TT(0, 1) * dL_da + TT(0, 1) * TT(1, 1) * dL_db + TT(1, 1) * TT(1, 1) * dL_dc);
-                dcov[5] = (TT(0, 2) * TT(0, 2) * dL_da + TT(0, 2) * TT(1, 2) * dL_db + TT(1, 2) * TT(1, 2) * dL_dc);
-                dcov[1] = 2 * TT(0, 0) * TT(0, 1) * dL_da + (TT(0, 0) * TT(1, 1) + TT(0, 1) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 1) * dL_dc;
-                dcov[2] = 2 * TT(0, 0) * TT(0, 2) * dL_da + (TT(0, 0) * TT(1, 2) + TT(0, 2) * TT(1, 0)) * dL_db + 2 * TT(1, 0) * TT(1, 2) * dL_dc;
-                dcov[4] = 2 * TT(0, 2) * TT(0, 1) * dL_da + (TT(0, 1) * TT(1, 2) + TT(0, 2) * TT(1, 1)) * dL_db + 2 * TT(1, 1) * TT(1, 2) * dL_dc;
-            } else {
-    #pragma unroll
-                for (int i = 0; i < 6; i++) dcov[i] = 0;
+            // (1) conic gradient -> covariance gradient and the mean's share through the projected covariance
+            float G[6];
+            const float3 g_cov = covariance_chain(mean, cov6, make_float3(co.x, co.y, co.z), make_float3(r1.y, r1.z, r1.w), a.view, a.fx, a.fy,
+                                                  a.tanx, a.tany, G);
+            if (a.dL_dcov3D) {      // the reference's 6-vector counts each off-diagonal entry twice
+                float* o = a.dL_dcov3D + 6 * (size_t)idx;
+                o[0] = G[0]; o[1] = 2.f * G[1]; o[2] = 2.f * G[2]; o[3] = G[3]; o[4] = 2.f * G[4]; o[5] = G[5];
             }
-            if (a.dL_dcov3D) {
-    #pragma unroll
-                for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = dcov[i];
-            }
-
-            const float dL_dT00 = 2 * (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_da + (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_db;
-            const float dL_dT01 = 2 * (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_da + (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_db;
-            const float dL_dT02 = 2 * (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_da + (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_db;
-            const float dL_dT10 = 2 * (TT(1, 0) * VV(0, 0) + TT(1, 1) * VV(0, 1) + TT(1, 2) * VV(0, 2)) * dL_dc + (TT(0, 0) * VV(0, 0) + TT(0, 1) * VV(0, 1) + TT(0, 2) * VV(0, 2)) * dL_db;
-            const float dL_dT11 = 2 * (TT(1, 0) * VV(1, 0) + TT(1, 1) * VV(1, 1) + TT(1, 2) * VV(1, 2)) * dL_dc + (TT(0, 0) * VV(1, 0) + TT(0, 1) * VV(1, 1) + TT(0, 2) * VV(1, 2)) * dL_db;
-            const float dL_dT12 = 2 * (TT(1, 0) * VV(2, 0) + TT(1, 1) * VV(2, 1) + TT(1, 2) * VV(2, 2)) * dL_dc + (TT(0, 0) * VV(2, 0) + TT(0, 1) * VV(2, 1) + TT(0, 2) * VV(2, 2)) * dL_db;
-            const float dL_dJ00 = WW(0, 0) * dL_dT00 + WW(0, 1) * dL_dT01 + WW(0, 2) * dL_dT02;
-            const float dL_dJ02 = WW(2, 0) * dL_dT00 + WW(2, 1) * dL_dT01 + WW(2, 2) * dL_dT02;
-            const float dL_dJ11 = WW(1, 0) * dL_dT10 + WW(1, 1) * dL_dT11 + WW(1, 2) * dL_dT12;
-            const float dL_dJ12 = WW(2, 0) * dL_dT10 + WW(2, 1) * dL_dT11 + WW(2, 2) * dL_dT12;
-    #undef TT
-    #undef VV
-    #undef WW
-            const float3 t = ct.t;
-            const float tz = 1.f / t.z;
-            const float tz2 = tz * tz;
-            const float tz3 = tz2 * tz;
-            const float dL_dtx = x_grad_mul * -a.fx * tz2 * dL_dJ02;
-            const float dL_dty = y_grad_mul * -a.fy * tz2 * dL_dJ12;
-            const float dL_dtz = -a.fx * tz2 * dL_dJ00 - a.fy * tz2 * dL_dJ11 + (2 * a.fx * t.x) * tz3 * dL_dJ02 + (2 * a.fy * t.y) * tz3 * dL_dJ12;
-            const float* vm = a.view;
-            const float3 g_cov = make_float3(vm[0] * dL_dtx + vm[1] * dL_dty + vm[2] * dL_dtz,
-                                             vm[4] * dL_dtx + vm[5] * dL_dty + vm[6] * dL_dtz,
-                                             vm[8] * dL_dtx + vm[9] * dL_dty + vm[10] * dL_dtz);
-            float dm0 = g_cov.x, dm1 = g_cov.y, dm2 = g_cov.z;
-
-            const float* proj = a.proj;
-            const float4 m_hom = xform4x4(mean, proj);
-            const float m_w = 1.0f / (m_hom.w + 0.0000001f);
-            const float mul1 = (proj[0] * mean.x + proj[4] * mean.y + proj[8] * mean.z + proj[12]) * m_w * m_w;
-            const float mul2 = (proj[1] * mean.x + proj[5] * mean.y + proj[9] * mean.z + proj[13]) * m_w * m_w;
-            const float g2x = r0.w, g2y = r1.x;
-            float3 g_m2d;
-            g_m2d.x = (proj[0] * m_w - proj[3] * mul1) * g2x + (proj[1] * m_w - proj[3] * mul2) * g2y;
-            g_m2d.y = (proj[4] * m_w - proj[7] * mul1) * g2x + (proj[5] * m_w - proj[7] * mul2) * g2y;
-            g_m2d.z = (proj[8] * m_w - proj[11] * mul1) * g2x + (proj[9] * m_w - proj[11] * mul2) * g2y;
-            dm0 += g_m2d.x; dm1 += g_m2d.y; dm2 += g_m2d.z;
-
-            float3 g_depth = make_float3(0.f, 0.f, 0.f);
+            // (2) screen-space mean gradient through the perspective division (backward.cu:346-372)
+            const float* P = a.proj;
+            const float hx = P[0] * mean.x + P[4] * mean.y + P[8] * mean.z + P[12], hy = P[1] * mean.x + P[5] * mean.y + P[9] * mean.z + P[13];
+            const float hw = P[3] * mean.x + P[7] * mean.y + P[11] * mean.z + P[15];
+            const float rw = 1.0f / (hw + 0.0000001f);
+            const float kx = hx * rw * rw, ky = hy * rw * rw, g2x = r0.w, g2y = r1.x;
+            const float3 g_m2d = make_float3((P[0] * rw - P[3] * kx) * g2x + (P[1] * rw - P[3] * ky) * g2y,
+                                             (P[4] * rw - P[7] * kx) * g2x + (P[5] * rw - P[7] * ky) * g2y,
+                                             (P[8] * rw - P[11] * kx) * g2x + (P[9] * rw - P[11] * ky) * g2y);
+            // (3) pose package: the splat's own depth z = (Wc p + trans).z carries gradient too
+            float3 g_geo = make_float3(g_cov.x + g_m2d.x, g_cov.y + g_m2d.y, g_cov.z + g_m2d.z);
             if (a.pose) {
                 const float dz = r2.y;
-                g_depth = make_float3(vm[2] * dz, vm[6] * dz, vm[10] * dz);
-                dm0 += g_depth.x; dm1 += g_depth.y; dm2 += g_depth.z;
+                g_geo.x += a.view[2] * dz; g_geo.y += a.view[6] * dz; g_geo.z += a.view[10] * dz;
             }
+            // (4) colour gradient -> SH coefficients and the view direction's share of the mean gradient
             float3 g_sh = make_float3(0.f, 0.f, 0.f);
-            if (a.shs) {
-                if (has_col) {
-                    const float3 dcol = make_float3(r0.x, r0.y, r0.z);
-                    if (staged)
-                        g_sh = sh_backward(a.D, 16, mean, a.campos, my_row, a.clamped[idx], dcol, a.dL_dsh ? my_row : nullptr);
-                    else
-                        g_sh = sh_backward(a.D, a.M, mean, a.campos, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dcol,
-                                           a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
-                    dm0 += g_sh.x; dm1 += g_sh.y; dm2 += g_sh.z;
-                }
+            if (a.shs && has_col) {
+                const float3 dcol = make_float3(r0.x, r0.y, r0.z);
+                if (staged)
+                    g_sh = sh_color_backward(a.D, 16, mean, a.campos, my_row, a.clamped[idx], dcol, a.dL_dsh ? my_row : nullptr);
+                else
+                    g_sh = sh_color_backward(a.D, a.M, mean, a.campos, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dcol,
+                                             a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
             }
             if (a.dL_dmean3D) {
-                a.dL_dmean3D[3 * (size_t)idx] = dm0;
-                a.dL_dmean3D[3 * (size_t)idx + 1] = dm1;
-                a.dL_dmean3D[3 * (size_t)idx + 2] = dm2;
+                a.dL_dmean3D[3 * (size_t)idx] = g_geo.x + g_sh.x;
+                a.dL_dmean3D[3 * (size_t)idx + 1] = g_geo.y + g_sh.y;
+                a.dL_dmean3D[3 * (size_t)idx + 2] = g_geo.z + g_sh.z;
             }
-
+            // (5) covariance gradient -> scale and quaternion
             if (want_sr) {
-                float q4[4] = {q.x, q.y, q.z, q.w};
                 float ds[3], dq[4];
-                cov3d_backward(s3, a.mod, q4, dcov, ds, dq);
+                covariance_param_grads(s3, a.mod, q, G, ds, dq);
                 if (a.dL_dscale) {
                     a.dL_dscale[3 * (size_t)idx] = ds[0]; a.dL_dscale[3 * (size_t)idx + 1] = ds[1]; a.dL_dscale[3 * (size_t)idx + 2] = ds[2];
                 }
                 if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(dq[0], dq[1], dq[2], dq[3]);
             }
-
+            // (6) pose package: dL/dtau for T_w2c <- exp([rho, theta]) T_w2c at 0.  With
+            //   p_C = Wc p + trans:  drho = Wc (g_geo + g_sh),  dtheta = p_C x (Wc g_geo) + 2 Wc a,
+            //   a = (X_12, X_20, X_01) of the antisymmetric X = Sigma G - G Sigma (how the covariance turns with the camera).
+            // Everything per Gaussian is kept in the WORLD frame -- p_C x (Wc g) = Wc (p x g) + trans x (Wc g) -- and the
+            // rotation is applied once per wave to the sums (tw: rho part, g_geo, p x g_geo, a).
             if (a.pose) {
-                // dL/dtau for T_w2c <- exp([rho,theta]) T_w2c at 0:
-                //   drho   = R g_geo + R g_sh
-                //   dtheta = p_C x (R g_geo) + axial(Sigma_C G_C^T - G_C^T Sigma_C)
-                // with R[r][c] = view[4c+r], Sigma_C = R Sigma_W R^T, G_C = R G_W R^T, G_W symmetric.
-                float Rm[3][3];
-    #pragma unroll
-                for (int r = 0; r < 3; r++)
-    #pragma unroll
-                    for (int c = 0; c < 3; c++) Rm[r][c] = vm[c * 4 + r];
-                const float gg[3] = {g_cov.x + g_m2d.x + g_depth.x, g_cov.y + g_m2d.y + g_depth.y, g_cov.z + g_m2d.z + g_depth.z};
-                const float gs[3] = {g_sh.x, g_sh.y, g_sh.z};
-                const float mw[3] = {mean.x, mean.y, mean.z};
-                float pc[3], Rg[3], Rs[3];
-    #pragma unroll
-                for (int r = 0; r < 3; r++) {
-                    pc[r] = Rm[r][0] * mw[0] + Rm[r][1] * mw[1] + Rm[r][2] * mw[2] + vm[12 + r];
-                    Rg[r] = Rm[r][0] * gg[0] + Rm[r][1] * gg[1] + Rm[r][2] * gg[2];
-                    Rs[r] = Rm[r][0] * gs[0] + Rm[r][1] * gs[1] + Rm[r][2] * gs[2];
-                }
-                const float GW[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]}, {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]}, {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
-                const float SW[3][3] = {{cov6[0], cov6[1], cov6[2]}, {cov6[1], cov6[3], cov6[4]}, {cov6[2], cov6[4], cov6[5]}};
-                float SC[3][3], GC[3][3], tmp[3][3];
-    #pragma unroll
-                for (int i = 0; i < 3; i++)
-    #pragma unroll
-                    for (int j = 0; j < 3; j++) tmp[i][j] = Rm[i][0] * SW[0][j] + Rm[i][1] * SW[1][j] + Rm[i][2] * SW[2][j];
-    #pragma unroll
-                for (int i = 0; i < 3; i++)
-    #pragma unroll
-                    for (int j = 0; j < 3; j++) SC[i][j] = tmp[i][0] * Rm[j][0] + tmp[i][1] * Rm[j][1] + tmp[i][2] * Rm[j][2];
-    #pragma unroll
-                for (int i = 0; i < 3; i++)
-    #pragma unroll
-                    for (int j = 0; j < 3; j++) tmp[i][j] = Rm[i][0] * GW[0][j] + Rm[i][1] * GW[1][j] + Rm[i][2] * GW[2][j];
-    #pragma unroll
-                for (int i = 0; i < 3; i++)
-    #pragma unroll
-                    for (int j = 0; j < 3; j++) GC[i][j] = tmp[i][0] * Rm[j][0] + tmp[i][1] * Rm[j][1] + tmp[i][2] * Rm[j][2];
-                // A = SC*GC^T - GC^T*SC ; only the three antisymmetric combinations are needed
-                auto Aij = [&](int i, int j) {
-                    float v = 0.f;
-    #pragma unroll
-                    for (int k = 0; k < 3; k++) v += SC[i][k] * GC[j][k] - GC[k][i] * SC[k][j];
-                    return v;
-                };
-                tau[0] += Rg[0] + Rs[0]; tau[1] += Rg[1] + Rs[1]; tau[2] += Rg[2] + Rs[2];
-                tau[3] += pc[1] * Rg[2] - pc[2] * Rg[1] + (Aij(1, 2) - Aij(2, 1));
-                tau[4] += pc[2] * Rg[0] - pc[0] * Rg[2] + (Aij(2, 0) - Aij(0, 2));
-                tau[5] += pc[0] * Rg[1] - pc[1] * Rg[0] + (Aij(0, 1) - Aij(1, 0));
+                tw[0] += g_geo.x + g_sh.x; tw[1] += g_geo.y + g_sh.y; tw[2] += g_geo.z + g_sh.z;
+                tw[3] += g_geo.x; tw[4] += g_geo.y; tw[5] += g_geo.z;
+                tw[6] += mean.y * g_geo.z - mean.z * g_geo.y; tw[7] += mean.z * g_geo.x - mean.x * g_geo.z; tw[8] += mean.x * g_geo.y - mean.y * g_geo.x;
+                // P = Sigma G; X_ij = P_ij - P_ji
+                const float P01 = cov6[0] * G[1] + cov6[1] * G[3] + cov6[2] * G[4], P10 = cov6[1] * G[0] + cov6[3] * G[1] + cov6[4] * G[2];
+                const float P02 = cov6[0] * G[2] + cov6[1] * G[4] + cov6[2] * G[5], P20 = cov6[2] * G[0] + cov6[4] * G[1] + cov6[5] * G[2];
+                const float P12 = cov6[1] * G[2] + cov6[3] * G[4] + cov6[4] * G[5], P21 = cov6[2] * G[1] + cov6[4] * G[3] + cov6[5] * G[4];
+                tw[9] += 2.f * (P12 - P21); tw[10] += 2.f * (P20 - P02); tw[11] += 2.f * (P01 - P10);
             }
         }
         if (staged && a.dL_dsh) {
@@ -2103,12 +2023,26 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         __syncthreads();
     }
     if (a.pose) {
-        // wave reduction in fp64, one fp64 atomic per wave and component into one of GSR_TAU_SLOTS partial sums
-        // (64 B apart: ~4000 waves adding into six words would queue up at the memory-side atomic unit)
+        // wave reduction in fp64, rotation into the camera frame, then one fp64 atomic per wave and component into one of
+        // GSR_TAU_SLOTS partial sums (64 B apart: ~4000 waves adding into six words would queue up at the memory-side atomic unit)
+        double sw[12];
 #pragma unroll
-        for (int i = 0; i < 6; i++) {
-            const double t = wave_sum_d((double)tau[i]);
-            if (lane == 0 && t != 0.0) atomicAdd(&a.tau_acc[(blockIdx.x & (GSR_TAU_SLOTS - 1)) * 8 + i], t);
+        for (int i = 0; i < 12; i++) sw[i] = wave_sum_d((double)tw[i]);
+        if (lane == 0) {
+            const float* vm = a.view;
+            double tau[6], wg[3];
+#pragma unroll
+            for (int r = 0; r < 3; r++) {
+                const double w0 = vm[r], w1 = vm[4 + r], w2 = vm[8 + r];          // row r of Wc
+                tau[r] = w0 * sw[0] + w1 * sw[1] + w2 * sw[2];
+                wg[r] = w0 * sw[3] + w1 * sw[4] + w2 * sw[5];
+                tau[3 + r] = w0 * (sw[6] + sw[9]) + w1 * (sw[7] + sw[10]) + w2 * (sw[8] + sw[11]);
+            }
+            const double t0 = vm[12], t1 = vm[13], t2 = vm[14];
+            tau[3] += t1 * wg[2] - t2 * wg[1]; tau[4] += t2 * wg[0] - t0 * wg[2]; tau[5] += t0 * wg[1] - t1 * wg[0];
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+                if (tau[i] != 0.0) atomicAdd(&a.tau_acc[(blockIdx.x & (GSR_TAU_SLOTS - 1)) * 8 + i], tau[i]);
         }
     }
   }
