@@ -385,3 +385,31 @@ def test_speculation_on_a_half_empty_scene():
     assert out[True][2]["fallbacks"] == 0
     assert out[True][2]["num_rendered"] < 0.8 * out[False][2]["num_rendered"]
     assert torch.allclose(out[True][0], out[False][0], atol=2e-6) and torch.allclose(out[True][1], out[False][1], atol=2e-6)
+
+
+def test_converged_exit_with_an_overflowing_speculative_bin_returns_a_verified_render():
+    """ADVICE (round 1): when the loop stops on convergence, the forward it hands back was enqueued speculatively; if that
+    speculation failed -- here: a tile whose bin overflows GSR_LSORT_CAP, so the compositing kernel gives up on it -- the
+    returned images must still be those of a complete render at the final pose.  Dense faint splats make every tile's list
+    longer than 2048 even after the depth bounds (nothing saturates, so nothing can be dropped); a huge threshold makes the
+    first update 'converge'."""
+    from tests import replay as PL
+    sc = S.small(P=40000, W=64, H=48, sh_degree=1, seed=43, scale_med=0.12)
+    sc.opacities[:] = np.clip(sc.opacities * 0.02, 0.004, 0.02)
+    model, bg, view, init = _setup(sc, seed=5)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    vp = view()
+    R, T, info = fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=10, converged_threshold=1.0)
+    torch.cuda.synchronize()
+    assert info["converged"] and info["iters"] == 1
+    assert info["fallbacks"] >= 1          # the speculative forward at the final pose was caught and redone
+    chk = view()
+    chk.update_RT(R.clone(), T.clone())
+    with torch.no_grad():
+        pkg = PL.render(chk, model, bg)
+    assert torch.allclose(fr.color, pkg["render"], atol=2e-4), float((fr.color - pkg["render"]).abs().max())
+    assert torch.allclose(fr.depth, pkg["depth"], atol=2e-3)
+    assert torch.allclose(fr.alpha, pkg["opacity"], atol=2e-4)
+    assert int((fr.radii != pkg["radii"]).sum()) <= 2
+    nt = pkg["n_touched"]
+    assert int((fr.n_touched - nt).abs().sum()) <= max(4, int(2e-3 * int(nt.sum())))
