@@ -11,6 +11,7 @@
 #include <mutex>
 #include <atomic>
 #include <thread>
+#include <algorithm>
 
 #include "gsr.h"
 #include "gsr_kernels.h"
@@ -663,16 +664,26 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         HIPCHK(hipStreamWaitEvent(side->st, side->fork, 0));
     }
     if (!cx.native_loop) {
+        // (a caller that carves its gradient tensors out of one allocation -- this repo's Python layer does -- gets ONE memset:
+        // exactly adjacent ranges are merged)
         const size_t Pn = (size_t)P;
-        HIPCHK(hipMemsetAsync(dL_dmean2D, 0, Pn * 3 * sizeof(float), zs));
-        HIPCHK(hipMemsetAsync(dL_dconic, 0, Pn * 4 * sizeof(float), zs));
-        HIPCHK(hipMemsetAsync(dL_dopacity, 0, Pn * sizeof(float), zs));
-        HIPCHK(hipMemsetAsync(dL_dcolor, 0, Pn * 3 * sizeof(float), zs));
-        if (dL_dmean3D) HIPCHK(hipMemsetAsync(dL_dmean3D, 0, Pn * 3 * sizeof(float), zs));
-        if (dL_dcov3D) HIPCHK(hipMemsetAsync(dL_dcov3D, 0, Pn * 6 * sizeof(float), zs));
-        if (dL_dsh && M > 0) HIPCHK(hipMemsetAsync(dL_dsh, 0, Pn * M * 3 * sizeof(float), zs));
-        if (dL_dscale) HIPCHK(hipMemsetAsync(dL_dscale, 0, Pn * 3 * sizeof(float), zs));
-        if (dL_drot) HIPCHK(hipMemsetAsync(dL_drot, 0, Pn * 4 * sizeof(float), zs));
+        struct Range { char* p; size_t n; };
+        Range rg[9];
+        int nr = 0;
+        auto add = [&](float* ptr, size_t bytes) { if (ptr && bytes) rg[nr++] = Range{reinterpret_cast<char*>(ptr), bytes}; };
+        add(dL_dmean2D, Pn * 3 * sizeof(float)); add(dL_dconic, Pn * 4 * sizeof(float)); add(dL_dopacity, Pn * sizeof(float));
+        add(dL_dcolor, Pn * 3 * sizeof(float)); add(dL_dmean3D, Pn * 3 * sizeof(float)); add(dL_dcov3D, Pn * 6 * sizeof(float));
+        if (M > 0) add(dL_dsh, Pn * M * 3 * sizeof(float));
+        add(dL_dscale, Pn * 3 * sizeof(float)); add(dL_drot, Pn * 4 * sizeof(float));
+        std::sort(rg, rg + nr, [](const Range& x, const Range& y) { return x.p < y.p; });
+        for (int i = 0; i < nr;) {
+            char* p0 = rg[i].p;
+            size_t n = rg[i].n;
+            int j = i + 1;
+            while (j < nr && rg[j].p == p0 + n) { n += rg[j].n; j++; }
+            HIPCHK(hipMemsetAsync(p0, 0, n, zs));
+            i = j;
+        }
     }
     if (side) HIPCHK(hipEventRecord(side->join, side->st));
     if (!cx.native_loop) {      // accumulators of K7 (atomically summed)

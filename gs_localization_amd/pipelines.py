@@ -148,6 +148,7 @@ class FusedRefiner:
         a.dL_dmean3D, a.dL_dcov3D, a.dL_dsh, a.dL_dscale, a.dL_drot = map(p, (self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot))
         a.dL_dtau, a.loss_out = p(self.g_tau), p(self.loss_out)
         a.geometry_buffer, a.binning_buffer, a.image_buffer = self.ws[0].fn, self.ws[1].fn, self.ws[2].fn
+        a.geometry_ctx, a.binning_ctx, a.image_ctx = self.ws[0].key, self.ws[1].key, self.ws[2].key
         a.lr, a.converged_threshold, a.max_iters = float(lr), float(converged_threshold), int(iters)
         a.stop_on_converged = int(bool(stop_on_converged))
         a.speculative = int(bool(speculative))

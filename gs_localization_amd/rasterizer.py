@@ -76,13 +76,29 @@ def _ptr(t):
 
 
 class _Workspace:
-    """One resizable device byte buffer (the std::function<char*(size_t)> of rasterize_points.cu:27-33)."""
+    """One resizable device byte buffer (the std::function<char*(size_t)> of rasterize_points.cu:27-33).  All workspaces
+    share ONE C trampoline (building a ctypes callback per forward costs more host time than the forward's launches); the
+    callback context is the workspace's key in a registry."""
+    _registry = {}
+    _next_key = [1]
+    _lock = threading.Lock()
 
     def __init__(self, device):
         self.device = device
         self.t = torch.empty(0, dtype=torch.uint8, device=device)
-        self.fn = _lib.RESIZE_FN(self._resize)
         self.error = None
+        with _Workspace._lock:
+            self.key = _Workspace._next_key[0]
+            _Workspace._next_key[0] += 1
+            _Workspace._registry[self.key] = self
+        self.fn = _WORKSPACE_TRAMPOLINE
+        self.ctx = C.c_void_p(self.key)
+
+    def __del__(self):
+        try:
+            _Workspace._registry.pop(self.key, None)
+        except Exception:
+            pass
 
     def _resize(self, _ctx, nbytes):
         try:
@@ -99,6 +115,14 @@ class _Workspace:
             if w.error is not None:
                 ex, w.error = w.error, None
                 raise ex
+
+
+def _workspace_dispatch(ctx, nbytes):
+    w = _Workspace._registry.get(ctx)
+    return w._resize(ctx, nbytes) if w is not None else 0
+
+
+_WORKSPACE_TRAMPOLINE = _lib.RESIZE_FN(_workspace_dispatch)
 
 
 class _SpecCache(threading.local):
@@ -156,9 +180,8 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp = (
         _f32c(t) for t in (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
     bg, view, proj, campos = (_f32c(t.to(dev)) for t in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos))
-    color = torch.empty((3, H, W), dtype=torch.float32, device=dev)
-    depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
-    alpha = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    images = torch.empty((5, H, W), dtype=torch.float32, device=dev)      # one allocation: colour | depth | opacity
+    color, depth, alpha = images[0:3], images[3:4], images[4:5]
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
     n_touched = torch.empty((P,), dtype=torch.int32, device=dev) if want_touched else None
     M = sh.size(1) if sh.numel() != 0 else 0
@@ -166,7 +189,7 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     stream = torch.cuda.current_stream(dev).cuda_stream
     spec = C.byref(_spec_cache.get(lib, dev, stream, W, H)) if (P > 0 and speculation_enabled(want_touched)) else None
     with torch.cuda.device(dev):
-        rc = lib.gsr_forward_speculative(spec, geom.fn, None, binning.fn, None, img.fn, None, P, int(rs.sh_degree), M, _ptr(bg),
+        rc = lib.gsr_forward_speculative(spec, geom.fn, geom.ctx, binning.fn, binning.ctx, img.fn, img.ctx, P, int(rs.sh_degree), M, _ptr(bg),
                                          W, H, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
                                          float(rs.scale_modifier), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(view),
                                          _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
@@ -189,14 +212,26 @@ def _backward_impl(rs, num_rendered, saved, consts, grad_color, grad_depth, grad
     M = sh.size(1) if sh.numel() != 0 else 0
     H, W = int(rs.image_height), int(rs.image_width)
     grad_color, grad_depth, grad_alpha = (_f32c(g) for g in (grad_color, grad_depth, grad_alpha))
+    # All gradient tensors are slices of ONE allocation, the 16-byte-aligned ones first: the library then zero-fills the whole
+    # block with a single memset instead of ten (host time is what the reference-style loop is short of).
+    want_sh = bool(need["sh"] and M > 0)
+    shapes = [("conic", (P, 2, 2)), ("rot", (P, 4) if need["rotations"] else None), ("sh", (P, M, 3) if want_sh else None),
+              ("m2d", (P, 3)), ("m3d", (P, 3)), ("cov", (P, 6)), ("col", (P, 3)), ("scale", (P, 3) if need["scales"] else None),
+              ("opac", (P, 1)), ("tau", (8,) if pose_mode else None)]
+    total = sum(int(torch.Size(shp).numel()) for _, shp in shapes if shp is not None)
+    flat = torch.empty((total,), dtype=torch.float32, device=dev)
+    out, off = {}, 0
+    for name, shp in shapes:
+        if shp is None:
+            out[name] = None
+            continue
+        n = int(torch.Size(shp).numel())
+        out[name] = flat[off:off + n].view(shp)
+        off += n
+    dL_dconic, dL_drotations, dL_dsh, dL_dmeans2D, dL_dmeans3D, dL_dcov3D, dL_dcolors, dL_dscales, dL_dopacity = (
+        out[k] for k in ("conic", "rot", "sh", "m2d", "m3d", "cov", "col", "scale", "opac"))
+    dL_dtau = out["tau"][:6] if pose_mode else None
     e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-    dL_dmeans2D, dL_dconic, dL_dopacity, dL_dcolors = e(P, 3), e(P, 2, 2), e(P, 1), e(P, 3)
-    dL_dmeans3D, dL_dcov3D = e(P, 3), e(P, 6)
-    # optional outputs: skipped (NULL) when autograd does not need them
-    dL_dsh = e(P, M, 3) if (need["sh"] and M > 0) else None
-    dL_dscales = e(P, 3) if need["scales"] else None
-    dL_drotations = e(P, 4) if need["rotations"] else None
-    dL_dtau = e(6) if pose_mode else None
     stream = torch.cuda.current_stream(dev).cuda_stream
     with torch.cuda.device(dev):
         rc = lib.gsr_backward(P, int(rs.sh_degree), M, int(num_rendered), _ptr(bg), W, H, _ptr(means3D), _ptr(sh),

@@ -146,7 +146,7 @@ def test_spec_state_contract_through_the_c_abi():
         bufs = [RZ._Workspace(dev) for _ in range(3)]
         color = torch.empty((3, H, W), device=dev); depth = torch.empty((1, H, W), device=dev); alpha = torch.empty((1, H, W), device=dev)
         radii = torch.empty(sc.P, dtype=torch.int32, device=dev)
-        rc = lib.gsr_forward_speculative(state, bufs[0].fn, None, bufs[1].fn, None, bufs[2].fn, None, sc.P, 1, 4, bg.data_ptr(), W, H,
+        rc = lib.gsr_forward_speculative(state, bufs[0].fn, bufs[0].ctx, bufs[1].fn, bufs[1].ctx, bufs[2].fn, bufs[2].ctx, sc.P, 1, 4, bg.data_ptr(), W, H,
                                          means.data_ptr(), shs.data_ptr(), None, opac.data_ptr(), scales.data_ptr(), 1.0, rots.data_ptr(),
                                          None, view.data_ptr(), proj.data_ptr(), campos.data_ptr(), sc.tanfovx, sc.tanfovy, 0,
                                          color.data_ptr(), depth.data_ptr(), alpha.data_ptr(), radii.data_ptr(), 0, None,
