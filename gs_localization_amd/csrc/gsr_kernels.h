@@ -498,7 +498,9 @@ __global__ void __launch_bounds__(64) k_sh_color(PreArgs a)
 // memory-side atomic unit serialises (MI355X_MICROARCH.md, "Global float atomics": everybody into one row = 14x slower).
 // The counters are therefore kept in GSR_TBIN_COPIES private copies (workgroup b uses copy b mod copies); k_tile_scan adds
 // the copies up and gives every copy its own sub-range of the tile's segment.
-#define GSR_TBIN_COPIES 16
+#ifndef GSR_TBIN_COPIES
+#define GSR_TBIN_COPIES 4          // (1: emit +10 %; 16: the single-workgroup scan takes 20-40 us; measured on S-1M-640 and the 1.5 M training scene)
+#endif
 // Workgroups of 1024 lanes: the walk is a short chain of dependent loads per Gaussian, so what counts is how many of them
 // are in flight -- 16 waves per workgroup, two workgroups per CU -- while the LDS counters still aggregate a few thousand
 // Gaussians.
@@ -507,7 +509,8 @@ struct TileBinArgs {
     int P, gx, gy, ntiles, gpb;                    // gpb: Gaussians per workgroup (multiple of GSR_TBIN_THREADS)
     int copies;                                    // private copies of the per-tile counters (1 ... GSR_TBIN_COPIES)
     const uint32_t* tiles_touched; const ushort4* rects; const float2* xy; const float4* conic_op; const float* depths;
-    uint32_t* tile_count;                          // [copies][ntiles]: count kernel adds; the scan turns them into sub-range starts
+    uint32_t* tile_count;                          // [copies][ntiles]: the count kernel adds into them
+    const uint32_t* tile_start;                    // [copies][ntiles]: start of each copy's sub-range inside the tile's segment (scan -> emit)
     const uint32_t* tile_offset;                   // [ntiles + 1]   (emit)
     uint32_t* tile_fill;                           // [copies][ntiles]: how much of each sub-range has been handed out (emit)
     uint16_t* block_counts;                        // [workgroups][ntiles]: what each workgroup counted (count writes, emit reads); LDSAGG only
@@ -648,32 +651,46 @@ __global__ void __launch_bounds__(GSR_TBIN_THREADS) k_tile_count(TileBinArgs a)
 }
 
 // One workgroup.  Per tile: total over the counter copies; tile_offset = exclusive prefix sum of the totals (ntiles + 1
-// entries); every copy's counter becomes the start of that copy's sub-range inside the tile's segment; tile_fill = 0;
-// the grand total goes to *total_out.
-__global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, int copies, uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_offset,
-                                                     uint32_t* __restrict__ tile_fill, uint32_t* __restrict__ total_out)
+// entries); tile_start[copy][tile] = where that copy's sub-range begins inside the tile's segment; tile_fill = 0;
+// the grand total goes to *total_out and, if given, to a word of pinned host memory the host is polling (host_total[0] =
+// total, host_total[1] = seq, written last).  Each lane owns a run of consecutive tiles: one round of independent loads,
+// one block-wide scan of the per-lane sums, one round of stores.
+#define GSR_TSCAN_PER_LANE 16          // 1024 lanes x 16 tiles: up to 16 384 tiles per pass (more: passes with a carry)
+__global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, int copies, const uint32_t* __restrict__ tile_count, uint32_t* __restrict__ tile_start,
+                                                     uint32_t* __restrict__ tile_offset, uint32_t* __restrict__ tile_fill,
+                                                     uint32_t* __restrict__ total_out, volatile uint32_t* host_total, uint32_t seq)
 {
     __shared__ uint32_t s_wave[16];
     __shared__ uint32_t s_carry;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid == 0) s_carry = 0u;
     __syncthreads();
-    for (int t0 = 0; t0 < ntiles; t0 += 1024) {
-        const int t = t0 + tid;
-        uint32_t c = 0u;
-        if (t < ntiles) {
-            uint32_t v[GSR_TBIN_COPIES];          // all copies first: independent loads, one round trip
+    const int per = min(GSR_TSCAN_PER_LANE, (ntiles + 1023) / 1024);
+    for (int t0 = 0; t0 < ntiles; t0 += 1024 * per) {
+        const int first = t0 + tid * per;
+        uint32_t tot[GSR_TSCAN_PER_LANE];
+        uint32_t mine = 0u;
 #pragma unroll
-            for (int k = 0; k < GSR_TBIN_COPIES; k++) v[k] = (k < copies) ? tile_count[(size_t)k * ntiles + t] : 0u;
+        for (int q = 0; q < GSR_TSCAN_PER_LANE; q++) {
+            tot[q] = 0u;
+            const int t = first + q;
+            if (q < per && t < ntiles) {
+                uint32_t v[GSR_TBIN_COPIES];              // all copies first: independent loads, one round trip
 #pragma unroll
-            for (int k = 0; k < GSR_TBIN_COPIES; k++)
-                if (k < copies) {
-                    tile_count[(size_t)k * ntiles + t] = c;          // start of copy k's sub-range, relative to the tile's segment
-                    tile_fill[(size_t)k * ntiles + t] = 0u;
-                    c += v[k];
-                }
+                for (int k = 0; k < GSR_TBIN_COPIES; k++) v[k] = (k < copies) ? tile_count[(size_t)k * ntiles + t] : 0u;
+                uint32_t c = 0u;
+#pragma unroll
+                for (int k = 0; k < GSR_TBIN_COPIES; k++)
+                    if (k < copies) {
+                        tile_start[(size_t)k * ntiles + t] = c;          // start of copy k's sub-range, relative to the tile's segment
+                        tile_fill[(size_t)k * ntiles + t] = 0u;
+                        c += v[k];
+                    }
+                tot[q] = c;
+                mine += c;
+            }
         }
-        uint32_t incl = c;
+        uint32_t incl = mine;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const uint32_t o = __shfl_up(incl, off, 64);
@@ -681,14 +698,22 @@ __global__ void __launch_bounds__(1024) k_tile_scan(int ntiles, int copies, uint
         }
         if (lane == 63) s_wave[wv] = incl;
         __syncthreads();
-        uint32_t before = s_carry;
-        for (int w = 0; w < wv; w++) before += s_wave[w];
-        if (t < ntiles) tile_offset[t] = before + incl - c;
+        uint32_t run = s_carry + incl - mine;
+        for (int w = 0; w < wv; w++) run += s_wave[w];
+#pragma unroll
+        for (int q = 0; q < GSR_TSCAN_PER_LANE; q++) {
+            const int t = first + q;
+            if (q < per && t < ntiles) { tile_offset[t] = run; run += tot[q]; }
+        }
         __syncthreads();
-        if (tid == 1023) s_carry = before + incl;
+        if (tid == 1023) s_carry = run;
         __syncthreads();
     }
-    if (tid == 0) { tile_offset[ntiles] = s_carry; *total_out = s_carry; }
+    if (tid == 0) {
+        tile_offset[ntiles] = s_carry;
+        *total_out = s_carry;
+        if (host_total != nullptr) { host_total[0] = s_carry; __threadfence_system(); host_total[1] = seq; }
+    }
 }
 
 // The emit makes `bands` passes over the image, a band of tile rows at a time: every workgroup writes its keys of band 0,
@@ -708,7 +733,7 @@ __global__ void __launch_bounds__(GSR_TBIN_THREADS) k_tile_emit(TileBinArgs a, i
         const uint16_t* row = a.block_counts + (size_t)blockIdx.x * a.ntiles;
         for (int t = threadIdx.x; t < a.ntiles; t += GSR_TBIN_THREADS) {
             const uint32_t c = row[t];          // what this workgroup counted for the tile (k_tile_count): reserve that much
-            s_base[t] = (c != 0u) ? a.tile_offset[t] + a.tile_count[copy + t] + atomicAdd(&a.tile_fill[copy + t], c) : 0u;
+            s_base[t] = (c != 0u) ? a.tile_offset[t] + a.tile_start[copy + t] + atomicAdd(&a.tile_fill[copy + t], c) : 0u;
             s_cnt[t] = 0u;
         }
         WalkItem it[KPT];
