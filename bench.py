@@ -72,18 +72,26 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the CPU port on one thread on S-800k-chess (minutes)")
     ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--pose-only", action="store_true", help="skip the Gaussian-parameter gradients (not the headline)")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
+                    help="process-group backend for N > 1; gloo (collectives on host tensors) lets the N > 1 code path be rehearsed on a box with one GPU")
+    ap.add_argument("--device-index", type=int, default=None, help="GPU of this rank (default: LOCAL_RANK); rehearsals put every rank on GPU 0")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
+    dev_index = local_rank if args.device_index is None else args.device_index
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")      # where the tensors of the (tiny) collectives live
 
     from gs_localization_amd import _lib, scenes as S, shard
     from tests import replay as PL      # the reference-style Python loop on the drop-in packages (test infrastructure)
@@ -239,7 +247,7 @@ def main():
             lib.gsr_profile_sampling(1)
     elapsed = elapsed_runs[0]
     if world > 1:
-        t = torch.tensor([elapsed, elapsed_py, elapsed_single, elapsed_plain] + elapsed_runs, dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, elapsed_py, elapsed_single, elapsed_plain] + elapsed_runs, dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         vals = [float(x) for x in t.tolist()]
         elapsed, elapsed_py, elapsed_single, elapsed_plain, elapsed_runs = vals[0], vals[1], vals[2], vals[3], vals[4:]
@@ -253,7 +261,7 @@ def main():
         te, re = PL.pose_errors(w2c_gt[:3, :3], w2c_gt[:3, 3], Rr.detach().cpu().numpy(), Tt.detach().cpu().numpy())
         rows.append([float(frame_ids[f]), te, re, float(info["iters"])])
     te0, re0 = PL.pose_errors(w2c_gt[:3, :3], w2c_gt[:3, 3], w2c_init[:3, :3], w2c_init[:3, 3])
-    res = shard.gather_results(torch.tensor(rows, dtype=torch.float64, device=dev), world * F, rank, world)
+    res = shard.gather_results(torch.tensor(rows, dtype=torch.float64, device=coll_dev), world * F, rank, world)
 
     train = None
     if rank == 0 and world == 1 and not args.no_train_leg:
