@@ -16,6 +16,7 @@ from typing import NamedTuple
 import ctypes as C
 import os
 import threading
+import weakref
 
 import torch
 import torch.nn as nn
@@ -78,8 +79,9 @@ def _ptr(t):
 class _Workspace:
     """One resizable device byte buffer (the std::function<char*(size_t)> of rasterize_points.cu:27-33).  All workspaces
     share ONE C trampoline (building a ctypes callback per forward costs more host time than the forward's launches); the
-    callback context is the workspace's key in a registry."""
-    _registry = {}
+    callback context is the workspace's key in a registry -- of WEAK references: a forward's workspaces die with the call
+    (their tensors live on in what autograd saved), and a registry that kept them alive would keep every forward's buffers."""
+    _registry = weakref.WeakValueDictionary()
     _next_key = [1]
     _lock = threading.Lock()
 
@@ -93,12 +95,6 @@ class _Workspace:
             _Workspace._registry[self.key] = self
         self.fn = _WORKSPACE_TRAMPOLINE
         self.ctx = C.c_void_p(self.key)
-
-    def __del__(self):
-        try:
-            _Workspace._registry.pop(self.key, None)
-        except Exception:
-            pass
 
     def _resize(self, _ctx, nbytes):
         try:

@@ -86,12 +86,18 @@ class TrainReplay:
             image_height=self.H, image_width=self.W, tanfovx=sc.tanfovx, tanfovy=sc.tanfovy, bg=self.bg, scale_modifier=1.0,
             viewmatrix=vw["view"], projmatrix=vw["proj"], sh_degree=1, campos=vw["campos"], prefiltered=False, debug=False))
 
-    def render(self, vw):
+    def render(self, vw, marks=None):
+        """marks: optional pair of torch.cuda.Event recorded right around the rasterizer call (the activations stay outside)"""
         p = self.par
         act = dict(means3D=p["xyz"], shs=torch.cat((p["f_dc"], p["f_rest"]), dim=1), opacities=torch.sigmoid(p["opacity"]),
                    scales=torch.exp(p["scaling"]), rotations=torch.nn.functional.normalize(p["rotation"]))
         means2D = torch.zeros_like(p["xyz"], requires_grad=True)
-        image, radii, depth, alpha = self.rasterizer(vw)(means2D=means2D, colors_precomp=None, cov3D_precomp=None, **act)
+        rast = self.rasterizer(vw)
+        if marks:
+            marks[0].record()
+        image, radii, depth, alpha = rast(means2D=means2D, colors_precomp=None, cov3D_precomp=None, **act)
+        if marks:
+            marks[1].record()
         return dict(image=image, radii=radii, depth=depth, alpha=alpha, means2D=means2D, act=act)
 
     def step(self, iteration, events=None, keep=False):
@@ -102,7 +108,7 @@ class TrainReplay:
         rec(0)
         vi = int(self.rng.integers(len(self.views)))
         vw = self.views[vi]
-        out = self.render(vw)
+        out = self.render(vw, marks=events[5:7] if events and len(events) >= 7 else None)
         if keep:
             for tname in ("opacities", "scales", "rotations", "shs"):
                 out["act"][tname].retain_grad()
@@ -195,7 +201,7 @@ class TrainReplay:
 
 def time_steps(tr, first_iteration, n, warm=3):
     """ms per step and per phase over n steps (no densification inside: the caller picks the window)."""
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
     it = first_iteration
     for _ in range(warm):
         tr.step(it); it += 1
@@ -206,12 +212,12 @@ def time_steps(tr, first_iteration, n, warm=3):
         tr.step(it); it += 1
     torch.cuda.synchronize()
     wall = (time.perf_counter() - t0) / n
-    acc = np.zeros(4)
+    acc = np.zeros(5)
     m = min(n, 10)
     for _ in range(m):
         tr.step(it, events=ev); it += 1
         torch.cuda.synchronize()
-        acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(4)]
+        acc += [ev[i].elapsed_time(ev[i + 1]) for i in range(4)] + [ev[5].elapsed_time(ev[6])]
     acc /= m
     return dict(P=tr.P, ms_per_step=1e3 * wall, render_fwd_ms=acc[0], loss_epilogue_ms=acc[1], backward_ms=acc[2],
-                stats_and_adam_ms=acc[3]), it
+                stats_and_adam_ms=acc[3], rasterizer_fwd_ms=acc[4]), it

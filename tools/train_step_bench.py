@@ -16,7 +16,7 @@ def main():
         RZ._spec_cache.states.clear()
         tr = TrainReplay(P0=P, P1=P, W=W, H=H, densify_from=10**9)
         r, _ = time_steps(tr, 1, 50, warm=5)
-        print(f"train step {W}x{H} P={P:8d} SH1: {r['ms_per_step']:6.2f} ms/step; rasterizer fwd (+activations) {r['render_fwd_ms']:.2f} ms, "
+        print(f"train step {W}x{H} P={P:8d} SH1: {r['ms_per_step']:6.2f} ms/step; render() {r['render_fwd_ms']:.2f} ms of which the rasterizer forward {r['rasterizer_fwd_ms']:.2f} ms, "
               f"loss epilogue {r['loss_epilogue_ms']:.2f} ms, backward {r['backward_ms']:.2f} ms, densification stats + Adam {r['stats_and_adam_ms']:.2f} ms; "
               f"speculative forwards verified/missed {RZ.speculation_counters()}", flush=True)
         del tr
