@@ -824,10 +824,14 @@ struct FusedLoss {
 };
 __device__ __forceinline__ float sgnf(float d) { return (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f); }
 
+// Record layout: what the walk reads per list entry is a (16 B), the first half of b (8 B) and c (16 B), and the fields sit
+// where the packed fp32 instructions want their operand PAIRS: (x, y) - (px, py), (B2, C2) * dy, (r, g) * w, (b, depth) * w are
+// one v_pk_* each -- same IEEE operations, two per issue slot.
+typedef float gsr_f32x2 __attribute__((ext_vector_type(2)));
 struct SplatLDS {
-    float4 a[GSR_BLOCK];   // x, y, A2, B2
-    float4 b[GSR_BLOCK];   // C2, opacity, depth, id (bits)
-    float4 c[GSR_BLOCK];   // r, g, b, quadrant mask (bits)
+    float4 a[GSR_BLOCK];   // x, y, B2, C2
+    float4 b[GSR_BLOCK];   // A2, opacity | id (bits), quadrant mask (bits)
+    float4 c[GSR_BLOCK];   // r, g, b, depth
     alignas(8) uint8_t list[4][GSR_BLOCK];   // per wave: staged splats that can touch its 8x8 block, in list order
 };
 
@@ -992,7 +996,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
     // T > 0: still compositing.  T <= 0: finished (or outside the image); the pixel's transmittance is -T.  With a
     // negative T every later test_T = T (1 - alpha) is negative, i.e. "below 1e-4": the splat is neither blended nor
     // counted, and the kill branch keeps T where it is -- no flag and no second register to carry.
-    float T = inside ? 1.0f : 0.f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dd = 0.f;
+    float T = inside ? 1.0f : 0.f;
+    gsr_f32x2 Crg = {0.f, 0.f}, Cbd = {0.f, 0.f};      // accumulated (r, g) and (b, depth)
+    const gsr_f32x2 pxy = {pxf, pyf};
     uint32_t last_contributor = 0;
     float zneed = 0.f;        // depth bound of what this pixel had to look at (rounded up to its group of eight)
 
@@ -1039,10 +1045,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
             const uint32_t id = (LIST != GSR_LIST_SORTED) ? (uint32_t)s_keys[base + tid] : point_list[range.x + base + tid];
             const float2 m = xy[id];
             const float4 co = conic_op[id];
-            s.a[tid] = make_float4(m.x, m.y, (-0.5f * GSR_LOG2E) * co.x, (-GSR_LOG2E) * co.y);
-            s.b[tid] = make_float4((-0.5f * GSR_LOG2E) * co.z, co.w, depths[id], __uint_as_float(id));
             const uint32_t qm = quadrant_mask(m.x, m.y, co.x, co.y, co.z, co.w, tx * GSR_TILE, ty * GSR_TILE);
-            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], __uint_as_float(qm));
+            s.a[tid] = make_float4(m.x, m.y, (-GSR_LOG2E) * co.y, (-0.5f * GSR_LOG2E) * co.z);
+            s.b[tid] = make_float4((-0.5f * GSR_LOG2E) * co.x, co.w, __uint_as_float(id), __uint_as_float(qm));
+            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], depths[id]);
         }
         __syncthreads();
         GSR_T_TICK(3)
@@ -1050,7 +1056,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
         int cnt = 0;
         for (int c0 = 0; c0 < n; c0 += 64) {
             const int jj = c0 + lane;
-            const bool hit = jj < n && ((__float_as_uint(s.c[min(jj, GSR_BLOCK - 1)].w) >> wv) & 1u);
+            const bool hit = jj < n && ((__float_as_uint(s.b[min(jj, GSR_BLOCK - 1)].w) >> wv) & 1u);
             const unsigned long long mk = __ballot(hit);
             if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
             cnt += (int)__popcll(mk);
@@ -1070,10 +1076,11 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
             for (int sidx = 0; sidx < 8; sidx++) {
                 const int j = (int)(((sidx < 4 ? plo : phi) >> (8 * (sidx & 3))) & 0xFFu);
                 const float4 A = s.a[j];
-                const float4 B = s.b[j];
+                const float2 B = *reinterpret_cast<const float2*>(&s.b[j]);
                 const float4 Cc = s.c[j];
-                const float dx = A.x - pxf, dy = A.y - pyf;
-                const float p2 = __builtin_fmaf(dx, __builtin_fmaf(A.z, dx, A.w * dy), (B.x * dy) * dy);
+                const gsr_f32x2 d = (gsr_f32x2){A.x, A.y} - pxy;                      // dx, dy
+                const gsr_f32x2 tu = (gsr_f32x2){A.z, A.w} * (gsr_f32x2){d.y, d.y};   // B2 dy, C2 dy
+                const float p2 = __builtin_fmaf(d.x, __builtin_fmaf(B.x, d.x, tu.x), tu.y * d.y);
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, B.y * G);
                 const float test_T = T * (1.f - alpha);
@@ -1081,8 +1088,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
                 const bool kill = valid && test_T < 0.0001f;
                 const bool blend = valid && !kill;
                 const float w = blend ? alpha * T : 0.f;
-                C0 = __builtin_fmaf(Cc.x, w, C0); C1 = __builtin_fmaf(Cc.y, w, C1); C2 = __builtin_fmaf(Cc.z, w, C2);
-                Dd = __builtin_fmaf(B.z, w, Dd);
+                Crg = __builtin_elementwise_fma((gsr_f32x2){Cc.x, Cc.y}, (gsr_f32x2){w, w}, Crg);
+                Cbd = __builtin_elementwise_fma((gsr_f32x2){Cc.z, Cc.w}, (gsr_f32x2){w, w}, Cbd);
                 T = kill ? __uint_as_float(__float_as_uint(T) | 0x80000000u) : (valid ? test_T : T);      // kill: T -> -|T|
                 last_contributor = blend ? (uint32_t)(consumed + base + j + 1) : last_contributor;      // 1-based position in the tile list
 #if GSR_TIMING
@@ -1093,13 +1100,13 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
                     const int c = (int)__popcll(__ballot(valid && test_T > 0.5f));
                     asm volatile("v_writelane_b32 %0, %1, %2" : "+v"(tcnt) : "s"(c), "i"(sidx));
                 }
-                if (sidx == 7) zlast = B.z;
+                if (sidx == 7) zlast = Cc.w;
             }
             zneed = alive0 ? zlast : zneed;
             if (TOUCHED) {
                 if (lane < 8 && tcnt != 0) {
                     const int j = (int)s.list[wv][g0 + lane];
-                    atomicAdd(&n_touched[__float_as_uint(s.b[j].w)], tcnt);
+                    atomicAdd(&n_touched[__float_as_uint(s.b[j].z)], tcnt);
                 }
             }
         }
@@ -1111,9 +1118,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
             const float4 A = s.a[j];
             const float4 B = s.b[j];
             const float4 Cc = s.c[j];
-            if (T > 0.f) zneed = B.z;
-            const float dx = A.x - pxf, dy = A.y - pyf;
-            const float p2 = __builtin_fmaf(dx, __builtin_fmaf(A.z, dx, A.w * dy), (B.x * dy) * dy);
+            if (T > 0.f) zneed = Cc.w;
+            const gsr_f32x2 d = (gsr_f32x2){A.x, A.y} - pxy;
+            const gsr_f32x2 tu = (gsr_f32x2){A.z, A.w} * (gsr_f32x2){d.y, d.y};
+            const float p2 = __builtin_fmaf(d.x, __builtin_fmaf(B.x, d.x, tu.x), tu.y * d.y);
             const float G = __builtin_amdgcn_exp2f(p2);
             const float alpha = fminf(0.99f, B.y * G);
             const float test_T = T * (1.f - alpha);
@@ -1121,13 +1129,13 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
             const bool kill = valid && test_T < 0.0001f;
             const bool blend = valid && !kill;
             const float w = blend ? alpha * T : 0.f;
-            C0 = __builtin_fmaf(Cc.x, w, C0); C1 = __builtin_fmaf(Cc.y, w, C1); C2 = __builtin_fmaf(Cc.z, w, C2);
-            Dd = __builtin_fmaf(B.z, w, Dd);
+            Crg = __builtin_elementwise_fma((gsr_f32x2){Cc.x, Cc.y}, (gsr_f32x2){w, w}, Crg);
+            Cbd = __builtin_elementwise_fma((gsr_f32x2){Cc.z, Cc.w}, (gsr_f32x2){w, w}, Cbd);
             T = kill ? __uint_as_float(__float_as_uint(T) | 0x80000000u) : (valid ? test_T : T);
             last_contributor = blend ? (uint32_t)(consumed + base + j + 1) : last_contributor;
             if (TOUCHED) {
                 const int c = (int)__popcll(__ballot(valid && test_T > 0.5f));
-                if (c != 0 && lane == 0) atomicAdd(&n_touched[__float_as_uint(B.w)], c);
+                if (c != 0 && lane == 0) atomicAdd(&n_touched[__float_as_uint(B.z)], c);
             }
         }
         GSR_T_TICK(5)
@@ -1164,7 +1172,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
         }
     }
     const size_t N = (size_t)W * H;
-    const float img3[3] = {C0 + T_out * bg[0], C1 + T_out * bg[1], C2 + T_out * bg[2]};
+    const float Dd = Cbd.y;
+    const float img3[3] = {Crg.x + T_out * bg[0], Crg.y + T_out * bg[1], Cbd.x + T_out * bg[2]};
     if (inside) {
         n_contrib[pix_id] = last_contributor;
         out_color[pix_id] = img3[0];
@@ -1250,9 +1259,9 @@ typedef float gsr_f32x4 __attribute__((ext_vector_type(4)));
 // splats staged per batch: 128 keeps the workgroup at ~31 KB of LDS = 5 workgroups per CU
 #define GSR_BWD_BATCH 128
 struct BwdMfmaLDS {
-    float4 a[GSR_BWD_BATCH];            // x, y, A2, B2 (pre-scaled conic, see K6)
-    float4 b[GSR_BWD_BATCH];            // C2, opacity, depth, id (bits)
-    float4 c[GSR_BWD_BATCH];            // r, g, b, quadrant mask (bits)
+    float4 a[GSR_BWD_BATCH];            // x, y, B2, C2 (pre-scaled conic and field order as in K6's SplatLDS)
+    float4 b[GSR_BWD_BATCH];            // A2, opacity | id (bits), quadrant mask (bits)
+    float4 c[GSR_BWD_BATCH];            // r, g, b, depth
     float4 d[GSR_BWD_BATCH];            // conic a, b, c as stored (for the recombination), unused
     float acc[GSR_BWD_BATCH][10];       // per staged splat: 0-3 = sum W1 (dpx,dpy,dpz,dLd), 4-9 = W2 moments
     float wt[4][64 * GSR_WT_STRIDE];    // per wave: [pixel][0..7] = W1 of 8 splats, [8..15] = W2
@@ -1281,6 +1290,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
     const bool inside = px < W && py < H;
     const int pix_id = W * py + px;
     const float pxf = (float)px, pyf = (float)py;
+    const gsr_f32x2 pxy = {pxf, pyf};
     const uint2 range = ranges[tile];
     const size_t N = (size_t)W * H;
     // tile-centred frame for the moments (|u|,|v| <= 7.5 keeps the polynomial recombination well conditioned)
@@ -1335,10 +1345,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             const uint32_t id = point_list[range.x + (total - 1 - base - tid)];
             const float2 mm = xy[id];
             const float4 co = conic_op[id];
-            s.a[tid] = make_float4(mm.x, mm.y, (-0.5f * GSR_LOG2E) * co.x, (-GSR_LOG2E) * co.y);
-            s.b[tid] = make_float4((-0.5f * GSR_LOG2E) * co.z, co.w, depths[id], __uint_as_float(id));
             const uint32_t qm = quadrant_mask(mm.x, mm.y, co.x, co.y, co.z, co.w, tx * GSR_TILE, ty * GSR_TILE);
-            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], __uint_as_float(qm));
+            s.a[tid] = make_float4(mm.x, mm.y, (-GSR_LOG2E) * co.y, (-0.5f * GSR_LOG2E) * co.z);
+            s.b[tid] = make_float4((-0.5f * GSR_LOG2E) * co.x, co.w, __uint_as_float(id), __uint_as_float(qm));
+            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], depths[id]);
             s.d[tid] = make_float4(co.x, co.y, co.z, 0.f);
         }
         if (tid < GSR_BWD_BATCH) {
@@ -1350,7 +1360,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         int cnt = 0;
         for (int c0 = 0; c0 < n; c0 += 64) {
             const int jj = c0 + lane;
-            const bool hit = jj < n && ((__float_as_uint(s.c[min(jj, GSR_BWD_BATCH - 1)].w) >> wv) & 1u) &&
+            const bool hit = jj < n && ((__float_as_uint(s.b[min(jj, GSR_BWD_BATCH - 1)].w) >> wv) & 1u) &&
                              (total - base - jj) <= wave_max;
             const unsigned long long mk = __ballot(hit);
             if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
@@ -1373,10 +1383,11 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                     const int j = (int)(((sidx < 4 ? plo : phi) >> (8 * (sidx & 3))) & 0xFFu);
                     const int contributor = total - base - j;
                     const float4 A = s.a[j];
-                    const float4 B = s.b[j];
+                    const float2 B = *reinterpret_cast<const float2*>(&s.b[j]);
                     const float4 Cc = s.c[j];
-                    const float dx = A.x - pxf, dy = A.y - pyf;
-                    const float p2 = __builtin_fmaf(dx, __builtin_fmaf(A.z, dx, A.w * dy), (B.x * dy) * dy);
+                    const gsr_f32x2 d = (gsr_f32x2){A.x, A.y} - pxy;                      // as K6, bit for bit
+                    const gsr_f32x2 tu = (gsr_f32x2){A.z, A.w} * (gsr_f32x2){d.y, d.y};
+                    const float p2 = __builtin_fmaf(d.x, __builtin_fmaf(B.x, d.x, tu.x), tu.y * d.y);
                     const float G = __builtin_amdgcn_exp2f(p2);
                     const float alpha = fminf(0.99f, B.y * G);
                     const bool valid = (contributor <= last_contributor) && !(alpha < 1.0f / 255.0f) && !(p2 > 0.0f);
@@ -1390,7 +1401,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                     //     v = c . dL/dpix + depth * dL/ddepth - dL/dalpha
                     // carries the same information:  sum_ch (value_ch - X_ch) dL_ch - (alpha - A) dL/dalpha
                     //                              = (v - V) + (1 - alpha) dL/dalpha
-                    const float v = __builtin_fmaf(B.z, dLd, __builtin_fmaf(Cc.z, dpz, __builtin_fmaf(Cc.y, dpy, Cc.x * dpx))) - dLa;
+                    const float v = __builtin_fmaf(Cc.w, dLd, __builtin_fmaf(Cc.z, dpz, __builtin_fmaf(Cc.y, dpy, Cc.x * dpx))) - dLa;
                     av = __builtin_fmaf(last_alpha, lv, (1.f - last_alpha) * av);
                     float dL_dopa = __builtin_fmaf(1.f - ae, dLa, v - av);
                     dL_dopa = __builtin_fmaf(dL_dopa, T, nTf_bg * r1ma);
@@ -1453,7 +1464,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         for (int e = tid; e < n * 10; e += GSR_BLOCK) {
             const int j = e / 10, q = e - j * 10;
             const float val = s.acc[j][q];
-            if (val != 0.f && (POSE || q != 9)) atomicAdd(&acc[(size_t)__float_as_uint(s.b[j].w) * GSR_ACC_STRIDE + q], val);
+            if (val != 0.f && (POSE || q != 9)) atomicAdd(&acc[(size_t)__float_as_uint(s.b[j].z) * GSR_ACC_STRIDE + q], val);
         }
         GSR_T_TICK(8)
     }
