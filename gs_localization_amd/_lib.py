@@ -68,7 +68,7 @@ class RefineArgs(C.Structure):
         ("image_buffer", RESIZE_FN), ("image_ctx", _vp),
         ("lr", _f), ("converged_threshold", _f), ("max_iters", _i), ("stop_on_converged", _i),
         ("speculative", _i), ("bound_margin_mul", _f), ("bound_margin_add", _f), ("stats_out", C.POINTER(_i)),
-        ("warm_state", C.POINTER(_i)), ("stream", _vp),
+        ("warm_state", C.POINTER(_i)), ("carry_state", C.POINTER(_i)), ("stream", _vp),
     ]
 
 

@@ -921,26 +921,32 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     const int poff = (warm_buf >= 0) ? (warm_buf ^ 1) : 0;
     int n_fallbacks = 0, last_R = 0, fail_streak = 0, spec_resume = 0;
     bool last_local = false;
-    {   // gradient tensors: zero-filled once per call, then maintained row by row (PreBwdArgs::dirty)
+    // What the previous call on these buffers left behind (see gsr_refine_args.carry_state); dropped until this call succeeds.
+    const int carried = a->carry_state ? *a->carry_state : 0;
+    if (a->carry_state) *a->carry_state = 0;
+    {   // gradient tensors: zero-filled once, then maintained row by row (PreBwdArgs::dirty) -- across calls too when the caller
+        // vouches for them (carried bit 0)
         const size_t Pn = (size_t)a->P;
-        HIPCHK(hipMemsetAsync(a->dL_dmean2D, 0, Pn * 3 * sizeof(float), st));
-        HIPCHK(hipMemsetAsync(a->dL_dconic, 0, Pn * 4 * sizeof(float), st));
-        HIPCHK(hipMemsetAsync(a->dL_dopacity, 0, Pn * sizeof(float), st));
-        HIPCHK(hipMemsetAsync(a->dL_dcolor, 0, Pn * 3 * sizeof(float), st));
-        if (a->dL_dmean3D) HIPCHK(hipMemsetAsync(a->dL_dmean3D, 0, Pn * 3 * sizeof(float), st));
-        if (a->dL_dcov3D) HIPCHK(hipMemsetAsync(a->dL_dcov3D, 0, Pn * 6 * sizeof(float), st));
-        if (a->dL_dsh && a->M > 0) HIPCHK(hipMemsetAsync(a->dL_dsh, 0, Pn * a->M * 3 * sizeof(float), st));
-        if (a->dL_dscale) HIPCHK(hipMemsetAsync(a->dL_dscale, 0, Pn * 3 * sizeof(float), st));
-        if (a->dL_drot) HIPCHK(hipMemsetAsync(a->dL_drot, 0, Pn * 4 * sizeof(float), st));
-        HIPCHK(hipMemsetAsync(ps + GSR_PS_CONV, 0, 5 * sizeof(float), st));      // converged, loss, |tau|, poison, ticket
-        // K7's accumulator records: cleared once here, afterwards K8 clears every record it consumes
         Geom gg;
         char* gptr = (char*)cached_resize(&gb, carve_geom(nullptr, a->P, gg));
         if (!gptr) return fail(GSR_E_ALLOC, "geometry buffer callback returned NULL%s", "");
         carve_geom(gptr, a->P, gg);
-        HIPCHK(hipMemsetAsync(gg.acc, 0, Pn * GSR_ACC_STRIDE * sizeof(float), st));
+        if (!(carried & 1)) {
+            HIPCHK(hipMemsetAsync(a->dL_dmean2D, 0, Pn * 3 * sizeof(float), st));
+            HIPCHK(hipMemsetAsync(a->dL_dconic, 0, Pn * 4 * sizeof(float), st));
+            HIPCHK(hipMemsetAsync(a->dL_dopacity, 0, Pn * sizeof(float), st));
+            HIPCHK(hipMemsetAsync(a->dL_dcolor, 0, Pn * 3 * sizeof(float), st));
+            if (a->dL_dmean3D) HIPCHK(hipMemsetAsync(a->dL_dmean3D, 0, Pn * 3 * sizeof(float), st));
+            if (a->dL_dcov3D) HIPCHK(hipMemsetAsync(a->dL_dcov3D, 0, Pn * 6 * sizeof(float), st));
+            if (a->dL_dsh && a->M > 0) HIPCHK(hipMemsetAsync(a->dL_dsh, 0, Pn * a->M * 3 * sizeof(float), st));
+            if (a->dL_dscale) HIPCHK(hipMemsetAsync(a->dL_dscale, 0, Pn * 3 * sizeof(float), st));
+            if (a->dL_drot) HIPCHK(hipMemsetAsync(a->dL_drot, 0, Pn * 4 * sizeof(float), st));
+            // K7's accumulator records: cleared once here, afterwards K8 clears every record it consumes
+            HIPCHK(hipMemsetAsync(gg.acc, 0, Pn * GSR_ACC_STRIDE * sizeof(float), st));
+            HIPCHK(hipMemsetAsync(gg.dirty, 0, Pn, st));
+        }
+        HIPCHK(hipMemsetAsync(ps + GSR_PS_CONV, 0, 5 * sizeof(float), st));      // converged, loss, |tau|, poison, ticket
         HIPCHK(hipMemsetAsync(gg.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));      // then kept clean by the pose step
-        HIPCHK(hipMemsetAsync(gg.dirty, 0, Pn, st));
         // image workspace: flags, cursors and both bound buffers start from zero; afterwards the kernels keep them so
         Img im0;
         char* iptr = (char*)cached_resize(&ib, carve_img(nullptr, a->width, a->height, im0));
@@ -958,7 +964,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (warm_buf != 1) HIPCHK(hipMemsetAsync(im0.zbc[1], 0, (size_t)im0.nsb * sizeof(float), st));
         HIPCHK(hipMemsetAsync(a->loss_out, 0, 4 * sizeof(float), st));
     }
-    bool cov_cached = false;        // the first forward stores every Gaussian's 3D covariance, the others reuse it
+    bool cov_cached = (carried & 2) != 0;      // the first forward stores every Gaussian's 3D covariance, the others (and, vouched for, later calls) reuse it
     const int debug = 0;
     auto par = [&](int it) { return (it + poff) & 1; };      // which of the two bound buffers iteration `it` WRITES
     // Margin of the speculative bounds.  Given by the caller: fixed.  Otherwise adaptive: bound = (1 + m) z + m metres
@@ -1101,6 +1107,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     }
     HIPCHK(hipStreamSynchronize(st));
     ctx_lease.clean = true;
+    if (a->carry_state) *a->carry_state = (cov_cached ? 2 : 0) | 1;
     if (a->warm_state) *a->warm_state = (a->speculative && last_enq >= 0) ? (par(last_enq) + 1) : 0;
     if (a->stats_out) {
         if (last_local && ib.ptr) {      // instances binned by the last forward = sum of the tile list lengths

@@ -97,6 +97,14 @@ class FusedRefiner:
         self.state = torch.zeros(_lib.POSE_STATE_FLOATS, dtype=torch.float32, device=dev)
         self.ws = [_Workspace(dev), _Workspace(dev), _Workspace(dev)]
         self._warm = C.c_int(0)          # gsr_refine_args.warm_state of this refiner's image workspace
+        # gsr_refine_args.carry_state: this refiner owns the gradient tensors, the workspaces and a frozen map, and nothing else
+        # writes them between two refine() calls -- so the second call need not zero-fill 300 MB of gradients again
+        self._carry = C.c_int(0)
+        self._carry_versions = None      # torch's in-place-modification counters of those tensors when the last call returned
+
+    def _tensor_versions(self):
+        ts = (self.scales, self.rots, self.g_m2d, self.g_conic, self.g_opac, self.g_col, self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot)
+        return tuple(-1 if t is None else t._version for t in ts)
 
     def refine(self, viewpoint, config, initial_R, initial_T, background, iters=50, lr=0.001, converged_threshold=1e-4,
                stop_on_converged=True, speculative=True, bound_margin=None, warm_start=False):
@@ -134,6 +142,11 @@ class FusedRefiner:
         if not warm_start:
             self._warm.value = 0
         a.warm_state = C.pointer(self._warm)
+        # (anything torch has written into them since -- fr.g_sh.zero_(), an optimiser stepping the scales -- shows in the
+        # tensors' version counters and withdraws the promise)
+        if self._carry_versions != self._tensor_versions():
+            self._carry.value = 0
+        a.carry_state = C.pointer(self._carry)
         a.width, a.height = self.W, self.H
         a.tan_fovx, a.tan_fovy = math.tan(viewpoint.FoVx * 0.5), math.tan(viewpoint.FoVy * 0.5)
         a.background, a.projmatrix_raw = p(bg), p(proj_raw)
@@ -163,6 +176,7 @@ class FusedRefiner:
             rc = self.lib.gsr_refine(C.byref(a), C.byref(n_done), C.byref(conv))
             type(self.ws[0]).raise_pending(*self.ws)
             _lib.check(rc)
+        self._carry_versions = self._tensor_versions()
         self._keep = (proj_raw, gt_image, gt_depth, mask, bg)        # alive until the stream has drained
         s = self.state.cpu()
         viewpoint.update_RT(s[0:9].reshape(3, 3).clone(), s[9:12].clone())

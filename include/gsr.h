@@ -259,6 +259,15 @@ typedef struct gsr_refine_args {
      * frames of a sequence see almost the same depths.  As always the speculation is verified and redone if it
      * fails, so a stale or unrelated set of bounds costs time, never exactness. */
     int* warm_state;
+    /* Nullable HOST int, in/out: what the previous call left behind that this one may rely on.  0 on input = nothing.
+     * Pass back the value the previous call wrote here ONLY if nothing below was touched in between -- the same geometry
+     * workspace, the same gradient tensors (all dL_d* of this struct), the same Gaussians (P, scales, rotations,
+     * scale_modifier):
+     *   bit 0  the gradient tensors are exactly what that call left (zero except the rows its last backward wrote, which
+     *          the workspace's dirty bits list): this call does not zero-fill them again (300 MB at 1 M Gaussians);
+     *   bit 1  the workspace holds every Gaussian's 3D covariance: the first forward reads them instead of rebuilding them.
+     * Set to 0 when the call fails. */
+    int* carry_state;
     void* stream;
 } gsr_refine_args;
 int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
