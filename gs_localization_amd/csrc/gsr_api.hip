@@ -1110,7 +1110,9 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     if (a->carry_state) *a->carry_state = (cov_cached ? 2 : 0) | 1;
     if (a->warm_state) *a->warm_state = (a->speculative && last_enq >= 0) ? (par(last_enq) + 1) : 0;
     if (a->stats_out) {
-        if (last_local && ib.ptr) {      // instances binned by the last forward = sum of the tile list lengths
+        const bool want_count = a->stats_out[1] != -1;
+        if (!want_count) last_R = -1;
+        if (want_count && last_local && ib.ptr) {      // instances binned by the last forward = sum of the tile list lengths
             Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
             const int nt = ((a->width + GSR_TILE - 1) / GSR_TILE) * ((a->height + GSR_TILE - 1) / GSR_TILE);
             std::vector<uint2> rg((size_t)nt);

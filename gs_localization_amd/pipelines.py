@@ -107,19 +107,21 @@ class FusedRefiner:
         return tuple(-1 if t is None else t._version for t in ts)
 
     def refine(self, viewpoint, config, initial_R, initial_T, background, iters=50, lr=0.001, converged_threshold=1e-4,
-               stop_on_converged=True, speculative=True, bound_margin=None, warm_start=False):
+               stop_on_converged=True, speculative=True, bound_margin=None, warm_start=False, count_instances=False):
         C, _lib = self._C, self._lib_mod
         dev = self.dev
         # speculative=True: exact optimisation (include/gsr.h, gsr_refine_args.speculative): ~9x fewer binned
         # instances and ~7x fewer SH rows on S-1M-640.  Neutral for one frame at a time (one more host sync per
         # iteration), +14 % with 4 frames in flight per GPU (median 2075 vs 1812 it/s on MI355X).
         viewpoint.update_RT(initial_R, initial_T)
-        st = torch.zeros(_lib.POSE_STATE_FLOATS, dtype=torch.float32)
-        st[0:9] = viewpoint.R.detach().float().cpu().reshape(-1)
-        st[9:12] = viewpoint.T.detach().float().cpu()
-        st[18] = float(viewpoint.exposure_a.detach())
-        st[19] = float(viewpoint.exposure_b.detach())
-        self.state.copy_(st)
+        # the pose state is filled on the device (four tiny copies, no host round trip: reading R, T and the exposure back to
+        # build it on the host cost four stream synchronisations per call)
+        with torch.no_grad():
+            self.state.zero_()
+            self.state[0:9].copy_(viewpoint.R.detach().reshape(-1))
+            self.state[9:12].copy_(viewpoint.T.detach().reshape(-1))
+            self.state[18:19].copy_(viewpoint.exposure_a.detach().reshape(-1))
+            self.state[19:20].copy_(viewpoint.exposure_b.detach().reshape(-1))
         proj_raw = viewpoint.projection_matrix.detach().float().contiguous().to(dev)
         gt_image = viewpoint.original_image.detach().float().contiguous().to(dev)
         mono = bool(config["Training"]["monocular"])
@@ -128,7 +130,8 @@ class FusedRefiner:
             gd = viewpoint.depth
             gd = torch.from_numpy(gd) if not torch.is_tensor(gd) else gd
             gt_depth = gd.to(dtype=torch.float32, device=dev).contiguous()
-        mask = viewpoint.grad_mask.to(device=dev).reshape(self.H, self.W).to(torch.uint8).contiguous()
+        mask = viewpoint.grad_mask.to(device=dev).reshape(self.H, self.W).contiguous()
+        mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)      # (a bool tensor already is one byte per pixel)
         bg = background.detach().float().contiguous().to(dev)
         alpha_cfg = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.98
         stream = torch.cuda.current_stream(dev).cuda_stream
@@ -167,7 +170,9 @@ class FusedRefiner:
         a.speculative = int(bool(speculative))
         # bound_margin=None: adaptive margin of the speculative depth bounds (include/gsr.h); (mul, add) fixes it
         a.bound_margin_mul, a.bound_margin_add = (0.0, 0.0) if bound_margin is None else (float(bound_margin[0]), float(bound_margin[1]))
-        stats = (C.c_int * 2)()
+        # count_instances: also report how many tile instances the LAST forward binned (info["num_rendered"]; costs a copy of
+        # the tile ranges to the host and a stream synchronisation)
+        stats = (C.c_int * 2)(0, 0 if count_instances else -1)
         a.stats_out = stats
         a.stream = stream
         n_done, conv = C.c_int(0), C.c_int(0)

@@ -252,7 +252,8 @@ typedef struct gsr_refine_args {
      * from the 2nd iteration on, tile instances deeper than bound_margin_mul * z + bound_margin_add, z = the
      * depth the tile had to look at in the previous iteration, are not binned.  0 disables. */
     int speculative; float bound_margin_mul, bound_margin_add;     /* mul <= 0: adaptive, (1+m) z + m with m in [0.01, 0.05] */
-    int* stats_out;             /* nullable host int[2]: number of redone forwards, last num_rendered */
+    int* stats_out;             /* nullable host int[2]: number of redone forwards, last num_rendered (set [1] = -1 before the call
+                                 * to skip that count when the last forward binned by tile: it costs a device->host copy) */
     /* Nullable HOST int, in/out: warm start of the speculation for frame sequences.  0 on input = the image workspace
      * holds no depth bounds (the first iteration bins with the global sorts).  Pass the value the previous call on the
      * SAME image workspace (same size) left here to start speculating from that frame's bounds at once -- consecutive

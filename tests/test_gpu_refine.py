@@ -192,7 +192,7 @@ def test_speculative_binning_is_exact_and_falls_back():
     for name, kw in (("full", dict(speculative=False)), ("spec", dict(speculative=True)),
                      ("tight", dict(speculative=True, bound_margin=(0.6, 0.0)))):
         vp = view()
-        R, T, info = fr.refine(vp, cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=12, stop_on_converged=False, **kw)
+        R, T, info = fr.refine(vp, cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=12, stop_on_converged=False, count_instances=True, **kw)
         runs[name] = (R.clone(), T.clone(), info, fr.color.clone(), fr.depth.clone())
     Rf, Tf, inf_f, cf, df = runs["full"]
     assert inf_f["fallbacks"] == 0
@@ -380,9 +380,9 @@ def test_warm_start_of_the_speculation_is_exact():
         assert torch.allclose(a[3], b[3], atol=5e-3 if name == "far" else 5e-4), name
     assert warm_same[2]["fallbacks"] == 0
     # a cold start bins its first iteration completely, a warm one does not: fewer instances in a 1-iteration call
-    fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=1, stop_on_converged=False)
+    fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=1, stop_on_converged=False, count_instances=True)
     n_cold = fr.last_info["num_rendered"]
-    fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=1, stop_on_converged=False, warm_start=True)
+    fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=1, stop_on_converged=False, warm_start=True, count_instances=True)
     assert fr.last_info["num_rendered"] < 0.6 * n_cold
 
 
@@ -419,7 +419,7 @@ def test_speculation_on_a_half_empty_scene():
     for spec in (False, True):
         vp = view()
         R, T, info = fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=12, stop_on_converged=False,
-                               speculative=spec)
+                               speculative=spec, count_instances=True)
         out[spec] = (R.clone(), T.clone(), info, fr.alpha.clone())
     a = out[False][3]
     assert float((a[..., sc.W // 2 + 16:] < 0.9).float().mean()) > 0.5       # the right half really is unsaturated

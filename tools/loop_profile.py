@@ -19,13 +19,13 @@ nk = lib.gsr_profile_kernel_count(); names = [lib.gsr_profile_kernel_name(i).dec
 import time
 MARGIN = tuple(float(x) for x in os.environ["MARGIN"].split(",")) if "MARGIN" in os.environ else None
 for spec in [False, True, False, True]:
-    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False, speculative=spec, bound_margin=MARGIN)
+    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False, speculative=spec, bound_margin=MARGIN, count_instances=True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=100, stop_on_converged=False, speculative=spec, bound_margin=MARGIN)
+    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=100, stop_on_converged=False, speculative=spec, bound_margin=MARGIN, count_instances=True)
     torch.cuda.synchronize(); wall = (time.perf_counter() - t0) / 100
     info = dict(fr.last_info)
     lib.gsr_profile_enable((1 << nk) - 1)
-    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=40, stop_on_converged=False, speculative=spec, bound_margin=MARGIN)
+    fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=40, stop_on_converged=False, speculative=spec, bound_margin=MARGIN, count_instances=True)
     torch.cuda.synchronize()
     ms = (C.c_double * nk)(); cnt = (C.c_longlong * nk)(); lib.gsr_profile_collect(ms, cnt); lib.gsr_profile_enable(0)
     d = {names[i]: round(ms[i] / 40, 4) for i in range(nk)}        # ms per iteration (all launches of that kernel)

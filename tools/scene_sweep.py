@@ -21,12 +21,12 @@ for make in (S.s_50k_fern, S.s_800k_chess, S.s_1m_640, S.s_3m_cam):
     fr = PL.FusedRefiner(model, H, W, device=dev)
     out = {}
     for spec in (False, True):
-        fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=5, stop_on_converged=False, speculative=spec)
+        fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=5, stop_on_converged=False, speculative=spec, count_instances=True)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=100, stop_on_converged=False, speculative=spec)
+        fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=100, stop_on_converged=False, speculative=spec, count_instances=True)
         torch.cuda.synchronize(); el = time.perf_counter() - t0
         out[spec] = (100 / el, dict(fr.last_info))
-    Rr, Tt, info = fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=50, stop_on_converged=True)
+    Rr, Tt, info = fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=50, stop_on_converged=True, count_instances=True)
     te, re = PL.pose_errors(np.eye(3), np.zeros(3), Rr.detach().cpu().numpy(), Tt.detach().cpu().numpy())
     print(f"{sc.name:14s} P={sc.P:8d} {W}x{H}: plain {out[False][0]:7.1f} it/s (R'={out[False][1]['num_rendered']}), speculative {out[True][0]:7.1f} it/s "
           f"(R'={out[True][1]['num_rendered']}, redone {out[True][1]['fallbacks']}); 50-iter refine: {100*te:.2f} cm {re:.3f} deg, iters {info['iters']}, converged {info['converged']}", flush=True)
