@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
-    ap.add_argument("--frames-in-flight", type=int, default=4, help="query frames refined concurrently per GPU")
+    ap.add_argument("--frames-in-flight", type=int, default=8, help="query frames refined concurrently per GPU")
     ap.add_argument("--repeats", type=int, default=3, help="the timed region is run this many times; `value` is the first, the rest show the spread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the CPU port on one thread on S-800k-chess (minutes)")

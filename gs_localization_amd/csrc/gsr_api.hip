@@ -981,6 +981,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     Img imv_loop{};                // the image workspace's carving (for the pose step launch)
     int slot_mode[2] = {0, 0};
     int last_enq = -1;            // last iteration whose forward was enqueued: its bounds are the newest
+    bool last_counted = false;    // ... and it already counted n_touched
     auto enqueue = [&](int it, int mode) -> int {
         slot_mode[it & 1] = mode;
         last_enq = it;
@@ -1004,10 +1005,13 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         cx.fold.proj_raw = a->projmatrix_raw; cx.fold.lr = a->lr; cx.fold.conv_thr = a->converged_threshold; cx.fold.loss_zero = a->loss_out;
         cx.fold.host_status = h_status + 8 * (it & 1); cx.fold.seq = it + 1; cx.fold.loss_shards = imv.loss_shards;
         cx.fold.clear_b = (mode != 0) ? imv.zbc[par(it) ^ 1] : nullptr; cx.fold.clear_n = imv.nsb;
+        // n_touched is wanted for the LAST forward only (see the end): an iteration known to be the last counts it itself
+        const bool count_touched = (it == a->max_iters - 1) && a->n_touched != nullptr;
+        last_counted = count_touched;
         int R = forward_impl(cx, cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
                              a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
                              a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
-                             a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, /*n_touched: see the end*/ nullptr, a->stream);
+                             a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, count_touched ? a->n_touched : nullptr, a->stream);
         if (R < 0) return R;
         last_R = R;
         last_local = (mode == 1);      // the bin-by-tile forward does not bring its instance count to the host
@@ -1087,7 +1091,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (rc < 0) return rc;
         if (a->stop_on_converged && conv) *converged = 1;
     }
-    if (last_enq >= 0 && gb.ptr && bb.ptr && ib.ptr) {
+    if (last_enq >= 0 && !last_counted && a->n_touched && gb.ptr && bb.ptr && ib.ptr) {
         // n_touched (fifth output of the pose package's forward) is only wanted for the LAST forward, and counting it
         // costs every iteration's compositing kernel an eighth of its instructions: the loop runs the variant
         // without it and the lists of the last forward are composited once more here, with the counters.  Same
