@@ -326,6 +326,20 @@ int gsr_debug_timing(unsigned long long* out48)
             for (size_t w = 0; w < GSR_TIM_WAVES; w++) sum += h[((size_t)k * GSR_TIM_WAVES + w) * 12 + q];
             out48[k * 16 + q] = sum;
         }
+    // slots 12..15 of each kernel: the largest accumulated wave lifetime (slot 9) of any row, the number of rows used, and the
+    // 50th / 99th percentile of the rows' lifetimes -- is the kernel's duration its mean wave or its slowest one?
+    for (int k = 0; k < 3; k++) {
+        std::vector<unsigned long long> life;
+        for (size_t w = 0; w < GSR_TIM_WAVES; w++) {
+            const unsigned long long v = h[((size_t)k * GSR_TIM_WAVES + w) * 12 + 9];
+            if (v) life.push_back(v);
+        }
+        std::sort(life.begin(), life.end());
+        out48[k * 16 + 12] = life.empty() ? 0 : life.back();
+        out48[k * 16 + 13] = life.size();
+        out48[k * 16 + 14] = life.empty() ? 0 : life[life.size() / 2];
+        out48[k * 16 + 15] = life.empty() ? 0 : life[life.size() * 99 / 100];
+    }
     std::fill(h.begin(), h.end(), 0ull);
     if (hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_tim), h.data(), h.size() * 8) != hipSuccess) return -2;
     return 0;
