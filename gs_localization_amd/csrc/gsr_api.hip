@@ -104,6 +104,7 @@ struct Carver {
 struct Geom {   // per-Gaussian state carried from forward to backward
     float* depths; float2* xy; float4* conic_op; float* rgb; float* cov3D; uint8_t* clamped;
     uint32_t* tiles_touched; ushort4* rects; float* acc; double* tau_acc; uint8_t* dirty;
+    gsr::SurvLists surv;      // work lists of the forward's survivors (k_preprocess -> k_sh_color, k_preprocess_bwd)
 };
 size_t carve_geom(char* base, int P, Geom& g)
 {
@@ -120,6 +121,9 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.acc = c.take<float>(GSR_ACC_STRIDE * n);
     g.dirty = c.take<uint8_t>(n);
     g.tau_acc = c.take<double>(8 * GSR_TAU_SLOTS);
+    g.surv.cap = gsr::surv_cap(P);
+    g.surv.n = c.take<uint32_t>((size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE);
+    g.surv.ids = c.take<uint32_t>((size_t)GSR_SURV_LISTS * g.surv.cap);
     return c.size();
 }
 
@@ -205,6 +209,7 @@ struct PassCtx {
     bool lean = false;             // this forward's radii are not an output (see k_preprocess)
     uint32_t* ticket = nullptr;    // backward: the chain-rule kernel's last workgroup runs the pose step `fold` (see PreBwdArgs)
     gsr::PoseStepArgs fold = {};
+    gsr::GradRows rows = {};       // native loop: the gradient tensors the kernels keep consistent through the dirty bits
 };
 // gsr_forward_speculative: bounds, flags, cursors and the unsorted bins live in the caller's persistent state buffer
 // instead of the per-call image / binning buffers (which then only hold what the backward reads)
@@ -497,7 +502,11 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     pa.clamped = g.clamped; pa.tiles_touched = g.tiles_touched; pa.rects = g.rects;
     pa.guard = cx.guard;
     pa.n_touched = n_touched;
-    pa.shc_span = shc_span(P);
+    pa.surv = g.surv;
+    pa.dirty = cx.native_loop ? g.dirty : nullptr;
+    pa.rows = cx.rows;
+    // (inside gsr_refine the list counters are cleared by the chain-rule kernel's last workgroup, once every consumer is done)
+    if (!cx.native_loop) HIPCHK(hipMemsetAsync(g.surv.n, 0, (size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE * sizeof(uint32_t), st));
     // Two ways to a tile's list.  With depth bounds from a previous forward (speculation) the few surviving instances are
     // appended to fixed-capacity per-tile bins by the preprocess itself; without them every instance is binned exactly
     // (count -> scan -> emit) and the compositing kernel orders each tile's segment lazily.  (More than 65 536 tiles: the
@@ -547,11 +556,11 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         if (side) {
             HIPCHK(hipEventRecord(side->fork, st));
             HIPCHK(hipStreamWaitEvent(side->st, side->fork, 0));
-            hipLaunchKernelGGL(k_sh_color, dim3((P + pa.shc_span - 1) / pa.shc_span), dim3(64), 0, side->st, pa);
+            hipLaunchKernelGGL(k_sh_color, dim3(surv_grid(P, GSR_SHC_RESIDENT)), dim3(64), 0, side->st, pa);
             HIPCHK(hipEventRecord(side->join, side->st));
         } else {
             ProfScope ps(K_SH_COLOR, st);
-            hipLaunchKernelGGL(k_sh_color, dim3((P + pa.shc_span - 1) / pa.shc_span), dim3(64), 0, st, pa);
+            hipLaunchKernelGGL(k_sh_color, dim3(surv_grid(P, GSR_SHC_RESIDENT)), dim3(64), 0, st, pa);
         }
         LAUNCHCHK("k_sh_color");
     }
@@ -739,8 +748,8 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     if (pb.ticket) pb.fold.tau_acc = g.tau_acc;
     {
         ProfScope ps(K_PREPROCESS_BWD, st);
-        pb.span = k8_span(P);
-        hipLaunchKernelGGL(k_preprocess_bwd, dim3((P + pb.span - 1) / pb.span), dim3(64), 0, st, pb);
+        pb.surv = g.surv;
+        hipLaunchKernelGGL(k_preprocess_bwd, dim3(surv_grid(P, GSR_K8_RESIDENT)), dim3(64), 0, st, pb);
     }
     LAUNCHCHK("k_preprocess_bwd");
     if (pose_mode && !cx.native_loop) {
@@ -961,6 +970,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         }
         HIPCHK(hipMemsetAsync(ps + GSR_PS_CONV, 0, 5 * sizeof(float), st));      // converged, loss, |tau|, poison, ticket
         HIPCHK(hipMemsetAsync(gg.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));      // then kept clean by the pose step
+        HIPCHK(hipMemsetAsync(gg.surv.n, 0, (size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE * sizeof(uint32_t), st));      // ... and the work-list counters too
+        cx.rows = GradRows{a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor, a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, a->M};
         // image workspace: flags, cursors and both bound buffers start from zero; afterwards the kernels keep them so
         Img im0;
         char* iptr = (char*)cached_resize(&ib, carve_img(nullptr, a->width, a->height, im0));

@@ -130,6 +130,57 @@ __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int 
 #define GSR_COOP_AREA 8           // rectangles with more tiles than this are walked by the whole wave
 #endif
 
+// ---------------------------------------------------------------------------------------------
+// Work lists.  After the preprocess only the Gaussians that were binned into at least one tile ("survivors": a few
+// per cent of the map in a speculative iteration of the native loop, the visible ones otherwise) have any work left in
+// the forward (SH colour) and in the per-Gaussian half of the backward (chain rule).  k_preprocess appends them to
+// GSR_SURV_LISTS sub-lists -- workgroup b to sub-list b mod GSR_SURV_LISTS, one wave-aggregated returning atomic per wave
+// that has any; a single counter would serialise thousands of same-address atomics at the memory side (tens of ns each) --
+// and k_sh_color / k_preprocess_bwd walk the lists on dense lanes instead of scanning all P Gaussians for the few that
+// matter (48 MB of accumulator records + 4 MB of flags per iteration at 1 M Gaussians).  Sub-list s owns ids[s * cap ...),
+// cap = the number of Gaussians its workgroups cover; the counters sit 256 B apart.  Order inside a list is arrival order:
+// every consumer writes per-Gaussian rows or adds into sums, neither depends on it.
+// ---------------------------------------------------------------------------------------------
+#define GSR_SURV_LISTS 64
+#define GSR_SURV_CSTRIDE 64
+struct SurvLists { uint32_t* ids; uint32_t* n; uint32_t cap; };
+static inline uint32_t surv_cap(int P)
+{
+    const uint32_t blocks = ((uint32_t)(P > 0 ? P : 1) + GSR_BLOCK - 1) / GSR_BLOCK;
+    return (blocks + GSR_SURV_LISTS - 1) / GSR_SURV_LISTS * GSR_BLOCK;
+}
+// workgroups (of one wave) a list consumer is launched with: a multiple of GSR_SURV_LISTS, at most `resident`
+static inline int surv_grid(int P, int resident)
+{
+    const int chunks = (int)((surv_cap(P) + 63u) / 64u);                     // longest possible sub-list, in 64-entry chunks
+    const int per_list = chunks < resident / GSR_SURV_LISTS ? chunks : resident / GSR_SURV_LISTS;
+    return GSR_SURV_LISTS * (per_list > 0 ? per_list : 1);
+}
+
+// The per-Gaussian gradient rows (native loop: maintained from one iteration to the next through the dirty bits, see
+// PreBwdArgs::dirty).  bit 0 of a dirty byte = the small rows hold values, bit 1 = the dL_dsh row does.
+struct GradRows {
+    float* mean2D; float* conic; float* opacity; float* color; float* mean3D; float* cov3D; float* sh; float* scale; float* rot; int M;
+};
+__device__ __forceinline__ void zero_grad_rows(const GradRows& r, size_t idx, bool small, bool sh_row)
+{
+    if (small) {
+        r.color[3 * idx] = 0.f; r.color[3 * idx + 1] = 0.f; r.color[3 * idx + 2] = 0.f;
+        r.mean2D[3 * idx] = 0.f; r.mean2D[3 * idx + 1] = 0.f;
+        reinterpret_cast<float4*>(r.conic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+        r.opacity[idx] = 0.f;
+        if (r.mean3D) { r.mean3D[3 * idx] = 0.f; r.mean3D[3 * idx + 1] = 0.f; r.mean3D[3 * idx + 2] = 0.f; }
+        if (r.cov3D) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) r.cov3D[6 * idx + i] = 0.f;
+        }
+        if (r.scale) { r.scale[3 * idx] = 0.f; r.scale[3 * idx + 1] = 0.f; r.scale[3 * idx + 2] = 0.f; }
+        if (r.rot) reinterpret_cast<float4*>(r.rot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    if (sh_row && r.sh)
+        for (int i = 0; i < r.M * 3; i++) r.sh[idx * r.M * 3 + i] = 0.f;
+}
+
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
     uint32_t* tile_count; int ntiles;      // exact-bin path: ntiles counter words (all copies) zeroed here for k_tile_count (nullable)
@@ -148,8 +199,12 @@ struct PreArgs {
     float tanx, tany, fx, fy;
     int* radii; float2* xy; float* depths; float* cov3D; float* rgb; float4* conic_op;
     uint8_t* clamped; uint32_t* tiles_touched; ushort4* rects;
-    int shc_span;            // k_sh_color: Gaussians per wave (shc_span())
     int cov_all;             // k_preprocess: compute and store cov3D for every Gaussian, culled or not (see there)
+    SurvLists surv;          // work lists: k_preprocess appends, k_sh_color walks (ids nullable: no lists kept)
+    // Native loop only (dirty nullable): a Gaussian that is NOT a survivor of this forward gets no gradient this iteration;
+    // whatever the previous iteration left in its rows is cleared here, by the one kernel that visits every Gaussian anyway
+    // (k_preprocess_bwd only sees the survivors).  Skipped on a frozen (converged) iteration, whose backward does not run.
+    uint8_t* dirty; GradRows rows;
 };
 
 // Real spherical-harmonics basis of the 3DGS convention (signs and constants as forward.cu:20-71 / sh_utils.py), degree <= 3:
@@ -404,65 +459,62 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
         // compositing kernel treats every such tile that ends unsaturated as a failed speculation)
         a.tiles_touched[idx] = cnt;
     }
+    // survivors -> this workgroup's work list (see SurvLists)
+    const bool surv = vis && cnt != 0u;
+    if (a.surv.ids != nullptr) {
+        const unsigned long long mk = __ballot(surv);
+        if (mk != 0ull) {
+            const int lane = tid & 63;
+            const uint32_t sl = blockIdx.x & (GSR_SURV_LISTS - 1);
+            uint32_t at = 0u;
+            if (lane == 0) at = atomicAdd(&a.surv.n[sl * GSR_SURV_CSTRIDE], (uint32_t)__popcll(mk));
+            at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+            if (surv) a.surv.ids[(size_t)sl * a.surv.cap + at + (uint32_t)__popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+        }
+    }
+    if (a.dirty != nullptr && live && !surv && !a.guard.frozen()) {
+        const uint8_t d = a.dirty[idx];
+        if (d != 0) { zero_grad_rows(a.rows, (size_t)idx, (d & 1) != 0, (d & 2) != 0); a.dirty[idx] = 0; }
+    }
     GSR_T_TICK(4)
     GSR_T_FLUSH(32)
 }
 
-// SH -> RGB (forward.cu:20-71) as its own kernel: it only needs radii > 0 from the geometry pass, so the host
-// runs it on a side stream underneath the (latency-bound) sort chain and joins before compositing.
-// Summation order is the reference's; SH rows arrive as one coalesced stream per block (see above).
-#define GSR_SHC_SPAN 256
-#define GSR_SHC_SPAN_MAX 2048
+// SH -> RGB (forward.cu:20-71) as its own kernel: it only needs the survivors of the geometry pass, so the host
+// runs it on a side stream underneath the (latency-bound) binning chain and joins before compositing.
+// Summation order is the reference's.
 #define GSR_SHC_ROWS 64
-// Gaussians per wave: like K8 (k8_span) the kernel is a chain of dependent memory phases per wave, so the span is
-// chosen to make every wave resident at once (129 registers, ~18 KB of LDS: 8 waves per CU)
-static inline int shc_span(int P)
-{
-    const int resident = 256 * 8;
-    int span = ((P + resident - 1) / resident + GSR_SHC_SPAN - 1) / GSR_SHC_SPAN * GSR_SHC_SPAN;
-    if (span < GSR_SHC_SPAN) span = GSR_SHC_SPAN;
-    if (span > GSR_SHC_SPAN_MAX) span = GSR_SHC_SPAN_MAX;
-    return span;
-}
+// One WAVE per 64-entry chunk of a work list (workgroup w: sub-list w mod GSR_SURV_LISTS, chunks w / GSR_SURV_LISTS, ... in
+// steps of gridDim / GSR_SURV_LISTS): the chunk's 192-B SH rows are staged through LDS as 16-B-per-lane streams and every
+// lane then evaluates one Gaussian.  The kernel is a chain of dependent memory phases per wave (list -> rows -> stores), so
+// the host launches at most as many waves as are resident at once (129 registers, 13 KB of LDS: 8 per CU).
+#define GSR_SHC_RESIDENT (256 * 8)
 __global__ void __launch_bounds__(64) k_sh_color(PreArgs a)
 {
-    // One wave per a.shc_span Gaussians: the ones that need a colour are compacted first (4 candidates per lane at a
-    // time), then handled on dense lanes with their SH rows staged GSR_SHC_ROWS at a time through LDS.
     __shared__ float4 s_sh[GSR_SHC_ROWS * GSR_SH16_LDS4];
-    __shared__ uint16_t s_list[GSR_SHC_SPAN_MAX];
     const int lane = threadIdx.x;
-    const int base = blockIdx.x * a.shc_span;
     if (a.guard.poisoned()) return;
     // only splats that were binned into at least one tile can ever be composited (this also skips everything
     // the native loop's speculative depth bounds dropped)
-    int nact = 0;
-    for (int q0 = 0; q0 < a.shc_span / 64; q0 += GSR_SHC_SPAN / 64)
-#pragma unroll
-    for (int qq = 0; qq < GSR_SHC_SPAN / 64; qq++) {
-        const int local = (q0 + qq) * 64 + lane;
-        const int idx = base + local;
-        const bool need = idx < a.P && a.tiles_touched[idx] > 0;
-        const unsigned long long mk = __ballot(need);
-        if (need) s_list[nact + (int)__popcll(mk & ((1ull << lane) - 1ull))] = (uint16_t)local;
-        nact += (int)__popcll(mk);
-    }
-    __syncthreads();
+    const uint32_t sl = blockIdx.x & (GSR_SURV_LISTS - 1);
+    const uint32_t n = a.surv.n[sl * GSR_SURV_CSTRIDE];
+    const uint32_t* __restrict__ list = a.surv.ids + (size_t)sl * a.surv.cap;
+    const uint32_t step = (gridDim.x / GSR_SURV_LISTS) * GSR_SHC_ROWS;
     const bool staged = sh16_vector_ok(a.M, a.shs);
-    for (int c0 = 0; c0 < nact; c0 += GSR_SHC_ROWS) {
-        const int nrow = min(GSR_SHC_ROWS, nact - c0);
+    for (uint32_t c0 = (blockIdx.x / GSR_SURV_LISTS) * GSR_SHC_ROWS; c0 < n; c0 += step) {
+        const int nrow = (int)min((uint32_t)GSR_SHC_ROWS, n - c0);
+        const int idx = (lane < nrow) ? (int)list[c0 + lane] : 0;
         if (staged) {
 #pragma unroll
             for (int i = 0; i < GSR_SH16_ROW4; i++) {
                 const int j = lane + 64 * i;
                 const int r = j / GSR_SH16_ROW4, part = j - r * GSR_SH16_ROW4;
-                if (r < nrow)
-                    s_sh[r * GSR_SH16_LDS4 + part] =
-                        reinterpret_cast<const float4*>(a.shs)[(size_t)(base + s_list[c0 + r]) * GSR_SH16_ROW4 + part];
+                const int rid = __shfl(idx, r, 64);
+                if (r < nrow) s_sh[r * GSR_SH16_LDS4 + part] = reinterpret_cast<const float4*>(a.shs)[(size_t)rid * GSR_SH16_ROW4 + part];
             }
         }
         __syncthreads();
         if (lane < nrow) {
-            const int idx = base + (int)s_list[c0 + lane];
             const float3 p = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
             uint8_t cb;
             const float3 c = staged ? sh_to_rgb(a.D, 16, p, a.campos, reinterpret_cast<const float*>(&s_sh[lane * GSR_SH16_LDS4]), cb)
@@ -1718,7 +1770,7 @@ struct PreBwdArgs {
     // A row is re-zeroed only when it held values and gets none this time, instead of 300 MB of memsets per call.
     uint8_t* dirty;
     LoopGuard guard;
-    int span;       // Gaussians per wave: a multiple of GSR_K8_SPAN, at most GSR_K8_SPAN_MAX (k8_span)
+    SurvLists surv; // the forward's work lists (k_preprocess): the only Gaussians whose records can hold anything
     // Native loop only (ticket nullable): the workgroup that finishes LAST runs the pose step (Adam, update_pose, camera
     // matrices, status for the host) right here instead of in a launch of its own: every workgroup bumps the ticket once its
     // dL/dtau sums are out; whoever draws the last number sees all of them.
@@ -1856,32 +1908,21 @@ __device__ __forceinline__ void covariance_param_grads(const float* scale3, floa
     dq[3] = 2.f * (r * (E[1][0] - E[0][1]) + x * (E[0][2] + E[2][0]) + y * (E[1][2] + E[2][1])) - 4.f * z * (E[0][0] + E[1][1]);
 }
 
-// One WAVE per `span` consecutive Gaussians (workgroup = 64 lanes, ~19 KB of LDS, no cross-wave barriers).  Pass 1
-// looks at every Gaussian of the span (GSR_K8_SPAN = 4 per lane at a time) and compacts the active ones; pass 2 runs
-// the chain rule on dense lanes, SH rows staged through LDS GSR_K8_ROWS at a time.
-// The kernel is bound by the latency of a wave's dependent phases (records -> compaction -> parameter gathers -> chain
-// rule -> stores) at the 2 waves per SIMD its 242 registers allow, so its duration is (rounds of resident waves) x
-// (one wave's latency): the host picks the span that lets all waves be resident at once (k8_span) -- 35 -> 27 us at
-// 1 M Gaussians (span 512 instead of 256), and the heavier second pass runs on fuller lanes.
-#define GSR_K8_SPAN 256
-#define GSR_K8_SPAN_MAX 2048
+// One WAVE per 64-entry chunk of a work list (workgroup = 64 lanes, ~15 KB of LDS, no cross-wave barriers; workgroup w walks
+// sub-list w mod GSR_SURV_LISTS from chunk w / GSR_SURV_LISTS in steps of gridDim / GSR_SURV_LISTS).  Every lane looks at
+// one survivor's accumulator record; the ones K7 added anything to run the chain rule, SH rows staged through LDS.
+// The kernel is bound by the latency of a wave's dependent phases (list -> record -> parameter gathers -> chain rule ->
+// stores) at the 2 waves per SIMD its registers allow, so the host launches at most as many waves as are resident at once.
+// (Round 1 / early round 2 scanned all P Gaussians' records for the active ones: 48 MB per iteration at 1 M Gaussians for the
+// ~4 % that had work.)
 #define GSR_K8_ROWS 64
-static inline int k8_span(int P)
-{
-    const int resident = 256 * 4 * 2;                       // CUs x SIMDs x waves per SIMD at this register count
-    int span = ((P + resident - 1) / resident + GSR_K8_SPAN - 1) / GSR_K8_SPAN * GSR_K8_SPAN;
-    if (span < GSR_K8_SPAN) span = GSR_K8_SPAN;
-    if (span > GSR_K8_SPAN_MAX) span = GSR_K8_SPAN_MAX;
-    return span;
-}
+#define GSR_K8_RESIDENT (256 * 4 * 2)
 __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
 {
     __shared__ float4 s_sh[GSR_K8_ROWS * GSR_SH16_LDS4];
-    __shared__ uint16_t s_list[GSR_K8_SPAN_MAX];      // active Gaussians of the span (index within the span), compacted
-    __shared__ uint8_t s_flag[GSR_K8_SPAN_MAX];       // per compacted entry: 1 = has a colour gradient (SH row needed)
+    __shared__ uint32_t s_q[2 * GSR_K8_ROWS];      // queue of active Gaussians: index | has a colour gradient << 31
     __shared__ PoseStepLDS s_pose;
     const int lane = threadIdx.x;
-    const int base = blockIdx.x * a.span;
     const bool frozen = a.guard.frozen();      // (a frozen iteration still takes its ticket: the last workgroup publishes the status)
     if (frozen && a.ticket == nullptr) return;
     float tw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // world-frame sums behind dL/dtau, see (6) below
@@ -1889,92 +1930,79 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     // SH rows in (and dL_dsh rows out) as 16-B-per-lane streams of whole 192-B rows through LDS
     const bool staged = (a.shs != nullptr) && sh16_vector_ok(a.M, a.shs) &&
                         (a.dL_dsh == nullptr || (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u) == 0);
-    // ---- pass 1.  Reads the packed sums of K7 and decides who has work: a Gaussian nobody blended has an
-    // all-zero record and all-zero gradients, whatever its other parameters are, so only `active` ones (any
-    // non-zero sum) go through the chain rule below.
-    int nact = 0;
-    for (int q0 = 0; q0 < a.span / 64; q0 += GSR_K8_SPAN / 64)
-#pragma unroll
-    for (int qq = 0; qq < GSR_K8_SPAN / 64; qq++) {
-        const int local = (q0 + qq) * 64 + lane;
-        const int idx = base + local;
-        const bool live = idx < a.P;
-        const bool vis = live && a.radii[idx] > 0;
-        float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-        if (vis) {
-            const float4* rec = reinterpret_cast<const float4*>(a.acc + (size_t)idx * GSR_ACC_STRIDE);
-            r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
-        }
-        const bool active = vis && (r0.x != 0.f || r0.y != 0.f || r0.z != 0.f || r0.w != 0.f || r1.x != 0.f || r1.y != 0.f ||
-                                    r1.z != 0.f || r1.w != 0.f || r2.x != 0.f || r2.y != 0.f);
-        // zero colour gradient => zero SH gradient whatever the coefficients are: their row is not even read
-        const bool has_col = active && (r0.x != 0.f || r0.y != 0.f || r0.z != 0.f);
-        // The gradient tensors are zero wherever nothing is written: the host zero-fills them per call, or (native
-        // loop) once per frame, after which the dirty bits say which rows hold values from the iteration before.
-        const uint8_t was = (a.dirty != nullptr && live) ? a.dirty[idx] : (uint8_t)0;
-        if (a.dirty != nullptr && live) {
-            const uint8_t now = (uint8_t)((active ? 1 : 0) | (has_col ? 2 : 0));
-            if (now != was) a.dirty[idx] = now;
-        }
-        if (active) {
-            a.dL_dcolor[3 * (size_t)idx] = r0.x; a.dL_dcolor[3 * (size_t)idx + 1] = r0.y; a.dL_dcolor[3 * (size_t)idx + 2] = r0.z;
-            a.dL_dmean2D[3 * (size_t)idx] = r0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = r1.x;
-            reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(r1.y, r1.z, 0.f, r1.w);
-            a.dL_dopacity[idx] = r2.x;
-        } else if (was & 1) {
-            // no gradient any more: clear what the previous iteration left in its rows
-            a.dL_dcolor[3 * (size_t)idx] = 0.f; a.dL_dcolor[3 * (size_t)idx + 1] = 0.f; a.dL_dcolor[3 * (size_t)idx + 2] = 0.f;
-            a.dL_dmean2D[3 * (size_t)idx] = 0.f; a.dL_dmean2D[3 * (size_t)idx + 1] = 0.f;
-            reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-            a.dL_dopacity[idx] = 0.f;
-            if (a.dL_dmean3D) { a.dL_dmean3D[3 * (size_t)idx] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 1] = 0.f; a.dL_dmean3D[3 * (size_t)idx + 2] = 0.f; }
-            if (a.dL_dcov3D) {
-#pragma unroll
-                for (int i = 0; i < 6; i++) a.dL_dcov3D[6 * (size_t)idx + i] = 0.f;
+    const GradRows rows = {a.dL_dmean2D, a.dL_dconic, a.dL_dopacity, a.dL_dcolor, a.dL_dmean3D, a.dL_dcov3D, a.dL_dsh, a.dL_dscale, a.dL_drot, a.M};
+    const uint32_t sl = blockIdx.x & (GSR_SURV_LISTS - 1);
+    const uint32_t n = a.surv.n[sl * GSR_SURV_CSTRIDE];
+    const uint32_t* __restrict__ list = a.surv.ids + (size_t)sl * a.surv.cap;
+    const uint32_t step = (gridDim.x / GSR_SURV_LISTS) * GSR_K8_ROWS;
+    uint32_t c0 = (blockIdx.x / GSR_SURV_LISTS) * GSR_K8_ROWS;
+    int qn = 0;          // active Gaussians queued in s_q (wave-uniform)
+    for (;;) {
+        // ---- fill: look at chunks of the list until 64 active Gaussians are queued (or the list ends).  A survivor nobody
+        // blended has an all-zero record and all-zero gradients, whatever its other parameters are: on a long list (complete
+        // bins: half of the survivors) the chain rule below would otherwise run on half-empty lanes.
+        while (qn < GSR_K8_ROWS && c0 < n) {
+            const bool in = c0 + (uint32_t)lane < n;
+            const int idx = in ? (int)list[c0 + lane] : 0;
+            c0 += step;
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+            if (in) {
+                const float4* rec = reinterpret_cast<const float4*>(a.acc + (size_t)idx * GSR_ACC_STRIDE);
+                r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
             }
-            if (a.dL_dscale) { a.dL_dscale[3 * (size_t)idx] = 0.f; a.dL_dscale[3 * (size_t)idx + 1] = 0.f; a.dL_dscale[3 * (size_t)idx + 2] = 0.f; }
-            if (a.dL_drot) reinterpret_cast<float4*>(a.dL_drot)[idx] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        if ((was & 2) && !has_col && a.dL_dsh)       // had an SH gradient last iteration, has none now
-            for (int i = 0; i < a.M * 3; i++) a.dL_dsh[(size_t)idx * a.M * 3 + i] = 0.f;
-        // compact the active Gaussians: pass 2 runs on dense lanes (and re-reads their records, L2 hits)
-        const unsigned long long mk = __ballot(active);
-        if (active) {
-            const int pos = nact + (int)__popcll(mk & ((1ull << lane) - 1ull));
-            s_list[pos] = (uint16_t)local;
-            s_flag[pos] = has_col ? 1 : 0;
-        }
-        nact += (int)__popcll(mk);
-    }
-    __syncthreads();
-
-    // ---- pass 2: lane k takes the k-th active Gaussian of the chunk
-    for (int c0 = 0; c0 < nact; c0 += GSR_K8_ROWS) {
-        const int nrow = min(GSR_K8_ROWS, nact - c0);
-        if (staged) {
-#pragma unroll
-            for (int i = 0; i < GSR_SH16_ROW4; i++) {
-                const int j = lane + 64 * i;
-                const int r = j / GSR_SH16_ROW4, part = j - r * GSR_SH16_ROW4;
-                if (r < nrow && s_flag[c0 + r])
-                    s_sh[r * GSR_SH16_LDS4 + part] =
-                        reinterpret_cast<const float4*>(a.shs)[(size_t)(base + s_list[c0 + r]) * GSR_SH16_ROW4 + part];
+            const bool active = in && (r0.x != 0.f || r0.y != 0.f || r0.z != 0.f || r0.w != 0.f || r1.x != 0.f || r1.y != 0.f ||
+                                       r1.z != 0.f || r1.w != 0.f || r2.x != 0.f || r2.y != 0.f);
+            // zero colour gradient => zero SH gradient whatever the coefficients are: their row is not even read
+            const bool has_col = active && (r0.x != 0.f || r0.y != 0.f || r0.z != 0.f);
+            // The gradient tensors are zero wherever nothing is written: the host zero-fills them per call, or (native
+            // loop) once per frame, after which the dirty bits say which rows hold values from the iteration before.
+            // (Rows of Gaussians that are not on this iteration's lists were cleared by k_preprocess.)
+            const uint8_t was = (a.dirty != nullptr && in) ? a.dirty[idx] : (uint8_t)0;
+            if (a.dirty != nullptr && in) {
+                const uint8_t now = (uint8_t)((active ? 1 : 0) | (has_col ? 2 : 0));
+                if (now != was) a.dirty[idx] = now;
             }
+            if (active) {
+                a.dL_dcolor[3 * (size_t)idx] = r0.x; a.dL_dcolor[3 * (size_t)idx + 1] = r0.y; a.dL_dcolor[3 * (size_t)idx + 2] = r0.z;
+                a.dL_dmean2D[3 * (size_t)idx] = r0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = r1.x;
+                reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(r1.y, r1.z, 0.f, r1.w);
+                a.dL_dopacity[idx] = r2.x;
+            } else if (was & 1) zero_grad_rows(rows, (size_t)idx, true, false);      // no gradient any more
+            if ((was & 2) && !has_col) zero_grad_rows(rows, (size_t)idx, false, true);       // had an SH gradient last iteration, has none now
+            const unsigned long long mk = __ballot(active);
+            if (active) s_q[qn + (int)__popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)idx | (has_col ? 0x80000000u : 0u);
+            qn += (int)__popcll(mk);
         }
+        if (qn == 0) break;
         __syncthreads();
-        const bool vis = lane < nrow;
-        const int idx = base + (vis ? (int)s_list[c0 + lane] : 0);
-        float* my_row = reinterpret_cast<float*>(&s_sh[lane * GSR_SH16_LDS4]);
+        // ---- chain rule on the first (up to) 64 queued Gaussians, dense lanes (their records are re-read: L2 hits)
+        const int nrow = min(qn, GSR_K8_ROWS);
+        const bool active = lane < nrow;
+        const uint32_t qe = active ? s_q[lane] : 0u;
+        const int idx = (int)(qe & 0x7FFFFFFFu);
+        const bool has_col = (qe >> 31) != 0u;
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-        if (vis) {
+        if (active) {
             float4* rec = reinterpret_cast<float4*>(a.acc + (size_t)idx * GSR_ACC_STRIDE);
             r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
             if (a.dirty != nullptr) {      // native loop: leave the record clean for the next iteration's K7 (no 48 MB memset)
                 rec[0] = make_float4(0.f, 0.f, 0.f, 0.f); rec[1] = rec[0]; rec[2] = rec[0];
             }
         }
-        const bool has_col = vis && s_flag[c0 + lane];
-        if (vis) {
+        const unsigned long long colmask = __ballot(has_col);
+        if (staged) {
+#pragma unroll
+            for (int i = 0; i < GSR_SH16_ROW4; i++) {
+                const int j = lane + 64 * i;
+                const int r = j / GSR_SH16_ROW4, part = j - r * GSR_SH16_ROW4;
+                const int rid = __shfl(idx, r, 64);
+                if ((colmask >> r) & 1ull)
+                    s_sh[r * GSR_SH16_LDS4 + part] = reinterpret_cast<const float4*>(a.shs)[(size_t)rid * GSR_SH16_ROW4 + part];
+            }
+        }
+        __syncthreads();
+        float* my_row = reinterpret_cast<float*>(&s_sh[lane * GSR_SH16_LDS4]);
+        if (active) {
             float cov6[6];
 #pragma unroll
             for (int i = 0; i < 6; i++) cov6[i] = a.cov3D[6 * (size_t)idx + i];
@@ -2057,16 +2085,21 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             for (int i = 0; i < GSR_SH16_ROW4; i++) {
                 const int j = lane + 64 * i;
                 const int r = j / GSR_SH16_ROW4, part = j - r * GSR_SH16_ROW4;
-                if (r < nrow && s_flag[c0 + r])
-                    reinterpret_cast<float4*>(a.dL_dsh)[(size_t)(base + s_list[c0 + r]) * GSR_SH16_ROW4 + part] =
-                        s_sh[r * GSR_SH16_LDS4 + part];
+                const int rid = __shfl(idx, r, 64);
+                if ((colmask >> r) & 1ull)
+                    reinterpret_cast<float4*>(a.dL_dsh)[(size_t)rid * GSR_SH16_ROW4 + part] = s_sh[r * GSR_SH16_LDS4 + part];
             }
         }
+        // the rest of the queue moves to the front
+        const uint32_t keep = (nrow + lane < qn) ? s_q[nrow + lane] : 0u;
+        __syncthreads();
+        if (nrow + lane < qn) s_q[lane] = keep;
+        qn -= nrow;
         __syncthreads();
     }
     if (a.pose) {
         // wave reduction in fp64, rotation into the camera frame, then one fp64 atomic per wave and component into one of
-        // GSR_TAU_SLOTS partial sums (64 B apart: ~4000 waves adding into six words would queue up at the memory-side atomic unit)
+        // GSR_TAU_SLOTS partial sums (64 B apart: thousands of waves adding into six words would queue up at the memory-side atomic unit)
         double sw[12];
 #pragma unroll
         for (int i = 0; i < 12; i++) sw[i] = wave_sum_d((double)tw[i]);
@@ -2108,6 +2141,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             // last of all: everybody's sums are in (read below with agent-scope atomic loads, past this CU's L1)
             if (lane == 0) *a.ticket = 0u;             // (the next launch starts counting from zero)
             reinterpret_cast<uint32_t*>(&a.tau_acc[lane * 8 + 6])[0] = 0u;      // the group counters too, also on a frozen iteration
+            a.surv.n[lane * GSR_SURV_CSTRIDE] = 0u;    // every workgroup is past its work list: the next forward appends from zero
             pose_step_wave(a.fold, a.guard, s_pose);
         }
     }
