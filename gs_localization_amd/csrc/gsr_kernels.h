@@ -205,6 +205,9 @@ struct PreArgs {
     // whatever the previous iteration left in its rows is cleared here, by the one kernel that visits every Gaussian anyway
     // (k_preprocess_bwd only sees the survivors).  Skipped on a frozen (converged) iteration, whose backward does not run.
     uint8_t* dirty; GradRows rows;
+    // Native loop only (tile_order nullable): workgroup 0 turns the per-tile work the previous backward measured into this
+    // iteration's launch order of the compositing kernels (see tile_order_from_work)
+    const uint32_t* tile_work; uint32_t* tile_order; int order_tiles;
 };
 
 // Real spherical-harmonics basis of the 3DGS convention (signs and constants as forward.cu:20-71 / sh_utils.py), degree <= 3:
@@ -254,6 +257,49 @@ __device__ __forceinline__ bool sh16_vector_ok(int M, const float* shs)
     return M == 16 && ((reinterpret_cast<uintptr_t>(shs) & 15u) == 0);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Work-balanced launch order of the compositing kernels (native loop).  All tiles of a 640x480 image are resident at once
+// (1200 workgroups on 256 CUs x 5), so K6 / K7 last as long as their slowest CU, and a tile's list is anything between a
+// third and three times the mean.  Workgroups are handed to the CUs breadth-first -- blocks b, b + 256, b + 512, ... share a
+// CU (tools/micro/dispatch_order.hip) -- so if the blocks are numbered by DEcreasing work, in a snake over the CUs (ranks
+// 0..255 left to right, 256..511 right to left, ...), every CU gets one tile of each weight class and the heaviest tiles
+// get the lightest company.  The work of a tile is what K7 measured one iteration earlier (the longest of its four waves'
+// walks); the pose moves by a fraction of a pixel per iteration, so the estimate is good, and ANY permutation is correct.
+// One workgroup, counting sort (the work is a small integer: groups of eight list entries, clamped to 255): histogram in LDS,
+// prefix sum over the 256 classes, one returning LDS atomic per tile for its place among its equals (arrival order: any
+// permutation is correct) -- three barriers, about a microsecond.  (With more tiles than resident workgroups the order is heaviest-first: the classic list-scheduling rule.)
+// ---------------------------------------------------------------------------------------------
+#define GSR_ORDER_MAX_TILES 65536
+__device__ __forceinline__ void tile_order_from_work(const uint32_t* __restrict__ work, uint32_t* __restrict__ order, int ntiles, uint32_t* s_cls /*[256]*/)
+{
+    __shared__ uint32_t s_wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    s_cls[tid] = 0u;
+    __syncthreads();
+    for (int t = tid; t < ntiles; t += GSR_BLOCK) atomicAdd(&s_cls[255u - min(work[t], 255u)], 1u);      // class 0 = heaviest
+    __syncthreads();
+    const uint32_t mine = s_cls[tid];
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t start = incl - mine;
+    for (int w = 0; w < wv; w++) start += s_wsum[w];
+    s_cls[tid] = start;                                                 // first rank of class tid
+    __syncthreads();
+    for (int t = tid; t < ntiles; t += GSR_BLOCK) {
+        const int r = (int)atomicAdd(&s_cls[255u - min(work[t], 255u)], 1u);          // rank, heaviest first
+        // rank r goes to block (r / 256) * 256 + snake(r % 256)
+        const int row = r >> 8, i = r & 255;
+        const int in_row = min(256, ntiles - (row << 8));
+        order[(row << 8) + ((row & 1) ? (in_row - 1 - i) : i)] = (uint32_t)t;
+    }
+}
+
 __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 {
     // (the per-tile bounds are read straight from global memory: only the few lanes of a wave whose splat survives
@@ -261,6 +307,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     // a barrier per workgroup for a staged copy -- an eighth of the kernel's time, and a limit on the tile count)
     extern __shared__ float s_zbc[];      // a.zbc_lds floats: the superblock bounds (0: read them from global memory)
     const int tid = threadIdx.x;
+    if (a.tile_order != nullptr && blockIdx.x == 0) {      // (before the poison test: the order must be a permutation whatever happens)
+        __shared__ uint32_t s_cls[GSR_BLOCK];
+        tile_order_from_work(a.tile_work, a.tile_order, a.order_tiles, s_cls);
+    }
     if (a.guard.poisoned()) return;
     GSR_T_DECL
     if (a.zbc_lds > 0) {
@@ -999,14 +1049,15 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
                                                           int* __restrict__ n_touched, float* __restrict__ zb_next,
                                                           const float* __restrict__ zb_used, uint32_t* __restrict__ fail,
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
-                                                          int sbx, FusedLoss fl)
+                                                          int sbx, FusedLoss fl, const uint32_t* __restrict__ tile_order)
 {
     // (tile_cursor: GSR_LIST_BINS the per-tile append cursors; GSR_LIST_EXACT the tile_offset array of k_tile_scan)
     __shared__ SplatLDS s;
     __shared__ float s_zmax[4];
     __shared__ unsigned long long s_keys[LIST != GSR_LIST_SORTED ? GSR_LSORT_CAP : 1];
     GSR_T_DECL
-    const int tile = xcd_remap(blockIdx.x, ntiles);
+    // (tile_order: the native loop's work-balanced launch order, see tile_order_from_work; otherwise XCD-contiguous runs of tiles)
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_remap(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int px = tx * GSR_TILE + (wv & 1) * 8 + (tid & 7), py = ty * GSR_TILE + (wv >> 1) * 8 + ((tid >> 3) & 7);
@@ -1308,15 +1359,29 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
 // ---------------------------------------------------------------------------------------------
 typedef float gsr_f32x4 __attribute__((ext_vector_type(4)));
 #define GSR_WT_STRIDE 17
+// Weight transposition for the contraction.  A pixel lane p produces 16 values per group of eight splats (row m = 2 * splat +
+// {0: W1, 1: W2}); the MFMA's A operand wants lane (k = lane / 16, m = lane % 16) to hold row m of pixel 4 t + k for the steps
+// t = 0 ... 15.  Layout (floats): region k = p % 4 (GSR_WT_REGION apart), inside it row m at 16 m, inside the row the sixteen
+// t = p / 4 in four chunks of four with chunk index (t / 4) ^ (m / 4):
+//   * a reader fetches its sixteen operands with FOUR ds_read_b128 (one per chunk) in front of sixteen back-to-back MFMAs --
+//     the [pixel][17] layout needed sixteen 4-byte reads, each one an LDS round trip in front of an MFMA pair;
+//   * region stride 272 = 16 mod 64 and the chunk swizzle make the writers' 64 lanes (fixed m) and each 16-lane reader
+//     group (fixed k and chunk) fall into distinct banks;
+//   * W1 and W2 of a splat share a chunk swizzle (same m / 4): one ds_write2_b32 per splat, as before.
+#define GSR_WT_REGION 272
 // splats staged per batch: 128 keeps the workgroup at ~31 KB of LDS = 5 workgroups per CU
 #define GSR_BWD_BATCH 128
 struct BwdMfmaLDS {
-    float4 a[GSR_BWD_BATCH];            // x, y, B2, C2 (pre-scaled conic and field order as in K6's SplatLDS)
-    float4 b[GSR_BWD_BATCH];            // A2, opacity | id (bits), quadrant mask (bits)
-    float4 c[GSR_BWD_BATCH];            // r, g, b, depth
+    // (slot GSR_BWD_BATCH of a, b, c, acc is the NULL splat -- opacity 0, so alpha = 0 and every update of the walk is the
+    // identity -- that pads a wave's list to a multiple of eight: the bodies of a group then need no "is there an entry" test)
+    float4 a[GSR_BWD_BATCH + 1];        // x, y, B2, C2 (pre-scaled conic and field order as in K6's SplatLDS)
+    float4 b[GSR_BWD_BATCH + 1];        // A2, opacity | id (bits), quadrant mask (bits)
+    float4 c[GSR_BWD_BATCH + 1];        // r, g, b, depth
     float4 d[GSR_BWD_BATCH];            // conic a, b, c as stored (for the recombination), unused
-    float acc[GSR_BWD_BATCH][10];       // per staged splat: 0-3 = sum W1 (dpx,dpy,dpz,dLd), 4-9 = W2 moments
-    float wt[4][64 * GSR_WT_STRIDE];    // per wave: [pixel][0..7] = W1 of 8 splats, [8..15] = W2
+    float acc[GSR_BWD_BATCH + 1][10];   // per staged splat: 0-3 = sum W1 (dpx,dpy,dpz,dLd), 4-9 = W2 moments
+    // per wave: the weight transposition buffer of the contraction, see GSR_WT_REGION (before the walk: [pixel][17] scratch
+    // for the B operands, the same 1088 floats)
+    alignas(16) float wt[4][64 * GSR_WT_STRIDE];
     int wmax[4];
     alignas(8) uint8_t list[4][GSR_BWD_BATCH];
 };
@@ -1330,12 +1395,13 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                                                                const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
                                                                const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
                                                                const float* __restrict__ dL_dalphas, float* __restrict__ acc,
-                                                               LoopGuard guard)
+                                                               LoopGuard guard, const uint32_t* __restrict__ tile_order,
+                                                               uint32_t* __restrict__ tile_work)
 {
     __shared__ BwdMfmaLDS s;
     if (guard.frozen()) return;
     GSR_T_DECL
-    const int tile = xcd_remap(blockIdx.x, ntiles);
+    const int tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_remap(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int px = tx * GSR_TILE + (wv & 1) * 8 + (tid & 7), py = ty * GSR_TILE + (wv >> 1) * 8 + ((tid >> 3) & 7);
@@ -1376,16 +1442,29 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
     if (lane == 0) s.wmax[wv] = m;
+    if (tid == 0) {
+        s.a[GSR_BWD_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); s.b[GSR_BWD_BATCH] = s.a[GSR_BWD_BATCH]; s.c[GSR_BWD_BATCH] = s.a[GSR_BWD_BATCH];
+#pragma unroll
+        for (int q = 0; q < 10; q++) s.acc[GSR_BWD_BATCH][q] = 0.f;
+    }
     __syncthreads();
     const int total = max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3]));
     const int wave_max = s.wmax[wv];
 
     float av = 0.f, lv = 0.f, last_alpha = 0.f;      // the "composited behind me" recurrence, see the loop body
+    int walked = 0;                                  // groups of eight list entries this wave has gone through (-> tile_work)
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const int arow = (lane >> 4), acol = (lane & 15);
-    // which (row, column) entries of the MFMA result this lane owns are meaningful: rows 0-7 (W1) x columns 0-3,
-    // rows 8-15 (W2) x columns 4-9
-    const bool owns = (arow < 2) ? (acol < 4) : (acol >= 4 && acol < 10);
+    // D of the MFMA: lane (arow, acol) holds column acol of rows 4 arow + r = {W1, W2 of splat 2 arow, W1, W2 of splat 2 arow + 1};
+    // meaningful are W1 rows x columns 0-3 and W2 rows x columns 4-9
+    const bool own1 = acol < 4;
+    // writer side: where pixel lane p puts row m is wt[wbase[m / 4] + 16 m]; reader side: chunk q of this lane's row
+    int wbase[4], rbase[4];
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+        wbase[y] = GSR_WT_REGION * (lane & 3) + 4 * ((lane >> 4) ^ y) + ((lane >> 2) & 3);
+        rbase[y] = GSR_WT_REGION * arow + 16 * acol + 4 * (y ^ (acol >> 2));
+    }
 
     GSR_T_TICK(0)
     for (int base = 0; base < total; base += GSR_BWD_BATCH) {
@@ -1418,20 +1497,20 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
             cnt += (int)__popcll(mk);
         }
+        if (lane < ((8 - (cnt & 7)) & 7)) s.list[wv][cnt + lane] = (uint8_t)GSR_BWD_BATCH;      // pad to a multiple of eight with the null splat
+        walked += (cnt + 7) >> 3;
         GSR_T_TICK(3)
         GSR_T_COUNT(11, cnt)
         for (int g0 = 0; g0 < cnt; g0 += 8) {
-            float* row = wt + lane * GSR_WT_STRIDE;
             // the 8 list entries of this group in one 8-byte LDS read -> scalar registers, so that the splat
             // records of the whole group can be fetched without waiting for each other
             const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(&s.list[wv][g0]);
             const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)packed);
             const uint32_t phi = __builtin_amdgcn_readfirstlane((uint32_t)(packed >> 32));
-            const int gn = min(8, cnt - g0);          // wave-uniform
 #pragma unroll
             for (int sidx = 0; sidx < 8; sidx++) {
                 float w1 = 0.f, w2 = 0.f;
-                if (sidx < gn) {
+                {
                     const int j = (int)(((sidx < 4 ? plo : phi) >> (8 * (sidx & 3))) & 0xFFu);
                     const int contributor = total - base - j;
                     const float4 A = s.a[j];
@@ -1460,30 +1539,27 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                     w2 = valid ? G * dL_dopa : 0.f;
                     lv = v; last_alpha = ae;
                 }
-                row[sidx] = w1;
-                row[8 + sidx] = w2;
+                wt[wbase[sidx >> 1] + 16 * (2 * sidx)] = w1;
+                wt[wbase[sidx >> 1] + 16 * (2 * sidx + 1)] = w2;
             }
             GSR_T_TICK(4)
             // S[16 rows = {W1,W2} x 8 splats][16 cols] += W[rows][4 pixels] * g[4 pixels][cols], 16 steps
             // (two accumulators: the 16x16x4 f32 MFMA issues every 32 cycles but a dependent one waits 40)
             gsr_f32x4 D = {0.f, 0.f, 0.f, 0.f}, D2 = {0.f, 0.f, 0.f, 0.f};
+            gsr_f32x4 aop[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) aop[q] = *reinterpret_cast<const gsr_f32x4*>(&wt[rbase[q]]);
 #pragma unroll
             for (int t = 0; t < 16; t += 2) {
-                const float aop0 = wt[(4 * t + arow) * GSR_WT_STRIDE + acol];
-                const float aop1 = wt[(4 * t + 4 + arow) * GSR_WT_STRIDE + acol];
-                D = __builtin_amdgcn_mfma_f32_16x16x4f32(aop0, Breg[t], D, 0, 0, 0);
-                D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop1, Breg[t + 1], D2, 0, 0, 0);
+                D = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[t >> 2][t & 3], Breg[t], D, 0, 0, 0);
+                D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[t >> 2][(t & 3) + 1], Breg[t + 1], D2, 0, 0, 0);
             }
             D = D + D2;
-            // D: lane holds column acol, rows 4*arow + r, i.e. splat (arow & 1) * 4 + r of the group.  Merge the
-            // four waves in LDS (unconditional float atomics: adding 0 is harmless, a branch per value is not free).
-            if (owns) {
-                const uint32_t four = (arow & 1) ? phi : plo;
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int sidx = (arow & 1) * 4 + r;
-                    if (sidx < gn) atomicAdd(&s.acc[(four >> (8 * r)) & 0xFFu][acol], D[r]);
-                }
+            // Merge the four waves in LDS (unconditional float atomics: adding 0 is harmless, a branch per value is not free).
+            if (acol < 10) {
+                const uint32_t pair = (((arow & 2) ? phi : plo) >> (16 * (arow & 1))) & 0xFFFFu;      // list bytes of splats 2 arow, 2 arow + 1
+                atomicAdd(&s.acc[pair & 0xFFu][acol], own1 ? D[0] : D[1]);
+                atomicAdd(&s.acc[pair >> 8][acol], own1 ? D[2] : D[3]);
             }
             GSR_T_TICK(5)
         }
@@ -1519,6 +1595,11 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             if (val != 0.f && (POSE || q != 9)) atomicAdd(&acc[(size_t)__float_as_uint(s.b[j].z) * GSR_ACC_STRIDE + q], val);
         }
         GSR_T_TICK(8)
+    }
+    if (tile_work != nullptr) {      // this tile's weight in the next iteration's launch order: its longest wave + a share for the staging
+        if (lane == 0) s.wmax[wv] = walked;
+        __syncthreads();
+        if (tid == 0) tile_work[tile] = (uint32_t)(max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3])) + 2 * ((total + GSR_BWD_BATCH - 1) / GSR_BWD_BATCH));
     }
     GSR_T_FLUSH(16)
 }
