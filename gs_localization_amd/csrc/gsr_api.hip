@@ -141,7 +141,7 @@ struct Img {
     float* zbc[2]; int sbx, nsb;                         // bounds per 4x4-tile superblock
     uint32_t* tile_cursor; size_t clear_words;           // bin-by-tile path: per-tile append cursors (GSR_CURSOR_STRIDE apart)
     float* loss_shards;                                   // native loop: GSR_LOSS_SHARDS x 16 floats (fused tracking loss)
-    uint32_t* tile_work; uint32_t* tile_order;            // native loop: per-tile work of the last backward -> launch order of the compositing kernels
+    uint32_t* tile_work[2]; uint32_t* tile_order[2];      // native loop: per-tile work of the last forward [0] / backward [1] compositing -> their launch orders
 };
 size_t carve_img(char* base, int W, int H, Img& im)
 {
@@ -169,8 +169,8 @@ size_t carve_img(char* base, int W, int H, Img& im)
     im.fail = c.take<uint32_t>(im.clear_words);
     im.tile_cursor = base ? im.fail + 16 : nullptr;
     im.loss_shards = c.take<float>(GSR_LOSS_SHARDS * 16);
-    im.tile_work = c.take<uint32_t>(nt);
-    im.tile_order = c.take<uint32_t>(nt);
+    im.tile_work[0] = c.take<uint32_t>(nt); im.tile_work[1] = c.take<uint32_t>(nt);      // (contiguous: one memset)
+    im.tile_order[0] = c.take<uint32_t>(nt); im.tile_order[1] = c.take<uint32_t>(nt);
     return c.size();
 }
 
@@ -508,7 +508,8 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     pa.n_touched = n_touched;
     pa.surv = g.surv;
     const bool balanced = cx.balance && cx.native_loop && ntiles <= GSR_ORDER_MAX_TILES && !sp.state;
-    pa.tile_work = balanced ? im.tile_work : nullptr; pa.tile_order = balanced ? im.tile_order : nullptr; pa.order_tiles = ntiles;
+    for (int k = 0; k < 2; k++) { pa.tile_work[k] = balanced ? im.tile_work[k] : nullptr; pa.tile_order[k] = balanced ? im.tile_order[k] : nullptr; }
+    pa.order_tiles = ntiles;
     pa.dirty = cx.native_loop ? g.dirty : nullptr;
     pa.rows = cx.rows;
     // (inside gsr_refine the list counters are cleared by the chain-rule kernel's last workgroup, once every consumer is done)
@@ -549,7 +550,8 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         pa.lean = (cx.lean && cx.native_loop && by_tile && pa.cov_all == 0) ? 1 : 0;
         // (the exact-bin path has the preprocess zero the per-tile counters, all copies: at least that many threads)
         pa.ntiles = ntiles * im.copies;
-        const int blocks = by_tile ? pblocks : std::max(pblocks, (pa.ntiles + GSR_BLOCK - 1) / GSR_BLOCK);
+        // (the first two workgroups also compute the launch orders of the compositing kernels: there must be two)
+        const int blocks = std::max(by_tile ? pblocks : std::max(pblocks, (pa.ntiles + GSR_BLOCK - 1) / GSR_BLOCK), balanced ? 2 : 1);
         hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(GSR_BLOCK), (size_t)pa.zbc_lds * sizeof(float), st, pa);
     }
     LAUNCHCHK("k_preprocess");
@@ -629,7 +631,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
                      by_tile ? im.tile_cursor : im.tile_offset, width, height, gx, ntiles, (const float2*)g.xy, feat, \
                      (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
                      zb_next, zb_prev, cx.guard.poison ? const_cast<uint32_t*>(cx.guard.poison) : im.fail, \
-                     sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order
+                     sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], balanced ? im.tile_work[0] : (uint32_t*)nullptr
         if (by_tile) {
             if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
             else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
@@ -730,8 +732,8 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
                      (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas, (const uint32_t*)im.n_contrib, dL_dpix, \
                      dL_ddepths, dL_dalphas, g.acc
         const bool balanced = cx.balance && cx.native_loop && ntiles <= GSR_ORDER_MAX_TILES;
-        const uint32_t* order = balanced ? im.tile_order : nullptr;
-        uint32_t* work = balanced ? im.tile_work : nullptr;
+        const uint32_t* order = balanced ? im.tile_order[1] : nullptr;
+        uint32_t* work = balanced ? im.tile_work[1] : nullptr;
         if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work);
         else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work);
 #undef GSR_BWD_ARGS
@@ -988,7 +990,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         carve_img(iptr, a->width, a->height, im0);
         HIPCHK(hipMemsetAsync(im0.fail, 0, im0.clear_words * sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(im0.loss_shards, 0, GSR_LOSS_SHARDS * 16 * sizeof(float), st));
-        HIPCHK(hipMemsetAsync(im0.tile_work, 0, (size_t)((a->width + GSR_TILE - 1) / GSR_TILE) * ((a->height + GSR_TILE - 1) / GSR_TILE) * sizeof(uint32_t), st));
+        HIPCHK(hipMemsetAsync(im0.tile_work[0], 0, (size_t)(im0.tile_work[1] - im0.tile_work[0]) * 2 * sizeof(uint32_t), st));
         cx.balance = getenv("GSR_NO_BALANCE") == nullptr;
         HIPCHK(hipMemsetAsync(a->dL_dalpha, 0, (size_t)a->width * a->height * sizeof(float), st));      // no gradient flows into opacity
         cx.floss.gt_image = a->gt_image; cx.floss.gt_depth = a->gt_depth; cx.floss.grad_mask = a->grad_mask;
@@ -1142,7 +1144,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                            a->height, gx, gx * gy, (const float2*)g.xy, (const float*)g.rgb, (const float*)g.depths,
                            (const float4*)g.conic_op, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
                            a->n_touched, (float*)nullptr, (const float*)nullptr, im.fail, 1.f, 0.f, (float*)nullptr,
-                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr);
+                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr);
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
     HIPCHK(hipStreamSynchronize(st));

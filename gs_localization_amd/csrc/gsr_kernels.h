@@ -207,7 +207,8 @@ struct PreArgs {
     uint8_t* dirty; GradRows rows;
     // Native loop only (tile_order nullable): workgroup 0 turns the per-tile work the previous backward measured into this
     // iteration's launch order of the compositing kernels (see tile_order_from_work)
-    const uint32_t* tile_work; uint32_t* tile_order; int order_tiles;
+    // ([0]: k_render_fwd's order from the work it measured, [1]: k_render_bwd_mfma's)
+    const uint32_t* tile_work[2]; uint32_t* tile_order[2]; int order_tiles;
 };
 
 // Real spherical-harmonics basis of the 3DGS convention (signs and constants as forward.cu:20-71 / sh_utils.py), degree <= 3:
@@ -307,9 +308,9 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     // a barrier per workgroup for a staged copy -- an eighth of the kernel's time, and a limit on the tile count)
     extern __shared__ float s_zbc[];      // a.zbc_lds floats: the superblock bounds (0: read them from global memory)
     const int tid = threadIdx.x;
-    if (a.tile_order != nullptr && blockIdx.x == 0) {      // (before the poison test: the order must be a permutation whatever happens)
+    if (a.tile_order[0] != nullptr && blockIdx.x < 2) {      // (before the poison test: the orders must be permutations whatever happens)
         __shared__ uint32_t s_cls[GSR_BLOCK];
-        tile_order_from_work(a.tile_work, a.tile_order, a.order_tiles, s_cls);
+        tile_order_from_work(a.tile_work[blockIdx.x], a.tile_order[blockIdx.x], a.order_tiles, s_cls);
     }
     if (a.guard.poisoned()) return;
     GSR_T_DECL
@@ -1049,7 +1050,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
                                                           int* __restrict__ n_touched, float* __restrict__ zb_next,
                                                           const float* __restrict__ zb_used, uint32_t* __restrict__ fail,
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
-                                                          int sbx, FusedLoss fl, const uint32_t* __restrict__ tile_order)
+                                                          int sbx, FusedLoss fl, const uint32_t* __restrict__ tile_order,
+                                                          uint32_t* __restrict__ tile_work)
 {
     // (tile_cursor: GSR_LIST_BINS the per-tile append cursors; GSR_LIST_EXACT the tile_offset array of k_tile_scan)
     __shared__ SplatLDS s;
@@ -1078,6 +1080,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
         range.y = tile_cursor[tile + 1];
     } else range = ranges[tile];
     const int total = (int)(range.y - range.x);
+    int walked = 0, overhead = 0;      // -> tile_work: groups of eight this wave composited; staging / ordering cost in the same unit
 
     if (LIST == GSR_LIST_BINS) {
         // this tile's bin arrives unsorted: order it by (depth bits, index) in LDS (bitonic network), keep it there
@@ -1094,6 +1097,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
         GSR_T_TICK(0)
         lds_bitonic_sort(s_keys, npow);
         for (int i = tid; i < total; i += GSR_BLOCK) point_list[range.x + i] = (uint32_t)s_keys[i];
+        // (measured: a compare-exchange step of the network costs about a seventh of a group of eight composited entries,
+        // twice / four times that above 512 / 1024 keys)
+        const int lg = 31 - __builtin_clz((unsigned)npow);
+        overhead += (lg * (lg + 1) / 2) * max(1, npow >> 9) / 7;
     }
     GSR_T_TICK(1)
     // T > 0: still compositing.  T <= 0: finished (or outside the image); the pixel's transmittance is -T.  With a
@@ -1144,6 +1151,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
         GSR_T_TICK(2)
         GSR_T_COUNT(10, 1)
         const int n = min(GSR_BLOCK, m - base);
+        overhead += 3;
         if (tid < n) {
             const uint32_t id = (LIST != GSR_LIST_SORTED) ? (uint32_t)s_keys[base + tid] : point_list[range.x + base + tid];
             const float2 m = xy[id];
@@ -1168,6 +1176,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
         const int full = cnt & ~7;
         for (int g0 = 0; g0 < full; g0 += 8) {
             if (__all(T <= 0.f)) break;                // whole wave finished: stop early
+            walked++;
             GSR_T_COUNT(11, 8)
             const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(&s.list[wv][g0]);
             const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)packed);
@@ -1251,6 +1260,12 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
     // these lists (n_touched) can need: no pixel looks beyond the slice in which the last one terminated
     if (LIST == GSR_LIST_EXACT && tid == 0) ranges[tile] = make_uint2(range.x, range.x + (uint32_t)min(consumed, total));
     GSR_T_TICK(6)
+    if (tile_work != nullptr) {      // this tile's weight in the next iteration's launch order
+        __shared__ int s_walk[4];
+        if (lane == 0) s_walk[wv] = walked;
+        __syncthreads();
+        if (tid == 0) tile_work[tile] = (uint32_t)(max(max(s_walk[0], s_walk[1]), max(s_walk[2], s_walk[3])) + 1 + overhead);
+    }
     const bool done = (T <= 0.f);
     const float T_out = fabsf(T);
     if (zb_next != nullptr) {
