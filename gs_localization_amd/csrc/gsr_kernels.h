@@ -1373,6 +1373,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
 // being branched around.  alpha is recomputed with K6's expression (pre-scaled conic, v_exp_f32), bit for bit.
 // ---------------------------------------------------------------------------------------------
 typedef float gsr_f32x4 __attribute__((ext_vector_type(4)));
+template <bool B> struct BoolTag { static constexpr bool value = B; };
 #define GSR_WT_STRIDE 17
 // Weight transposition for the contraction.  A pixel lane p produces 16 values per group of eight splats (row m = 2 * splat +
 // {0: W1, 1: W2}); the MFMA's A operand wants lane (k = lane / 16, m = lane % 16) to hold row m of pixel 4 t + k for the steps
@@ -1466,7 +1467,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
     const int total = max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3]));
     const int wave_max = s.wmax[wv];
 
-    float av = 0.f, lv = 0.f, last_alpha = 0.f;      // the "composited behind me" recurrence, see the loop body
+    float av = 0.f, lv = 0.f, last_alpha = 0.f, om_last = 1.f;      // the "composited behind me" recurrence, see the loop body (om_last = 1 - last_alpha)
+    const bool simple = __all(dLa == 0.f && nTf_bg == 0.f) != 0;
     int walked = 0;                                  // groups of eight list entries this wave has gone through (-> tile_work)
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
     const int arow = (lane >> 4), acol = (lane & 15);
@@ -1522,6 +1524,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(&s.list[wv][g0]);
             const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)packed);
             const uint32_t phi = __builtin_amdgcn_readfirstlane((uint32_t)(packed >> 32));
+            // (SIMPLE: no gradient arrives through the opacity image and the background term vanishes for every pixel of the
+            // wave -- the tracking loss over a black background, i.e. the native loop: four vector instructions less per entry)
+            auto bodies = [&](auto simple_tag) {
+            constexpr bool SIMPLE = decltype(simple_tag)::value;
 #pragma unroll
             for (int sidx = 0; sidx < 8; sidx++) {
                 float w1 = 0.f, w2 = 0.f;
@@ -1538,7 +1544,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                     const float alpha = fminf(0.99f, B.y * G);
                     const bool valid = (contributor <= last_contributor) && !(alpha < 1.0f / 255.0f) && !(p2 > 0.0f);
                     const float ae = valid ? alpha : 0.f;          // skipped => transparent: every update below is the identity
-                    const float r1ma = __builtin_amdgcn_rcpf(1.f - ae);
+                    const float om = 1.f - ae;
+                    const float r1ma = __builtin_amdgcn_rcpf(om);
                     T = T * r1ma;
                     w1 = ae * T;
                     // backward.cu:520-547 keeps four "composited behind me" recurrences (r, g, b, depth) plus the
@@ -1547,16 +1554,20 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                     //     v = c . dL/dpix + depth * dL/ddepth - dL/dalpha
                     // carries the same information:  sum_ch (value_ch - X_ch) dL_ch - (alpha - A) dL/dalpha
                     //                              = (v - V) + (1 - alpha) dL/dalpha
-                    const float v = __builtin_fmaf(Cc.w, dLd, __builtin_fmaf(Cc.z, dpz, __builtin_fmaf(Cc.y, dpy, Cc.x * dpx))) - dLa;
-                    av = __builtin_fmaf(last_alpha, lv, (1.f - last_alpha) * av);
-                    float dL_dopa = __builtin_fmaf(1.f - ae, dLa, v - av);
-                    dL_dopa = __builtin_fmaf(dL_dopa, T, nTf_bg * r1ma);
+                    const float vc = __builtin_fmaf(Cc.w, dLd, __builtin_fmaf(Cc.z, dpz, __builtin_fmaf(Cc.y, dpy, Cc.x * dpx)));
+                    const float v = SIMPLE ? vc : vc - dLa;
+                    av = __builtin_fmaf(last_alpha, lv, om_last * av);
+                    float dL_dopa;
+                    if (SIMPLE) dL_dopa = (v - av) * T;
+                    else dL_dopa = __builtin_fmaf(__builtin_fmaf(om, dLa, v - av), T, nTf_bg * r1ma);
                     w2 = valid ? G * dL_dopa : 0.f;
-                    lv = v; last_alpha = ae;
+                    lv = v; last_alpha = ae; om_last = om;
                 }
                 wt[wbase[sidx >> 1] + 16 * (2 * sidx)] = w1;
                 wt[wbase[sidx >> 1] + 16 * (2 * sidx + 1)] = w2;
             }
+            };
+            if (simple) bodies(BoolTag<true>{}); else bodies(BoolTag<false>{});
             GSR_T_TICK(4)
             // S[16 rows = {W1,W2} x 8 splats][16 cols] += W[rows][4 pixels] * g[4 pixels][cols], 16 steps
             // (two accumulators: the 16x16x4 f32 MFMA issues every 32 cycles but a dependent one waits 40)
