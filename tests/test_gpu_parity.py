@@ -332,3 +332,22 @@ def test_lazy_slice_ordering_of_long_tile_lists(case):
                 assert U.rel_l1(g["tau"], go["tau"]) <= 1e-4
     finally:
         O.set_accumulate_double(False)
+
+
+@pytest.mark.parametrize("pose", [False, True])
+def test_work_lists_with_clustered_survivors(pose):
+    """k_preprocess appends the Gaussians that reach a tile to 64 sub-lists by workgroup (SurvLists); SH colour and the
+    per-Gaussian chain rule walk those lists.  Here everything visible sits in one run of indices -- a handful of sub-lists
+    take all survivors, the others stay empty -- and P is neither a multiple of the workgroup size nor of the list count."""
+    sc = S.small(P=40037, W=96, H=80, sh_degree=3, seed=21, scale_med=0.05)
+    hidden = np.ones(sc.P, bool)
+    hidden[1000:3300] = False
+    sc.means3D[hidden] = np.array([0.0, 0.0, -8.0], np.float32)          # behind the camera
+    cam = U.scene_inputs(sc, W2C)
+    grads = U.random_grads(sc, seed=21)
+    f, go = U.oracle_run(sc, cam, grads, pose=pose)
+    o, g = U.hip_run(sc, cam, grads, pose=pose)
+    assert 0 < (f.radii > 0).sum() <= 2300
+    _check_forward(o, f, pose)
+    _check_grads(g, go, pose, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
+    assert not np.any(g["sh"][hidden]) and not np.any(g["means3D"][hidden])

@@ -455,3 +455,24 @@ def test_converged_exit_with_an_overflowing_speculative_bin_returns_a_verified_r
     assert int((fr.radii != pkg["radii"]).sum()) <= 2
     nt = pkg["n_touched"]
     assert int((fr.n_touched - nt).abs().sum()) <= max(4, int(2e-3 * int(nt.sum())))
+
+
+def test_work_balanced_tile_order_changes_nothing(monkeypatch):
+    """The native loop launches the compositing kernels in a per-iteration tile order sorted by the work the previous
+    iteration measured (tile_order_from_work).  Any permutation of the tiles is correct: same poses and images with the
+    ordering switched off (GSR_NO_BALANCE, read by gsr_refine on every call), up to the order of the fp32 atomics."""
+    from tests import replay as PL
+    sc = S.small(P=60000, W=208, H=160, sh_degree=2, seed=12, scale_med=0.04)      # 13 x 10 tiles, a ragged last row of blocks
+    model, bg, view, init = _setup(sc, seed=4)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    out = {}
+    for name in ("balanced", "plain"):
+        if name == "plain":
+            monkeypatch.setenv("GSR_NO_BALANCE", "1")
+        R, T, info = fr.refine(view(), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=10, stop_on_converged=False)
+        out[name] = (R.clone(), T.clone(), fr.color.clone(), fr.depth.clone(), info)
+    monkeypatch.delenv("GSR_NO_BALANCE")
+    (R1, T1, c1, d1, i1), (R2, T2, c2, d2, i2) = out["balanced"], out["plain"]
+    assert i1["fallbacks"] == 0 and i2["fallbacks"] == 0
+    assert torch.allclose(R1, R2, atol=2e-6) and torch.allclose(T1, T2, atol=2e-6)
+    assert torch.allclose(c1, c2, atol=5e-4) and torch.allclose(d1, d2, atol=5e-3)
