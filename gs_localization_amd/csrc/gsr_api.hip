@@ -105,6 +105,7 @@ struct Geom {   // per-Gaussian state carried from forward to backward
     float* depths; float2* xy; float4* conic_op; float* rgb; float* cov3D; uint8_t* clamped;
     uint32_t* tiles_touched; ushort4* rects; float* acc; double* tau_acc; uint8_t* dirty;
     gsr::SurvLists surv;      // work lists of the forward's survivors (k_preprocess -> k_sh_color, k_preprocess_bwd)
+    float* rec;               // packed splat records (GSR_REC_*), P + 1
 };
 size_t carve_geom(char* base, int P, Geom& g)
 {
@@ -121,6 +122,7 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.acc = c.take<float>(GSR_ACC_STRIDE * n);
     g.dirty = c.take<uint8_t>(n);
     g.tau_acc = c.take<double>(8 * GSR_TAU_SLOTS);
+    g.rec = c.take<float>((n + 1) * GSR_REC_STRIDE);
     g.surv.cap = gsr::surv_cap(P);
     g.surv.n = c.take<uint32_t>((size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE);
     g.surv.ids = c.take<uint32_t>((size_t)GSR_SURV_LISTS * g.surv.cap);
@@ -507,6 +509,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     pa.guard = cx.guard;
     pa.n_touched = n_touched;
     pa.surv = g.surv;
+    pa.rec = g.rec;
     const bool balanced = cx.balance && cx.native_loop && ntiles <= GSR_ORDER_MAX_TILES && !sp.state;
     for (int k = 0; k < 2; k++) { pa.tile_work[k] = balanced ? im.tile_work[k] : nullptr; pa.tile_order[k] = balanced ? im.tile_order[k] : nullptr; }
     pa.order_tiles = ntiles;
@@ -734,8 +737,8 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         const bool balanced = cx.balance && cx.native_loop && ntiles <= GSR_ORDER_MAX_TILES;
         const uint32_t* order = balanced ? im.tile_order[1] : nullptr;
         uint32_t* work = balanced ? im.tile_work[1] : nullptr;
-        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work);
-        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work);
+        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P);
+        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P);
 #undef GSR_BWD_ARGS
     }
     LAUNCHCHK("k_render_bwd");

@@ -181,6 +181,17 @@ __device__ __forceinline__ void zero_grad_rows(const GradRows& r, size_t idx, bo
         for (int i = 0; i < r.M * 3; i++) r.sh[idx * r.M * 3 + i] = 0.f;
 }
 
+// Packed per-Gaussian splat record (GSR_REC_STRIDE floats), everything the backward compositing walk needs per list entry:
+//   0 x  1 y  2 B2  3 C2  4 A2  5 opacity  6 r  7 g  8 b  9 depth   (A2, B2, C2: the conic pre-multiplied as in SplatLDS)
+// written by k_preprocess (geometry) and k_sh_color (colour) and read by K7 with SCALAR loads: a list entry is the same for all
+// 64 lanes of a wave, so its record belongs in scalar registers -- 40 B per wave through the scalar cache instead of
+// 40 B x 64 lanes through the LDS pipe, which K7 kept 65 % busy with exactly that.  Record P is the null splat (all zero).
+#define GSR_REC_STRIDE 12
+#define GSR_LOG2E 1.4426950408889634f
+#define GSR_CONST_AS __attribute__((address_space(4)))
+typedef float gsr_sf8 __attribute__((ext_vector_type(8)));
+typedef float gsr_sf2 __attribute__((ext_vector_type(2)));
+
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
     uint32_t* tile_count; int ntiles;      // exact-bin path: ntiles counter words (all copies) zeroed here for k_tile_count (nullable)
@@ -198,6 +209,7 @@ struct PreArgs {
     const float* view; const float* proj; const float* campos;
     float tanx, tany, fx, fy;
     int* radii; float2* xy; float* depths; float* cov3D; float* rgb; float4* conic_op;
+    float* rec;              // packed splat records for the backward compositing walk (GSR_REC_*), P + 1 of them
     uint8_t* clamped; uint32_t* tiles_touched; ushort4* rects;
     int cov_all;             // k_preprocess: compute and store cov3D for every Gaussian, culled or not (see there)
     SurvLists surv;          // work lists: k_preprocess appends, k_sh_color walks (ids nullable: no lists kept)
@@ -330,6 +342,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     float zv = 0.f;
     uint32_t cnt = 0;
 
+    if (idx == 0) {      // the null splat
+        float4* nr = reinterpret_cast<float4*>(a.rec + (size_t)a.P * GSR_REC_STRIDE);
+        nr[0] = make_float4(0.f, 0.f, 0.f, 0.f); nr[1] = nr[0]; nr[2] = nr[0];
+    }
     if (live) {
         a.radii[idx] = 0;
         a.tiles_touched[idx] = 0;
@@ -415,6 +431,13 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                     a.radii[idx] = (int)my_radius;
                     a.xy[idx] = pix;
                     a.conic_op[idx] = make_float4(conic.x, conic.y, conic.z, opacity);
+                    {
+                        float* rec = a.rec + (size_t)idx * GSR_REC_STRIDE;
+                        *reinterpret_cast<float4*>(rec) = make_float4(pix.x, pix.y, (-GSR_LOG2E) * conic.y, (-0.5f * GSR_LOG2E) * conic.z);
+                        *reinterpret_cast<float2*>(rec + 4) = make_float2((-0.5f * GSR_LOG2E) * conic.x, opacity);
+                        rec[9] = pview.z;
+                        if (a.colors_pre != nullptr) { rec[6] = a.colors_pre[3 * idx]; rec[7] = a.colors_pre[3 * idx + 1]; rec[8] = a.colors_pre[3 * idx + 2]; }
+                    }
                     a.rects[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
                     // exact count of tiles this splat can change
                     tt = make_tile_test(pix, conic, opacity);
@@ -571,6 +594,8 @@ __global__ void __launch_bounds__(64) k_sh_color(PreArgs a)
             const float3 c = staged ? sh_to_rgb(a.D, 16, p, a.campos, reinterpret_cast<const float*>(&s_sh[lane * GSR_SH16_LDS4]), cb)
                                     : sh_to_rgb(a.D, a.M, p, a.campos, a.shs + (size_t)idx * a.M * 3, cb);
             a.rgb[3 * idx] = c.x; a.rgb[3 * idx + 1] = c.y; a.rgb[3 * idx + 2] = c.z;
+            float* rec = a.rec + (size_t)idx * GSR_REC_STRIDE;
+            rec[6] = c.x; rec[7] = c.y; rec[8] = c.z;
             a.clamped[idx] = cb;
         }
         __syncthreads();
@@ -895,7 +920,6 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
     return m;
 }
 
-#define GSR_LOG2E 1.4426950408889634f
 // The inner loop is shaped by one fact: a tile's walk is a long dependent chain and a wave issues at most one
 // instruction every four cycles, VALU or scalar, so the kernel's duration is (list length) x (instructions per
 // list entry) -- not bytes, not flops.
@@ -1388,12 +1412,13 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 // splats staged per batch: 128 keeps the workgroup at ~31 KB of LDS = 5 workgroups per CU
 #define GSR_BWD_BATCH 128
 struct BwdMfmaLDS {
-    // (slot GSR_BWD_BATCH of a, b, c, acc is the NULL splat -- opacity 0, so alpha = 0 and every update of the walk is the
+    // (record P / slot GSR_BWD_BATCH of acc is the NULL splat -- opacity 0, so alpha = 0 and every update of the walk is the
     // identity -- that pads a wave's list to a multiple of eight: the bodies of a group then need no "is there an entry" test)
-    float4 a[GSR_BWD_BATCH + 1];        // x, y, B2, C2 (pre-scaled conic and field order as in K6's SplatLDS)
-    float4 b[GSR_BWD_BATCH + 1];        // A2, opacity | id (bits), quadrant mask (bits)
-    float4 c[GSR_BWD_BATCH + 1];        // r, g, b, depth
-    float4 d[GSR_BWD_BATCH];            // conic a, b, c as stored (for the recombination), unused
+    // (what the WALK reads per entry comes from the packed records in global memory through scalar loads, GSR_REC_*; these
+    // staged copies serve the per-batch recombination only)
+    float4 a[GSR_BWD_BATCH];            // x, y, opacity, id (bits)
+    float4 d[GSR_BWD_BATCH];            // conic a, b, c as stored, quadrant mask (bits)
+    uint32_t off[4][GSR_BWD_BATCH];     // per wave: record offsets (floats) of its list entries, same order as `list`
     float acc[GSR_BWD_BATCH + 1][10];   // per staged splat: 0-3 = sum W1 (dpx,dpy,dpz,dLd), 4-9 = W2 moments
     // per wave: the weight transposition buffer of the contraction, see GSR_WT_REGION (before the walk: [pixel][17] scratch
     // for the B operands, the same 1088 floats)
@@ -1412,9 +1437,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                                                                const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
                                                                const float* __restrict__ dL_dalphas, float* __restrict__ acc,
                                                                LoopGuard guard, const uint32_t* __restrict__ tile_order,
-                                                               uint32_t* __restrict__ tile_work)
+                                                               uint32_t* __restrict__ tile_work, const float* __restrict__ rec, int P)
 {
     __shared__ BwdMfmaLDS s;
+    const GSR_CONST_AS float* crec = (const GSR_CONST_AS float*)rec;      // (constant address space + wave-uniform offsets: s_load)
     if (guard.frozen()) return;
     GSR_T_DECL
     const int tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_remap(blockIdx.x, ntiles);
@@ -1458,11 +1484,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
     if (lane == 0) s.wmax[wv] = m;
-    if (tid == 0) {
-        s.a[GSR_BWD_BATCH] = make_float4(0.f, 0.f, 0.f, 0.f); s.b[GSR_BWD_BATCH] = s.a[GSR_BWD_BATCH]; s.c[GSR_BWD_BATCH] = s.a[GSR_BWD_BATCH];
-#pragma unroll
-        for (int q = 0; q < 10; q++) s.acc[GSR_BWD_BATCH][q] = 0.f;
-    }
+    if (tid < 10) s.acc[GSR_BWD_BATCH][tid] = 0.f;
     __syncthreads();
     const int total = max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3]));
     const int wave_max = s.wmax[wv];
@@ -1494,10 +1516,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             const float2 mm = xy[id];
             const float4 co = conic_op[id];
             const uint32_t qm = quadrant_mask(mm.x, mm.y, co.x, co.y, co.z, co.w, tx * GSR_TILE, ty * GSR_TILE);
-            s.a[tid] = make_float4(mm.x, mm.y, (-GSR_LOG2E) * co.y, (-0.5f * GSR_LOG2E) * co.z);
-            s.b[tid] = make_float4((-0.5f * GSR_LOG2E) * co.x, co.w, __uint_as_float(id), __uint_as_float(qm));
-            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], depths[id]);
-            s.d[tid] = make_float4(co.x, co.y, co.z, 0.f);
+            s.a[tid] = make_float4(mm.x, mm.y, co.w, __uint_as_float(id));
+            s.d[tid] = make_float4(co.x, co.y, co.z, __uint_as_float(qm));
         }
         if (tid < GSR_BWD_BATCH) {
 #pragma unroll
@@ -1508,13 +1528,20 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         int cnt = 0;
         for (int c0 = 0; c0 < n; c0 += 64) {
             const int jj = c0 + lane;
-            const bool hit = jj < n && ((__float_as_uint(s.b[min(jj, GSR_BWD_BATCH - 1)].w) >> wv) & 1u) &&
+            const bool hit = jj < n && ((__float_as_uint(s.d[min(jj, GSR_BWD_BATCH - 1)].w) >> wv) & 1u) &&
                              (total - base - jj) <= wave_max;
             const unsigned long long mk = __ballot(hit);
-            if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
+            if (hit) {
+                const int at = cnt + (int)__popcll(mk & ((1ull << lane) - 1ull));
+                s.list[wv][at] = (uint8_t)jj;
+                s.off[wv][at] = __float_as_uint(s.a[jj].w) * GSR_REC_STRIDE;
+            }
             cnt += (int)__popcll(mk);
         }
-        if (lane < ((8 - (cnt & 7)) & 7)) s.list[wv][cnt + lane] = (uint8_t)GSR_BWD_BATCH;      // pad to a multiple of eight with the null splat
+        if (lane < ((8 - (cnt & 7)) & 7)) {      // pad to a multiple of eight with the null splat
+            s.list[wv][cnt + lane] = (uint8_t)GSR_BWD_BATCH;
+            s.off[wv][cnt + lane] = (uint32_t)P * GSR_REC_STRIDE;
+        }
         walked += (cnt + 7) >> 3;
         GSR_T_TICK(3)
         GSR_T_COUNT(11, cnt)
@@ -1524,24 +1551,38 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(&s.list[wv][g0]);
             const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)packed);
             const uint32_t phi = __builtin_amdgcn_readfirstlane((uint32_t)(packed >> 32));
+            const uint4 o03 = *reinterpret_cast<const uint4*>(&s.off[wv][g0]), o47 = *reinterpret_cast<const uint4*>(&s.off[wv][g0 + 4]);
+#define GSR_RFL(v) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(v)))
+            const uint32_t offs[8] = {GSR_RFL(o03.x), GSR_RFL(o03.y), GSR_RFL(o03.z), GSR_RFL(o03.w), GSR_RFL(o47.x), GSR_RFL(o47.y), GSR_RFL(o47.z), GSR_RFL(o47.w)};
+#undef GSR_RFL
             // (SIMPLE: no gradient arrives through the opacity image and the background term vanishes for every pixel of the
             // wave -- the tracking loss over a black background, i.e. the native loop: four vector instructions less per entry)
             auto bodies = [&](auto simple_tag) {
             constexpr bool SIMPLE = decltype(simple_tag)::value;
+            // The entry's record: x y B2 C2 A2 opacity r g | b depth, wave-uniform address: scalar loads.  Scalar loads return
+            // out of order, so the only wait there is for them is "all of them": the NEXT entry's record is requested right
+            // after this entry's first use of its own (nothing else in flight at that point) and has the rest of the body to arrive.
+            gsr_sf8 n8 = *reinterpret_cast<const GSR_CONST_AS gsr_sf8*>(crec + offs[0]);
+            gsr_sf2 n2 = *reinterpret_cast<const GSR_CONST_AS gsr_sf2*>(crec + offs[0] + 8);
 #pragma unroll
             for (int sidx = 0; sidx < 8; sidx++) {
                 float w1 = 0.f, w2 = 0.f;
                 {
                     const int j = (int)(((sidx < 4 ? plo : phi) >> (8 * (sidx & 3))) & 0xFFu);
                     const int contributor = total - base - j;
-                    const float4 A = s.a[j];
-                    const float2 B = *reinterpret_cast<const float2*>(&s.b[j]);
-                    const float4 Cc = s.c[j];
-                    const gsr_f32x2 d = (gsr_f32x2){A.x, A.y} - pxy;                      // as K6, bit for bit
-                    const gsr_f32x2 tu = (gsr_f32x2){A.z, A.w} * (gsr_f32x2){d.y, d.y};
-                    const float p2 = __builtin_fmaf(d.x, __builtin_fmaf(B.x, d.x, tu.x), tu.y * d.y);
+                    const gsr_sf8 r8 = n8;
+                    const gsr_sf2 r2 = n2;
+                    const gsr_f32x2 d = (gsr_f32x2){r8[0], r8[1]} - pxy;                  // as K6, bit for bit
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (sidx < 7) {
+                        n8 = *reinterpret_cast<const GSR_CONST_AS gsr_sf8*>(crec + offs[sidx + 1]);
+                        n2 = *reinterpret_cast<const GSR_CONST_AS gsr_sf2*>(crec + offs[sidx + 1] + 8);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    const gsr_f32x2 tu = (gsr_f32x2){r8[2], r8[3]} * (gsr_f32x2){d.y, d.y};
+                    const float p2 = __builtin_fmaf(d.x, __builtin_fmaf(r8[4], d.x, tu.x), tu.y * d.y);
                     const float G = __builtin_amdgcn_exp2f(p2);
-                    const float alpha = fminf(0.99f, B.y * G);
+                    const float alpha = fminf(0.99f, r8[5] * G);
                     const bool valid = (contributor <= last_contributor) && !(alpha < 1.0f / 255.0f) && !(p2 > 0.0f);
                     const float ae = valid ? alpha : 0.f;          // skipped => transparent: every update below is the identity
                     const float om = 1.f - ae;
@@ -1554,7 +1595,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                     //     v = c . dL/dpix + depth * dL/ddepth - dL/dalpha
                     // carries the same information:  sum_ch (value_ch - X_ch) dL_ch - (alpha - A) dL/dalpha
                     //                              = (v - V) + (1 - alpha) dL/dalpha
-                    const float vc = __builtin_fmaf(Cc.w, dLd, __builtin_fmaf(Cc.z, dpz, __builtin_fmaf(Cc.y, dpy, Cc.x * dpx)));
+                    const float vc = __builtin_fmaf(r2[1], dLd, __builtin_fmaf(r2[0], dpz, __builtin_fmaf(r8[7], dpy, r8[6] * dpx)));
                     const float v = SIMPLE ? vc : vc - dLa;
                     av = __builtin_fmaf(last_alpha, lv, om_last * av);
                     float dL_dopa;
@@ -1599,7 +1640,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             const float dz = q[3];
             const float4 A = s.a[tid];
             const float4 Dc = s.d[tid];
-            const float mu = A.x - cx0, mv = A.y - cy0, ca = Dc.x, cb = Dc.y, cc = Dc.z, o = s.b[tid].y;
+            const float mu = A.x - cx0, mv = A.y - cy0, ca = Dc.x, cb = Dc.y, cc = Dc.z, o = A.z;
             const float sdx = mu * M0 - Mu, sdy = mv * M0 - Mv;
             const float sxx = mu * mu * M0 - 2.f * mu * Mu + Muu;
             const float sxy = mu * mv * M0 - mu * Mv - mv * Mu + Muv;
@@ -1618,7 +1659,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         for (int e = tid; e < n * 10; e += GSR_BLOCK) {
             const int j = e / 10, q = e - j * 10;
             const float val = s.acc[j][q];
-            if (val != 0.f && (POSE || q != 9)) atomicAdd(&acc[(size_t)__float_as_uint(s.b[j].z) * GSR_ACC_STRIDE + q], val);
+            if (val != 0.f && (POSE || q != 9)) atomicAdd(&acc[(size_t)__float_as_uint(s.a[j].w) * GSR_ACC_STRIDE + q], val);
         }
         GSR_T_TICK(8)
     }
