@@ -102,7 +102,7 @@ struct Carver {
 };
 
 struct Geom {   // per-Gaussian state carried from forward to backward
-    float* depths; float2* xy; float4* conic_op; float* rgb; float* cov3D; uint8_t* clamped;
+    float* cov3D; uint8_t* clamped;
     uint32_t* tiles_touched; ushort4* rects; float* acc; double* tau_acc; uint8_t* dirty;
     gsr::SurvLists surv;      // work lists of the forward's survivors (k_preprocess -> k_sh_color, k_preprocess_bwd)
     float* rec;               // packed splat records (GSR_REC_*), P + 1
@@ -111,10 +111,6 @@ size_t carve_geom(char* base, int P, Geom& g)
 {
     Carver c(base);
     const size_t n = P > 0 ? (size_t)P : 1;
-    g.depths = c.take<float>(n);
-    g.xy = c.take<float2>(n);
-    g.conic_op = c.take<float4>(n);
-    g.rgb = c.take<float>(3 * n);
     g.cov3D = c.take<float>(6 * n);
     g.clamped = c.take<uint8_t>(n);
     g.tiles_touched = c.take<uint32_t>(n);
@@ -504,7 +500,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     if (cx.cov_cache == 2 && cov3D_precomp == nullptr) pa.cov3D_pre = g.cov3D;
     pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos;
     pa.tanx = tan_fovx; pa.tany = tan_fovy; pa.fx = focal_x; pa.fy = focal_y;
-    pa.radii = radii; pa.xy = g.xy; pa.depths = g.depths; pa.cov3D = g.cov3D; pa.rgb = g.rgb; pa.conic_op = g.conic_op;
+    pa.radii = radii; pa.cov3D = g.cov3D;
     pa.clamped = g.clamped; pa.tiles_touched = g.tiles_touched; pa.rects = g.rects;
     pa.guard = cx.guard;
     pa.n_touched = n_touched;
@@ -580,7 +576,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     if (!by_tile) {
         TileBinArgs ta;
         ta.P = P; ta.gx = gx; ta.gy = gy; ta.ntiles = ntiles; ta.gpb = tile_bin_gpb(P);
-        ta.tiles_touched = g.tiles_touched; ta.rects = g.rects; ta.xy = g.xy; ta.conic_op = g.conic_op; ta.depths = g.depths;
+        ta.tiles_touched = g.tiles_touched; ta.rects = g.rects; ta.rec = g.rec;
         ta.tile_count = im.tile_count; ta.tile_start = im.tile_start; ta.tile_offset = im.tile_offset; ta.tile_fill = im.tile_fill; ta.keys = nullptr;
         ta.block_counts = im.block_counts; ta.copies = im.copies;
         const int tblocks = (P + ta.gpb - 1) / ta.gpb;
@@ -626,13 +622,11 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         }
         LAUNCHCHK("k_tile_emit");
     }
-    const float* feat = colors_precomp ? colors_precomp : g.rgb;
     if (side) HIPCHK(hipStreamWaitEvent(st, side->join, 0));
     {
         ProfScope psr(K_RENDER_FWD, st);
 #define GSR_FWD_ARGS im.ranges, by_tile ? bl.vals : b.vals, by_tile ? (const unsigned long long*)bl.bins : (const unsigned long long*)b.keys, \
-                     by_tile ? im.tile_cursor : im.tile_offset, width, height, gx, ntiles, (const float2*)g.xy, feat, \
-                     (const float*)g.depths, (const float4*)g.conic_op, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
+                     by_tile ? im.tile_cursor : im.tile_offset, width, height, gx, ntiles, (const float*)g.rec, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
                      zb_next, zb_prev, cx.guard.poison ? const_cast<uint32_t*>(cx.guard.poison) : im.fail, \
                      sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], balanced ? im.tile_work[0] : (uint32_t*)nullptr
         if (by_tile) {
@@ -728,11 +722,9 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
         if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));
     }
-    const float* color_ptr = colors_precomp ? colors_precomp : g.rgb;
     {
         ProfScope psb(K_RENDER_BWD, st);
-#define GSR_BWD_ARGS (const uint2*)im.ranges, point_list, width, height, gx, ntiles, background, (const float2*)g.xy, \
-                     (const float4*)g.conic_op, color_ptr, (const float*)g.depths, alphas, (const uint32_t*)im.n_contrib, dL_dpix, \
+#define GSR_BWD_ARGS (const uint2*)im.ranges, point_list, width, height, gx, ntiles, background, alphas, (const uint32_t*)im.n_contrib, dL_dpix, \
                      dL_ddepths, dL_dalphas, g.acc
         const bool balanced = cx.balance && cx.native_loop && ntiles <= GSR_ORDER_MAX_TILES;
         const uint32_t* order = balanced ? im.tile_order[1] : nullptr;
@@ -749,7 +741,7 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     pb.means = means3D; pb.radii = radii; pb.shs = shs; pb.clamped = g.clamped;
     pb.scales = scales; pb.rots = rotations; pb.mod = scale_modifier;
     pb.cov3D = cov3D_precomp ? cov3D_precomp : g.cov3D;
-    pb.conic_op = g.conic_op;
+    pb.rec = g.rec;
     pb.view = viewmatrix; pb.proj = projmatrix; pb.campos = campos;
     pb.fx = focal_x; pb.fy = focal_y; pb.tanx = tan_fovx; pb.tany = tan_fovy;
     pb.acc = g.acc;
@@ -1144,8 +1136,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         HIPCHK(hipMemsetAsync(a->n_touched, 0, (size_t)a->P * sizeof(int), st));
         hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_SORTED>), dim3(gx * gy), dim3(GSR_BLOCK), 0, st, im.ranges,
                            reinterpret_cast<uint32_t*>(bb.ptr), (const unsigned long long*)nullptr, (uint32_t*)nullptr, a->width,
-                           a->height, gx, gx * gy, (const float2*)g.xy, (const float*)g.rgb, (const float*)g.depths,
-                           (const float4*)g.conic_op, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
+                           a->height, gx, gx * gy, (const float*)g.rec, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
                            a->n_touched, (float*)nullptr, (const float*)nullptr, im.fail, 1.f, 0.f, (float*)nullptr,
                            im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr);
         LAUNCHCHK("k_render_fwd (n_touched)");

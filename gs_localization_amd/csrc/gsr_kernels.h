@@ -181,16 +181,30 @@ __device__ __forceinline__ void zero_grad_rows(const GradRows& r, size_t idx, bo
         for (int i = 0; i < r.M * 3; i++) r.sh[idx * r.M * 3 + i] = 0.f;
 }
 
-// Packed per-Gaussian splat record (GSR_REC_STRIDE floats), everything the backward compositing walk needs per list entry:
-//   0 x  1 y  2 B2  3 C2  4 A2  5 opacity  6 r  7 g  8 b  9 depth   (A2, B2, C2: the conic pre-multiplied as in SplatLDS)
-// written by k_preprocess (geometry) and k_sh_color (colour) and read by K7 with SCALAR loads: a list entry is the same for all
-// 64 lanes of a wave, so its record belongs in scalar registers -- 40 B per wave through the scalar cache instead of
-// 40 B x 64 lanes through the LDS pipe, which K7 kept 65 % busy with exactly that.  Record P is the null splat (all zero).
+// Packed per-Gaussian splat record (GSR_REC_STRIDE floats = 48 B): the forward's whole per-Gaussian screen-space state,
+//   0 x  1 y  2 B2  3 C2 | 4 A2  5 opacity  6 depth  7 - | 8 r  9 g  10 b  11 -
+// with the conic (a, b, c) stored pre-multiplied for the exponent, A2 = -a/2 log2e, B2 = -b log2e, C2 = -c/2 log2e (see
+// k_render_fwd).  Written by k_preprocess (two 16-B stores; the colour too when it is precomputed) and k_sh_color (one);
+// gathered by the compositing kernels' staging, the exact-bin walks and the chain-rule kernel with 16-B loads of one
+// contiguous record (round 1 kept xy / conic / colour / depth in four arrays: four cache lines per gathered splat), and
+// read by K7's walk with SCALAR loads: a list entry is the same for all 64 lanes of a wave, so its record belongs in scalar
+// registers -- 48 B per wave through the scalar cache instead of 40 B x 64 lanes through the LDS pipe, which K7 kept 65 % busy
+// with exactly that.  Record P is the null splat (all zero).
 #define GSR_REC_STRIDE 12
 #define GSR_LOG2E 1.4426950408889634f
 #define GSR_CONST_AS __attribute__((address_space(4)))
 typedef float gsr_sf8 __attribute__((ext_vector_type(8)));
-typedef float gsr_sf2 __attribute__((ext_vector_type(2)));
+typedef float gsr_sf4 __attribute__((ext_vector_type(4)));
+struct SplatRec { float x, y, a, b, c, opacity, depth; };      // (a, b, c: the conic as stored, recovered from A2, B2, C2 to 1 ulp)
+__device__ __forceinline__ SplatRec load_splat_rec(const float* __restrict__ rec, uint32_t id)
+{
+    const float4* r = reinterpret_cast<const float4*>(rec + (size_t)id * GSR_REC_STRIDE);
+    const float4 r0 = r[0], r1 = r[1];
+    SplatRec o;
+    o.x = r0.x; o.y = r0.y; o.b = r0.z * (-1.0f / GSR_LOG2E); o.c = r0.w * (-2.0f / GSR_LOG2E); o.a = r1.x * (-2.0f / GSR_LOG2E);
+    o.opacity = r1.y; o.depth = r1.z;
+    return o;
+}
 
 struct PreArgs {
     int P, D, M, W, H, gx, gy;
@@ -208,8 +222,8 @@ struct PreArgs {
     const float* shs; const float* cov3D_pre; const float* colors_pre;
     const float* view; const float* proj; const float* campos;
     float tanx, tany, fx, fy;
-    int* radii; float2* xy; float* depths; float* cov3D; float* rgb; float4* conic_op;
-    float* rec;              // packed splat records for the backward compositing walk (GSR_REC_*), P + 1 of them
+    int* radii; float* cov3D;
+    float* rec;              // packed splat records (GSR_REC_*), P + 1 of them
     uint8_t* clamped; uint32_t* tiles_touched; ushort4* rects;
     int cov_all;             // k_preprocess: compute and store cov3D for every Gaussian, culled or not (see there)
     SurvLists surv;          // work lists: k_preprocess appends, k_sh_color walks (ids nullable: no lists kept)
@@ -427,16 +441,12 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                 if ((x1 - x0) * (y1 - y0) != 0) {
                     vis = true;
                     const float opacity = a.opac[idx];
-                    a.depths[idx] = pview.z;
                     a.radii[idx] = (int)my_radius;
-                    a.xy[idx] = pix;
-                    a.conic_op[idx] = make_float4(conic.x, conic.y, conic.z, opacity);
                     {
-                        float* rec = a.rec + (size_t)idx * GSR_REC_STRIDE;
-                        *reinterpret_cast<float4*>(rec) = make_float4(pix.x, pix.y, (-GSR_LOG2E) * conic.y, (-0.5f * GSR_LOG2E) * conic.z);
-                        *reinterpret_cast<float2*>(rec + 4) = make_float2((-0.5f * GSR_LOG2E) * conic.x, opacity);
-                        rec[9] = pview.z;
-                        if (a.colors_pre != nullptr) { rec[6] = a.colors_pre[3 * idx]; rec[7] = a.colors_pre[3 * idx + 1]; rec[8] = a.colors_pre[3 * idx + 2]; }
+                        float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * GSR_REC_STRIDE);
+                        rec[0] = make_float4(pix.x, pix.y, (-GSR_LOG2E) * conic.y, (-0.5f * GSR_LOG2E) * conic.z);
+                        rec[1] = make_float4((-0.5f * GSR_LOG2E) * conic.x, opacity, pview.z, 0.f);
+                        if (a.colors_pre != nullptr) rec[2] = make_float4(a.colors_pre[3 * idx], a.colors_pre[3 * idx + 1], a.colors_pre[3 * idx + 2], 0.f);
                     }
                     a.rects[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
                     // exact count of tiles this splat can change
@@ -593,9 +603,7 @@ __global__ void __launch_bounds__(64) k_sh_color(PreArgs a)
             uint8_t cb;
             const float3 c = staged ? sh_to_rgb(a.D, 16, p, a.campos, reinterpret_cast<const float*>(&s_sh[lane * GSR_SH16_LDS4]), cb)
                                     : sh_to_rgb(a.D, a.M, p, a.campos, a.shs + (size_t)idx * a.M * 3, cb);
-            a.rgb[3 * idx] = c.x; a.rgb[3 * idx + 1] = c.y; a.rgb[3 * idx + 2] = c.z;
-            float* rec = a.rec + (size_t)idx * GSR_REC_STRIDE;
-            rec[6] = c.x; rec[7] = c.y; rec[8] = c.z;
+            reinterpret_cast<float4*>(a.rec + (size_t)idx * GSR_REC_STRIDE)[2] = make_float4(c.x, c.y, c.z, 0.f);
             a.clamped[idx] = cb;
         }
         __syncthreads();
@@ -636,7 +644,7 @@ __global__ void __launch_bounds__(64) k_sh_color(PreArgs a)
 struct TileBinArgs {
     int P, gx, gy, ntiles, gpb;                    // gpb: Gaussians per workgroup (multiple of GSR_TBIN_THREADS)
     int copies;                                    // private copies of the per-tile counters (1 ... GSR_TBIN_COPIES)
-    const uint32_t* tiles_touched; const ushort4* rects; const float2* xy; const float4* conic_op; const float* depths;
+    const uint32_t* tiles_touched; const ushort4* rects; const float* rec;
     uint32_t* tile_count;                          // [copies][ntiles]: the count kernel adds into them
     const uint32_t* tile_start;                    // [copies][ntiles]: start of each copy's sub-range inside the tile's segment (scan -> emit)
     const uint32_t* tile_offset;                   // [ntiles + 1]   (emit)
@@ -678,13 +686,13 @@ __device__ __forceinline__ void walk_load(const TileBinArgs& a, int g0, WalkItem
         WalkItem w = {};
         if (g0 + k * GSR_TBIN_THREADS < a.gpb && idx < a.P && a.tiles_touched[idx] != 0u) {
             const ushort4 r = a.rects[idx];
-            const float4 co = a.conic_op[idx];
-            const TileTest tt = make_tile_test(a.xy[idx], make_float3(co.x, co.y, co.z), co.w);
+            const SplatRec sr = load_splat_rec(a.rec, (uint32_t)idx);
+            const TileTest tt = make_tile_test(make_float2(sr.x, sr.y), make_float3(sr.a, sr.b, sr.c), sr.opacity);
             w.x0 = r.x; w.y0 = r.y; w.x1 = r.z; w.y1 = r.w;
             clip_rect(tt, w.x0, w.y0, w.x1, w.y1);
             w.mx = tt.mx; w.my = tt.my; w.at = tt.A * tt.twoq; w.B = tt.B; w.det = tt.det; w.dye = tt.dye; w.invA = tt.invA;
             w.all = !tt.cull;
-            w.key = ((unsigned long long)__float_as_uint(a.depths[idx]) << 32) | (uint32_t)idx;
+            w.key = ((unsigned long long)__float_as_uint(sr.depth) << 32) | (uint32_t)idx;
         }
         it[k] = w;
     }
@@ -1066,9 +1074,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
                                                           const unsigned long long* __restrict__ bins,
                                                           uint32_t* __restrict__ tile_cursor,
                                                           int W, int H, int gx,
-                                                          int ntiles, const float2* __restrict__ xy,
-                                                          const float* __restrict__ rgb, const float* __restrict__ depths,
-                                                          const float4* __restrict__ conic_op, const float* __restrict__ bg,
+                                                          int ntiles, const float* __restrict__ rec, const float* __restrict__ bg,
                                                           float* __restrict__ out_color, float* __restrict__ out_depth,
                                                           float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
                                                           int* __restrict__ n_touched, float* __restrict__ zb_next,
@@ -1178,12 +1184,13 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
         overhead += 3;
         if (tid < n) {
             const uint32_t id = (LIST != GSR_LIST_SORTED) ? (uint32_t)s_keys[base + tid] : point_list[range.x + base + tid];
-            const float2 m = xy[id];
-            const float4 co = conic_op[id];
-            const uint32_t qm = quadrant_mask(m.x, m.y, co.x, co.y, co.z, co.w, tx * GSR_TILE, ty * GSR_TILE);
-            s.a[tid] = make_float4(m.x, m.y, (-GSR_LOG2E) * co.y, (-0.5f * GSR_LOG2E) * co.z);
-            s.b[tid] = make_float4((-0.5f * GSR_LOG2E) * co.x, co.w, __uint_as_float(id), __uint_as_float(qm));
-            s.c[tid] = make_float4(rgb[3 * id], rgb[3 * id + 1], rgb[3 * id + 2], depths[id]);
+            const float4* r = reinterpret_cast<const float4*>(rec + (size_t)id * GSR_REC_STRIDE);
+            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            const uint32_t qm = quadrant_mask(r0.x, r0.y, r1.x * (-2.0f / GSR_LOG2E), r0.z * (-1.0f / GSR_LOG2E), r0.w * (-2.0f / GSR_LOG2E), r1.y,
+                                              tx * GSR_TILE, ty * GSR_TILE);
+            s.a[tid] = r0;
+            s.b[tid] = make_float4(r1.x, r1.y, __uint_as_float(id), __uint_as_float(qm));
+            s.c[tid] = make_float4(r2.x, r2.y, r2.z, r1.z);
         }
         __syncthreads();
         GSR_T_TICK(3)
@@ -1431,8 +1438,6 @@ template <bool POSE>
 __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* __restrict__ ranges,
                                                                const uint32_t* __restrict__ point_list, int W, int H, int gx,
                                                                int ntiles, const float* __restrict__ bg,
-                                                               const float2* __restrict__ xy, const float4* __restrict__ conic_op,
-                                                               const float* __restrict__ rgb, const float* __restrict__ depths,
                                                                const float* __restrict__ alphas, const uint32_t* __restrict__ n_contrib,
                                                                const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
                                                                const float* __restrict__ dL_dalphas, float* __restrict__ acc,
@@ -1513,11 +1518,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         const int n = min(GSR_BWD_BATCH, total - base);
         if (tid < n) {
             const uint32_t id = point_list[range.x + (total - 1 - base - tid)];
-            const float2 mm = xy[id];
-            const float4 co = conic_op[id];
-            const uint32_t qm = quadrant_mask(mm.x, mm.y, co.x, co.y, co.z, co.w, tx * GSR_TILE, ty * GSR_TILE);
-            s.a[tid] = make_float4(mm.x, mm.y, co.w, __uint_as_float(id));
-            s.d[tid] = make_float4(co.x, co.y, co.z, __uint_as_float(qm));
+            const SplatRec sr = load_splat_rec(rec, id);
+            const uint32_t qm = quadrant_mask(sr.x, sr.y, sr.a, sr.b, sr.c, sr.opacity, tx * GSR_TILE, ty * GSR_TILE);
+            s.a[tid] = make_float4(sr.x, sr.y, sr.opacity, __uint_as_float(id));
+            s.d[tid] = make_float4(sr.a, sr.b, sr.c, __uint_as_float(qm));
         }
         if (tid < GSR_BWD_BATCH) {
 #pragma unroll
@@ -1559,11 +1563,11 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             // wave -- the tracking loss over a black background, i.e. the native loop: four vector instructions less per entry)
             auto bodies = [&](auto simple_tag) {
             constexpr bool SIMPLE = decltype(simple_tag)::value;
-            // The entry's record: x y B2 C2 A2 opacity r g | b depth, wave-uniform address: scalar loads.  Scalar loads return
+            // The entry's record: x y B2 C2 A2 opacity depth - | r g b -, wave-uniform address: scalar loads.  Scalar loads return
             // out of order, so the only wait there is for them is "all of them": the NEXT entry's record is requested right
             // after this entry's first use of its own (nothing else in flight at that point) and has the rest of the body to arrive.
             gsr_sf8 n8 = *reinterpret_cast<const GSR_CONST_AS gsr_sf8*>(crec + offs[0]);
-            gsr_sf2 n2 = *reinterpret_cast<const GSR_CONST_AS gsr_sf2*>(crec + offs[0] + 8);
+            gsr_sf4 n4 = *reinterpret_cast<const GSR_CONST_AS gsr_sf4*>(crec + offs[0] + 8);
 #pragma unroll
             for (int sidx = 0; sidx < 8; sidx++) {
                 float w1 = 0.f, w2 = 0.f;
@@ -1571,12 +1575,12 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                     const int j = (int)(((sidx < 4 ? plo : phi) >> (8 * (sidx & 3))) & 0xFFu);
                     const int contributor = total - base - j;
                     const gsr_sf8 r8 = n8;
-                    const gsr_sf2 r2 = n2;
+                    const gsr_sf4 r4 = n4;
                     const gsr_f32x2 d = (gsr_f32x2){r8[0], r8[1]} - pxy;                  // as K6, bit for bit
                     __builtin_amdgcn_sched_barrier(0);
                     if (sidx < 7) {
                         n8 = *reinterpret_cast<const GSR_CONST_AS gsr_sf8*>(crec + offs[sidx + 1]);
-                        n2 = *reinterpret_cast<const GSR_CONST_AS gsr_sf2*>(crec + offs[sidx + 1] + 8);
+                        n4 = *reinterpret_cast<const GSR_CONST_AS gsr_sf4*>(crec + offs[sidx + 1] + 8);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     const gsr_f32x2 tu = (gsr_f32x2){r8[2], r8[3]} * (gsr_f32x2){d.y, d.y};
@@ -1595,7 +1599,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                     //     v = c . dL/dpix + depth * dL/ddepth - dL/dalpha
                     // carries the same information:  sum_ch (value_ch - X_ch) dL_ch - (alpha - A) dL/dalpha
                     //                              = (v - V) + (1 - alpha) dL/dalpha
-                    const float vc = __builtin_fmaf(r2[1], dLd, __builtin_fmaf(r2[0], dpz, __builtin_fmaf(r8[7], dpy, r8[6] * dpx)));
+                    const float vc = __builtin_fmaf(r8[6], dLd, __builtin_fmaf(r4[2], dpz, __builtin_fmaf(r4[1], dpy, r4[0] * dpx)));
                     const float v = SIMPLE ? vc : vc - dLa;
                     av = __builtin_fmaf(last_alpha, lv, om_last * av);
                     float dL_dopa;
@@ -1906,7 +1910,7 @@ struct PreBwdArgs {
     int P, D, M;
     const float* means; const int* radii; const float* shs; const uint8_t* clamped;
     const float* scales; const float* rots; float mod; const float* cov3D;   // cov3D: precomp or geom state
-    const float4* conic_op;                               // the conic (and opacity) the forward stored
+    const float* rec;                                     // the forward's packed splat records (the conic it used)
     const float* view; const float* proj; const float* campos;
     float fx, fy, tanx, tany;
     float* acc;                                           // packed K7 sums, GSR_ACC_STRIDE floats per Gaussian
@@ -2155,7 +2159,8 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
 #pragma unroll
             for (int i = 0; i < 6; i++) cov6[i] = a.cov3D[6 * (size_t)idx + i];
             const float3 mean = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
-            const float4 co = a.conic_op[idx];
+            const SplatRec sr = load_splat_rec(a.rec, (uint32_t)idx);
+            const float3 co = make_float3(sr.a, sr.b, sr.c);
             // (scale and rotation are only needed at the very end; requested here, their latency is hidden by the chain rule)
             const bool want_sr = a.scales && (a.dL_dscale || a.dL_drot);
             float s3[3] = {0.f, 0.f, 0.f};
