@@ -1416,8 +1416,8 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 //     group (fixed k and chunk) fall into distinct banks;
 //   * W1 and W2 of a splat share a chunk swizzle (same m / 4): one ds_write2_b32 per splat, as before.
 #define GSR_WT_REGION 272
-// splats staged per batch: 128 keeps the workgroup at ~31 KB of LDS = 5 workgroups per CU
-#define GSR_BWD_BATCH 128
+// splats staged per batch: 64 keeps the workgroup (four private accumulator slices) at ~31 KB of LDS = 5 workgroups per CU
+#define GSR_BWD_BATCH 64
 struct BwdMfmaLDS {
     // (record P / slot GSR_BWD_BATCH of acc is the NULL splat -- opacity 0, so alpha = 0 and every update of the walk is the
     // identity -- that pads a wave's list to a multiple of eight: the bodies of a group then need no "is there an entry" test)
@@ -1426,7 +1426,11 @@ struct BwdMfmaLDS {
     float4 a[GSR_BWD_BATCH];            // x, y, opacity, id (bits)
     float4 d[GSR_BWD_BATCH];            // conic a, b, c as stored, quadrant mask (bits)
     uint32_t off[4][GSR_BWD_BATCH];     // per wave: record offsets (floats) of its list entries, same order as `list`
-    float acc[GSR_BWD_BATCH + 1][10];   // per staged splat: 0-3 = sum W1 (dpx,dpy,dpz,dLd), 4-9 = W2 moments
+    // per wave and staged splat: 0-3 = sum W1 (dpx,dpy,dpz,dLd), 4-9 = W2 moments.  Every wave has its own slice and writes each
+    // (splat, column) of its list once per batch with a plain store; the recombination adds the slices of the waves that had
+    // the splat on their list.  (One shared slice merged with ds_add_f32 cost 123 LDS cycles per instruction -- a float atomic
+    // occupies the LDS about three cycles per lane -- two thirds of the kernel's LDS time and 9 of its 60 us.)
+    float acc[4][GSR_BWD_BATCH + 1][10];
     // per wave: the weight transposition buffer of the contraction, see GSR_WT_REGION (before the walk: [pixel][17] scratch
     // for the B operands, the same 1088 floats)
     alignas(16) float wt[4][64 * GSR_WT_STRIDE];
@@ -1489,7 +1493,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
     if (lane == 0) s.wmax[wv] = m;
-    if (tid < 10) s.acc[GSR_BWD_BATCH][tid] = 0.f;
+    if (tid < 40) s.acc[tid / 10][GSR_BWD_BATCH][tid % 10] = 0.f;
     __syncthreads();
     const int total = max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3]));
     const int wave_max = s.wmax[wv];
@@ -1522,10 +1526,6 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             const uint32_t qm = quadrant_mask(sr.x, sr.y, sr.a, sr.b, sr.c, sr.opacity, tx * GSR_TILE, ty * GSR_TILE);
             s.a[tid] = make_float4(sr.x, sr.y, sr.opacity, __uint_as_float(id));
             s.d[tid] = make_float4(sr.a, sr.b, sr.c, __uint_as_float(qm));
-        }
-        if (tid < GSR_BWD_BATCH) {
-#pragma unroll
-            for (int q = 0; q < 10; q++) s.acc[tid][q] = 0.f;
         }
         __syncthreads();
         GSR_T_TICK(2)
@@ -1626,11 +1626,11 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                 D2 = __builtin_amdgcn_mfma_f32_16x16x4f32(aop[t >> 2][(t & 3) + 1], Breg[t + 1], D2, 0, 0, 0);
             }
             D = D + D2;
-            // Merge the four waves in LDS (unconditional float atomics: adding 0 is harmless, a branch per value is not free).
+            // This wave's sums of the group's eight splats -> its slice (plain stores; padding goes to the null slot).
             if (acol < 10) {
                 const uint32_t pair = (((arow & 2) ? phi : plo) >> (16 * (arow & 1))) & 0xFFFFu;      // list bytes of splats 2 arow, 2 arow + 1
-                atomicAdd(&s.acc[pair & 0xFFu][acol], own1 ? D[0] : D[1]);
-                atomicAdd(&s.acc[pair >> 8][acol], own1 ? D[2] : D[3]);
+                s.acc[wv][pair & 0xFFu][acol] = own1 ? D[0] : D[1];
+                s.acc[wv][pair >> 8][acol] = own1 ? D[2] : D[3];
             }
             GSR_T_TICK(5)
         }
@@ -1639,11 +1639,20 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         GSR_T_TICK(7)
         // per staged splat: recombine the moments into the nine (ten) gradient sums (in place) ...
         if (tid < n) {
-            float* q = s.acc[tid];
-            const float M0 = q[4], Mu = q[5], Mv = q[6], Muu = q[7], Muv = q[8], Mvv = q[9];
-            const float dz = q[3];
             const float4 A = s.a[tid];
             const float4 Dc = s.d[tid];
+            // the slices of the waves that had this splat on their list (the compaction's own test)
+            float m[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < 4; w++)
+                if (((__float_as_uint(Dc.w) >> w) & 1u) && (total - base - tid) <= s.wmax[w]) {
+#pragma unroll
+                    for (int c = 0; c < 10; c++) m[c] += s.acc[w][tid][c];
+                }
+            float* q = s.acc[0][tid];
+            q[0] = m[0]; q[1] = m[1]; q[2] = m[2];
+            const float M0 = m[4], Mu = m[5], Mv = m[6], Muu = m[7], Muv = m[8], Mvv = m[9];
+            const float dz = m[3];
             const float mu = A.x - cx0, mv = A.y - cy0, ca = Dc.x, cb = Dc.y, cc = Dc.z, o = A.z;
             const float sdx = mu * M0 - Mu, sdy = mv * M0 - Mv;
             const float sxx = mu * mu * M0 - 2.f * mu * Mu + Muu;
@@ -1662,7 +1671,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         // floats of the packed per-Gaussian records instead of 64 scattered rows
         for (int e = tid; e < n * 10; e += GSR_BLOCK) {
             const int j = e / 10, q = e - j * 10;
-            const float val = s.acc[j][q];
+            const float val = s.acc[0][j][q];
             if (val != 0.f && (POSE || q != 9)) atomicAdd(&acc[(size_t)__float_as_uint(s.a[j].w) * GSR_ACC_STRIDE + q], val);
         }
         GSR_T_TICK(8)
