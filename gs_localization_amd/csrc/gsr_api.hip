@@ -546,12 +546,17 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     {
         ProfScope ps(K_PREPROCESS, st);
         pa.zbc_lds = (pa.zbc != nullptr && im.nsb <= 4096) ? im.nsb : 0;
-        pa.lean = (cx.lean && cx.native_loop && by_tile && pa.cov_all == 0) ? 1 : 0;
+        pa.lean = (cx.lean && cx.native_loop && by_tile && pa.cov_all == 0 && pa.zbc_lds > 0 && scales != nullptr && getenv("GSR_NO_LEAN") == nullptr) ? 1 : 0;
         // (the exact-bin path has the preprocess zero the per-tile counters, all copies: at least that many threads)
         pa.ntiles = ntiles * im.copies;
         // (the first two workgroups also compute the launch orders of the compositing kernels: there must be two)
         const int blocks = std::max(by_tile ? pblocks : std::max(pblocks, (pa.ntiles + GSR_BLOCK - 1) / GSR_BLOCK), balanced ? 2 : 1);
-        hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(GSR_BLOCK), (size_t)pa.zbc_lds * sizeof(float), st, pa);
+        if (pa.lean) {
+            // radii are not an output of this forward: conservative test for all Gaussians, exact geometry for the few it leaves
+            const int lblocks = std::max((P + GSR_LEAN_PER_LANE * GSR_BLOCK - 1) / (GSR_LEAN_PER_LANE * GSR_BLOCK), balanced ? 2 : 1);
+            hipLaunchKernelGGL(k_preprocess_lean, dim3(lblocks), dim3(GSR_BLOCK), (size_t)pa.zbc_lds * sizeof(float), st, pa);
+        } else
+            hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(GSR_BLOCK), (size_t)pa.zbc_lds * sizeof(float), st, pa);
     }
     LAUNCHCHK("k_preprocess");
     // SH colours only feed the compositing kernel: fork them onto the side stream, join before K6.  (Not on the

@@ -146,8 +146,9 @@ __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int 
 struct SurvLists { uint32_t* ids; uint32_t* n; uint32_t cap; };
 static inline uint32_t surv_cap(int P)
 {
-    const uint32_t blocks = ((uint32_t)(P > 0 ? P : 1) + GSR_BLOCK - 1) / GSR_BLOCK;
-    return (blocks + GSR_SURV_LISTS - 1) / GSR_SURV_LISTS * GSR_BLOCK;
+    // (what the workgroups b = s mod GSR_SURV_LISTS of k_preprocess / k_preprocess_lean cover: 256 / 1024 Gaussians each)
+    const uint32_t blocks = ((uint32_t)(P > 0 ? P : 1) + 4 * GSR_BLOCK - 1) / (4 * GSR_BLOCK);
+    return (blocks + GSR_SURV_LISTS - 1) / GSR_SURV_LISTS * (4 * GSR_BLOCK);
 }
 // workgroups (of one wave) a list consumer is launched with: a multiple of GSR_SURV_LISTS, at most `resident`
 static inline int surv_grid(int P, int resident)
@@ -327,28 +328,18 @@ __device__ __forceinline__ void tile_order_from_work(const uint32_t* __restrict_
     }
 }
 
-__global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
+// Everything k_preprocess does for ONE Gaussian (lane) once its index is known: exact geometry, the bound tests, binning on
+// the by-tile path, survivor list, stale gradient rows.  Called with idx = the thread's global index (k_preprocess) or a
+// compacted candidate (k_preprocess_lean); wave-level pieces (cooperative walks, list appends) work on any 64 lanes.
+// FLAT (k_preprocess_lean: every live lane of the wave has a footprint to walk): the tile instances of all lanes are laid end to
+// end (prefix sum of the clipped rectangles' areas) and taken 64 at a time -- each lane finds whose instance it got (binary
+// search in the wave's prefix array), fetches that Gaussian's terms from the owning lane (ds_bpermute) and tests / appends
+// ONE tile, so that a round is one set of independent bound loads and returning atomics instead of a chain of them per
+// Gaussian.  s_flat: 128 words of LDS per wave (prefix array, per-owner counts).
+template <bool FLAT>
+__device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, const bool live, const float* s_zbc, const int tid, const uint32_t sublist,
+                                               uint32_t* s_flat = nullptr)
 {
-    // (the per-tile bounds are read straight from global memory: only the few lanes of a wave whose splat survives
-    // the superblock test look at them, a dozen reads per wave that hit in L1/L2, against 1 200 loads + LDS stores and
-    // a barrier per workgroup for a staged copy -- an eighth of the kernel's time, and a limit on the tile count)
-    extern __shared__ float s_zbc[];      // a.zbc_lds floats: the superblock bounds (0: read them from global memory)
-    const int tid = threadIdx.x;
-    if (a.tile_order[0] != nullptr && blockIdx.x < 2) {      // (before the poison test: the orders must be permutations whatever happens)
-        __shared__ uint32_t s_cls[GSR_BLOCK];
-        tile_order_from_work(a.tile_work[blockIdx.x], a.tile_order[blockIdx.x], a.order_tiles, s_cls);
-    }
-    if (a.guard.poisoned()) return;
-    GSR_T_DECL
-    if (a.zbc_lds > 0) {
-        for (int i = tid; i < a.zbc_lds; i += GSR_BLOCK) s_zbc[i] = a.zbc[i];
-        __syncthreads();
-    }
-    GSR_T_TICK(0)
-    const bool lean = a.lean != 0 && a.zbc_lds > 0 && a.scales != nullptr && !a.guard.frozen();
-    const int idx = blockIdx.x * GSR_BLOCK + tid;
-    if (a.tile_count != nullptr && idx < a.ntiles) a.tile_count[idx] = 0u;      // (k_tile_count adds into them next)
-    const bool live = idx < a.P;
     bool vis = false, coop = false, own = false;
     float3 p = make_float3(0.f, 0.f, 0.f);
     TileTest tt = {};
@@ -356,10 +347,6 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     float zv = 0.f;
     uint32_t cnt = 0;
 
-    if (idx == 0) {      // the null splat
-        float4* nr = reinterpret_cast<float4*>(a.rec + (size_t)a.P * GSR_REC_STRIDE);
-        nr[0] = make_float4(0.f, 0.f, 0.f, 0.f); nr[1] = nr[0]; nr[2] = nr[0];
-    }
     if (live) {
         a.radii[idx] = 0;
         a.tiles_touched[idx] = 0;
@@ -369,36 +356,6 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
         const float pw = 1.0f / (ph.w + 0.0000001f);
         const float3 pproj = make_float3(ph.x * pw, ph.y * pw, ph.z * pw);
         const float3 pview = xform4x3(p, a.view);
-        // Native loop, iterations whose `radii` the caller cannot get (a.lean: not the last one; not after convergence):
-        // 98 % of the Gaussians in front of the camera lie behind the bound of every tile they could touch and leave with
-        // tiles_touched = 0 -- after 600 instructions of exact geometry.  A radius bound from the largest scale,
-        //     lambda_max(cov2D + 0.3 I) <= |J|_F^2 s_max^2 + 0.92    (J: the perspective Jacobian with the clamped x/z, y/z of
-        //     forward.cu:90-96; the reference's radius formula mid + sqrt(max(0.1, mid^2 - det)) <= trace + 0.32),
-        // gives a larger rectangle; behind all of ITS superblocks => behind all of the exact rectangle's.  Such a lane skips
-        // the geometry (its radius stays 0: only this differs from the exact path), and a wave whose 64 lanes all do -- a
-        // third of them on S-1M-640 -- skips it altogether.  No compaction, no barrier (DESIGN.md section 8 has the
-        // versions with them: slower).
-        bool settled = false;
-        if (lean && pview.z > 0.2f) {
-            const float smax = a.mod * fmaxf(a.scales[3 * idx], fmaxf(a.scales[3 * idx + 1], a.scales[3 * idx + 2]));
-            const float rz = 1.0f / pview.z;
-            const float ccx = fminf(1.3f * a.tanx, fmaxf(-1.3f * a.tanx, pview.x * rz));
-            const float ccy = fminf(1.3f * a.tany, fmaxf(-1.3f * a.tany, pview.y * rz));
-            const float jx = a.fx * rz, jy = a.fy * rz;
-            const float jn2 = jx * jx * (1.f + ccx * ccx) + jy * jy * (1.f + ccy * ccy);
-            const float rb = fminf(1.0e6f, ceilf(3.f * __builtin_amdgcn_sqrtf((jn2 * smax) * smax * 1.001f + 0.95f) * 1.001f) + 1.f);
-            if (rb == rb) {          // (NaN: the exact code decides)
-                int x0, y0, x1, y1;
-                get_rect(ndc2pix(pproj.x, a.W), ndc2pix(pproj.y, a.H), (int)rb, a.gx, a.gy, x0, y0, x1, y1);
-                if ((x1 - x0) * (y1 - y0) == 0) settled = true;
-                else {
-                    float zc = 0.f;
-                    for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
-                        for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, s_zbc[sy * a.sbx + sx]);
-                    settled = pview.z > zc * a.zb_mul + a.zb_add;
-                }
-            }
-        }
         float cov6[6];
         if (a.cov_all) {
             // native loop, first forward of a refinement: the map does not change while the pose is refined, so the
@@ -411,7 +368,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 #pragma unroll
             for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov6[i];
         }
-        if (pview.z > 0.2f && !settled) {     // near cull (auxiliary.h:150)
+        if (pview.z > 0.2f) {     // near cull (auxiliary.h:150)
             if (a.cov_all) {
             } else if (a.cov3D_pre != nullptr) {
 #pragma unroll
@@ -457,7 +414,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                     if (a.zb != nullptr) {
                         // behind the bound of every superblock the rectangle overlaps => behind every tile's bound
                         float zc = 0.f;
-                        if (a.zbc_lds > 0) {
+                        if (s_zbc != nullptr && a.zbc_lds > 0) {
                             for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
                                 for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, s_zbc[sy * a.sbx + sx]);
                         } else {
@@ -477,8 +434,85 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
             }
         }
     }
-    GSR_T_TICK(1)
-    if (own) {      // small footprint: the lane walks its own rectangle
+    if (FLAT) {
+        const int lane = tid & 63;
+        const bool walker = own || coop;
+        const int area = walker ? (rx1 - rx0) * (ry1 - ry0) : 0;
+        int incl = area;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        uint32_t* pref = s_flat;            // first instance slot of lane's Gaussian (lanes without a footprint share their successor's)
+        uint32_t* ocnt = s_flat + 64;       // instances appended per owner
+        pref[lane] = (uint32_t)(incl - area);
+        ocnt[lane] = 0u;
+        __builtin_amdgcn_wave_barrier();
+#define GSR_PERM_F(v, src) __uint_as_float((uint32_t)__builtin_amdgcn_ds_bpermute((src) << 2, (int)__float_as_uint(v)))
+#define GSR_PERM_I(v, src) __builtin_amdgcn_ds_bpermute((src) << 2, (int)(v))
+        // four steps (256 instances) per round, phase by phase: every bound load of the round is in flight before the first
+        // is needed, likewise the returning atomics on the tile cursors
+        for (int u0 = 0; u0 < total; u0 += 4 * 64) {
+            int f_tile[4], f_src[4]; float f_z[4], f_zb[4]; uint32_t f_id[4]; bool f_in[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                f_in[k] = false; f_tile[k] = 0; f_zb[k] = 0.f; f_z[k] = 0.f; f_id[k] = 0u; f_src[k] = 0;
+                if (u0 + 64 * k >= total) continue;          // (wave-uniform)
+                const int u = u0 + 64 * k + lane;
+                const bool act = u < total;
+                int src = 0;
+                if (act) {
+#pragma unroll
+                    for (int step = 32; step > 0; step >>= 1)
+                        if (pref[src + step] <= (uint32_t)u) src += step;
+                }
+                TileTest bt;
+                bt.mx = GSR_PERM_F(tt.mx, src); bt.my = GSR_PERM_F(tt.my, src); bt.A = GSR_PERM_F(tt.A, src); bt.B = GSR_PERM_F(tt.B, src);
+                bt.det = GSR_PERM_F(tt.det, src); bt.twoq = GSR_PERM_F(tt.twoq, src); bt.dye = GSR_PERM_F(tt.dye, src); bt.invA = GSR_PERM_F(tt.invA, src);
+                bt.C = 0.f; bt.dxe = 0.f; bt.dyext = 0.f;      // (not used by row_span)
+                const int flags = GSR_PERM_I((int)tt.cull | ((int)tt.none << 1), src);
+                bt.cull = (flags & 1) != 0; bt.none = (flags & 2) != 0;
+                f_z[k] = GSR_PERM_F(zv, src);
+                const int bx0 = GSR_PERM_I(rx0, src), by0 = GSR_PERM_I(ry0, src), bx1 = GSR_PERM_I(rx1, src);
+                f_id[k] = (uint32_t)GSR_PERM_I(idx, src);
+                f_src[k] = src;
+                if (act) {
+                    const int bw = bx1 - bx0, t = u - (int)pref[src];
+                    const int row = (int)((float)t * __builtin_amdgcn_rcpf((float)bw) + 0.001f);      // t / bw (corrected below)
+                    int ry = row, rxo = t - row * bw;
+                    if (rxo < 0) { ry--; rxo += bw; } else if (rxo >= bw) { ry++; rxo -= bw; }
+                    const int y = by0 + ry, x = bx0 + rxo;
+                    int lo, hi;
+                    row_span(bt, y, bx0, bx1, lo, hi);
+                    f_tile[k] = y * a.gx + x;
+                    f_in[k] = x >= lo && x <= hi;
+                    if (f_in[k]) f_zb[k] = a.zb[f_tile[k]];
+                }
+            }
+            uint32_t f_pos[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                // behind everything this tile needed last iteration (+ margin): speculatively dropped
+                f_in[k] = f_in[k] && f_z[k] <= f_zb[k] * a.zb_mul + a.zb_add;
+                f_pos[k] = GSR_LSORT_CAP;
+                if (f_in[k]) {
+                    atomicAdd(&ocnt[f_src[k]], 1u);
+                    f_pos[k] = atomicAdd(&a.tile_cursor[f_tile[k] * GSR_CURSOR_STRIDE], 1u);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (f_pos[k] < GSR_LSORT_CAP)
+                    a.bins[(size_t)f_tile[k] * GSR_LSORT_CAP + f_pos[k]] = ((unsigned long long)__float_as_uint(f_z[k]) << 32) | f_id[k];
+        }
+#undef GSR_PERM_F
+#undef GSR_PERM_I
+        __builtin_amdgcn_wave_barrier();
+        if (walker) cnt = ocnt[lane];
+    }
+    if (!FLAT && own) {      // small footprint: the lane walks its own rectangle
         for (int y = ry0; y < ry1; y++) {
             int lo, hi;
             row_span(tt, y, rx0, rx1, lo, hi);
@@ -493,8 +527,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
                 }
         }
     }
-    GSR_T_TICK(2)
-    if (a.bins != nullptr) {
+    if (!FLAT && a.bins != nullptr) {
         // Large footprints: the 64 lanes of the wave walk the rectangle together (one tile per lane), so no lane
         // is left issuing hundreds of dependent atomics on its own.
         const int lane = tid & 63;
@@ -513,7 +546,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 #undef GSR_BCAST_F
             const int bx0 = __builtin_amdgcn_readlane(rx0, src), by0 = __builtin_amdgcn_readlane(ry0, src);
             const int bx1 = __builtin_amdgcn_readlane(rx1, src), by1 = __builtin_amdgcn_readlane(ry1, src);
-            const uint32_t bidx = (uint32_t)(blockIdx.x * GSR_BLOCK + (tid & ~63) + src);
+            const uint32_t bidx = (uint32_t)__builtin_amdgcn_readlane(idx, src);
             const int bw = bx1 - bx0, area = bw * (by1 - by0);
             uint32_t c_cnt = 0;
             for (int t0 = 0; t0 < area; t0 += 64) {
@@ -537,7 +570,6 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
             if (lane == src) cnt = c_cnt;
         }
     }
-    GSR_T_TICK(3)
     if (vis) {
         // (what was dropped is not recorded: an instance can only be dropped from a tile whose bound is finite, and the
         // compositing kernel treats every such tile that ends unsaturated as a failed speculation)
@@ -549,7 +581,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
         const unsigned long long mk = __ballot(surv);
         if (mk != 0ull) {
             const int lane = tid & 63;
-            const uint32_t sl = blockIdx.x & (GSR_SURV_LISTS - 1);
+            const uint32_t sl = sublist;
             uint32_t at = 0u;
             if (lane == 0) at = atomicAdd(&a.surv.n[sl * GSR_SURV_CSTRIDE], (uint32_t)__popcll(mk));
             at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
@@ -560,7 +592,137 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
         const uint8_t d = a.dirty[idx];
         if (d != 0) { zero_grad_rows(a.rows, (size_t)idx, (d & 1) != 0, (d & 2) != 0); a.dirty[idx] = 0; }
     }
-    GSR_T_TICK(4)
+}
+
+__global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
+{
+    // (the per-tile bounds are read straight from global memory: only the few lanes of a wave whose splat survives
+    // the superblock test look at them, a dozen reads per wave that hit in L1/L2, against 1 200 loads + LDS stores and
+    // a barrier per workgroup for a staged copy -- an eighth of the kernel's time, and a limit on the tile count)
+    extern __shared__ float s_zbc[];      // a.zbc_lds floats: the superblock bounds (0: read them from global memory)
+    const int tid = threadIdx.x;
+    if (a.tile_order[0] != nullptr && blockIdx.x < 2) {      // (before the poison test: the orders must be permutations whatever happens)
+        __shared__ uint32_t s_cls[GSR_BLOCK];
+        tile_order_from_work(a.tile_work[blockIdx.x], a.tile_order[blockIdx.x], a.order_tiles, s_cls);
+    }
+    if (a.guard.poisoned()) return;
+    GSR_T_DECL
+    if (a.zbc_lds > 0) {
+        for (int i = tid; i < a.zbc_lds; i += GSR_BLOCK) s_zbc[i] = a.zbc[i];
+        __syncthreads();
+    }
+    const int idx = blockIdx.x * GSR_BLOCK + tid;
+    if (a.tile_count != nullptr && idx < a.ntiles) a.tile_count[idx] = 0u;      // (k_tile_count adds into them next)
+    if (idx == 0) {      // the null splat
+        float4* nr = reinterpret_cast<float4*>(a.rec + (size_t)a.P * GSR_REC_STRIDE);
+        nr[0] = make_float4(0.f, 0.f, 0.f, 0.f); nr[1] = nr[0]; nr[2] = nr[0];
+    }
+    preprocess_one<false>(a, idx, idx < a.P, s_zbc, tid, blockIdx.x & (GSR_SURV_LISTS - 1));
+}
+
+// ---------------------------------------------------------------------------------------------
+// The preprocess of a native-loop iteration whose `radii` the caller cannot get (PreArgs::lean: speculative binning, not
+// the last iteration).  98 % of the Gaussians in front of the camera lie behind the depth bound of every tile they could
+// touch and would leave k_preprocess with tiles_touched = 0 -- after ~1 000 instructions of exact geometry and footprint walk,
+// which a wave executes in full as soon as ONE of its 64 lanes needs it (two waves out of three on S-1M-640, for 1.7 lanes).
+// Here a wave looks at GSR_LEAN_PER_LANE x 64 Gaussians:
+//   1. every lane bounds its Gaussians' radii from their largest scale,
+//         lambda_max(cov2D + 0.3 I) <= |J|_F^2 s_max^2 + 0.92    (J: the perspective Jacobian with the clamped x/z, y/z of
+//         forward.cu:90-96; the reference's radius formula mid + sqrt(max(0.1, mid^2 - det)) <= trace + 0.32),
+//      which gives a rectangle that contains the exact one; behind the bounds of all ITS superblocks => behind every tile's:
+//      settled, and nothing is written for such a Gaussian (neither radii nor tiles_touched are read in such an iteration:
+//      the consumers walk the survivor lists);
+//   2. the others -- under 2 %, four or five per wave -- are compacted (ballot + prefix, the wave's own 1 KB of LDS, no workgroup
+//      barrier) and the wave runs preprocess_one ONCE on them, dense lanes, flattened footprint walk.
+// A frozen (converged) iteration's forward is the render the caller gets back, radii included: then nobody is settled, the
+// flags are zeroed here, and the kernel computes exactly what k_preprocess would.
+// ---------------------------------------------------------------------------------------------
+#ifndef GSR_LEAN_PER_LANE
+#define GSR_LEAN_PER_LANE 4
+#endif
+__global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_lean(PreArgs a)
+{
+    extern __shared__ float s_zbc[];      // a.zbc_lds floats: the superblock bounds
+    __shared__ uint32_t s_cand[4][GSR_LEAN_PER_LANE * 64];
+    __shared__ uint32_t s_flat[4][128];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (a.tile_order[0] != nullptr && blockIdx.x < 2) {      // (before the poison test: the orders must be permutations whatever happens)
+        __shared__ uint32_t s_cls[GSR_BLOCK];
+        tile_order_from_work(a.tile_work[blockIdx.x], a.tile_order[blockIdx.x], a.order_tiles, s_cls);
+    }
+    if (a.guard.poisoned()) return;
+    GSR_T_DECL
+    for (int i = tid; i < a.zbc_lds; i += GSR_BLOCK) s_zbc[i] = a.zbc[i];
+    __syncthreads();
+    GSR_T_TICK(0)
+    const bool frozen = a.guard.frozen();
+    if (blockIdx.x == 0 && tid == 0) {      // the null splat
+        float4* nr = reinterpret_cast<float4*>(a.rec + (size_t)a.P * GSR_REC_STRIDE);
+        nr[0] = make_float4(0.f, 0.f, 0.f, 0.f); nr[1] = nr[0]; nr[2] = nr[0];
+    }
+    const int base = (blockIdx.x * 4 + wv) * (GSR_LEAN_PER_LANE * 64);
+    int ncand = 0;                             // wave-uniform
+    // (all the loads of the wave's Gaussians first: one round trip, not one per sub-chunk)
+    float3 pk[GSR_LEAN_PER_LANE]; float sk[GSR_LEAN_PER_LANE]; uint8_t dk[GSR_LEAN_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < GSR_LEAN_PER_LANE; k++) {
+        const int idx = min(base + k * 64 + lane, a.P - 1);
+        pk[k] = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
+        sk[k] = fmaxf(a.scales[3 * idx], fmaxf(a.scales[3 * idx + 1], a.scales[3 * idx + 2]));
+        dk[k] = (a.dirty != nullptr) ? a.dirty[idx] : (uint8_t)0;
+    }
+#pragma unroll
+    for (int k = 0; k < GSR_LEAN_PER_LANE; k++) {
+        const int idx = base + k * 64 + lane;
+        const bool live = idx < a.P;
+        bool cand = false;
+        if (live) {
+            if (frozen) { a.radii[idx] = 0; a.tiles_touched[idx] = 0; }
+            const float3 p = pk[k];
+            const float3 pview = xform4x3(p, a.view);
+            if (pview.z > 0.2f) {     // near cull (auxiliary.h:150)
+                cand = true;
+                // (hardware reciprocals and fp32 pixel centres: the radius bound carries a 0.2 % and two-pixel allowance)
+                const float4 ph = xform4x4(p, a.proj);
+                const float pw = __builtin_amdgcn_rcpf(ph.w + 0.0000001f);
+                const float smax = a.mod * sk[k];
+                const float rz = __builtin_amdgcn_rcpf(pview.z);
+                const float ccx = fminf(1.3f * a.tanx, fmaxf(-1.3f * a.tanx, pview.x * rz));
+                const float ccy = fminf(1.3f * a.tany, fmaxf(-1.3f * a.tany, pview.y * rz));
+                const float jx = a.fx * rz, jy = a.fy * rz;
+                const float jn2 = jx * jx * (1.f + ccx * ccx) + jy * jy * (1.f + ccy * ccy);
+                const float rb = fminf(1.0e6f, ceilf(3.f * __builtin_amdgcn_sqrtf((jn2 * smax) * smax * 1.002f + 0.95f) * 1.002f) + 2.f);
+                if (rb == rb && !frozen) {          // (NaN: the exact code decides)
+                    const float pxf = ((ph.x * pw + 1.f) * (float)a.W - 1.f) * 0.5f, pyf = ((ph.y * pw + 1.f) * (float)a.H - 1.f) * 0.5f;
+                    int x0, y0, x1, y1;
+                    get_rect(pxf, pyf, (int)rb, a.gx, a.gy, x0, y0, x1, y1);
+                    if ((x1 - x0) * (y1 - y0) == 0) cand = false;
+                    else {
+                        float zc = 0.f;
+                        for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
+                            for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, s_zbc[sy * a.sbx + sx]);
+                        cand = !(pview.z > zc * a.zb_mul + a.zb_add);
+                    }
+                }
+            }
+        }
+        // (a Gaussian that is not even a candidate gets no gradient this iteration: see PreArgs::dirty; candidates: preprocess_one)
+        if (a.dirty != nullptr && live && !cand && !frozen) {
+            const uint8_t d = dk[k];
+            if (d != 0) { zero_grad_rows(a.rows, (size_t)idx, (d & 1) != 0, (d & 2) != 0); a.dirty[idx] = 0; }
+        }
+        const unsigned long long mk = __ballot(cand);
+        if (cand) s_cand[wv][ncand + (int)__popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+        ncand += (int)__popcll(mk);
+    }
+    __builtin_amdgcn_wave_barrier();
+    GSR_T_TICK(1)
+    GSR_T_COUNT(10, ncand)
+    for (int c0 = 0; c0 < ncand; c0 += 64) {
+        const bool mine = c0 + lane < ncand;
+        preprocess_one<true>(a, mine ? (int)s_cand[wv][c0 + lane] : 0, mine, s_zbc, tid, blockIdx.x & (GSR_SURV_LISTS - 1), s_flat[wv]);
+    }
+    GSR_T_TICK(2)
     GSR_T_FLUSH(32)
 }
 

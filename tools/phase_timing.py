@@ -42,10 +42,10 @@ show("k_render_fwd", 0, ["bins load", "sort + writeback", "batch top (barrier_an
 nw = 1200 * 4 * ITERS
 show("k_render_bwd_mfma", 16, ["prologue", "batch top barrier", "staging + barrier", "compaction", "weights (8 splats)", "mfma + lds atomics",
                                "(loop exit)", "barrier after groups", "recombine + global atomics", "(wave lifetime)", "batches", "list entries"])
-nw = (sc.P + 255) // 256 * 4 * ITERS
-show("k_preprocess", 32, ["bounds -> LDS + barrier", "geometry, bound test", "own rectangle walk (divergent)", "cooperative walks", "flags, counts",
-                          "", "", "", "", "(wave lifetime)", "", ""])
+nw = (sc.P + 255) // 256 * ITERS      # one wave per 256 Gaussians
+show("k_preprocess_lean", 32, ["bounds -> LDS + barrier", "conservative pass (4 x 64 Gaussians)", "exact pass on the compacted candidates", "", "",
+                               "", "", "", "", "(wave lifetime)", "candidates", ""])
 # Is a kernel's duration its mean wave or its slowest one?  (rows = wave positions; all tiles of K6 / K7 are resident at once)
-for name, base, launches in (("k_render_fwd", 0, ITERS), ("k_render_bwd_mfma", 16, ITERS), ("k_preprocess", 32, ITERS)):
+for name, base, launches in (("k_render_fwd", 0, ITERS), ("k_render_bwd_mfma", 16, ITERS), ("k_preprocess_lean", 32, ITERS)):
     print("%-20s wave lifetime per launch (cycles): median %8.0f   99th percentile %8.0f   max %8.0f   (%d rows)" %
           (name, v[base + 14] / launches, v[base + 15] / launches, v[base + 12] / launches, v[base + 13]))
