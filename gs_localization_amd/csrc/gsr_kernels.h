@@ -1162,6 +1162,40 @@ __device__ __forceinline__ void lds_bitonic_sort(unsigned long long* s_keys, int
         }
 }
 
+// At most GSR_BLOCK keys (one per thread, ~0 = none; real keys are unique): every wave sorts its 64 keys in REGISTERS (bitonic
+// network over the lanes: 21 compare-exchange steps through ds_bpermute, no barrier, no LDS traffic of its own), the four
+// sorted runs meet in s_keys, and every thread finds its key's final place by counting, in each of the other three runs,
+// the keys below its own (6-step binary searches).  Three barriers instead of the 36 of the LDS network on 256 keys: ~5 k
+// instead of ~16 k cycles per wave on the native loop's bins (a fifth of k_render_fwd's time).  s_keys[0, total) sorted on return.
+__device__ __forceinline__ void sort_block_keys(unsigned long long key, unsigned long long* s_keys)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int k = 2; k <= 64; k <<= 1)
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const unsigned long long other = __shfl_xor(key, j, 64);
+            const bool take_min = ((lane & j) == 0) == ((lane & k) == 0);      // lower lane of an ascending pair, or upper lane of a descending one
+            key = (take_min == (other < key)) ? other : key;
+        }
+    s_keys[tid] = key;
+    __syncthreads();
+    int rank = lane;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        if (w == wv) continue;
+        const unsigned long long* run = s_keys + w * 64;
+        int pos = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+            if (run[pos + step - 1] < key) pos += step;
+        rank += pos + ((pos == 63 && run[63] < key) ? 1 : 0);
+    }
+    __syncthreads();
+    if (key != ~0ull) s_keys[rank] = key;
+    __syncthreads();
+}
+
 // GSR_LIST_EXACT: picks the next slice of a tile's unordered segment keys[0, total).  Keys are unique (the index is part
 // of them).  Among the keys above `lo` (all of them when `first`) finds a threshold `hi` such that the number m of keys in
 // (lo, hi] satisfies 1 <= m <= limit and, unless the keys run out of distinguishing bits earlier, m >= limit / 4:
@@ -1282,17 +1316,23 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
             return;
         }
         if (tid == 0) ranges[tile] = range;
-        int npow = 64;
-        while (npow < total) npow <<= 1;
-        for (int i = tid; i < npow; i += GSR_BLOCK) s_keys[i] = (i < total) ? bins[range.x + i] : ~0ull;
-        __syncthreads();
-        GSR_T_TICK(0)
-        lds_bitonic_sort(s_keys, npow);
+        if (total <= GSR_BLOCK) {          // one key per thread: register sort + merge by counting (the common case of the native loop)
+            GSR_T_TICK(0)
+            sort_block_keys((tid < total) ? bins[range.x + tid] : ~0ull, s_keys);
+            overhead += 2;
+        } else {
+            int npow = 512;
+            while (npow < total) npow <<= 1;
+            for (int i = tid; i < npow; i += GSR_BLOCK) s_keys[i] = (i < total) ? bins[range.x + i] : ~0ull;
+            __syncthreads();
+            GSR_T_TICK(0)
+            lds_bitonic_sort(s_keys, npow);
+            // (measured: a compare-exchange step of the network costs about a seventh of a group of eight composited entries,
+            // twice / four times that above 512 / 1024 keys)
+            const int lg = 31 - __builtin_clz((unsigned)npow);
+            overhead += (lg * (lg + 1) / 2) * max(1, npow >> 9) / 7;
+        }
         for (int i = tid; i < total; i += GSR_BLOCK) point_list[range.x + i] = (uint32_t)s_keys[i];
-        // (measured: a compare-exchange step of the network costs about a seventh of a group of eight composited entries,
-        // twice / four times that above 512 / 1024 keys)
-        const int lg = 31 - __builtin_clz((unsigned)npow);
-        overhead += (lg * (lg + 1) / 2) * max(1, npow >> 9) / 7;
     }
     GSR_T_TICK(1)
     // T > 0: still compositing.  T <= 0: finished (or outside the image); the pixel's transmittance is -T.  With a
