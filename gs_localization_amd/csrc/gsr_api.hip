@@ -547,6 +547,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         ProfScope ps(K_PREPROCESS, st);
         pa.zbc_lds = (pa.zbc != nullptr && im.nsb <= 4096) ? im.nsb : 0;
         pa.lean = (cx.lean && cx.native_loop && by_tile && pa.cov_all == 0 && pa.zbc_lds > 0 && scales != nullptr && getenv("GSR_NO_LEAN") == nullptr) ? 1 : 0;
+        pa.sh_here = (pa.lean && colors_precomp == nullptr && M <= 16 && getenv("GSR_SH_SEPARATE") == nullptr) ? 1 : 0;
         // (the exact-bin path has the preprocess zero the per-tile counters, all copies: at least that many threads)
         pa.ntiles = ntiles * im.copies;
         // (the first two workgroups also compute the launch orders of the compositing kernels: there must be two)
@@ -564,7 +565,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     // fork/join costs more than it gains -- measured 0.466 vs 0.434 ms per iteration.)
     SideLease side_lease(colors_precomp == nullptr && !debug && !by_tile, dev);
     Side* side = side_lease.sd;
-    if (colors_precomp == nullptr) {
+    if (colors_precomp == nullptr && !pa.sh_here) {
         if (side) {
             HIPCHK(hipEventRecord(side->fork, st));
             HIPCHK(hipStreamWaitEvent(side->st, side->fork, 0));

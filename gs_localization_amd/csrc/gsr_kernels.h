@@ -143,12 +143,16 @@ __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int 
 // ---------------------------------------------------------------------------------------------
 #define GSR_SURV_LISTS 64
 #define GSR_SURV_CSTRIDE 64
+#ifndef GSR_LEAN_PER_LANE
+#define GSR_LEAN_PER_LANE 4      // Gaussians per lane of k_preprocess_lean
+#endif
 struct SurvLists { uint32_t* ids; uint32_t* n; uint32_t cap; };
 static inline uint32_t surv_cap(int P)
 {
-    // (what the workgroups b = s mod GSR_SURV_LISTS of k_preprocess / k_preprocess_lean cover: 256 / 1024 Gaussians each)
-    const uint32_t blocks = ((uint32_t)(P > 0 ? P : 1) + 4 * GSR_BLOCK - 1) / (4 * GSR_BLOCK);
-    return (blocks + GSR_SURV_LISTS - 1) / GSR_SURV_LISTS * (4 * GSR_BLOCK);
+    // (what the workgroups b = s mod GSR_SURV_LISTS of k_preprocess / k_preprocess_lean cover: 256 / GSR_LEAN_PER_LANE x 256 Gaussians each)
+    const uint32_t per = GSR_LEAN_PER_LANE * GSR_BLOCK;
+    const uint32_t blocks = ((uint32_t)(P > 0 ? P : 1) + per - 1) / per;
+    return (blocks + GSR_SURV_LISTS - 1) / GSR_SURV_LISTS * per;
 }
 // workgroups (of one wave) a list consumer is launched with: a multiple of GSR_SURV_LISTS, at most `resident`
 static inline int surv_grid(int P, int resident)
@@ -227,6 +231,7 @@ struct PreArgs {
     float* rec;              // packed splat records (GSR_REC_*), P + 1 of them
     uint8_t* clamped; uint32_t* tiles_touched; ushort4* rects;
     int cov_all;             // k_preprocess: compute and store cov3D for every Gaussian, culled or not (see there)
+    int sh_here;             // k_preprocess_lean: evaluate the survivors' SH colour itself (no k_sh_color launch behind it)
     SurvLists surv;          // work lists: k_preprocess appends, k_sh_color walks (ids nullable: no lists kept)
     // Native loop only (dirty nullable): a Gaussian that is NOT a survivor of this forward gets no gradient this iteration;
     // whatever the previous iteration left in its rows is cleared here, by the one kernel that visits every Gaussian anyway
@@ -592,6 +597,23 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
         const uint8_t d = a.dirty[idx];
         if (d != 0) { zero_grad_rows(a.rows, (size_t)idx, (d & 1) != 0, (d & 2) != 0); a.dirty[idx] = 0; }
     }
+    // k_preprocess_lean (a.sh_here): the wave's lanes are dense with survivors, so their colour is evaluated right here -- one
+    // kernel (and one chain of dependent memory phases) less per iteration than with k_sh_color behind this one.
+    if (FLAT && a.sh_here && surv) {
+        float row[48];
+        if (sh16_vector_ok(a.M, a.shs)) {
+            const float4* r4 = reinterpret_cast<const float4*>(a.shs) + (size_t)idx * GSR_SH16_ROW4;
+#pragma unroll
+            for (int i = 0; i < GSR_SH16_ROW4; i++) { const float4 v = r4[i]; row[4 * i] = v.x; row[4 * i + 1] = v.y; row[4 * i + 2] = v.z; row[4 * i + 3] = v.w; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 48; i++) row[i] = (i < a.M * 3) ? a.shs[(size_t)idx * a.M * 3 + i] : 0.f;
+        }
+        uint8_t cb;
+        const float3 c = sh_to_rgb(a.D, a.M, p, a.campos, row, cb);
+        reinterpret_cast<float4*>(a.rec + (size_t)idx * GSR_REC_STRIDE)[2] = make_float4(c.x, c.y, c.z, 0.f);
+        a.clamped[idx] = cb;
+    }
 }
 
 __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
@@ -637,9 +659,6 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 // A frozen (converged) iteration's forward is the render the caller gets back, radii included: then nobody is settled, the
 // flags are zeroed here, and the kernel computes exactly what k_preprocess would.
 // ---------------------------------------------------------------------------------------------
-#ifndef GSR_LEAN_PER_LANE
-#define GSR_LEAN_PER_LANE 4
-#endif
 __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_lean(PreArgs a)
 {
     extern __shared__ float s_zbc[];      // a.zbc_lds floats: the superblock bounds
