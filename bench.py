@@ -325,6 +325,9 @@ def main():
                          "algorithmic_bytes_per_launch": per_kernel_bytes[dominant], "avg_launch_ms": dom_avg_ms,
                          "launches_timed": int(dom_n),
                          "avg_launch_ms_single_frame": native_ms[True][dominant],
+                         # (avg_launch_ms is a launch of the timed region, where F frames share the GPU; a frame alone:)
+                         "frac_single_frame": (per_kernel_bytes[dominant] / (native_ms[True][dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                                              if native_ms[True][dominant] > 0 else None,
                          # what the kernel is actually bound by: vector + matrix issue slots (rocprofv3 SQ pass, profiles/issue.json)
                          "issue_frac": issue,
                          # whole iteration: HBM bytes per steady-state iteration (sum of the loop's kernels, profiles/traffic.json)
