@@ -1637,26 +1637,28 @@ template <bool B> struct BoolTag { static constexpr bool value = B; };
 //     group (fixed k and chunk) fall into distinct banks;
 //   * W1 and W2 of a splat share a chunk swizzle (same m / 4): one ds_write2_b32 per splat, as before.
 #define GSR_WT_REGION 272
-// splats staged per batch: 64 keeps the workgroup (four private accumulator slices) at ~31 KB of LDS = 5 workgroups per CU
-#define GSR_BWD_BATCH 64
+#define GSR_BWD_STAGE 128      // splats looked at per batch
+#define GSR_BWD_LIST 64        // ... of which a wave can take this many onto its list: the batch ends where the first list is full
 struct BwdMfmaLDS {
-    // (record P / slot GSR_BWD_BATCH of acc is the NULL splat -- opacity 0, so alpha = 0 and every update of the walk is the
-    // identity -- that pads a wave's list to a multiple of eight: the bodies of a group then need no "is there an entry" test)
-    // (what the WALK reads per entry comes from the packed records in global memory through scalar loads, GSR_REC_*; these
-    // staged copies serve the per-batch recombination only)
-    float4 a[GSR_BWD_BATCH];            // x, y, opacity, id (bits)
-    float4 d[GSR_BWD_BATCH];            // conic a, b, c as stored, quadrant mask (bits)
-    uint32_t off[4][GSR_BWD_BATCH];     // per wave: record offsets (floats) of its list entries, same order as `list`
-    // per wave and staged splat: 0-3 = sum W1 (dpx,dpy,dpz,dLd), 4-9 = W2 moments.  Every wave has its own slice and writes each
-    // (splat, column) of its list once per batch with a plain store; the recombination adds the slices of the waves that had
-    // the splat on their list.  (One shared slice merged with ds_add_f32 cost 123 LDS cycles per instruction -- a float atomic
-    // occupies the LDS about three cycles per lane -- two thirds of the kernel's LDS time and 9 of its 60 us.)
-    float acc[4][GSR_BWD_BATCH + 1][10];
+    // (what the WALK reads per entry comes from the packed records in global memory through scalar loads, GSR_REC_*; a padded
+    // list entry points at record P, the NULL splat -- opacity 0, so alpha = 0 and every update of the walk is the identity --
+    // so that the bodies of a group need no "is there an entry" test)
+    uint32_t ids[GSR_BWD_STAGE];             // staged splats, deepest first
+    uint8_t qm[GSR_BWD_STAGE];               // their quadrant masks
+    uint8_t inv[4][GSR_BWD_STAGE];           // per wave: where on its list a staged splat sits (valid for the ones that are on it)
+    uint32_t off[4][GSR_BWD_LIST];           // per wave: record offsets (floats) of its list entries
+    alignas(8) uint8_t list[4][GSR_BWD_LIST];   // ... and their staged slots
+    // per wave and LIST POSITION: 0-3 = sum W1 (dpx,dpy,dpz,dLd), 4-9 = W2 moments.  Every wave has its own slice and writes each
+    // (entry, column) once per batch with a plain store; the recombination adds the slices of the waves that had the splat on
+    // their list.  (One shared slice merged with ds_add_f32 cost 123 LDS cycles per instruction -- a float atomic occupies the
+    // LDS about three cycles per lane -- two thirds of the kernel's LDS time and 9 of its 60 us.)  Four slices of 128 rows would
+    // not fit five workgroups per CU; 64 rows do, and a batch looks at up to 128 splats but ends where the first wave's list is
+    // full (a wave takes about half of a tile's splats): 1.2 batches per tile instead of 2, each with its barriers and staging.
+    float acc[4][GSR_BWD_LIST][10];
     // per wave: the weight transposition buffer of the contraction, see GSR_WT_REGION (before the walk: [pixel][17] scratch
-    // for the B operands, the same 1088 floats)
+    // for the B operands, the same 1088 floats; between a batch's walk and the next: the recombined sums on their way out)
     alignas(16) float wt[4][64 * GSR_WT_STRIDE];
-    int wmax[4];
-    alignas(8) uint8_t list[4][GSR_BWD_BATCH];
+    int wmax[4], lim[4];
 };
 
 template <bool POSE>
@@ -1714,7 +1716,6 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
     if (lane == 0) s.wmax[wv] = m;
-    if (tid < 40) s.acc[tid / 10][GSR_BWD_BATCH][tid % 10] = 0.f;
     __syncthreads();
     const int total = max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3]));
     const int wave_max = s.wmax[wv];
@@ -1736,35 +1737,44 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
     }
 
     GSR_T_TICK(0)
-    for (int base = 0; base < total; base += GSR_BWD_BATCH) {
+    int nbatch = 0;
+    for (int base = 0, taken = 0; base < total; base += taken) {
         __syncthreads();
         GSR_T_TICK(1)
         GSR_T_COUNT(10, 1)
-        const int n = min(GSR_BWD_BATCH, total - base);
+        nbatch++;
+        const int n = min(GSR_BWD_STAGE, total - base);
         if (tid < n) {
             const uint32_t id = point_list[range.x + (total - 1 - base - tid)];
             const SplatRec sr = load_splat_rec(rec, id);
-            const uint32_t qm = quadrant_mask(sr.x, sr.y, sr.a, sr.b, sr.c, sr.opacity, tx * GSR_TILE, ty * GSR_TILE);
-            s.a[tid] = make_float4(sr.x, sr.y, sr.opacity, __uint_as_float(id));
-            s.d[tid] = make_float4(sr.a, sr.b, sr.c, __uint_as_float(qm));
+            s.ids[tid] = id;
+            s.qm[tid] = (uint8_t)quadrant_mask(sr.x, sr.y, sr.a, sr.b, sr.c, sr.opacity, tx * GSR_TILE, ty * GSR_TILE);
         }
         __syncthreads();
         GSR_T_TICK(2)
-        int cnt = 0;
+        // this wave's list (staged order), at most GSR_BWD_LIST entries; lim = the staged slot of the first splat that did not fit
+        int cnt = 0, lim = n;
         for (int c0 = 0; c0 < n; c0 += 64) {
             const int jj = c0 + lane;
-            const bool hit = jj < n && ((__float_as_uint(s.d[min(jj, GSR_BWD_BATCH - 1)].w) >> wv) & 1u) &&
-                             (total - base - jj) <= wave_max;
+            const bool hit = jj < n && ((s.qm[min(jj, GSR_BWD_STAGE - 1)] >> wv) & 1u) && (total - base - jj) <= wave_max;
             const unsigned long long mk = __ballot(hit);
-            if (hit) {
-                const int at = cnt + (int)__popcll(mk & ((1ull << lane) - 1ull));
+            const int at = cnt + (int)__popcll(mk & ((1ull << lane) - 1ull));
+            if (hit && at < GSR_BWD_LIST) {
                 s.list[wv][at] = (uint8_t)jj;
-                s.off[wv][at] = __float_as_uint(s.a[jj].w) * GSR_REC_STRIDE;
+                s.off[wv][at] = s.ids[jj] * GSR_REC_STRIDE;
+                s.inv[wv][jj] = (uint8_t)at;
             }
-            cnt += (int)__popcll(mk);
+            const unsigned long long over = __ballot(hit && at == GSR_BWD_LIST);
+            if (over != 0ull && lim == n) lim = c0 + (int)__builtin_ctzll(over);
+            cnt = min(GSR_BWD_LIST, cnt + (int)__popcll(mk));
         }
+        if (lane == 0) s.lim[wv] = lim;
+        __syncthreads();
+        taken = min(min(s.lim[0], s.lim[1]), min(s.lim[2], s.lim[3]));      // (>= 64 unless the tile's list ends first: a full list has 64 hits)
+        // what lies beyond the end of the batch stays for the next one (the list is in staged order)
+        cnt = (int)__popcll(__ballot(lane < cnt && (int)s.list[wv][min(lane, GSR_BWD_LIST - 1)] < taken));
         if (lane < ((8 - (cnt & 7)) & 7)) {      // pad to a multiple of eight with the null splat
-            s.list[wv][cnt + lane] = (uint8_t)GSR_BWD_BATCH;
+            s.list[wv][cnt + lane] = (uint8_t)0;
             s.off[wv][cnt + lane] = (uint32_t)P * GSR_REC_STRIDE;
         }
         walked += (cnt + 7) >> 3;
@@ -1848,59 +1858,59 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             }
             D = D + D2;
             // This wave's sums of the group's eight splats -> its slice (plain stores; padding goes to the null slot).
-            if (acol < 10) {
-                const uint32_t pair = (((arow & 2) ? phi : plo) >> (16 * (arow & 1))) & 0xFFFFu;      // list bytes of splats 2 arow, 2 arow + 1
-                s.acc[wv][pair & 0xFFu][acol] = own1 ? D[0] : D[1];
-                s.acc[wv][pair >> 8][acol] = own1 ? D[2] : D[3];
+            if (acol < 10) {      // rows of list positions g0 + 2 arow, g0 + 2 arow + 1
+                s.acc[wv][g0 + 2 * arow][acol] = own1 ? D[0] : D[1];
+                s.acc[wv][g0 + 2 * arow + 1][acol] = own1 ? D[2] : D[3];
             }
             GSR_T_TICK(5)
         }
         GSR_T_TICK(6)
         __syncthreads();
         GSR_T_TICK(7)
-        // per staged splat: recombine the moments into the nine (ten) gradient sums (in place) ...
-        if (tid < n) {
-            const float4 A = s.a[tid];
-            const float4 Dc = s.d[tid];
-            // the slices of the waves that had this splat on their list (the compaction's own test)
+        // per staged splat of the batch: add the slices of the waves that had it on their list (the compaction's own test),
+        // recombine the moments into the nine (ten) gradient sums ...
+        float* out = &s.wt[0][0];              // (the transposition buffers are idle between the walks: 4 x 1088 floats)
+        if (tid < taken) {
+            const uint32_t id = s.ids[tid], qmask = s.qm[tid];
+            const SplatRec sr = load_splat_rec(rec, id);
             float m[10] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < 4; w++)
-                if (((__float_as_uint(Dc.w) >> w) & 1u) && (total - base - tid) <= s.wmax[w]) {
+                if (((qmask >> w) & 1u) && (total - base - tid) <= s.wmax[w]) {
+                    const float* row = s.acc[w][s.inv[w][tid]];
 #pragma unroll
-                    for (int c = 0; c < 10; c++) m[c] += s.acc[w][tid][c];
+                    for (int c = 0; c < 10; c++) m[c] += row[c];
                 }
-            float* q = s.acc[0][tid];
-            q[0] = m[0]; q[1] = m[1]; q[2] = m[2];
             const float M0 = m[4], Mu = m[5], Mv = m[6], Muu = m[7], Muv = m[8], Mvv = m[9];
-            const float dz = m[3];
-            const float mu = A.x - cx0, mv = A.y - cy0, ca = Dc.x, cb = Dc.y, cc = Dc.z, o = A.z;
+            const float mu = sr.x - cx0, mv = sr.y - cy0, ca = sr.a, cb = sr.b, cc = sr.c, o = sr.opacity;
             const float sdx = mu * M0 - Mu, sdy = mv * M0 - Mv;
             const float sxx = mu * mu * M0 - 2.f * mu * Mu + Muu;
             const float sxy = mu * mv * M0 - mu * Mv - mv * Mu + Muv;
             const float syy = mv * mv * M0 - 2.f * mv * Mv + Mvv;
+            float* q = out + tid * 10;
+            q[0] = m[0]; q[1] = m[1]; q[2] = m[2];
             q[3] = -o * ddelx_dx * (ca * sdx + cb * sdy);
             q[4] = -o * ddely_dy * (cc * sdy + cb * sdx);
             q[5] = -0.5f * o * sxx;
             q[6] = -0.5f * o * sxy;
             q[7] = -0.5f * o * syy;
             q[8] = M0;
-            q[9] = dz;
+            q[9] = m[3];
         }
         __syncthreads();
         // ... and flush them: one lane per (splat, quantity), so that a wave instruction adds runs of consecutive
         // floats of the packed per-Gaussian records instead of 64 scattered rows
-        for (int e = tid; e < n * 10; e += GSR_BLOCK) {
+        for (int e = tid; e < taken * 10; e += GSR_BLOCK) {
             const int j = e / 10, q = e - j * 10;
-            const float val = s.acc[0][j][q];
-            if (val != 0.f && (POSE || q != 9)) atomicAdd(&acc[(size_t)__float_as_uint(s.a[j].w) * GSR_ACC_STRIDE + q], val);
+            const float val = out[e];
+            if (val != 0.f && (POSE || q != 9)) atomicAdd(&acc[(size_t)s.ids[j] * GSR_ACC_STRIDE + q], val);
         }
         GSR_T_TICK(8)
     }
     if (tile_work != nullptr) {      // this tile's weight in the next iteration's launch order: its longest wave + a share for the staging
         if (lane == 0) s.wmax[wv] = walked;
         __syncthreads();
-        if (tid == 0) tile_work[tile] = (uint32_t)(max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3])) + 2 * ((total + GSR_BWD_BATCH - 1) / GSR_BWD_BATCH));
+        if (tid == 0) tile_work[tile] = (uint32_t)(max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3])) + 2 * nbatch);
     }
     GSR_T_FLUSH(16)
 }
