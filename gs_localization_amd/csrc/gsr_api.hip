@@ -186,11 +186,15 @@ size_t carve_bin(char* base, int R, Bin& b)
 
 // bin-by-tile path: sorted index lists (same place as Bin::vals, which is all the backward reads) + the bins
 struct BinLocal { uint32_t* vals; unsigned long long* bins; };
-size_t carve_bin_local(char* base, int ntiles, BinLocal& b)
+// Entries per bin.  What a saturating tile needs behind its depth bound is a few hundred; a tile WITHOUT a bound (one that does not
+// saturate) gets its complete list, ~R / tiles: room for four times the in-LDS sort's limit while that is affordable
+// (96 KB per tile: 118 MB at 640x480).
+int bin_capacity(int ntiles) { return ntiles <= 4096 ? 4 * GSR_LSORT_CAP : GSR_LSORT_CAP; }
+size_t carve_bin_local(char* base, int ntiles, int cap, BinLocal& b)
 {
     Carver c(base);
-    b.vals = c.take<uint32_t>((size_t)ntiles * GSR_LSORT_CAP);
-    b.bins = c.take<unsigned long long>((size_t)ntiles * GSR_LSORT_CAP);
+    b.vals = c.take<uint32_t>((size_t)ntiles * cap);
+    b.bins = c.take<unsigned long long>((size_t)ntiles * cap);
     return c.size();
 }
 
@@ -525,13 +529,15 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     pa.zbc = zb_prev ? im.zbc[sp.parity ^ 1] : nullptr; pa.sbx = im.sbx;
     float* zbc_next = (sp.mode != 0) ? im.zbc[sp.parity] : nullptr;
     BinLocal bl{nullptr, nullptr};
+    const int bin_cap = (sp.state != nullptr) ? GSR_LSORT_CAP : bin_capacity(ntiles);      // (a caller's state buffer holds 2048-entry bins)
+    pa.bin_cap = bin_cap;
     if (by_tile) {
         // (with a state buffer the unsorted bins live there and the per-call buffer only holds the sorted lists)
-        const size_t lbytes = state_bins ? (size_t)ntiles * GSR_LSORT_CAP * sizeof(uint32_t) : carve_bin_local(nullptr, ntiles, bl);
+        const size_t lbytes = state_bins ? (size_t)ntiles * GSR_LSORT_CAP * sizeof(uint32_t) : carve_bin_local(nullptr, ntiles, bin_cap, bl);
         char* lptr = (char*)binning_buffer(binning_ctx, lbytes);
         if (!lptr) return fail(GSR_E_ALLOC, "binning buffer callback returned NULL%s", "");
         if (state_bins) { bl.vals = reinterpret_cast<uint32_t*>(lptr); bl.bins = state_bins; }
-        else carve_bin_local(lptr, ntiles, bl);
+        else carve_bin_local(lptr, ntiles, bin_cap, bl);
     }
     pa.tile_cursor = by_tile ? im.tile_cursor : nullptr;
     pa.bins = bl.bins;
@@ -634,7 +640,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
 #define GSR_FWD_ARGS im.ranges, by_tile ? bl.vals : b.vals, by_tile ? (const unsigned long long*)bl.bins : (const unsigned long long*)b.keys, \
                      by_tile ? im.tile_cursor : im.tile_offset, width, height, gx, ntiles, (const float*)g.rec, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
                      zb_next, zb_prev, cx.guard.poison ? const_cast<uint32_t*>(cx.guard.poison) : im.fail, \
-                     sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], balanced ? im.tile_work[0] : (uint32_t*)nullptr
+                     sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], balanced ? im.tile_work[0] : (uint32_t*)nullptr, bin_cap
         if (by_tile) {
             if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
             else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
@@ -1144,7 +1150,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                            reinterpret_cast<uint32_t*>(bb.ptr), (const unsigned long long*)nullptr, (uint32_t*)nullptr, a->width,
                            a->height, gx, gx * gy, (const float*)g.rec, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
                            a->n_touched, (float*)nullptr, (const float*)nullptr, im.fail, 1.f, 0.f, (float*)nullptr,
-                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0);
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
     HIPCHK(hipStreamSynchronize(st));

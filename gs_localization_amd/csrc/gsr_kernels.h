@@ -220,7 +220,7 @@ struct PreArgs {
     int zbc_lds;                           // k_preprocess: number of superblock bounds staged in LDS (0: read from global)
     int lean;                              // k_preprocess: radii of this forward are not an output (see the kernel)
     // bin-by-tile path (nullable): per-tile append cursors and fixed-capacity bins of (depth bits << 32 | index)
-    uint32_t* tile_cursor; unsigned long long* bins;
+    uint32_t* tile_cursor; unsigned long long* bins; int bin_cap;      // (bin_cap: entries per bin)
     int* n_touched;          // nullable: cleared here (one 4-B store per Gaussian) instead of by a separate memset
     LoopGuard guard;
     const float* means; const float* scales; float mod; const float* rots; const float* opac;
@@ -501,7 +501,7 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
             for (int k = 0; k < 4; k++) {
                 // behind everything this tile needed last iteration (+ margin): speculatively dropped
                 f_in[k] = f_in[k] && f_z[k] <= f_zb[k] * a.zb_mul + a.zb_add;
-                f_pos[k] = GSR_LSORT_CAP;
+                f_pos[k] = (uint32_t)a.bin_cap;
                 if (f_in[k]) {
                     atomicAdd(&ocnt[f_src[k]], 1u);
                     f_pos[k] = atomicAdd(&a.tile_cursor[f_tile[k] * GSR_CURSOR_STRIDE], 1u);
@@ -509,8 +509,8 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
             }
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (f_pos[k] < GSR_LSORT_CAP)
-                    a.bins[(size_t)f_tile[k] * GSR_LSORT_CAP + f_pos[k]] = ((unsigned long long)__float_as_uint(f_z[k]) << 32) | f_id[k];
+                if (f_pos[k] < (uint32_t)a.bin_cap)
+                    a.bins[(size_t)f_tile[k] * a.bin_cap + f_pos[k]] = ((unsigned long long)__float_as_uint(f_z[k]) << 32) | f_id[k];
         }
 #undef GSR_PERM_F
 #undef GSR_PERM_I
@@ -527,8 +527,8 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
                     cnt++;
                     const int tile = y * a.gx + x;
                     const uint32_t pos = atomicAdd(&a.tile_cursor[tile * GSR_CURSOR_STRIDE], 1u);
-                    if (pos < GSR_LSORT_CAP)
-                        a.bins[(size_t)tile * GSR_LSORT_CAP + pos] = ((unsigned long long)__float_as_uint(zv) << 32) | (uint32_t)idx;
+                    if (pos < (uint32_t)a.bin_cap)
+                        a.bins[(size_t)tile * a.bin_cap + pos] = ((unsigned long long)__float_as_uint(zv) << 32) | (uint32_t)idx;
                 }
         }
     }
@@ -566,8 +566,8 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
                     if (pass) {
                         const int tile = y * a.gx + x;
                         const uint32_t pos = atomicAdd(&a.tile_cursor[tile * GSR_CURSOR_STRIDE], 1u);
-                        if (pos < GSR_LSORT_CAP)
-                            a.bins[(size_t)tile * GSR_LSORT_CAP + pos] = ((unsigned long long)__float_as_uint(bz) << 32) | bidx;
+                        if (pos < (uint32_t)a.bin_cap)
+                            a.bins[(size_t)tile * a.bin_cap + pos] = ((unsigned long long)__float_as_uint(bz) << 32) | bidx;
                     }
                 }
                 c_cnt += (uint32_t)__popcll(__ballot(pass));
@@ -1284,7 +1284,7 @@ __device__ __forceinline__ void select_slice(const unsigned long long* __restric
 // (5 workgroups per CU keep every tile of a 640x480 image resident in one round: 96 registers.  The slice-ordering variant
 // with the n_touched counters needs a few more and gets 4 per CU rather than spilling.)
 template <bool TOUCHED, int LIST>
-__global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT) ? 4 : 5) k_render_fwd(uint2* __restrict__ ranges,
+__global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED) ? 4 : 5) k_render_fwd(uint2* __restrict__ ranges,
                                                           uint32_t* __restrict__ point_list,
                                                           const unsigned long long* __restrict__ bins,
                                                           uint32_t* __restrict__ tile_cursor,
@@ -1296,7 +1296,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
                                                           const float* __restrict__ zb_used, uint32_t* __restrict__ fail,
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
                                                           int sbx, FusedLoss fl, const uint32_t* __restrict__ tile_order,
-                                                          uint32_t* __restrict__ tile_work)
+                                                          uint32_t* __restrict__ tile_work, int bin_cap)
 {
     // (tile_cursor: GSR_LIST_BINS the per-tile append cursors; GSR_LIST_EXACT the tile_offset array of k_tile_scan)
     __shared__ SplatLDS s;
@@ -1318,7 +1318,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
         __shared__ uint32_t s_cursor;
         if (tid == 0) { s_cursor = tile_cursor[tile * GSR_CURSOR_STRIDE]; tile_cursor[tile * GSR_CURSOR_STRIDE] = 0u; }
         __syncthreads();
-        range.x = (uint32_t)tile * GSR_LSORT_CAP;
+        range.x = (uint32_t)tile * (uint32_t)bin_cap;
         range.y = range.x + s_cursor;
     } else if (LIST == GSR_LIST_EXACT) {
         range.x = tile_cursor[tile];
@@ -1327,13 +1327,17 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
     const int total = (int)(range.y - range.x);
     int walked = 0, overhead = 0;      // -> tile_work: groups of eight this wave composited; staging / ordering cost in the same unit
 
-    if (LIST == GSR_LIST_BINS) {
-        // this tile's bin arrives unsorted: order it by (depth bits, index) in LDS (bitonic network), keep it there
+    // A bin longer than the in-LDS sort takes (a tile that does not saturate -- the edge of the scene's coverage, a
+    // semi-transparent region -- has no depth bound and gets its complete list) is ordered lazily, slice by slice, like a
+    // segment of the exact bins; only a bin that overflowed its capacity fails the forward.
+    const bool lazy = (LIST == GSR_LIST_EXACT) || (LIST == GSR_LIST_BINS && total > GSR_LSORT_CAP);
+    if (LIST == GSR_LIST_BINS && total > bin_cap) {          // block-uniform: entries were dropped; the host redoes the forward with complete lists
+        if (tid == 0) atomicAdd(fail, 0x10000u);
+        return;
+    }
+    if (LIST == GSR_LIST_BINS && !lazy) {
+        // this tile's bin arrives unsorted: order it by (depth bits, index) in LDS, keep it there
         // for the staging below and write the sorted indices (and the tile's range) back for the backward pass
-        if (total > GSR_LSORT_CAP) {          // block-uniform: give up, the host redoes the forward with complete lists
-            if (tid == 0) atomicAdd(fail, 0x10000u);
-            return;
-        }
         if (tid == 0) ranges[tile] = range;
         if (total <= GSR_BLOCK) {          // one key per thread: register sort + merge by counting (the common case of the native loop)
             GSR_T_TICK(0)
@@ -1368,7 +1372,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
     int consumed = 0, m = total;
     unsigned long long slice_lo = 0ull;
   for (bool first_slice = true;; first_slice = false) {
-    if (LIST == GSR_LIST_EXACT) {
+    if (lazy) {
         if (consumed >= total) break;
         if (__syncthreads_and(T <= 0.f)) break;          // every pixel of the tile has terminated: the rest is never ordered
         const unsigned long long* seg = bins + range.x;
@@ -1504,13 +1508,13 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST == GSR_LIST_EXACT)
         }
         GSR_T_TICK(5)
     }
-    if (LIST != GSR_LIST_EXACT) break;
+    if (!lazy) break;
     consumed += m;
     __syncthreads();          // (the next slice overwrites s_keys and the staging buffers)
   }
     // GSR_LIST_EXACT: the tile's range is what has been ORDERED -- all that the backward pass and a re-compositing of
     // these lists (n_touched) can need: no pixel looks beyond the slice in which the last one terminated
-    if (LIST == GSR_LIST_EXACT && tid == 0) ranges[tile] = make_uint2(range.x, range.x + (uint32_t)min(consumed, total));
+    if (lazy && tid == 0) ranges[tile] = make_uint2(range.x, range.x + (uint32_t)min(consumed, total));
     GSR_T_TICK(6)
     if (tile_work != nullptr) {      // this tile's weight in the next iteration's launch order
         __shared__ int s_walk[4];

@@ -431,13 +431,13 @@ def test_speculation_on_a_half_empty_scene():
 
 def test_converged_exit_with_an_overflowing_speculative_bin_returns_a_verified_render():
     """ADVICE (round 1): when the loop stops on convergence, the forward it hands back was enqueued speculatively; if that
-    speculation failed -- here: a tile whose bin overflows GSR_LSORT_CAP, so the compositing kernel gives up on it -- the
-    returned images must still be those of a complete render at the final pose.  Dense faint splats make every tile's list
-    longer than 2048 even after the depth bounds (nothing saturates, so nothing can be dropped); a huge threshold makes the
-    first update 'converge'."""
+    speculation failed -- here: a tile whose bin overflows its capacity (8192 entries at this size), so the compositing kernel
+    gives up on it -- the returned images must still be those of a complete render at the final pose.  Dense faint splats
+    make every tile's list longer than that even after the depth bounds (nothing saturates, so nothing can be dropped); a huge
+    threshold makes the first update 'converge'."""
     from tests import replay as PL
-    sc = S.small(P=40000, W=64, H=48, sh_degree=1, seed=43, scale_med=0.12)
-    sc.opacities[:] = np.clip(sc.opacities * 0.02, 0.004, 0.02)
+    sc = S.small(P=250000, W=64, H=48, sh_degree=1, seed=43, scale_med=0.12)
+    sc.opacities[:] = np.clip(sc.opacities * 0.01, 0.005, 0.01)
     model, bg, view, init = _setup(sc, seed=5)
     fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
     vp = view()
@@ -500,3 +500,25 @@ def test_lean_preprocess_changes_nothing(monkeypatch, env):
     assert torch.allclose(R1, R2, atol=2e-6) and torch.allclose(T1, T2, atol=2e-6)
     assert torch.allclose(c1, c2, atol=5e-4) and torch.allclose(d1, d2, atol=5e-3)
     assert (n1 - n2).abs().sum().item() <= max(2, 1e-4 * n2.sum().item())
+
+
+def test_long_bins_are_ordered_lazily():
+    """A tile that does not saturate has no depth bound and gets its complete list in the native loop's bin; up to the bin
+    capacity (8192 entries here) such a bin is ordered slice by slice instead of failing the speculation: same poses and images
+    as the loop without speculation, no forward redone, although most tiles carry lists of a few thousand entries."""
+    from tests import replay as PL
+    sc = S.small(P=45000, W=64, H=48, sh_degree=1, seed=47, scale_med=0.1)
+    sc.opacities[:] = np.clip(sc.opacities * 0.01, 0.002, 0.01)
+    model, bg, view, init = _setup(sc, seed=7)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    out = {}
+    for spec in (False, True):
+        R, T, info = fr.refine(view(), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=6, stop_on_converged=False,
+                               speculative=spec, count_instances=True)
+        out[spec] = (R.clone(), T.clone(), info, fr.color.clone(), fr.alpha.clone())
+    ntiles = 4 * 3
+    assert out[True][2]["num_rendered"] > 2048 * ntiles and out[True][2]["num_rendered"] <= 8192 * ntiles      # long bins, within capacity
+    assert float(out[True][4].max()) < 0.999                                                                     # nothing saturates
+    assert out[True][2]["fallbacks"] == 0
+    assert torch.allclose(out[True][0], out[False][0], atol=2e-6) and torch.allclose(out[True][1], out[False][1], atol=2e-6)
+    assert torch.allclose(out[True][3], out[False][3], atol=5e-4)
