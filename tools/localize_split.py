@@ -8,7 +8,7 @@ handed out on demand from a shared counter (gs_localization_amd/shard.py -- a fr
 flight per GPU on the native loop (`FusedRefiner`), ONE gather of the result rows at the end (RCCL over xGMI).
 
 No dataset exists here: the split is synthetic -- a map of --gaussians Gaussians (S-800k-chess by default), --frames query
-poses scattered 0.3 m / 10 deg around the map's reference view, each observed as the map's own render at that pose, each
+poses scattered --spread (0.1 m / 4 deg) around the map's reference view, each observed as the map's own render at that pose, each
 started from an initial pose up to 5 cm / 3 deg off (a different amount per frame, so that iteration counts differ).
 
   python tools/localize_split.py --frames 64                                   # one GPU
@@ -38,6 +38,10 @@ def main():
     ap.add_argument("--assign", choices=("queue", "static"), default="queue")
     ap.add_argument("--chunk", type=int, default=1, help="frames claimed per trip to the shared counter")
     ap.add_argument("--iters", type=int, default=50)
+    ap.add_argument("--spread", type=float, nargs=2, default=(0.1, 4.0), metavar=("METRES", "DEGREES"),
+                    help="query poses are scattered this far around the map's reference view.  The synthetic map is the frustum-shaped "
+                         "cloud seen from that view: 0.3 m / 10 deg already looks past its edge (most tiles never saturate, no depth "
+                         "bounds, complete lists: the stress case)")
     args = ap.parse_args()
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     if world > 1:
@@ -59,7 +63,7 @@ def main():
     def frame_setup(f):
         """ground-truth pose, observation and initial pose of query frame f (the same on whichever rank draws it)"""
         rng = np.random.default_rng(7000 + f)
-        gt = S.se3_exp(np.concatenate([rng.uniform(-0.3, 0.3, 3), np.radians(rng.uniform(-10, 10, 3))]))
+        gt = S.se3_exp(np.concatenate([rng.uniform(-args.spread[0], args.spread[0], 3), np.radians(rng.uniform(-args.spread[1], args.spread[1], 3))]))
         off = rng.uniform(0.1, 1.0)                 # 0.5 ... 5 cm and 0.3 ... 3 deg: some frames converge early, some never
         dt = rng.normal(size=3); dt *= 0.05 * off / np.linalg.norm(dt)
         dr = rng.normal(size=3); dr *= math.radians(3.0 * off) / np.linalg.norm(dr)
@@ -114,7 +118,7 @@ def main():
         res = res.cpu()
         m = shard.median_errors(res)
         pr = torch.stack(per_rank).cpu().numpy()
-        out = {"workload": f"synthetic test split: {args.frames} query frames, {args.gaussians} Gaussians, 640x480, up to {args.iters} iterations each",
+        out = {"workload": f"synthetic test split: {args.frames} query frames within {args.spread[0]} m / {args.spread[1]} deg, {args.gaussians} Gaussians, 640x480, up to {args.iters} iterations each",
                "n_gpus": world, "frames_in_flight_per_gpu": F, "assign": args.assign, "frames_per_s": args.frames / wall,
                "iterations_per_s": float(res[:, 3].sum()) / wall, "wall_s": wall,
                "median_trans_err_cm": 100.0 * m["median_t_m"], "median_rot_err_deg": m["median_R_deg"], "recall": m["recall"],
