@@ -277,7 +277,9 @@ def main():
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
             traffic = tj.get(dominant)
-            loop_kernels = ("preprocess_fwd", "sh_color", "render_fwd", "render_bwd", "preprocess_bwd")
+            # (a steady-state iteration of the native loop: k_preprocess_lean with the SH colour inside -- maps below 200 k Gaussians:
+            # k_preprocess + k_sh_color --, the two compositing kernels, the chain-rule kernel)
+            loop_kernels = (("preprocess_lean",) if "preprocess_lean" in tj else ("preprocess_fwd", "sh_color")) + ("render_fwd", "render_bwd", "preprocess_bwd")
             if all(k in tj for k in loop_kernels):
                 iter_traffic = sum(tj[k] for k in loop_kernels)
         except Exception:

@@ -552,7 +552,10 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     {
         ProfScope ps(K_PREPROCESS, st);
         pa.zbc_lds = (pa.zbc != nullptr && im.nsb <= 4096) ? im.nsb : 0;
-        pa.lean = (cx.lean && cx.native_loop && by_tile && pa.cov_all == 0 && pa.zbc_lds > 0 && scales != nullptr && getenv("GSR_NO_LEAN") == nullptr) ? 1 : 0;
+        // (k_preprocess_lean trades parallelism for instruction count -- a wave per 256 Gaussians: it pays from a few hundred thousand
+        // Gaussians on; a 50 k map keeps the one-lane-per-Gaussian kernel: 8 270 against 7 015 it/s)
+        pa.lean = (cx.lean && cx.native_loop && by_tile && pa.cov_all == 0 && pa.zbc_lds > 0 && scales != nullptr && P >= 200000 &&
+                   getenv("GSR_NO_LEAN") == nullptr) ? 1 : 0;
         pa.sh_here = (pa.lean && colors_precomp == nullptr && M <= 16 && getenv("GSR_SH_SEPARATE") == nullptr) ? 1 : 0;
         // (the exact-bin path has the preprocess zero the per-tile counters, all copies: at least that many threads)
         pa.ntiles = ntiles * im.copies;

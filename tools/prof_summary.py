@@ -21,7 +21,7 @@ from collections import defaultdict
 csv.field_size_limit(sys.maxsize)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-OURS = {"k_preprocess(": "preprocess_fwd", "k_sh_color": "sh_color", "k_tile_count": "tile_count", "k_tile_scan": "tile_scan",
+OURS = {"k_preprocess_lean": "preprocess_lean", "k_preprocess(": "preprocess_fwd", "k_sh_color": "sh_color", "k_tile_count": "tile_count", "k_tile_scan": "tile_scan",
         "k_tile_emit": "tile_emit", "k_tracking_loss": "tracking_loss", "k_pose_step": "pose_step", "k_pose_init": "pose_step",
         "k_tau_finish": "pose_step", "k_preprocess_bwd": "preprocess_bwd", "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd"}
 
