@@ -13,6 +13,8 @@ vp = PL.make_frame(sc, model, dev, bg)
 init = PL.perturbed_start(1000, device=dev)
 fr = PL.FusedRefiner(model, H, W, device=dev)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 60
-fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=iters, stop_on_converged=False, count_instances=True)
+# (LOOP_PLAIN=1: without depth speculation -- complete lists, the exact-bin path, in every iteration)
+fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=iters, stop_on_converged=False, count_instances=True,
+          speculative=not os.environ.get("LOOP_PLAIN"))
 torch.cuda.synchronize()
 print("iterations", iters, fr.last_info)
