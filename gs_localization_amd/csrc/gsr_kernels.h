@@ -1602,9 +1602,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
 // K7  per-tile back-to-front gradient (replaces backward.cu:399-581 renderCUDA).
 // Same tile / lane mapping as K6.  Differences from the reference's schedule (results identical up to fp32
 // summation order):  (1) the walk starts at the tile's deepest contributor (max n_contrib), not at the end of
-// the tile list;  (2) the per-splat sums are contracted over the 64 pixels of a wave on the matrix cores, merged
-// across the 4 waves with LDS float atomics, and leave the workgroup as ONE global atomic per (tile, splat,
-// quantity) instead of one per (pixel, splat, quantity).
+// the tile list;  (2) the per-splat sums are contracted over the 64 pixels of a wave on the matrix cores, written to
+// per-wave slices in LDS, added up once per batch, and leave the workgroup as ONE global atomic per (tile, splat,
+// quantity) instead of one per (pixel, splat, quantity);  (3) a list entry's splat record is read with scalar loads
+// (GSR_REC_*), not staged in LDS.
 // ---------------------------------------------------------------------------------------------
 // packed per-Gaussian accumulator record of K7 (floats): 0-2 dL/dcolor, 3-4 dL/dmean2D, 5-7 dL/dconic (a,b,c),
 // 8 dL/dopacity, 9 dL/dz (pose package), 10-11 padding
@@ -1619,8 +1620,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
 // That is a dense contraction  S[splat][col] = sum_pixel W[splat][pixel] * g[pixel][col]  (10 columns), which
 // goes to the matrix cores: v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain, MI355X_MICROARCH.md) with
 // A = 8 splats x {W1,W2} (16 rows) by 4 pixels, B = 4 pixels by 16 columns, 16 steps per 64-pixel wave.
-// The weights are transposed through a per-wave LDS buffer ([pixel][17] floats, conflict-free both ways);
-// the 16 B operands per lane are pixel constants and stay in registers for the whole kernel.
+// The weights are transposed through a per-wave LDS buffer (GSR_WT_REGION below); the 16 B operands per lane are pixel
+// constants and stay in registers for the whole kernel.
 //
 // Like K6 the walk is a dependent chain whose length is (entries) x (instructions per entry), so the per-entry
 // body is branch-free: a splat that is skipped for this pixel (behind its last contributor, alpha < 1/255 or
