@@ -522,6 +522,8 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     // (count -> scan -> emit) and the compositing kernel orders each tile's segment lazily.  (More than 65 536 tiles: the
     // fixed-capacity bins would not fit; such a forward bins exactly and only records bounds.)
     const bool by_tile = sp.mode == 1 && ntiles <= 65536;
+    // (complete lists: the compositing kernel evaluates the colours of the splats it stages, see LazySH)
+    pa.lazy_sh = (!by_tile && colors_precomp == nullptr && M <= 16 && !debug && getenv("GSR_SH_EAGER") == nullptr) ? 1 : 0;
     const float* zb_prev = by_tile ? im.zb[sp.parity ^ 1] : nullptr;
     float* zb_next = (sp.mode != 0) ? im.zb[sp.parity] : nullptr;
     pa.zb = zb_prev;
@@ -572,9 +574,9 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     // SH colours only feed the compositing kernel: fork them onto the side stream, join before K6.  (Not on the
     // by-tile path: without the binning chain there is nothing latency-bound to hide them under, and the
     // fork/join costs more than it gains -- measured 0.466 vs 0.434 ms per iteration.)
-    SideLease side_lease(colors_precomp == nullptr && !debug && !by_tile, dev);
+    SideLease side_lease(colors_precomp == nullptr && !debug && !by_tile && !pa.lazy_sh, dev);
     Side* side = side_lease.sd;
-    if (colors_precomp == nullptr && !pa.sh_here) {
+    if (colors_precomp == nullptr && !pa.sh_here && !pa.lazy_sh) {
         if (side) {
             HIPCHK(hipEventRecord(side->fork, st));
             HIPCHK(hipStreamWaitEvent(side->st, side->fork, 0));
@@ -643,7 +645,8 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
 #define GSR_FWD_ARGS im.ranges, by_tile ? bl.vals : b.vals, by_tile ? (const unsigned long long*)bl.bins : (const unsigned long long*)b.keys, \
                      by_tile ? im.tile_cursor : im.tile_offset, width, height, gx, ntiles, (const float*)g.rec, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
                      zb_next, zb_prev, cx.guard.poison ? const_cast<uint32_t*>(cx.guard.poison) : im.fail, \
-                     sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], balanced ? im.tile_work[0] : (uint32_t*)nullptr, bin_cap
+                     sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], balanced ? im.tile_work[0] : (uint32_t*)nullptr, bin_cap, \
+                     LazySH{pa.lazy_sh ? shs : nullptr, means3D, cam_pos, D, M, g.clamped, g.rec}
         if (by_tile) {
             if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
             else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
@@ -1153,7 +1156,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                            reinterpret_cast<uint32_t*>(bb.ptr), (const unsigned long long*)nullptr, (uint32_t*)nullptr, a->width,
                            a->height, gx, gx * gy, (const float*)g.rec, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
                            a->n_touched, (float*)nullptr, (const float*)nullptr, im.fail, 1.f, 0.f, (float*)nullptr,
-                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0);
+                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{});
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
     HIPCHK(hipStreamSynchronize(st));

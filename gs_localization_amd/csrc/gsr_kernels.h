@@ -232,6 +232,7 @@ struct PreArgs {
     uint8_t* clamped; uint32_t* tiles_touched; ushort4* rects;
     int cov_all;             // k_preprocess: compute and store cov3D for every Gaussian, culled or not (see there)
     int sh_here;             // k_preprocess_lean: evaluate the survivors' SH colour itself (no k_sh_color launch behind it)
+    int lazy_sh;             // complete lists: no k_sh_color either -- k_render_fwd evaluates the colours of the splats it stages (LazySH)
     SurvLists surv;          // work lists: k_preprocess appends, k_sh_color walks (ids nullable: no lists kept)
     // Native loop only (dirty nullable): a Gaussian that is NOT a survivor of this forward gets no gradient this iteration;
     // whatever the previous iteration left in its rows is cleared here, by the one kernel that visits every Gaussian anyway
@@ -288,6 +289,37 @@ __device__ __forceinline__ float3 sh_to_rgb(int deg, int M, float3 pos, const fl
 __device__ __forceinline__ bool sh16_vector_ok(int M, const float* shs)
 {
     return M == 16 && ((reinterpret_cast<uintptr_t>(shs) & 15u) == 0);
+}
+// sh_to_rgb for a lane that reads its own 16-coefficient row from global memory (the lean preprocess, lazy colours in the
+// compositing kernel): the 192 B arrive as 16-B loads, six at a time, and are consumed in coefficient order (same sums as
+// sh_to_rgb); half a row in flight keeps the register footprint of the callers' hot loops intact.
+__device__ __forceinline__ float3 sh_row16_to_rgb(int deg, float3 pos, const float* campos, const float4* __restrict__ row4, uint8_t& clamp_bits)
+{
+    const float vx = pos.x - campos[0], vy = pos.y - campos[1], vz = pos.z - campos[2];
+    const float len = sqrtf(vx * vx + vy * vy + vz * vz);
+    float B[16];
+    sh_basis(deg, vx / len, vy / len, vz / len, B);
+    const int nk = (deg + 1) * (deg + 1);
+    float c[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        float4 v[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) v[i] = row4[6 * half + i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            const float e[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int idx = 4 * (6 * half + i) + j, k = idx / 3, ch = idx - 3 * k;
+                if (k < nk) c[ch] += B[k] * e[j];
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    c[0] += 0.5f; c[1] += 0.5f; c[2] += 0.5f;
+    clamp_bits = (uint8_t)((c[0] < 0 ? 1 : 0) | (c[1] < 0 ? 2 : 0) | (c[2] < 0 ? 4 : 0));
+    return make_float3(fmaxf(c[0], 0.0f), fmaxf(c[1], 0.0f), fmaxf(c[2], 0.0f));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -408,7 +440,8 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
                         float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * GSR_REC_STRIDE);
                         rec[0] = make_float4(pix.x, pix.y, (-GSR_LOG2E) * conic.y, (-0.5f * GSR_LOG2E) * conic.z);
                         rec[1] = make_float4((-0.5f * GSR_LOG2E) * conic.x, opacity, pview.z, 0.f);
-                        if (a.colors_pre != nullptr) rec[2] = make_float4(a.colors_pre[3 * idx], a.colors_pre[3 * idx + 1], a.colors_pre[3 * idx + 2], 0.f);
+                        if (a.colors_pre != nullptr) rec[2] = make_float4(a.colors_pre[3 * idx], a.colors_pre[3 * idx + 1], a.colors_pre[3 * idx + 2], 1.f);
+                        else if (a.lazy_sh) rec[2] = make_float4(0.f, 0.f, 0.f, 0.f);      // (.w = 0: colour not evaluated yet, see LazySH)
                     }
                     a.rects[idx] = make_ushort4((unsigned short)x0, (unsigned short)y0, (unsigned short)x1, (unsigned short)y1);
                     // exact count of tiles this splat can change
@@ -600,17 +633,10 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
     // k_preprocess_lean (a.sh_here): the wave's lanes are dense with survivors, so their colour is evaluated right here -- one
     // kernel (and one chain of dependent memory phases) less per iteration than with k_sh_color behind this one.
     if (FLAT && a.sh_here && surv) {
-        float row[48];
-        if (sh16_vector_ok(a.M, a.shs)) {
-            const float4* r4 = reinterpret_cast<const float4*>(a.shs) + (size_t)idx * GSR_SH16_ROW4;
-#pragma unroll
-            for (int i = 0; i < GSR_SH16_ROW4; i++) { const float4 v = r4[i]; row[4 * i] = v.x; row[4 * i + 1] = v.y; row[4 * i + 2] = v.z; row[4 * i + 3] = v.w; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 48; i++) row[i] = (i < a.M * 3) ? a.shs[(size_t)idx * a.M * 3 + i] : 0.f;
-        }
         uint8_t cb;
-        const float3 c = sh_to_rgb(a.D, a.M, p, a.campos, row, cb);
+        const float3 c = sh16_vector_ok(a.M, a.shs)
+                             ? sh_row16_to_rgb(a.D, p, a.campos, reinterpret_cast<const float4*>(a.shs) + (size_t)idx * GSR_SH16_ROW4, cb)
+                             : sh_to_rgb(a.D, a.M, p, a.campos, a.shs + (size_t)idx * a.M * 3, cb);
         reinterpret_cast<float4*>(a.rec + (size_t)idx * GSR_REC_STRIDE)[2] = make_float4(c.x, c.y, c.z, 0.f);
         a.clamped[idx] = cb;
     }
@@ -1131,6 +1157,15 @@ __device__ __forceinline__ uint32_t quadrant_mask(float mx, float my, float A, f
 // kernel's epilogue, where the pixel's colour, depth and opacity are still in registers -- one launch and one pass over
 // the images less per iteration.  Partial sums go to GSR_LOSS_SHARDS x {loss, dL/da, dL/db} accumulators (64 B apart),
 // which the pose step adds up and clears.  out == nullptr: not fused (drop-in packages, gsr_tracking_loss).
+// Complete lists (every forward without depth bounds: training, the first iteration of a refinement, the plain loop): all
+// ~770 k visible Gaussians of S-1M-640 are binned, but the compositing kernel only ever stages the front of each tile's list
+// (~380 k entries, 10 % of the instances).  Evaluating SH -> RGB for all of them beforehand read 148 MB of SH rows and cost
+// 55 us per iteration (3 370 against 4 140 it/s without it), more than any other kernel of that path.  Instead the staging
+// phase of k_render_fwd<.., GSR_LIST_EXACT> evaluates the colour of a splat the first time some tile stages it and leaves it
+// in the splat's record (.w of the colour quad = 1: evaluated) for the other tiles and for the backward pass; `clamped` too.
+// Two tiles staging the same splat at the same time both evaluate it and write the same values.  shs == nullptr: not lazy.
+struct LazySH { const float* shs; const float* means; const float* campos; int D, M; uint8_t* clamped; float* rec; };
+
 #define GSR_LOSS_SHARDS 16
 struct FusedLoss {
     const float* gt_image; const float* gt_depth; const uint8_t* grad_mask; const float* exposure;
@@ -1289,14 +1324,14 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                                                           const unsigned long long* __restrict__ bins,
                                                           uint32_t* __restrict__ tile_cursor,
                                                           int W, int H, int gx,
-                                                          int ntiles, const float* __restrict__ rec, const float* __restrict__ bg,
+                                                          int ntiles, const float* rec, const float* __restrict__ bg,
                                                           float* __restrict__ out_color, float* __restrict__ out_depth,
                                                           float* __restrict__ out_alpha, uint32_t* __restrict__ n_contrib,
                                                           int* __restrict__ n_touched, float* __restrict__ zb_next,
                                                           const float* __restrict__ zb_used, uint32_t* __restrict__ fail,
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
                                                           int sbx, FusedLoss fl, const uint32_t* __restrict__ tile_order,
-                                                          uint32_t* __restrict__ tile_work, int bin_cap)
+                                                          uint32_t* __restrict__ tile_work, int bin_cap, LazySH lz)
 {
     // (tile_cursor: GSR_LIST_BINS the per-tile append cursors; GSR_LIST_EXACT the tile_offset array of k_tile_scan)
     __shared__ SplatLDS s;
@@ -1410,7 +1445,18 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         if (tid < n) {
             const uint32_t id = (LIST != GSR_LIST_SORTED) ? (uint32_t)s_keys[base + tid] : point_list[range.x + base + tid];
             const float4* r = reinterpret_cast<const float4*>(rec + (size_t)id * GSR_REC_STRIDE);
-            const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+            const float4 r0 = r[0], r1 = r[1];
+            float4 r2 = r[2];
+            if (LIST == GSR_LIST_EXACT && lz.shs != nullptr && r2.w == 0.f) {      // first tile to stage this splat: its colour (LazySH)
+                uint8_t cb;
+                const float3 pm = make_float3(lz.means[3 * (size_t)id], lz.means[3 * (size_t)id + 1], lz.means[3 * (size_t)id + 2]);
+                const float3 c = sh16_vector_ok(lz.M, lz.shs)
+                                     ? sh_row16_to_rgb(lz.D, pm, lz.campos, reinterpret_cast<const float4*>(lz.shs) + (size_t)id * GSR_SH16_ROW4, cb)
+                                     : sh_to_rgb(lz.D, lz.M, pm, lz.campos, lz.shs + (size_t)id * lz.M * 3, cb);
+                r2 = make_float4(c.x, c.y, c.z, 1.f);
+                reinterpret_cast<float4*>(lz.rec + (size_t)id * GSR_REC_STRIDE)[2] = r2;
+                lz.clamped[id] = cb;
+            }
             const uint32_t qm = quadrant_mask(r0.x, r0.y, r1.x * (-2.0f / GSR_LOG2E), r0.z * (-1.0f / GSR_LOG2E), r0.w * (-2.0f / GSR_LOG2E), r1.y,
                                               tx * GSR_TILE, ty * GSR_TILE);
             s.a[tid] = r0;
