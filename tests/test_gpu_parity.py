@@ -351,3 +351,25 @@ def test_work_lists_with_clustered_survivors(pose):
     _check_forward(o, f, pose)
     _check_grads(g, go, pose, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
     assert not np.any(g["sh"][hidden]) and not np.any(g["means3D"][hidden])
+
+
+@pytest.mark.parametrize("pose", [False, True])
+def test_lazy_sh_colours_change_nothing(monkeypatch, pose):
+    """A forward with complete lists evaluates SH -> RGB lazily, in the compositing kernel's staging, for the splats some tile
+    really stages (LazySH); GSR_SH_EAGER brings back k_sh_color for every visible Gaussian.  Same sums in the same order: the
+    images are bit-identical, the gradients agree to the noise of the fp32 atomics, clamped channels included."""
+    sc = S.small(P=30000, W=112, H=80, sh_degree=3, seed=31, scale_med=0.06)
+    sc.shs[:, 0, :] -= 1.2          # push a good part of the colours below zero: clamped channels
+    cam = U.scene_inputs(sc, W2C)
+    grads = U.random_grads(sc, seed=31)
+    o1, g1 = U.hip_run(sc, cam, grads, pose=pose)
+    monkeypatch.setenv("GSR_SH_EAGER", "1")
+    o2, g2 = U.hip_run(sc, cam, grads, pose=pose)
+    monkeypatch.delenv("GSR_SH_EAGER")
+    for k in ("color", "depth", "alpha", "radii"):
+        assert np.array_equal(o1[k], o2[k]), k
+    for k in ("means3D", "opacities", "sh", "scales", "rotations"):
+        assert U.rel_l1(g1[k], g2[k]) <= 2e-6, k
+    f, go = U.oracle_run(sc, cam, grads, pose=pose)
+    _check_forward(o1, f, pose)
+    _check_grads(g1, go, pose, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
