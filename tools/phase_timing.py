@@ -18,12 +18,12 @@ fr = PL.FusedRefiner(model, H, W, device=dev)
 nk = lib.gsr_profile_kernel_count(); names = [lib.gsr_profile_kernel_name(i).decode() for i in range(nk)]
 ITERS = 40
 nk = lib.gsr_profile_kernel_count(); names = [lib.gsr_profile_kernel_name(i).decode() for i in range(nk)]
-fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False, speculative=True)
+fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False, speculative=not os.environ.get("LOOP_PLAIN"))
 torch.cuda.synchronize()
 out = (C.c_ulonglong * 48)()
 assert lib.gsr_debug_timing(out) == 0, "not a GSR_TIMING build"
 lib.gsr_profile_enable((1 << nk) - 1)
-fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=ITERS, stop_on_converged=False, speculative=True)
+fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=ITERS, stop_on_converged=False, speculative=not os.environ.get("LOOP_PLAIN"))
 torch.cuda.synchronize()
 ms = (C.c_double * nk)(); cnt = (C.c_longlong * nk)(); lib.gsr_profile_collect(ms, cnt); lib.gsr_profile_enable(0)
 print({names[i]: (round(ms[i] / max(cnt[i], 1), 4), cnt[i]) for i in range(nk)})
