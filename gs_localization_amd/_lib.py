@@ -69,7 +69,15 @@ class RefineArgs(C.Structure):
         ("lr", _f), ("converged_threshold", _f), ("max_iters", _i), ("stop_on_converged", _i),
         ("speculative", _i), ("bound_margin_mul", _f), ("bound_margin_add", _f), ("stats_out", C.POINTER(_i)),
         ("warm_state", C.POINTER(_i)), ("carry_state", C.POINTER(_i)), ("stream", _vp),
+        ("flags", C.c_uint), ("lean_min_P", _i),
+        ("init_R", _vp), ("init_T", _vp), ("init_exposure_a", _vp), ("init_exposure_b", _vp),
+        ("pose_state_host", C.POINTER(_f)),
     ]
+
+
+# the GSR_ABI_VERSION these ctypes mirrors (SpecState, RefineArgs, the pose-state layout) were written for
+ABI_VERSION = 2
+REFINE_NO_LEAN, REFINE_SH_SEPARATE, REFINE_NO_BALANCE, REFINE_LOG_REDO = 1, 2, 4, 8
 
 
 POSE_STATE_FLOATS = 96
@@ -78,6 +86,7 @@ SIGNATURES.update({
     "gsr_pose_init": (_i, [_vp, _vp, _vp]),
     "gsr_pose_step": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp]),
     "gsr_refine": (_i, [C.POINTER(RefineArgs), C.POINTER(_i), C.POINTER(_i)]),
+    "gsr_debug_lean_check": (_i, [C.POINTER(RefineArgs), C.POINTER(C.c_longlong)]),
 })
 
 _lib = None
@@ -100,6 +109,10 @@ def load():
             fn = getattr(lib, name)
             fn.restype = res
             fn.argtypes = args
+        got = lib.gsr_abi_version()
+        if got != ABI_VERSION:      # a stale .so would read these structs with another layout
+            raise GsrError(f"{LIB_PATH} has ABI version {got}, this package was written for {ABI_VERSION}: rebuild it "
+                           "(python -c 'import __graft_entry__ as g; g.build()')")
         _lib = lib
     return _lib
 

@@ -106,6 +106,7 @@ struct Geom {   // per-Gaussian state carried from forward to backward
     uint32_t* tiles_touched; ushort4* rects; float* acc; double* tau_acc; uint8_t* dirty;
     gsr::SurvLists surv;      // work lists of the forward's survivors (k_preprocess -> k_sh_color, k_preprocess_bwd)
     float* rec;               // packed splat records (GSR_REC_*), P + 1
+    float* lam;               // per-Gaussian bound on sqrt(lambda_max(Sigma)) (PreArgs::lam), valid whenever cov3D holds every covariance
 };
 size_t carve_geom(char* base, int P, Geom& g)
 {
@@ -122,6 +123,7 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.surv.cap = gsr::surv_cap(P);
     g.surv.n = c.take<uint32_t>((size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE);
     g.surv.ids = c.take<uint32_t>((size_t)GSR_SURV_LISTS * g.surv.cap);
+    g.lam = c.take<float>(n);
     return c.size();
 }
 
@@ -216,6 +218,10 @@ struct PassCtx {
     gsr::PoseStepArgs fold = {};
     gsr::GradRows rows = {};       // native loop: the gradient tensors the kernels keep consistent through the dirty bits
     bool balance = false;          // native loop: compositing kernels launched in work-balanced tile order (tile_order_from_work)
+    unsigned flags = 0;            // GSR_REFINE_* diagnostics of the caller
+    int lean_min_P = 200000;       // k_preprocess_lean from this many Gaussians on
+    int* n_lean = nullptr;         // counts the forwards that ran k_preprocess_lean (gsr_refine_args.stats_out[2])
+    bool sh_eager = false;         // diagnostics (debug bit 1 of gsr_forward): k_sh_color for every visible Gaussian instead of lazy colours
 };
 // gsr_forward_speculative: bounds, flags, cursors and the unsorted bins live in the caller's persistent state buffer
 // instead of the per-call image / binning buffers (which then only hold what the backward reads)
@@ -283,7 +289,7 @@ struct SideLease {          // RAII: returns the Side to its device's pool
 };
 
 // Pinned status slots + events of one gsr_refine call, pooled for the same reason.
-struct LoopCtx { float* h_status = nullptr; };      // 2 slots x 8 floats of pinned, device-visible host memory
+struct LoopCtx { float* h_status = nullptr; };      // pinned, device-visible host memory: 2 slots x 8 floats + a copy of the pose state
 struct LoopCtxPool { std::mutex mu; std::vector<LoopCtx*> free_list; };
 LoopCtxPool g_loop_ctx;
 LoopCtx* loop_ctx_acquire()
@@ -293,7 +299,7 @@ LoopCtx* loop_ctx_acquire()
         if (!g_loop_ctx.free_list.empty()) { LoopCtx* c = g_loop_ctx.free_list.back(); g_loop_ctx.free_list.pop_back(); return c; }
     }
     LoopCtx* c = new LoopCtx();
-    if (hipHostMalloc((void**)&c->h_status, 2 * 8 * sizeof(float)) != hipSuccess) {
+    if (hipHostMalloc((void**)&c->h_status, (2 * 8 + GSR_POSE_STATE_FLOATS) * sizeof(float)) != hipSuccess) {
         (void)hipGetLastError();
         delete c;
         return nullptr;
@@ -504,7 +510,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     if (cx.cov_cache == 2 && cov3D_precomp == nullptr) pa.cov3D_pre = g.cov3D;
     pa.view = viewmatrix; pa.proj = projmatrix; pa.campos = cam_pos;
     pa.tanx = tan_fovx; pa.tany = tan_fovy; pa.fx = focal_x; pa.fy = focal_y;
-    pa.radii = radii; pa.cov3D = g.cov3D;
+    pa.radii = radii; pa.cov3D = g.cov3D; pa.lam = g.lam;
     pa.clamped = g.clamped; pa.tiles_touched = g.tiles_touched; pa.rects = g.rects;
     pa.guard = cx.guard;
     pa.n_touched = n_touched;
@@ -523,7 +529,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     // fixed-capacity bins would not fit; such a forward bins exactly and only records bounds.)
     const bool by_tile = sp.mode == 1 && ntiles <= 65536;
     // (complete lists: the compositing kernel evaluates the colours of the splats it stages, see LazySH)
-    pa.lazy_sh = (!by_tile && colors_precomp == nullptr && M <= 16 && !debug && getenv("GSR_SH_EAGER") == nullptr) ? 1 : 0;
+    pa.lazy_sh = (!by_tile && colors_precomp == nullptr && M <= 16 && !debug && !cx.sh_eager) ? 1 : 0;
     const float* zb_prev = by_tile ? im.zb[sp.parity ^ 1] : nullptr;
     float* zb_next = (sp.mode != 0) ? im.zb[sp.parity] : nullptr;
     pa.zb = zb_prev;
@@ -556,9 +562,11 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         pa.zbc_lds = (pa.zbc != nullptr && im.nsb <= 4096) ? im.nsb : 0;
         // (k_preprocess_lean trades parallelism for instruction count -- a wave per 256 Gaussians: it pays from a few hundred thousand
         // Gaussians on; a 50 k map keeps the one-lane-per-Gaussian kernel: 8 270 against 7 015 it/s)
-        pa.lean = (cx.lean && cx.native_loop && by_tile && pa.cov_all == 0 && pa.zbc_lds > 0 && scales != nullptr && P >= 200000 &&
-                   getenv("GSR_NO_LEAN") == nullptr) ? 1 : 0;
-        pa.sh_here = (pa.lean && colors_precomp == nullptr && M <= 16 && getenv("GSR_SH_SEPARATE") == nullptr) ? 1 : 0;
+        // (cov_cache == 2: the workspace holds every Gaussian's covariance AND the extent bound the conservative test reads)
+        pa.lean = (cx.lean && cx.native_loop && by_tile && cx.cov_cache == 2 && pa.cov_all == 0 && pa.zbc_lds > 0 && scales != nullptr &&
+                   cov3D_precomp == nullptr && P >= cx.lean_min_P && !(cx.flags & GSR_REFINE_NO_LEAN)) ? 1 : 0;
+        pa.sh_here = (pa.lean && colors_precomp == nullptr && M <= 16 && !(cx.flags & GSR_REFINE_SH_SEPARATE)) ? 1 : 0;
+        if (pa.lean && cx.n_lean) ++*cx.n_lean;
         // (the exact-bin path has the preprocess zero the per-tile counters, all copies: at least that many threads)
         pa.ntiles = ntiles * im.copies;
         // (the first two workgroups also compute the launch orders of the compositing kernels: there must be two)
@@ -785,7 +793,15 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
 
 }  // namespace
 
-int gsr_forward(GSR_FWD_PARAMS) { return forward_impl(PassCtx{}, GSR_FWD_PASS); }
+// (debug bit 1, value 2: diagnostics -- SH colours of every visible Gaussian up front instead of lazily in the compositing kernel)
+static PassCtx dropin_ctx(int& debug)
+{
+    PassCtx cx;
+    cx.sh_eager = (debug & 2) != 0;
+    debug &= 1;
+    return cx;
+}
+int gsr_forward(GSR_FWD_PARAMS) { const PassCtx cx = dropin_ctx(debug); return forward_impl(cx, GSR_FWD_PASS); }
 
 size_t gsr_spec_state_bytes(int width, int height)
 {
@@ -796,15 +812,15 @@ size_t gsr_spec_state_bytes(int width, int height)
 int gsr_forward_speculative(gsr_spec_state* s, GSR_FWD_PARAMS)
 {
     using namespace gsr;
+    PassCtx cx = dropin_ctx(debug);
     if (!s || !s->device_buffer || P <= 0 || width <= 0 || height <= 0) {
         if (s) { s->valid = 0; s->last_speculative = 0; }
-        return forward_impl(PassCtx{}, GSR_FWD_PASS);
+        return forward_impl(cx, GSR_FWD_PASS);
     }
     if (s->width == 0 && s->height == 0) { s->width = width; s->height = height; }
     if (s->width != width || s->height != height)
         return fail(GSR_E_INVALID, "gsr_forward_speculative: the state was sized for another image size%s", "");
     hipStream_t st = (hipStream_t)stream;
-    PassCtx cx;
     cx.spec.state = static_cast<char*>(s->device_buffer);
     s->last_speculative = 0;
     const int next = (s->parity ^ 1) & 1;          // the bound buffer this forward writes
@@ -831,7 +847,7 @@ int gsr_forward_speculative(gsr_spec_state* s, GSR_FWD_PARAMS)
     return R;
 }
 
-int gsr_backward(GSR_BWD_PARAMS) { return backward_impl(PassCtx{}, GSR_BWD_PASS); }
+int gsr_backward(GSR_BWD_PARAMS) { debug &= 1; return backward_impl(PassCtx{}, GSR_BWD_PASS); }
 
 int gsr_tracking_loss(int width, int height, const float* image, const float* depth, const float* opacity,
                       const float* gt_image, const float* gt_depth, const uint8_t* grad_mask, const float* exposure,
@@ -962,6 +978,10 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     cx.native_loop = true;
     cx.guard.poison = poison;
     cx.guard.conv = a->stop_on_converged ? ps + GSR_PS_CONV : nullptr;
+    cx.flags = a->flags;
+    if (a->lean_min_P > 0) cx.lean_min_P = a->lean_min_P;
+    int n_lean = 0;
+    cx.n_lean = &n_lean;
     // warm start: the previous call on this workspace left its last bounds in buffer warm_buf (0 / 1); iteration 0 must
     // READ that buffer, i.e. write the other one
     const int warm_buf = (a->speculative && a->warm_state && (*a->warm_state == 1 || *a->warm_state == 2)) ? *a->warm_state - 1 : -1;
@@ -992,6 +1012,11 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             HIPCHK(hipMemsetAsync(gg.acc, 0, Pn * GSR_ACC_STRIDE * sizeof(float), st));
             HIPCHK(hipMemsetAsync(gg.dirty, 0, Pn, st));
         }
+        if (a->init_R) {
+            if (!a->init_T || !a->init_exposure_a || !a->init_exposure_b) return fail(GSR_E_INVALID, "gsr_refine: init_R, init_T, init_exposure_a/b go together%s", "");
+            hipLaunchKernelGGL(k_pose_load, dim3(1), dim3(64), 0, st, ps, a->init_R, a->init_T, a->init_exposure_a, a->init_exposure_b, a->projmatrix_raw);
+            { const int debug = 0; LAUNCHCHK("k_pose_load"); }
+        }
         HIPCHK(hipMemsetAsync(ps + GSR_PS_CONV, 0, 5 * sizeof(float), st));      // converged, loss, |tau|, poison, ticket
         HIPCHK(hipMemsetAsync(gg.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));      // then kept clean by the pose step
         HIPCHK(hipMemsetAsync(gg.surv.n, 0, (size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE * sizeof(uint32_t), st));      // ... and the work-list counters too
@@ -1004,7 +1029,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         HIPCHK(hipMemsetAsync(im0.fail, 0, im0.clear_words * sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(im0.loss_shards, 0, GSR_LOSS_SHARDS * 16 * sizeof(float), st));
         HIPCHK(hipMemsetAsync(im0.tile_work[0], 0, (size_t)(im0.tile_work[1] - im0.tile_work[0]) * 2 * sizeof(uint32_t), st));
-        cx.balance = getenv("GSR_NO_BALANCE") == nullptr;
+        cx.balance = !(a->flags & GSR_REFINE_NO_BALANCE);
         HIPCHK(hipMemsetAsync(a->dL_dalpha, 0, (size_t)a->width * a->height * sizeof(float), st));      // no gradient flows into opacity
         cx.floss.gt_image = a->gt_image; cx.floss.gt_depth = a->gt_depth; cx.floss.grad_mask = a->grad_mask;
         cx.floss.exposure = ps + GSR_PS_PARAM + 6; cx.floss.opacity_thr = a->opacity_threshold; cx.floss.depth_w = a->depth_weight;
@@ -1084,7 +1109,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (pz != 0u) {
             n_fallbacks++;
             HIPCHK(hipStreamSynchronize(st));
-            if (getenv("GSR_DEBUG_TILES")) fprintf(stderr, "[gsr] iteration %d: speculation failed (0x%x), redone\n", it, pz);
+            if (a->flags & GSR_REFINE_LOG_REDO) fprintf(stderr, "[gsr] iteration %d: speculation failed (0x%x), redone\n", it, pz);
             HIPCHK(hipMemsetAsync(poison, 0, sizeof(uint32_t), st));
             HIPCHK(hipMemsetAsync(imv_loop.loss_shards, 0, GSR_LOSS_SHARDS * 16 * sizeof(float), st));      // the failed forward added to them
             int rc2 = enqueue(it, 2);
@@ -1159,7 +1184,9 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                            im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{});
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
+    if (a->pose_state_host) HIPCHK(hipMemcpyAsync(h_status + 16, ps, GSR_POSE_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    if (a->pose_state_host) memcpy(a->pose_state_host, h_status + 16, GSR_POSE_STATE_FLOATS * sizeof(float));
     ctx_lease.clean = true;
     if (a->carry_state) *a->carry_state = (cov_cached ? 2 : 0) | 1;
     if (a->warm_state) *a->warm_state = (a->speculative && last_enq >= 0) ? (par(last_enq) + 1) : 0;
@@ -1176,8 +1203,53 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             for (int i = 0; i < nt; i++) sum += (long long)(rg[i].y - rg[i].x);
             last_R = (int)sum;
         }
-        a->stats_out[0] = n_fallbacks; a->stats_out[1] = last_R;
+        a->stats_out[0] = n_fallbacks; a->stats_out[1] = last_R; a->stats_out[2] = n_lean; a->stats_out[3] = 0;
     }
+    return 0;
+}
+
+int gsr_debug_lean_check(const gsr_refine_args* a, long long out[5])
+{
+    using namespace gsr;
+    const int debug = 0;
+    if (!a || !out) return fail(GSR_E_INVALID, "gsr_debug_lean_check: NULL argument%s", "");
+    if (!a->warm_state || *a->warm_state < 1 || *a->warm_state > 2 || !a->carry_state || !(*a->carry_state & 2))
+        return fail(GSR_E_INVALID, "gsr_debug_lean_check: needs the warm_state / carry_state a speculative gsr_refine on these workspaces left%s", "");
+    if (!a->pose_state || !a->means3D || !a->opacities || !a->geometry_buffer || !a->image_buffer || a->P <= 0)
+        return fail(GSR_E_INVALID, "gsr_debug_lean_check: a required pointer is NULL%s", "");
+    hipStream_t st = (hipStream_t)a->stream;
+    int rc = select_device_of(a->pose_state);
+    if (rc != GSR_OK) return rc;
+    Geom g;
+    char* gptr = (char*)a->geometry_buffer(a->geometry_ctx, carve_geom(nullptr, a->P, g));
+    if (!gptr) return fail(GSR_E_ALLOC, "geometry buffer callback returned NULL%s", "");
+    carve_geom(gptr, a->P, g);
+    Img im;
+    char* iptr = (char*)a->image_buffer(a->image_ctx, carve_img(nullptr, a->width, a->height, im));
+    if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
+    carve_img(iptr, a->width, a->height, im);
+    const int buf = *a->warm_state - 1;          // the bounds the last forward recorded: what the next iteration would bin with
+    const float* ps = a->pose_state;
+    PreArgs pa = {};
+    pa.P = a->P; pa.W = a->width; pa.H = a->height;
+    pa.gx = (a->width + GSR_TILE - 1) / GSR_TILE; pa.gy = (a->height + GSR_TILE - 1) / GSR_TILE;
+    pa.means = a->means3D; pa.opac = a->opacities; pa.mod = a->scale_modifier;
+    pa.view = ps + GSR_PS_VIEW; pa.proj = ps + GSR_PS_PROJ; pa.campos = ps + GSR_PS_CAMPOS;
+    pa.tanx = a->tan_fovx; pa.tany = a->tan_fovy;
+    pa.fx = a->width / (2.0f * a->tan_fovx); pa.fy = a->height / (2.0f * a->tan_fovy);
+    pa.cov3D_pre = g.cov3D; pa.lam = g.lam;
+    pa.zb = im.zb[buf]; pa.zbc = im.zbc[buf]; pa.sbx = im.sbx;
+    pa.zb_mul = 1.05f; pa.zb_add = 0.05f;
+    unsigned long long* d = reinterpret_cast<unsigned long long*>(im.loss_shards);      // scratch (gsr_refine clears these words when it starts)
+    HIPCHK(hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), st));
+    hipLaunchKernelGGL(k_lean_check, dim3((a->P + GSR_BLOCK - 1) / GSR_BLOCK), dim3(GSR_BLOCK), 0, st, pa, d);
+    LAUNCHCHK("k_lean_check");
+    unsigned long long h[5] = {0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (int i = 0; i < 4; i++) out[i] = (long long)h[i];
+    out[4] = h[4] ? (long long)(0xFFFFFFFFull - h[4]) : -1;
     return 0;
 }
 

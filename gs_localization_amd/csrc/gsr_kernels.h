@@ -228,6 +228,8 @@ struct PreArgs {
     const float* view; const float* proj; const float* campos;
     float tanx, tany, fx, fy;
     int* radii; float* cov3D;
+    float* lam;              // [P] upper bound on sqrt(lambda_max(Sigma_3D)) of every Gaussian (scale_modifier included): written next to
+                             // cov3D by a cov_all forward, read by k_preprocess_lean's conservative test (nullable elsewhere)
     float* rec;              // packed splat records (GSR_REC_*), P + 1 of them
     uint8_t* clamped; uint32_t* tiles_touched; ushort4* rects;
     int cov_all;             // k_preprocess: compute and store cov3D for every Gaussian, culled or not (see there)
@@ -365,6 +367,60 @@ __device__ __forceinline__ void tile_order_from_work(const uint32_t* __restrict_
     }
 }
 
+// Upper bound on sqrt(lambda_max(Sigma)) of a symmetric positive semi-definite 3x3 matrix given by its six unique entries -- the
+// "largest scale" of a Gaussian whatever produced its covariance (a quaternion that is not normalised is used as given,
+// forward.cu:127: its R is not orthogonal and max(scale) says nothing about Sigma).  lambda_max <= min(Frobenius norm,
+// largest absolute row sum); exact for a diagonal Sigma, within 3^(1/4) of the truth in the worst case.  NaN / Inf propagate
+// (the caller then leaves the decision to the exact code).
+__device__ __forceinline__ float sigma_extent_bound(const float* c6)
+{
+    const float f2 = c6[0] * c6[0] + c6[3] * c6[3] + c6[5] * c6[5] + 2.f * (c6[1] * c6[1] + c6[2] * c6[2] + c6[4] * c6[4]);
+    const float r0 = fabsf(c6[0]) + fabsf(c6[1]) + fabsf(c6[2]), r1 = fabsf(c6[1]) + fabsf(c6[3]) + fabsf(c6[4]),
+                r2 = fabsf(c6[2]) + fabsf(c6[4]) + fabsf(c6[5]);
+    const float lmax = fminf(sqrtf(f2), fmaxf(r0, fmaxf(r1, r2)));
+    return sqrtf(lmax) * 1.00001f;
+}
+// Upper bound on |W|_2^2 of the view matrix's 3x3 block (1 for a rigid camera pose, up to rounding; the bound must hold for
+// whatever the caller passes): largest absolute row sum of W W^T.
+__device__ __forceinline__ float view_norm2_bound(const float* view)
+{
+    const float r0[3] = {view[0], view[4], view[8]}, r1[3] = {view[1], view[5], view[9]}, r2[3] = {view[2], view[6], view[10]};
+    const float g00 = r0[0] * r0[0] + r0[1] * r0[1] + r0[2] * r0[2], g11 = r1[0] * r1[0] + r1[1] * r1[1] + r1[2] * r1[2],
+                g22 = r2[0] * r2[0] + r2[1] * r2[1] + r2[2] * r2[2];
+    const float g01 = fabsf(r0[0] * r1[0] + r0[1] * r1[1] + r0[2] * r1[2]), g02 = fabsf(r0[0] * r2[0] + r0[1] * r2[1] + r0[2] * r2[2]),
+                g12 = fabsf(r1[0] * r2[0] + r1[1] * r2[1] + r1[2] * r2[2]);
+    return fmaxf(g00 + g01 + g02, fmaxf(g01 + g11 + g12, g02 + g12 + g22)) * 1.0001f;
+}
+// The conservative test of k_preprocess_lean for one Gaussian in front of the near plane (pview.z > 0.2): can it still be
+// binned into a tile under the current depth bounds?  false = settled (behind the bound of every superblock a rectangle
+// CONTAINING its exact tile rectangle overlaps, or that rectangle is empty).
+//   cov2D = J W Sigma W^T J^T  =>  lambda_max(cov2D + 0.3 I) <= |J|_F^2 |W|_2^2 lambda_max(Sigma) + 0.3, J the 2x3 perspective
+//   Jacobian with the clamped x/z, y/z of forward.cu:90-96; the reference's radius uses mid + sqrt(max(0.1, mid^2 - det)) <=
+//   lambda_max + sqrt(0.1); together <= jn2 wn2 seff^2 + 0.62 (0.95 here).  seff = sigma_extent_bound of the Gaussian's actual
+//   Sigma, wn2 = view_norm2_bound: no assumption on the quaternion, the scale modifier or the pose matrix.  Hardware
+//   reciprocals and fp32 pixel centres are covered by a 0.2 % + 0.2 % + two-pixel allowance; a bound of a million pixels or
+//   more (or NaN) is not trusted at all: candidate, the exact code decides.
+__device__ __forceinline__ bool lean_candidate(const PreArgs& a, float3 p, float3 pview, float seff, float wn2, const float* zbc)
+{
+    const float4 ph = xform4x4(p, a.proj);
+    const float pw = __builtin_amdgcn_rcpf(ph.w + 0.0000001f);
+    const float rz = __builtin_amdgcn_rcpf(pview.z);
+    const float ccx = fminf(1.3f * a.tanx, fmaxf(-1.3f * a.tanx, pview.x * rz));
+    const float ccy = fminf(1.3f * a.tany, fmaxf(-1.3f * a.tany, pview.y * rz));
+    const float jx = a.fx * rz, jy = a.fy * rz;
+    const float jn2 = (jx * jx * (1.f + ccx * ccx) + jy * jy * (1.f + ccy * ccy)) * wn2;
+    const float rb = ceilf(3.f * __builtin_amdgcn_sqrtf((jn2 * seff) * seff * 1.002f + 0.95f) * 1.002f) + 2.f;
+    if (!(rb < 1.0e6f)) return true;
+    const float pxf = ((ph.x * pw + 1.f) * (float)a.W - 1.f) * 0.5f, pyf = ((ph.y * pw + 1.f) * (float)a.H - 1.f) * 0.5f;
+    int x0, y0, x1, y1;
+    get_rect(pxf, pyf, (int)rb, a.gx, a.gy, x0, y0, x1, y1);
+    if ((x1 - x0) * (y1 - y0) == 0) return false;
+    float zc = 0.f;
+    for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
+        for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, zbc[sy * a.sbx + sx]);
+    return !(pview.z > zc * a.zb_mul + a.zb_add);
+}
+
 // Everything k_preprocess does for ONE Gaussian (lane) once its index is known: exact geometry, the bound tests, binning on
 // the by-tile path, survivor list, stale gradient rows.  Called with idx = the thread's global index (k_preprocess) or a
 // compacted candidate (k_preprocess_lean); wave-level pieces (cooperative walks, list appends) work on any 64 lanes.
@@ -404,6 +460,7 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
             cov3d_from_scale_rot(s3, a.mod, q4, cov6);
 #pragma unroll
             for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov6[i];
+            if (a.lam != nullptr) a.lam[idx] = sigma_extent_bound(cov6);
         }
         if (pview.z > 0.2f) {     // near cull (auxiliary.h:150)
             if (a.cov_all) {
@@ -674,9 +731,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 // touch and would leave k_preprocess with tiles_touched = 0 -- after ~1 000 instructions of exact geometry and footprint walk,
 // which a wave executes in full as soon as ONE of its 64 lanes needs it (two waves out of three on S-1M-640, for 1.7 lanes).
 // Here a wave looks at GSR_LEAN_PER_LANE x 64 Gaussians:
-//   1. every lane bounds its Gaussians' radii from their largest scale,
-//         lambda_max(cov2D + 0.3 I) <= |J|_F^2 s_max^2 + 0.92    (J: the perspective Jacobian with the clamped x/z, y/z of
-//         forward.cu:90-96; the reference's radius formula mid + sqrt(max(0.1, mid^2 - det)) <= trace + 0.32),
+//   1. every lane bounds its Gaussians' radii from a stored bound on their 3D extent (PreArgs::lam, lean_candidate):
+//         lambda_max(cov2D + 0.3 I) <= |J|_F^2 |W|_2^2 lambda_max(Sigma) + 0.3
 //      which gives a rectangle that contains the exact one; behind the bounds of all ITS superblocks => behind every tile's:
 //      settled, and nothing is written for such a Gaussian (neither radii nor tiles_touched are read in such an iteration:
 //      the consumers walk the survivor lists);
@@ -713,9 +769,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_lean(PreArgs a)
     for (int k = 0; k < GSR_LEAN_PER_LANE; k++) {
         const int idx = min(base + k * 64 + lane, a.P - 1);
         pk[k] = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
-        sk[k] = fmaxf(a.scales[3 * idx], fmaxf(a.scales[3 * idx + 1], a.scales[3 * idx + 2]));
+        sk[k] = a.lam[idx];
         dk[k] = (a.dirty != nullptr) ? a.dirty[idx] : (uint8_t)0;
     }
+    const float wn2 = view_norm2_bound(a.view);
 #pragma unroll
     for (int k = 0; k < GSR_LEAN_PER_LANE; k++) {
         const int idx = base + k * 64 + lane;
@@ -725,31 +782,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_lean(PreArgs a)
             if (frozen) { a.radii[idx] = 0; a.tiles_touched[idx] = 0; }
             const float3 p = pk[k];
             const float3 pview = xform4x3(p, a.view);
-            if (pview.z > 0.2f) {     // near cull (auxiliary.h:150)
-                cand = true;
-                // (hardware reciprocals and fp32 pixel centres: the radius bound carries a 0.2 % and two-pixel allowance)
-                const float4 ph = xform4x4(p, a.proj);
-                const float pw = __builtin_amdgcn_rcpf(ph.w + 0.0000001f);
-                const float smax = a.mod * sk[k];
-                const float rz = __builtin_amdgcn_rcpf(pview.z);
-                const float ccx = fminf(1.3f * a.tanx, fmaxf(-1.3f * a.tanx, pview.x * rz));
-                const float ccy = fminf(1.3f * a.tany, fmaxf(-1.3f * a.tany, pview.y * rz));
-                const float jx = a.fx * rz, jy = a.fy * rz;
-                const float jn2 = jx * jx * (1.f + ccx * ccx) + jy * jy * (1.f + ccy * ccy);
-                const float rb = fminf(1.0e6f, ceilf(3.f * __builtin_amdgcn_sqrtf((jn2 * smax) * smax * 1.002f + 0.95f) * 1.002f) + 2.f);
-                if (rb == rb && !frozen) {          // (NaN: the exact code decides)
-                    const float pxf = ((ph.x * pw + 1.f) * (float)a.W - 1.f) * 0.5f, pyf = ((ph.y * pw + 1.f) * (float)a.H - 1.f) * 0.5f;
-                    int x0, y0, x1, y1;
-                    get_rect(pxf, pyf, (int)rb, a.gx, a.gy, x0, y0, x1, y1);
-                    if ((x1 - x0) * (y1 - y0) == 0) cand = false;
-                    else {
-                        float zc = 0.f;
-                        for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
-                            for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, s_zbc[sy * a.sbx + sx]);
-                        cand = !(pview.z > zc * a.zb_mul + a.zb_add);
-                    }
-                }
-            }
+            if (pview.z > 0.2f)       // near cull (auxiliary.h:150); a frozen forward's radii are an output: nobody is settled
+                cand = frozen ? true : lean_candidate(a, p, pview, sk[k], wn2, s_zbc);
         }
         // (a Gaussian that is not even a candidate gets no gradient this iteration: see PreArgs::dirty; candidates: preprocess_one)
         if (a.dirty != nullptr && live && !cand && !frozen) {
@@ -769,6 +803,64 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_lean(PreArgs a)
     }
     GSR_T_TICK(2)
     GSR_T_FLUSH(32)
+}
+
+// Differential check of the conservative test (gsr_debug_lean_check; tests only).  One lane per Gaussian: lean_candidate with
+// the same inputs k_preprocess_lean gives it, and next to it the exact geometry of preprocess_one (same building blocks, same
+// expression order) with the exact footprint walk against the same per-tile bounds, counting instead of appending.
+// out[0] settled, out[1] candidates, out[2] Gaussians the exact walk bins somewhere, out[3] settled AND binned (violations),
+// out[4] smallest violating index + 1 (atomicMin on ~index is awkward: kept as max of ~idx).
+__global__ void __launch_bounds__(GSR_BLOCK) k_lean_check(PreArgs a, unsigned long long* out)
+{
+    const int idx = blockIdx.x * GSR_BLOCK + threadIdx.x;
+    if (idx >= a.P) return;
+    const float3 p = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
+    const float3 pview = xform4x3(p, a.view);
+    bool cand = false;
+    uint32_t cnt = 0;
+    if (pview.z > 0.2f) {
+        cand = lean_candidate(a, p, pview, a.lam[idx], view_norm2_bound(a.view), a.zbc);
+        const float4 ph = xform4x4(p, a.proj);
+        const float pw = 1.0f / (ph.w + 0.0000001f);
+        const float3 pproj = make_float3(ph.x * pw, ph.y * pw, ph.z * pw);
+        float cov6[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov6[i] = a.cov3D_pre[6 * (size_t)idx + i];
+        Cov2DTerms ct;
+        cov2d_terms(p, a.fx, a.fy, a.tanx, a.tany, cov6, a.view, ct);
+        const float cx = ct.cov.m[0][0] + 0.3f, cy = ct.cov.m[0][1], cz = ct.cov.m[1][1] + 0.3f;
+        const float det = (cx * cz - cy * cy);
+        if (det != 0.0f) {
+            const float det_inv = 1.f / det;
+            const float3 conic = make_float3(cz * det_inv, -cy * det_inv, cx * det_inv);
+            const float mid = 0.5f * (cx + cz);
+            const float lambda1 = mid + sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float lambda2 = mid - sqrtf(fmaxf(0.1f, mid * mid - det));
+            const float my_radius = ceilf(3.f * sqrtf(fmaxf(lambda1, lambda2)));
+            const float2 pix = make_float2(ndc2pix(pproj.x, a.W), ndc2pix(pproj.y, a.H));
+            int x0, y0, x1, y1;
+            get_rect(pix.x, pix.y, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
+            if ((x1 - x0) * (y1 - y0) != 0) {
+                const TileTest tt = make_tile_test(pix, conic, a.opac[idx]);
+                clip_rect(tt, x0, y0, x1, y1);
+                for (int y = y0; y < y1; y++) {
+                    int lo, hi;
+                    row_span(tt, y, x0, x1, lo, hi);
+                    for (int x = lo; x <= hi; x++)
+                        if (pview.z <= a.zb[y * a.gx + x] * a.zb_mul + a.zb_add) cnt++;
+                }
+            }
+        }
+    }
+    const bool bad = !cand && cnt != 0u;
+    const unsigned long long m_set = __ballot(!cand), m_cand = __ballot(cand), m_bin = __ballot(cnt != 0u), m_bad = __ballot(bad);
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&out[0], (unsigned long long)__popcll(m_set));
+        atomicAdd(&out[1], (unsigned long long)__popcll(m_cand));
+        atomicAdd(&out[2], (unsigned long long)__popcll(m_bin));
+        if (m_bad != 0ull) atomicAdd(&out[3], (unsigned long long)__popcll(m_bad));
+    }
+    if (bad) atomicMax(&out[4], (unsigned long long)(0xFFFFFFFFu - (uint32_t)idx));      // -> smallest violating index
 }
 
 // SH -> RGB (forward.cu:20-71) as its own kernel: it only needs the survivors of the geometry pass, so the host
@@ -2027,6 +2119,22 @@ __global__ void k_pose_init(float* st, const float* proj_raw)
         float R[9], T[3];
         for (int i = 0; i < 9; i++) R[i] = st[GSR_PS_R + i];
         for (int i = 0; i < 3; i++) T[i] = st[GSR_PS_T + i];
+        pose_write_camera(st, R, T, proj_raw);
+    }
+}
+
+// gsr_refine_args.init_*: the whole initial state from the caller's device tensors (zeros, R, T, exposure, camera) in one launch
+__global__ void k_pose_load(float* st, const float* R0, const float* T0, const float* ea, const float* eb, const float* proj_raw)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float R[9], T[3];
+        for (int i = 0; i < 9; i++) R[i] = R0[i];
+        for (int i = 0; i < 3; i++) T[i] = T0[i];
+        const float a = ea[0], b = eb[0];
+        for (int i = 0; i < GSR_PS_SIZE; i++) st[i] = 0.f;
+        for (int i = 0; i < 9; i++) st[GSR_PS_R + i] = R[i];
+        for (int i = 0; i < 3; i++) st[GSR_PS_T + i] = T[i];
+        st[GSR_PS_PARAM + 6] = a; st[GSR_PS_PARAM + 7] = b;
         pose_write_camera(st, R, T, proj_raw);
     }
 }

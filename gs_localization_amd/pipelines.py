@@ -101,53 +101,78 @@ class FusedRefiner:
         # writes them between two refine() calls -- so the second call need not zero-fill 300 MB of gradients again
         self._carry = C.c_int(0)
         self._carry_versions = None      # torch's in-place-modification counters of those tensors when the last call returned
+        self._conv_cache = {}
+        self._state_host = (C.c_float * _lib.POSE_STATE_FLOATS)()
 
     def _tensor_versions(self):
         ts = (self.scales, self.rots, self.g_m2d, self.g_conic, self.g_opac, self.g_col, self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot)
         return tuple(-1 if t is None else t._version for t in ts)
 
+    def _cached(self, slot, t, make):
+        """Per-refiner cache of the per-frame constants' device-side conversions (projection matrix, background, mask ...):
+        keyed by the source tensor's identity and in-place-modification counter, so a caller that hands in the same tensors for
+        every frame (the reference's scripts do: one projection matrix, one background per run) pays for them once."""
+        if not torch.is_tensor(t):          # (a numpy depth map: no modification counter to trust)
+            return make(t)
+        key = (id(t), t._version)
+        hit = self._conv_cache.get(slot)
+        if hit is None or hit[0] != key or hit[1] is not t:
+            hit = (key, t, make(t))
+            self._conv_cache[slot] = hit
+        return hit[2]
+
+    @staticmethod
+    def _env_flags():
+        """GSR_NO_LEAN / GSR_SH_SEPARATE / GSR_NO_BALANCE / GSR_DEBUG_TILES of the environment -> gsr_refine_args.flags (the
+        library itself reads no environment variable on this path)."""
+        import os
+        from . import _lib
+        env = os.environ
+        return ((_lib.REFINE_NO_LEAN if "GSR_NO_LEAN" in env else 0) | (_lib.REFINE_SH_SEPARATE if "GSR_SH_SEPARATE" in env else 0) |
+                (_lib.REFINE_NO_BALANCE if "GSR_NO_BALANCE" in env else 0) | (_lib.REFINE_LOG_REDO if "GSR_DEBUG_TILES" in env else 0))
+
     def refine(self, viewpoint, config, initial_R, initial_T, background, iters=50, lr=0.001, converged_threshold=1e-4,
-               stop_on_converged=True, speculative=True, bound_margin=None, warm_start=False, count_instances=False):
+               stop_on_converged=True, speculative=True, bound_margin=None, warm_start=None, count_instances=False,
+               scale_modifier=1.0, lean_min_P=0, flags=None):
         C, _lib = self._C, self._lib_mod
         dev = self.dev
         # speculative=True: exact optimisation (include/gsr.h, gsr_refine_args.speculative): ~9x fewer binned
-        # instances and ~7x fewer SH rows on S-1M-640.  Neutral for one frame at a time (one more host sync per
-        # iteration), +14 % with 4 frames in flight per GPU (median 2075 vs 1812 it/s on MI355X).
+        # instances and ~7x fewer SH rows on S-1M-640.
         viewpoint.update_RT(initial_R, initial_T)
-        # the pose state is filled on the device (four tiny copies, no host round trip: reading R, T and the exposure back to
-        # build it on the host cost four stream synchronisations per call)
-        with torch.no_grad():
-            self.state.zero_()
-            self.state[0:9].copy_(viewpoint.R.detach().reshape(-1))
-            self.state[9:12].copy_(viewpoint.T.detach().reshape(-1))
-            self.state[18:19].copy_(viewpoint.exposure_a.detach().reshape(-1))
-            self.state[19:20].copy_(viewpoint.exposure_b.detach().reshape(-1))
-        proj_raw = viewpoint.projection_matrix.detach().float().contiguous().to(dev)
-        gt_image = viewpoint.original_image.detach().float().contiguous().to(dev)
+        f32d = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        # the start pose goes to the library as the camera's own device tensors (gsr_refine_args.init_*: the pose state is
+        # built by one launch inside the call; reading R, T and the exposure back to build it on the host would cost four
+        # stream synchronisations, five tiny torch copies cost five launches)
+        R0, T0 = f32d(viewpoint.R), f32d(viewpoint.T)
+        ea0, eb0 = f32d(viewpoint.exposure_a).reshape(-1), f32d(viewpoint.exposure_b).reshape(-1)
+        proj_raw = self._cached("proj", viewpoint.projection_matrix, f32d)
+        gt_image = self._cached("gt", viewpoint.original_image, f32d)
         mono = bool(config["Training"]["monocular"])
         gt_depth = None
         if not mono:
-            gd = viewpoint.depth
-            gd = torch.from_numpy(gd) if not torch.is_tensor(gd) else gd
-            gt_depth = gd.to(dtype=torch.float32, device=dev).contiguous()
-        mask = viewpoint.grad_mask.to(device=dev).reshape(self.H, self.W).contiguous()
-        mask = mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)      # (a bool tensor already is one byte per pixel)
-        bg = background.detach().float().contiguous().to(dev)
+            gt_depth = self._cached("gtd", viewpoint.depth, lambda gd: (torch.from_numpy(gd) if not torch.is_tensor(gd) else gd).to(dtype=torch.float32, device=dev).contiguous())
+
+        def make_mask(m):
+            m = m.to(device=dev).reshape(self.H, self.W).contiguous()
+            return m.view(torch.uint8) if m.dtype == torch.bool else m.to(torch.uint8)      # (a bool tensor already is one byte per pixel)
+        mask = self._cached("mask", viewpoint.grad_mask, make_mask)
+        bg = self._cached("bg", background, f32d)
         alpha_cfg = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.98
         stream = torch.cuda.current_stream(dev).cuda_stream
         p = lambda t: None if t is None else t.data_ptr()
         a = _lib.RefineArgs()
         a.P, a.D, a.M = self.P, int(self.model.active_sh_degree), self.M
         a.means3D, a.shs, a.opacities, a.scales, a.rotations = map(p, (self.means3D, self.shs, self.opac, self.scales, self.rots))
-        a.scale_modifier = 1.0
-        # warm_start=True: frame sequences -- start speculating from the depth bounds the previous refine() of this
-        # refiner left behind instead of binning the first iteration with the global sorts (still verified, still exact)
-        if not warm_start:
+        a.scale_modifier = float(scale_modifier)
+        # warm_start: start speculating from the depth bounds the previous refine() of this refiner left behind instead of
+        # binning the first iteration completely (still verified on the device, still exact: stale bounds cost one redone
+        # forward).  None = whenever such bounds exist -- consecutive query frames of a sequence see almost the same depths.
+        if warm_start is False:
             self._warm.value = 0
         a.warm_state = C.pointer(self._warm)
         # (anything torch has written into them since -- fr.g_sh.zero_(), an optimiser stepping the scales -- shows in the
-        # tensors' version counters and withdraws the promise)
-        if self._carry_versions != self._tensor_versions():
+        # tensors' version counters and withdraws the promise; so does another scale modifier)
+        if self._carry_versions != self._tensor_versions() + (float(scale_modifier),):
             self._carry.value = 0
         a.carry_state = C.pointer(self._carry)
         a.width, a.height = self.W, self.H
@@ -158,6 +183,8 @@ class FusedRefiner:
         a.depth_weight = float(1 - alpha_cfg)
         a.monocular = int(mono)
         a.pose_state = p(self.state)
+        a.init_R, a.init_T, a.init_exposure_a, a.init_exposure_b = p(R0), p(T0), p(ea0), p(eb0)
+        a.pose_state_host = self._state_host
         a.out_color, a.out_depth, a.out_alpha, a.radii, a.n_touched = map(p, (self.color, self.depth, self.alpha, self.radii, self.n_touched))
         a.dL_dimage, a.dL_ddepth, a.dL_dalpha = map(p, (self.g_img, self.g_depth, self.g_alpha))
         a.dL_dmean2D, a.dL_dconic, a.dL_dopacity, a.dL_dcolor = map(p, (self.g_m2d, self.g_conic, self.g_opac, self.g_col))
@@ -172,26 +199,38 @@ class FusedRefiner:
         a.bound_margin_mul, a.bound_margin_add = (0.0, 0.0) if bound_margin is None else (float(bound_margin[0]), float(bound_margin[1]))
         # count_instances: also report how many tile instances the LAST forward binned (info["num_rendered"]; costs a copy of
         # the tile ranges to the host and a stream synchronisation)
-        stats = (C.c_int * 2)(0, 0 if count_instances else -1)
+        stats = (C.c_int * 4)(0, 0 if count_instances else -1, 0, 0)
         a.stats_out = stats
         a.stream = stream
+        a.flags = self._env_flags() if flags is None else int(flags)
+        a.lean_min_P = int(lean_min_P)
         n_done, conv = C.c_int(0), C.c_int(0)
         with torch.cuda.device(dev):
-            _lib.check(self.lib.gsr_pose_init(p(self.state), p(proj_raw), stream))
             rc = self.lib.gsr_refine(C.byref(a), C.byref(n_done), C.byref(conv))
             type(self.ws[0]).raise_pending(*self.ws)
             _lib.check(rc)
-        self._carry_versions = self._tensor_versions()
-        self._keep = (proj_raw, gt_image, gt_depth, mask, bg)        # alive until the stream has drained
-        s = self.state.cpu()
-        viewpoint.update_RT(s[0:9].reshape(3, 3).clone(), s[9:12].clone())
+        self._carry_versions = self._tensor_versions() + (float(scale_modifier),)
+        self._last_args = a                                          # (gsr_debug_lean_check takes the same struct)
+        self._keep = (R0, T0, ea0, eb0, proj_raw, gt_image, gt_depth, mask, bg)        # alive until the stream has drained
+        # the final pose came back with the call (gsr_refine_args.pose_state_host): no second blocking read
+        s = torch.tensor(self._state_host[0:40], dtype=torch.float32)
+        viewpoint.update_RT(s[0:9].reshape(3, 3).to(dev), s[9:12].to(dev))
         with torch.no_grad():
             viewpoint.exposure_a.fill_(float(s[18]))
             viewpoint.exposure_b.fill_(float(s[19]))
-        self.last_info = {"fallbacks": int(stats[0]), "num_rendered": int(stats[1])}
+        self.last_info = {"fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2])}
         return viewpoint.R, viewpoint.T, {"iters": n_done.value, "converged": bool(conv.value), "loss": float(s[38]),
-                                          "fallbacks": int(stats[0]), "num_rendered": int(stats[1]),
+                                          "fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]),
                                           "render": self.color, "depth": self.depth, "opacity": self.alpha}
+
+    def lean_check(self):
+        """gsr_debug_lean_check on the state the last refine() left (tests): (settled, candidates, binned by the exact walk,
+        violations, first violating index)."""
+        C, _lib = self._C, self._lib_mod
+        out = (C.c_longlong * 5)()
+        with torch.cuda.device(self.dev):
+            _lib.check(self.lib.gsr_debug_lean_check(C.byref(self._last_args), out))
+        return tuple(int(x) for x in out)
 
 
 def pose_errors(R_gt, t_gt, R, t):

@@ -190,7 +190,7 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
                                          float(rs.scale_modifier), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(view),
                                          _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
                                          int(bool(rs.prefiltered)), color.data_ptr(), depth.data_ptr(), alpha.data_ptr(),
-                                         _ptr(radii), int(bool(rs.debug)), _ptr(n_touched), stream)
+                                         _ptr(radii), int(bool(rs.debug)) | (2 if "GSR_SH_EAGER" in os.environ else 0), _ptr(n_touched), stream)
     _Workspace.raise_pending(geom, binning, img)          # e.g. torch's out-of-memory error, not a bare GSR_E_ALLOC
     num_rendered = _lib.check(rc)
     saved = (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom.t, binning.t, img.t, alpha,

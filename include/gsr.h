@@ -29,7 +29,10 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+/* 2: gsr_refine_args gained `carry_state` (round 2) and the fields behind `stream` (flags, lean_min_P); stats_out is int[4];
+ *    pose-state words 41 (ticket) and 84..87 (Adam beta products); gsr_debug_lean_check.  A caller must compare
+ *    gsr_abi_version() with the GSR_ABI_VERSION it was compiled against before it passes any struct. */
+#define GSR_ABI_VERSION 2
 
 enum {
     GSR_OK = 0,
@@ -54,6 +57,9 @@ typedef void* (*gsr_resize_fn)(void* ctx, size_t bytes);
  *   radii [P] int32 (fully written)
  *   n_touched [P] int32 nullable -- `diff_gaussian_rasterization_pose` 5th output
  *       (gs_localization/pipelines/tools/__init__.py:130); fully written when given.
+ *   debug: bit 0 = the reference's debug flag (synchronise and check after every kernel, auxiliary.h:166-173);
+ *       bit 1 (value 2) = diagnostics: SH colours of every visible Gaussian up front (k_sh_color) instead of lazily in the
+ *       compositing kernel -- same results (tests/test_gpu_parity.py); the library reads no environment variable here.
  * Returns num_rendered (the `int rendered` of rasterize_points.cu:82) or a negative error.
  * Performs one blocking device->host read of num_rendered, like rasterizer_impl.cu:282. */
 int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx,
@@ -252,8 +258,9 @@ typedef struct gsr_refine_args {
      * from the 2nd iteration on, tile instances deeper than bound_margin_mul * z + bound_margin_add, z = the
      * depth the tile had to look at in the previous iteration, are not binned.  0 disables. */
     int speculative; float bound_margin_mul, bound_margin_add;     /* mul <= 0: adaptive, (1+m) z + m with m in [0.01, 0.05] */
-    int* stats_out;             /* nullable host int[2]: number of redone forwards, last num_rendered (set [1] = -1 before the call
-                                 * to skip that count when the last forward binned by tile: it costs a device->host copy) */
+    int* stats_out;             /* nullable host int[4]: [0] number of redone forwards, [1] last num_rendered (set [1] = -1 before the
+                                 * call to skip that count when the last forward binned by tile: it costs a device->host copy),
+                                 * [2] forwards that ran k_preprocess_lean (the conservative-bound preprocess), [3] reserved (0) */
     /* Nullable HOST int, in/out: warm start of the speculation for frame sequences.  0 on input = the image workspace
      * holds no depth bounds (the first iteration bins with the global sorts).  Pass the value the previous call on the
      * SAME image workspace (same size) left here to start speculating from that frame's bounds at once -- consecutive
@@ -270,8 +277,35 @@ typedef struct gsr_refine_args {
      * Set to 0 when the call fails. */
     int* carry_state;
     void* stream;
+    /* ---- appended with GSR_ABI_VERSION 2 (new fields only ever go here, behind `stream`) ---- */
+    unsigned flags;             /* GSR_REFINE_* bits below; 0 = product behaviour */
+    int lean_min_P;             /* k_preprocess_lean is used from this many Gaussians on; 0 = default (200 000) */
+    /* Start pose given as the caller's own device tensors (nullable, all four or none): the call begins by building pose_state
+     * from them on the device -- zeros, R [9] row-major, T [3], exposure_a [1], exposure_b [1], then what gsr_pose_init does --
+     * in ONE launch, instead of the caller assembling the state with five tiny copies (viewpoint.update_RT + Camera properties,
+     * tools/camera_utils.py:124-158).  NULL: pose_state is taken as it is (gsr_pose_init already applied). */
+    const float* init_R; const float* init_T; const float* init_exposure_a; const float* init_exposure_b;
+    /* Nullable HOST float[GSR_POSE_STATE_FLOATS]: receives the final pose state (R, T, exposure, last loss ...) before the call
+     * returns -- the call ends with a stream synchronisation anyway, so this costs one small copy and saves the caller a second
+     * blocking read of the pose (update_RT of 7scenes_localize_full_dslam.py:84). */
+    float* pose_state_host;
 } gsr_refine_args;
+/* diagnostic switches of gsr_refine (tests / tools; the results must not depend on any of them) */
+#define GSR_REFINE_NO_LEAN     1u   /* k_preprocess + k_sh_color in every iteration instead of k_preprocess_lean */
+#define GSR_REFINE_SH_SEPARATE 2u   /* k_preprocess_lean without the fused SH colour (k_sh_color behind it) */
+#define GSR_REFINE_NO_BALANCE  4u   /* compositing kernels in XCD order instead of the work-balanced tile order */
+#define GSR_REFINE_LOG_REDO    8u   /* one stderr line per redone (failed-speculation) forward */
 int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
+
+/* Differential check of k_preprocess_lean's conservative test (tests only; replaces nothing in the reference -- it guards the
+ * kernel that stands in for forward.cu:155-256 + rasterizer_impl.cu:70-111 in the loop's steady state).  Call right after a
+ * gsr_refine that returned *warm_state != 0, with the same args (same workspaces): at the pose the state now holds, with the
+ * depth bounds that call left behind (what its NEXT iteration would have binned with), every Gaussian goes through
+ * (1) the conservative radius-bound test of k_preprocess_lean and (2) the exact geometry + exact footprint walk of k_preprocess
+ * against the same per-tile bounds.  out[0] = Gaussians the conservative test settles ("nothing to do"), out[1] = candidates it
+ * leaves, out[2] = Gaussians the exact walk bins into at least one tile, out[3] = VIOLATIONS: settled although the exact walk
+ * bins them (must be 0), out[4] = index of the first violation or -1.  Blocking. */
+int gsr_debug_lean_check(const gsr_refine_args* args, long long out[5]);
 
 /* Map on-disk rows -> device layout.  Replaces the per-property column gathering of
  * load_ply (gs_localization/pipelines/tools/gaussian_model.py:377-467; gaussian_splatting/scene/

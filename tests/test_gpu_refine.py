@@ -478,28 +478,7 @@ def test_work_balanced_tile_order_changes_nothing(monkeypatch):
     assert torch.allclose(c1, c2, atol=5e-4) and torch.allclose(d1, d2, atol=5e-3)
 
 
-@pytest.mark.parametrize("env", ["GSR_NO_LEAN", "GSR_SH_SEPARATE"])
-def test_lean_preprocess_changes_nothing(monkeypatch, env):
-    """Speculative iterations whose radii nobody can ask for run k_preprocess_lean (conservative radius bound for every
-    Gaussian, exact geometry + flattened footprint walk + SH colour for the few candidates, compacted per wave).  With the
-    kernel switched off (GSR_NO_LEAN: k_preprocess + k_sh_color for every iteration) or only its SH part (GSR_SH_SEPARATE) the
-    loop must take the same path: same poses, same final images, same n_touched."""
-    from tests import replay as PL
-    sc = S.small(P=90000, W=176, H=144, sh_degree=3, seed=14, scale_med=0.035)
-    model, bg, view, init = _setup(sc, seed=6)
-    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
-    out = {}
-    for name in ("lean", "off"):
-        if name == "off":
-            monkeypatch.setenv(env, "1")
-        R, T, info = fr.refine(view(), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=9, stop_on_converged=False)
-        out[name] = (R.clone(), T.clone(), fr.color.clone(), fr.depth.clone(), fr.n_touched.clone(), info)
-    monkeypatch.delenv(env)
-    (R1, T1, c1, d1, n1, i1), (R2, T2, c2, d2, n2, i2) = out["lean"], out["off"]
-    assert i1["fallbacks"] == 0 and i2["fallbacks"] == 0
-    assert torch.allclose(R1, R2, atol=2e-6) and torch.allclose(T1, T2, atol=2e-6)
-    assert torch.allclose(c1, c2, atol=5e-4) and torch.allclose(d1, d2, atol=5e-3)
-    assert (n1 - n2).abs().sum().item() <= max(2, 1e-4 * n2.sum().item())
+# (k_preprocess_lean: tests/test_gpu_lean.py)
 
 
 def test_long_bins_are_ordered_lazily():
