@@ -63,7 +63,8 @@ def algorithmic_bytes(P, V, R, R_eff, N, M, ntiles):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--steps", type=int, default=50,
+                    help="iterations per refinement call (the reference refines a frame for at most 50: 7scenes_localize_full_dslam.py:66)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--frames-in-flight", type=int, default=8, help="query frames refined concurrently per GPU")
@@ -77,6 +78,18 @@ def main():
     ap.add_argument("--device-index", type=int, default=None, help="GPU of this rank (default: LOCAL_RANK); rehearsals put every rank on GPU 0")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: start the N ranks here (one process per GPU, torch.distributed.run over
+        # RCCL), BEFORE anything touches the GPU in this process, hand their output through and exit with their status.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -88,6 +101,8 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -183,19 +198,26 @@ def main():
     # ---- (b) the native loop (gsr_refine), one frame at a time; per-kernel breakdown from a separate short run
     frs = [PL.FusedRefiner(model, H, W, device=dev, gaussian_grads=not args.pose_only) for _ in range(F)]
 
-    def native(f, iters, stop=False, speculative=True):
+    def native(f, iters, stop=False, speculative=True, warm=None):
+        # warm=None: the refiner's default -- a frame starts from the depth bounds its predecessor on this refiner left behind
+        # (consecutive frames of a sequence; here: the same frame again), verified on the device like every speculation
         return frs[f].refine(vps[f], config, inits[f][:3, :3].clone(), inits[f][:3, 3].clone(), background, iters=iters,
-                             stop_on_converged=stop, speculative=speculative)
+                             stop_on_converged=stop, speculative=speculative, warm_start=warm)
 
-    def timed_single(spec):
+    def timed_single(spec, iters=K, warm=None):
         native(0, Wm, speculative=spec)
         barrier(); torch.cuda.synchronize()
         t = time.perf_counter()
-        native(0, K, speculative=spec)
+        native(0, iters, speculative=spec, warm=warm)
         torch.cuda.synchronize(); barrier()
         return time.perf_counter() - t
-    elapsed_single = timed_single(True)
+    elapsed_single = min(timed_single(True) for _ in range(3))
     elapsed_plain = timed_single(False)
+    elapsed_cold = timed_single(True, warm=False)          # first iteration bins completely (no bounds from a previous frame)
+    # per-call fixed cost: one K-iteration call against the marginal cost of an iteration inside a long call
+    elapsed_long = min(timed_single(True, iters=4 * K) for _ in range(2))
+    steady_ms = 1e3 * (elapsed_long - elapsed_single) / (3 * K)
+    per_call_overhead_ms = 1e3 * elapsed_single - K * steady_ms
     PROF_ITERS = 40
     native_ms = {}
     for spec in (True, False):
@@ -247,10 +269,18 @@ def main():
             lib.gsr_profile_sampling(1)
     elapsed = elapsed_runs[0]
     if world > 1:
-        t = torch.tensor([elapsed, elapsed_py, elapsed_single, elapsed_plain] + elapsed_runs, dtype=torch.float64, device=coll_dev)
+        t = torch.tensor([elapsed, elapsed_py, elapsed_single, elapsed_plain, elapsed_cold] + elapsed_runs, dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         vals = [float(x) for x in t.tolist()]
-        elapsed, elapsed_py, elapsed_single, elapsed_plain, elapsed_runs = vals[0], vals[1], vals[2], vals[3], vals[4:]
+        elapsed, elapsed_py, elapsed_single, elapsed_plain, elapsed_cold, elapsed_runs = vals[0], vals[1], vals[2], vals[3], vals[4], vals[5:]
+    # how many ranks really took part (a launcher that started fewer than --gpus would otherwise go unnoticed)
+    ranks_seen = 1
+    if world > 1:
+        ones = torch.ones(1, dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+        ranks_seen = int(round(float(ones.item())))
+    if ranks_seen != args.gpus:
+        sys.exit(f"bench.py: {ranks_seen} ranks took part, --gpus {args.gpus} expected")
 
     # ---- pose error of full 50-iteration refinements with the reference's early exit (untimed), all frames gathered
     run_all(50, stop=True)
@@ -295,6 +325,7 @@ def main():
             "value": iters_total / elapsed,
             "unit": "iters/s",
             "n_gpus": world,
+            "ranks_seen": ranks_seen,
             "steps": K,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K,
@@ -313,6 +344,12 @@ def main():
                        "loop": "native gsr_refine (render, tracking loss, backward, Adam, update_pose per iteration)"},
             "value_repeats": [iters_total / e for e in elapsed_runs],
             "single_frame_iters_per_s": single,
+            "single_frame_cold_start_iters_per_s": world * K / elapsed_cold,
+            # one refinement call of K iterations on one frame: its time, the marginal cost of an iteration inside a long call,
+            # and what the call costs on top of K of those (host set-up, first iteration, the n_touched pass, final read-back)
+            "single_frame_call_ms": 1e3 * elapsed_single,
+            "steady_state_ms_per_iter": steady_ms,
+            "per_call_overhead_ms": per_call_overhead_ms,
             "plain_loop_iters_per_s": world * K / elapsed_plain,
             "python_loop_iters_per_s": world * K / elapsed_py,
             "pose_err_cm_median": 100.0 * float(np.median(res[:, 1])),

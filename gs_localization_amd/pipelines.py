@@ -221,6 +221,8 @@ class FusedRefiner:
         self.last_info = {"fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2])}
         return viewpoint.R, viewpoint.T, {"iters": n_done.value, "converged": bool(conv.value), "loss": float(s[38]),
                                           "fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]),
+                                          # (host copies of the final pose: no device read-back for the caller's error statistics)
+                                          "R_host": s[0:9].reshape(3, 3).numpy().copy(), "T_host": s[9:12].numpy().copy(),
                                           "render": self.color, "depth": self.depth, "opacity": self.alpha}
 
     def lean_check(self):

@@ -23,18 +23,31 @@ def shard_frames(n_frames, rank, world):
     return list(range(rank, n_frames, world))
 
 
-class FrameQueue:
-    """Hands out frame ids [0, n_frames) exactly once across all ranks and threads."""
+_queue_generation = [0]      # queues created so far in this process (every rank creates them in the same order)
 
-    def __init__(self, n_frames, rank=0, world=1, assign="queue", chunk=1, key="gsr_frames"):
+
+class FrameQueue:
+    """Hands out frame ids [0, n_frames) exactly once across all ranks and threads.
+
+    The shared counter lives in the process group's rendezvous store under `key` and is never reset, so every queue needs a
+    key of its own.  key=None (the default) derives one from a per-process generation count: all ranks construct their queues
+    in the same order (run_split is a collective in that sense), so the n-th queue gets the same fresh key everywhere -- a
+    warm-up pass followed by a measured pass, or several sequences, just work.  A caller that passes `key` itself must make
+    it unique per run.  `store` is the c10d store to count in (default: the default process group's)."""
+
+    def __init__(self, n_frames, rank=0, world=1, assign="queue", chunk=1, key=None, store=None):
         self.n, self.rank, self.world, self.assign, self.chunk = int(n_frames), rank, world, assign, max(1, int(chunk))
         self._lock = threading.Lock()
         self._local = []            # frames claimed but not yet handed to a worker
         self._next_static = rank
         self._counter = 0
         self._store = None
+        if key is None:
+            _queue_generation[0] += 1
+            key = f"gsr_frames/{_queue_generation[0]}"
         if assign == "queue" and world > 1:
-            base = dist.distributed_c10d._get_default_store()
+            # (torch exposes the default group's store only through this helper; a caller can pass its own store instead)
+            base = store if store is not None else dist.distributed_c10d._get_default_store()
             self._store = dist.PrefixStore(key, base)
         elif assign not in ("queue", "static"):
             raise ValueError("assign must be 'queue' or 'static'")
@@ -62,7 +75,7 @@ class FrameQueue:
             return lo
 
 
-def run_split(n_frames, refine_fn, rank=0, world=1, slots=1, assign="queue", chunk=1, row_width=5, key="gsr_frames"):
+def run_split(n_frames, refine_fn, rank=0, world=1, slots=1, assign="queue", chunk=1, row_width=5, key=None):
     """Every rank calls this.  refine_fn(slot, frame_id) -> sequence of floats (the frame's result row WITHOUT the leading
     frame id, at most row_width - 2 values); `slots` worker threads per rank call it concurrently (frames in flight on one
     GPU).  Returns (local rows [n_local, row_width] float64 with columns frame_id, values..., rank; busy seconds per slot)."""

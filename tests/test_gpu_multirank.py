@@ -1,0 +1,59 @@
+"""-m gpu : the N > 1 drivers, executed.  `gpurun` boxes have one GPU, so the ranks of these rehearsals share GPU 0 and the
+(tiny) collectives run over gloo on host tensors -- everything else is the code path an 8-GPU node runs: `bench.py --gpus N`
+starting its own ranks, the barrier / max-over-ranks timing, `ranks_seen`, the shared-counter frame queue and the one gather
+of BASELINE.json config 2's driver (tools/localize_split.py; reference: 7scenes_localize_full_dslam.py:352-389)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _json_line(cmd, timeout=900):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable] + cmd, cwd=ROOT, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+BENCH = ["bench.py", "--steps", "5", "--warmup", "1", "--frames-in-flight", "2", "--repeats", "1", "--gaussians", "300000",
+         "--no-cpu-baseline", "--no-train-leg"]
+
+
+def test_bench_gpus_flag_launches_the_ranks():
+    one = _json_line(BENCH)
+    two = _json_line(BENCH + ["--gpus", "2", "--backend", "gloo", "--device-index", "0"])
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
+    assert two["n_gpus"] == 2 and two["ranks_seen"] == 2
+    assert two["config"]["parallelism"].startswith("frames: 2 GPU")
+    # both ranks share one GPU here: the aggregate stays within a factor of two of the single rank's
+    assert 0.5 * one["value"] <= two["value"] <= 2.0 * one["value"], (one["value"], two["value"])
+    for k in ("roofline", "single_frame_iters_per_s", "per_call_overhead_ms", "steady_state_ms_per_iter"):
+        assert k in two
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable] + BENCH + ["--gpus", "2"], cwd=ROOT, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_split_driver_one_gpu_and_two_ranks():
+    args = ["tools/localize_split.py", "--frames", "32", "--gaussians", "300000", "--in-flight", "4"]
+    one = _json_line(args)
+    assert one["n_gpus"] == 1 and one["frames_per_s"] > 0
+    # (start poses are up to 5 cm / 3 deg off -- median 2.75 cm / 1.65 deg -- and Adam moves each component by ~lr per iteration)
+    assert one["median_trans_err_cm"] < 1.5 and one["median_rot_err_deg"] < 1.0, one
+    assert sum(one["per_rank"]["frames"]) == 32
+    two = _json_line(args + ["--gpus", "2", "--backend", "gloo", "--device-index", "0"])
+    assert two["n_gpus"] == 2 and sum(two["per_rank"]["frames"]) == 32 and min(two["per_rank"]["frames"]) > 0
+    # the same frames whichever rank refined them: same medians up to the order of the fp32 atomics
+    assert abs(two["median_trans_err_cm"] - one["median_trans_err_cm"]) < 0.05
+    assert abs(two["median_rot_err_deg"] - one["median_rot_err_deg"]) < 0.02

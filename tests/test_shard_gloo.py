@@ -22,9 +22,13 @@ def _worker(rank, world, port, n_frames, assign, slots, out):
     def refine(slot, f):            # stands in for FusedRefiner.refine: (trans err, rot err, iterations)
         time.sleep(0.004 * _cost_units(f, world))
         return 0.001 * f, 0.1 * f, float(_cost_units(f, world))
+    # a warm-up pass on the same process group first (the shared counter is never reset, so every run_split must count
+    # under a key of its own -- the default derives a fresh one per call, identically on every rank)
+    warm, _ = shard.run_split(3, lambda slot, f: (0.0, 0.0, 0.0), rank, world, slots=1, assign=assign)
+    assert shard.gather_results(warm, 3, rank, world) is not None or rank != 0
     dist.barrier()
     t0 = time.perf_counter()
-    local, busy = shard.run_split(n_frames, refine, rank, world, slots=slots, assign=assign, chunk=1, key=f"q{port}")
+    local, busy = shard.run_split(n_frames, refine, rank, world, slots=slots, assign=assign, chunk=1)
     wall = time.perf_counter() - t0
     t = torch.tensor([wall, sum(busy)], dtype=torch.float64)
     walls = [torch.zeros(2, dtype=torch.float64) for _ in range(world)]

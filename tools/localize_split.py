@@ -42,13 +42,31 @@ def main():
                     help="query poses are scattered this far around the map's reference view.  The synthetic map is the frustum-shaped "
                          "cloud seen from that view: 0.3 m / 10 deg already looks past its edge (most tiles never saturate, no depth "
                          "bounds, complete lists: the stress case)")
+    ap.add_argument("--gpus", type=int, default=None, help="without a launcher: start this many ranks (torch.distributed.run) and exit with their status")
+    ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: the N > 1 path rehearsed on a box with one GPU (collectives on host tensors)")
+    ap.add_argument("--device-index", type=int, default=None, help="GPU of this rank (default: LOCAL_RANK)")
     args = ap.parse_args()
+    if args.gpus and args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+                                  "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]))
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
+    if args.gpus and args.gpus != world:
+        sys.exit(f"localize_split.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    dev_index = local_rank if args.device_index is None else args.device_index
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
     from gs_localization_amd import scenes as S, shard
     from tests import replay as RP
 
@@ -90,7 +108,7 @@ def main():
             fr = loaded.pop(f, None) or observe(f, gt)
             i0 = torch.tensor(init, dtype=torch.float32, device=dev)
             R, T, info = refiners[slot].refine(fr, RP.TRACKING_CONFIG, i0[:3, :3].clone(), i0[:3, 3].clone(), bg, iters=args.iters)
-            te, re = RP.pose_errors(gt[:3, :3], gt[:3, 3], R.detach().cpu().numpy(), T.detach().cpu().numpy())
+            te, re = RP.pose_errors(gt[:3, :3], gt[:3, 3], info["R_host"], info["T_host"])
         return te, re, float(info["iters"])
 
     refine(0, 0)                                    # warm-up (allocations, first-touch), untimed
@@ -106,9 +124,9 @@ def main():
     if world > 1:
         dist.barrier()
     wall = time.perf_counter() - t0
-    res = shard.gather_results(local.to(dev), args.frames, rank, world)
+    res = shard.gather_results(local.to(coll_dev), args.frames, rank, world)
     stats = torch.tensor([t_rank, sum(busy) / F, float(local.shape[0]), float(local[:, 3].sum()) if local.numel() else 0.0],
-                         dtype=torch.float64, device=dev)
+                         dtype=torch.float64, device=coll_dev)
     per_rank = [torch.zeros_like(stats) for _ in range(world)]
     if world > 1:
         dist.all_gather(per_rank, stats)
