@@ -210,7 +210,7 @@ struct SpecCtx { int mode = 0; int parity = 0; float mul = 1.05f, add = 0.05f; c
 struct PassCtx {
     bool native_loop = false;      // gsr_refine: gradient tensors and accumulators are maintained by the kernels, not re-zeroed here
     SpecCtx spec;
-    gsr::LoopGuard guard = {nullptr, nullptr};      // device-side poison / converged words (see LoopGuard)
+    gsr::LoopGuard guard = {nullptr, nullptr, 0u};      // device-side poison / converged words and this group's tag (see LoopGuard)
     gsr::FusedLoss floss = {};     // tracking loss evaluated in the compositing kernel's epilogue (out == nullptr: not fused)
     int cov_cache = 0;             // 1 = this forward stores every Gaussian's 3D covariance in the geometry buffer, 2 = reads them back
     bool lean = false;             // this forward's radii are not an output (see k_preprocess)
@@ -332,12 +332,12 @@ extern "C" {
 const char* gsr_last_error(void) { return g_err.c_str(); }
 
 // diagnostic builds only (GSR_TIMING): copies the 32 phase counters out and clears them; -1 in product builds
-int gsr_debug_timing(unsigned long long* out48)
+int gsr_debug_timing(unsigned long long* out48)          // (64 entries since the chain-rule kernel has its slots: 48-63)
 {
 #if GSR_TIMING
-    static std::vector<unsigned long long> h((size_t)3 * GSR_TIM_WAVES * 12);
+    static std::vector<unsigned long long> h((size_t)4 * GSR_TIM_WAVES * 12);
     if (hipMemcpyFromSymbol(h.data(), HIP_SYMBOL(gsr::g_tim), h.size() * 8) != hipSuccess) return -2;
-    for (int k = 0; k < 3; k++)
+    for (int k = 0; k < 4; k++)
         for (int q = 0; q < 12; q++) {
             unsigned long long sum = 0;
             for (size_t w = 0; w < GSR_TIM_WAVES; w++) sum += h[((size_t)k * GSR_TIM_WAVES + w) * 12 + q];
@@ -345,7 +345,7 @@ int gsr_debug_timing(unsigned long long* out48)
         }
     // slots 12..15 of each kernel: the largest accumulated wave lifetime (slot 9) of any row, the number of rows used, and the
     // 50th / 99th percentile of the rows' lifetimes -- is the kernel's duration its mean wave or its slowest one?
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < 4; k++) {
         std::vector<unsigned long long> life;
         for (size_t w = 0; w < GSR_TIM_WAVES; w++) {
             const unsigned long long v = h[((size_t)k * GSR_TIM_WAVES + w) * 12 + 9];
@@ -654,7 +654,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
                      by_tile ? im.tile_cursor : im.tile_offset, width, height, gx, ntiles, (const float*)g.rec, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
                      zb_next, zb_prev, cx.guard.poison ? const_cast<uint32_t*>(cx.guard.poison) : im.fail, \
                      sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], balanced ? im.tile_work[0] : (uint32_t*)nullptr, bin_cap, \
-                     LazySH{pa.lazy_sh ? shs : nullptr, means3D, cam_pos, D, M, g.clamped, g.rec}
+                     LazySH{pa.lazy_sh ? shs : nullptr, means3D, cam_pos, D, M, g.clamped, g.rec}, (cx.guard.poison ? cx.guard.tag << 2 : 0u)
         if (by_tile) {
             if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
             else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
@@ -865,7 +865,7 @@ int gsr_tracking_loss(int width, int height, const float* image, const float* de
     if (rc != GSR_OK) return rc;
     HIPCHK(hipMemsetAsync(out, 0, 4 * sizeof(float), st));
     LossArgs la;
-    la.guard = LoopGuard{nullptr, nullptr};
+    la.guard = LoopGuard{nullptr, nullptr, 0u};
     la.clear_a = nullptr; la.clear_b = nullptr; la.clear_n = 0;
     la.W = width; la.H = height; la.image = image; la.depth = depth; la.opacity = opacity; la.gt_image = gt_image;
     la.gt_depth = gt_depth; la.grad_mask = grad_mask; la.exposure = exposure; la.opacity_thr = opacity_threshold;
@@ -900,7 +900,7 @@ int gsr_pose_step(float* pose_state, const float* dL_dtau, const float* loss_out
     if (rc != GSR_OK) return rc;
     gsr::PoseStepArgs q = {};
     q.st = pose_state; q.dL_dtau = dL_dtau; q.loss_out = loss_out; q.proj_raw = projmatrix_raw; q.lr = lr; q.conv_thr = converged_threshold;
-    hipLaunchKernelGGL(gsr::k_pose_step, dim3(1), dim3(64), 0, st, q, gsr::LoopGuard{nullptr, nullptr});
+    hipLaunchKernelGGL(gsr::k_pose_step, dim3(1), dim3(64), 0, st, q, gsr::LoopGuard{nullptr, nullptr, 0u});
     LAUNCHCHK("k_pose_step");
     return 0;
 }
@@ -932,9 +932,10 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     hipStream_t st = (hipStream_t)a->stream;
     int rc = select_device_of(a->pose_state);
     if (rc != GSR_OK) return rc;
-    // Pinned status slots (one per iteration parity): {converged, loss, |tau|, poison, sequence number}, written by the
-    // pose-step kernel of each iteration.  On an error return kernels that write these slots may still be in flight: the
-    // stream is drained before the slots go back to the pool, so that the next holder never sees a stale word.
+    // Pinned status slots, one per group parity: ONE word each, (sequence number << 4) | overflow << 2 | bound failure << 1 |
+    // converged, written by the pose step that closes each kernel group (pose_step_wave).  On an error return kernels that
+    // write these slots may still be in flight: the stream is drained before the slots go back to the pool, so that the next
+    // holder never sees a stale word.
     struct CtxLease {
         LoopCtx* c; hipStream_t st; bool clean = false;
         explicit CtxLease(hipStream_t s_) : c(loop_ctx_acquire()), st(s_) {}
@@ -947,21 +948,24 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     } ctx_lease(st);
     if (!ctx_lease.c) return fail(GSR_E_HIP, "gsr_refine: could not create the pinned status slots%s", "");
     float* h_status = ctx_lease.c->h_status;
-    for (int i = 0; i < 16; i++) h_status[i] = 0.f;          // sequence words of both slots start at 0
-    // Waits until the pose step of iteration `it` has published its status (sequence word == it + 1).  The kernel
-    // writes the slot itself (k_pose_step), so there is no copy and no event.  A few thousand polls cover the common case
-    // (the status is at most one iteration away); after that the thread yields between polls -- with several frames in
-    // flight per GPU and eight GPUs per node, dozens of these loops share the host's cores -- and the stream is queried
-    // now and then so that a failed launch cannot turn this into an endless wait.
-    auto wait_status = [&](int it) -> int {
-        volatile int* seqw = reinterpret_cast<volatile int*>(h_status + 8 * (it & 1)) + 4;
+    auto slot_of = [&](int g) { return reinterpret_cast<volatile uint32_t*>(h_status + 8 * (g & 1)); };
+    *slot_of(0) = 0u; *slot_of(1) = 0u;
+    // Waits until the pose step of group `g` has published its status word (sequence bits == g + 1) and returns it in `word`.
+    // The kernel writes the slot itself, so there is no copy and no event.  A few thousand polls cover the common case (the
+    // status is at most one group away); after that the thread yields between polls -- with several frames in flight per GPU
+    // and eight GPUs per node, dozens of these loops share the host's cores -- and the stream is queried now and then so that
+    // a failed launch cannot turn this into an endless wait.
+    auto wait_status = [&](int g, uint32_t& word) -> int {
+        volatile uint32_t* w = slot_of(g);
         for (unsigned spins = 0;; spins++) {
-            if (*seqw == it + 1) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
+            const uint32_t v = *w;
+            if ((v >> 4) == (uint32_t)(g + 1)) { word = v; return 0; }
             if (spins > 4096u) std::this_thread::yield();
             if ((spins & 0x3FFFu) == 0x3FFFu) {
                 const hipError_t q = hipStreamQuery(st);
                 if (q == hipSuccess) {          // everything enqueued has run: one last look, then give up
-                    if (*seqw == it + 1) { std::atomic_thread_fence(std::memory_order_acquire); return 0; }
+                    const uint32_t v2 = *w;
+                    if ((v2 >> 4) == (uint32_t)(g + 1)) { word = v2; return 0; }
                     return fail(GSR_E_HIP, "gsr_refine: the iteration finished without publishing its status%s", "");
                 }
                 if (q != hipErrorNotReady) return fail(GSR_E_HIP, "gsr_refine: %s", hipGetErrorString(q));
@@ -1017,28 +1021,36 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             hipLaunchKernelGGL(k_pose_load, dim3(1), dim3(64), 0, st, ps, a->init_R, a->init_T, a->init_exposure_a, a->init_exposure_b, a->projmatrix_raw);
             { const int debug = 0; LAUNCHCHK("k_pose_load"); }
         }
-        HIPCHK(hipMemsetAsync(ps + GSR_PS_CONV, 0, 5 * sizeof(float), st));      // converged, loss, |tau|, poison, ticket
-        HIPCHK(hipMemsetAsync(gg.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));      // then kept clean by the pose step
-        HIPCHK(hipMemsetAsync(gg.surv.n, 0, (size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE * sizeof(uint32_t), st));      // ... and the work-list counters too
         cx.rows = GradRows{a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor, a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, a->M};
         // image workspace: flags, cursors and both bound buffers start from zero; afterwards the kernels keep them so
         Img im0;
         char* iptr = (char*)cached_resize(&ib, carve_img(nullptr, a->width, a->height, im0));
         if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
         carve_img(iptr, a->width, a->height, im0);
-        HIPCHK(hipMemsetAsync(im0.fail, 0, im0.clear_words * sizeof(uint32_t), st));
-        HIPCHK(hipMemsetAsync(im0.loss_shards, 0, GSR_LOSS_SHARDS * 16 * sizeof(float), st));
-        HIPCHK(hipMemsetAsync(im0.tile_work[0], 0, (size_t)(im0.tile_work[1] - im0.tile_work[0]) * 2 * sizeof(uint32_t), st));
+        if (!(carried & 1)) HIPCHK(hipMemsetAsync(a->dL_dalpha, 0, (size_t)a->width * a->height * sizeof(float), st));      // no gradient flows into opacity; nothing writes it afterwards
+        {   // the small arrays, one launch (k_refine_init)
+            ClearRanges cr = {};
+            int k = 0;
+            auto add = [&](void* ptr, size_t words) { cr.p[k] = static_cast<uint32_t*>(ptr); cr.n[k] = (uint32_t)words; k++; };
+            add(ps + GSR_PS_CONV, 5);                                                   // converged, loss, |tau|, poison, ticket
+            add(gg.tau_acc, 2 * 8 * GSR_TAU_SLOTS);                                     // (doubles) then kept clean by the pose step
+            add(gg.surv.n, (size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE);                  // ... and the work-list counters by the chain-rule kernel
+            add(im0.fail, im0.clear_words);
+            add(im0.loss_shards, GSR_LOSS_SHARDS * 16);
+            add(im0.tile_work[0], (size_t)(im0.tile_work[1] - im0.tile_work[0]) * 2);
+            // (a warm start keeps the bounds the previous call recorded in buffer `warm_buf`; zbc[0], zbc[1] are carved 256 B apart at least)
+            if (warm_buf != 0) add(im0.zbc[0], (size_t)im0.nsb);
+            if (warm_buf != 1) add(im0.zbc[1], (size_t)im0.nsb);
+            add(a->loss_out, 4);
+            static_assert(sizeof(cr.p) / sizeof(cr.p[0]) >= 9, "ClearRanges too small");
+            hipLaunchKernelGGL(k_refine_init, dim3(32), dim3(GSR_BLOCK), 0, st, cr);
+            { const int debug = 0; LAUNCHCHK("k_refine_init"); }
+        }
         cx.balance = !(a->flags & GSR_REFINE_NO_BALANCE);
-        HIPCHK(hipMemsetAsync(a->dL_dalpha, 0, (size_t)a->width * a->height * sizeof(float), st));      // no gradient flows into opacity
         cx.floss.gt_image = a->gt_image; cx.floss.gt_depth = a->gt_depth; cx.floss.grad_mask = a->grad_mask;
         cx.floss.exposure = ps + GSR_PS_PARAM + 6; cx.floss.opacity_thr = a->opacity_threshold; cx.floss.depth_w = a->depth_weight;
         cx.floss.monocular = a->monocular; cx.floss.dL_dimage = a->dL_dimage; cx.floss.dL_ddepth = a->dL_ddepth;
         cx.floss.out = im0.loss_shards; cx.floss.conv = a->stop_on_converged ? ps + GSR_PS_CONV : nullptr;
-        // (a warm start keeps the bounds the previous call recorded in buffer `warm_buf`)
-        if (warm_buf != 0) HIPCHK(hipMemsetAsync(im0.zbc[0], 0, (size_t)im0.nsb * sizeof(float), st));
-        if (warm_buf != 1) HIPCHK(hipMemsetAsync(im0.zbc[1], 0, (size_t)im0.nsb * sizeof(float), st));
-        HIPCHK(hipMemsetAsync(a->loss_out, 0, 4 * sizeof(float), st));
     }
     bool cov_cached = (carried & 2) != 0;      // the first forward stores every Gaussian's 3D covariance, the others (and, vouched for, later calls) reuse it
     const int debug = 0;
@@ -1051,38 +1063,43 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     int margin_streak = 0;
     if (!adaptive_margin) { cx.spec.mul = a->bound_margin_mul; cx.spec.add = a->bound_margin_add; }
 
-    // One iteration = forward (with the tracking loss in its compositing epilogue), backward, Adam + update_pose, all
-    // enqueued without waiting for the device (a forward with complete lists still reads its instance count back, as
-    // the reference does).  The pose step publishes the status words to the slot of the iteration's parity.
+    // One kernel GROUP = forward (with the tracking loss in its compositing epilogue), backward, chain rule with Adam + update_pose
+    // in its last workgroup -- all enqueued without waiting for the device (a forward with complete lists still reads its
+    // instance count back, as the reference does).  The pose step that closes a group publishes the group's status word.
+    // Groups are numbered g = 0, 1, ...; group g writes bounds buffer par(g), reads par(g) ^ 1, carries tag g + 1.
+    // A group whose speculative forward fails its verification skips its own loss / backward / pose step ON THE DEVICE and the
+    // next group -- enqueued one ahead, as always -- runs as the retry of the same iteration with the bounds the failed forward
+    // recorded (LoopGuard).  The host only keeps count: a failed group does not advance the iteration number.  It steps in
+    // (drain, complete lists, back-off) when a bin overflowed or the retry failed as well.
     Img imv_loop{};                // the image workspace's carving (for the pose step launch)
-    int slot_mode[2] = {0, 0};
-    int last_enq = -1;            // last iteration whose forward was enqueued: its bounds are the newest
+    int last_enq = -1;            // last group whose forward was enqueued: its bounds are the newest
     bool last_counted = false;    // ... and it already counted n_touched
-    auto enqueue = [&](int it, int mode) -> int {
-        slot_mode[it & 1] = mode;
-        last_enq = it;
+    auto enqueue = [&](int g, int logical, int mode) -> int {
+        last_enq = g;
         if (adaptive_margin) {
-            const float m = (it == 0 && warm_buf >= 0) ? 0.05f : margin_m;      // (bounds recorded for another frame: be generous)
+            const float m = (g == 0 && warm_buf >= 0) ? 0.05f : margin_m;      // (bounds recorded for another frame: be generous)
             cx.spec.mul = 1.f + m; cx.spec.add = m;
         }
-        reinterpret_cast<volatile int*>(h_status + 8 * (it & 1))[4] = 0;      // (nothing in flight writes this slot any more)
+        *slot_of(g) = 0u;      // (nothing in flight writes this slot any more: group g - 2 has been settled)
         cx.spec.mode = mode;
-        cx.spec.parity = par(it);
+        cx.spec.parity = par(g);
+        cx.guard.tag = (uint32_t)(g + 1);
         cx.cov_cache = cov_cached ? 2 : 1;
         cov_cached = true;
-        cx.lean = (mode == 1) && (it != a->max_iters - 1);
+        const bool maybe_last = (logical == a->max_iters - 1);
+        cx.lean = (mode == 1) && !maybe_last;
         Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
         imv_loop = imv;
         // Adam + update_pose run in the chain-rule kernel's last workgroup (no launch of their own); they also finish the fp64
-        // dL/dtau reduction, clear the superblock bounds buffer iteration it+1 accumulates into and publish the status
+        // dL/dtau reduction, clear the superblock bounds buffer the next group accumulates into and publish the status
         cx.ticket = reinterpret_cast<uint32_t*>(ps + GSR_PS_TICKET);
         cx.fold = PoseStepArgs{};
         cx.fold.st = ps; cx.fold.dL_dtau = a->dL_dtau; cx.fold.dL_dtau_out = a->dL_dtau; cx.fold.loss_out = a->loss_out;
         cx.fold.proj_raw = a->projmatrix_raw; cx.fold.lr = a->lr; cx.fold.conv_thr = a->converged_threshold; cx.fold.loss_zero = a->loss_out;
-        cx.fold.host_status = h_status + 8 * (it & 1); cx.fold.seq = it + 1; cx.fold.loss_shards = imv.loss_shards;
-        cx.fold.clear_b = (mode != 0) ? imv.zbc[par(it) ^ 1] : nullptr; cx.fold.clear_n = imv.nsb;
-        // n_touched is wanted for the LAST forward only (see the end): an iteration known to be the last counts it itself
-        const bool count_touched = (it == a->max_iters - 1) && a->n_touched != nullptr;
+        cx.fold.host_status = const_cast<uint32_t*>(slot_of(g)); cx.fold.seq = g + 1; cx.fold.loss_shards = imv.loss_shards;
+        cx.fold.clear_b = (mode != 0) ? imv.zbc[par(g) ^ 1] : nullptr; cx.fold.clear_n = imv.nsb;
+        // n_touched is wanted for the LAST forward only (see the end): a group that may be the last counts it itself
+        const bool count_touched = maybe_last && a->n_touched != nullptr;
         last_counted = count_touched;
         int R = forward_impl(cx, cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
                              a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
@@ -1100,73 +1117,92 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (rc2 < 0) return rc2;
         return 0;
     };
-    // Wait for iteration `it`'s status.  A poisoned iteration (failed speculation: its loss, backward and pose step
-    // and everything enqueued behind it were skipped on the device) is redone here with complete lists.
-    auto settle = [&](int it, bool& conv_out) -> int {
-        { const int wrc = wait_status(it); if (wrc < 0) return wrc; }
-        const float* hs = h_status + 8 * (it & 1);
-        uint32_t pz; memcpy(&pz, hs + 3, sizeof(pz));
-        if (pz != 0u) {
-            n_fallbacks++;
-            HIPCHK(hipStreamSynchronize(st));
-            if (a->flags & GSR_REFINE_LOG_REDO) fprintf(stderr, "[gsr] iteration %d: speculation failed (0x%x), redone\n", it, pz);
-            HIPCHK(hipMemsetAsync(poison, 0, sizeof(uint32_t), st));
-            HIPCHK(hipMemsetAsync(imv_loop.loss_shards, 0, GSR_LOSS_SHARDS * 16 * sizeof(float), st));      // the failed forward added to them
-            int rc2 = enqueue(it, 2);
-            if (rc2 < 0) return rc2;
-            { const int wrc = wait_status(it); if (wrc < 0) return wrc; }
-            // back off: a scene whose lists stay long after culling would otherwise pay for both forwards every time
-            fail_streak++;
-            if (fail_streak >= 2) spec_resume = it + 1 + (1 << (fail_streak < 6 ? fail_streak : 6));
-            if (adaptive_margin) { margin_m = fminf(0.05f, margin_m * 2.f); margin_streak = 0; }
-            conv_out = hs[0] != 0.f;
-            return 1;       // redone: whatever was enqueued behind it was skipped and must be enqueued again
-        }
-        if (slot_mode[it & 1] == 1) {
+    // Speculative binning: from the second iteration on, instances lying behind what their tile needed in the previous
+    // iteration (x margin) are not binned; the compositing kernel verifies the speculation, so results never depend on it.
+    auto mode_of = [&](int logical) { return a->speculative ? (((logical == 0 && warm_buf < 0) || logical < spec_resume) ? 2 : 1) : 0; };
+    std::vector<int> group_mode;   // mode each group was enqueued with
+    int enq = 0, settled_n = 0;    // groups enqueued / whose status the host has seen (in order)
+    int succ = 0;                  // iterations completed (groups whose pose step ran)
+    int streak = 0;                // failed groups in a row
+    bool conv_seen = false;        // (stop_on_converged) an update reported convergence: what follows is the frozen render at the final pose
+    bool final_rendered = false;   // ... and that render has been enqueued / verified
+    auto enqueue_next = [&](int logical, int mode) -> int {
+        const int rc2 = enqueue(enq, logical, mode);
+        if (rc2 < 0) return rc2;
+        group_mode.push_back(mode);
+        enq++;
+        return 0;
+    };
+    auto after_success = [&](int g, uint32_t w) {      // bookkeeping for a group that passed its verification
+        streak = 0;
+        if (group_mode[g] == 1) {
             fail_streak = 0;
             if (adaptive_margin && ++margin_streak >= 8) { margin_m = fmaxf(0.01f, margin_m * 0.8f); margin_streak = 0; }
         }
-        conv_out = hs[0] != 0.f;
-        return 0;
+        if (conv_seen) return;                          // (a frozen group: the render at the final pose)
+        succ++;
+        if (a->stop_on_converged && (w & 1u)) { conv_seen = true; *converged = 1; }
     };
-    // Speculative binning: from the second iteration on, instances lying behind what their tile needed in the
-    // previous iteration (x margin) are not binned; the compositing kernel verifies the speculation and a failed
-    // one is redone with complete lists, so results never depend on it.
-    auto mode_of = [&](int it) { return a->speculative ? (((it == 0 && warm_buf < 0) || it < spec_resume) ? 2 : 1) : 0; };
-    int it = 0, settled = -1;
-    bool prev_pending = false;
-    while (it < a->max_iters) {
-        rc = enqueue(it, mode_of(it));
-        if (rc < 0) return rc;
-        if (prev_pending && settled < it - 1) {
-            bool conv = false;
-            rc = settle(it - 1, conv);
+    while (true) {
+        const int inflight = enq - settled_n;
+        // keep two groups in flight -- the one waited for and one behind it -- while iterations remain
+        if (!conv_seen && inflight < 2 && succ + inflight < a->max_iters) {
+            rc = enqueue_next(succ + inflight, mode_of(succ + inflight));
             if (rc < 0) return rc;
-            settled = it - 1;
-            if (a->stop_on_converged && conv) {
-                // reference: `if converged: break` -- the forward of iteration `it` is the render at the final pose; its
-                // update is frozen on the device.  (After a redo it was skipped: render it again.)  That forward is what the
-                // caller gets back, so its speculation must be verified like any other: its (frozen) pose step still
-                // publishes the poison word, and a failed one is rendered once more with complete lists.
-                if (rc == 1) { rc = enqueue(it, mode_of(it)); if (rc < 0) return rc; }
-                bool ignored = false;
-                rc = settle(it, ignored);
-                if (rc < 0) return rc;
-                *converged = 1;
-                break;
-            }
-            if (rc == 1) continue;      // iteration `it` was skipped on the device: enqueue it again
+            continue;
         }
-        prev_pending = true;
-        it++;
-        *iters_done = it;
+        if (inflight == 0) {
+            // reference: `if converged: break` -- the caller gets the render at the final pose: one more (frozen) forward, unless
+            // the iterations are used up (then, like the reference, the last loop body's render)
+            if (conv_seen && succ < a->max_iters && !final_rendered) {
+                rc = enqueue_next(succ, mode_of(succ));
+                if (rc < 0) return rc;
+                final_rendered = true;
+                continue;
+            }
+            break;
+        }
+        const int g = settled_n;
+        uint32_t w = 0;
+        { const int wrc = wait_status(g, w); if (wrc < 0) return wrc; }
+        settled_n++;
+        if (conv_seen) final_rendered = true;           // (the group behind a converged one is that frozen forward)
+        if ((w & 6u) == 0u) { after_success(g, w); continue; }
+        // ---- group g failed its verification: nothing of it counts; the device is already retrying with the next group
+        n_fallbacks++;
+        streak++;
+        const bool overflow = (w & 4u) != 0u;
+        if (a->flags & GSR_REFINE_LOG_REDO)
+            fprintf(stderr, "[gsr] group %d: speculation failed (%s)%s\n", g, overflow ? "bin overflow" : "unsaturated tile behind a finite bound",
+                    (streak < 2 && !overflow && !conv_seen) ? ", retried on the device" : ", host steps in");
+        if (adaptive_margin) { margin_m = fminf(0.05f, margin_m * 2.f); margin_streak = 0; }
+        if (!conv_seen && !overflow && streak < 2) continue;
+        // ---- the host steps in: drain what is in flight (a retry that may well have succeeded), then complete lists if need be
+        HIPCHK(hipStreamSynchronize(st));
+        bool resolved = false;
+        while (settled_n < enq) {
+            const int g2 = settled_n;
+            uint32_t w2 = 0;
+            { const int wrc = wait_status(g2, w2); if (wrc < 0) return wrc; }
+            settled_n++;
+            if (w2 & 6u) { n_fallbacks++; resolved = false; }
+            else { after_success(g2, w2); resolved = true; }
+        }
+        if (!resolved) {
+            const int g3 = enq;
+            rc = enqueue_next(succ, 2);                 // complete lists: cannot fail
+            if (rc < 0) return rc;
+            uint32_t w3 = 0;
+            { const int wrc = wait_status(g3, w3); if (wrc < 0) return wrc; }
+            settled_n++;
+            if (w3 & 6u) return fail(GSR_E_HIP, "gsr_refine: a forward with complete lists failed its verification%s", "");
+            after_success(g3, w3);
+            // back off: a scene whose lists stay long after culling would otherwise pay for failed forwards again and again
+            fail_streak++;
+            if (fail_streak >= 2) spec_resume = succ + (1 << (fail_streak < 6 ? fail_streak : 6));
+        }
     }
-    if (!*converged && prev_pending && it > 0 && settled < it - 1) {      // the last iteration's status
-        bool conv = false;
-        rc = settle(it - 1, conv);
-        if (rc < 0) return rc;
-        if (a->stop_on_converged && conv) *converged = 1;
-    }
+    *iters_done = succ;
     if (last_enq >= 0 && !last_counted && a->n_touched && gb.ptr && bb.ptr && ib.ptr) {
         // n_touched (fifth output of the pose package's forward) is only wanted for the LAST forward, and counting it
         // costs every iteration's compositing kernel an eighth of its instructions: the loop runs the variant
@@ -1181,7 +1217,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                            reinterpret_cast<uint32_t*>(bb.ptr), (const unsigned long long*)nullptr, (uint32_t*)nullptr, a->width,
                            a->height, gx, gx * gy, (const float*)g.rec, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
                            a->n_touched, (float*)nullptr, (const float*)nullptr, im.fail, 1.f, 0.f, (float*)nullptr,
-                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{});
+                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{}, 0u);
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
     if (a->pose_state_host) HIPCHK(hipMemcpyAsync(h_status + 16, ps, GSR_POSE_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToHost, st));

@@ -13,7 +13,7 @@ namespace gsr {
 #endif
 #if GSR_TIMING
 #define GSR_TIM_WAVES (16384 * 4)
-__device__ unsigned long long g_tim[3][GSR_TIM_WAVES][12];      // [kernel][wave][slot]: every wave owns its row, no atomics
+__device__ unsigned long long g_tim[4][GSR_TIM_WAVES][12];      // [kernel][wave][slot]: every wave owns its row, no atomics
 #define GSR_T_DECL long long t_prev_ = clock64(); const long long t_start_ = t_prev_; long long t_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
 #define GSR_T_TICK(slot) { const long long now_ = clock64(); t_acc_[slot] += now_ - t_prev_; t_prev_ = now_; }
 #define GSR_T_COUNT(slot, v) { t_acc_[slot] += (v); }
@@ -25,17 +25,24 @@ __device__ unsigned long long g_tim[3][GSR_TIM_WAVES][12];      // [kernel][wave
 #define GSR_T_FLUSH(base)
 #endif
 
-// Device-side guards of the native refinement loop (gsr_refine).  The host enqueues iteration i+1 before it has
-// seen iteration i's flags, so every kernel of the loop checks them itself:
-//   poison != 0 : a speculative forward failed its verification; everything downstream is skipped until the
-//                 host has redone that iteration with complete lists,
+// Device-side guards of the native refinement loop (gsr_refine).  The host enqueues kernel GROUPS (preprocess, compositing,
+// backward compositing, chain rule + pose step) one ahead of the statuses it has seen, so every kernel of a group checks
+// two device words itself:
+//   poison : (tag << 2) | flags of the last group whose speculative forward failed its verification (flag bit 0: a tile ran out
+//            of list with an unsaturated pixel; bit 1: a bin overflowed).  A kernel is poisoned iff the word carries ITS OWN
+//            group's tag: the rest of that group (loss, backward, pose step) is skipped, the pose does not move -- and the NEXT
+//            group, already enqueued, runs as the retry of the same iteration without any host intervention: it bins with the
+//            bounds the failed forward recorded, in which every failed tile has no bound (complete list) and every other tile
+//            the exact depth it needed at this very pose.  Tags only grow, so nothing ever has to be cleared.
 //   conv   != 0 : the pose update already converged; loss, backward and pose step are skipped (frozen).
 // Both pointers are NULL outside the native loop.
 struct LoopGuard {
-    const uint32_t* poison; const float* conv;
-    __device__ __forceinline__ bool poisoned() const { return poison != nullptr && *poison != 0u; }
+    const uint32_t* poison; const float* conv; uint32_t tag;
+    __device__ __forceinline__ bool poisoned() const { return poison != nullptr && (*poison >> 2) == tag; }
     __device__ __forceinline__ bool frozen() const { return poisoned() || (conv != nullptr && *conv != 0.f); }
 };
+#define GSR_FAIL_BOUND 1u        // poison / fail word flags
+#define GSR_FAIL_OVERFLOW 2u
 
 // ---------------------------------------------------------------------------------------------
 // K1  per-Gaussian preprocess (replaces forward.cu:155-256 preprocessCUDA).
@@ -1271,6 +1278,7 @@ __device__ __forceinline__ float sgnf(float d) { return (d > 0.f) ? 1.f : ((d < 
 // where the packed fp32 instructions want their operand PAIRS: (x, y) - (px, py), (B2, C2) * dy, (r, g) * w, (b, depth) * w are
 // one v_pk_* each -- same IEEE operations, two per issue slot.
 typedef float gsr_f32x2 __attribute__((ext_vector_type(2)));
+typedef float gsr_f32x4 __attribute__((ext_vector_type(4)));
 struct SplatLDS {
     float4 a[GSR_BLOCK];   // x, y, B2, C2
     float4 b[GSR_BLOCK];   // A2, opacity | id (bits), quadrant mask (bits)
@@ -1423,8 +1431,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                                                           const float* __restrict__ zb_used, uint32_t* __restrict__ fail,
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
                                                           int sbx, FusedLoss fl, const uint32_t* __restrict__ tile_order,
-                                                          uint32_t* __restrict__ tile_work, int bin_cap, LazySH lz)
+                                                          uint32_t* __restrict__ tile_work, int bin_cap, LazySH lz, uint32_t fail_tag)
 {
+    // (fail: the word a failed verification is reported in -- the loop's poison word with fail_tag = this group's tag << 2, see
+    // LoopGuard; the drop-in speculation's flag word with fail_tag = 0)
     // (tile_cursor: GSR_LIST_BINS the per-tile append cursors; GSR_LIST_EXACT the tile_offset array of k_tile_scan)
     __shared__ SplatLDS s;
     __shared__ float s_zmax[4];
@@ -1459,7 +1469,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     // segment of the exact bins; only a bin that overflowed its capacity fails the forward.
     const bool lazy = (LIST == GSR_LIST_EXACT) || (LIST == GSR_LIST_BINS && total > GSR_LSORT_CAP);
     if (LIST == GSR_LIST_BINS && total > bin_cap) {          // block-uniform: entries were dropped; the host redoes the forward with complete lists
-        if (tid == 0) atomicAdd(fail, 0x10000u);
+        if (tid == 0) atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);
         return;
     }
     if (LIST == GSR_LIST_BINS && !lazy) {
@@ -1510,7 +1520,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             select_slice(seg, total, first_slice, slice_lo, first_slice ? GSR_SLICE_FIRST : GSR_LSORT_CAP,
                          reinterpret_cast<uint32_t*>(s_keys), slice_hi, m);
         if (m <= 0) {          // cannot happen with distinct keys (the index is part of them): corrupted bins -- fail loudly, never spin
-            if (tid == 0) atomicAdd(fail, 0x10000u);
+            if (tid == 0) atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);
             break;
         }
         __shared__ uint32_t s_fill;
@@ -1538,7 +1548,16 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             const uint32_t id = (LIST != GSR_LIST_SORTED) ? (uint32_t)s_keys[base + tid] : point_list[range.x + base + tid];
             const float4* r = reinterpret_cast<const float4*>(rec + (size_t)id * GSR_REC_STRIDE);
             const float4 r0 = r[0], r1 = r[1];
-            float4 r2 = r[2];
+            float4 r2;
+            if (LIST == GSR_LIST_EXACT && lz.shs != nullptr) {
+                // (LazySH: another workgroup of this launch may be publishing this quad right now.  It is read and written as ONE
+                // 16-byte access -- a volatile vector access, which the compiler neither splits nor reorders nor repeats; on gfx950 an
+                // aligned global_load / store_dwordx4 is a single transaction on one cache line, so a reader sees either the
+                // unevaluated quad (w = 0) or the complete one (w = 1).  Two tiles that both find w = 0 both evaluate the colour and
+                // store the same bits; the same goes for the byte they store into `clamped`.)
+                const gsr_f32x4 q = *reinterpret_cast<const volatile gsr_f32x4*>(r + 2);
+                r2 = make_float4(q[0], q[1], q[2], q[3]);
+            } else r2 = r[2];
             if (LIST == GSR_LIST_EXACT && lz.shs != nullptr && r2.w == 0.f) {      // first tile to stage this splat: its colour (LazySH)
                 uint8_t cb;
                 const float3 pm = make_float3(lz.means[3 * (size_t)id], lz.means[3 * (size_t)id + 1], lz.means[3 * (size_t)id + 2]);
@@ -1546,7 +1565,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                                      ? sh_row16_to_rgb(lz.D, pm, lz.campos, reinterpret_cast<const float4*>(lz.shs) + (size_t)id * GSR_SH16_ROW4, cb)
                                      : sh_to_rgb(lz.D, lz.M, pm, lz.campos, lz.shs + (size_t)id * lz.M * 3, cb);
                 r2 = make_float4(c.x, c.y, c.z, 1.f);
-                reinterpret_cast<float4*>(lz.rec + (size_t)id * GSR_REC_STRIDE)[2] = r2;
+                *reinterpret_cast<volatile gsr_f32x4*>(lz.rec + (size_t)id * GSR_REC_STRIDE + 8) = (gsr_f32x4){c.x, c.y, c.z, 1.f};
                 lz.clamped[id] = cb;
             }
             const uint32_t qm = quadrant_mask(r0.x, r0.y, r1.x * (-2.0f / GSR_LOG2E), r0.z * (-1.0f / GSR_LOG2E), r0.w * (-2.0f / GSR_LOG2E), r1.y,
@@ -1680,7 +1699,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             atomicMax(reinterpret_cast<int*>(zbc_next) + sb, __float_as_int(bound));     // bounds are >= 0: int order = float order
             // zb_used: the bounds this forward was binned with.  Instances can only have been dropped from a tile whose
             // bound was finite; if such a tile ends with an unsaturated pixel, a dropped instance may be missing.
-            if (unfinished && zb_used != nullptr && zb_used[tile] < __builtin_huge_valf()) atomicAdd(fail, 1u);
+            if (unfinished && zb_used != nullptr && zb_used[tile] < __builtin_huge_valf()) atomicMax(fail, fail_tag | GSR_FAIL_BOUND);
         }
     }
     const size_t N = (size_t)W * H;
@@ -1729,7 +1748,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         __syncthreads();
         if (tid < 3) {
             const float t = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
-            if (t != 0.f) atomicAdd(&fl.out[(blockIdx.x & (GSR_LOSS_SHARDS - 1)) * 16 + tid], t);
+            if (t != 0.f) atomicAdd(&fl.out[(blockIdx.x & (GSR_LOSS_SHARDS - 1)) * 16 + tid], t);      // (fl.out: this group's buffer, see PoseStepArgs::loss_shards)
         }
     }
     GSR_T_TICK(7)
@@ -1767,7 +1786,6 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
 // "colour behind" accumulators absorb the previous splat exactly as they would one step later -- instead of
 // being branched around.  alpha is recomputed with K6's expression (pre-scaled conic, v_exp_f32), bit for bit.
 // ---------------------------------------------------------------------------------------------
-typedef float gsr_f32x4 __attribute__((ext_vector_type(4)));
 template <bool B> struct BoolTag { static constexpr bool value = B; };
 #define GSR_WT_STRIDE 17
 // Weight transposition for the contraction.  A pixel lane p produces 16 values per group of eight splats (row m = 2 * splat +
@@ -2123,6 +2141,18 @@ __global__ void k_pose_init(float* st, const float* proj_raw)
     }
 }
 
+// Every small array a gsr_refine call wants cleared before its first iteration (flags, cursors, counters, partial sums, bounds
+// buffers -- a hundred KB in all), in ONE launch instead of a dozen memsets: what a 20-iteration call spends on enqueueing those
+// is a fifth of an iteration each.  Ranges of 32-bit words; unused ranges have n = 0.
+struct ClearRanges { uint32_t* p[10]; uint32_t n[10]; };
+__global__ void __launch_bounds__(GSR_BLOCK) k_refine_init(ClearRanges c)
+{
+    const uint32_t i0 = blockIdx.x * GSR_BLOCK + threadIdx.x, step = gridDim.x * GSR_BLOCK;
+#pragma unroll
+    for (int r = 0; r < 10; r++)
+        for (uint32_t i = i0; i < c.n[r]; i += step) c.p[r][i] = 0u;
+}
+
 // gsr_refine_args.init_*: the whole initial state from the caller's device tensors (zeros, R, T, exposure, camera) in one launch
 __global__ void k_pose_load(float* st, const float* R0, const float* T0, const float* ea, const float* eb, const float* proj_raw)
 {
@@ -2142,105 +2172,24 @@ __global__ void k_pose_load(float* st, const float* R0, const float* T0, const f
 // Adam (torch.optim.Adam defaults, one lr for the four groups of 7scenes_localize_full_dslam.py:33-64) on
 // [rot(3), trans(3), exposure_a, exposure_b], then update_pose (tools/pose_utils.py:54-122):
 // T_w2c <- SE3_exp([trans, rot]) T_w2c, deltas <- 0, converged = |tau| < threshold.
-// tau_acc (nullable): the fp64 block sums of K8/K9; when given, this kernel also finishes the dL/dtau
-// reduction (writes dL_dtau_out) so that the separate k_tau_finish launch is not needed in the native loop.
-// loss_zero (nullable): the native loop's loss accumulator, cleared here for the next iteration once consumed.
-__device__ __forceinline__ void pose_step_body(float* st, const float* s_t6, bool have_tau_acc, float* dL_dtau_out, const float* loss_out,
-                                               const float* proj_raw, float lr, float conv_thr, float* loss_zero)
-{
-    // inputs -> registers (independent reads, one wait), see pose_write_camera
-    float t6[6], m[8], v[8], par[8], R[9], T[3], lo[3];
-#pragma unroll
-    for (int i = 0; i < 6; i++) t6[i] = s_t6[i];
-#pragma unroll
-    for (int i = 0; i < 8; i++) { m[i] = st[GSR_PS_M + i]; v[i] = st[GSR_PS_V + i]; par[i] = st[GSR_PS_PARAM + i]; }
-#pragma unroll
-    for (int i = 0; i < 9; i++) R[i] = st[GSR_PS_R + i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) { T[i] = st[GSR_PS_T + i]; lo[i] = loss_out[i]; }
-    const float step = st[GSR_PS_STEP] + 1.f;
-    double* beta = reinterpret_cast<double*>(st + GSR_PS_BETA);
-    const double b1p = beta[0], b2p = beta[1];
-    if (have_tau_acc && dL_dtau_out) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) dL_dtau_out[i] = t6[i];
-    }
-    const float g[8] = {t6[3], t6[4], t6[5], t6[0], t6[1], t6[2], lo[1], lo[2]};
-    // beta^step as running products in double (torch evaluates beta ** step in double too; one multiplication per step
-    // instead of two software pow() calls on a single lane)
-    const double b1t = (step == 1.f ? 1.0 : b1p) * 0.9, b2t = (step == 1.f ? 1.0 : b2p) * 0.999;
-    const double bc1 = 1.0 - b1t, bc2 = 1.0 - b2t;
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    const float w1 = (float)(1.0 - 0.9), w2 = (float)(1.0 - 0.999);
-#pragma unroll
-    for (int i = 0; i < 8; i++) {
-        m[i] = m[i] + w1 * (g[i] - m[i]);                      // exp_avg.lerp_(grad, 1 - beta1)
-        v[i] = v[i] * 0.999f + w2 * (g[i] * g[i]);             // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
-        const float denom = sqrtf(v[i]) / bc2_sqrt + 1e-8f;
-        par[i] = par[i] + (-step_size) * (m[i] / denom);
-    }
-    // update_pose
-    const float th[3] = {par[0], par[1], par[2]};
-    const float rho[3] = {par[3], par[4], par[5]};
-    const float Wm[9] = {0.f, -th[2], th[1], th[2], 0.f, -th[0], -th[1], th[0], 0.f};
-    float W2[9];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) W2[i * 3 + j] = Wm[i * 3] * Wm[j] + Wm[i * 3 + 1] * Wm[3 + j] + Wm[i * 3 + 2] * Wm[6 + j];
-    const float angle = sqrtf(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
-    float cW, cW2, vW, vW2;
-    if (angle < 1e-5f) { cW = 1.f; cW2 = 0.5f; vW = 0.5f; vW2 = 1.0f / 6.0f; }
-    else {
-        cW = sinf(angle) / angle; cW2 = (1.f - cosf(angle)) / (angle * angle);
-        vW = (1.0f - cosf(angle)) / (angle * angle); vW2 = (angle - sinf(angle)) / (angle * angle * angle);
-    }
-    float Re[9], Vm[9];
-#pragma unroll
-    for (int i = 0; i < 9; i++) {
-        const float I = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
-        Re[i] = I + cW * Wm[i] + cW2 * W2[i];
-        Vm[i] = I + Wm[i] * vW + W2[i] * vW2;
-    }
-    float te[3], Rn[9], Tn[3];
-#pragma unroll
-    for (int i = 0; i < 3; i++) te[i] = Vm[i * 3] * rho[0] + Vm[i * 3 + 1] * rho[1] + Vm[i * 3 + 2] * rho[2];
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) Rn[i * 3 + j] = Re[i * 3] * R[j] + Re[i * 3 + 1] * R[3 + j] + Re[i * 3 + 2] * R[6 + j];
-        Tn[i] = Re[i * 3] * T[0] + Re[i * 3 + 1] * T[1] + Re[i * 3 + 2] * T[2] + te[i];
-    }
-    const float taun = sqrtf(rho[0] * rho[0] + rho[1] * rho[1] + rho[2] * rho[2] + th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
-    // results
-    st[GSR_PS_STEP] = step;
-    beta[0] = b1t; beta[1] = b2t;
-#pragma unroll
-    for (int i = 0; i < 8; i++) { st[GSR_PS_M + i] = m[i]; st[GSR_PS_V + i] = v[i]; }
-    st[GSR_PS_PARAM + 6] = par[6]; st[GSR_PS_PARAM + 7] = par[7];
-#pragma unroll
-    for (int i = 0; i < 9; i++) st[GSR_PS_R + i] = Rn[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) st[GSR_PS_T + i] = Tn[i];
-#pragma unroll
-    for (int i = 0; i < 6; i++) st[GSR_PS_PARAM + i] = 0.f;          // cam_rot_delta / cam_trans_delta .fill_(0)
-    st[GSR_PS_CONV] = (taun < conv_thr) ? 1.f : 0.f;
-    st[GSR_PS_TAUN] = taun;
-    st[GSR_PS_LOSS] = lo[0];
-    if (loss_zero != nullptr) { loss_zero[0] = 0.f; loss_zero[1] = 0.f; loss_zero[2] = 0.f; loss_zero[3] = 0.f; }
-    pose_write_camera(st, Rn, Tn, proj_raw);
-}
-
-// The whole pose step on one wave (64 lanes; called by k_pose_step and, in the native loop, by the last workgroup of the
-// chain-rule kernel).  The update itself is one lane's work, but as a chain of ~130 dependent global accesses it took 11 us:
-// the state, the loss terms and the projection matrix are brought into LDS by the whole wave first and written back at the end.
-// host_status (nullable, pinned host memory, 8 floats): the native loop's per-iteration status {converged, loss, |tau|,
-// poison bits} followed by the sequence number `seq`, written on every path -- no copy kernel, no event: the host polls
-// the sequence word.  tau_acc is read with agent-scope atomic loads (other workgroups of the same launch added to it).
+//
+// The whole pose step on one wave of 64 lanes (k_pose_step, and in the native loop the last workgroup of the chain-rule kernel,
+// where it is a serial tail behind the slowest workgroup of every iteration: round 2 spent 21 k cycles here -- half of that
+// kernel's duration -- in four dependent global round trips, a one-lane chain of ~1 500 instructions and a system-scope fence).
+//   * every global read of the step is issued first (state, the 64 fp64 partial sums of dL/dtau, loss shards, projection):
+//     one round trip; fp64 wave reductions; everything meets in LDS;
+//   * Adam runs on eight lanes, one parameter each (its two correctly rounded divisions and the square root are most of the
+//     one-lane chain); beta^step as running products in double (torch evaluates beta ** step in double too);
+//   * SE3_exp and the camera rebuild (pose_write_camera) stay on lane 0 -- short once the rest is gone;
+//   * the host gets ONE 32-bit status word (native loop): (seq << 4) | overflow << 2 | bound failure << 1 | converged -- a single
+//     store needs no fence; loss and |tau| stay in the state, which the host copies out once at the end of the call.
+// tau_acc (nullable): the fp64 block sums of K8/K9; when given, the step also finishes the dL/dtau reduction (writes
+// dL_dtau_out).  loss_shards (nullable): the native loop's fused-loss partial sums.  Whether or not the update runs (a failed
+// or frozen group only publishes its status), the loss shards and the superblock bounds the next forward accumulates into
+// (clear_b) are cleared here: the last workgroup of every group does it, so a failed forward leaves nothing behind.
 struct PoseStepArgs {
     float* st; const float* dL_dtau; double* tau_acc; float* dL_dtau_out; const float* loss_out; const float* proj_raw;
-    float lr, conv_thr; float* loss_zero; float* host_status; int seq; float* loss_shards; float* clear_b; int clear_n;
+    float lr, conv_thr; float* loss_zero; uint32_t* host_status; int seq; float* loss_shards; float* clear_b; int clear_n;
 };
 struct alignas(16) PoseStepLDS { float st[GSR_PS_SIZE]; float t6[8]; float loss[4]; float proj[16]; };
 __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard guard, PoseStepLDS& s)
@@ -2248,49 +2197,135 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
     const bool run = !guard.frozen();          // wave-uniform
     const int lane = threadIdx.x & 63;
     float* st = q.st;
+    const uint32_t pz = guard.poison ? *guard.poison : 0u;
+    // (1) every global read first
+    float va = 0.f, vb = 0.f, ls = 0.f, pj = 0.f, tq = 0.f;
+    double tv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     if (run) {
-        for (int i = lane; i < GSR_PS_SIZE; i += 64) s.st[i] = st[i];
-        if (q.tau_acc != nullptr) {            // lane = slot: 64 partial sums per component -> fp64 wave reduction
-            double v[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++)
-                v[i] = __hip_atomic_load(&q.tau_acc[lane * 8 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        va = st[lane];
+        if (lane < GSR_PS_SIZE - 64) vb = st[64 + lane];
+        if (q.tau_acc != nullptr) {            // lane = slot: 64 partial sums per component (other workgroups of this launch added to them:
+#pragma unroll                                 //  agent-scope atomic loads, past this CU's L1)
+            for (int i = 0; i < 6; i++) tv[i] = __hip_atomic_load(&q.tau_acc[lane * 8 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (lane < 6) tq = q.dL_dtau[lane];
+        if (lane < 16) pj = q.proj_raw[lane];
+    }
+    // fused loss: lane = shard * 4 + component
+    if (q.loss_shards != nullptr) {
+        const int at = (lane >> 2) * 16 + (lane & 3);
+        if (run) ls = q.loss_shards[at];
+        q.loss_shards[at] = 0.f;               // (also what a failed forward added)
+    } else if (run && lane < 4) ls = q.loss_out[lane];
+    if (q.clear_b != nullptr)                  // per-superblock bounds the next forward accumulates into
+        for (int i = lane; i < q.clear_n; i += 64) q.clear_b[i] = 0.f;
+    float conv_out = 0.f;
+    if (run) {
+        s.st[lane] = va;
+        if (lane < GSR_PS_SIZE - 64) s.st[64 + lane] = vb;
+        if (q.tau_acc != nullptr) {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                const double t = wave_sum_d(v[i]);
+                const double t = wave_sum_d(tv[i]);
                 if (lane == 0) s.t6[i] = (float)t;
             }
             if (q.loss_zero != nullptr) {      // native loop: leave the partial sums clean for the next backward
 #pragma unroll
-                for (int i = 0; i < 8; i++) q.tau_acc[lane * 8 + i] = 0.0;
+                for (int i = 0; i < 6; i++) q.tau_acc[lane * 8 + i] = 0.0;
             }
-        } else if (lane < 6) s.t6[lane] = q.dL_dtau[lane];
+        } else if (lane < 6) s.t6[lane] = tq;
         if (q.loss_shards != nullptr) {
-            // fused loss: lane = shard * 4 + component -- one load per lane (sixteen load -> store round trips on four lanes
-            // were most of this step's time), summed over the shards by shuffles, shards cleared for the next iteration
-            const int c = lane & 3, sh = lane >> 2;
-            float v = q.loss_shards[sh * 16 + c];
-            q.loss_shards[sh * 16 + c] = 0.f;
 #pragma unroll
-            for (int off = 4; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-            if (lane < 4) s.loss[lane] = v;
-        } else if (lane < 4) s.loss[lane] = q.loss_out[lane];
-        if (q.clear_b != nullptr)                    // per-superblock bounds the next forward accumulates into
-            for (int i = lane; i < q.clear_n; i += 64) q.clear_b[i] = 0.f;
-        if (lane >= 16 && lane < 32) s.proj[lane - 16] = q.proj_raw[lane - 16];
-        __builtin_amdgcn_wave_barrier();
-        if (lane == 0) pose_step_body(s.st, s.t6, q.tau_acc != nullptr, q.dL_dtau_out, s.loss, s.proj, q.lr, q.conv_thr, nullptr);
-        __builtin_amdgcn_wave_barrier();
+            for (int off = 4; off < 64; off <<= 1) ls += __shfl_xor(ls, off, 64);
+        }
+        if (lane < 4) s.loss[lane] = ls;
+        if (lane < 16) s.proj[lane] = pj;
+        __syncthreads();
+        // (2) Adam, one parameter per lane: [rot(3), trans(3), exposure_a, exposure_b] <- gradients [theta(3), rho(3), da, db]
+        const float step = s.st[GSR_PS_STEP] + 1.f;
+        const double* beta = reinterpret_cast<const double*>(s.st + GSR_PS_BETA);
+        const double b1t = (step == 1.f ? 1.0 : beta[0]) * 0.9, b2t = (step == 1.f ? 1.0 : beta[1]) * 0.999;
+        const double bc1 = 1.0 - b1t, bc2 = 1.0 - b2t;
+        const float step_size = (float)((double)q.lr / bc1);
+        const float bc2_sqrt = (float)sqrt(bc2);
+        const float w1 = (float)(1.0 - 0.9), w2 = (float)(1.0 - 0.999);
+        float par = 0.f, m = 0.f, v = 0.f;
+        if (lane < 8) {
+            const float g = (lane < 3) ? s.t6[3 + lane] : ((lane < 6) ? s.t6[lane - 3] : s.loss[lane - 5]);
+            m = s.st[GSR_PS_M + lane]; v = s.st[GSR_PS_V + lane]; par = s.st[GSR_PS_PARAM + lane];
+            m = m + w1 * (g - m);                                  // exp_avg.lerp_(grad, 1 - beta1)
+            v = v * 0.999f + w2 * (g * g);                         // exp_avg_sq.mul_(beta2).addcmul_(grad, grad, 1 - beta2)
+            const float denom = sqrtf(v) / bc2_sqrt + 1e-8f;
+            par = par + (-step_size) * (m / denom);
+        }
+        __syncthreads();                       // (everybody has read the old state)
+        if (lane < 8) { s.st[GSR_PS_M + lane] = m; s.st[GSR_PS_V + lane] = v; }
+        if (lane == 6 || lane == 7) s.st[GSR_PS_PARAM + lane] = par;
+        if (lane < 6) {
+            s.st[GSR_PS_PARAM + lane] = 0.f;                       // cam_rot_delta / cam_trans_delta .fill_(0)
+            if (q.tau_acc != nullptr && q.dL_dtau_out != nullptr) q.dL_dtau_out[lane] = s.t6[lane];
+        }
+#define GSR_RL(k) __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(par), k))
+        const float th[3] = {GSR_RL(0), GSR_RL(1), GSR_RL(2)}, rho[3] = {GSR_RL(3), GSR_RL(4), GSR_RL(5)};
+#undef GSR_RL
+        // (3) update_pose on lane 0
+        if (lane == 0) {
+            float R[9], T[3];
+#pragma unroll
+            for (int i = 0; i < 9; i++) R[i] = s.st[GSR_PS_R + i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) T[i] = s.st[GSR_PS_T + i];
+            const float Wm[9] = {0.f, -th[2], th[1], th[2], 0.f, -th[0], -th[1], th[0], 0.f};
+            float W2[9];
+#pragma unroll
+            for (int i = 0; i < 3; i++)
+#pragma unroll
+                for (int j = 0; j < 3; j++) W2[i * 3 + j] = Wm[i * 3] * Wm[j] + Wm[i * 3 + 1] * Wm[3 + j] + Wm[i * 3 + 2] * Wm[6 + j];
+            const float angle = sqrtf(th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
+            float cW, cW2, vW, vW2;
+            if (angle < 1e-5f) { cW = 1.f; cW2 = 0.5f; vW = 0.5f; vW2 = 1.0f / 6.0f; }
+            else {
+                cW = sinf(angle) / angle; cW2 = (1.f - cosf(angle)) / (angle * angle);
+                vW = (1.0f - cosf(angle)) / (angle * angle); vW2 = (angle - sinf(angle)) / (angle * angle * angle);
+            }
+            float Re[9], Vm[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) {
+                const float I = (i == 0 || i == 4 || i == 8) ? 1.f : 0.f;
+                Re[i] = I + cW * Wm[i] + cW2 * W2[i];
+                Vm[i] = I + Wm[i] * vW + W2[i] * vW2;
+            }
+            float te[3], Rn[9], Tn[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) te[i] = Vm[i * 3] * rho[0] + Vm[i * 3 + 1] * rho[1] + Vm[i * 3 + 2] * rho[2];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) Rn[i * 3 + j] = Re[i * 3] * R[j] + Re[i * 3 + 1] * R[3 + j] + Re[i * 3 + 2] * R[6 + j];
+                Tn[i] = Re[i * 3] * T[0] + Re[i * 3 + 1] * T[1] + Re[i * 3 + 2] * T[2] + te[i];
+            }
+            const float taun = sqrtf(rho[0] * rho[0] + rho[1] * rho[1] + rho[2] * rho[2] + th[0] * th[0] + th[1] * th[1] + th[2] * th[2]);
+            s.st[GSR_PS_STEP] = step;
+            double* beta_w = reinterpret_cast<double*>(s.st + GSR_PS_BETA);
+            beta_w[0] = b1t; beta_w[1] = b2t;
+#pragma unroll
+            for (int i = 0; i < 9; i++) s.st[GSR_PS_R + i] = Rn[i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) s.st[GSR_PS_T + i] = Tn[i];
+            s.st[GSR_PS_CONV] = (taun < q.conv_thr) ? 1.f : 0.f;
+            s.st[GSR_PS_TAUN] = taun;
+            s.st[GSR_PS_LOSS] = s.loss[0];
+            pose_write_camera(s.st, Rn, Tn, s.proj);
+        }
+        __syncthreads();
+        conv_out = s.st[GSR_PS_CONV];
         for (int i = lane; i < GSR_PS_SIZE; i += 64)
             if (i != GSR_PS_POISON && i != GSR_PS_TICKET) st[i] = s.st[i];           // (those two words belong to other kernels and the host)
         if (q.loss_zero != nullptr && lane < 4) q.loss_zero[lane] = 0.f;
-    }
+    } else conv_out = st[GSR_PS_CONV];
     if (lane == 0 && q.host_status != nullptr) {
-        const float* cur = run ? s.st : st;
-        q.host_status[0] = cur[GSR_PS_CONV]; q.host_status[1] = cur[GSR_PS_LOSS]; q.host_status[2] = cur[GSR_PS_TAUN];
-        q.host_status[3] = __uint_as_float(guard.poison ? *guard.poison : 0u);
-        __threadfence_system();
-        reinterpret_cast<volatile int*>(q.host_status)[4] = q.seq;
+        const uint32_t flags = ((pz >> 2) == guard.tag && guard.poison != nullptr) ? (pz & 3u) : 0u;
+        // one 32-bit store into pinned host memory: the host polls the sequence bits and finds the flags in the same word
+        *reinterpret_cast<volatile uint32_t*>(q.host_status) = ((uint32_t)q.seq << 4) | (flags << 1) | (conv_out != 0.f ? 1u : 0u);
     }
 }
 __global__ void __launch_bounds__(64) k_pose_step(PoseStepArgs q, LoopGuard guard)
@@ -2477,6 +2512,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     const bool frozen = a.guard.frozen();      // (a frozen iteration still takes its ticket: the last workgroup publishes the status)
     if (frozen && a.ticket == nullptr) return;
     float tw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // world-frame sums behind dL/dtau, see (6) below
+    GSR_T_DECL
   if (!frozen) {
     // SH rows in (and dL_dsh rows out) as 16-B-per-lane streams of whole 192-B rows through LDS
     const bool staged = (a.shs != nullptr) && sh16_vector_ok(a.M, a.shs) &&
@@ -2524,8 +2560,10 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             if (active) s_q[qn + (int)__popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)idx | (has_col ? 0x80000000u : 0u);
             qn += (int)__popcll(mk);
         }
+        GSR_T_TICK(0)
         if (qn == 0) break;
         __syncthreads();
+        GSR_T_COUNT(10, 1)
         // ---- chain rule on the first (up to) 64 queued Gaussians, dense lanes (their records are re-read: L2 hits)
         const int nrow = min(qn, GSR_K8_ROWS);
         const bool active = lane < nrow;
@@ -2552,6 +2590,8 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             }
         }
         __syncthreads();
+        GSR_T_TICK(1)
+        GSR_T_COUNT(11, nrow)
         float* my_row = reinterpret_cast<float*>(&s_sh[lane * GSR_SH16_LDS4]);
         if (active) {
             float cov6[6];
@@ -2591,6 +2631,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
                 const float dz = r2.y;
                 g_geo.x += a.view[2] * dz; g_geo.y += a.view[6] * dz; g_geo.z += a.view[10] * dz;
             }
+            GSR_T_TICK(2)
             // (4) colour gradient -> SH coefficients and the view direction's share of the mean gradient
             float3 g_sh = make_float3(0.f, 0.f, 0.f);
             if (a.shs && has_col) {
@@ -2601,6 +2642,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
                     g_sh = sh_color_backward(a.D, a.M, mean, a.campos, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dcol,
                                              a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
             }
+            GSR_T_TICK(3)
             if (a.dL_dmean3D) {
                 a.dL_dmean3D[3 * (size_t)idx] = g_geo.x + g_sh.x;
                 a.dL_dmean3D[3 * (size_t)idx + 1] = g_geo.y + g_sh.y;
@@ -2631,6 +2673,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
                 tw[9] += 2.f * (P12 - P21); tw[10] += 2.f * (P20 - P02); tw[11] += 2.f * (P01 - P10);
             }
         }
+        GSR_T_TICK(4)
         if (staged && a.dL_dsh) {
             __syncthreads();
 #pragma unroll
@@ -2648,6 +2691,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         if (nrow + lane < qn) s_q[lane] = keep;
         qn -= nrow;
         __syncthreads();
+        GSR_T_TICK(5)
     }
     if (a.pose) {
         // wave reduction in fp64, rotation into the camera frame, then one fp64 atomic per wave and component into one of
@@ -2672,6 +2716,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
                 if (tau[i] != 0.0) atomicAdd(&a.tau_acc[(blockIdx.x & (GSR_TAU_SLOTS - 1)) * 8 + i], tau[i]);
         }
     }
+    GSR_T_TICK(6)
   }
     if (a.ticket != nullptr) {
         // Two levels: ~2000 workgroups drawing from ONE counter would queue up at the memory-side atomic unit for longer
@@ -2689,14 +2734,17 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             if (t == in_grp - 1u) t = atomicAdd(a.ticket, 1u) + 0x10000u;
         }
         t = (uint32_t)__builtin_amdgcn_readfirstlane((int)t);
+        GSR_T_TICK(7)
         if (t == 0x10000u + ngrp - 1u) {
             // last of all: everybody's sums are in (read below with agent-scope atomic loads, past this CU's L1)
             if (lane == 0) *a.ticket = 0u;             // (the next launch starts counting from zero)
             reinterpret_cast<uint32_t*>(&a.tau_acc[lane * 8 + 6])[0] = 0u;      // the group counters too, also on a frozen iteration
             a.surv.n[lane * GSR_SURV_CSTRIDE] = 0u;    // every workgroup is past its work list: the next forward appends from zero
             pose_step_wave(a.fold, a.guard, s_pose);
+            GSR_T_TICK(8)
         }
     }
+    GSR_T_FLUSH(48)
 }
 
 __device__ __forceinline__ double tau_total(const double* acc, int i)

@@ -105,7 +105,7 @@ class FusedRefiner:
         self._state_host = (C.c_float * _lib.POSE_STATE_FLOATS)()
 
     def _tensor_versions(self):
-        ts = (self.scales, self.rots, self.g_m2d, self.g_conic, self.g_opac, self.g_col, self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot)
+        ts = (self.scales, self.rots, self.g_alpha, self.g_m2d, self.g_conic, self.g_opac, self.g_col, self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot)
         return tuple(-1 if t is None else t._version for t in ts)
 
     def _cached(self, slot, t, make):

@@ -352,9 +352,9 @@ int gsr_profile_enable(unsigned mask);
 /* Bracket only one launch in `every` of each enabled kernel (default 1 = all): an event pair around a kernel keeps it
  * from overlapping its neighbours, which costs ~5 % with several frames in flight. */
 int gsr_profile_sampling(unsigned every);
-/* Diagnostic builds only (compiled with -DGSR_TIMING=1): copies out and clears 48 shader-clock phase totals
- * (slots 0-15 compositing forward, 16-31 compositing backward, 32-47 preprocess).  Returns -1 in product builds. */
-int gsr_debug_timing(unsigned long long* out48);
+/* Diagnostic builds only (compiled with -DGSR_TIMING=1): copies out and clears 64 shader-clock phase totals
+ * (slots 0-15 compositing forward, 16-31 compositing backward, 32-47 preprocess, 48-63 chain rule).  Returns -1 in product builds. */
+int gsr_debug_timing(unsigned long long* out64);
 int gsr_profile_collect(double* ms, long long* launches);
 int gsr_profile_kernel_count(void);
 const char* gsr_profile_kernel_name(int id);

@@ -13,6 +13,9 @@ from tests import util as U
 
 pytestmark = pytest.mark.gpu
 
+# fixed per-tensor bounds (rel-L1) of the training step's gradients against the oracle on the same opacity image
+TRAIN_GRAD_TOL = {"means3D": 5e-5, "means2D": 5e-5, "opacities": 5e-5, "sh": 5e-5, "scales": 5e-5, "rotations": 5e-5}
+
 
 def _check_step_against_oracle(tr, it):
     from oracle import oracle as O
@@ -25,18 +28,19 @@ def _check_step_against_oracle(tr, it):
     assert np.abs(gd).sum() > 0 and np.abs(gc).sum() > 0           # grad_depth != 0: the Pearson term is live
     # Tolerance.  The reference's backward rebuilds every pixel's transmittance from the saved opacity image,
     # T_final = 1 - alpha (backward.cu:445), and 95 % of these pixels are saturated (alpha > 0.999): one ulp of alpha is 1e-4 of
-    # T_final and scales every weight of that pixel.  With the SSIM gradient changing sign from pixel to pixel the per-Gaussian
-    # sums cancel, and the algorithm's own answer moves by 4e-4 ... 2e-3 when the alpha image is nudged by +-1 ulp (`noise`
-    # below, oracle against oracle).  Two correct fp32 implementations (v_exp_f32 here, expf there) cannot agree better than a
-    # fraction of that; the bar is 2e-5 or a tenth of that sensitivity, whichever is larger.  (Sums in double in the oracle, as in
-    # test_large_images: its fp32 atomics' order noise, 3e-6 here, stays out of the comparison.)
+    # T_final and scales every weight of that pixel, so two correct forwards (v_exp_f32 here, expf there) that agree to 1e-7 in
+    # alpha hand their backwards different inputs.  The opacity image is an INPUT of the backward (rasterize_points.cu:121-206
+    # takes it as an argument): the oracle's backward is therefore run on the opacity image the HIP forward produced -- the same
+    # input both backwards -- and the comparison needs no allowance for that conditioning: fixed bounds per tensor.  (Sums in
+    # double in the oracle, as in test_large_images: its fp32 atomics' order noise, 3e-6 here, stays out of the comparison.)
     O.set_accumulate_double(True)
     try:
-        f, go = U.oracle_run(sc, cam, (gc, gd, ga), pose=False)
+        f, _ = U.oracle_run(sc, cam, None, pose=False)
         a_own = f.alpha
-        up = np.random.default_rng(0).uniform(size=a_own.shape) < 0.5
-        f.alpha = np.where(up, np.nextafter(a_own, np.float32(2)), np.nextafter(a_own, np.float32(0))).astype(np.float32)
-        g_nudged = O.backward(f, gc, gd, ga, pose_mode=False)
+        a_hip = L["alpha"].detach().cpu().numpy().reshape(a_own.shape).astype(np.float32)
+        assert U.rel_l1(a_hip, a_own) <= 1e-4
+        f.alpha = a_hip
+        go = O.backward(f, gc, gd, ga, pose_mode=False)
         f.alpha = a_own
     finally:
         O.set_accumulate_double(False)
@@ -44,10 +48,13 @@ def _check_step_against_oracle(tr, it):
     for k, ref in (("image", f.color), ("depth", f.depth), ("alpha", f.alpha)):
         e = U.rel_l1(L[k].detach().cpu().numpy(), ref)
         assert e <= 1e-4, (it, tr.P, k, e)
+    errs = {}
     for k in ("means3D", "means2D", "opacities", "sh", "scales", "rotations"):
         got = L["grads"][k].cpu().numpy()
-        e, noise = U.rel_l1(got.reshape(go[k].shape), go[k]), U.rel_l1(g_nudged[k], go[k])
-        assert e <= max(2e-5, 0.1 * noise), (it, tr.P, k, e, noise)
+        errs[k] = U.rel_l1(got.reshape(go[k].shape), go[k])
+    print("train replay gradient errors at P =", tr.P, {k: float("%.2e" % v) for k, v in errs.items()})
+    for k, e in errs.items():
+        assert e <= TRAIN_GRAD_TOL[k], (it, tr.P, k, e)
     return sc.P
 
 

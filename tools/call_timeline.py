@@ -1,0 +1,36 @@
+"""What one FusedRefiner.refine() call of K iterations costs next to K steady-state iterations (bench.py's per_call_overhead_ms),
+split into host phases.  usage: python tools/call_timeline.py [K] [calls]
+Under `rocprofv3 --kernel-trace` the kernel trace of the same run is what tools/kt_calls.py takes apart (one call = the kernels
+from one k_pose_load to the next)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gs_localization_amd import scenes as S
+from tests import replay as PL
+dev = torch.device("cuda:0")
+K = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+sc = S.s_1m_640(); H, W = sc.H, sc.W
+model = PL.GaussianMap.from_scene(sc, device=dev)
+bg = torch.zeros(3, device=dev)
+vp = PL.make_frame(sc, model, dev, bg)
+init = PL.perturbed_start(1000, device=dev)
+fr = PL.FusedRefiner(model, H, W, device=dev)
+def call(k):
+    return fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=k, stop_on_converged=False)
+call(K); call(K); torch.cuda.synchronize()
+ts = []
+for _ in range(calls):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); call(K); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+tl = []
+for _ in range(3):
+    torch.cuda.synchronize(); t0 = time.perf_counter(); call(5 * K); torch.cuda.synchronize(); tl.append(time.perf_counter() - t0)
+tk, t5 = min(ts), min(tl)
+steady = (t5 - tk) / (4 * K)
+print("K = %d: call %.3f ms (min of %d; median %.3f), steady state %.1f us / iteration, per-call overhead %.3f ms, %d it/s" %
+      (K, 1e3 * tk, calls, 1e3 * sorted(ts)[len(ts) // 2], 1e6 * steady, 1e3 * (tk - K * steady), K / tk))
+import cProfile, pstats
+pr = cProfile.Profile(); pr.enable()
+for _ in range(20):
+    call(K)
+pr.disable(); pstats.Stats(pr).sort_stats("tottime").print_stats(14)

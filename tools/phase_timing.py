@@ -20,7 +20,7 @@ ITERS = 40
 nk = lib.gsr_profile_kernel_count(); names = [lib.gsr_profile_kernel_name(i).decode() for i in range(nk)]
 fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False, speculative=not os.environ.get("LOOP_PLAIN"))
 torch.cuda.synchronize()
-out = (C.c_ulonglong * 48)()
+out = (C.c_ulonglong * 64)()
 assert lib.gsr_debug_timing(out) == 0, "not a GSR_TIMING build"
 lib.gsr_profile_enable((1 << nk) - 1)
 fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=ITERS, stop_on_converged=False, speculative=not os.environ.get("LOOP_PLAIN"))
@@ -45,7 +45,13 @@ show("k_render_bwd_mfma", 16, ["prologue", "batch top barrier", "staging + barri
 nw = (sc.P + 255) // 256 * ITERS      # one wave per 256 Gaussians
 show("k_preprocess_lean", 32, ["bounds -> LDS + barrier", "conservative pass (4 x 64 Gaussians)", "exact pass on the compacted candidates", "", "",
                                "", "", "", "", "(wave lifetime)", "candidates", ""])
+# (working waves of the chain-rule kernel: the ones that ran at least one round)
+rounds = max(v[48 + 10], 1)
+print("k_preprocess_bwd (cycles per ROUND of <= 64 Gaussians, mean over %d rounds = %.1f per launch; %d Gaussians per launch)" % (rounds, rounds / ITERS, v[48 + 11] / ITERS))
+for i, l in enumerate(["fill: list -> records -> queue", "barrier, records again, SH rows in", "loads + covariance chain + mean2D", "SH backward",
+                       "stores, scale / rotation, pose sums", "SH rows out, queue shift", "fp64 reduction + dL/dtau atomics (per wave)", "ticket", "pose step (last wave)"]):
+    print("  %-44s %10.0f" % (l, v[48 + i] / (rounds if i < 6 else ITERS * (2048 if i < 8 else 1))))
 # Is a kernel's duration its mean wave or its slowest one?  (rows = wave positions; all tiles of K6 / K7 are resident at once)
-for name, base, launches in (("k_render_fwd", 0, ITERS), ("k_render_bwd_mfma", 16, ITERS), ("k_preprocess_lean", 32, ITERS)):
+for name, base, launches in (("k_render_fwd", 0, ITERS), ("k_render_bwd_mfma", 16, ITERS), ("k_preprocess_lean", 32, ITERS), ("k_preprocess_bwd", 48, ITERS)):
     print("%-20s wave lifetime per launch (cycles): median %8.0f   99th percentile %8.0f   max %8.0f   (%d rows)" %
           (name, v[base + 14] / launches, v[base + 15] / launches, v[base + 12] / launches, v[base + 13]))
