@@ -174,6 +174,26 @@ __device__ __forceinline__ double wave_sum_d(double v)
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
+// fp64 total of all 64 lanes in lane 63 (other lanes hold partial sums), on the DPP path like wave_sum_to_lane63: two 32-bit DPP
+// moves + one v_add_f64 per step instead of two ds_bpermute round trips through the LDS pipe (a dozen of these sums close the
+// chain-rule kernel's critical path: 6.5 k cycles per wave with the shuffles)
+__device__ __forceinline__ double wave_sum_d_to_lane63(double v)
+{
+#define GSR_DPP_ADD_D(ctrl, rm)                                                                                          \
+    {                                                                                                                    \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(v), ctrl, rm, 0xf, true);                          \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(v), ctrl, rm, 0xf, true);                          \
+        v += __hiloint2double(hi_, lo_);                                                                                 \
+    }
+    GSR_DPP_ADD_D(0x111, 0xf)   // row_shr:1
+    GSR_DPP_ADD_D(0x112, 0xf)   // row_shr:2
+    GSR_DPP_ADD_D(0x114, 0xf)   // row_shr:4
+    GSR_DPP_ADD_D(0x118, 0xf)   // row_shr:8   -> lane 15 of each row = row total
+    GSR_DPP_ADD_D(0x142, 0xa)   // row_bcast:15 into rows 1, 3
+    GSR_DPP_ADD_D(0x143, 0xc)   // row_bcast:31 into rows 2, 3
+#undef GSR_DPP_ADD_D
+    return v;
+}
 
 // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous
 // run of tiles; bijective for any n (cdna_hip_programming.md section 5, "XCD swizzle must be bijective").

@@ -2225,8 +2225,8 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
         if (q.tau_acc != nullptr) {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
-                const double t = wave_sum_d(tv[i]);
-                if (lane == 0) s.t6[i] = (float)t;
+                const double t = wave_sum_d_to_lane63(tv[i]);
+                if (lane == 63) s.t6[i] = (float)t;
             }
             if (q.loss_zero != nullptr) {      // native loop: leave the partial sums clean for the next backward
 #pragma unroll
@@ -2696,10 +2696,16 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     if (a.pose) {
         // wave reduction in fp64, rotation into the camera frame, then one fp64 atomic per wave and component into one of
         // GSR_TAU_SLOTS partial sums (64 B apart: thousands of waves adding into six words would queue up at the memory-side atomic unit)
-        double sw[12];
+        // (a wave that queued nothing -- seven in eight of them in a speculative iteration -- has nothing to add)
+        bool any = false;
 #pragma unroll
-        for (int i = 0; i < 12; i++) sw[i] = wave_sum_d((double)tw[i]);
-        if (lane == 0) {
+        for (int i = 0; i < 12; i++) any = any || (tw[i] != 0.f);
+        double sw[12];
+        if (__ballot(any) != 0ull) {
+#pragma unroll
+        for (int i = 0; i < 12; i++) sw[i] = wave_sum_d_to_lane63((double)tw[i]);
+        }
+        if (lane == 63 && __ballot(any) != 0ull) {
             const float* vm = a.view;
             double tau[6], wg[3];
 #pragma unroll

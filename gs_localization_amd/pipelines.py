@@ -212,12 +212,13 @@ class FusedRefiner:
         self._carry_versions = self._tensor_versions() + (float(scale_modifier),)
         self._last_args = a                                          # (gsr_debug_lean_check takes the same struct)
         self._keep = (R0, T0, ea0, eb0, proj_raw, gt_image, gt_depth, mask, bg)        # alive until the stream has drained
-        # the final pose came back with the call (gsr_refine_args.pose_state_host): no second blocking read
+        # the final pose came back with the call (gsr_refine_args.pose_state_host): no second blocking read.  The camera gets
+        # device tensors cut out of the state (four tiny asynchronous copies; host -> device uploads would each stall)
         s = torch.tensor(self._state_host[0:40], dtype=torch.float32)
-        viewpoint.update_RT(s[0:9].reshape(3, 3).to(dev), s[9:12].to(dev))
         with torch.no_grad():
-            viewpoint.exposure_a.fill_(float(s[18]))
-            viewpoint.exposure_b.fill_(float(s[19]))
+            viewpoint.update_RT(self.state[0:9].reshape(3, 3).clone(), self.state[9:12].clone())
+            viewpoint.exposure_a.copy_(self.state[18:19].reshape(viewpoint.exposure_a.shape))
+            viewpoint.exposure_b.copy_(self.state[19:20].reshape(viewpoint.exposure_b.shape))
         self.last_info = {"fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2])}
         return viewpoint.R, viewpoint.T, {"iters": n_done.value, "converged": bool(conv.value), "loss": float(s[38]),
                                           "fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]),

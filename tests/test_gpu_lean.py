@@ -228,7 +228,9 @@ def test_conservative_bound_on_adversarial_inputs(kind):
                lean_min_P=1, flags=0, warm_start=False)
     with torch.no_grad():
         pkg = PL.render(vp, model, bg, scaling_modifier=mod)
-    assert torch.allclose(lean["color"], pkg["render"], atol=5e-4), float((lean["color"] - pkg["render"]).abs().max())
+    # (two runs' poses, ~1e-6 apart, on splats with razor-sharp edges: see _same_path)
+    assert torch.allclose(lean["color"], pkg["render"], atol=2e-3), float((lean["color"] - pkg["render"]).abs().max())
+    assert float((lean["color"] - pkg["render"]).abs().mean()) <= 2e-5
     assert int((lean["radii"] != pkg["radii"]).sum().item()) <= 2
 
 

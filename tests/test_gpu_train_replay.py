@@ -13,8 +13,8 @@ from tests import util as U
 
 pytestmark = pytest.mark.gpu
 
-# fixed per-tensor bounds (rel-L1) of the training step's gradients against the oracle on the same opacity image
-TRAIN_GRAD_TOL = {"means3D": 5e-5, "means2D": 5e-5, "opacities": 5e-5, "sh": 5e-5, "scales": 5e-5, "rotations": 5e-5}
+# fixed per-tensor bounds (rel-L1) of the training step's gradients against the oracle (see _check_step_against_oracle)
+TRAIN_GRAD_TOL = {"means3D": 1e-4, "means2D": 1e-4, "opacities": 1e-4, "sh": 1e-4, "scales": 1e-4, "rotations": 1e-4}
 
 
 def _check_step_against_oracle(tr, it):
@@ -28,19 +28,21 @@ def _check_step_against_oracle(tr, it):
     assert np.abs(gd).sum() > 0 and np.abs(gc).sum() > 0           # grad_depth != 0: the Pearson term is live
     # Tolerance.  The reference's backward rebuilds every pixel's transmittance from the saved opacity image,
     # T_final = 1 - alpha (backward.cu:445), and 95 % of these pixels are saturated (alpha > 0.999): one ulp of alpha is 1e-4 of
-    # T_final and scales every weight of that pixel, so two correct forwards (v_exp_f32 here, expf there) that agree to 1e-7 in
-    # alpha hand their backwards different inputs.  The opacity image is an INPUT of the backward (rasterize_points.cu:121-206
-    # takes it as an argument): the oracle's backward is therefore run on the opacity image the HIP forward produced -- the same
-    # input both backwards -- and the comparison needs no allowance for that conditioning: fixed bounds per tensor.  (Sums in
-    # double in the oracle, as in test_large_images: its fp32 atomics' order noise, 3e-6 here, stays out of the comparison.)
+    # T_final and scales every weight of that pixel.  With the SSIM gradient changing sign from pixel to pixel the per-Gaussian
+    # sums cancel: the algorithm's own answer moves by 4e-4 ... 2e-3 when its alpha image is nudged by +-1 ulp (printed below as
+    # `conditioning`, oracle against oracle).  Two correct fp32 forwards (v_exp_f32 here, expf there) differ by such ulps, so
+    # the backwards cannot agree to the 2e-5 of the localisation configs; measured: 1e-5 ... 4e-5 at the three sizes.  The bound
+    # is FIXED, 1e-4 per tensor -- a quarter of the smallest conditioning figure; a wrong list order or a dropped instance shows
+    # as 1e-2.  (Handing the oracle's backward the HIP forward's opacity image instead was tried: its own n_contrib then no
+    # longer matches that image on the pixels where the T < 1e-4 test flips, and the error grows to 4e-4.)  Sums in double in
+    # the oracle, as in test_large_images: its fp32 atomics' order noise, 3e-6 here, stays out of the comparison.
     O.set_accumulate_double(True)
     try:
-        f, _ = U.oracle_run(sc, cam, None, pose=False)
+        f, go = U.oracle_run(sc, cam, (gc, gd, ga), pose=False)
         a_own = f.alpha
-        a_hip = L["alpha"].detach().cpu().numpy().reshape(a_own.shape).astype(np.float32)
-        assert U.rel_l1(a_hip, a_own) <= 1e-4
-        f.alpha = a_hip
-        go = O.backward(f, gc, gd, ga, pose_mode=False)
+        up = np.random.default_rng(0).uniform(size=a_own.shape) < 0.5
+        f.alpha = np.where(up, np.nextafter(a_own, np.float32(2)), np.nextafter(a_own, np.float32(0))).astype(np.float32)
+        g_nudged = O.backward(f, gc, gd, ga, pose_mode=False)
         f.alpha = a_own
     finally:
         O.set_accumulate_double(False)
@@ -48,11 +50,13 @@ def _check_step_against_oracle(tr, it):
     for k, ref in (("image", f.color), ("depth", f.depth), ("alpha", f.alpha)):
         e = U.rel_l1(L[k].detach().cpu().numpy(), ref)
         assert e <= 1e-4, (it, tr.P, k, e)
-    errs = {}
+    errs, cond = {}, {}
     for k in ("means3D", "means2D", "opacities", "sh", "scales", "rotations"):
         got = L["grads"][k].cpu().numpy()
         errs[k] = U.rel_l1(got.reshape(go[k].shape), go[k])
-    print("train replay gradient errors at P =", tr.P, {k: float("%.2e" % v) for k, v in errs.items()})
+        cond[k] = U.rel_l1(g_nudged[k], go[k])
+    print("train replay at P =", tr.P, "gradient errors", {k: float("%.1e" % v) for k, v in errs.items()},
+          "conditioning (oracle, alpha +-1 ulp)", {k: float("%.1e" % v) for k, v in cond.items()})
     for k, e in errs.items():
         assert e <= TRAIN_GRAD_TOL[k], (it, tr.P, k, e)
     return sc.P
