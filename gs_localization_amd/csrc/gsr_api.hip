@@ -192,6 +192,16 @@ struct BinLocal { uint32_t* vals; unsigned long long* bins; };
 // saturate) gets its complete list, ~R / tiles: room for four times the in-LDS sort's limit while that is affordable
 // (96 KB per tile: 118 MB at 640x480).
 int bin_capacity(int ntiles) { return ntiles <= 4096 ? 4 * GSR_LSORT_CAP : GSR_LSORT_CAP; }
+// Entries per bin for COMPLETE lists (k_preprocess_bin): eight times the mean number of Gaussians per tile, a power of two,
+// at least 8 192.  (S-1M-640: 8 192 for a mean list of 2 800 after exact culling; S-3M-cam: 16 384 for 7 200.)  A tile that
+// needs more makes the forward fall back to the exact count -> scan -> emit path; 12 bytes per entry.
+int full_bin_capacity(int P, int ntiles)
+{
+    long long want = 8ll * P / (ntiles > 0 ? ntiles : 1);
+    int cap = 4 * GSR_LSORT_CAP;
+    while (cap < want && cap < (1 << 20)) cap <<= 1;
+    return cap;
+}
 size_t carve_bin_local(char* base, int ntiles, int cap, BinLocal& b)
 {
     Carver c(base);
@@ -222,6 +232,8 @@ struct PassCtx {
     int lean_min_P = 200000;       // k_preprocess_lean from this many Gaussians on
     int* n_lean = nullptr;         // counts the forwards that ran k_preprocess_lean (gsr_refine_args.stats_out[2])
     bool sh_eager = false;         // diagnostics (debug bit 1 of gsr_forward): k_sh_color for every visible Gaussian instead of lazy colours
+    bool exact_bins = false;       // complete lists through count -> scan -> emit (after a bin of k_preprocess_bin overflowed; diagnostics)
+    bool* used_full_bins = nullptr;   // out: this forward binned its complete lists into fixed-capacity bins (k_preprocess_bin)
 };
 // gsr_forward_speculative: bounds, flags, cursors and the unsorted bins live in the caller's persistent state buffer
 // instead of the per-call image / binning buffers (which then only hold what the backward reads)
@@ -437,6 +449,7 @@ int allow_large_lds(int dev)
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gsr::k_tile_count<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gsr::k_tile_emit<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gsr::k_tile_emit<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
+    HIPCHK(hipFuncSetAttribute(reinterpret_cast<const void*>(gsr::k_preprocess_bin), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024));
     done[dev] = true;
     return GSR_OK;
 }
@@ -537,8 +550,18 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     pa.zbc = zb_prev ? im.zbc[sp.parity ^ 1] : nullptr; pa.sbx = im.sbx;
     float* zbc_next = (sp.mode != 0) ? im.zbc[sp.parity] : nullptr;
     BinLocal bl{nullptr, nullptr};
-    const int bin_cap = (sp.state != nullptr) ? GSR_LSORT_CAP : bin_capacity(ntiles);      // (a caller's state buffer holds 2048-entry bins)
+    // Complete lists (no depth bounds to speculate with): binned by the preprocess kernel itself into fixed-capacity bins
+    // (k_preprocess_bin) while their counters fit the LDS; otherwise, and after a bin overflowed, count -> scan -> emit.
+    const bool full_bins = !by_tile && !cx.exact_bins && ntiles <= kTileBinLdsTiles;
+    if (cx.used_full_bins) *cx.used_full_bins = full_bins;
+    const int bin_cap = full_bins ? full_bin_capacity(P, ntiles)
+                                  : ((sp.state != nullptr) ? GSR_LSORT_CAP : bin_capacity(ntiles));      // (a caller's state buffer holds 2048-entry bins)
     pa.bin_cap = bin_cap;
+    if (full_bins) {
+        char* lptr = (char*)binning_buffer(binning_ctx, carve_bin_local(nullptr, ntiles, bin_cap, bl));
+        if (!lptr) return fail(GSR_E_ALLOC, "binning buffer callback returned NULL%s", "");
+        carve_bin_local(lptr, ntiles, bin_cap, bl);
+    }
     if (by_tile) {
         // (with a state buffer the unsorted bins live there and the per-call buffer only holds the sorted lists)
         const size_t lbytes = state_bins ? (size_t)ntiles * GSR_LSORT_CAP * sizeof(uint32_t) : carve_bin_local(nullptr, ntiles, bin_cap, bl);
@@ -547,16 +570,17 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         if (state_bins) { bl.vals = reinterpret_cast<uint32_t*>(lptr); bl.bins = state_bins; }
         else carve_bin_local(lptr, ntiles, bin_cap, bl);
     }
-    pa.tile_cursor = by_tile ? im.tile_cursor : nullptr;
+    pa.tile_cursor = (by_tile || full_bins) ? im.tile_cursor : nullptr;
     pa.bins = bl.bins;
-    pa.tile_count = by_tile ? nullptr : im.tile_count;
+    pa.tile_count = (by_tile || full_bins) ? nullptr : im.tile_count;
     pa.ntiles = ntiles;
     // (on the by-tile path inside gsr_refine these words are cleared by the kernels that consume them: the tile cursors
     // by the compositing kernel, the superblock bounds by the pose step)
     if (sp.mode != 0 && !(by_tile && cx.native_loop)) {
         HIPCHK(hipMemsetAsync(im.fail, 0, im.clear_words * sizeof(uint32_t), st));
         HIPCHK(hipMemsetAsync(zbc_next, 0, (size_t)im.nsb * sizeof(float), st));
-    }
+    } else if (full_bins && !cx.native_loop)      // (the stateless entry points get a fresh image buffer per call: flag + cursors)
+        HIPCHK(hipMemsetAsync(im.fail, 0, im.clear_words * sizeof(uint32_t), st));
     {
         ProfScope ps(K_PREPROCESS, st);
         pa.zbc_lds = (pa.zbc != nullptr && im.nsb <= 4096) ? im.nsb : 0;
@@ -571,7 +595,17 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         pa.ntiles = ntiles * im.copies;
         // (the first two workgroups also compute the launch orders of the compositing kernels: there must be two)
         const int blocks = std::max(by_tile ? pblocks : std::max(pblocks, (pa.ntiles + GSR_BLOCK - 1) / GSR_BLOCK), balanced ? 2 : 1);
-        if (pa.lean) {
+        if (full_bins) {
+            rc = allow_large_lds(dev);
+            if (rc != GSR_OK) return rc;
+            pa.lean = 0; pa.sh_here = 0;
+            pa.ntiles = ntiles;
+            int bands = (int)(((size_t)P * 36 + (12u << 20) - 1) / (12u << 20));          // (~4.4 instances of 8 B per Gaussian: a band's keys fit the L2s)
+            bands = std::max(1, std::min(bands, std::min(gy, 16)));
+            const int gpb = GSR_PBIN_KPT * GSR_PBIN_THREADS;
+            hipLaunchKernelGGL(k_preprocess_bin, dim3(std::max((P + gpb - 1) / gpb, balanced ? 2 : 1)), dim3(GSR_PBIN_THREADS),
+                               (size_t)2 * ntiles * sizeof(uint32_t), st, pa, bands);
+        } else if (pa.lean) {
             // radii are not an output of this forward: conservative test for all Gaussians, exact geometry for the few it leaves
             const int lblocks = std::max((P + GSR_LEAN_PER_LANE * GSR_BLOCK - 1) / (GSR_LEAN_PER_LANE * GSR_BLOCK), balanced ? 2 : 1);
             hipLaunchKernelGGL(k_preprocess_lean, dim3(lblocks), dim3(GSR_BLOCK), (size_t)pa.zbc_lds * sizeof(float), st, pa);
@@ -598,7 +632,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     }
     int R = 0;
     Bin b{nullptr, nullptr};
-    if (!by_tile) {
+    if (!by_tile && !full_bins) {
         TileBinArgs ta;
         ta.P = P; ta.gx = gx; ta.gy = gy; ta.ntiles = ntiles; ta.gpb = tile_bin_gpb(P);
         ta.tiles_touched = g.tiles_touched; ta.rects = g.rects; ta.rec = g.rec;
@@ -650,14 +684,19 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     if (side) HIPCHK(hipStreamWaitEvent(st, side->join, 0));
     {
         ProfScope psr(K_RENDER_FWD, st);
-#define GSR_FWD_ARGS im.ranges, by_tile ? bl.vals : b.vals, by_tile ? (const unsigned long long*)bl.bins : (const unsigned long long*)b.keys, \
-                     by_tile ? im.tile_cursor : im.tile_offset, width, height, gx, ntiles, (const float*)g.rec, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
+        const bool local = by_tile || full_bins;
+#define GSR_FWD_ARGS im.ranges, local ? bl.vals : b.vals, local ? (const unsigned long long*)bl.bins : (const unsigned long long*)b.keys, \
+                     local ? im.tile_cursor : im.tile_offset, width, height, gx, ntiles, (const float*)g.rec, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
                      zb_next, zb_prev, cx.guard.poison ? const_cast<uint32_t*>(cx.guard.poison) : im.fail, \
                      sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], balanced ? im.tile_work[0] : (uint32_t*)nullptr, bin_cap, \
-                     LazySH{pa.lazy_sh ? shs : nullptr, means3D, cam_pos, D, M, g.clamped, g.rec}, (cx.guard.poison ? cx.guard.tag << 2 : 0u)
+                     LazySH{pa.lazy_sh ? shs : nullptr, means3D, cam_pos, D, M, g.clamped, g.rec}, (cx.guard.poison ? cx.guard.tag << 2 : 0u), \
+                     full_bins ? im.tile_count : (uint32_t*)nullptr
         if (by_tile) {
             if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
             else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+        } else if (full_bins) {
+            if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS_FULL>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+            else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS_FULL>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
         } else {
             if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_EXACT>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
             else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_EXACT>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
@@ -665,6 +704,19 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
 #undef GSR_FWD_ARGS
     }
     LAUNCHCHK("k_render_fwd");
+    if (full_bins && !cx.native_loop) {
+        // The stateless entry points: one blocking 4-byte read per forward, as rasterizer_impl.cu:282 -- there the instance count,
+        // here the flag word: did a tile's complete list overflow its bin?  Then the forward is redone on the exact path.
+        // (gsr_refine learns the same from the group's status word.)
+        uint32_t flag = 0;
+        HIPCHK(hipMemcpyAsync(&flag, im.fail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (flag & GSR_FAIL_OVERFLOW) {
+            PassCtx cx2 = cx;
+            cx2.exact_bins = true;
+            return forward_impl(cx2, GSR_FWD_PASS);
+        }
+    }
     return R;
 }
 
@@ -1073,6 +1125,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     // (drain, complete lists, back-off) when a bin overflowed or the retry failed as well.
     Img imv_loop{};                // the image workspace's carving (for the pose step launch)
     int last_enq = -1;            // last group whose forward was enqueued: its bounds are the newest
+    bool last_full = false;       // ... binned complete lists into fixed-capacity bins (k_preprocess_bin)
     bool last_counted = false;    // ... and it already counted n_touched
     auto enqueue = [&](int g, int logical, int mode) -> int {
         last_enq = g;
@@ -1101,13 +1154,14 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         // n_touched is wanted for the LAST forward only (see the end): a group that may be the last counts it itself
         const bool count_touched = maybe_last && a->n_touched != nullptr;
         last_counted = count_touched;
+        cx.used_full_bins = &last_full;
         int R = forward_impl(cx, cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
                              a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
                              a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
                              a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, count_touched ? a->n_touched : nullptr, a->stream);
         if (R < 0) return R;
         last_R = R;
-        last_local = (mode == 1);      // the bin-by-tile forward does not bring its instance count to the host
+        last_local = (mode == 1) || last_full;      // a forward that bins into per-tile bins does not bring its instance count to the host
         // (the tracking loss was evaluated in the compositing kernel's epilogue: cx.floss)
         int rc2 = backward_impl(cx, a->P, a->D, a->M, R, a->background, a->width, a->height, a->means3D, a->shs, nullptr, a->out_alpha,
                                 a->scales, a->scale_modifier, a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ,
@@ -1176,6 +1230,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             fprintf(stderr, "[gsr] group %d: speculation failed (%s)%s\n", g, overflow ? "bin overflow" : "unsaturated tile behind a finite bound",
                     (streak < 2 && !overflow && !conv_seen) ? ", retried on the device" : ", host steps in");
         if (adaptive_margin) { margin_m = fminf(0.05f, margin_m * 2.f); margin_streak = 0; }
+        if (overflow) cx.exact_bins = true;             // (complete lists go through count -> scan -> emit for the rest of this call)
         if (!conv_seen && !overflow && streak < 2) continue;
         // ---- the host steps in: drain what is in flight (a retry that may well have succeeded), then complete lists if need be
         HIPCHK(hipStreamSynchronize(st));
@@ -1185,7 +1240,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             uint32_t w2 = 0;
             { const int wrc = wait_status(g2, w2); if (wrc < 0) return wrc; }
             settled_n++;
-            if (w2 & 6u) { n_fallbacks++; resolved = false; }
+            if (w2 & 6u) { n_fallbacks++; resolved = false; if (w2 & 4u) cx.exact_bins = true; }
             else { after_success(g2, w2); resolved = true; }
         }
         if (!resolved) {
@@ -1217,7 +1272,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                            reinterpret_cast<uint32_t*>(bb.ptr), (const unsigned long long*)nullptr, (uint32_t*)nullptr, a->width,
                            a->height, gx, gx * gy, (const float*)g.rec, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
                            a->n_touched, (float*)nullptr, (const float*)nullptr, im.fail, 1.f, 0.f, (float*)nullptr,
-                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{}, 0u);
+                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{}, 0u, (uint32_t*)nullptr);
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
     if (a->pose_state_host) HIPCHK(hipMemcpyAsync(h_status + 16, ps, GSR_POSE_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToHost, st));
@@ -1232,11 +1287,18 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         if (want_count && last_local && ib.ptr) {      // instances binned by the last forward = sum of the tile list lengths
             Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
             const int nt = ((a->width + GSR_TILE - 1) / GSR_TILE) * ((a->height + GSR_TILE - 1) / GSR_TILE);
-            std::vector<uint2> rg((size_t)nt);
-            HIPCHK(hipMemcpyAsync(rg.data(), imv.ranges, rg.size() * sizeof(uint2), hipMemcpyDeviceToHost, st));
-            HIPCHK(hipStreamSynchronize(st));
             long long sum = 0;
-            for (int i = 0; i < nt; i++) sum += (long long)(rg[i].y - rg[i].x);
+            if (last_full) {          // (complete lists are ordered lazily: the ranges only cover what was ordered; the full counts sit in tile_count)
+                std::vector<uint32_t> tc((size_t)nt);
+                HIPCHK(hipMemcpyAsync(tc.data(), imv.tile_count, tc.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                for (int i = 0; i < nt; i++) sum += (long long)tc[i];
+            } else {
+                std::vector<uint2> rg((size_t)nt);
+                HIPCHK(hipMemcpyAsync(rg.data(), imv.ranges, rg.size() * sizeof(uint2), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                for (int i = 0; i < nt; i++) sum += (long long)(rg[i].y - rg[i].x);
+            }
             last_R = (int)sum;
         }
         a->stats_out[0] = n_fallbacks; a->stats_out[1] = last_R; a->stats_out[2] = n_lean; a->stats_out[3] = 0;

@@ -346,26 +346,28 @@ __device__ __forceinline__ float3 sh_row16_to_rgb(int deg, float3 pos, const flo
 #define GSR_ORDER_MAX_TILES 65536
 __device__ __forceinline__ void tile_order_from_work(const uint32_t* __restrict__ work, uint32_t* __restrict__ order, int ntiles, uint32_t* s_cls /*[256]*/)
 {
+    // (the first GSR_BLOCK threads of the workgroup do the work; a wider workgroup's other threads only keep the barriers company)
     __shared__ uint32_t s_wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    s_cls[tid] = 0u;
+    const bool act = tid < GSR_BLOCK;
+    if (act) s_cls[tid] = 0u;
     __syncthreads();
-    for (int t = tid; t < ntiles; t += GSR_BLOCK) atomicAdd(&s_cls[255u - min(work[t], 255u)], 1u);      // class 0 = heaviest
+    for (int t = tid; act && t < ntiles; t += GSR_BLOCK) atomicAdd(&s_cls[255u - min(work[t], 255u)], 1u);      // class 0 = heaviest
     __syncthreads();
-    const uint32_t mine = s_cls[tid];
+    const uint32_t mine = act ? s_cls[tid] : 0u;
     uint32_t incl = mine;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
         const uint32_t o = __shfl_up(incl, off, 64);
         if (lane >= off) incl += o;
     }
-    if (lane == 63) s_wsum[wv] = incl;
+    if (act && lane == 63) s_wsum[wv] = incl;
     __syncthreads();
     uint32_t start = incl - mine;
-    for (int w = 0; w < wv; w++) start += s_wsum[w];
-    s_cls[tid] = start;                                                 // first rank of class tid
+    for (int w = 0; act && w < wv; w++) start += s_wsum[w];
+    if (act) s_cls[tid] = start;                                        // first rank of class tid
     __syncthreads();
-    for (int t = tid; t < ntiles; t += GSR_BLOCK) {
+    for (int t = tid; act && t < ntiles; t += GSR_BLOCK) {
         const int r = (int)atomicAdd(&s_cls[255u - min(work[t], 255u)], 1u);          // rank, heaviest first
         // rank r goes to block (r / 256) * 256 + snake(r % 256)
         const int row = r >> 8, i = r & 255;
@@ -374,6 +376,28 @@ __device__ __forceinline__ void tile_order_from_work(const uint32_t* __restrict_
     }
 }
 
+// What the walk keeps per Gaussian between its passes over the image (registers): the span test without the terms only
+// needed once, the clipped rectangle, the key.
+struct WalkItem {
+    float mx, my, at, B, det, dye, invA;           // at = A * twoq
+    int x0, y0, x1, y1;                            // clipped tile rectangle; x1 == x0: nothing to do
+    unsigned long long key;
+    bool all;                                      // conic not positive definite: every tile of the rectangle
+};
+__device__ __forceinline__ void item_span(const WalkItem& t, int ty, int& lo, int& hi)      // row_span on the cached terms
+{
+    if (t.all) { lo = t.x0; hi = t.x1 - 1; return; }
+    lo = 1; hi = 0;
+    const float dyh = t.my - (float)(ty * GSR_TILE), dyl = dyh - (float)(GSR_TILE - 1);
+    const float dy1 = fminf(dyh, fmaxf(dyl, t.dye)), dy2 = fminf(dyh, fmaxf(dyl, -t.dye));
+    const float disc1 = t.at - t.det * dy1 * dy1, disc2 = t.at - t.det * dy2 * dy2;
+    if (fminf(disc1, disc2) < -1e-3f * t.at) return;
+    const float dmax = (__builtin_amdgcn_sqrtf(fmaxf(disc1, 0.f)) - t.B * dy1) * t.invA;
+    const float dmin = (-__builtin_amdgcn_sqrtf(fmaxf(disc2, 0.f)) - t.B * dy2) * t.invA;
+    const float pa = t.mx - dmax - 0.01f, pb = t.mx - dmin + 0.01f;
+    lo = max(t.x0, (int)ceilf((pa - (float)(GSR_TILE - 1)) * (1.f / GSR_TILE)));
+    hi = min(t.x1 - 1, (int)floorf(pb * (1.f / GSR_TILE)));
+}
 // Upper bound on sqrt(lambda_max(Sigma)) of a symmetric positive semi-definite 3x3 matrix given by its six unique entries -- the
 // "largest scale" of a Gaussian whatever produced its covariance (a quaternion that is not normalised is used as given,
 // forward.cu:127: its R is not orthogonal and max(scale) says nothing about Sigma).  lambda_max <= min(Frobenius norm,
@@ -436,11 +460,13 @@ __device__ __forceinline__ bool lean_candidate(const PreArgs& a, float3 p, float
 // search in the wave's prefix array), fetches that Gaussian's terms from the owning lane (ds_bpermute) and tests / appends
 // ONE tile, so that a round is one set of independent bound loads and returning atomics instead of a chain of them per
 // Gaussian.  s_flat: 128 words of LDS per wave (prefix array, per-owner counts).
+// wout (nullable; complete lists binned by the same kernel, k_preprocess_bin): receives what the row walk needs -- span terms, the
+// clipped rectangle, the key -- straight from this lane's registers (x1 == x0: nothing to walk).
 template <bool FLAT>
 __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, const bool live, const float* s_zbc, const int tid, const uint32_t sublist,
-                                               uint32_t* s_flat = nullptr)
+                                               uint32_t* s_flat = nullptr, WalkItem* wout = nullptr)
 {
-    bool vis = false, coop = false, own = false;
+    bool vis = false, coop = false, own = false, store_cov = false;
     float3 p = make_float3(0.f, 0.f, 0.f);
     TileTest tt = {};
     int rx0 = 0, ry0 = 0, rx1 = 0, ry1 = 0;
@@ -479,8 +505,7 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
                 const float4 q = reinterpret_cast<const float4*>(a.rots)[idx];
                 float q4[4] = {q.x, q.y, q.z, q.w};
                 cov3d_from_scale_rot(s3, a.mod, q4, cov6);
-#pragma unroll
-                for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov6[i];
+                store_cov = true;          // (kept for the backward pass -- of the Gaussians that turn out to be visible only)
             }
             Cov2DTerms ct;
             cov2d_terms(p, a.fx, a.fy, a.tanx, a.tany, cov6, a.view, ct);
@@ -500,6 +525,10 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
                     vis = true;
                     const float opacity = a.opac[idx];
                     a.radii[idx] = (int)my_radius;
+                    if (store_cov) {
+#pragma unroll
+                        for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov6[i];
+                    }
                     {
                         float4* rec = reinterpret_cast<float4*>(a.rec + (size_t)idx * GSR_REC_STRIDE);
                         rec[0] = make_float4(pix.x, pix.y, (-GSR_LOG2E) * conic.y, (-0.5f * GSR_LOG2E) * conic.z);
@@ -525,9 +554,16 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
                         }
                         far_everywhere = pview.z > zc * a.zb_mul + a.zb_add;
                     }
-                    if (a.bins == nullptr) {
-                        // exact-bin path: k_tile_count / k_tile_emit walk the tiles; here only "can this splat reach any pixel"
+                    if (a.bins == nullptr || wout != nullptr) {
+                        // complete lists: k_tile_count / k_tile_emit (or the second half of k_preprocess_bin) walk the tiles; here
+                        // only "can this splat reach any pixel"
                         cnt = tt.none ? 0u : 1u;
+                        if (wout != nullptr && cnt != 0u) {
+                            wout->x0 = rx0; wout->y0 = ry0; wout->x1 = rx1; wout->y1 = ry1;
+                            wout->mx = tt.mx; wout->my = tt.my; wout->at = tt.A * tt.twoq; wout->B = tt.B; wout->det = tt.det; wout->dye = tt.dye;
+                            wout->invA = tt.invA; wout->all = !tt.cull;
+                            wout->key = ((unsigned long long)__float_as_uint(pview.z) << 32) | (uint32_t)idx;
+                        }
                     } else if (!far_everywhere) {
                         if ((rx1 - rx0) * (ry1 - ry0) > GSR_COOP_AREA) coop = true;      // whole wave helps below
                         else own = true;
@@ -959,28 +995,6 @@ struct TileBinArgs {
     unsigned long long* keys;                      // [R] (emit)
 };
 
-// What the walk keeps per Gaussian between its passes over the image (registers): the span test without the terms only
-// needed once, the clipped rectangle, the key.
-struct WalkItem {
-    float mx, my, at, B, det, dye, invA;           // at = A * twoq
-    int x0, y0, x1, y1;                            // clipped tile rectangle; x1 == x0: nothing to do
-    unsigned long long key;
-    bool all;                                      // conic not positive definite: every tile of the rectangle
-};
-__device__ __forceinline__ void item_span(const WalkItem& t, int ty, int& lo, int& hi)      // row_span on the cached terms
-{
-    if (t.all) { lo = t.x0; hi = t.x1 - 1; return; }
-    lo = 1; hi = 0;
-    const float dyh = t.my - (float)(ty * GSR_TILE), dyl = dyh - (float)(GSR_TILE - 1);
-    const float dy1 = fminf(dyh, fmaxf(dyl, t.dye)), dy2 = fminf(dyh, fmaxf(dyl, -t.dye));
-    const float disc1 = t.at - t.det * dy1 * dy1, disc2 = t.at - t.det * dy2 * dy2;
-    if (fminf(disc1, disc2) < -1e-3f * t.at) return;
-    const float dmax = (__builtin_amdgcn_sqrtf(fmaxf(disc1, 0.f)) - t.B * dy1) * t.invA;
-    const float dmin = (-__builtin_amdgcn_sqrtf(fmaxf(disc2, 0.f)) - t.B * dy2) * t.invA;
-    const float pa = t.mx - dmax - 0.01f, pb = t.mx - dmin + 0.01f;
-    lo = max(t.x0, (int)ceilf((pa - (float)(GSR_TILE - 1)) * (1.f / GSR_TILE)));
-    hi = min(t.x1 - 1, (int)floorf(pb * (1.f / GSR_TILE)));
-}
 // (g0: offset of the KPT x 1024 window inside the workgroup's gpb Gaussians)
 template <int KPT>
 __device__ __forceinline__ void walk_load(const TileBinArgs& a, int g0, WalkItem (&it)[KPT])
@@ -1197,6 +1211,69 @@ __global__ void __launch_bounds__(GSR_TBIN_THREADS) k_tile_emit(TileBinArgs a, i
 }
 
 // ---------------------------------------------------------------------------------------------
+// Complete lists in ONE kernel (round 3): preprocess + count + reserve + emit.  k_preprocess -> k_tile_count -> k_tile_scan ->
+// [host reads the total] -> k_tile_emit moved every visible Gaussian's record through HBM twice more (both walks re-read it and
+// re-derived the span terms: 299 MB per forward on S-1M-640 for 148 MB of algorithmic traffic), needed a single-workgroup scan in
+// the middle and a blocking read to size the key array.  Here a workgroup of 1024 lanes computes the geometry of its KPT x 1024
+// Gaussians (preprocess_one, the same code), keeps each one's walk terms in REGISTERS, and walks the rows twice from there:
+//   count    one LDS add per (Gaussian, tile) instance;
+//   reserve  one returning atomic per (workgroup, tile) on the tile's cursor: the workgroup's run inside the tile's bin;
+//   emit     (depth bits << 32 | index) keys into the run, banded over the tile rows like k_tile_emit.
+// The bins are the bin-by-tile path's: tile-major, fixed capacity (`bin_cap`, sized by the host from P / tiles with generous
+// head-room), cursors cleared by the compositing kernel that consumes them -- no prefix sum over the tiles, no instance count
+// on the host.  A tile that overflows its bin makes the compositing kernel report GSR_FAIL_OVERFLOW and the host falls back
+// to the exact count -> scan -> emit path.  k_render_fwd<.., GSR_LIST_BINS_FULL> orders such a bin lazily, like a segment.
+// ---------------------------------------------------------------------------------------------
+#define GSR_PBIN_THREADS 512
+#define GSR_PBIN_KPT 4             // 2 048 Gaussians per workgroup: enough for the LDS counters to aggregate, two workgroups per CU
+__global__ void __launch_bounds__(GSR_PBIN_THREADS) k_preprocess_bin(PreArgs a, int bands)
+{
+    extern __shared__ uint32_t s_tb[];        // [0, ntiles) running count, [ntiles, 2 ntiles) where this workgroup's keys of the tile start
+    __shared__ uint32_t s_pref[GSR_PBIN_THREADS];
+    constexpr int KPT = GSR_PBIN_KPT, gpb = GSR_PBIN_KPT * GSR_PBIN_THREADS;
+    uint32_t* s_cnt = s_tb;
+    uint32_t* s_base = s_tb + a.ntiles;
+    const int tid = threadIdx.x;
+    if (a.tile_order[0] != nullptr && blockIdx.x < 2) {      // native loop: this iteration's launch orders of the compositing kernels
+        __shared__ uint32_t s_cls[GSR_BLOCK];
+        tile_order_from_work(a.tile_work[blockIdx.x], a.tile_order[blockIdx.x], a.order_tiles, s_cls);
+    }
+    if (a.guard.poisoned()) return;
+    for (int t = tid; t < a.ntiles; t += GSR_PBIN_THREADS) s_cnt[t] = 0u;
+    if (blockIdx.x == 0 && tid == 0) {      // the null splat
+        float4* nr = reinterpret_cast<float4*>(a.rec + (size_t)a.P * GSR_REC_STRIDE);
+        nr[0] = make_float4(0.f, 0.f, 0.f, 0.f); nr[1] = nr[0]; nr[2] = nr[0];
+    }
+    WalkItem it[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; k++) {
+        const int idx = blockIdx.x * gpb + k * GSR_PBIN_THREADS + tid;
+        it[k] = WalkItem{};
+        // (work lists: every 1024-Gaussian stretch counts as one block of surv_cap()'s accounting)
+        const uint32_t vblock = (uint32_t)idx >> 10;
+        preprocess_one<false>(a, idx, idx < a.P, nullptr, tid, vblock & (GSR_SURV_LISTS - 1), nullptr, &it[k]);
+    }
+    TileBinArgs ta = {};
+    ta.gx = a.gx; ta.gy = a.gy;
+    __syncthreads();
+    walk_rows<KPT>(ta, it, 0, a.gy, s_pref, [&](int tile, unsigned long long) { atomicAdd(&s_cnt[tile], 1u); });
+    __syncthreads();
+    for (int t = tid; t < a.ntiles; t += GSR_PBIN_THREADS) {
+        const uint32_t c = s_cnt[t];
+        s_base[t] = (c != 0u) ? atomicAdd(&a.tile_cursor[t * GSR_CURSOR_STRIDE], c) : 0u;
+        s_cnt[t] = 0u;
+    }
+    const int bh = (a.gy + bands - 1) / bands;
+    for (int b0 = 0; b0 < a.gy; b0 += bh) {
+        __syncthreads();
+        walk_rows<KPT>(ta, it, b0, min(a.gy, b0 + bh), s_pref, [&](int tile, unsigned long long key) {
+            const uint32_t pos = s_base[tile] + atomicAdd(&s_cnt[tile], 1u);
+            if (pos < (uint32_t)a.bin_cap) a.bins[(size_t)tile * a.bin_cap + pos] = key;
+        });
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K6  per-tile front-to-back compositing (replaces forward.cu:261-379 renderCUDA).
 // One workgroup (4 waves) per 16x16 tile, one lane per pixel.  Batches of 256 splats are gathered
 // once into LDS (44 B each: xy, conic, opacity, rgb, depth, id) and broadcast-read by every lane.
@@ -1294,6 +1371,8 @@ struct SplatLDS {
 #define GSR_LIST_SORTED 0
 #define GSR_LIST_BINS 1
 #define GSR_LIST_EXACT 2
+#define GSR_LIST_BINS_FULL 3       // a bin like GSR_LIST_BINS holding the tile's COMPLETE list (k_preprocess_bin): treated like a segment
+                                   // of the exact bins -- lazy slices above GSR_SLICE_ALL keys, lazy SH colours
 #define GSR_SLICE_FIRST 512        // GSR_LIST_EXACT: the first slice aims at this many keys (most tiles saturate within it),
 #define GSR_SLICE_ALL 1024         // unless the whole segment is no longer than this; later slices take up to GSR_LSORT_CAP
 #define GSR_SEL_BITS 11            // radix of the selection histogram (2048 counters, aliased onto the key buffer)
@@ -1431,8 +1510,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                                                           const float* __restrict__ zb_used, uint32_t* __restrict__ fail,
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
                                                           int sbx, FusedLoss fl, const uint32_t* __restrict__ tile_order,
-                                                          uint32_t* __restrict__ tile_work, int bin_cap, LazySH lz, uint32_t fail_tag)
+                                                          uint32_t* __restrict__ tile_work, int bin_cap, LazySH lz, uint32_t fail_tag,
+                                                          uint32_t* __restrict__ tile_total)
 {
+    // (tile_total, nullable: GSR_LIST_BINS_FULL leaves every tile's complete instance count there -- statistics only)
     // (fail: the word a failed verification is reported in -- the loop's poison word with fail_tag = this group's tag << 2, see
     // LoopGuard; the drop-in speculation's flag word with fail_tag = 0)
     // (tile_cursor: GSR_LIST_BINS the per-tile append cursors; GSR_LIST_EXACT the tile_offset array of k_tile_scan)
@@ -1449,7 +1530,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     const int pix_id = W * py + px;
     const float pxf = (float)px, pyf = (float)py;
     uint2 range;
-    if (LIST == GSR_LIST_BINS) {
+    constexpr bool kBins = (LIST == GSR_LIST_BINS || LIST == GSR_LIST_BINS_FULL);
+    constexpr bool kFull = (LIST == GSR_LIST_EXACT || LIST == GSR_LIST_BINS_FULL);      // complete lists: lazy ordering, lazy SH colours
+    if (kBins) {
         // one lane reads the tile's cursor and clears it for the next iteration's appends (no memset); everybody else
         // gets the count through LDS
         __shared__ uint32_t s_cursor;
@@ -1462,17 +1545,18 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         range.y = tile_cursor[tile + 1];
     } else range = ranges[tile];
     const int total = (int)(range.y - range.x);
+    if (LIST == GSR_LIST_BINS_FULL && tile_total != nullptr && tid == 0) tile_total[tile] = (uint32_t)total;
     int walked = 0, overhead = 0;      // -> tile_work: groups of eight this wave composited; staging / ordering cost in the same unit
 
     // A bin longer than the in-LDS sort takes (a tile that does not saturate -- the edge of the scene's coverage, a
     // semi-transparent region -- has no depth bound and gets its complete list) is ordered lazily, slice by slice, like a
     // segment of the exact bins; only a bin that overflowed its capacity fails the forward.
-    const bool lazy = (LIST == GSR_LIST_EXACT) || (LIST == GSR_LIST_BINS && total > GSR_LSORT_CAP);
-    if (LIST == GSR_LIST_BINS && total > bin_cap) {          // block-uniform: entries were dropped; the host redoes the forward with complete lists
+    const bool lazy = (LIST == GSR_LIST_EXACT) || (LIST == GSR_LIST_BINS && total > GSR_LSORT_CAP) || (LIST == GSR_LIST_BINS_FULL && total > GSR_SLICE_ALL);
+    if (kBins && total > bin_cap) {          // block-uniform: entries were dropped; the host redoes the forward with complete lists
         if (tid == 0) atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);
         return;
     }
-    if (LIST == GSR_LIST_BINS && !lazy) {
+    if (kBins && !lazy) {
         // this tile's bin arrives unsorted: order it by (depth bits, index) in LDS, keep it there
         // for the staging below and write the sorted indices (and the tile's range) back for the backward pass
         if (tid == 0) ranges[tile] = range;
@@ -1549,7 +1633,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             const float4* r = reinterpret_cast<const float4*>(rec + (size_t)id * GSR_REC_STRIDE);
             const float4 r0 = r[0], r1 = r[1];
             float4 r2;
-            if (LIST == GSR_LIST_EXACT && lz.shs != nullptr) {
+            if (kFull && lz.shs != nullptr) {
                 // (LazySH: another workgroup of this launch may be publishing this quad right now.  It is read and written as ONE
                 // 16-byte access -- a volatile vector access, which the compiler neither splits nor reorders nor repeats; on gfx950 an
                 // aligned global_load / store_dwordx4 is a single transaction on one cache line, so a reader sees either the
@@ -1558,7 +1642,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                 const gsr_f32x4 q = *reinterpret_cast<const volatile gsr_f32x4*>(r + 2);
                 r2 = make_float4(q[0], q[1], q[2], q[3]);
             } else r2 = r[2];
-            if (LIST == GSR_LIST_EXACT && lz.shs != nullptr && r2.w == 0.f) {      // first tile to stage this splat: its colour (LazySH)
+            if (kFull && lz.shs != nullptr && r2.w == 0.f) {      // first tile to stage this splat: its colour (LazySH)
                 uint8_t cb;
                 const float3 pm = make_float3(lz.means[3 * (size_t)id], lz.means[3 * (size_t)id + 1], lz.means[3 * (size_t)id + 2]);
                 const float3 c = sh16_vector_ok(lz.M, lz.shs)
