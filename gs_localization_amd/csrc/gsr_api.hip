@@ -106,7 +106,7 @@ struct Geom {   // per-Gaussian state carried from forward to backward
     uint32_t* tiles_touched; ushort4* rects; float* acc; double* tau_acc; uint8_t* dirty;
     gsr::SurvLists surv;      // work lists of the forward's survivors (k_preprocess -> k_sh_color, k_preprocess_bwd)
     float* rec;               // packed splat records (GSR_REC_*), P + 1
-    float* lam;               // per-Gaussian bound on sqrt(lambda_max(Sigma)) (PreArgs::lam), valid whenever cov3D holds every covariance
+    float* lam;               // per-Gaussian float4 (mean, bound on sqrt(lambda_max(Sigma))) (PreArgs::lam), valid whenever cov3D holds every covariance
 };
 size_t carve_geom(char* base, int P, Geom& g)
 {
@@ -123,7 +123,7 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.surv.cap = gsr::surv_cap(P);
     g.surv.n = c.take<uint32_t>((size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE);
     g.surv.ids = c.take<uint32_t>((size_t)GSR_SURV_LISTS * g.surv.cap);
-    g.lam = c.take<float>(n);
+    g.lam = c.take<float>(4 * n);
     return c.size();
 }
 
@@ -581,6 +581,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         HIPCHK(hipMemsetAsync(zbc_next, 0, (size_t)im.nsb * sizeof(float), st));
     } else if (full_bins && !cx.native_loop)      // (the stateless entry points get a fresh image buffer per call: flag + cursors)
         HIPCHK(hipMemsetAsync(im.fail, 0, im.clear_words * sizeof(uint32_t), st));
+    if (full_bins && !cx.native_loop) HIPCHK(hipMemsetAsync(im.tile_count + ntiles, 0, sizeof(uint32_t), st));      // (the compositing kernel adds up num_rendered there)
     {
         ProfScope ps(K_PREPROCESS, st);
         pa.zbc_lds = (pa.zbc != nullptr && im.nsb <= 4096) ? im.nsb : 0;
@@ -708,9 +709,11 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         // The stateless entry points: one blocking 4-byte read per forward, as rasterizer_impl.cu:282 -- there the instance count,
         // here the flag word: did a tile's complete list overflow its bin?  Then the forward is redone on the exact path.
         // (gsr_refine learns the same from the group's status word.)
-        uint32_t flag = 0;
+        uint32_t flag = 0, total = 0;
         HIPCHK(hipMemcpyAsync(&flag, im.fail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(&total, im.tile_count + ntiles, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        R = (int)std::min<uint32_t>(total, 0x7fffffffu);          // num_rendered (after exact tile culling), as the reference returns it
         if (flag & GSR_FAIL_OVERFLOW) {
             PassCtx cx2 = cx;
             cx2.exact_bins = true;

@@ -235,8 +235,9 @@ struct PreArgs {
     const float* view; const float* proj; const float* campos;
     float tanx, tany, fx, fy;
     int* radii; float* cov3D;
-    float* lam;              // [P] upper bound on sqrt(lambda_max(Sigma_3D)) of every Gaussian (scale_modifier included): written next to
-                             // cov3D by a cov_all forward, read by k_preprocess_lean's conservative test (nullable elsewhere)
+    float* lam;              // [P] float4 (x, y, z, e): the mean and e = an upper bound on sqrt(lambda_max(Sigma_3D)) of every Gaussian
+                             // (scale_modifier included), written next to cov3D by a cov_all forward: ALL that k_preprocess_lean's
+                             // conservative test reads per Gaussian, as one 16-byte load (nullable elsewhere)
     float* rec;              // packed splat records (GSR_REC_*), P + 1 of them
     uint8_t* clamped; uint32_t* tiles_touched; ushort4* rects;
     int cov_all;             // k_preprocess: compute and store cov3D for every Gaussian, culled or not (see there)
@@ -473,6 +474,18 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
     float zv = 0.f;
     uint32_t cnt = 0;
 
+    // FLAT (the compacted candidates of k_preprocess_lean: every live lane is in front of the camera and will need all of it):
+    // everything the lane reads about its Gaussian is requested up front -- one round trip instead of a chain of four (mean ->
+    // covariance -> opacity -> SH row; the wave's lifetime is these dependent round trips, not arithmetic).  The SH row is only
+    // touched (its two cache lines), not held in registers.
+    float cov_h[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, opac_h = 0.f, sh_touch0 = 0.f, sh_touch1 = 0.f;
+    const bool hoist = FLAT && live && a.cov3D_pre != nullptr && !a.cov_all;
+    if (hoist) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) cov_h[i] = a.cov3D_pre[6 * (size_t)idx + i];
+        opac_h = a.opac[idx];
+        if (a.sh_here && a.shs != nullptr && a.M >= 16) { sh_touch0 = a.shs[(size_t)idx * a.M * 3]; sh_touch1 = a.shs[(size_t)idx * a.M * 3 + 32]; }
+    }
     if (live) {
         a.radii[idx] = 0;
         a.tiles_touched[idx] = 0;
@@ -493,10 +506,13 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
             cov3d_from_scale_rot(s3, a.mod, q4, cov6);
 #pragma unroll
             for (int i = 0; i < 6; i++) a.cov3D[6 * (size_t)idx + i] = cov6[i];
-            if (a.lam != nullptr) a.lam[idx] = sigma_extent_bound(cov6);
+            if (a.lam != nullptr) reinterpret_cast<float4*>(a.lam)[idx] = make_float4(p.x, p.y, p.z, sigma_extent_bound(cov6));
         }
         if (pview.z > 0.2f) {     // near cull (auxiliary.h:150)
             if (a.cov_all) {
+            } else if (hoist) {
+#pragma unroll
+                for (int i = 0; i < 6; i++) cov6[i] = cov_h[i];
             } else if (a.cov3D_pre != nullptr) {
 #pragma unroll
                 for (int i = 0; i < 6; i++) cov6[i] = a.cov3D_pre[6 * (size_t)idx + i];
@@ -523,7 +539,7 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
                 get_rect(pix.x, pix.y, (int)my_radius, a.gx, a.gy, x0, y0, x1, y1);
                 if ((x1 - x0) * (y1 - y0) != 0) {
                     vis = true;
-                    const float opacity = a.opac[idx];
+                    const float opacity = hoist ? opac_h : a.opac[idx];
                     a.radii[idx] = (int)my_radius;
                     if (store_cov) {
 #pragma unroll
@@ -732,6 +748,7 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
     }
     // k_preprocess_lean (a.sh_here): the wave's lanes are dense with survivors, so their colour is evaluated right here -- one
     // kernel (and one chain of dependent memory phases) less per iteration than with k_sh_color behind this one.
+    if (FLAT && a.sh_here) asm volatile("" : : "v"(sh_touch0), "v"(sh_touch1));      // (keeps the two touches above alive up to here)
     if (FLAT && a.sh_here && surv) {
         uint8_t cb;
         const float3 c = sh16_vector_ok(a.M, a.shs)
@@ -811,8 +828,9 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_lean(PreArgs a)
 #pragma unroll
     for (int k = 0; k < GSR_LEAN_PER_LANE; k++) {
         const int idx = min(base + k * 64 + lane, a.P - 1);
-        pk[k] = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
-        sk[k] = a.lam[idx];
+        const float4 ml = reinterpret_cast<const float4*>(a.lam)[idx];      // (mean, extent bound): one coalesced 16-byte load
+        pk[k] = make_float3(ml.x, ml.y, ml.z);
+        sk[k] = ml.w;
         dk[k] = (a.dirty != nullptr) ? a.dirty[idx] : (uint8_t)0;
     }
     const float wn2 = view_norm2_bound(a.view);
@@ -862,7 +880,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_lean_check(PreArgs a, unsigned lo
     bool cand = false;
     uint32_t cnt = 0;
     if (pview.z > 0.2f) {
-        cand = lean_candidate(a, p, pview, a.lam[idx], view_norm2_bound(a.view), a.zbc);
+        cand = lean_candidate(a, p, pview, a.lam[4 * (size_t)idx + 3], view_norm2_bound(a.view), a.zbc);
         const float4 ph = xform4x4(p, a.proj);
         const float pw = 1.0f / (ph.w + 0.0000001f);
         const float3 pproj = make_float3(ph.x * pw, ph.y * pw, ph.z * pw);
@@ -1513,7 +1531,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                                                           uint32_t* __restrict__ tile_work, int bin_cap, LazySH lz, uint32_t fail_tag,
                                                           uint32_t* __restrict__ tile_total)
 {
-    // (tile_total, nullable: GSR_LIST_BINS_FULL leaves every tile's complete instance count there -- statistics only)
+    // (tile_total, nullable, ntiles + 1 words: GSR_LIST_BINS_FULL leaves every tile's complete instance count there and adds it to
+    // the last word -- the forward's num_rendered)
     // (fail: the word a failed verification is reported in -- the loop's poison word with fail_tag = this group's tag << 2, see
     // LoopGuard; the drop-in speculation's flag word with fail_tag = 0)
     // (tile_cursor: GSR_LIST_BINS the per-tile append cursors; GSR_LIST_EXACT the tile_offset array of k_tile_scan)
@@ -1545,7 +1564,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         range.y = tile_cursor[tile + 1];
     } else range = ranges[tile];
     const int total = (int)(range.y - range.x);
-    if (LIST == GSR_LIST_BINS_FULL && tile_total != nullptr && tid == 0) tile_total[tile] = (uint32_t)total;
+    if (LIST == GSR_LIST_BINS_FULL && tile_total != nullptr && tid == 0) {
+        tile_total[tile] = (uint32_t)total;
+        atomicAdd(&tile_total[ntiles], (uint32_t)total);      // (word ntiles: the forward's num_rendered, zeroed by the host)
+    }
     int walked = 0, overhead = 0;      // -> tile_work: groups of eight this wave composited; staging / ordering cost in the same unit
 
     // A bin longer than the in-LDS sort takes (a tile that does not saturate -- the edge of the scene's coverage, a
