@@ -131,6 +131,7 @@ size_t carve_geom(char* base, int P, Geom& g)
 // back to per-instance atomics in HBM.  At most kTileBinMaxGroups workgroups share the Gaussians (tile_bin_gpb).
 constexpr int kTileBinLdsTiles = 16 * 1024;
 constexpr int kTileBinMaxGroups = 2048;
+constexpr int kFullBinMaxTiles = 2048;      // k_preprocess_bin (complete lists in one kernel) up to this many tiles
 
 struct Img {
     uint32_t* n_contrib; uint2* ranges;
@@ -205,8 +206,8 @@ int full_bin_capacity(int P, int ntiles)
 size_t carve_bin_local(char* base, int ntiles, int cap, BinLocal& b)
 {
     Carver c(base);
-    b.vals = c.take<uint32_t>((size_t)ntiles * cap);
-    b.bins = c.take<unsigned long long>((size_t)ntiles * cap);
+    b.vals = c.take<uint32_t>((size_t)ntiles * (cap + GSR_BIN_PAD));
+    b.bins = c.take<unsigned long long>((size_t)ntiles * (cap + GSR_BIN_PAD));
     return c.size();
 }
 
@@ -250,7 +251,7 @@ size_t carve_spec(char* base, int W, int H, Img& im, unsigned long long** bins)
     im.clear_words = 16 + (size_t)gx * gy * GSR_CURSOR_STRIDE;
     im.fail = c.take<uint32_t>(im.clear_words);
     im.tile_cursor = base ? im.fail + 16 : nullptr;
-    unsigned long long* b = c.take<unsigned long long>((size_t)gx * gy * GSR_LSORT_CAP);
+    unsigned long long* b = c.take<unsigned long long>((size_t)gx * gy * (GSR_LSORT_CAP + GSR_BIN_PAD));
     if (bins) *bins = b;
     return c.size();
 }
@@ -552,7 +553,9 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     BinLocal bl{nullptr, nullptr};
     // Complete lists (no depth bounds to speculate with): binned by the preprocess kernel itself into fixed-capacity bins
     // (k_preprocess_bin) while their counters fit the LDS; otherwise, and after a bin overflowed, count -> scan -> emit.
-    const bool full_bins = !by_tile && !cx.exact_bins && ntiles <= kTileBinLdsTiles;
+    // (measured: 85 us against 30 + 20 + 8 + 43 us and a blocking read at 1 200 tiles / 1 M Gaussians, but 300 against 253 us at the
+    // training configuration's 4 293 tiles / 1.5 M: large images keep the three-kernel path)
+    const bool full_bins = !by_tile && !cx.exact_bins && ntiles <= kFullBinMaxTiles;
     if (cx.used_full_bins) *cx.used_full_bins = full_bins;
     const int bin_cap = full_bins ? full_bin_capacity(P, ntiles)
                                   : ((sp.state != nullptr) ? GSR_LSORT_CAP : bin_capacity(ntiles));      // (a caller's state buffer holds 2048-entry bins)
@@ -564,7 +567,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     }
     if (by_tile) {
         // (with a state buffer the unsorted bins live there and the per-call buffer only holds the sorted lists)
-        const size_t lbytes = state_bins ? (size_t)ntiles * GSR_LSORT_CAP * sizeof(uint32_t) : carve_bin_local(nullptr, ntiles, bin_cap, bl);
+        const size_t lbytes = state_bins ? (size_t)ntiles * (GSR_LSORT_CAP + GSR_BIN_PAD) * sizeof(uint32_t) : carve_bin_local(nullptr, ntiles, bin_cap, bl);
         char* lptr = (char*)binning_buffer(binning_ctx, lbytes);
         if (!lptr) return fail(GSR_E_ALLOC, "binning buffer callback returned NULL%s", "");
         if (state_bins) { bl.vals = reinterpret_cast<uint32_t*>(lptr); bl.bins = state_bins; }
@@ -581,7 +584,6 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         HIPCHK(hipMemsetAsync(zbc_next, 0, (size_t)im.nsb * sizeof(float), st));
     } else if (full_bins && !cx.native_loop)      // (the stateless entry points get a fresh image buffer per call: flag + cursors)
         HIPCHK(hipMemsetAsync(im.fail, 0, im.clear_words * sizeof(uint32_t), st));
-    if (full_bins && !cx.native_loop) HIPCHK(hipMemsetAsync(im.tile_count + ntiles, 0, sizeof(uint32_t), st));      // (the compositing kernel adds up num_rendered there)
     {
         ProfScope ps(K_PREPROCESS, st);
         pa.zbc_lds = (pa.zbc != nullptr && im.nsb <= 4096) ? im.nsb : 0;
@@ -601,8 +603,11 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
             if (rc != GSR_OK) return rc;
             pa.lean = 0; pa.sh_here = 0;
             pa.ntiles = ntiles;
-            int bands = (int)(((size_t)P * 36 + (12u << 20) - 1) / (12u << 20));          // (~4.4 instances of 8 B per Gaussian: a band's keys fit the L2s)
-            bands = std::max(1, std::min(bands, std::min(gy, 16)));
+            // bands of tile rows the emit walks one after the other (see k_tile_emit): every band is another pass over the wave's row
+            // lists (~5 us on S-1M-640), so as few as keep a band's scattered 8-byte stores inside the L2s until their lines are
+            // complete -- measured on the MI355X: 1 band 4 040 it/s, 2 bands 4 180, 3 bands 4 110, 5 bands 3 960 (S-1M-640, plain loop)
+            int bands = (int)(((size_t)P * 20 + (12u << 20) - 1) / (12u << 20));
+            bands = std::max(1, std::min(bands, std::min(gy, 4)));
             const int gpb = GSR_PBIN_KPT * GSR_PBIN_THREADS;
             hipLaunchKernelGGL(k_preprocess_bin, dim3(std::max((P + gpb - 1) / gpb, balanced ? 2 : 1)), dim3(GSR_PBIN_THREADS),
                                (size_t)2 * ntiles * sizeof(uint32_t), st, pa, bands);
@@ -709,11 +714,14 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         // The stateless entry points: one blocking 4-byte read per forward, as rasterizer_impl.cu:282 -- there the instance count,
         // here the flag word: did a tile's complete list overflow its bin?  Then the forward is redone on the exact path.
         // (gsr_refine learns the same from the group's status word.)
-        uint32_t flag = 0, total = 0;
+        uint32_t flag = 0;
+        std::vector<uint32_t> per_tile((size_t)ntiles);
         HIPCHK(hipMemcpyAsync(&flag, im.fail, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(&total, im.tile_count + ntiles, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(per_tile.data(), im.tile_count, per_tile.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        R = (int)std::min<uint32_t>(total, 0x7fffffffu);          // num_rendered (after exact tile culling), as the reference returns it
+        unsigned long long total = 0;
+        for (uint32_t c : per_tile) total += c;
+        R = (int)std::min<unsigned long long>(total, 0x7fffffffull);          // num_rendered (after exact tile culling), as the reference returns it
         if (flag & GSR_FAIL_OVERFLOW) {
             PassCtx cx2 = cx;
             cx2.exact_bins = true;
