@@ -103,6 +103,27 @@ class FusedRefiner:
         self._carry_versions = None      # torch's in-place-modification counters of those tensors when the last call returned
         self._conv_cache = {}
         self._state_host = (C.c_float * _lib.POSE_STATE_FLOATS)()
+        self._state_host_t = torch.from_numpy(np.frombuffer(self._state_host, dtype=np.float32))      # (a view: no copy per call)
+        # gsr_refine_args: everything that does not change from call to call is filled in once
+        p = lambda t: None if t is None else t.data_ptr()
+        a = _lib.RefineArgs()
+        a.P, a.M = self.P, self.M
+        a.means3D, a.shs, a.opacities, a.scales, a.rotations = map(p, (self.means3D, self.shs, self.opac, self.scales, self.rots))
+        a.width, a.height = self.W, self.H
+        a.pose_state = p(self.state)
+        a.pose_state_host = self._state_host
+        a.out_color, a.out_depth, a.out_alpha, a.radii, a.n_touched = map(p, (self.color, self.depth, self.alpha, self.radii, self.n_touched))
+        a.dL_dimage, a.dL_ddepth, a.dL_dalpha = map(p, (self.g_img, self.g_depth, self.g_alpha))
+        a.dL_dmean2D, a.dL_dconic, a.dL_dopacity, a.dL_dcolor = map(p, (self.g_m2d, self.g_conic, self.g_opac, self.g_col))
+        a.dL_dmean3D, a.dL_dcov3D, a.dL_dsh, a.dL_dscale, a.dL_drot = map(p, (self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot))
+        a.dL_dtau, a.loss_out = p(self.g_tau), p(self.loss_out)
+        a.geometry_buffer, a.binning_buffer, a.image_buffer = self.ws[0].fn, self.ws[1].fn, self.ws[2].fn
+        a.geometry_ctx, a.binning_ctx, a.image_ctx = self.ws[0].key, self.ws[1].key, self.ws[2].key
+        a.warm_state = C.pointer(self._warm)
+        a.carry_state = C.pointer(self._carry)
+        self._stats = (C.c_int * 4)(0, 0, 0, 0)
+        a.stats_out = self._stats
+        self._args = a
 
     def _tensor_versions(self):
         ts = (self.scales, self.rots, self.g_alpha, self.g_m2d, self.g_conic, self.g_opac, self.g_col, self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot)
@@ -160,38 +181,25 @@ class FusedRefiner:
         alpha_cfg = config["Training"]["alpha"] if "alpha" in config["Training"] else 0.98
         stream = torch.cuda.current_stream(dev).cuda_stream
         p = lambda t: None if t is None else t.data_ptr()
-        a = _lib.RefineArgs()
-        a.P, a.D, a.M = self.P, int(self.model.active_sh_degree), self.M
-        a.means3D, a.shs, a.opacities, a.scales, a.rotations = map(p, (self.means3D, self.shs, self.opac, self.scales, self.rots))
+        a = self._args
+        a.D = int(self.model.active_sh_degree)
         a.scale_modifier = float(scale_modifier)
         # warm_start: start speculating from the depth bounds the previous refine() of this refiner left behind instead of
         # binning the first iteration completely (still verified on the device, still exact: stale bounds cost one redone
         # forward).  None = whenever such bounds exist -- consecutive query frames of a sequence see almost the same depths.
         if warm_start is False:
             self._warm.value = 0
-        a.warm_state = C.pointer(self._warm)
         # (anything torch has written into them since -- fr.g_sh.zero_(), an optimiser stepping the scales -- shows in the
         # tensors' version counters and withdraws the promise; so does another scale modifier)
         if self._carry_versions != self._tensor_versions() + (float(scale_modifier),):
             self._carry.value = 0
-        a.carry_state = C.pointer(self._carry)
-        a.width, a.height = self.W, self.H
         a.tan_fovx, a.tan_fovy = math.tan(viewpoint.FoVx * 0.5), math.tan(viewpoint.FoVy * 0.5)
         a.background, a.projmatrix_raw = p(bg), p(proj_raw)
         a.gt_image, a.gt_depth, a.grad_mask = p(gt_image), p(gt_depth), p(mask)
         a.opacity_threshold = float(config["Training"]["opacity_threshold"])
         a.depth_weight = float(1 - alpha_cfg)
         a.monocular = int(mono)
-        a.pose_state = p(self.state)
         a.init_R, a.init_T, a.init_exposure_a, a.init_exposure_b = p(R0), p(T0), p(ea0), p(eb0)
-        a.pose_state_host = self._state_host
-        a.out_color, a.out_depth, a.out_alpha, a.radii, a.n_touched = map(p, (self.color, self.depth, self.alpha, self.radii, self.n_touched))
-        a.dL_dimage, a.dL_ddepth, a.dL_dalpha = map(p, (self.g_img, self.g_depth, self.g_alpha))
-        a.dL_dmean2D, a.dL_dconic, a.dL_dopacity, a.dL_dcolor = map(p, (self.g_m2d, self.g_conic, self.g_opac, self.g_col))
-        a.dL_dmean3D, a.dL_dcov3D, a.dL_dsh, a.dL_dscale, a.dL_drot = map(p, (self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot))
-        a.dL_dtau, a.loss_out = p(self.g_tau), p(self.loss_out)
-        a.geometry_buffer, a.binning_buffer, a.image_buffer = self.ws[0].fn, self.ws[1].fn, self.ws[2].fn
-        a.geometry_ctx, a.binning_ctx, a.image_ctx = self.ws[0].key, self.ws[1].key, self.ws[2].key
         a.lr, a.converged_threshold, a.max_iters = float(lr), float(converged_threshold), int(iters)
         a.stop_on_converged = int(bool(stop_on_converged))
         a.speculative = int(bool(speculative))
@@ -199,8 +207,8 @@ class FusedRefiner:
         a.bound_margin_mul, a.bound_margin_add = (0.0, 0.0) if bound_margin is None else (float(bound_margin[0]), float(bound_margin[1]))
         # count_instances: also report how many tile instances the LAST forward binned (info["num_rendered"]; costs a copy of
         # the tile ranges to the host and a stream synchronisation)
-        stats = (C.c_int * 4)(0, 0 if count_instances else -1, 0, 0)
-        a.stats_out = stats
+        stats = self._stats
+        stats[0], stats[1], stats[2], stats[3] = 0, (0 if count_instances else -1), 0, 0
         a.stream = stream
         a.flags = self._env_flags() if flags is None else int(flags)
         a.lean_min_P = int(lean_min_P)
@@ -213,17 +221,18 @@ class FusedRefiner:
         self._last_args = a                                          # (gsr_debug_lean_check takes the same struct)
         self._keep = (R0, T0, ea0, eb0, proj_raw, gt_image, gt_depth, mask, bg)        # alive until the stream has drained
         # the final pose came back with the call (gsr_refine_args.pose_state_host): no second blocking read.  The camera gets
-        # device tensors cut out of the state (four tiny asynchronous copies; host -> device uploads would each stall)
-        s = torch.tensor(self._state_host[0:40], dtype=torch.float32)
+        # device tensors cut out of ONE copy of the state (asynchronous; host -> device uploads would each stall)
+        s = self._state_host_t
         with torch.no_grad():
-            viewpoint.update_RT(self.state[0:9].reshape(3, 3).clone(), self.state[9:12].clone())
-            viewpoint.exposure_a.copy_(self.state[18:19].reshape(viewpoint.exposure_a.shape))
-            viewpoint.exposure_b.copy_(self.state[19:20].reshape(viewpoint.exposure_b.shape))
+            st = self.state[0:20].clone()
+            viewpoint.update_RT(st[0:9].view(3, 3), st[9:12])
+            viewpoint.exposure_a.copy_(st[18:19].view(viewpoint.exposure_a.shape))
+            viewpoint.exposure_b.copy_(st[19:20].view(viewpoint.exposure_b.shape))
         self.last_info = {"fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2])}
         return viewpoint.R, viewpoint.T, {"iters": n_done.value, "converged": bool(conv.value), "loss": float(s[38]),
                                           "fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]),
                                           # (host copies of the final pose: no device read-back for the caller's error statistics)
-                                          "R_host": s[0:9].reshape(3, 3).numpy().copy(), "T_host": s[9:12].numpy().copy(),
+                                          "R_host": s[0:9].numpy().reshape(3, 3).copy(), "T_host": s[9:12].numpy().copy(),
                                           "render": self.color, "depth": self.depth, "opacity": self.alpha}
 
     def lean_check(self):

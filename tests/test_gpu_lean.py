@@ -214,10 +214,10 @@ def test_conservative_bound_on_adversarial_inputs(kind):
     lean = _run(fr, view(), init, bg, 8, scale_modifier=mod, lean_min_P=1, flags=0)
     assert lean["info"]["lean_iters"] > 0, lean["info"]
     assert lean["info"]["fallbacks"] == nolean["info"]["fallbacks"], (lean["info"], nolean["info"])
-    _same_path(lean, nolean, kind + ": lean vs no-lean")
-    # (speculative against complete lists: other lists, other atomics order -> poses 1e-6 apart; these scenes have splats with
-    # razor-sharp edges -- |q| = 5 shrinks one axis of Sigma 49-fold -- where that moves single pixels by 1e-3)
-    _same_path(lean, plain, kind + ": lean vs complete lists", img_tol=2e-3)
+    # (any two runs: other atomics order -> poses ~1e-6 apart; these scenes have splats with razor-sharp edges -- |q| = 5 shrinks one
+    # axis of Sigma 49-fold -- where that moves single pixels by 1e-3: the image criteria of the BASELINE-size tests)
+    _same_path(lean, nolean, kind + ": lean vs no-lean", strict_pixels=False)
+    _same_path(lean, plain, kind + ": lean vs complete lists", strict_pixels=False)
     settled, cand, binned, bad, first = fr.lean_check()
     assert bad == 0, (kind, bad, first)
     assert settled + cand == sc.P and binned > 0
