@@ -696,7 +696,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
                      zb_next, zb_prev, cx.guard.poison ? const_cast<uint32_t*>(cx.guard.poison) : im.fail, \
                      sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], balanced ? im.tile_work[0] : (uint32_t*)nullptr, bin_cap, \
                      LazySH{pa.lazy_sh ? shs : nullptr, means3D, cam_pos, D, M, g.clamped, g.rec}, (cx.guard.poison ? cx.guard.tag << 2 : 0u), \
-                     full_bins ? im.tile_count : (uint32_t*)nullptr
+                     full_bins ? im.tile_count : (uint32_t*)nullptr, (P < (1 << 28)) ? 1 : 0
         if (by_tile) {
             if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
             else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
@@ -818,8 +818,8 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         const bool balanced = cx.balance && cx.native_loop && ntiles <= GSR_ORDER_MAX_TILES;
         const uint32_t* order = balanced ? im.tile_order[1] : nullptr;
         uint32_t* work = balanced ? im.tile_work[1] : nullptr;
-        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P);
-        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P);
+        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0);
+        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0);
 #undef GSR_BWD_ARGS
     }
     LAUNCHCHK("k_render_bwd");
@@ -1283,7 +1283,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                            reinterpret_cast<uint32_t*>(bb.ptr), (const unsigned long long*)nullptr, (uint32_t*)nullptr, a->width,
                            a->height, gx, gx * gy, (const float*)g.rec, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
                            a->n_touched, (float*)nullptr, (const float*)nullptr, im.fail, 1.f, 0.f, (float*)nullptr,
-                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{}, 0u, (uint32_t*)nullptr);
+                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{}, 0u, (uint32_t*)nullptr, (a->P < (1 << 28)) ? 1 : 0);
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
     if (a->pose_state_host) HIPCHK(hipMemcpyAsync(h_status + 16, ps, GSR_POSE_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToHost, st));

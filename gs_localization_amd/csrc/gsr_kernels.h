@@ -1535,8 +1535,11 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
                                                           int sbx, FusedLoss fl, const uint32_t* __restrict__ tile_order,
                                                           uint32_t* __restrict__ tile_work, int bin_cap, LazySH lz, uint32_t fail_tag,
-                                                          uint32_t* __restrict__ tile_total)
+                                                          uint32_t* __restrict__ tile_total, int pack_qm)
 {
+    // (pack_qm: the sorted index list carries every staged splat's quadrant mask for this tile in bits 28-31 of its entry -- written
+    // below, read by k_render_bwd_mfma's staging, which then needs neither the splat's record nor the span arithmetic again.
+    // The host sets it when P < 2^28.)
     // (tile_total, nullable, ntiles words: GSR_LIST_BINS_FULL leaves every tile's complete instance count there; their sum is the
     // forward's num_rendered)
     // (fail: the word a failed verification is reported in -- the loop's poison word with fail_tag = this group's tag << 2, see
@@ -1656,7 +1659,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         const int n = min(GSR_BLOCK, m - base);
         overhead += 3;
         if (tid < n) {
-            const uint32_t id = (LIST != GSR_LIST_SORTED) ? (uint32_t)s_keys[base + tid] : point_list[range.x + base + tid];
+            const uint32_t id = (LIST != GSR_LIST_SORTED) ? (uint32_t)s_keys[base + tid]
+                                                           : (pack_qm ? (point_list[range.x + base + tid] & 0x0FFFFFFFu) : point_list[range.x + base + tid]);
             const float4* r = reinterpret_cast<const float4*>(rec + (size_t)id * GSR_REC_STRIDE);
             const float4 r0 = r[0], r1 = r[1];
             float4 r2;
@@ -1681,6 +1685,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             }
             const uint32_t qm = quadrant_mask(r0.x, r0.y, r1.x * (-2.0f / GSR_LOG2E), r0.z * (-1.0f / GSR_LOG2E), r0.w * (-2.0f / GSR_LOG2E), r1.y,
                                               tx * GSR_TILE, ty * GSR_TILE);
+            if (LIST != GSR_LIST_SORTED && pack_qm) point_list[range.x + consumed + base + tid] = id | (qm << 28);
             s.a[tid] = r0;
             s.b[tid] = make_float4(r1.x, r1.y, __uint_as_float(id), __uint_as_float(qm));
             s.c[tid] = make_float4(r2.x, r2.y, r2.z, r1.z);
@@ -1941,7 +1946,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                                                                const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
                                                                const float* __restrict__ dL_dalphas, float* __restrict__ acc,
                                                                LoopGuard guard, const uint32_t* __restrict__ tile_order,
-                                                               uint32_t* __restrict__ tile_work, const float* __restrict__ rec, int P)
+                                                               uint32_t* __restrict__ tile_work, const float* __restrict__ rec, int P, int pack_qm)
 {
     __shared__ BwdMfmaLDS s;
     const GSR_CONST_AS float* crec = (const GSR_CONST_AS float*)rec;      // (constant address space + wave-uniform offsets: s_load)
@@ -2017,10 +2022,15 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         nbatch++;
         const int n = min(GSR_BWD_STAGE, total - base);
         if (tid < n) {
-            const uint32_t id = point_list[range.x + (total - 1 - base - tid)];
-            const SplatRec sr = load_splat_rec(rec, id);
-            s.ids[tid] = id;
-            s.qm[tid] = (uint8_t)quadrant_mask(sr.x, sr.y, sr.a, sr.b, sr.c, sr.opacity, tx * GSR_TILE, ty * GSR_TILE);
+            const uint32_t e = point_list[range.x + (total - 1 - base - tid)];
+            if (pack_qm) {          // the forward left this tile's quadrant mask of the splat in the entry (k_render_fwd, pack_qm)
+                s.ids[tid] = e & 0x0FFFFFFFu;
+                s.qm[tid] = (uint8_t)(e >> 28);
+            } else {
+                const SplatRec sr = load_splat_rec(rec, e);
+                s.ids[tid] = e;
+                s.qm[tid] = (uint8_t)quadrant_mask(sr.x, sr.y, sr.a, sr.b, sr.c, sr.opacity, tx * GSR_TILE, ty * GSR_TILE);
+            }
         }
         __syncthreads();
         GSR_T_TICK(2)

@@ -21,7 +21,8 @@ from collections import defaultdict
 csv.field_size_limit(sys.maxsize)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-OURS = {"k_preprocess_lean": "preprocess_lean", "k_preprocess(": "preprocess_fwd", "k_sh_color": "sh_color", "k_tile_count": "tile_count", "k_tile_scan": "tile_scan",
+OURS = {"k_preprocess_lean": "preprocess_lean", "k_preprocess_bin": "preprocess_bin", "k_preprocess(": "preprocess_fwd", "k_refine_init": "refine_init",
+        "k_pose_load": "refine_init", "k_sh_color": "sh_color", "k_tile_count": "tile_count", "k_tile_scan": "tile_scan",
         "k_tile_emit": "tile_emit", "k_tracking_loss": "tracking_loss", "k_pose_step": "pose_step", "k_pose_init": "pose_step",
         "k_tau_finish": "pose_step", "k_preprocess_bwd": "preprocess_bwd", "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd"}
 
@@ -55,6 +56,7 @@ def main():
     ap.add_argument("--sq", help="counter_collection.csv of an SQ pass: SQ_BUSY_CU_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_LDS SQ_WAVES")
     ap.add_argument("--iters", type=int, default=0, help="refinement iterations under the profiler (default: k_render_bwd launches)")
     ap.add_argument("--cmd", default="")
+    ap.add_argument("--no-latest", action="store_true", help="do not overwrite profiles/traffic.json / issue.json (secondary passes, e.g. the plain loop)")
     a = ap.parse_args()
     os.makedirs(os.path.join(ROOT, "profiles"), exist_ok=True)
     rows = list(csv.DictReader(open(a.kt)))
@@ -93,7 +95,8 @@ def main():
                   "fetch_raw_bytes": fe, "fetch_x2_bytes": 2 * fe, "write_bytes": wr, "hbm_bytes_corrected": 2 * fe + wr}
     if out:
         json.dump(out, open(os.path.join(ROOT, "profiles", f"{a.tag}_traffic.json"), "w"), indent=1)
-        json.dump({k: v["hbm_bytes_corrected"] for k, v in out.items()}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+        if not a.no_latest:
+            json.dump({k: v["hbm_bytes_corrected"] for k, v in out.items()}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     if a.sq:
         # Issue-slot utilisation per kernel: a CU issues at most one VALU instruction per cycle (4 SIMDs x one wave64 instruction
         # per 4 cycles) -> valu = SQ_INSTS_VALU / SQ_BUSY_CU_CYCLES; the fp32 MFMA occupies its SIMD's pipe for
@@ -116,7 +119,8 @@ def main():
                             "lds_insts_per_wave": g("SQ_INSTS_LDS") / max(g("SQ_WAVES"), 1.0), "mfma_insts_per_wave": g("SQ_INSTS_MFMA") / max(g("SQ_WAVES"), 1.0)}
                 f.write(f"| {k} | {cnt[k].get('SQ_WAVES', 0)} | {g('SQ_WAVES'):.0f} | {g('SQ_INSTS_VALU') / 1e6:.2f} M | {g('SQ_INSTS_MFMA') / 1e6:.2f} M | "
                         f"{g('SQ_INSTS_LDS') / 1e6:.2f} M | {busy / 1e6:.1f} M | {valu:.2f} | {mfma:.2f} | {issue[k]['valu_insts_per_wave']:.0f} |\n")
-        json.dump(issue, open(os.path.join(ROOT, "profiles", "issue.json"), "w"), indent=1)
+        if not a.no_latest:
+            json.dump(issue, open(os.path.join(ROOT, "profiles", "issue.json"), "w"), indent=1)
         print(json.dumps(issue, indent=1))
     print(open(os.path.join(ROOT, "profiles", f"{a.tag}_kernel_stats.md")).read())
     print(json.dumps(out, indent=1))
