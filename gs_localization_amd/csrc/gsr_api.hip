@@ -139,7 +139,7 @@ struct Img {
     // and the total (one word)
     uint32_t* tile_count; uint32_t* tile_start; uint32_t* tile_offset; uint32_t* tile_fill; uint32_t* total; uint16_t* block_counts; int copies;
     float* zb[2]; uint32_t* fail;                       // speculative depth bounds of the native loop, verification flag
-    float* zbc[2]; int sbx, nsb;                         // bounds per 4x4-tile superblock
+    float* zbc[2]; int sbx, sby, nsb;                    // bounds per 4x4-tile superblock
     uint32_t* tile_cursor; size_t clear_words;           // bin-by-tile path: per-tile append cursors (GSR_CURSOR_STRIDE apart)
     float* loss_shards;                                   // native loop: GSR_LOSS_SHARDS x 16 floats (fused tracking loss)
     uint32_t* tile_work[2]; uint32_t* tile_order[2];      // native loop: per-tile work of the last forward [0] / backward [1] compositing -> their launch orders
@@ -162,7 +162,8 @@ size_t carve_img(char* base, int W, int H, Img& im)
     im.zb[0] = c.take<float>((size_t)gx * gy);
     im.zb[1] = c.take<float>((size_t)gx * gy);
     im.sbx = (gx + 3) / 4;
-    im.nsb = im.sbx * ((gy + 3) / 4);
+    im.sby = (gy + 3) / 4;
+    im.nsb = im.sbx * im.sby;
     im.zbc[0] = c.take<float>((size_t)im.nsb);
     im.zbc[1] = c.take<float>((size_t)im.nsb);
     // fail | tile_cursor are contiguous: one memset clears them
@@ -245,7 +246,8 @@ size_t carve_spec(char* base, int W, int H, Img& im, unsigned long long** bins)
     im.zb[0] = c.take<float>((size_t)gx * gy);
     im.zb[1] = c.take<float>((size_t)gx * gy);
     im.sbx = (gx + 3) / 4;
-    im.nsb = im.sbx * ((gy + 3) / 4);
+    im.sby = (gy + 3) / 4;
+    im.nsb = im.sbx * im.sby;
     im.zbc[0] = c.take<float>((size_t)im.nsb);
     im.zbc[1] = c.take<float>((size_t)im.nsb);
     im.clear_words = 16 + (size_t)gx * gy * GSR_CURSOR_STRIDE;
@@ -369,6 +371,19 @@ int gsr_debug_timing(unsigned long long* out48)          // (64 entries since th
         out48[k * 16 + 13] = life.size();
         out48[k * 16 + 14] = life.empty() ? 0 : life[life.size() / 2];
         out48[k * 16 + 15] = life.empty() ? 0 : life[life.size() * 99 / 100];
+    }
+    if (const char* dump = getenv("GSR_TIM_DUMP")) {          // raw per-wave rows: "<kernel> <row> <12 slots>" (diagnostics)
+        if (FILE* f = fopen(dump, "w")) {
+            for (int k = 0; k < 4; k++)
+                for (size_t w = 0; w < GSR_TIM_WAVES; w++) {
+                    const unsigned long long* r = &h[((size_t)k * GSR_TIM_WAVES + w) * 12];
+                    if (r[9] == 0ull) continue;
+                    fprintf(f, "%d %zu", k, w);
+                    for (int q = 0; q < 12; q++) fprintf(f, " %llu", r[q]);
+                    fprintf(f, "\n");
+                }
+            fclose(f);
+        }
     }
     std::fill(h.begin(), h.end(), 0ull);
     if (hipMemcpyToSymbol(HIP_SYMBOL(gsr::g_tim), h.data(), h.size() * 8) != hipSuccess) return -2;
@@ -548,7 +563,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     float* zb_next = (sp.mode != 0) ? im.zb[sp.parity] : nullptr;
     pa.zb = zb_prev;
     pa.zb_mul = sp.mul; pa.zb_add = sp.add;
-    pa.zbc = zb_prev ? im.zbc[sp.parity ^ 1] : nullptr; pa.sbx = im.sbx;
+    pa.zbc = zb_prev ? im.zbc[sp.parity ^ 1] : nullptr; pa.sbx = im.sbx; pa.sby = im.sby;
     float* zbc_next = (sp.mode != 0) ? im.zbc[sp.parity] : nullptr;
     BinLocal bl{nullptr, nullptr};
     // Complete lists (no depth bounds to speculate with): binned by the preprocess kernel itself into fixed-capacity bins
@@ -614,7 +629,8 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         } else if (pa.lean) {
             // radii are not an output of this forward: conservative test for all Gaussians, exact geometry for the few it leaves
             const int lblocks = std::max((P + GSR_LEAN_PER_LANE * GSR_BLOCK - 1) / (GSR_LEAN_PER_LANE * GSR_BLOCK), balanced ? 2 : 1);
-            hipLaunchKernelGGL(k_preprocess_lean, dim3(lblocks), dim3(GSR_BLOCK), (size_t)pa.zbc_lds * sizeof(float), st, pa);
+            // (LDS: the superblock bounds and the coarser levels the kernel builds behind them)
+            hipLaunchKernelGGL(k_preprocess_lean, dim3(lblocks), dim3(GSR_BLOCK), bound_pyramid_floats(im.sbx, im.sby) * sizeof(float), st, pa);
         } else
             hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(GSR_BLOCK), (size_t)pa.zbc_lds * sizeof(float), st, pa);
     }
@@ -1347,7 +1363,7 @@ int gsr_debug_lean_check(const gsr_refine_args* a, long long out[5])
     pa.tanx = a->tan_fovx; pa.tany = a->tan_fovy;
     pa.fx = a->width / (2.0f * a->tan_fovx); pa.fy = a->height / (2.0f * a->tan_fovy);
     pa.cov3D_pre = g.cov3D; pa.lam = g.lam;
-    pa.zb = im.zb[buf]; pa.zbc = im.zbc[buf]; pa.sbx = im.sbx;
+    pa.zb = im.zb[buf]; pa.zbc = im.zbc[buf]; pa.sbx = im.sbx; pa.sby = im.sby;
     pa.zb_mul = 1.05f; pa.zb_add = 0.05f;
     unsigned long long* d = reinterpret_cast<unsigned long long*>(im.loss_shards);      // scratch (gsr_refine clears these words when it starts)
     HIPCHK(hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), st));

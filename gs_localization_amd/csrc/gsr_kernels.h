@@ -228,7 +228,7 @@ struct PreArgs {
     uint32_t* tile_count; int ntiles;      // exact-bin path: ntiles counter words (all copies) zeroed here for k_tile_count (nullable)
     const float* zb;                       // speculative per-tile depth bounds of the native loop (nullable): the depth each
     float zb_mul, zb_add;                  // tile had to look at; an instance is kept if z <= zb * zb_mul + zb_add
-    const float* zbc; int sbx;             // the same per 4x4-tile superblock (max of its tiles): quick reject
+    const float* zbc; int sbx, sby;        // the same per 4x4-tile superblock (max of its tiles): quick reject; sbx x sby superblocks
     int zbc_lds;                           // k_preprocess: number of superblock bounds staged in LDS (0: read from global)
     int lean;                              // k_preprocess: radii of this forward are not an output (see the kernel)
     // bin-by-tile path (nullable): per-tile append cursors and fixed-capacity bins of (depth bits << 32 | index)
@@ -437,6 +437,14 @@ __device__ __forceinline__ float view_norm2_bound(const float* view)
 //   Sigma, wn2 = view_norm2_bound: no assumption on the quaternion, the scale modifier or the pose matrix.  Hardware
 //   reciprocals and fp32 pixel centres are covered by a 0.2 % + 0.2 % + two-pixel allowance; a bound of a million pixels or
 //   more (or NaN) is not trusted at all: candidate, the exact code decides.
+// zbc: the superblock bounds; MIP: followed (k_preprocess_lean's copy in LDS, build_bound_pyramid) by coarser levels, each the
+// maximum over 2 x 2 cells of the one below, down to a level of at most 3 x 3 cells.  The bound of a rectangle is then the maximum
+// over at most 3 x 3 cells of the finest level on which it spans no more than that -- nine independent LDS reads.  (Round 2
+// walked the rectangle's superblocks one by one: a loop of up to 80 dependent LDS reads whose trip count is the LARGEST of the
+// wave's 64 lanes -- one big splat near the camera among a wave's 256 Gaussians, which half of the waves have, and the
+// conservative pass took 45 k cycles instead of 22 k: that pass, not the exact one, was the kernel's slow tail,
+// profiles/r03_phase_clocks.md.)  Coarser cells only make the test more conservative.
+template <bool MIP>
 __device__ __forceinline__ bool lean_candidate(const PreArgs& a, float3 p, float3 pview, float seff, float wn2, const float* zbc)
 {
     const float4 ph = xform4x4(p, a.proj);
@@ -453,9 +461,43 @@ __device__ __forceinline__ bool lean_candidate(const PreArgs& a, float3 p, float
     get_rect(pxf, pyf, (int)rb, a.gx, a.gy, x0, y0, x1, y1);
     if ((x1 - x0) * (y1 - y0) == 0) return false;
     float zc = 0.f;
-    for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
-        for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, zbc[sy * a.sbx + sx]);
+    if (MIP) {
+        int sx0 = x0 >> 2, sx1 = (x1 - 1) >> 2, sy0 = y0 >> 2, sy1 = (y1 - 1) >> 2, w = a.sbx, h = a.sby, off = 0;
+        while (sx1 - sx0 > 2 || sy1 - sy0 > 2) {
+            off += w * h; w = (w + 1) >> 1; h = (h + 1) >> 1;
+            sx0 >>= 1; sx1 >>= 1; sy0 >>= 1; sy1 >>= 1;
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) zc = fmaxf(zc, zbc[off + min(sy0 + dy, sy1) * w + min(sx0 + dx, sx1)]);
+    } else {
+        for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
+            for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, zbc[sy * a.sbx + sx]);
+    }
     return !(pview.z > zc * a.zb_mul + a.zb_add);
+}
+// Appends the coarser levels behind the sbx x sby superblock bounds in s (LDS, all threads of the workgroup; s[0, sbx * sby) staged
+// and a barrier passed): level l + 1 = maxima over 2 x 2 cells of level l, until a level has at most 3 x 3 cells.
+__device__ __forceinline__ void build_bound_pyramid(float* s, int sbx, int sby)
+{
+    int w = sbx, h = sby, off = 0;
+    while (w > 3 || h > 3) {
+        const int nw = (w + 1) >> 1, nh = (h + 1) >> 1, noff = off + w * h;
+        for (int i = threadIdx.x; i < nw * nh; i += blockDim.x) {
+            const int cx = i % nw, cy = i / nw, x0 = 2 * cx, y0 = 2 * cy, x1 = min(x0 + 1, w - 1), y1 = min(y0 + 1, h - 1);
+            s[noff + i] = fmaxf(fmaxf(s[off + y0 * w + x0], s[off + y0 * w + x1]), fmaxf(s[off + y1 * w + x0], s[off + y1 * w + x1]));
+        }
+        __syncthreads();
+        off = noff; w = nw; h = nh;
+    }
+}
+static inline size_t bound_pyramid_floats(int sbx, int sby)
+{
+    size_t n = (size_t)sbx * sby;
+    int w = sbx, h = sby;
+    while (w > 3 || h > 3) { w = (w + 1) >> 1; h = (h + 1) >> 1; n += (size_t)w * h; }
+    return n;
 }
 
 // Everything k_preprocess does for ONE Gaussian (lane) once its index is known: exact geometry, the bound tests, binning on
@@ -613,6 +655,9 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
 #define GSR_PERM_I(v, src) __builtin_amdgcn_ds_bpermute((src) << 2, (int)(v))
         // four steps (256 instances) per round, phase by phase: every bound load of the round is in flight before the first
         // is needed, likewise the returning atomics on the tile cursors
+#if GSR_TIMING
+        if ((tid & 63) == 0 && s_flat != nullptr) s_flat[128] += (uint32_t)total;      // (diagnostics: instances walked by this wave)
+#endif
         for (int u0 = 0; u0 < total; u0 += 4 * 64) {
             int f_tile[4], f_src[4]; float f_z[4], f_zb[4]; uint32_t f_id[4]; bool f_in[4];
 #pragma unroll
@@ -810,7 +855,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_lean(PreArgs a)
 {
     extern __shared__ float s_zbc[];      // a.zbc_lds floats: the superblock bounds
     __shared__ uint32_t s_cand[4][GSR_LEAN_PER_LANE * 64];
-    __shared__ uint32_t s_flat[4][128];
+    __shared__ uint32_t s_flat[4][132];      // (128 words per wave; word 128: diagnostics of the timing build)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (a.tile_order[0] != nullptr && blockIdx.x < 2) {      // (before the poison test: the orders must be permutations whatever happens)
         __shared__ uint32_t s_cls[GSR_BLOCK];
@@ -820,6 +865,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_lean(PreArgs a)
     GSR_T_DECL
     for (int i = tid; i < a.zbc_lds; i += GSR_BLOCK) s_zbc[i] = a.zbc[i];
     __syncthreads();
+    build_bound_pyramid(s_zbc, a.sbx, a.sby);
     GSR_T_TICK(0)
     const bool frozen = a.guard.frozen();
     if (blockIdx.x == 0 && tid == 0) {      // the null splat
@@ -849,7 +895,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_lean(PreArgs a)
             const float3 p = pk[k];
             const float3 pview = xform4x3(p, a.view);
             if (pview.z > 0.2f)       // near cull (auxiliary.h:150); a frozen forward's radii are an output: nobody is settled
-                cand = frozen ? true : lean_candidate(a, p, pview, sk[k], wn2, s_zbc);
+                cand = frozen ? true : lean_candidate<true>(a, p, pview, sk[k], wn2, s_zbc);
         }
         // (a Gaussian that is not even a candidate gets no gradient this iteration: see PreArgs::dirty; candidates: preprocess_one)
         if (a.dirty != nullptr && live && !cand && !frozen) {
@@ -863,11 +909,19 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_lean(PreArgs a)
     __builtin_amdgcn_wave_barrier();
     GSR_T_TICK(1)
     GSR_T_COUNT(10, ncand)
+#if GSR_TIMING
+    if (lane == 0) s_flat[wv][128] = 0u;
+    __builtin_amdgcn_wave_barrier();
+#endif
     for (int c0 = 0; c0 < ncand; c0 += 64) {
         const bool mine = c0 + lane < ncand;
         preprocess_one<true>(a, mine ? (int)s_cand[wv][c0 + lane] : 0, mine, s_zbc, tid, blockIdx.x & (GSR_SURV_LISTS - 1), s_flat[wv]);
     }
     GSR_T_TICK(2)
+#if GSR_TIMING
+    __builtin_amdgcn_wave_barrier();
+    GSR_T_COUNT(11, s_flat[wv][128])
+#endif
     GSR_T_FLUSH(32)
 }
 
@@ -885,7 +939,8 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_lean_check(PreArgs a, unsigned lo
     bool cand = false;
     uint32_t cnt = 0;
     if (pview.z > 0.2f) {
-        cand = lean_candidate(a, p, pview, a.lam[4 * (size_t)idx + 3], view_norm2_bound(a.view), a.zbc);
+        // (the bounds without the coarser levels k_preprocess_lean adds in LDS: what this settles is a superset of what the kernel settles)
+        cand = lean_candidate<false>(a, p, pview, a.lam[4 * (size_t)idx + 3], view_norm2_bound(a.view), a.zbc);
         const float4 ph = xform4x4(p, a.proj);
         const float pw = 1.0f / (ph.w + 0.0000001f);
         const float3 pproj = make_float3(ph.x * pw, ph.y * pw, ph.z * pw);
