@@ -632,7 +632,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
             // (LDS: the superblock bounds and the coarser levels the kernel builds behind them)
             hipLaunchKernelGGL(k_preprocess_lean, dim3(lblocks), dim3(GSR_BLOCK), bound_pyramid_floats(im.sbx, im.sby) * sizeof(float), st, pa);
         } else
-            hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(GSR_BLOCK), (size_t)pa.zbc_lds * sizeof(float), st, pa);
+            hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(GSR_BLOCK), (pa.zbc_lds > 0 ? bound_pyramid_floats(im.sbx, im.sby) : 0) * sizeof(float), st, pa);
     }
     LAUNCHCHK("k_preprocess");
     // SH colours only feed the compositing kernel: fork them onto the side stream, join before K6.  (Not on the

@@ -444,6 +444,27 @@ __device__ __forceinline__ float view_norm2_bound(const float* view)
 // wave's 64 lanes -- one big splat near the camera among a wave's 256 Gaussians, which half of the waves have, and the
 // conservative pass took 45 k cycles instead of 22 k: that pass, not the exact one, was the kernel's slow tail,
 // profiles/r03_phase_clocks.md.)  Coarser cells only make the test more conservative.
+// (largest superblock bound under the non-empty tile rectangle [x0, x1) x [y0, y1))
+template <bool MIP>
+__device__ __forceinline__ float rect_bound_max(const float* zbc, int sbx, int sby, int x0, int y0, int x1, int y1)
+{
+    float zc = 0.f;
+    if (MIP) {
+        int sx0 = x0 >> 2, sx1 = (x1 - 1) >> 2, sy0 = y0 >> 2, sy1 = (y1 - 1) >> 2, w = sbx, h = sby, off = 0;
+        while (sx1 - sx0 > 2 || sy1 - sy0 > 2) {
+            off += w * h; w = (w + 1) >> 1; h = (h + 1) >> 1;
+            sx0 >>= 1; sx1 >>= 1; sy0 >>= 1; sy1 >>= 1;
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; dy++)
+#pragma unroll
+            for (int dx = 0; dx < 3; dx++) zc = fmaxf(zc, zbc[off + min(sy0 + dy, sy1) * w + min(sx0 + dx, sx1)]);
+    } else {
+        for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
+            for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, zbc[sy * sbx + sx]);
+    }
+    return zc;
+}
 template <bool MIP>
 __device__ __forceinline__ bool lean_candidate(const PreArgs& a, float3 p, float3 pview, float seff, float wn2, const float* zbc)
 {
@@ -460,21 +481,7 @@ __device__ __forceinline__ bool lean_candidate(const PreArgs& a, float3 p, float
     int x0, y0, x1, y1;
     get_rect(pxf, pyf, (int)rb, a.gx, a.gy, x0, y0, x1, y1);
     if ((x1 - x0) * (y1 - y0) == 0) return false;
-    float zc = 0.f;
-    if (MIP) {
-        int sx0 = x0 >> 2, sx1 = (x1 - 1) >> 2, sy0 = y0 >> 2, sy1 = (y1 - 1) >> 2, w = a.sbx, h = a.sby, off = 0;
-        while (sx1 - sx0 > 2 || sy1 - sy0 > 2) {
-            off += w * h; w = (w + 1) >> 1; h = (h + 1) >> 1;
-            sx0 >>= 1; sx1 >>= 1; sy0 >>= 1; sy1 >>= 1;
-        }
-#pragma unroll
-        for (int dy = 0; dy < 3; dy++)
-#pragma unroll
-            for (int dx = 0; dx < 3; dx++) zc = fmaxf(zc, zbc[off + min(sy0 + dy, sy1) * w + min(sx0 + dx, sx1)]);
-    } else {
-        for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
-            for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, zbc[sy * a.sbx + sx]);
-    }
+    const float zc = rect_bound_max<MIP>(zbc, a.sbx, a.sby, x0, y0, x1, y1);
     return !(pview.z > zc * a.zb_mul + a.zb_add);
 }
 // Appends the coarser levels behind the sbx x sby superblock bounds in s (LDS, all threads of the workgroup; s[0, sbx * sby) staged
@@ -607,14 +614,9 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
                     bool far_everywhere = false;
                     if (a.zb != nullptr) {
                         // behind the bound of every superblock the rectangle overlaps => behind every tile's bound
-                        float zc = 0.f;
-                        if (s_zbc != nullptr && a.zbc_lds > 0) {
-                            for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
-                                for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, s_zbc[sy * a.sbx + sx]);
-                        } else {
-                            for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
-                                for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, a.zbc[sy * a.sbx + sx]);
-                        }
+                        // (s_zbc: the bounds in LDS with the coarser levels behind them, build_bound_pyramid; otherwise global memory)
+                        const float zc = (s_zbc != nullptr && a.zbc_lds > 0) ? rect_bound_max<true>(s_zbc, a.sbx, a.sby, x0, y0, x1, y1)
+                                                                              : rect_bound_max<false>(a.zbc, a.sbx, a.sby, x0, y0, x1, y1);
                         far_everywhere = pview.z > zc * a.zb_mul + a.zb_add;
                     }
                     if (a.bins == nullptr || wout != nullptr) {
@@ -825,6 +827,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     if (a.zbc_lds > 0) {
         for (int i = tid; i < a.zbc_lds; i += GSR_BLOCK) s_zbc[i] = a.zbc[i];
         __syncthreads();
+        build_bound_pyramid(s_zbc, a.sbx, a.sby);
     }
     const int idx = blockIdx.x * GSR_BLOCK + tid;
     if (a.tile_count != nullptr && idx < a.ntiles) a.tile_count[idx] = 0u;      // (k_tile_count adds into them next)
@@ -2699,6 +2702,10 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     const uint32_t* __restrict__ list = a.surv.ids + (size_t)sl * a.surv.cap;
     const uint32_t step = (gridDim.x / GSR_SURV_LISTS) * GSR_K8_ROWS;
     uint32_t c0 = (blockIdx.x / GSR_SURV_LISTS) * GSR_K8_ROWS;
+    // (the first chunk of the list is requested together with the list's length -- inside the sub-list's allocation whatever the
+    // length turns out to be -- instead of one round trip behind it)
+    const uint32_t first_c0 = c0;
+    const uint32_t first_entry = list[c0 + (uint32_t)lane];
     int qn = 0;          // active Gaussians queued in s_q (wave-uniform)
     for (;;) {
         // ---- fill: look at chunks of the list until 64 active Gaussians are queued (or the list ends).  A survivor nobody
@@ -2706,7 +2713,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         // bins: half of the survivors) the chain rule below would otherwise run on half-empty lanes.
         while (qn < GSR_K8_ROWS && c0 < n) {
             const bool in = c0 + (uint32_t)lane < n;
-            const int idx = in ? (int)list[c0 + lane] : 0;
+            const int idx = in ? (int)(c0 == first_c0 ? first_entry : list[c0 + lane]) : 0;
             c0 += step;
             float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
             if (in) {
@@ -2755,6 +2762,24 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             }
         }
         const unsigned long long colmask = __ballot(has_col);
+        // Every per-Gaussian read of the round is requested here, in FRONT of the SH rows, so that one round trip covers them all
+        // (the rows' LDS stores wait for the last loads issued; round 2 asked for these after the barrier below: a second trip).
+        float cov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        float3 mean = make_float3(0.f, 0.f, 0.f);
+        SplatRec sr = {};
+        const bool want_sr = a.scales && (a.dL_dscale || a.dL_drot);
+        float s3[3] = {0.f, 0.f, 0.f};
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 6; i++) cov6[i] = a.cov3D[6 * (size_t)idx + i];
+            mean = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
+            sr = load_splat_rec(a.rec, (uint32_t)idx);
+            if (want_sr) {
+                s3[0] = a.scales[3 * idx]; s3[1] = a.scales[3 * idx + 1]; s3[2] = a.scales[3 * idx + 2];
+                q = reinterpret_cast<const float4*>(a.rots)[idx];
+            }
+        }
         if (staged) {
 #pragma unroll
             for (int i = 0; i < GSR_SH16_ROW4; i++) {
@@ -2770,20 +2795,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         GSR_T_COUNT(11, nrow)
         float* my_row = reinterpret_cast<float*>(&s_sh[lane * GSR_SH16_LDS4]);
         if (active) {
-            float cov6[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++) cov6[i] = a.cov3D[6 * (size_t)idx + i];
-            const float3 mean = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
-            const SplatRec sr = load_splat_rec(a.rec, (uint32_t)idx);
             const float3 co = make_float3(sr.a, sr.b, sr.c);
-            // (scale and rotation are only needed at the very end; requested here, their latency is hidden by the chain rule)
-            const bool want_sr = a.scales && (a.dL_dscale || a.dL_drot);
-            float s3[3] = {0.f, 0.f, 0.f};
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (want_sr) {
-                s3[0] = a.scales[3 * idx]; s3[1] = a.scales[3 * idx + 1]; s3[2] = a.scales[3 * idx + 2];
-                q = reinterpret_cast<const float4*>(a.rots)[idx];
-            }
             // (1) conic gradient -> covariance gradient and the mean's share through the projected covariance
             float G[6];
             const float3 g_cov = covariance_chain(mean, cov6, make_float3(co.x, co.y, co.z), make_float3(r1.y, r1.z, r1.w), a.view, a.fx, a.fy,
