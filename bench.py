@@ -67,7 +67,8 @@ def main():
                     help="iterations per refinement call (the reference refines a frame for at most 50: 7scenes_localize_full_dslam.py:66)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
-    ap.add_argument("--frames-in-flight", type=int, default=8, help="query frames refined concurrently per GPU")
+    ap.add_argument("--frames-in-flight", type=int, default=12,
+                    help="query frames refined concurrently per GPU (measured on one MI355X, round 3: 9 650 it/s with 8, 10 100 with 12 or 16)")
     ap.add_argument("--repeats", type=int, default=3, help="the timed region is run this many times; `value` is the first, the rest show the spread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the CPU port on one thread on S-800k-chess (minutes)")
