@@ -158,6 +158,9 @@ __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int 
 #ifndef GSR_LEAN_PER_LANE
 #define GSR_LEAN_PER_LANE 4      // Gaussians per lane of k_preprocess_lean
 #endif
+#ifndef GSR_LEAN_POOL
+#define GSR_LEAN_POOL 1          // waves of a workgroup that pool their candidates for one exact pass (1, 2 or 4)
+#endif
 struct SurvLists { uint32_t* ids; uint32_t* n; uint32_t cap; };
 static inline uint32_t surv_cap(int P)
 {
@@ -916,10 +919,35 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_lean(PreArgs a)
     if (lane == 0) s_flat[wv][128] = 0u;
     __builtin_amdgcn_wave_barrier();
 #endif
+#if GSR_LEAN_POOL > 1
+    // The exact pass costs ~1 800 vector instructions per WAVE whether four of its lanes are live or sixty-four: GSR_LEAN_POOL
+    // neighbouring waves hand their candidates to the first of them (the conservative passes end within a few hundred cycles of each
+    // other since the bound pyramid), which runs ONE exact pass on the pooled list; the others are done.
+    __shared__ int s_ncand[4];
+    if (lane == 0) s_ncand[wv] = ncand;
+    __syncthreads();
+    if ((wv % GSR_LEAN_POOL) != 0) { GSR_T_TICK(2) GSR_T_FLUSH(32) return; }
+    int pooled = 0;
+#pragma unroll
+    for (int w = 0; w < GSR_LEAN_POOL; w++) pooled += s_ncand[wv + w];
+    for (int c0 = 0; c0 < pooled; c0 += 64) {
+        const int j = c0 + lane;
+        const bool mine = j < pooled;
+        int idx = 0, run = 0;
+#pragma unroll
+        for (int w = 0; w < GSR_LEAN_POOL; w++) {          // (candidate j of the pooled list: wave w's list behind wave w - 1's)
+            const int n_w = s_ncand[wv + w];
+            if (mine && j >= run && j < run + n_w) idx = (int)s_cand[wv + w][j - run];
+            run += n_w;
+        }
+        preprocess_one<true>(a, idx, mine, s_zbc, tid, blockIdx.x & (GSR_SURV_LISTS - 1), s_flat[wv]);
+    }
+#else
     for (int c0 = 0; c0 < ncand; c0 += 64) {
         const bool mine = c0 + lane < ncand;
         preprocess_one<true>(a, mine ? (int)s_cand[wv][c0 + lane] : 0, mine, s_zbc, tid, blockIdx.x & (GSR_SURV_LISTS - 1), s_flat[wv]);
     }
+#endif
     GSR_T_TICK(2)
 #if GSR_TIMING
     __builtin_amdgcn_wave_barrier();
