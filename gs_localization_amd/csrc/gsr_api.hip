@@ -143,6 +143,7 @@ struct Img {
     uint32_t* tile_cursor; size_t clear_words;           // bin-by-tile path: per-tile append cursors (GSR_CURSOR_STRIDE apart)
     float* loss_shards;                                   // native loop: GSR_LOSS_SHARDS x 16 floats (fused tracking loss)
     uint32_t* tile_work[2]; uint32_t* tile_order[2];      // native loop: per-tile work of the last forward [0] / backward [1] compositing -> their launch orders
+    uint32_t* tile_hold;                                  // native loop: forwards a tile still goes without a depth bound after a failed verification
 };
 size_t carve_img(char* base, int W, int H, Img& im)
 {
@@ -173,6 +174,7 @@ size_t carve_img(char* base, int W, int H, Img& im)
     im.loss_shards = c.take<float>(GSR_LOSS_SHARDS * 16);
     im.tile_work[0] = c.take<uint32_t>(nt); im.tile_work[1] = c.take<uint32_t>(nt);      // (contiguous: one memset)
     im.tile_order[0] = c.take<uint32_t>(nt); im.tile_order[1] = c.take<uint32_t>(nt);
+    im.tile_hold = c.take<uint32_t>(nt);
     return c.size();
 }
 
@@ -712,7 +714,8 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
                      zb_next, zb_prev, cx.guard.poison ? const_cast<uint32_t*>(cx.guard.poison) : im.fail, \
                      sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], balanced ? im.tile_work[0] : (uint32_t*)nullptr, bin_cap, \
                      LazySH{pa.lazy_sh ? shs : nullptr, means3D, cam_pos, D, M, g.clamped, g.rec}, (cx.guard.poison ? cx.guard.tag << 2 : 0u), \
-                     full_bins ? im.tile_count : (uint32_t*)nullptr, (P < (1 << 28)) ? 1 : 0
+                     full_bins ? im.tile_count : (uint32_t*)nullptr, (P < (1 << 28)) ? 1 : 0, \
+                     (cx.native_loop && !sp.state && sp.mode != 0) ? im.tile_hold : (uint32_t*)nullptr
         if (by_tile) {
             if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
             else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
@@ -1121,7 +1124,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             if (warm_buf != 0) add(im0.zbc[0], (size_t)im0.nsb);
             if (warm_buf != 1) add(im0.zbc[1], (size_t)im0.nsb);
             add(a->loss_out, 4);
-            static_assert(sizeof(cr.p) / sizeof(cr.p[0]) >= 9, "ClearRanges too small");
+            add(im0.tile_hold, (size_t)(im0.tile_work[1] - im0.tile_work[0]));
+            static_assert(sizeof(cr.p) / sizeof(cr.p[0]) >= 10, "ClearRanges too small");
             hipLaunchKernelGGL(k_refine_init, dim3(32), dim3(GSR_BLOCK), 0, st, cr);
             { const int debug = 0; LAUNCHCHK("k_refine_init"); }
         }
@@ -1299,7 +1303,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                            reinterpret_cast<uint32_t*>(bb.ptr), (const unsigned long long*)nullptr, (uint32_t*)nullptr, a->width,
                            a->height, gx, gx * gy, (const float*)g.rec, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
                            a->n_touched, (float*)nullptr, (const float*)nullptr, im.fail, 1.f, 0.f, (float*)nullptr,
-                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{}, 0u, (uint32_t*)nullptr, (a->P < (1 << 28)) ? 1 : 0);
+                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{}, 0u, (uint32_t*)nullptr, (a->P < (1 << 28)) ? 1 : 0, (uint32_t*)nullptr);
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
     if (a->pose_state_host) HIPCHK(hipMemcpyAsync(h_status + 16, ps, GSR_POSE_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToHost, st));

@@ -41,6 +41,7 @@ struct LoopGuard {
     __device__ __forceinline__ bool poisoned() const { return poison != nullptr && (*poison >> 2) == tag; }
     __device__ __forceinline__ bool frozen() const { return poisoned() || (conv != nullptr && *conv != 0.f); }
 };
+#define GSR_HOLD_FORWARDS 32u    // forwards a tile goes without a depth bound after failing a verification (native loop)
 #define GSR_FAIL_BOUND 1u        // poison / fail word flags
 #define GSR_FAIL_OVERFLOW 2u
 
@@ -1621,8 +1622,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
                                                           int sbx, FusedLoss fl, const uint32_t* __restrict__ tile_order,
                                                           uint32_t* __restrict__ tile_work, int bin_cap, LazySH lz, uint32_t fail_tag,
-                                                          uint32_t* __restrict__ tile_total, int pack_qm)
+                                                          uint32_t* __restrict__ tile_total, int pack_qm, uint32_t* __restrict__ tile_hold)
 {
+    // (tile_hold, nullable, native loop: per tile, for how many more forwards it goes without a depth bound after it failed a
+    // verification -- see where the bounds are recorded)
     // (pack_qm: the sorted index list carries every staged splat's quadrant mask for this tile in bits 28-31 of its entry -- written
     // below, read by k_render_bwd_mfma's staging, which then needs neither the splat's record nor the span arithmetic again.
     // The host sets it when P < 2^28.)
@@ -1895,13 +1898,28 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         __syncthreads();
         if (tid == 0) {
             zm = fmaxf(fmaxf(s_zmax[0], s_zmax[1]), fmaxf(s_zmax[2], s_zmax[3]));
-            const float bound = unfinished ? __builtin_huge_valf() : zm;      // (the margin is applied where the bound is used)
+            float bound = unfinished ? __builtin_huge_valf() : zm;      // (the margin is applied where the bound is used)
+            const bool failed_here = unfinished && zb_used != nullptr && zb_used[tile] < __builtin_huge_valf();
+            if (tile_hold != nullptr) {
+                // A tile at the edge of the map's coverage saturates in one iteration and not in the next: with a bound recorded every
+                // time it saturates it fails every other forward (measured on poses 0.3 m / 10 deg off the map's reference view: 33
+                // failed groups in a 50-iteration refinement).  A tile that failed TWICE in a call keeps its complete list for the next
+                // GSR_HOLD_FORWARDS forwards -- its own list only; everybody else keeps speculating.
+                // (the FIRST failure of a tile in a call is not held: a warm start from another frame's bounds fails in many
+                // tiles once, and their retry records good bounds)
+                const uint32_t word = tile_hold[tile];
+                uint32_t hold = word & 0xFFu, nfail = word >> 8;
+                if (failed_here) { nfail++; hold = (nfail >= 2u) ? GSR_HOLD_FORWARDS : 0u; }
+                else if (hold > 0u) hold--;
+                if (failed_here || (word & 0xFFu) != 0u) tile_hold[tile] = (nfail << 8) | hold;
+                if (hold > 0u) bound = __builtin_huge_valf();
+            }
             zb_next[tile] = bound;
             const int sb = (ty >> 2) * sbx + (tx >> 2);
             atomicMax(reinterpret_cast<int*>(zbc_next) + sb, __float_as_int(bound));     // bounds are >= 0: int order = float order
             // zb_used: the bounds this forward was binned with.  Instances can only have been dropped from a tile whose
             // bound was finite; if such a tile ends with an unsaturated pixel, a dropped instance may be missing.
-            if (unfinished && zb_used != nullptr && zb_used[tile] < __builtin_huge_valf()) atomicMax(fail, fail_tag | GSR_FAIL_BOUND);
+            if (failed_here) atomicMax(fail, fail_tag | GSR_FAIL_BOUND);
         }
     }
     const size_t N = (size_t)W * H;

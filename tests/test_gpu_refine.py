@@ -380,7 +380,7 @@ def test_warm_start_of_the_speculation_is_exact():
         assert torch.allclose(a[3], b[3], atol=5e-3 if name == "far" else 5e-4), name
     assert warm_same[2]["fallbacks"] == 0
     # a cold start bins its first iteration completely, a warm one does not: fewer instances in a 1-iteration call
-    fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=1, stop_on_converged=False, count_instances=True)
+    fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=1, stop_on_converged=False, warm_start=False, count_instances=True)
     n_cold = fr.last_info["num_rendered"]
     fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=1, stop_on_converged=False, warm_start=True, count_instances=True)
     assert fr.last_info["num_rendered"] < 0.6 * n_cold
