@@ -196,6 +196,26 @@ def main():
     elapsed_py = time.perf_counter() - t0
     del _pkg
 
+    # ---- (a') what one forward / backward through the drop-in pose package costs the HOST: the same calls on a scene so small
+    # (2 000 Gaussians, 64x48) that the GPU work is a few launch latencies -- wall time per call, the forward's one blocking read
+    # included.  (Of the Python loop's ~1.8 ms per iteration the library's kernels are ~0.3 ms; the rest is this and torch.)
+    host_us = None
+    if rank == 0:
+        tiny = S.small(P=2000, W=64, H=48, sh_degree=3, seed=3, scale_med=0.06)
+        tmodel = PL.GaussianMap.from_scene(tiny, device=dev)
+        tvp = PL.make_frame(tiny, tmodel, dev, background)
+        fw = bw = 0.0
+        for it_ in range(60):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            tpkg = PL.render(tvp, tmodel, background)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            (tpkg["render"].sum() + tpkg["depth"].sum()).backward()
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            if it_ >= 10:
+                fw += t1 - t0; bw += t2 - t1
+        host_us = {"forward": 1e6 * fw / 50, "backward_incl_two_torch_sums": 1e6 * bw / 50, "scene": "2 000 Gaussians, 64x48: GPU work negligible"}
+        del tiny, tmodel, tvp, tpkg
+
     # ---- (b) the native loop (gsr_refine), one frame at a time; per-kernel breakdown from a separate short run
     frs = [PL.FusedRefiner(model, H, W, device=dev, gaussian_grads=not args.pose_only) for _ in range(F)]
 
@@ -353,6 +373,7 @@ def main():
             "per_call_overhead_ms": per_call_overhead_ms,
             "plain_loop_iters_per_s": world * K / elapsed_plain,
             "python_loop_iters_per_s": world * K / elapsed_py,
+            "dropin_host_us_per_call": host_us,
             "pose_err_cm_median": 100.0 * float(np.median(res[:, 1])),
             "pose_err_deg_median": float(np.median(res[:, 2])),
             "pose_err_init_cm_deg": [100.0 * te0, re0],

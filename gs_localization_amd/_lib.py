@@ -29,6 +29,8 @@ SIGNATURES = {
     "gsr_geometry_bytes": (C.c_size_t, [_i]),
     "gsr_image_bytes": (C.c_size_t, [_i, _i]),
     "gsr_binning_bytes": (C.c_size_t, [_i]),
+    "gsr_binning_bytes_bins": (C.c_size_t, [_i, _i, _i]),
+    "gsr_fixed_buffer_resize": (_vp, [_vp, C.c_size_t]),
     "gsr_forward_stats": (_i, [_i, _i, _i, _vp, _vp, _vp, C.POINTER(C.c_longlong), _vp]),
     "gsr_profile_enable": (_i, [C.c_uint]),
     "gsr_profile_sampling": (_i, [C.c_uint]),
@@ -40,6 +42,14 @@ SIGNATURES = {
     "gsr_abi_version": (_i, []),
     "gsr_device_ok": (_i, []),
 }
+
+class FixedBuffer(C.Structure):
+    """mirror of `gsr_fixed_buffer` (include/gsr.h)"""
+    _fields_ = [("ptr", _vp), ("capacity", C.c_size_t), ("requested", C.c_size_t)]
+
+
+E_ALLOC = -3
+
 
 class SpecState(C.Structure):
     """mirror of `gsr_spec_state` (include/gsr.h)"""
@@ -90,6 +100,16 @@ SIGNATURES.update({
 })
 
 _lib = None
+_fixed_fn = None
+
+
+def fixed_buffer_fn():
+    """`gsr_fixed_buffer_resize` as a RESIZE_FN value: a resize callback that never enters the interpreter"""
+    global _fixed_fn
+    if _fixed_fn is None:
+        load()
+        _fixed_fn = RESIZE_FN(("gsr_fixed_buffer_resize", _lib))
+    return _fixed_fn
 
 
 class GsrError(RuntimeError):

@@ -442,6 +442,21 @@ int gsr_device_ok(void)
 size_t gsr_geometry_bytes(int P) { Geom g; return carve_geom(nullptr, P, g); }
 size_t gsr_image_bytes(int width, int height) { Img im; return carve_img(nullptr, width, height, im); }
 size_t gsr_binning_bytes(int num_rendered) { Bin b; return carve_bin(nullptr, num_rendered, b); }
+size_t gsr_binning_bytes_bins(int P, int width, int height)
+{
+    if (P <= 0 || width <= 0 || height <= 0) return 0;
+    const int ntiles = ((width + GSR_TILE - 1) / GSR_TILE) * ((height + GSR_TILE - 1) / GSR_TILE);
+    if (ntiles > kFullBinMaxTiles) return 0;
+    BinLocal bl;
+    return carve_bin_local(nullptr, ntiles, std::max(full_bin_capacity(P, ntiles), (int)GSR_LSORT_CAP), bl);
+}
+void* gsr_fixed_buffer_resize(void* ctx, size_t bytes)
+{
+    gsr_fixed_buffer* b = static_cast<gsr_fixed_buffer*>(ctx);
+    if (!b) return nullptr;
+    b->requested = bytes;
+    return (bytes <= b->capacity) ? b->ptr : nullptr;
+}
 
 namespace {
 
@@ -1209,6 +1224,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     int enq = 0, settled_n = 0;    // groups enqueued / whose status the host has seen (in order)
     int succ = 0;                  // iterations completed (groups whose pose step ran)
     int streak = 0;                // failed groups in a row
+    int n_host_redo = 0;           // forwards the HOST had to redo with complete lists (everything else was retried on the device)
     bool conv_seen = false;        // (stop_on_converged) an update reported convergence: what follows is the frozen render at the final pose
     bool final_rendered = false;   // ... and that render has been enqueued / verified
     auto enqueue_next = [&](int logical, int mode) -> int {
@@ -1275,6 +1291,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             else { after_success(g2, w2); resolved = true; }
         }
         if (!resolved) {
+            n_host_redo++;
             const int g3 = enq;
             rc = enqueue_next(succ, 2);                 // complete lists: cannot fail
             if (rc < 0) return rc;
@@ -1332,7 +1349,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             }
             last_R = (int)sum;
         }
-        a->stats_out[0] = n_fallbacks; a->stats_out[1] = last_R; a->stats_out[2] = n_lean; a->stats_out[3] = 0;
+        a->stats_out[0] = n_fallbacks; a->stats_out[1] = last_R; a->stats_out[2] = n_lean; a->stats_out[3] = n_host_redo;
     }
     return 0;
 }

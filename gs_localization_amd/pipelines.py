@@ -228,9 +228,9 @@ class FusedRefiner:
             viewpoint.update_RT(st[0:9].view(3, 3), st[9:12])
             viewpoint.exposure_a.copy_(st[18:19].view(viewpoint.exposure_a.shape))
             viewpoint.exposure_b.copy_(st[19:20].view(viewpoint.exposure_b.shape))
-        self.last_info = {"fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2])}
+        self.last_info = {"fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]), "host_redos": int(stats[3])}
         return viewpoint.R, viewpoint.T, {"iters": n_done.value, "converged": bool(conv.value), "loss": float(s[38]),
-                                          "fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]),
+                                          "fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]), "host_redos": int(stats[3]),
                                           # (host copies of the final pose: no device read-back for the caller's error statistics)
                                           "R_host": s[0:9].numpy().reshape(3, 3).copy(), "T_host": s[9:12].numpy().copy(),
                                           "render": self.color, "depth": self.depth, "opacity": self.alpha}

@@ -165,6 +165,23 @@ def speculation_counters(device=None):
     return v, m
 
 
+_size_cache = {}
+
+
+def _workspace_sizes(lib, P, W, H):
+    """(geometry, binning, image) bytes of a forward whose lists go into per-tile bins, or None when the binning workspace cannot
+    be sized up front (gsr_binning_bytes_bins == 0)"""
+    key = (P, W, H)
+    hit = _size_cache.get(key)
+    if hit is None:
+        b = int(lib.gsr_binning_bytes_bins(P, W, H))
+        hit = (int(lib.gsr_geometry_bytes(P)), b, int(lib.gsr_image_bytes(W, H))) if b > 0 else False
+        if len(_size_cache) > 64:
+            _size_cache.clear()
+        _size_cache[key] = hit
+    return hit or None
+
+
 def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, want_touched):
     lib = _lib.load()
     _require_gpu(means3D)
@@ -181,19 +198,44 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     radii = torch.empty((P,), dtype=torch.int32, device=dev)
     n_touched = torch.empty((P,), dtype=torch.int32, device=dev) if want_touched else None
     M = sh.size(1) if sh.numel() != 0 else 0
-    geom, binning, img = _Workspace(dev), _Workspace(dev), _Workspace(dev)
     stream = torch.cuda.current_stream(dev).cuda_stream
     spec = C.byref(_spec_cache.get(lib, dev, stream, W, H)) if (P > 0 and speculation_enabled(want_touched)) else None
-    with torch.cuda.device(dev):
-        rc = lib.gsr_forward_speculative(spec, geom.fn, geom.ctx, binning.fn, binning.ctx, img.fn, img.ctx, P, int(rs.sh_degree), M, _ptr(bg),
-                                         W, H, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
-                                         float(rs.scale_modifier), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(view),
-                                         _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
-                                         int(bool(rs.prefiltered)), color.data_ptr(), depth.data_ptr(), alpha.data_ptr(),
-                                         _ptr(radii), int(bool(rs.debug)) | (2 if "GSR_SH_EAGER" in os.environ else 0), _ptr(n_touched), stream)
-    _Workspace.raise_pending(geom, binning, img)          # e.g. torch's out-of-memory error, not a bare GSR_E_ALLOC
+    dbg = int(bool(rs.debug)) | (2 if "GSR_SH_EAGER" in os.environ else 0)
+
+    def call(fn_g, ctx_g, fn_b, ctx_b, fn_i, ctx_i):
+        with torch.cuda.device(dev):
+            return lib.gsr_forward_speculative(spec, fn_g, ctx_g, fn_b, ctx_b, fn_i, ctx_i, P, int(rs.sh_degree), M, _ptr(bg),
+                                               W, H, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
+                                               float(rs.scale_modifier), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(view),
+                                               _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
+                                               int(bool(rs.prefiltered)), color.data_ptr(), depth.data_ptr(), alpha.data_ptr(),
+                                               _ptr(radii), dbg, _ptr(n_touched), stream)
+
+    # The three workspaces.  Where their sizes are known before the call (per-tile bins: every image up to 2 048 tiles) they are
+    # allocated here and handed over through the library's own fixed-buffer callback -- no callback into the interpreter; the
+    # growing `_Workspace` route is the fallback (large images: the key array is sized from a device read-back, as the
+    # reference's is; a bin that overflowed).
+    geom_t = bin_t = img_t = None
+    rc = None
+    sizes = _workspace_sizes(lib, P, W, H) if P > 0 else None
+    if sizes is not None:
+        bufs = [torch.empty(n, dtype=torch.uint8, device=dev) for n in sizes]
+        fb = (_lib.FixedBuffer * 3)()
+        for k in range(3):
+            fb[k].ptr, fb[k].capacity = bufs[k].data_ptr(), sizes[k]
+        ff = _lib.fixed_buffer_fn()
+        rc = call(ff, C.addressof(fb[0]), ff, C.addressof(fb[1]), ff, C.addressof(fb[2]))
+        if rc == _lib.E_ALLOC:
+            rc = None
+        else:
+            geom_t, bin_t, img_t = bufs
+    if rc is None:
+        geom, binning, img = _Workspace(dev), _Workspace(dev), _Workspace(dev)
+        rc = call(geom.fn, geom.ctx, binning.fn, binning.ctx, img.fn, img.ctx)
+        _Workspace.raise_pending(geom, binning, img)          # e.g. torch's out-of-memory error, not a bare GSR_E_ALLOC
+        geom_t, bin_t, img_t = geom.t, binning.t, img.t
     num_rendered = _lib.check(rc)
-    saved = (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom.t, binning.t, img.t, alpha,
+    saved = (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_t, bin_t, img_t, alpha,
              opacities)
     consts = (bg, view, proj, campos)
     return num_rendered, color, radii, depth, alpha, n_touched, saved, consts

@@ -185,6 +185,17 @@ size_t gsr_geometry_bytes(int P);
 size_t gsr_image_bytes(int width, int height);
 size_t gsr_binning_bytes(int num_rendered);
 
+/* For callers that allocate the three workspaces of a forward up front instead of growing them on demand (a Python caller pays
+ * three callbacks into the interpreter per forward otherwise).  gsr_fixed_buffer_resize is a gsr_resize_fn whose context is a
+ * gsr_fixed_buffer: it returns `ptr` when the request fits `capacity` and NULL otherwise -- the forward then fails with
+ * GSR_E_ALLOC and the caller repeats it with growing buffers; `requested` receives the size asked for either way.
+ * gsr_binning_bytes_bins: an upper bound of what gsr_forward / gsr_forward_speculative ask their binning callback for while the
+ * lists are binned into per-tile bins; 0 for image sizes whose complete lists go through count -> scan -> emit, whose size
+ * depends on the scene (rasterizer_impl.cu:282: the reference sizes that buffer from a device read-back too). */
+typedef struct gsr_fixed_buffer { void* ptr; size_t capacity; size_t requested; } gsr_fixed_buffer;
+void* gsr_fixed_buffer_resize(void* ctx, size_t bytes);
+size_t gsr_binning_bytes_bins(int P, int width, int height);
+
 /* Statistics of the last forward on this buffer set (host ints, filled by a blocking copy):
  * stats[0] = visible Gaussians V (radii > 0), stats[1] = R (reference rule),
  * stats[2] = instances actually emitted after exact tile culling, stats[3] = R_eff
@@ -258,9 +269,10 @@ typedef struct gsr_refine_args {
      * from the 2nd iteration on, tile instances deeper than bound_margin_mul * z + bound_margin_add, z = the
      * depth the tile had to look at in the previous iteration, are not binned.  0 disables. */
     int speculative; float bound_margin_mul, bound_margin_add;     /* mul <= 0: adaptive, (1+m) z + m with m in [0.01, 0.05] */
-    int* stats_out;             /* nullable host int[4]: [0] number of redone forwards, [1] last num_rendered (set [1] = -1 before the
+    int* stats_out;             /* nullable host int[4]: [0] number of forwards that failed their verification, [1] last num_rendered (set [1] = -1 before the
                                  * call to skip that count when the last forward binned by tile: it costs a device->host copy),
-                                 * [2] forwards that ran k_preprocess_lean (the conservative-bound preprocess), [3] reserved (0) */
+                                 * [2] forwards that ran k_preprocess_lean (the conservative-bound preprocess), [3] how many of the
+                                 * [0] failed forwards the HOST redid with complete lists (the others were retried on the device) */
     /* Nullable HOST int, in/out: warm start of the speculation for frame sequences.  0 on input = the image workspace
      * holds no depth bounds (the first iteration bins with the global sorts).  Pass the value the previous call on the
      * SAME image workspace (same size) left here to start speculating from that frame's bounds at once -- consecutive

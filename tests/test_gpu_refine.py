@@ -204,6 +204,9 @@ def test_speculative_binning_is_exact_and_falls_back():
     assert runs["spec"][2]["fallbacks"] == 0
     assert runs["spec"][2]["num_rendered"] < 0.6 * inf_f["num_rendered"]      # lists really got shorter
     assert runs["tight"][2]["fallbacks"] > 0                                   # and the safety net really fires
+    # ... on the DEVICE: a failed group's successor retries with the bounds the failed forward recorded (LoopGuard tags); the host
+    # steps in (drain + complete lists) only when the retry fails too or a bin overflowed
+    assert runs["tight"][2]["host_redos"] < runs["tight"][2]["fallbacks"], runs["tight"][2]
 
 
 def test_concurrent_frames_on_one_gpu_match_sequential():
