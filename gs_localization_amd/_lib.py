@@ -124,6 +124,15 @@ def load():
             raise GsrError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64 / libhsa-runtime64.  If libgsr_hip.so is loaded
+        # FIRST it binds to the system's (/opt/rocm), torch then brings its own, and with two runtimes in the process the one
+        # initialised second sees no device (gsr_device_ok() == 0 although torch.cuda.is_available(); found in round 3 by running
+        # build() and smoke() in one process).  Loaded after torch, the library resolves against torch's runtime -- the one
+        # whose streams and device pointers it is handed anyway.
+        try:
+            import torch  # noqa: F401
+        except ImportError:          # (a Python caller without torch: the system runtime is the only one)
+            pass
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)

@@ -57,3 +57,11 @@ def test_split_driver_one_gpu_and_two_ranks():
     # the same frames whichever rank refined them: same medians up to the order of the fp32 atomics
     assert abs(two["median_trans_err_cm"] - one["median_trans_err_cm"]) < 0.05
     assert abs(two["median_rot_err_deg"] - one["median_rot_err_deg"]) < 0.02
+
+
+def test_build_then_smoke_in_one_process():
+    """`__graft_entry__.build()` loads the library, `smoke()` needs torch's HIP runtime AND the library's to be the same one: two
+    runtimes in a process leave the second without a device (round 3: `_lib.load()` imports torch first).  A fresh interpreter,
+    the order the driver may use."""
+    r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build(); g.smoke()"], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "smoke ok" in r.stdout, (r.stdout[-1500:], r.stderr[-3000:])
