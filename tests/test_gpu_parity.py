@@ -284,6 +284,29 @@ def test_other_baseline_configs_at_full_size(make):
     _check_grads(g, go, True, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
 
 
+def test_cambridge_script_image_size():
+    """BASELINE.json quotes config 3 at 852x480, but the reference's Cambridge script builds its cameras and masks at 1024x576
+    (gs_localization/pipelines/cambridge_localize_full.py:366): 64 x 36 = 2 304 tiles -- past the 2 048 up to which
+    complete lists go through k_preprocess_bin, so this is also the localisation-sized case of the count -> scan -> emit path.
+    S-3M-cam's distributions at 400 k Gaussians; forward and tracking-loss backward against the oracle, pose package."""
+    import os
+    from oracle import oracle as O
+    O.set_threads(min(64, os.cpu_count() or 1))
+    sc = S._draw("S-cam-1024", 400_000, 1024, 576, 744.0 * 1024 / 852, 744.0 * 1024 / 852, 2.0, 60.0, 0.05, 0.7, 3, 5)
+    o_gt, _ = U.hip_run(sc, U.scene_inputs(sc), pose=True)
+    cam = U.scene_inputs(sc, S.se3_exp([0.03, -0.02, 0.04, 0.006, -0.009, 0.007]))
+    o, _ = U.hip_run(sc, cam, pose=True)
+    grads = _tracking_grads(sc, o, o_gt)
+    O.set_accumulate_double(True)
+    try:
+        f, go = U.oracle_run(sc, cam, grads, pose=True)
+    finally:
+        O.set_accumulate_double(False)
+    o, g = U.hip_run(sc, cam, grads, pose=True)
+    _check_forward(o, f, True)
+    _check_grads(g, go, True, ["means3D", "means2D", "opacities", "sh", "scales", "rotations"])
+
+
 def test_training_config_package_a_at_size():
     """BASELINE.json config 4's shape (train.py through package (A)): 1296x840, SH degree 1, white background, 200 k
     Gaussians, gradients of an L1 image loss plus a depth and an opacity term (train.py:92-108 feeds all three)."""
