@@ -87,7 +87,7 @@ class RefineArgs(C.Structure):
 
 # the GSR_ABI_VERSION these ctypes mirrors (SpecState, RefineArgs, the pose-state layout) were written for
 ABI_VERSION = 2
-REFINE_NO_LEAN, REFINE_SH_SEPARATE, REFINE_NO_BALANCE, REFINE_LOG_REDO = 1, 2, 4, 8
+REFINE_NO_LEAN, REFINE_SH_SEPARATE, REFINE_NO_BALANCE, REFINE_LOG_REDO, REFINE_DETERMINISTIC = 1, 2, 4, 8, 16
 
 
 POSE_STATE_FLOATS = 96

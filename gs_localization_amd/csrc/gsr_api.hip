@@ -116,9 +116,9 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.clamped = c.take<uint8_t>(n);
     g.tiles_touched = c.take<uint32_t>(n);
     g.rects = c.take<ushort4>(n);
-    g.acc = c.take<float>(GSR_ACC_STRIDE * n);
+    g.acc = c.take<float>(2 * GSR_ACC_STRIDE * n);      // (twice the floats: the deterministic option keeps 64-bit fixed-point words here)
     g.dirty = c.take<uint8_t>(n);
-    g.tau_acc = c.take<double>(8 * GSR_TAU_SLOTS);
+    g.tau_acc = c.take<double>(16 * GSR_TAU_SLOTS);      // (second half: the deterministic option's world-frame sums 6 ... 11)
     g.rec = c.take<float>((n + 1) * GSR_REC_STRIDE);
     g.surv.cap = gsr::surv_cap(P);
     g.surv.n = c.take<uint32_t>((size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE);
@@ -238,6 +238,7 @@ struct PassCtx {
     bool sh_eager = false;         // diagnostics (debug bit 1 of gsr_forward): k_sh_color for every visible Gaussian instead of lazy colours
     bool exact_bins = false;       // complete lists through count -> scan -> emit (after a bin of k_preprocess_bin overflowed; diagnostics)
     bool* used_full_bins = nullptr;   // out: this forward binned its complete lists into fixed-capacity bins (k_preprocess_bin)
+    bool det = false;              // deterministic option (GSR_REFINE_DETERMINISTIC / debug bit 2 of the backward): integer sums across workgroups
 };
 // gsr_forward_speculative: bounds, flags, cursors and the unsorted bins live in the caller's persistent state buffer
 // instead of the per-call image / binning buffers (which then only hold what the backward reads)
@@ -842,8 +843,8 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     if (side) HIPCHK(hipEventRecord(side->join, side->st));
     if (!cx.native_loop) {      // accumulators of K7 (atomically summed)
         ProfScope psz(K_BWD_ZERO, st);
-        HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * sizeof(float), st));
-        if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, 8 * GSR_TAU_SLOTS * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * (cx.det ? sizeof(long long) : sizeof(float)), st));
+        if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, (cx.det ? 16 : 8) * GSR_TAU_SLOTS * sizeof(double), st));
     }
     {
         ProfScope psb(K_RENDER_BWD, st);
@@ -852,8 +853,8 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         const bool balanced = cx.balance && cx.native_loop && ntiles <= GSR_ORDER_MAX_TILES;
         const uint32_t* order = balanced ? im.tile_order[1] : nullptr;
         uint32_t* work = balanced ? im.tile_work[1] : nullptr;
-        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0);
-        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0);
+        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0);
+        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0);
 #undef GSR_BWD_ARGS
     }
     LAUNCHCHK("k_render_bwd");
@@ -875,14 +876,17 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     pb.guard = cx.guard;
     pb.ticket = cx.ticket; pb.fold = cx.fold;
     if (pb.ticket) pb.fold.tau_acc = g.tau_acc;
+    pb.fold.det = cx.det ? 1 : 0;
     {
         ProfScope ps(K_PREPROCESS_BWD, st);
         pb.surv = g.surv;
-        hipLaunchKernelGGL(k_preprocess_bwd, dim3(surv_grid(P, GSR_K8_RESIDENT)), dim3(64), 0, st, pb);
+        if (cx.det) hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(surv_grid(P, GSR_K8_RESIDENT)), dim3(64), 0, st, pb);
+        else hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(surv_grid(P, GSR_K8_RESIDENT)), dim3(64), 0, st, pb);
     }
     LAUNCHCHK("k_preprocess_bwd");
     if (pose_mode && !cx.native_loop) {
-        hipLaunchKernelGGL(k_tau_finish, dim3(1), dim3(64), 0, st, (const double*)g.tau_acc, dL_dtau);
+        if (cx.det) hipLaunchKernelGGL(k_tau_finish_det, dim3(1), dim3(64), 0, st, (const long long*)g.tau_acc, viewmatrix, dL_dtau);
+        else hipLaunchKernelGGL(k_tau_finish, dim3(1), dim3(64), 0, st, (const double*)g.tau_acc, dL_dtau);
         LAUNCHCHK("k_tau_finish");
     }
     return 0;
@@ -895,6 +899,7 @@ static PassCtx dropin_ctx(int& debug)
 {
     PassCtx cx;
     cx.sh_eager = (debug & 2) != 0;
+    cx.det = (debug & 4) != 0;
     debug &= 1;
     return cx;
 }
@@ -944,7 +949,7 @@ int gsr_forward_speculative(gsr_spec_state* s, GSR_FWD_PARAMS)
     return R;
 }
 
-int gsr_backward(GSR_BWD_PARAMS) { debug &= 1; return backward_impl(PassCtx{}, GSR_BWD_PASS); }
+int gsr_backward(GSR_BWD_PARAMS) { const PassCtx cx = dropin_ctx(debug); return backward_impl(cx, GSR_BWD_PASS); }
 
 int gsr_tracking_loss(int width, int height, const float* image, const float* depth, const float* opacity,
                       const float* gt_image, const float* gt_depth, const uint8_t* grad_mask, const float* exposure,
@@ -1080,6 +1085,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     cx.guard.poison = poison;
     cx.guard.conv = a->stop_on_converged ? ps + GSR_PS_CONV : nullptr;
     cx.flags = a->flags;
+    cx.det = (a->flags & GSR_REFINE_DETERMINISTIC) != 0;
     if (a->lean_min_P > 0) cx.lean_min_P = a->lean_min_P;
     int n_lean = 0;
     cx.n_lean = &n_lean;
@@ -1110,7 +1116,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             if (a->dL_dscale) HIPCHK(hipMemsetAsync(a->dL_dscale, 0, Pn * 3 * sizeof(float), st));
             if (a->dL_drot) HIPCHK(hipMemsetAsync(a->dL_drot, 0, Pn * 4 * sizeof(float), st));
             // K7's accumulator records: cleared once here, afterwards K8 clears every record it consumes
-            HIPCHK(hipMemsetAsync(gg.acc, 0, Pn * GSR_ACC_STRIDE * sizeof(float), st));
+            HIPCHK(hipMemsetAsync(gg.acc, 0, Pn * GSR_ACC_STRIDE * (cx.det ? sizeof(long long) : sizeof(float)), st));
             HIPCHK(hipMemsetAsync(gg.dirty, 0, Pn, st));
         }
         if (a->init_R) {
@@ -1130,7 +1136,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             int k = 0;
             auto add = [&](void* ptr, size_t words) { cr.p[k] = static_cast<uint32_t*>(ptr); cr.n[k] = (uint32_t)words; k++; };
             add(ps + GSR_PS_CONV, 5);                                                   // converged, loss, |tau|, poison, ticket
-            add(gg.tau_acc, 2 * 8 * GSR_TAU_SLOTS);                                     // (doubles) then kept clean by the pose step
+            add(gg.tau_acc, 2 * 16 * GSR_TAU_SLOTS);                                    // (doubles) then kept clean by the pose step
             add(gg.surv.n, (size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE);                  // ... and the work-list counters by the chain-rule kernel
             add(im0.fail, im0.clear_words);
             add(im0.loss_shards, GSR_LOSS_SHARDS * 16);
@@ -1149,6 +1155,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         cx.floss.exposure = ps + GSR_PS_PARAM + 6; cx.floss.opacity_thr = a->opacity_threshold; cx.floss.depth_w = a->depth_weight;
         cx.floss.monocular = a->monocular; cx.floss.dL_dimage = a->dL_dimage; cx.floss.dL_ddepth = a->dL_ddepth;
         cx.floss.out = im0.loss_shards; cx.floss.conv = a->stop_on_converged ? ps + GSR_PS_CONV : nullptr;
+        cx.floss.det = cx.det ? 1 : 0;
     }
     bool cov_cached = (carried & 2) != 0;      // the first forward stores every Gaussian's 3D covariance, the others (and, vouched for, later calls) reuse it
     const int debug = 0;

@@ -195,6 +195,37 @@ __device__ __forceinline__ double wave_sum_d_to_lane63(double v)
     return v;
 }
 
+// ---- deterministic accumulation (the `deterministic` option: gsr.h GSR_REFINE_DETERMINISTIC, debug bit 2 of the backward) ----
+// Floating-point atomics add in whatever order the workgroups arrive, and fp32 / fp64 addition is not associative: two runs of the same
+// backward differ in the last bits of every gradient that more than one tile contributes to.  In the deterministic mode everything
+// that is summed ACROSS workgroups -- the per-(tile, splat) gradient sums, the per-Gaussian terms of dL/dtau, the fused loss's partial
+// sums -- is converted to 64-bit fixed point first and added as integers: associative, so the result no longer depends on the order
+// (sums WITHIN a workgroup already run in a fixed order).  Resolution / range of a single addend: 2^-40 / +-2^23 (gradient sums),
+// 2^-32 / +-2^31 (pose terms), 2^-30 / +-2^33 (loss sums); an addend outside the range wraps (documented in INTEGRATION.md).
+#define GSR_FIX_ACC 1099511627776.0       // 2^40
+#define GSR_FIX_TAU 4294967296.0          // 2^32
+#define GSR_FIX_LOSS 1073741824.0         // 2^30
+__device__ __forceinline__ long long to_fixed(float v, double scale) { return __double2ll_rn((double)v * scale); }
+__device__ __forceinline__ double from_fixed(long long v, double scale) { return (double)v * (1.0 / scale); }
+// 64-bit integer total of all 64 lanes in lane 63 (other lanes: partial sums), DPP like wave_sum_d_to_lane63
+__device__ __forceinline__ long long wave_sum_ll_to_lane63(long long v)
+{
+#define GSR_DPP_ADD_LL(ctrl, rm)                                                                                         \
+    {                                                                                                                    \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(unsigned long long)v, ctrl, rm, 0xf, true); \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)((unsigned long long)v >> 32), ctrl, rm, 0xf, true); \
+        v += (long long)(((unsigned long long)hi_ << 32) | lo_);                                                         \
+    }
+    GSR_DPP_ADD_LL(0x111, 0xf)
+    GSR_DPP_ADD_LL(0x112, 0xf)
+    GSR_DPP_ADD_LL(0x114, 0xf)
+    GSR_DPP_ADD_LL(0x118, 0xf)
+    GSR_DPP_ADD_LL(0x142, 0xa)
+    GSR_DPP_ADD_LL(0x143, 0xc)
+#undef GSR_DPP_ADD_LL
+    return v;
+}
+
 // XCD-aware tile order: blocks b and b+8 share an XCD (and its L2), so give each XCD a contiguous
 // run of tiles; bijective for any n (cdna_hip_programming.md section 5, "XCD swizzle must be bijective").
 __device__ __forceinline__ int xcd_remap(int b, int n)

@@ -1459,6 +1459,7 @@ struct FusedLoss {
     float opacity_thr, depth_w; int monocular;
     float* dL_dimage; float* dL_ddepth; float* out;         // out: [GSR_LOSS_SHARDS][16] floats
     const float* conv;                                        // frozen after convergence, like k_tracking_loss
+    int det;                                                  // deterministic option: the shard's first three 64-bit words, fixed point
 };
 __device__ __forceinline__ float sgnf(float d) { return (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f); }
 
@@ -1968,7 +1969,11 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         __syncthreads();
         if (tid < 3) {
             const float t = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
-            if (t != 0.f) atomicAdd(&fl.out[(blockIdx.x & (GSR_LOSS_SHARDS - 1)) * 16 + tid], t);      // (fl.out: this group's buffer, see PoseStepArgs::loss_shards)
+            float* shard = fl.out + (blockIdx.x & (GSR_LOSS_SHARDS - 1)) * 16;      // (fl.out: this group's buffer, see PoseStepArgs::loss_shards)
+            if (t != 0.f) {
+                if (fl.det) atomicAdd(reinterpret_cast<unsigned long long*>(shard) + tid, (unsigned long long)to_fixed(t, GSR_FIX_LOSS));
+                else atomicAdd(&shard[tid], t);
+            }
         }
     }
     GSR_T_TICK(7)
@@ -2050,7 +2055,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                                                                const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
                                                                const float* __restrict__ dL_dalphas, float* __restrict__ acc,
                                                                LoopGuard guard, const uint32_t* __restrict__ tile_order,
-                                                               uint32_t* __restrict__ tile_work, const float* __restrict__ rec, int P, int pack_qm)
+                                                               uint32_t* __restrict__ tile_work, const float* __restrict__ rec, int P, int pack_qm, int det)
 {
     __shared__ BwdMfmaLDS s;
     const GSR_CONST_AS float* crec = (const GSR_CONST_AS float*)rec;      // (constant address space + wave-uniform offsets: s_load)
@@ -2289,7 +2294,11 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         for (int e = tid; e < taken * 10; e += GSR_BLOCK) {
             const int j = e / 10, q = e - j * 10;
             const float val = out[e];
-            if (val != 0.f && (POSE || q != 9)) atomicAdd(&acc[(size_t)s.ids[j] * GSR_ACC_STRIDE + q], val);
+            if (val != 0.f && (POSE || q != 9)) {
+                // (deterministic option: the record is GSR_ACC_STRIDE 64-bit fixed-point words, see gsr_device.h)
+                if (det) atomicAdd(reinterpret_cast<unsigned long long*>(acc) + (size_t)s.ids[j] * GSR_ACC_STRIDE + q, (unsigned long long)to_fixed(val, GSR_FIX_ACC));
+                else atomicAdd(&acc[(size_t)s.ids[j] * GSR_ACC_STRIDE + q], val);
+            }
         }
         GSR_T_TICK(8)
     }
@@ -2412,9 +2421,26 @@ __global__ void k_pose_load(float* st, const float* R0, const float* T0, const f
 // dL_dtau_out).  loss_shards (nullable): the native loop's fused-loss partial sums.  Whether or not the update runs (a failed
 // or frozen group only publishes its status), the loss shards and the superblock bounds the next forward accumulates into
 // (clear_b) are cleared here: the last workgroup of every group does it, so a failed forward leaves nothing behind.
+#define GSR_TAU_SLOTS 64      // partial sums of dL/dtau (k_preprocess_bwd), 64 B apart
+// dL/dtau from the twelve world-frame sums of the chain-rule kernel (k_preprocess_bwd, (6)): sw[0..2] the rho part, [3..5] sum g_geo,
+// [6..8] sum p x g_geo, [9..11] sum 2 a; Wc[r][c] = vm[4 c + r], trans = vm[12..14].
+__device__ __forceinline__ void tau_from_world_sums(const double* sw, const float* vm, double* tau)
+{
+    double wg[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) {
+        const double w0 = vm[r], w1 = vm[4 + r], w2 = vm[8 + r];          // row r of Wc
+        tau[r] = w0 * sw[0] + w1 * sw[1] + w2 * sw[2];
+        wg[r] = w0 * sw[3] + w1 * sw[4] + w2 * sw[5];
+        tau[3 + r] = w0 * (sw[6] + sw[9]) + w1 * (sw[7] + sw[10]) + w2 * (sw[8] + sw[11]);
+    }
+    const double t0 = vm[12], t1 = vm[13], t2 = vm[14];
+    tau[3] += t1 * wg[2] - t2 * wg[1]; tau[4] += t2 * wg[0] - t0 * wg[2]; tau[5] += t0 * wg[1] - t1 * wg[0];
+}
 struct PoseStepArgs {
     float* st; const float* dL_dtau; double* tau_acc; float* dL_dtau_out; const float* loss_out; const float* proj_raw;
     float lr, conv_thr; float* loss_zero; uint32_t* host_status; int seq; float* loss_shards; float* clear_b; int clear_n;
+    int det;        // deterministic option: tau_acc holds 12 fixed-point world-frame sums per slot, loss_shards fixed-point sums
 };
 struct alignas(16) PoseStepLDS { float st[GSR_PS_SIZE]; float t6[8]; float loss[4]; float proj[16]; };
 __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard guard, PoseStepLDS& s)
@@ -2426,17 +2452,28 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
     // (1) every global read first
     float va = 0.f, vb = 0.f, ls = 0.f, pj = 0.f, tq = 0.f;
     double tv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    long long tvi[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lsi = 0;
+    const bool det = q.det != 0;
     if (run) {
         va = st[lane];
         if (lane < GSR_PS_SIZE - 64) vb = st[64 + lane];
-        if (q.tau_acc != nullptr) {            // lane = slot: 64 partial sums per component (other workgroups of this launch added to them:
+        if (q.tau_acc != nullptr && det) {     // (deterministic option: the twelve world-frame sums of tau_pack, fixed point; second half behind the slots)
+            const long long* ta = reinterpret_cast<const long long*>(q.tau_acc);
+#pragma unroll
+            for (int i = 0; i < 12; i++)
+                tvi[i] = __hip_atomic_load(&ta[(i < 6 ? 0 : 8 * GSR_TAU_SLOTS) + lane * 8 + (i < 6 ? i : i - 6)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else if (q.tau_acc != nullptr) {     // lane = slot: 64 partial sums per component (other workgroups of this launch added to them:
 #pragma unroll                                 //  agent-scope atomic loads, past this CU's L1)
             for (int i = 0; i < 6; i++) tv[i] = __hip_atomic_load(&q.tau_acc[lane * 8 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else if (lane < 6) tq = q.dL_dtau[lane];
         if (lane < 16) pj = q.proj_raw[lane];
     }
     // fused loss: lane = shard * 4 + component
-    if (q.loss_shards != nullptr) {
+    if (q.loss_shards != nullptr && det) {
+        long long* sh = reinterpret_cast<long long*>(q.loss_shards + (lane >> 2) * 16) + (lane & 3);      // (component 3: unused, zero)
+        if (run) lsi = *sh;
+        *sh = 0;
+    } else if (q.loss_shards != nullptr) {
         const int at = (lane >> 2) * 16 + (lane & 3);
         if (run) ls = q.loss_shards[at];
         q.loss_shards[at] = 0.f;               // (also what a failed forward added)
@@ -2447,7 +2484,26 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
     if (run) {
         s.st[lane] = va;
         if (lane < GSR_PS_SIZE - 64) s.st[64 + lane] = vb;
-        if (q.tau_acc != nullptr) {
+        if (q.tau_acc != nullptr && det) {
+            double sw[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) sw[i] = from_fixed(wave_sum_ll_to_lane63(tvi[i]), GSR_FIX_TAU);
+            // the view matrix of this iteration sits in lanes 48 ... 63 of `va` (state words GSR_PS_VIEW ...)
+            float vmx[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) vmx[k] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(va), GSR_PS_VIEW + k));
+            if (lane == 63) {
+                double tau[6];
+                tau_from_world_sums(sw, vmx, tau);
+#pragma unroll
+                for (int i = 0; i < 6; i++) s.t6[i] = (float)tau[i];
+            }
+            if (q.loss_zero != nullptr) {
+                long long* ta = reinterpret_cast<long long*>(q.tau_acc);
+#pragma unroll
+                for (int i = 0; i < 6; i++) { ta[lane * 8 + i] = 0; ta[8 * GSR_TAU_SLOTS + lane * 8 + i] = 0; }
+            }
+        } else if (q.tau_acc != nullptr) {
 #pragma unroll
             for (int i = 0; i < 6; i++) {
                 const double t = wave_sum_d_to_lane63(tv[i]);
@@ -2458,7 +2514,11 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
                 for (int i = 0; i < 6; i++) q.tau_acc[lane * 8 + i] = 0.0;
             }
         } else if (lane < 6) s.t6[lane] = tq;
-        if (q.loss_shards != nullptr) {
+        if (q.loss_shards != nullptr && det) {
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1) lsi += __shfl_xor(lsi, off, 64);
+            ls = (float)from_fixed(lsi, GSR_FIX_LOSS);
+        } else if (q.loss_shards != nullptr) {
 #pragma unroll
             for (int off = 4; off < 64; off <<= 1) ls += __shfl_xor(ls, off, 64);
         }
@@ -2564,7 +2624,6 @@ __global__ void __launch_bounds__(64) k_pose_step(PoseStepArgs q, LoopGuard guar
 // preprocessCUDA, fused into one pass) + the SE(3) pose-gradient reduction of the pose package.
 // One lane per Gaussian; HBM-streaming.  Every output element is written exactly once.
 // ---------------------------------------------------------------------------------------------
-#define GSR_TAU_SLOTS 64
 struct PreBwdArgs {
     int P, D, M;
     const float* means; const int* radii; const float* shs; const uint8_t* clamped;
@@ -2728,6 +2787,32 @@ __device__ __forceinline__ void covariance_param_grads(const float* scale3, floa
 // ~4 % that had work.)
 #define GSR_K8_ROWS 64
 #define GSR_K8_RESIDENT (256 * 4 * 2)
+// K7's record of one Gaussian: twelve floats, or (DET, the deterministic option) twelve 64-bit fixed-point words
+template <bool DET>
+__device__ __forceinline__ void acc_load(const float* acc, size_t idx, float4& r0, float4& r1, float4& r2)
+{
+    if (DET) {
+        const longlong2* w = reinterpret_cast<const longlong2*>(reinterpret_cast<const long long*>(acc) + idx * GSR_ACC_STRIDE);
+        const longlong2 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
+#define GSR_FX(v) ((float)from_fixed(v, GSR_FIX_ACC))
+        r0 = make_float4(GSR_FX(w0.x), GSR_FX(w0.y), GSR_FX(w1.x), GSR_FX(w1.y));
+        r1 = make_float4(GSR_FX(w2.x), GSR_FX(w2.y), GSR_FX(w3.x), GSR_FX(w3.y));
+        r2 = make_float4(GSR_FX(w4.x), GSR_FX(w4.y), 0.f, 0.f);
+#undef GSR_FX
+    } else {
+        const float4* rec = reinterpret_cast<const float4*>(acc + idx * GSR_ACC_STRIDE);
+        r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
+    }
+}
+template <bool DET>
+__device__ __forceinline__ void acc_clear(float* acc, size_t idx)
+{
+    float4* rec = reinterpret_cast<float4*>(DET ? reinterpret_cast<float*>(reinterpret_cast<long long*>(acc) + idx * GSR_ACC_STRIDE) : acc + idx * GSR_ACC_STRIDE);
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < (DET ? 5 : 3); i++) rec[i] = z;
+}
+template <bool DET>
 __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
 {
     __shared__ float4 s_sh[GSR_K8_ROWS * GSR_SH16_LDS4];
@@ -2737,6 +2822,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     const bool frozen = a.guard.frozen();      // (a frozen iteration still takes its ticket: the last workgroup publishes the status)
     if (frozen && a.ticket == nullptr) return;
     float tw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // world-frame sums behind dL/dtau, see (6) below
+    long long twi[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... DET: in fixed point (which Gaussians share a lane depends on the lists' order)
     GSR_T_DECL
   if (!frozen) {
     // SH rows in (and dL_dsh rows out) as 16-B-per-lane streams of whole 192-B rows through LDS
@@ -2762,10 +2848,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             const int idx = in ? (int)(c0 == first_c0 ? first_entry : list[c0 + lane]) : 0;
             c0 += step;
             float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-            if (in) {
-                const float4* rec = reinterpret_cast<const float4*>(a.acc + (size_t)idx * GSR_ACC_STRIDE);
-                r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
-            }
+            if (in) acc_load<DET>(a.acc, (size_t)idx, r0, r1, r2);
             const bool active = in && (r0.x != 0.f || r0.y != 0.f || r0.z != 0.f || r0.w != 0.f || r1.x != 0.f || r1.y != 0.f ||
                                        r1.z != 0.f || r1.w != 0.f || r2.x != 0.f || r2.y != 0.f);
             // zero colour gradient => zero SH gradient whatever the coefficients are: their row is not even read
@@ -2801,11 +2884,8 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         const bool has_col = (qe >> 31) != 0u;
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         if (active) {
-            float4* rec = reinterpret_cast<float4*>(a.acc + (size_t)idx * GSR_ACC_STRIDE);
-            r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
-            if (a.dirty != nullptr) {      // native loop: leave the record clean for the next iteration's K7 (no 48 MB memset)
-                rec[0] = make_float4(0.f, 0.f, 0.f, 0.f); rec[1] = rec[0]; rec[2] = rec[0];
-            }
+            acc_load<DET>(a.acc, (size_t)idx, r0, r1, r2);
+            if (a.dirty != nullptr) acc_clear<DET>(a.acc, (size_t)idx);      // native loop: leave the record clean for the next iteration's K7 (no 48 MB memset)
         }
         const unsigned long long colmask = __ballot(has_col);
         // Every per-Gaussian read of the round is requested here, in FRONT of the SH rows, so that one round trip covers them all
@@ -2897,14 +2977,18 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             // Everything per Gaussian is kept in the WORLD frame -- p_C x (Wc g) = Wc (p x g) + trans x (Wc g) -- and the
             // rotation is applied once per wave to the sums (tw: rho part, g_geo, p x g_geo, a).
             if (a.pose) {
-                tw[0] += g_geo.x + g_sh.x; tw[1] += g_geo.y + g_sh.y; tw[2] += g_geo.z + g_sh.z;
-                tw[3] += g_geo.x; tw[4] += g_geo.y; tw[5] += g_geo.z;
-                tw[6] += mean.y * g_geo.z - mean.z * g_geo.y; tw[7] += mean.z * g_geo.x - mean.x * g_geo.z; tw[8] += mean.x * g_geo.y - mean.y * g_geo.x;
                 // P = Sigma G; X_ij = P_ij - P_ji
                 const float P01 = cov6[0] * G[1] + cov6[1] * G[3] + cov6[2] * G[4], P10 = cov6[1] * G[0] + cov6[3] * G[1] + cov6[4] * G[2];
                 const float P02 = cov6[0] * G[2] + cov6[1] * G[4] + cov6[2] * G[5], P20 = cov6[2] * G[0] + cov6[4] * G[1] + cov6[5] * G[2];
                 const float P12 = cov6[1] * G[2] + cov6[3] * G[4] + cov6[4] * G[5], P21 = cov6[2] * G[1] + cov6[4] * G[3] + cov6[5] * G[4];
-                tw[9] += 2.f * (P12 - P21); tw[10] += 2.f * (P20 - P02); tw[11] += 2.f * (P01 - P10);
+                const float term[12] = {g_geo.x + g_sh.x, g_geo.y + g_sh.y, g_geo.z + g_sh.z, g_geo.x, g_geo.y, g_geo.z,
+                                        mean.y * g_geo.z - mean.z * g_geo.y, mean.z * g_geo.x - mean.x * g_geo.z, mean.x * g_geo.y - mean.y * g_geo.x,
+                                        2.f * (P12 - P21), 2.f * (P20 - P02), 2.f * (P01 - P10)};
+#pragma unroll
+                for (int i = 0; i < 12; i++) {
+                    if (DET) twi[i] += to_fixed(term[i], GSR_FIX_TAU);
+                    else tw[i] += term[i];
+                }
             }
         }
         GSR_T_TICK(4)
@@ -2933,14 +3017,23 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         // (a wave that queued nothing -- seven in eight of them in a speculative iteration -- has nothing to add)
         bool any = false;
 #pragma unroll
-        for (int i = 0; i < 12; i++) any = any || (tw[i] != 0.f);
+        for (int i = 0; i < 12; i++) any = any || (DET ? twi[i] != 0 : tw[i] != 0.f);
         const bool wave_any = __ballot(any) != 0ull;          // (wave-uniform; evaluated by all lanes, outside the lane-63 branch below)
         double sw[12];
-        if (wave_any) {
+        if (DET && wave_any) {
+            // deterministic option: the twelve world-frame sums themselves leave the wave, as integers (the pose step rotates the totals)
+            unsigned long long* ta = reinterpret_cast<unsigned long long*>(a.tau_acc) + (blockIdx.x & (GSR_TAU_SLOTS - 1)) * 8;
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                const long long t = wave_sum_ll_to_lane63(twi[i]);
+                if (lane == 63 && t != 0) atomicAdd(&ta[(i < 6 ? 0 : 8 * GSR_TAU_SLOTS) + (i < 6 ? i : i - 6)], (unsigned long long)t);
+            }
+        }
+        if (!DET && wave_any) {
 #pragma unroll
             for (int i = 0; i < 12; i++) sw[i] = wave_sum_d_to_lane63((double)tw[i]);
         }
-        if (lane == 63 && wave_any) {
+        if (!DET && lane == 63 && wave_any) {
             const float* vm = a.view;
             double tau[6], wg[3];
 #pragma unroll
@@ -2997,6 +3090,22 @@ __device__ __forceinline__ double tau_total(const double* acc, int i)
 __global__ void k_tau_finish(const double* acc, float* out)
 {
     if (threadIdx.x < 6) out[threadIdx.x] = (float)tau_total(acc, threadIdx.x);
+}
+// deterministic option: the slots hold the twelve fixed-point world-frame sums (k_preprocess_bwd<true>); one wave, lane = slot
+__global__ void __launch_bounds__(64) k_tau_finish_det(const long long* acc, const float* view, float* out)
+{
+    const int lane = threadIdx.x;
+    double sw[12];
+#pragma unroll
+    for (int i = 0; i < 12; i++)
+        sw[i] = from_fixed(wave_sum_ll_to_lane63(acc[(i < 6 ? 0 : 8 * GSR_TAU_SLOTS) + lane * 8 + (i < 6 ? i : i - 6)]), GSR_FIX_TAU);
+    if (lane == 63) {
+        float vm[16];
+        for (int k = 0; k < 16; k++) vm[k] = view[k];
+        double tau[6];
+        tau_from_world_sums(sw, vm, tau);
+        for (int i = 0; i < 6; i++) out[i] = (float)tau[i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -144,13 +144,14 @@ class FusedRefiner:
 
     @staticmethod
     def _env_flags():
-        """GSR_NO_LEAN / GSR_SH_SEPARATE / GSR_NO_BALANCE / GSR_DEBUG_TILES of the environment -> gsr_refine_args.flags (the
-        library itself reads no environment variable on this path)."""
+        """GSR_NO_LEAN / GSR_SH_SEPARATE / GSR_NO_BALANCE / GSR_DEBUG_TILES / GSR_DETERMINISTIC of the environment ->
+        gsr_refine_args.flags (the library itself reads no environment variable on this path)."""
         import os
         from . import _lib
         env = os.environ
         return ((_lib.REFINE_NO_LEAN if "GSR_NO_LEAN" in env else 0) | (_lib.REFINE_SH_SEPARATE if "GSR_SH_SEPARATE" in env else 0) |
-                (_lib.REFINE_NO_BALANCE if "GSR_NO_BALANCE" in env else 0) | (_lib.REFINE_LOG_REDO if "GSR_DEBUG_TILES" in env else 0))
+                (_lib.REFINE_NO_BALANCE if "GSR_NO_BALANCE" in env else 0) | (_lib.REFINE_LOG_REDO if "GSR_DEBUG_TILES" in env else 0) |
+                (_lib.REFINE_DETERMINISTIC if "GSR_DETERMINISTIC" in env else 0))
 
     def refine(self, viewpoint, config, initial_R, initial_T, background, iters=50, lr=0.001, converged_threshold=1e-4,
                stop_on_converged=True, speculative=True, bound_margin=None, warm_start=None, count_instances=False,

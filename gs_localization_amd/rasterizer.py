@@ -278,7 +278,7 @@ def _backward_impl(rs, num_rendered, saved, consts, grad_color, grad_depth, grad
                               float(rs.tanfovx), float(rs.tanfovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
                               _ptr(imgBuffer), _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha), _ptr(dL_dmeans2D),
                               _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
-                              _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(rs.debug)),
+                              _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(rs.debug)) | (4 if "GSR_DETERMINISTIC" in os.environ else 0),
                               1 if pose_mode else 0, _ptr(dL_dtau), stream)
     _lib.check(rc)
     if dL_dsh is None and need["sh"]:

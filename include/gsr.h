@@ -60,6 +60,7 @@ typedef void* (*gsr_resize_fn)(void* ctx, size_t bytes);
  *   debug: bit 0 = the reference's debug flag (synchronise and check after every kernel, auxiliary.h:166-173);
  *       bit 1 (value 2) = diagnostics: SH colours of every visible Gaussian up front (k_sh_color) instead of lazily in the
  *       compositing kernel -- same results (tests/test_gpu_parity.py); the library reads no environment variable here.
+ *       gsr_backward only: bit 2 (value 4) = the deterministic option, see GSR_REFINE_DETERMINISTIC.
  * Returns num_rendered (the `int rendered` of rasterize_points.cu:82) or a negative error.
  * Performs one blocking device->host read of num_rendered, like rasterizer_impl.cu:282. */
 int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx,
@@ -307,6 +308,13 @@ typedef struct gsr_refine_args {
 #define GSR_REFINE_SH_SEPARATE 2u   /* k_preprocess_lean without the fused SH colour (k_sh_color behind it) */
 #define GSR_REFINE_NO_BALANCE  4u   /* compositing kernels in XCD order instead of the work-balanced tile order */
 #define GSR_REFINE_LOG_REDO    8u   /* one stderr line per redone (failed-speculation) forward */
+/* The deterministic option (the determinism the survey's section 5 asks for "for tests"; the reference's backward adds with float
+ * atomics, backward.cu:560-577, and is not reproducible either).  Every sum that crosses workgroups -- per-Gaussian gradient sums,
+ * the terms of dL/dtau, the fused loss -- is accumulated in 64-bit fixed point: two runs on the same inputs give the same bits, and
+ * so do the speculative, the plain and the GSR_REFINE_NO_LEAN loop among each other (tests/test_gpu_deterministic.py).  Results differ
+ * from the default mode's by rounding only.  A single per-(tile, Gaussian) gradient sum must stay below 2^23 in magnitude, a
+ * per-Gaussian pose term below 2^31, a per-tile loss sum below 2^33 (beyond that the integer wraps).  Costs ~3 % of an iteration. */
+#define GSR_REFINE_DETERMINISTIC 16u
 int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
 
 /* Differential check of k_preprocess_lean's conservative test (tests only; replaces nothing in the reference -- it guards the

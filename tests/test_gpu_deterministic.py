@@ -1,0 +1,131 @@
+"""-m gpu : the deterministic option (GSR_REFINE_DETERMINISTIC / debug bit 2 of gsr_backward; SURVEY.md section 5 asks for a determinism
+option "for tests").  Every sum that crosses workgroups is added in 64-bit fixed point, so
+
+  * two runs on the same inputs give the same BITS -- poses, loss, images, every gradient tensor;
+  * the loop's variants give the same bits AMONG EACH OTHER: speculative lists (k_preprocess_lean, depth-bounded bins, device-side
+    retries) against GSR_REFINE_NO_LEAN against complete lists in every iteration.  A list entry the speculation drops is one that no
+    pixel of its tile blends, so its contribution to every sum is exactly zero: with order-independent sums nothing may differ.  The
+    tolerance tests of test_gpu_lean.py / test_gpu_refine.py cannot see a discrepancy below the atomics' noise (1e-7 ... 1e-6 in
+    the pose); this one can;
+  * the results agree with the default mode's to rounding, and with the CPU oracle to the parity suite's tolerances.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from gs_localization_amd import _lib, scenes as S
+from tests import util as U
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+DET = _lib.REFINE_DETERMINISTIC
+GRADS = ("m2d", "conic", "opac", "col", "m3d", "cov", "sh", "scale", "rot", "tau")
+
+
+def _run(fr, vp, init, bg, iters, **kw):
+    from tests import replay as PL
+    kw.setdefault("warm_start", False)
+    R, T, info = fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=iters, stop_on_converged=False, **kw)
+    torch.cuda.synchronize()
+    out = dict(R=R.clone(), T=T.clone(), info=info, color=fr.color.clone(), depth=fr.depth.clone(), alpha=fr.alpha.clone(),
+               n_touched=fr.n_touched.clone(), radii=fr.radii.clone(), loss=fr.loss_out.clone())
+    for k in GRADS:
+        out["g_" + k] = getattr(fr, "g_" + k).clone()
+    return out
+
+
+def _bit_equal(a, b, name, skip=()):
+    bad = [k for k in a if k != "info" and k not in skip and not torch.equal(a[k], b[k])]
+    detail = {k: float((a[k].double() - b[k].double()).abs().max()) for k in bad}
+    assert not bad, (name, detail)
+
+
+def _loop_variants(sc, K, seed, lean_min_P=0):
+    from tests import replay as PL
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    init = PL.perturbed_start(seed, 0.02, 1.0, device=DEV)
+    view = lambda: PL.make_frame(sc, model, DEV, bg)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    kw = dict(lean_min_P=lean_min_P) if lean_min_P else {}
+    spec1 = _run(fr, view(), init, bg, K, flags=DET, **kw)
+    spec2 = _run(PL.FusedRefiner(model, sc.H, sc.W, device=DEV), view(), init, bg, K, flags=DET, **kw)      # fresh workspaces
+    nolean = _run(fr, view(), init, bg, K, flags=DET | _lib.REFINE_NO_LEAN, **kw)
+    plain = _run(fr, view(), init, bg, K, flags=DET, speculative=False, **kw)
+    default = _run(fr, view(), init, bg, K, flags=0, **kw)
+    return spec1, spec2, nolean, plain, default
+
+
+def _check_variants(spec1, spec2, nolean, plain, default, K):
+    assert spec1["info"]["lean_iters"] >= 1 and nolean["info"]["lean_iters"] == 0 and plain["info"]["lean_iters"] == 0, spec1["info"]
+    _bit_equal(spec1, spec2, "two deterministic runs")
+    _bit_equal(spec1, nolean, "speculative vs GSR_REFINE_NO_LEAN")
+    # (n_touched of the last forward counts on the lists it has: identical, the last forward of every variant keeps complete radii)
+    _bit_equal(spec1, plain, "speculative vs complete lists")
+    # against the default mode: same numbers up to the rounding of the sums
+    assert torch.allclose(spec1["R"], default["R"], atol=2e-6) and torch.allclose(spec1["T"], default["T"], atol=2e-6)
+    for k in ("m3d", "sh", "opac", "scale", "rot", "tau"):
+        a, b = spec1["g_" + k].cpu().numpy(), default["g_" + k].cpu().numpy()
+        assert U.rel_l1(a, b) <= 2e-4, (k, U.rel_l1(a, b))
+
+
+def test_loop_variants_agree_bit_for_bit_small_map():
+    sc = S.small(P=90000, W=176, H=144, sh_degree=3, seed=14, scale_med=0.035)
+    _check_variants(*_loop_variants(sc, 9, seed=6, lean_min_P=1), 9)
+
+
+def test_loop_variants_agree_bit_for_bit_at_the_headline_size():
+    """S-1M-640 (BASELINE.json configs[1]): 12 iterations, the product's own thresholds (the lean kernel runs: P >= 200 000)."""
+    _check_variants(*_loop_variants(S.s_1m_640(), 12, seed=3), 12)
+
+
+def test_half_empty_scene_with_a_large_start_offset():
+    """Half of the image dense, half sparse and faint (tiles without a depth bound), and a start 5 cm / 3 degrees off so that the view
+    moves under the speculation (bounds that go stale, retried forwards).  The deterministic loop with and without speculation ends in
+    the same bits."""
+    from tests import replay as PL
+    sc = S.small(P=60000, W=160, H=128, sh_degree=1, seed=14, scale_med=0.04)
+    right = sc.means3D[:, 0] > 0
+    keep = ~right | (np.arange(sc.P) % 40 == 0)
+    sc.means3D, sc.scales, sc.rotations, sc.opacities, sc.shs = (np.ascontiguousarray(x[keep]) for x in
+                                                                   (sc.means3D, sc.scales, sc.rotations, sc.opacities, sc.shs))
+    sc.opacities[sc.means3D[:, 0] > 0] *= 0.2
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    init = PL.perturbed_start(9, 0.05, 3.0, device=DEV)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    spec = _run(fr, PL.make_frame(sc, model, DEV, bg), init, bg, 20, flags=DET, lean_min_P=1)
+    plain = _run(fr, PL.make_frame(sc, model, DEV, bg), init, bg, 20, flags=DET, speculative=False)
+    print("speculative:", {k: spec["info"][k] for k in ("fallbacks", "lean_iters", "host_redos") if k in spec["info"]})
+    _bit_equal(spec, plain, "speculative vs complete lists, half-empty scene")
+
+
+def test_dropin_backward_is_reproducible(monkeypatch):
+    """The stateless packages: GSR_DETERMINISTIC=1 -> debug bit 2 of gsr_backward.  Two backward passes over the same forward give
+    the same bits; against the default mode: rounding (the default mode is the one the parity suite checks against the CPU oracle)."""
+    from tests import replay as PL
+    sc = S.small(P=20000, W=128, H=96, sh_degree=3, seed=3, scale_med=0.05)
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    init = PL.perturbed_start(2, 0.02, 1.0, device=DEV)
+
+    def grads():
+        vp = PL.make_frame(sc, model, DEV, bg)
+        vp.update_RT(init[:3, :3].clone(), init[:3, 3].clone())
+        for t in (model.get_xyz, model.get_features, model.get_opacity, model.get_scaling, model.get_rotation):
+            t.grad = None
+        pkg = PL.render(vp, model, bg)
+        PL.tracking_loss(PL.TRACKING_CONFIG, pkg["render"], pkg["depth"], pkg["opacity"], vp).backward()
+        torch.cuda.synchronize()
+        return dict(m3d=model.get_xyz.grad.clone(), sh=model.get_features.grad.clone(), opac=model.get_opacity.grad.clone(),
+                    scale=model.get_scaling.grad.clone(), rot=model.get_rotation.grad.clone(),
+                    tau=torch.cat([vp.cam_trans_delta.grad, vp.cam_rot_delta.grad]).clone())
+
+    default = grads()
+    monkeypatch.setenv("GSR_DETERMINISTIC", "1")
+    a, b = grads(), grads()
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+        assert U.rel_l1(a[k].cpu().numpy(), default[k].cpu().numpy()) <= 2e-5, (k, U.rel_l1(a[k].cpu().numpy(), default[k].cpu().numpy()))

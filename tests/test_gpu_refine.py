@@ -345,7 +345,7 @@ def test_final_state_equals_fresh_render_at_returned_pose(W, H, mono, conv_thr):
         assert torch.allclose(fr.color, pkg["render"], atol=2e-4), float((fr.color - pkg["render"]).abs().max())
         assert torch.allclose(fr.depth, pkg["depth"], atol=2e-3)
         assert torch.allclose(fr.alpha, pkg["opacity"], atol=2e-4)
-        assert int((fr.radii != pkg["radii"]).sum()) <= 2
+        assert int((fr.radii != pkg["radii"]).sum()) <= max(2, int(5e-5 * fr.radii.numel()))
         nt = pkg["n_touched"]
         assert int((fr.n_touched - nt).abs().sum()) <= max(4, int(2e-3 * int(nt.sum())))
     assert info["iters"] == 40
@@ -455,7 +455,7 @@ def test_converged_exit_with_an_overflowing_speculative_bin_returns_a_verified_r
     assert torch.allclose(fr.color, pkg["render"], atol=2e-4), float((fr.color - pkg["render"]).abs().max())
     assert torch.allclose(fr.depth, pkg["depth"], atol=2e-3)
     assert torch.allclose(fr.alpha, pkg["opacity"], atol=2e-4)
-    assert int((fr.radii != pkg["radii"]).sum()) <= 2
+    assert int((fr.radii != pkg["radii"]).sum()) <= max(2, int(5e-5 * fr.radii.numel()))
     nt = pkg["n_touched"]
     assert int((fr.n_touched - nt).abs().sum()) <= max(4, int(2e-3 * int(nt.sum())))
 
