@@ -313,7 +313,7 @@ typedef struct gsr_refine_args {
  * the terms of dL/dtau, the fused loss -- is accumulated in 64-bit fixed point: two runs on the same inputs give the same bits, and
  * so do the speculative, the plain and the GSR_REFINE_NO_LEAN loop among each other (tests/test_gpu_deterministic.py).  Results differ
  * from the default mode's by rounding only.  A single per-(tile, Gaussian) gradient sum must stay below 2^23 in magnitude, a
- * per-Gaussian pose term below 2^31, a per-tile loss sum below 2^33 (beyond that the integer wraps).  Costs ~3 % of an iteration. */
+ * per-Gaussian pose term below 2^31, a per-tile loss sum below 2^33 (beyond that the integer wraps).  Costs 0-3 % of a speculative iteration, 6 % with complete lists. */
 #define GSR_REFINE_DETERMINISTIC 16u
 int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
 
