@@ -1673,7 +1673,19 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     // segment of the exact bins; only a bin that overflowed its capacity fails the forward.
     const bool lazy = (LIST == GSR_LIST_EXACT) || (LIST == GSR_LIST_BINS && total > GSR_LSORT_CAP) || (LIST == GSR_LIST_BINS_FULL && total > GSR_SLICE_ALL);
     if (kBins && total > bin_cap) {          // block-uniform: entries were dropped; the host redoes the forward with complete lists
-        if (tid == 0) atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);
+        if (tid == 0) {
+            atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);
+            // The group enqueued behind this one bins with the bounds THIS forward records (it is the device-side retry): a tile
+            // that leaves without recording one would hand it whatever the buffer held before -- a stale per-tile bound next to
+            // superblock maxima this tile never contributed to, i.e. lists that are no longer depth-prefixes, from which a pixel can
+            // saturate on the wrong entries without failing its verification (found by the bit-for-bit fuzz of the deterministic
+            // option, round 3: poses 1e-4 off on scenes of 0.2 m splats).  No bound: the retry gets this tile's complete list (and,
+            // if that overflows its bin as well, fails in turn: the host then bins exactly).
+            if (zb_next != nullptr) {
+                zb_next[tile] = __builtin_huge_valf();
+                atomicMax(reinterpret_cast<int*>(zbc_next) + (ty >> 2) * sbx + (tx >> 2), __float_as_int(__builtin_huge_valf()));
+            }
+        }
         return;
     }
     if (kBins && !lazy) {

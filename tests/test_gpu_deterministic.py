@@ -102,6 +102,30 @@ def test_half_empty_scene_with_a_large_start_offset():
     _bit_equal(spec, plain, "speculative vs complete lists, half-empty scene")
 
 
+def test_overflowing_first_forward_does_not_hand_stale_bounds_to_its_retry():
+    """Found by tools/fuzz_speculation.py under the deterministic option (round 3).  Splats 0.2 m wide: every tile's complete list
+    overflows the fixed-capacity bins of the first forward, whose tiles then left the compositing kernel WITHOUT recording a depth
+    bound; the speculative group enqueued behind it (the device-side retry) binned with whatever the buffers held -- lists that
+    were not depth-prefixes -- passed its verification and moved the pose 1.4e-4 away from the plain loop's and the Python loop's.
+    The overflowing tile now records "no bound".  A previous call on the same workspace provides the stale bounds."""
+    from tests import replay as PL
+    sc = S.small(P=60000, W=150, H=185, sh_degree=3, seed=1026614153, scale_med=0.2)
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    init = torch.tensor(S.se3_exp(np.array([0.020133432009333933, -0.011872109397651393, 0.006790385897898772, 0.01091599154672567,
+                                            -0.019092896950391746, -0.002401738727523628])), dtype=torch.float32, device=DEV)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    for K in (1, 2, 4):
+        plain = _run(fr, PL.make_frame(sc, model, DEV, bg), init, bg, K, flags=DET, speculative=False)
+        spec = _run(fr, PL.make_frame(sc, model, DEV, bg), init, bg, K, flags=DET, lean_min_P=1)
+        assert plain["info"]["fallbacks"] >= 1, plain["info"]          # the scene really overflows the bins
+        _bit_equal(spec, plain, f"speculative vs complete lists, K = {K}")
+    vp = PL.make_frame(sc, model, DEV, bg)
+    Rp, Tp, _ = PL.python_loop(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), model, bg, iters=4)
+    assert torch.allclose(spec["R"], Rp, atol=2e-6) and torch.allclose(spec["T"], Tp, atol=2e-6), \
+        (float((spec["R"] - Rp).abs().max()), float((spec["T"] - Tp).abs().max()))
+
+
 def test_dropin_backward_is_reproducible(monkeypatch):
     """The stateless packages: GSR_DETERMINISTIC=1 -> debug bit 2 of gsr_backward.  Two backward passes over the same forward give
     the same bits; against the default mode: rounding (the default mode is the one the parity suite checks against the CPU oracle)."""
