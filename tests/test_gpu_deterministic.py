@@ -126,6 +126,39 @@ def test_overflowing_first_forward_does_not_hand_stale_bounds_to_its_retry():
         (float((spec["R"] - Rp).abs().max()), float((spec["T"] - Tp).abs().max()))
 
 
+def test_concurrent_frames_and_warm_starts_bit_for_bit():
+    """What bench.py and the split driver do -- several frames in flight on one GPU (one host thread and one stream each), every call
+    warm-started from the bounds the previous frame left in its workspace -- against the same frames refined one after the other from
+    cold starts: the same bits (the tolerance versions: test_gpu_refine.py)."""
+    import threading
+    from tests import replay as PL
+    sc = S.small(P=40000, W=160, H=128, sh_degree=2, seed=13, scale_med=0.04)
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    F, rounds = 3, 3
+    starts = [[torch.tensor(S.se3_exp(np.random.default_rng(90 + 10 * r + f).normal(size=6) * (0.01 if r < 2 else 0.15)), dtype=torch.float32, device=DEV)
+               for f in range(F)] for r in range(rounds)]                     # (the last round starts far off: stale bounds)
+    cold = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    want = [[_run(cold, PL.make_frame(sc, model, DEV, bg), starts[r][f], bg, 10, flags=DET, lean_min_P=1) for f in range(F)] for r in range(rounds)]
+    frs = [PL.FusedRefiner(model, sc.H, sc.W, device=DEV) for _ in range(F)]
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(F)]
+    vps = [[PL.make_frame(sc, model, DEV, bg) for f in range(F)] for r in range(rounds)]
+    got = [[None] * F for _ in range(rounds)]
+    torch.cuda.synchronize()
+
+    def work(f):
+        with torch.cuda.stream(streams[f]):
+            for r in range(rounds):
+                got[r][f] = _run(frs[f], vps[r][f], starts[r][f], bg, 10, flags=DET, lean_min_P=1, warm_start=(r > 0))
+    ts = [threading.Thread(target=work, args=(f,)) for f in range(F)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    torch.cuda.synchronize()
+    for r in range(rounds):
+        for f in range(F):
+            _bit_equal(got[r][f], want[r][f], f"round {r} frame {f}")
+
+
 def test_dropin_backward_is_reproducible(monkeypatch):
     """The stateless packages: GSR_DETERMINISTIC=1 -> debug bit 2 of gsr_backward.  Two backward passes over the same forward give
     the same bits; against the default mode: rounding (the default mode is the one the parity suite checks against the CPU oracle)."""
