@@ -1,6 +1,6 @@
 """Randomised check of the depth speculation: many small random scenes (sizes, densities, opacities, SH degrees, image
 shapes with partial tiles), each rendered (a) through the drop-in package at a sequence of nearby / far poses with and
-without gsr_forward_speculative -- images, radii and n_touched must be bit-identical -- and (b) through the native loop
+without gsr_forward_speculative -- images, radii, n_touched and (deterministic backward) every gradient must be bit-identical -- and (b) through the native loop
 with and without speculation under the deterministic option -- poses, images, radii, n_touched and all gradient tensors must be
 bit-identical.  Prints the number of cases, verified / missed guesses and redone forwards."""
 import sys, os, math
@@ -10,6 +10,7 @@ from gs_localization_amd import scenes as S, rasterizer as RZ
 from tests import replay as PL
 from tests import util as U
 dev = torch.device("cuda:0")
+os.environ["GSR_DETERMINISTIC"] = "1"      # drop-in backward: integer sums across workgroups (debug bit 2 of gsr_backward)
 N = int(os.environ.get("CASES", 120))
 rng = np.random.default_rng(int(os.environ.get("SEED", 1)))
 tot_v = tot_m = tot_fb = noisy = 0
@@ -36,18 +37,22 @@ for case in range(N):
         continue
     # (a) drop-in packages: a walk of poses, small steps with an occasional jump
     RZ._spec_cache.states.clear()
+    pix_grads = U.random_grads(sc, seed=case)
     tau = np.zeros(6)
     for step in range(6):
         tau = tau + walk[step]
         w2c = S.se3_exp(tau)
-        outs = []
+        outs, gouts = [], []
         for spec in ("1", "0"):
             os.environ["GSR_SPECULATION"] = spec
-            o, _ = U.hip_run(sc, U.scene_inputs(sc, w2c), None, pose=pose)
-            outs.append(o)
+            o, g = U.hip_run(sc, U.scene_inputs(sc, w2c), pix_grads, pose=pose)
+            outs.append(o); gouts.append(g)
         for k in ("color", "depth", "alpha", "radii") + (("n_touched",) if pose else ()):
             if not np.array_equal(outs[0][k], outs[1][k]):
                 print("MISMATCH", case, step, k, W, H, P, deg); sys.exit(1)
+        for k in gouts[0]:          # (GSR_DETERMINISTIC=1: the backward on speculative lists against the backward on complete lists, bit for bit)
+            if gouts[0][k] is not None and not np.array_equal(gouts[0][k], gouts[1][k]):
+                print("GRADIENT MISMATCH", case, step, k, W, H, P, deg, float(np.abs(gouts[0][k] - gouts[1][k]).max())); sys.exit(1)
     v, m = RZ.speculation_counters(); tot_v += v; tot_m += m
     os.environ["GSR_SPECULATION"] = "1"
     # (b) native loop
