@@ -81,6 +81,40 @@ def test_loop_variants_agree_bit_for_bit_at_the_headline_size():
     _check_variants(*_loop_variants(S.s_1m_640(), 12, seed=3), 12)
 
 
+def test_diagnostic_switches_and_pose_only_mode_change_no_bit():
+    """GSR_REFINE_NO_BALANCE (tile launch order), GSR_REFINE_SH_SEPARATE (k_sh_color behind the lean kernel instead of the fused
+    colour) and a refiner without Gaussian gradients (pose only) against the default configuration."""
+    from tests import replay as PL
+    sc = S.small(P=90000, W=176, H=144, sh_degree=3, seed=14, scale_med=0.035)
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    init = PL.perturbed_start(6, 0.02, 1.0, device=DEV)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    base = _run(fr, PL.make_frame(sc, model, DEV, bg), init, bg, 9, flags=DET, lean_min_P=1)
+    for name, fl in (("no balance", _lib.REFINE_NO_BALANCE), ("sh separate", _lib.REFINE_SH_SEPARATE)):
+        _bit_equal(_run(fr, PL.make_frame(sc, model, DEV, bg), init, bg, 9, flags=DET | fl, lean_min_P=1), base, name)
+    fr2 = PL.FusedRefiner(model, sc.H, sc.W, device=DEV, gaussian_grads=False)
+    R, T, info = fr2.refine(PL.make_frame(sc, model, DEV, bg), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=9,
+                            stop_on_converged=False, warm_start=False, lean_min_P=1, flags=DET)
+    torch.cuda.synchronize()
+    assert torch.equal(R, base["R"]) and torch.equal(T, base["T"]) and torch.equal(fr2.g_tau, base["g_tau"]) and torch.equal(fr2.color, base["color"])
+
+
+def test_image_with_more_tiles_than_the_fused_binning_kernel_takes():
+    """1296 x 840 (the training configuration's size): 4 293 tiles, complete lists through count -> scan -> emit instead of
+    k_preprocess_bin; speculative against complete lists."""
+    from tests import replay as PL
+    sc = S.small(P=200000, W=1296, H=840, sh_degree=1, seed=5, scale_med=0.02)
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    init = PL.perturbed_start(4, 0.02, 1.0, device=DEV)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    spec = _run(fr, PL.make_frame(sc, model, DEV, bg), init, bg, 8, flags=DET)
+    plain = _run(fr, PL.make_frame(sc, model, DEV, bg), init, bg, 8, flags=DET, speculative=False)
+    assert spec["info"]["lean_iters"] >= 1
+    _bit_equal(spec, plain, "speculative vs complete lists at 1296 x 840")
+
+
 def test_half_empty_scene_with_a_large_start_offset():
     """Half of the image dense, half sparse and faint (tiles without a depth bound), and a start 5 cm / 3 degrees off so that the view
     moves under the speculation (bounds that go stale, retried forwards).  The deterministic loop with and without speculation ends in
