@@ -12,13 +12,18 @@ from tests import util as U
 dev = torch.device("cuda:0")
 os.environ["GSR_DETERMINISTIC"] = "1"      # drop-in backward: integer sums across workgroups (debug bit 2 of gsr_backward)
 N = int(os.environ.get("CASES", 120))
+BIG = "BIG" in os.environ
 rng = np.random.default_rng(int(os.environ.get("SEED", 1)))
 tot_v = tot_m = tot_fb = noisy = 0
 for case in range(N):
-    W = int(rng.integers(40, 260)); H = int(rng.integers(40, 200))
-    P = int(rng.choice([200, 2000, 20000, 60000]))
+    if BIG:      # BIG=1: fewer, larger cases (the product's own lean threshold is reached; longer loops)
+        W = int(rng.integers(200, 700)); H = int(rng.integers(150, 500))
+        P = int(rng.choice([100000, 250000, 500000]))
+    else:
+        W = int(rng.integers(40, 260)); H = int(rng.integers(40, 200))
+        P = int(rng.choice([200, 2000, 20000, 60000]))
     deg = int(rng.integers(0, 4))
-    sc = S.small(P=P, W=W, H=H, sh_degree=deg, seed=int(rng.integers(1 << 30)), scale_med=float(rng.choice([0.01, 0.03, 0.08, 0.2])))
+    sc = S.small(P=P, W=W, H=H, sh_degree=deg, seed=int(rng.integers(1 << 30)), scale_med=float(rng.choice([0.005, 0.01, 0.03, 0.08] if BIG else [0.01, 0.03, 0.08, 0.2])))
     if rng.random() < 0.4:          # faint scene: many tiles never saturate
         sc.opacities *= np.float32(rng.choice([0.05, 0.3]))
     if rng.random() < 0.3:          # hole: drop the Gaussians of one image half
@@ -30,7 +35,7 @@ for case in range(N):
         continue
     # (every random number of the case is drawn here, so that ONLY=<case> replays exactly that case)
     walk = [rng.normal(size=6) * (0.003 if rng.random() < 0.8 else 0.2) for _ in range(6)]
-    K = int(rng.choice([6, 10, 25]))
+    K = int(rng.choice([6, 10, 25, 50] if BIG else [6, 10, 25]))
     far = rng.random() < 0.3           # a start far off: the view moves under the speculation, bounds go stale
     start = rng.normal(size=6) * (0.04 if far else 0.01)
     if "ONLY" in os.environ and case != int(os.environ["ONLY"]):
@@ -39,7 +44,7 @@ for case in range(N):
     RZ._spec_cache.states.clear()
     pix_grads = U.random_grads(sc, seed=case)
     tau = np.zeros(6)
-    for step in range(6):
+    for step in range(2 if BIG else 6):
         tau = tau + walk[step]
         w2c = S.se3_exp(tau)
         outs, gouts = [], []
