@@ -858,7 +858,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
 // A frozen (converged) iteration's forward is the render the caller gets back, radii included: then nobody is settled, the
 // flags are zeroed here, and the kernel computes exactly what k_preprocess would.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(GSR_BLOCK) k_preprocess_lean(PreArgs a)
+#ifndef GSR_LEAN_OCC
+#define GSR_LEAN_OCC 4      // waves per SIMD the register allocation aims at (experiments: -DGSR_LEAN_OCC=5 -> 93 VGPRs + 12 B of scratch)
+#endif
+__global__ void __launch_bounds__(GSR_BLOCK, GSR_LEAN_OCC) k_preprocess_lean(PreArgs a)
 {
     extern __shared__ float s_zbc[];      // a.zbc_lds floats: the superblock bounds
     __shared__ uint32_t s_cand[4][GSR_LEAN_PER_LANE * 64];
@@ -2455,6 +2458,7 @@ struct PoseStepArgs {
     int det;        // deterministic option: tau_acc holds 12 fixed-point world-frame sums per slot, loss_shards fixed-point sums
 };
 struct alignas(16) PoseStepLDS { float st[GSR_PS_SIZE]; float t6[8]; float loss[4]; float proj[16]; };
+template <bool DET>      // (compile time: the deterministic option's branches cost the default path's serial tail 2 k cycles as run-time tests)
 __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard guard, PoseStepLDS& s)
 {
     const bool run = !guard.frozen();          // wave-uniform
@@ -2465,7 +2469,7 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
     float va = 0.f, vb = 0.f, ls = 0.f, pj = 0.f, tq = 0.f;
     double tv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     long long tvi[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lsi = 0;
-    const bool det = q.det != 0;
+    constexpr bool det = DET;
     if (run) {
         va = st[lane];
         if (lane < GSR_PS_SIZE - 64) vb = st[64 + lane];
@@ -2628,7 +2632,7 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
 __global__ void __launch_bounds__(64) k_pose_step(PoseStepArgs q, LoopGuard guard)
 {
     __shared__ PoseStepLDS s;
-    if (blockIdx.x == 0) pose_step_wave(q, guard, s);
+    if (blockIdx.x == 0) pose_step_wave<false>(q, guard, s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -3086,7 +3090,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             if (lane == 0) *a.ticket = 0u;             // (the next launch starts counting from zero)
             reinterpret_cast<uint32_t*>(&a.tau_acc[lane * 8 + 6])[0] = 0u;      // the group counters too, also on a frozen iteration
             a.surv.n[lane * GSR_SURV_CSTRIDE] = 0u;    // every workgroup is past its work list: the next forward appends from zero
-            pose_step_wave(a.fold, a.guard, s_pose);
+            pose_step_wave<DET>(a.fold, a.guard, s_pose);
             GSR_T_TICK(8)
         }
     }
