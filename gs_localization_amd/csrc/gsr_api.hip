@@ -116,7 +116,7 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.clamped = c.take<uint8_t>(n);
     g.tiles_touched = c.take<uint32_t>(n);
     g.rects = c.take<ushort4>(n);
-    g.acc = c.take<float>(2 * GSR_ACC_STRIDE * n);      // (twice the floats: the deterministic option keeps 64-bit fixed-point words here)
+    g.acc = c.take<float>(4 * GSR_ACC_STRIDE * n);      // (four times the floats: the deterministic option keeps a pair of 64-bit fixed-point words per quantity)
     g.dirty = c.take<uint8_t>(n);
     g.tau_acc = c.take<double>(16 * GSR_TAU_SLOTS);      // (second half: the deterministic option's world-frame sums 6 ... 11)
     g.rec = c.take<float>((n + 1) * GSR_REC_STRIDE);
@@ -843,7 +843,7 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     if (side) HIPCHK(hipEventRecord(side->join, side->st));
     if (!cx.native_loop) {      // accumulators of K7 (atomically summed)
         ProfScope psz(K_BWD_ZERO, st);
-        HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * (cx.det ? sizeof(long long) : sizeof(float)), st));
+        HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * (cx.det ? 2 * sizeof(long long) : sizeof(float)), st));
         if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, (cx.det ? 16 : 8) * GSR_TAU_SLOTS * sizeof(double), st));
     }
     {
@@ -1116,7 +1116,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             if (a->dL_dscale) HIPCHK(hipMemsetAsync(a->dL_dscale, 0, Pn * 3 * sizeof(float), st));
             if (a->dL_drot) HIPCHK(hipMemsetAsync(a->dL_drot, 0, Pn * 4 * sizeof(float), st));
             // K7's accumulator records: cleared once here, afterwards K8 clears every record it consumes
-            HIPCHK(hipMemsetAsync(gg.acc, 0, Pn * GSR_ACC_STRIDE * (cx.det ? sizeof(long long) : sizeof(float)), st));
+            HIPCHK(hipMemsetAsync(gg.acc, 0, Pn * GSR_ACC_STRIDE * (cx.det ? 2 * sizeof(long long) : sizeof(float)), st));
             HIPCHK(hipMemsetAsync(gg.dirty, 0, Pn, st));
         }
         if (a->init_R) {

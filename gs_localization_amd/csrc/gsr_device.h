@@ -200,13 +200,22 @@ __device__ __forceinline__ double wave_sum_d_to_lane63(double v)
 // backward differ in the last bits of every gradient that more than one tile contributes to.  In the deterministic mode everything
 // that is summed ACROSS workgroups -- the per-(tile, splat) gradient sums, the per-Gaussian terms of dL/dtau, the fused loss's partial
 // sums -- is converted to 64-bit fixed point first and added as integers: associative, so the result no longer depends on the order
-// (sums WITHIN a workgroup already run in a fixed order).  Resolution / range of a single addend: 2^-40 / +-2^23 (gradient sums),
-// 2^-32 / +-2^31 (pose terms), 2^-30 / +-2^33 (loss sums); an addend outside the range wraps (documented in INTEGRATION.md).
-#define GSR_FIX_ACC 1099511627776.0       // 2^40
+// (sums WITHIN a workgroup already run in a fixed order).  The per-(tile, Gaussian) gradient sums span many orders of magnitude -- the
+// conic's moments of a splat hundreds of pixels wide under O(1) pixel gradients reach 1e10 per tile and cancel to 1e3 over the tiles,
+// under a mean loss they are 1e-6 -- so each takes TWO words: a coarse one (multiples of 2^-8, range +-2^55) and the remainder (2^-56);
+// neither sum can overflow, no carry passes between them, and their total is exact to 2^-57 per addend (fixed_split / fixed_join).
+// Pose terms: 2^-32 / +-2^31 per Gaussian; loss sums: 2^-30 / +-2^33 per tile (an addend outside the range wraps: INTEGRATION.md).
 #define GSR_FIX_TAU 4294967296.0          // 2^32
 #define GSR_FIX_LOSS 1073741824.0         // 2^30
 __device__ __forceinline__ long long to_fixed(float v, double scale) { return __double2ll_rn((double)v * scale); }
 __device__ __forceinline__ double from_fixed(long long v, double scale) { return (double)v * (1.0 / scale); }
+__device__ __forceinline__ void fixed_split(float v, long long& hi, long long& lo)
+{
+    const double d = (double)v;
+    hi = __double2ll_rn(d * 256.0);
+    lo = __double2ll_rn((d - (double)hi * (1.0 / 256.0)) * 72057594037927936.0);      // (the remainder, at most 2^-9 in magnitude, in units of 2^-56)
+}
+__device__ __forceinline__ double fixed_join(long long hi, long long lo) { return (double)hi * (1.0 / 256.0) + (double)lo * (1.0 / 72057594037927936.0); }
 // 64-bit integer total of all 64 lanes in lane 63 (other lanes: partial sums), DPP like wave_sum_d_to_lane63
 __device__ __forceinline__ long long wave_sum_ll_to_lane63(long long v)
 {

@@ -2310,9 +2310,14 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             const int j = e / 10, q = e - j * 10;
             const float val = out[e];
             if (val != 0.f && (POSE || q != 9)) {
-                // (deterministic option: the record is GSR_ACC_STRIDE 64-bit fixed-point words, see gsr_device.h)
-                if (det) atomicAdd(reinterpret_cast<unsigned long long*>(acc) + (size_t)s.ids[j] * GSR_ACC_STRIDE + q, (unsigned long long)to_fixed(val, GSR_FIX_ACC));
-                else atomicAdd(&acc[(size_t)s.ids[j] * GSR_ACC_STRIDE + q], val);
+                // (deterministic option: the record is GSR_ACC_STRIDE pairs of 64-bit fixed-point words, see gsr_device.h)
+                if (det) {
+                    long long hi, lo;
+                    fixed_split(val, hi, lo);
+                    unsigned long long* w = reinterpret_cast<unsigned long long*>(acc) + ((size_t)s.ids[j] * GSR_ACC_STRIDE + q) * 2;
+                    if (hi != 0) atomicAdd(w, (unsigned long long)hi);
+                    if (lo != 0) atomicAdd(w + 1, (unsigned long long)lo);
+                } else atomicAdd(&acc[(size_t)s.ids[j] * GSR_ACC_STRIDE + q], val);
             }
         }
         GSR_T_TICK(8)
@@ -2803,18 +2808,18 @@ __device__ __forceinline__ void covariance_param_grads(const float* scale3, floa
 // ~4 % that had work.)
 #define GSR_K8_ROWS 64
 #define GSR_K8_RESIDENT (256 * 4 * 2)
-// K7's record of one Gaussian: twelve floats, or (DET, the deterministic option) twelve 64-bit fixed-point words
+// K7's record of one Gaussian: twelve floats, or (DET, the deterministic option) twelve (coarse, fine) pairs of 64-bit fixed-point words
 template <bool DET>
 __device__ __forceinline__ void acc_load(const float* acc, size_t idx, float4& r0, float4& r1, float4& r2)
 {
     if (DET) {
-        const longlong2* w = reinterpret_cast<const longlong2*>(reinterpret_cast<const long long*>(acc) + idx * GSR_ACC_STRIDE);
-        const longlong2 w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4];
-#define GSR_FX(v) ((float)from_fixed(v, GSR_FIX_ACC))
-        r0 = make_float4(GSR_FX(w0.x), GSR_FX(w0.y), GSR_FX(w1.x), GSR_FX(w1.y));
-        r1 = make_float4(GSR_FX(w2.x), GSR_FX(w2.y), GSR_FX(w3.x), GSR_FX(w3.y));
-        r2 = make_float4(GSR_FX(w4.x), GSR_FX(w4.y), 0.f, 0.f);
-#undef GSR_FX
+        const longlong2* w = reinterpret_cast<const longlong2*>(acc) + idx * GSR_ACC_STRIDE;      // one (hi, lo) pair per quantity
+        float q[10];
+#pragma unroll
+        for (int i = 0; i < 10; i++) { const longlong2 p = w[i]; q[i] = (float)fixed_join(p.x, p.y); }
+        r0 = make_float4(q[0], q[1], q[2], q[3]);
+        r1 = make_float4(q[4], q[5], q[6], q[7]);
+        r2 = make_float4(q[8], q[9], 0.f, 0.f);
     } else {
         const float4* rec = reinterpret_cast<const float4*>(acc + idx * GSR_ACC_STRIDE);
         r0 = rec[0]; r1 = rec[1]; r2 = rec[2];
@@ -2823,10 +2828,10 @@ __device__ __forceinline__ void acc_load(const float* acc, size_t idx, float4& r
 template <bool DET>
 __device__ __forceinline__ void acc_clear(float* acc, size_t idx)
 {
-    float4* rec = reinterpret_cast<float4*>(DET ? reinterpret_cast<float*>(reinterpret_cast<long long*>(acc) + idx * GSR_ACC_STRIDE) : acc + idx * GSR_ACC_STRIDE);
+    float4* rec = DET ? reinterpret_cast<float4*>(acc) + idx * GSR_ACC_STRIDE : reinterpret_cast<float4*>(acc + idx * GSR_ACC_STRIDE);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < (DET ? 5 : 3); i++) rec[i] = z;
+    for (int i = 0; i < (DET ? 10 : 3); i++) rec[i] = z;
 }
 template <bool DET>
 __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)

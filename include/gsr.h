@@ -312,8 +312,10 @@ typedef struct gsr_refine_args {
  * atomics, backward.cu:560-577, and is not reproducible either).  Every sum that crosses workgroups -- per-Gaussian gradient sums,
  * the terms of dL/dtau, the fused loss -- is accumulated in 64-bit fixed point: two runs on the same inputs give the same bits, and
  * so do the speculative, the plain and the GSR_REFINE_NO_LEAN loop among each other (tests/test_gpu_deterministic.py).  Results differ
- * from the default mode's by rounding only.  A single per-(tile, Gaussian) gradient sum must stay below 2^23 in magnitude, a
- * per-Gaussian pose term below 2^31, a per-tile loss sum below 2^33 (beyond that the integer wraps).  Costs 0-3 % of a speculative iteration, 6 % with complete lists. */
+ * from the default mode's by rounding only.  Per-(tile, Gaussian) gradient sums are kept as a coarse word (2^-8, +-2^55) plus a
+ * remainder word (2^-56): no practical range limit; a per-Gaussian pose term must stay below 2^31 in magnitude, a per-tile loss sum
+ * below 2^33 (beyond that the integer wraps).  Costs 2-4 % of a speculative iteration, 15 % with complete lists; the geometry buffer
+ * reserves 192 B per Gaussian for the accumulator records in either mode. */
 #define GSR_REFINE_DETERMINISTIC 16u
 int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
 

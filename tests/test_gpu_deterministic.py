@@ -220,3 +220,21 @@ def test_dropin_backward_is_reproducible(monkeypatch):
     for k in a:
         assert torch.equal(a[k], b[k]), k
         assert U.rel_l1(a[k].cpu().numpy(), default[k].cpu().numpy()) <= 2e-5, (k, U.rel_l1(a[k].cpu().numpy(), default[k].cpu().numpy()))
+
+
+def test_deterministic_sums_have_the_range_for_large_splats_under_unit_pixel_gradients(monkeypatch):
+    """Splats hundreds of pixels wide under white-noise pixel gradients of unit variance: the conic's per-tile moment sums reach 1e8 ...
+    1e10 and cancel over the tiles (test_gpu_parity.py::test_large_images).  The first version of the option kept one 2^-40 word per
+    sum and wrapped here; the (coarse, remainder) pair does not: same gradients as the default mode to the order noise of ITS float
+    atomics, and bit-reproducible."""
+    sc = S.small(P=3000, W=1280, H=720, sh_degree=1, seed=31, scale_med=0.03)
+    cam = U.scene_inputs(sc, np.eye(4))
+    grads = U.random_grads(sc, seed=1)
+    _, g0 = U.hip_run(sc, cam, grads, pose=True)
+    monkeypatch.setenv("GSR_DETERMINISTIC", "1")
+    _, g1 = U.hip_run(sc, cam, grads, pose=True)
+    _, g2 = U.hip_run(sc, cam, grads, pose=True)
+    assert float(np.abs(g1["means2D"]).max()) > 50.0          # (the regime: sums far beyond what a mean loss produces)
+    for k in ("means3D", "means2D", "opacities", "sh", "scales", "rotations", "tau"):
+        assert np.array_equal(g1[k], g2[k]), k
+        assert U.rel_l1(g1[k], g0[k]) <= 1e-4, (k, U.rel_l1(g1[k], g0[k]))

@@ -35,7 +35,7 @@ def test_workspace_sizes():
     from gs_localization_amd import _lib
     lib = _lib.load()
     g1, g2 = lib.gsr_geometry_bytes(1000), lib.gsr_geometry_bytes(1_000_000)
-    assert 0 < g1 < g2 and g2 < 260 * 1_000_000      # (202 B per Gaussian: 96 of them the accumulator records, sized for the deterministic option)
+    assert 0 < g1 < g2 and g2 < 320 * 1_000_000      # (298 B per Gaussian: 192 of them the accumulator records, sized for the deterministic option)
     assert lib.gsr_image_bytes(640, 480) >= 640 * 480 * 4 + 1200 * 8
     assert lib.gsr_binning_bytes(1_000_000) >= 12 * 1_000_000
 
