@@ -211,6 +211,10 @@ class FusedRefiner:
         stats = self._stats
         stats[0], stats[1], stats[2], stats[3] = 0, (0 if count_instances else -1), 0, 0
         a.stream = stream
+        # a fresh pose state per call (k_pose_load fills all of it): the pose handed back below is a VIEW of it, not a copy -- three
+        # tiny torch kernels per call, each behind a host-side launch gap with the GPU idle (0.1 ms of a 3 ms call)
+        self.state = torch.empty(_lib.POSE_STATE_FLOATS, dtype=torch.float32, device=dev)
+        a.pose_state = self.state.data_ptr()
         a.flags = self._env_flags() if flags is None else int(flags)
         a.lean_min_P = int(lean_min_P)
         n_done, conv = C.c_int(0), C.c_int(0)
@@ -222,13 +226,13 @@ class FusedRefiner:
         self._last_args = a                                          # (gsr_debug_lean_check takes the same struct)
         self._keep = (R0, T0, ea0, eb0, proj_raw, gt_image, gt_depth, mask, bg)        # alive until the stream has drained
         # the final pose came back with the call (gsr_refine_args.pose_state_host): no second blocking read.  The camera gets
-        # device tensors cut out of ONE copy of the state (asynchronous; host -> device uploads would each stall)
+        # device tensors that are views of this call's state (no copy, no launch; host -> device uploads would each stall)
         s = self._state_host_t
         with torch.no_grad():
-            st = self.state[0:20].clone()
+            st = self.state
             viewpoint.update_RT(st[0:9].view(3, 3), st[9:12])
-            viewpoint.exposure_a.copy_(st[18:19].view(viewpoint.exposure_a.shape))
-            viewpoint.exposure_b.copy_(st[19:20].view(viewpoint.exposure_b.shape))
+            viewpoint.exposure_a.data = st[18:19].view(viewpoint.exposure_a.shape)
+            viewpoint.exposure_b.data = st[19:20].view(viewpoint.exposure_b.shape)
         self.last_info = {"fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]), "host_redos": int(stats[3])}
         return viewpoint.R, viewpoint.T, {"iters": n_done.value, "converged": bool(conv.value), "loss": float(s[38]),
                                           "fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]), "host_redos": int(stats[3]),
