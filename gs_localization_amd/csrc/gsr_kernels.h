@@ -2315,8 +2315,13 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                     long long hi, lo;
                     fixed_split(val, hi, lo);
                     unsigned long long* w = reinterpret_cast<unsigned long long*>(acc) + ((size_t)s.ids[j] * GSR_ACC_STRIDE + q) * 2;
-                    if (hi != 0) atomicAdd(w, (unsigned long long)hi);
-                    if (lo != 0) atomicAdd(w + 1, (unsigned long long)lo);
+                    // (an integer cannot carry a NaN or an infinity: pair 10 of the record counts the non-finite addends, and a
+                    // Gaussian that received one gets NaN gradients, as it would from the float atomics)
+                    if (!__builtin_isfinite(val)) atomicAdd(reinterpret_cast<unsigned long long*>(acc) + ((size_t)s.ids[j] * GSR_ACC_STRIDE + 10) * 2, 1ull);
+                    else {
+                        if (hi != 0) atomicAdd(w, (unsigned long long)hi);
+                        if (lo != 0) atomicAdd(w + 1, (unsigned long long)lo);
+                    }
                 } else atomicAdd(&acc[(size_t)s.ids[j] * GSR_ACC_STRIDE + q], val);
             }
         }
@@ -2817,6 +2822,10 @@ __device__ __forceinline__ void acc_load(const float* acc, size_t idx, float4& r
         float q[10];
 #pragma unroll
         for (int i = 0; i < 10; i++) { const longlong2 p = w[i]; q[i] = (float)fixed_join(p.x, p.y); }
+        if (w[10].x != 0) {          // a non-finite addend arrived (see the flush of k_render_bwd_mfma)
+#pragma unroll
+            for (int i = 0; i < 10; i++) q[i] = __builtin_nanf("");
+        }
         r0 = make_float4(q[0], q[1], q[2], q[3]);
         r1 = make_float4(q[4], q[5], q[6], q[7]);
         r2 = make_float4(q[8], q[9], 0.f, 0.f);
@@ -2831,7 +2840,7 @@ __device__ __forceinline__ void acc_clear(float* acc, size_t idx)
     float4* rec = DET ? reinterpret_cast<float4*>(acc) + idx * GSR_ACC_STRIDE : reinterpret_cast<float4*>(acc + idx * GSR_ACC_STRIDE);
     const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int i = 0; i < (DET ? 10 : 3); i++) rec[i] = z;
+    for (int i = 0; i < (DET ? 11 : 3); i++) rec[i] = z;
 }
 template <bool DET>
 __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)

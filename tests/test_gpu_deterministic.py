@@ -238,3 +238,20 @@ def test_deterministic_sums_have_the_range_for_large_splats_under_unit_pixel_gra
     for k in ("means3D", "means2D", "opacities", "sh", "scales", "rotations", "tau"):
         assert np.array_equal(g1[k], g2[k]), k
         assert U.rel_l1(g1[k], g0[k]) <= 1e-4, (k, U.rel_l1(g1[k], g0[k]))
+
+
+def test_non_finite_gradients_are_not_swallowed(monkeypatch):
+    """An integer sum cannot hold a NaN: the deterministic backward counts non-finite addends per Gaussian and hands such a Gaussian
+    NaN gradients -- the same Gaussians the float atomics of the default mode poison."""
+    sc = S.small(P=5000, W=96, H=64, sh_degree=1, seed=7, scale_med=0.05)
+    cam = U.scene_inputs(sc, np.eye(4))
+    gc, gd, ga = U.random_grads(sc, seed=2)
+    gc[1, 30, 40] = np.nan
+    gd[0, 10, 70] = np.inf
+    _, g0 = U.hip_run(sc, cam, (gc, gd, ga), pose=True)
+    monkeypatch.setenv("GSR_DETERMINISTIC", "1")
+    _, g1 = U.hip_run(sc, cam, (gc, gd, ga), pose=True)
+    bad0, bad1 = ~np.isfinite(g0["means3D"]).all(axis=1), ~np.isfinite(g1["means3D"]).all(axis=1)
+    assert bad0.sum() > 0 and np.array_equal(bad0, bad1), (int(bad0.sum()), int(bad1.sum()))
+    ok = ~bad0
+    assert U.rel_l1(g1["means3D"][ok], g0["means3D"][ok]) <= 1e-4
