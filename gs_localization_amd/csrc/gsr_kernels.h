@@ -1986,7 +1986,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             const float t = s_red[0][tid] + s_red[1][tid] + s_red[2][tid] + s_red[3][tid];
             float* shard = fl.out + (blockIdx.x & (GSR_LOSS_SHARDS - 1)) * 16;      // (fl.out: this group's buffer, see PoseStepArgs::loss_shards)
             if (t != 0.f) {
-                if (fl.det) atomicAdd(reinterpret_cast<unsigned long long*>(shard) + tid, (unsigned long long)to_fixed(t, GSR_FIX_LOSS));
+                // (deterministic option; word 3 of the shard counts non-finite sums: the pose step then reports NaN, as float sums would)
+                if (fl.det) atomicAdd(reinterpret_cast<unsigned long long*>(shard) + (__builtin_isfinite(t) ? tid : 3),
+                                      __builtin_isfinite(t) ? (unsigned long long)to_fixed(t, GSR_FIX_LOSS) : 1ull);
                 else atomicAdd(&shard[tid], t);
             }
         }
@@ -2478,7 +2480,7 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
     // (1) every global read first
     float va = 0.f, vb = 0.f, ls = 0.f, pj = 0.f, tq = 0.f;
     double tv[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-    long long tvi[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, lsi = 0;
+    long long tvi[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tvn = 0, lsi = 0;
     constexpr bool det = DET;
     if (run) {
         va = st[lane];
@@ -2488,6 +2490,7 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
 #pragma unroll
             for (int i = 0; i < 12; i++)
                 tvi[i] = __hip_atomic_load(&ta[(i < 6 ? 0 : 8 * GSR_TAU_SLOTS) + lane * 8 + (i < 6 ? i : i - 6)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tvn = __hip_atomic_load(&ta[lane * 8 + 7], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // (Gaussians whose terms were not finite)
         } else if (q.tau_acc != nullptr) {     // lane = slot: 64 partial sums per component (other workgroups of this launch added to them:
 #pragma unroll                                 //  agent-scope atomic loads, past this CU's L1)
             for (int i = 0; i < 6; i++) tv[i] = __hip_atomic_load(&q.tau_acc[lane * 8 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2518,16 +2521,18 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
             float vmx[16];
 #pragma unroll
             for (int k = 0; k < 16; k++) vmx[k] = __uint_as_float((uint32_t)__builtin_amdgcn_readlane((int)__float_as_uint(va), GSR_PS_VIEW + k));
+            const long long nonfinite = wave_sum_ll_to_lane63(tvn);
             if (lane == 63) {
                 double tau[6];
                 tau_from_world_sums(sw, vmx, tau);
 #pragma unroll
-                for (int i = 0; i < 6; i++) s.t6[i] = (float)tau[i];
+                for (int i = 0; i < 6; i++) s.t6[i] = (nonfinite != 0) ? __builtin_nanf("") : (float)tau[i];
             }
             if (q.loss_zero != nullptr) {
                 long long* ta = reinterpret_cast<long long*>(q.tau_acc);
 #pragma unroll
                 for (int i = 0; i < 6; i++) { ta[lane * 8 + i] = 0; ta[8 * GSR_TAU_SLOTS + lane * 8 + i] = 0; }
+                ta[lane * 8 + 7] = 0;
             }
         } else if (q.tau_acc != nullptr) {
 #pragma unroll
@@ -2543,7 +2548,7 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
         if (q.loss_shards != nullptr && det) {
 #pragma unroll
             for (int off = 4; off < 64; off <<= 1) lsi += __shfl_xor(lsi, off, 64);
-            ls = (float)from_fixed(lsi, GSR_FIX_LOSS);
+            ls = (__shfl(lsi, 3, 64) != 0) ? __builtin_nanf("") : (float)from_fixed(lsi, GSR_FIX_LOSS);      // (component 3: non-finite tile sums seen)
         } else if (q.loss_shards != nullptr) {
 #pragma unroll
             for (int off = 4; off < 64; off <<= 1) ls += __shfl_xor(ls, off, 64);
@@ -2853,6 +2858,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     if (frozen && a.ticket == nullptr) return;
     float tw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // world-frame sums behind dL/dtau, see (6) below
     long long twi[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... DET: in fixed point (which Gaussians share a lane depends on the lists' order)
+    long long twn = 0;                                         // ... and how many terms were not finite (word 7 of the slot: the pose step reports NaN)
     GSR_T_DECL
   if (!frozen) {
     // SH rows in (and dL_dsh rows out) as 16-B-per-lane streams of whole 192-B rows through LDS
@@ -3016,7 +3022,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
                                         2.f * (P12 - P21), 2.f * (P20 - P02), 2.f * (P01 - P10)};
 #pragma unroll
                 for (int i = 0; i < 12; i++) {
-                    if (DET) twi[i] += to_fixed(term[i], GSR_FIX_TAU);
+                    if (DET) { if (__builtin_isfinite(term[i])) twi[i] += to_fixed(term[i], GSR_FIX_TAU); else twn++; }
                     else tw[i] += term[i];
                 }
             }
@@ -3048,6 +3054,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         bool any = false;
 #pragma unroll
         for (int i = 0; i < 12; i++) any = any || (DET ? twi[i] != 0 : tw[i] != 0.f);
+        if (DET) any = any || (twn != 0);
         const bool wave_any = __ballot(any) != 0ull;          // (wave-uniform; evaluated by all lanes, outside the lane-63 branch below)
         double sw[12];
         if (DET && wave_any) {
@@ -3058,6 +3065,8 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
                 const long long t = wave_sum_ll_to_lane63(twi[i]);
                 if (lane == 63 && t != 0) atomicAdd(&ta[(i < 6 ? 0 : 8 * GSR_TAU_SLOTS) + (i < 6 ? i : i - 6)], (unsigned long long)t);
             }
+            const long long tn = wave_sum_ll_to_lane63(twn);
+            if (lane == 63 && tn != 0) atomicAdd(&ta[7], (unsigned long long)tn);
         }
         if (!DET && wave_any) {
 #pragma unroll
@@ -3129,12 +3138,13 @@ __global__ void __launch_bounds__(64) k_tau_finish_det(const long long* acc, con
 #pragma unroll
     for (int i = 0; i < 12; i++)
         sw[i] = from_fixed(wave_sum_ll_to_lane63(acc[(i < 6 ? 0 : 8 * GSR_TAU_SLOTS) + lane * 8 + (i < 6 ? i : i - 6)]), GSR_FIX_TAU);
+    const long long nonfinite = wave_sum_ll_to_lane63(acc[lane * 8 + 7]);
     if (lane == 63) {
         float vm[16];
         for (int k = 0; k < 16; k++) vm[k] = view[k];
         double tau[6];
         tau_from_world_sums(sw, vm, tau);
-        for (int i = 0; i < 6; i++) out[i] = (float)tau[i];
+        for (int i = 0; i < 6; i++) out[i] = (nonfinite != 0) ? __builtin_nanf("") : (float)tau[i];
     }
 }
 

@@ -255,3 +255,4 @@ def test_non_finite_gradients_are_not_swallowed(monkeypatch):
     assert bad0.sum() > 0 and np.array_equal(bad0, bad1), (int(bad0.sum()), int(bad1.sum()))
     ok = ~bad0
     assert U.rel_l1(g1["means3D"][ok], g0["means3D"][ok]) <= 1e-4
+    assert not np.isfinite(g0["tau"]).all() and not np.isfinite(g1["tau"]).all()          # (the pose gradient sums over all of them)
