@@ -97,6 +97,7 @@ SIGNATURES.update({
     "gsr_pose_step": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp]),
     "gsr_refine": (_i, [C.POINTER(RefineArgs), C.POINTER(_i), C.POINTER(_i)]),
     "gsr_debug_lean_check": (_i, [C.POINTER(RefineArgs), C.POINTER(C.c_longlong)]),
+    "gsr_debug_lam_offset": (C.c_size_t, [_i]),
 })
 
 _lib = None

@@ -1361,6 +1361,14 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     return 0;
 }
 
+size_t gsr_debug_lam_offset(int P)
+{
+    Geom g;
+    char* base = reinterpret_cast<char*>((uintptr_t)4096);      // (never dereferenced: carve_geom only does pointer arithmetic)
+    carve_geom(base, P, g);
+    return (size_t)(reinterpret_cast<char*>(g.lam) - base);
+}
+
 int gsr_debug_lean_check(const gsr_refine_args* a, long long out[5])
 {
     using namespace gsr;

@@ -158,6 +158,7 @@ __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int 
 #define GSR_SURV_CSTRIDE 64
 #ifndef GSR_LEAN_PER_LANE
 #define GSR_LEAN_PER_LANE 4      // Gaussians per lane of k_preprocess_lean
+static_assert(GSR_LEAN_PER_LANE * 256 == 1024, "surv_cap() and k_preprocess_bin's virtual blocks (idx >> 10) assume 1 024-Gaussian stretches: change them together");
 #endif
 #ifndef GSR_LEAN_POOL
 #define GSR_LEAN_POOL 1          // waves of a workgroup that pool their candidates for one exact pass (1, 2 or 4)
@@ -165,7 +166,9 @@ __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int 
 struct SurvLists { uint32_t* ids; uint32_t* n; uint32_t cap; };
 static inline uint32_t surv_cap(int P)
 {
-    // (what the workgroups b = s mod GSR_SURV_LISTS of k_preprocess / k_preprocess_lean cover: 256 / GSR_LEAN_PER_LANE x 256 Gaussians each)
+    // (what the workgroups b = s mod GSR_SURV_LISTS of k_preprocess / k_preprocess_lean cover: 256 / GSR_LEAN_PER_LANE x 256 Gaussians
+    // each; k_preprocess_bin's 2 048-Gaussian workgroups file their survivors by 1 024-Gaussian stretch, idx >> 10.  The largest of these
+    // sizes the sub-lists and bounds the others: ceil(n / 64) x 256 <= ceil(n / 256) x 1 024.)
     const uint32_t per = GSR_LEAN_PER_LANE * GSR_BLOCK;
     const uint32_t blocks = ((uint32_t)(P > 0 ? P : 1) + per - 1) / per;
     return (blocks + GSR_SURV_LISTS - 1) / GSR_SURV_LISTS * per;

@@ -126,7 +126,7 @@ class FusedRefiner:
         self._args = a
 
     def _tensor_versions(self):
-        ts = (self.scales, self.rots, self.g_alpha, self.g_m2d, self.g_conic, self.g_opac, self.g_col, self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot)
+        ts = (self.means3D, self.scales, self.rots, self.g_alpha, self.g_m2d, self.g_conic, self.g_opac, self.g_col, self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot)
         return tuple(-1 if t is None else t._version for t in ts)
 
     def _cached(self, slot, t, make):

@@ -328,6 +328,9 @@ int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
  * leaves, out[2] = Gaussians the exact walk bins into at least one tile, out[3] = VIOLATIONS: settled although the exact walk
  * bins them (must be 0), out[4] = index of the first violation or -1.  Blocking. */
 int gsr_debug_lean_check(const gsr_refine_args* args, long long out[5]);
+/* Byte offset of the per-Gaussian (mean, extent bound) quads inside a geometry workspace of gsr_geometry_bytes(P) bytes (tests only:
+ * tests/test_gpu_lean.py overwrites the bounds to see the check above fail). */
+size_t gsr_debug_lam_offset(int P);
 
 /* Map on-disk rows -> device layout.  Replaces the per-property column gathering of
  * load_ply (gs_localization/pipelines/tools/gaussian_model.py:377-467; gaussian_splatting/scene/

@@ -256,3 +256,22 @@ def test_non_finite_gradients_are_not_swallowed(monkeypatch):
     ok = ~bad0
     assert U.rel_l1(g1["means3D"][ok], g0["means3D"][ok]) <= 1e-4
     assert not np.isfinite(g0["tau"]).all() and not np.isfinite(g1["tau"]).all()          # (the pose gradient sums over all of them)
+
+
+def test_survivor_sublists_hold_a_fully_visible_map():
+    """140 000 Gaussians, all of them in view: the survivor work lists at their fullest (every sub-list takes whole 1 024-Gaussian
+    stretches, whichever kernel files the survivors: surv_cap).  Complete lists (k_preprocess_bin) against the speculative loop (other
+    kernels fill the lists) and against the Python loop."""
+    from tests import replay as PL
+    sc = S.small(P=140000, W=320, H=240, sh_degree=1, seed=17, scale_med=0.02)
+    sc.means3D[:, :2] *= np.float32(0.45)          # everything well inside the frustum
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    init = PL.perturbed_start(4, 0.01, 0.5, device=DEV)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    plain = _run(fr, PL.make_frame(sc, model, DEV, bg), init, bg, 4, flags=DET, speculative=False, count_instances=True)
+    spec = _run(fr, PL.make_frame(sc, model, DEV, bg), init, bg, 4, flags=DET, lean_min_P=1)
+    assert int((plain["radii"] > 0).sum()) > 0.9 * sc.P          # (the premise: nearly every Gaussian is visible)
+    _bit_equal(spec, plain, "speculative vs complete lists, fully visible map")
+    Rp, Tp, _ = PL.python_loop(PL.make_frame(sc, model, DEV, bg), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), model, bg, iters=4)
+    assert torch.allclose(plain["R"], Rp, atol=2e-6) and torch.allclose(plain["T"], Tp, atol=2e-6)

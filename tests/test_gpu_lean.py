@@ -245,10 +245,9 @@ def test_differential_check_flags_a_wrong_bound():
     fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
     _run(fr, view(), init, bg, 6, lean_min_P=1, flags=0)
     assert fr.lean_check()[3] == 0
-    # the (mean, extent bound) quads are the last array carved out of the geometry workspace (carve_geom: lam, 256-byte aligned)
+    # the (mean, extent bound) quads inside the geometry workspace
     lib = _lib.load()
-    gbytes = int(lib.gsr_geometry_bytes(sc.P))
-    off = (gbytes - 16 * sc.P) // 256 * 256
+    off = int(lib.gsr_debug_lam_offset(sc.P))
     quads = fr.ws[0].t[off:off + 16 * sc.P].view(torch.float32).view(sc.P, 4)
     assert torch.equal(quads[:, :3], torch.tensor(sc.means3D, device=DEV)), "not the (mean, extent) quads: carve_geom changed?"
     vals = quads[:, 3]
