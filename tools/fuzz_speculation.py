@@ -38,6 +38,9 @@ for case in range(N):
     K = int(rng.choice([6, 10, 25, 50] if BIG else [6, 10, 25]))
     far = rng.random() < 0.3           # a start far off: the view moves under the speculation, bounds go stale
     start = rng.normal(size=6) * (0.04 if far else 0.01)
+    cfg = {"Training": {"monocular": bool(rng.integers(2)), "alpha": float(rng.choice([0.9, 0.99])), "opacity_threshold": float(rng.choice([0.5, 0.99])),
+                        "edge_threshold": 1.1}}                      # (the tracking loss's variants: RGB only / RGB + depth, masks, thresholds)
+    mask_np = rng.random((1, H, W)) > (0.0 if rng.random() < 0.5 else 0.3)
     if "ONLY" in os.environ and case != int(os.environ["ONLY"]):
         continue
     # (a) drop-in packages: a walk of poses, small steps with an occasional jump
@@ -64,11 +67,12 @@ for case in range(N):
     if case % 2 == 0:
         model = PL.GaussianMap.from_scene(sc, device=dev)
         bg = torch.zeros(3, device=dev)
+        mask_t = torch.tensor(mask_np, dtype=torch.bool, device=dev)
         def view():
             vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, dev), sc, dev)
             with torch.no_grad():
                 pkg = PL.render(vp, model, bg)
-            vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=dev)
+            vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); vp.grad_mask = mask_t
             return vp
         fr = PL.FusedRefiner(model, H, W, device=dev)
         # The deterministic option (integer sums across workgroups) takes the atomics' noise out of the
@@ -77,7 +81,7 @@ for case in range(N):
         res = []
         init = torch.tensor(S.se3_exp(start), dtype=torch.float32, device=dev)
         for spec in (False, True):
-            R, T, info = fr.refine(view(), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=K, stop_on_converged=bool(case % 2),
+            R, T, info = fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=K, stop_on_converged=bool(case % 2),
                                    speculative=spec, warm_start=False, lean_min_P=1, flags=_lib.REFINE_DETERMINISTIC)
             torch.cuda.synchronize()
             out = {"R": R.clone(), "T": T.clone(), "color": fr.color.clone(), "depth": fr.depth.clone(), "alpha": fr.alpha.clone(),
