@@ -97,5 +97,17 @@ for case in range(N):
                   {k: float((res[0][0][k].double() - res[1][0][k].double()).abs().max()) for k in bad}, flush=True)
             sys.exit(1)
         lean_total = globals().get("lean_total", 0) + res[1][1].get("lean_iters", 0); globals()["lean_total"] = lean_total
+        if case % 4 == 0 and not (case % 2):
+            # ... and against the reference-style Python loop on the drop-in packages (torch loss, torch Adam, update_pose): rounding only
+            os.environ.pop("GSR_DETERMINISTIC", None)
+            vpy = view()
+            Rp, Tp, _ = PL.python_loop(vpy, cfg, init[:3, :3].clone(), init[:3, 3].clone(), model, bg, iters=K)
+            os.environ["GSR_DETERMINISTIC"] = "1"
+            dpy = max(float((res[0][0]["R"] - Rp).abs().max()), float((res[0][0]["T"] - Tp).abs().max()))
+            globals()["py_worst"] = max(globals().get("py_worst", 0.0), dpy); globals()["py_n"] = globals().get("py_n", 0) + 1
+            if dpy > 2e-6: globals()["py_soft"] = globals().get("py_soft", 0) + 1
+            if dpy > 1e-3:
+                print("PYTHON LOOP MISMATCH case", case, W, H, P, deg, "K", K, cfg, "%.2e" % dpy, flush=True); sys.exit(1)
 print(f"{N} cases ok: drop-in guesses verified {tot_v}, missed {tot_m}; native loop (deterministic option, bit for bit): forwards redone {tot_fb}, "
-      f"lean iterations {globals().get('lean_total', 0)}")
+      f"lean iterations {globals().get('lean_total', 0)}; against the Python loop ({globals().get('py_n', 0)} cases): worst pose difference "
+      f"{globals().get('py_worst', 0.0):.1e}, {globals().get('py_soft', 0)} beyond 2e-6")
