@@ -103,6 +103,21 @@ int main(void)
     for (int i = 0; i < 6; i++) tau_norm += h_tau[i] * h_tau[i];
     if (!(tau_norm > 0.f && isfinite(tau_norm) && h_gcol[0] > 1.f)) { fprintf(stderr, "unexpected gradients: |tau|^2=%g dL/dcol0=%g\n", tau_norm, h_gcol[0]); return 1; }
 
+    /* the deterministic option (debug bit 2): twice the same bits, and the default mode's numbers up to rounding */
+    float h_det[2][6], h_detcol[2][P * 3];
+    for (int rep = 0; rep < 2; rep++) {
+        rc = gsr_backward(P, 0, 0, R, d_bg, W, H, d_means, NULL, d_col, out_alpha, d_scales, 1.0f, d_rots, NULL, d_view, d_proj, d_campos, tanx, tany,
+                          radii, (char*)geom.p, (char*)binning.p, (char*)img.p, g_pix, g_depth, g_alpha, g_m2d, g_conic, g_opac, g_col, g_m3d, g_cov,
+                          NULL, g_scale, g_rot, 4, 1, g_tau, st);
+        if (rc < 0) { fprintf(stderr, "gsr_backward (deterministic): %s\n", gsr_last_error()); return 1; }
+        CK(hipStreamSynchronize(st));
+        CK(hipMemcpy(h_det[rep], g_tau, sizeof(h_tau), hipMemcpyDeviceToHost));
+        CK(hipMemcpy(h_detcol[rep], g_col, sizeof(h_gcol), hipMemcpyDeviceToHost));
+    }
+    if (memcmp(h_det[0], h_det[1], sizeof(h_tau)) != 0 || memcmp(h_detcol[0], h_detcol[1], sizeof(h_gcol)) != 0) { fprintf(stderr, "deterministic backward: two runs differ\n"); return 1; }
+    for (int i = 0; i < 6; i++)
+        if (fabsf(h_det[0][i] - h_tau[i]) > 1e-4f * sqrtf(tau_norm)) { fprintf(stderr, "deterministic dL/dtau[%d] = %g against %g\n", i, h_det[0][i], h_tau[i]); return 1; }
+
     /* error path: exactly one of shs / colors_precomp */
     rc = gsr_forward(resize_cb, &geom, resize_cb, &binning, resize_cb, &img, P, 0, 0, d_bg, W, H, d_means, NULL, NULL, d_opac, d_scales, 1.0f, d_rots,
                      NULL, d_view, d_proj, d_campos, tanx, tany, 0, out_color, out_depth, out_alpha, radii, 0, NULL, st);
