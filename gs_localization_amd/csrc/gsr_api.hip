@@ -1299,13 +1299,22 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         }
         if (!resolved) {
             n_host_redo++;
-            const int g3 = enq;
-            rc = enqueue_next(succ, 2);                 // complete lists: cannot fail
-            if (rc < 0) return rc;
+            // Complete lists.  Up to kFullBinMaxTiles tiles they go into fixed-capacity bins first (k_preprocess_bin), and a tile
+            // whose complete list is longer than its bin reports an overflow: only then -- once -- count -> scan -> emit, which
+            // cannot fail.  (A warm-started call reaches this point without ever having run a complete-list forward.)
             uint32_t w3 = 0;
-            { const int wrc = wait_status(g3, w3); if (wrc < 0) return wrc; }
-            settled_n++;
-            if (w3 & 6u) return fail(GSR_E_HIP, "gsr_refine: a forward with complete lists failed its verification%s", "");
+            int g3 = 0;
+            for (int attempt = 0;; attempt++) {
+                g3 = enq;
+                rc = enqueue_next(succ, 2);
+                if (rc < 0) return rc;
+                { const int wrc = wait_status(g3, w3); if (wrc < 0) return wrc; }
+                settled_n++;
+                if ((w3 & 6u) == 0u) break;
+                n_fallbacks++;
+                if ((w3 & 4u) && !cx.exact_bins && attempt == 0) { cx.exact_bins = true; continue; }
+                return fail(GSR_E_HIP, "gsr_refine: a forward with complete lists failed its verification%s", "");
+            }
             after_success(g3, w3);
             // back off: a scene whose lists stay long after culling would otherwise pay for failed forwards again and again
             fail_streak++;

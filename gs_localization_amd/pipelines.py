@@ -60,6 +60,9 @@ class FusedRefiner:
     computing every Gaussian-parameter gradient like the reference does (its map tensors require grad,
     tools/gaussian_model.py:437-462) although nothing consumes them; `False` is the pose-only fast path.
 
+    Aliasing: the R, T handed back (and `viewpoint.exposure_a/b.data`) are VIEWS of this call's device pose state -- the next
+    refine() allocates a fresh state, so they stay valid, but they share storage with each other; clone before writing in place.
+
     One documented difference in what is RETURNED next to the pose: the reference hands back the render_pkg of its last
     loop body, i.e. the render at the pose BEFORE the last update (7scenes_localize_full_dslam.py:66-93).  `refine` does the
     same when max_iters is reached; on early convergence its images (render / depth / opacity, radii, n_touched) are those
@@ -131,11 +134,13 @@ class FusedRefiner:
 
     def _cached(self, slot, t, make):
         """Per-refiner cache of the per-frame constants' device-side conversions (projection matrix, background, mask ...):
-        keyed by the source tensor's identity and in-place-modification counter, so a caller that hands in the same tensors for
-        every frame (the reference's scripts do: one projection matrix, one background per run) pays for them once."""
+        keyed by the source tensor's identity, storage address and in-place-modification counter, so a caller that hands in the
+        same tensors for every frame (the reference's scripts do: one projection matrix, one background per run) pays for them
+        once.  Contract: a write that bypasses torch's version counter (`t.data.copy_`, a numpy array shared with a CPU tensor)
+        is not seen -- hand in a new tensor, or clear `refiner._conv_cache`."""
         if not torch.is_tensor(t):          # (a numpy depth map: no modification counter to trust)
             return make(t)
-        key = (id(t), t._version)
+        key = (id(t), t.data_ptr(), t._version)
         hit = self._conv_cache.get(slot)
         if hit is None or hit[0] != key or hit[1] is not t:
             hit = (key, t, make(t))

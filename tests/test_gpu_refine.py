@@ -504,3 +504,51 @@ def test_long_bins_are_ordered_lazily():
     assert out[True][2]["fallbacks"] == 0
     assert torch.allclose(out[True][0], out[False][0], atol=2e-6) and torch.allclose(out[True][1], out[False][1], atol=2e-6)
     assert torch.allclose(out[True][3], out[False][3], atol=5e-4)
+
+
+def test_host_redo_of_a_warm_started_call_survives_an_overflowing_complete_list_bin():
+    """ADVICE (round 3): a warm-started call never runs a complete-list forward of its own, so when the host has to redo a
+    forward (here: the frozen render behind a converged update, at a pose a huge learning rate threw far from the one the depth
+    bounds were recorded at) the complete lists go into the fixed-capacity bins of k_preprocess_bin for the first time -- and one
+    tile of this scene holds 90 % of the map behind an opaque wall (its speculative list is short, its complete list is twenty
+    times its bin).  The redo must fall back to count -> scan -> emit instead of reporting an error, and what it returns must be
+    the render at the final pose."""
+    from tests import replay as PL
+    base = S.small(P=20000, W=320, H=240, sh_degree=1, seed=51, scale_med=0.05)
+    rng = np.random.default_rng(52)
+    f32 = lambda a: np.ascontiguousarray(a, np.float32)
+    # an opaque wall at z = 1 m around the optical axis ...
+    gx, gy = np.meshgrid(np.linspace(-0.45, 0.45, 13), np.linspace(-0.45, 0.45, 13))
+    wall = np.stack([gx.ravel() + 0.03, gy.ravel(), np.full(gx.size, 1.0)], 1)
+    nw = wall.shape[0]
+    # ... and 180 000 small splats 3 m away, all inside a few pixels behind it
+    nc = 180000
+    clus = np.stack([0.094 + rng.normal(0, 0.004, nc), rng.normal(0, 0.004, nc), rng.uniform(3.0, 3.2, nc)], 1)
+    ident = np.tile(np.array([[1.0, 0, 0, 0]]), (nw + nc, 1))
+    base.means3D = f32(np.concatenate([base.means3D, wall, clus]))
+    base.scales = f32(np.concatenate([base.scales, np.full((nw, 3), 0.15), np.full((nc, 3), 0.01)]))
+    base.rotations = f32(np.concatenate([base.rotations, ident]))
+    base.opacities = f32(np.concatenate([base.opacities, np.full((nw, 1), 0.99), np.full((nc, 1), 0.5)]))
+    base.shs = f32(np.concatenate([base.shs, rng.normal(0, 1, (nw + nc,) + base.shs.shape[1:]) * 0.3]))
+    sc = base
+    model, bg, view, init = _setup(sc, seed=6)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    # call 1 (cold): leaves depth bounds behind; its own complete-list forward overflows and goes through the exact path
+    _, _, info1 = fr.refine(view(), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False)
+    assert info1["fallbacks"] >= 1 and fr._warm.value in (1, 2)
+    # call 2 (warm): the first update "converges" (huge threshold) after a 0.05 rad / 5 cm step; the frozen forward at that pose
+    # fails its verification somewhere, and the host's redo meets the overflowing bin
+    vp = view()
+    R, T, info = fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=10, lr=0.05, converged_threshold=1.0,
+                           warm_start=True)
+    torch.cuda.synchronize()
+    assert info["converged"] and info["iters"] == 1
+    assert info["host_redos"] >= 1, info          # (otherwise this scene no longer exercises the redo: make the step larger)
+    chk = view()
+    chk.update_RT(R.clone(), T.clone())
+    with torch.no_grad():
+        pkg = PL.render(chk, model, bg)
+    assert torch.allclose(fr.color, pkg["render"], atol=2e-4), float((fr.color - pkg["render"]).abs().max())
+    assert torch.allclose(fr.depth, pkg["depth"], atol=2e-3)
+    assert torch.allclose(fr.alpha, pkg["opacity"], atol=2e-4)
+    assert int((fr.radii != pkg["radii"]).sum()) <= max(2, int(5e-5 * fr.radii.numel()))
