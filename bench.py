@@ -96,14 +96,15 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch.distributed as dist
     dev_index = local_rank if args.device_index is None else args.device_index
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} (or without a launcher)")
+    # A process group exists whenever a launcher started this process -- also for ONE rank (`torch.distributed.run
+    # --nproc-per-node 1`): barrier, all_reduce and the result gather then run through RCCL on device tensors exactly as on
+    # eight GPUs.  Without a launcher (the driver's N = 1 run) there is no group and no collective.
+    grouped = "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ
+    from gs_localization_amd import shard as _shard
+    if grouped:
+        _shard.init_process_group(args.backend, rank, world, device=torch.device("cuda", dev_index))
     assert torch.cuda.is_available(), "bench.py needs an MI355X; there is no CPU path"
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
@@ -138,7 +139,7 @@ def main():
         return PL.pose_adam(v)
 
     def barrier():
-        if world > 1:
+        if grouped:
             dist.barrier()
 
     nk = lib.gsr_profile_kernel_count()
@@ -289,14 +290,14 @@ def main():
             lib.gsr_profile_enable(0)
             lib.gsr_profile_sampling(1)
     elapsed = elapsed_runs[0]
-    if world > 1:
+    if grouped:
         t = torch.tensor([elapsed, elapsed_py, elapsed_single, elapsed_plain, elapsed_cold] + elapsed_runs, dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         vals = [float(x) for x in t.tolist()]
         elapsed, elapsed_py, elapsed_single, elapsed_plain, elapsed_cold, elapsed_runs = vals[0], vals[1], vals[2], vals[3], vals[4], vals[5:]
     # how many ranks really took part (a launcher that started fewer than --gpus would otherwise go unnoticed)
     ranks_seen = 1
-    if world > 1:
+    if grouped:
         ones = torch.ones(1, dtype=torch.float64, device=coll_dev)
         dist.all_reduce(ones, op=dist.ReduceOp.SUM)
         ranks_seen = int(round(float(ones.item())))
@@ -347,6 +348,8 @@ def main():
             "unit": "iters/s",
             "n_gpus": world,
             "ranks_seen": ranks_seen,
+            "collectives": (f"{args.backend} ({'RCCL' if args.backend == 'nccl' else 'host tensors'}): barrier, all_reduce(max), all_gather of the result rows"
+                            if grouped else "none (no launcher: one rank without a process group)"),
             "steps": K,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / K,
@@ -406,8 +409,8 @@ def main():
         if train is not None:
             out["train_step"] = train
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if grouped:
+        _shard.destroy_process_group()
 
 
 def _cpu_time(sc, w2c, threads, backward, budget_s, max_n):

@@ -11,11 +11,50 @@ one shared counter -- an atomic add on the process group's rendezvous store (a c
 `chunk` frames, nothing on the GPUs' links) -- so that every rank, and every frame slot in flight on it, takes the next
 unclaimed frames the moment it is free.  `assign="static"` is the round-robin split (no store traffic at all).
 """
+import datetime
+import os
 import threading
 import time
 
 import torch
 import torch.distributed as dist
+
+_STORE = None      # the rendezvous store of the process group init_process_group() below created (the frame queue counts in it)
+
+
+def init_process_group(backend, rank, world, device=None, timeout_s=600):
+    """One process per GPU: creates the rendezvous store ITSELF (public API only: `dist.TCPStore` on MASTER_ADDR / MASTER_PORT,
+    the way torch's own env:// rendezvous does -- under torchrun the elastic agent already serves that port and every worker
+    connects as a client) and hands it to `dist.init_process_group`, so that `FrameQueue` can count in it without reaching
+    into torch's private `_get_default_store()`.  backend "nccl" is RCCL on ROCm (`device` = this rank's GPU, bound eagerly
+    through `device_id`); "gloo" runs the same code on host tensors.  A world of ONE rank is a valid group: the collectives
+    below then still go through the backend (that is how the RCCL path is executed on a one-GPU box)."""
+    global _STORE
+    addr = os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    port = int(os.environ["MASTER_PORT"])
+    timeout = datetime.timedelta(seconds=timeout_s)
+    if os.environ.get("TORCHELASTIC_USE_AGENT_STORE", "False") == "True":
+        base = dist.TCPStore(addr, port, world, False, timeout)
+        store = dist.PrefixStore(f"/worker/attempt_{os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')}", base)
+    else:
+        store = dist.TCPStore(addr, port, world, rank == 0, timeout, multi_tenant=True)
+    kw = {}
+    if backend == "nccl" and device is not None:
+        kw["device_id"] = torch.device(device)
+    dist.init_process_group(backend, store=store, rank=rank, world_size=world, timeout=timeout, **kw)
+    _STORE = store
+    return store
+
+
+def destroy_process_group():
+    global _STORE
+    _STORE = None
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
+
+
+def group_active():
+    return dist.is_available() and dist.is_initialized()
 
 
 def shard_frames(n_frames, rank, world):
@@ -45,9 +84,11 @@ class FrameQueue:
         if key is None:
             _queue_generation[0] += 1
             key = f"gsr_frames/{_queue_generation[0]}"
-        if assign == "queue" and world > 1:
-            # (torch exposes the default group's store only through this helper; a caller can pass its own store instead)
-            base = store if store is not None else dist.distributed_c10d._get_default_store()
+        if assign == "queue" and (world > 1 or store is not None or (_STORE is not None and group_active())):
+            base = store if store is not None else _STORE
+            if base is None:
+                raise RuntimeError("FrameQueue: no rendezvous store -- initialise the process group with shard.init_process_group() "
+                                   "(which keeps the store it creates) or pass store=")
             self._store = dist.PrefixStore(key, base)
         elif assign not in ("queue", "static"):
             raise ValueError("assign must be 'queue' or 'static'")
@@ -109,8 +150,9 @@ def run_split(n_frames, refine_fn, rank=0, world=1, slots=1, assign="queue", chu
 
 def gather_results(local, n_frames, rank, world, group=None):
     """local: [n_local, K] rows (frame_id, ...) of this rank, any number of them.  Returns [n_frames, K] sorted by frame id
-    on rank 0 (None elsewhere): one all_gather of the row counts and one of the rows, padded to the largest shard."""
-    if world == 1:
+    on rank 0 (None elsewhere): one all_gather of the row counts and one of the rows, padded to the largest shard.  Without a
+    process group (a plain one-GPU run) there is nothing to gather; WITH one the collectives run even for a world of one rank."""
+    if world == 1 and not group_active():
         return local[torch.argsort(local[:, 0])]
     K = local.shape[1]
     counts = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]

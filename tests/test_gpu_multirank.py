@@ -30,7 +30,7 @@ BENCH = ["bench.py", "--steps", "5", "--warmup", "1", "--frames-in-flight", "2",
 def test_bench_gpus_flag_launches_the_ranks():
     one = _json_line(BENCH)
     two = _json_line(BENCH + ["--gpus", "2", "--backend", "gloo", "--device-index", "0"])
-    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1 and one["collectives"].startswith("none")
     assert two["n_gpus"] == 2 and two["ranks_seen"] == 2
     assert two["config"]["parallelism"].startswith("frames: 2 GPU")
     # both ranks share one GPU here: the aggregate stays within a factor of three of the single rank's (5-iteration calls: noisy)
@@ -57,6 +57,29 @@ def test_split_driver_one_gpu_and_two_ranks():
     # the same frames whichever rank refined them: same medians up to the order of the fp32 atomics
     assert abs(two["median_trans_err_cm"] - one["median_trans_err_cm"]) < 0.05
     assert abs(two["median_rot_err_deg"] - one["median_rot_err_deg"]) < 0.02
+
+
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def test_rccl_path_executes_with_one_rank():
+    """The 8-GPU launch line with ONE rank: `torch.distributed.run --nproc-per-node 1`, backend nccl (= RCCL on ROCm).  The process
+    group is created with `device_id=`, and barrier / all_reduce / the all_gather of the result rows run on DEVICE tensors through
+    RCCL -- with a world of one there is no xGMI traffic, but communicator set-up, stream handling and the collectives' device
+    path have then executed before the first multi-GPU box sees them.  Same for the split driver (whose frame queue then counts
+    in the rendezvous store)."""
+    launch = ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port"]
+    one = _json_line(launch + [str(_free_port())] + BENCH + ["--gpus", "1", "--backend", "nccl"])
+    assert one["n_gpus"] == 1 and one["ranks_seen"] == 1 and one["collectives"].startswith("nccl"), one.get("collectives")
+    assert one["value"] > 0 and one["pose_err_cm_median"] < 2.5
+    split = _json_line(launch + [str(_free_port()), "tools/localize_split.py", "--frames", "16", "--gaussians", "300000", "--in-flight", "4",
+                                 "--backend", "nccl"])
+    assert split["n_gpus"] == 1 and split["collectives"] == "nccl" and sum(split["per_rank"]["frames"]) == 16
+    assert split["median_trans_err_cm"] < 1.5 and split["median_rot_err_deg"] < 1.0, split
 
 
 def test_build_then_smoke_in_one_process():

@@ -83,20 +83,67 @@ def test_active_degree_below_max_degree():
         assert np.all(g["sh"][:, 4:, :] == 0)
 
 
-def test_precomputed_inputs_mode():
-    """colors_precomp + cov3D_precomp path (pipe.convert_SHs_python / compute_cov3D_python)"""
+@pytest.mark.parametrize("pose", [False, True])
+def test_precomputed_inputs_mode(pose):
+    """colors_precomp + cov3D_precomp path (pipe.convert_SHs_python / compute_cov3D_python; package (B):
+    gs_localization/pipelines/tools/__init__.py:85-112).  pose=True: dL/dtau then has no SH view-direction term, and the
+    covariance-rotation term comes from the caller's covariances."""
     sc = S.small(P=600, W=64, H=48, sh_degree=3, seed=7, scale_med=0.06)
     cam = U.scene_inputs(sc, W2C)
     f0, _ = U.oracle_run(sc, cam)
     st = f0.state()
     grads = U.random_grads(sc, seed=7)
-    f, go = U.oracle_run(sc, cam, grads, colors_precomp=st["rgb"], cov3D_precomp=st["cov3D"])
-    o, g = U.hip_run(sc, cam, grads, colors_precomp=st["rgb"], cov3D_precomp=st["cov3D"])
-    _check_forward(o, f, False)
-    _check_grads(g, go, False, ["means3D", "means2D", "opacities", "colors_precomp", "cov3Ds_precomp"])
+    f, go = U.oracle_run(sc, cam, grads, pose=pose, colors_precomp=st["rgb"], cov3D_precomp=st["cov3D"])
+    o, g = U.hip_run(sc, cam, grads, pose=pose, colors_precomp=st["rgb"], cov3D_precomp=st["cov3D"])
+    _check_forward(o, f, pose)
+    _check_grads(g, go, pose, ["means3D", "means2D", "opacities", "colors_precomp", "cov3Ds_precomp"])
     # SURVEY section 4: both input modes must render the same image
-    o2, _ = U.hip_run(sc, cam)
+    o2, _ = U.hip_run(sc, cam, pose=pose)
     assert U.rel_l1(o2["color"], o["color"]) <= 1e-6
+    # the mixed modes render() (B) can be configured into: SH colours with precomputed covariances, precomputed colours
+    # with scale / rotation
+    for kw in (dict(cov3D_precomp=st["cov3D"]), dict(colors_precomp=st["rgb"])):
+        f3, go3 = U.oracle_run(sc, cam, grads, pose=pose, **kw)
+        o3, g3 = U.hip_run(sc, cam, grads, pose=pose, **kw)
+        _check_forward(o3, f3, pose)
+        keys = ["means3D", "means2D", "opacities"] + (["sh", "cov3Ds_precomp"] if "cov3D_precomp" in kw else ["colors_precomp", "scales", "rotations"])
+        _check_grads(g3, go3, pose, keys)
+
+
+def test_isotropic_scaling_through_the_pose_package():
+    """render() (B) with an isotropic map: `scales = pc.get_scaling.repeat(1, 3)` (gs_localization/pipelines/tools/__init__.py:89-92).
+    The [P, 1] parameter's gradient is the row sum of the rasterizer's dL/dscale; images, dL/dtau and the other gradients as
+    for any anisotropic map."""
+    import torch
+    import diff_gaussian_rasterization_pose as pkg
+    sc = S.small(P=900, W=80, H=60, sh_degree=2, seed=31, scale_med=0.06)
+    sc.scales = np.ascontiguousarray(np.repeat(sc.scales[:, :1], 3, axis=1))
+    cam = U.scene_inputs(sc, W2C)
+    grads = U.random_grads(sc, seed=31)
+    f, go = U.oracle_run(sc, cam, grads, pose=True)
+    dev = "cuda:0"
+    t = lambda a, rg=True: torch.tensor(np.asarray(a, np.float32), device=dev, requires_grad=rg)
+    means3D, opac, shs, rots = t(sc.means3D), t(sc.opacities), t(sc.shs), t(sc.rotations)
+    iso = t(sc.scales[:, :1])
+    means2D = torch.zeros_like(means3D, requires_grad=True)
+    rs = pkg.GaussianRasterizationSettings(image_height=sc.H, image_width=sc.W, tanfovx=sc.tanfovx, tanfovy=sc.tanfovy, bg=t(sc.bg, False),
+                                           scale_modifier=1.0, viewmatrix=t(cam["view"], False), projmatrix=t(cam["proj"], False),
+                                           projmatrix_raw=t(cam["proj_raw"], False), sh_degree=sc.sh_degree, campos=t(cam["campos"], False),
+                                           prefiltered=False, debug=False)
+    theta = torch.zeros(3, device=dev, requires_grad=True)
+    rho = torch.zeros(3, device=dev, requires_grad=True)
+    color, radii, depth, alpha, n_touched = pkg.GaussianRasterizer(rs)(
+        means3D=means3D, means2D=means2D, opacities=opac, shs=shs, colors_precomp=None, scales=iso.repeat(1, 3), rotations=rots,
+        cov3D_precomp=None, theta=theta, rho=rho)
+    gc, gd, ga = (torch.tensor(x, device=dev) for x in grads)
+    ((color * gc).sum() + (depth * gd).sum() + (alpha * ga).sum()).backward()
+    o = dict(color=color.detach().cpu().numpy(), depth=depth.detach().cpu().numpy(), alpha=alpha.detach().cpu().numpy(),
+             radii=radii.cpu().numpy(), n_touched=n_touched.cpu().numpy())
+    _check_forward(o, f, True)
+    assert U.rel_l1(iso.grad.cpu().numpy()[:, 0], go["scales"].sum(axis=1)) <= GRAD_TOL
+    for k, v in (("means3D", means3D), ("opacities", opac), ("sh", shs), ("rotations", rots)):
+        assert U.rel_l1(v.grad.cpu().numpy().reshape(go[k].shape), go[k]) <= GRAD_TOL, k
+    assert U.rel_l1(np.concatenate([rho.grad.cpu().numpy(), theta.grad.cpu().numpy()]), go["tau"]) <= TAU_TOL
 
 
 def test_culling_branches():

@@ -16,8 +16,8 @@ def _cost_units(frame, world):
 def _worker(rank, world, port, n_frames, assign, slots, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
     from gs_localization_amd import shard
+    shard.init_process_group("gloo", rank, world)
 
     def refine(slot, f):            # stands in for FusedRefiner.refine: (trans err, rot err, iterations)
         time.sleep(0.004 * _cost_units(f, world))
@@ -38,7 +38,7 @@ def _worker(rank, world, port, n_frames, assign, slots, out):
         torch.save({"res": res, "walls": torch.stack(walls)}, out)
     else:
         assert res is None
-    dist.destroy_process_group()
+    shard.destroy_process_group()
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -58,12 +58,12 @@ def main():
     if args.gpus and args.gpus != world:
         sys.exit(f"localize_split.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     dev_index = local_rank if args.device_index is None else args.device_index
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
-        else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+    # (a launcher started this process -- also `--nproc-per-node 1`: the queue then counts in the store and the gather runs through
+    # the backend, RCCL on device tensors, exactly as on eight GPUs; no launcher: no group, no collective)
+    grouped = "WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ
+    from gs_localization_amd import shard as _shard
+    if grouped:
+        _shard.init_process_group(args.backend, rank, world, device=torch.device("cuda", dev_index))
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     coll_dev = dev if args.backend == "nccl" else torch.device("cpu")
@@ -115,20 +115,20 @@ def main():
     for f in range(min(args.frames, args.preload)):
         loaded[f] = observe(f, frame_setup(f)[0])
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     t0 = time.perf_counter()
     local, busy = shard.run_split(args.frames, refine, rank, world, slots=F, assign=args.assign, chunk=args.chunk)
     torch.cuda.synchronize()
     t_rank = time.perf_counter() - t0
-    if world > 1:
+    if grouped:
         dist.barrier()
     wall = time.perf_counter() - t0
     res = shard.gather_results(local.to(coll_dev), args.frames, rank, world)
     stats = torch.tensor([t_rank, sum(busy) / F, float(local.shape[0]), float(local[:, 3].sum()) if local.numel() else 0.0],
                          dtype=torch.float64, device=coll_dev)
     per_rank = [torch.zeros_like(stats) for _ in range(world)]
-    if world > 1:
+    if grouped:
         dist.all_gather(per_rank, stats)
     else:
         per_rank = [stats]
@@ -137,7 +137,7 @@ def main():
         m = shard.median_errors(res)
         pr = torch.stack(per_rank).cpu().numpy()
         out = {"workload": f"synthetic test split: {args.frames} query frames within {args.spread[0]} m / {args.spread[1]} deg, {args.gaussians} Gaussians, 640x480, up to {args.iters} iterations each",
-               "n_gpus": world, "frames_in_flight_per_gpu": F, "assign": args.assign, "frames_per_s": args.frames / wall,
+               "n_gpus": world, "collectives": (args.backend if grouped else "none"), "frames_in_flight_per_gpu": F, "assign": args.assign, "frames_per_s": args.frames / wall,
                "iterations_per_s": float(res[:, 3].sum()) / wall, "wall_s": wall,
                "median_trans_err_cm": 100.0 * m["median_t_m"], "median_rot_err_deg": m["median_R_deg"], "recall": m["recall"],
                "iterations_per_frame": {"min": float(res[:, 3].min()), "median": float(res[:, 3].median()), "max": float(res[:, 3].max())},
@@ -145,8 +145,8 @@ def main():
                             "iterations": [int(x) for x in pr[:, 3]]},
                "balance_max_over_mean_idle_time": float(pr[:, 0].max() / pr[:, 0].mean())}
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    if grouped:
+        _shard.destroy_process_group()
 
 
 if __name__ == "__main__":
