@@ -115,6 +115,13 @@ def s_3m_cam(seed=0):
     return _draw("S-3M-cam", 3_000_000, 852, 480, 744.0, 744.0, 2.0, 60.0, 0.05, 0.7, 3, seed)
 
 
+def s_3m_cam_1024(seed=0):
+    """S-3M-cam at the image size the reference's Cambridge script really uses (1024x576 masks,
+    gs_localization/pipelines/cambridge_localize_full.py:366): same field of view, 64 x 36 = 2 304 tiles."""
+    f = 744.0 * 1024 / 852
+    return _draw("S-3M-cam-1024", 3_000_000, 1024, 576, f, f, 2.0, 60.0, 0.05, 0.7, 3, seed)
+
+
 def s_50k_fern(seed=0):
     return _draw("S-50k-fern", 50_000, 504, 378, 400.0, 400.0, 0.5, 6.0, 0.03, 0.6, 3, seed)
 

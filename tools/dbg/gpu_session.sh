@@ -1,0 +1,28 @@
+#!/bin/bash
+# usage (GPU box, via gpurun): tools/dbg/gpu_session.sh <step> [...]  -- the round's GPU sessions, one named step per call;
+# everything lands in gpurun_out/r04/<step>*.log
+cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
+o=gpurun_out/r04; mkdir -p $o
+step=$1; shift
+case $step in
+  newtests)
+    python -m pytest tests/test_gpu_refine.py::test_host_redo_of_a_warm_started_call_survives_an_overflowing_complete_list_bin \
+      tests/test_gpu_parity.py::test_precomputed_inputs_mode tests/test_gpu_parity.py::test_isotropic_scaling_through_the_pose_package \
+      tests/test_gpu_fuzz.py tests/test_gpu_multirank.py::test_rccl_path_executes_with_one_rank -q -x 2>&1 | tail -25 > $o/newtests.log ;;
+  suite)
+    python -m pytest tests -q -m gpu -x 2>&1 | tail -15 > $o/suite$1.log ;;
+  profiles)      # evidence for BASELINE configs 3 and 4
+    tag=${1:-r04}
+    tools/profile_r04.sh $tag cam_plain s_3m_cam plain
+    tools/profile_r04.sh $tag cam_spec s_3m_cam
+    tools/profile_r04.sh $tag cam1024_plain s_3m_cam_1024 plain
+    tools/profile_r04.sh $tag cam1024_spec s_3m_cam_1024
+    tools/profile_r04.sh $tag train train
+    tools/profile_r04.sh $tag s1m_plain s_1m_640 plain ;;
+  bench)
+    python bench.py "$@" 2>$o/bench$BTAG.err | tail -1 > $o/bench$BTAG.json ;;
+  plain)         # quick A/B numbers of the complete-list path: it/s + per-kernel HIP-event times
+    for sc in s_1m_640 s_3m_cam s_3m_cam_1024; do SCENE=$sc LOOP_PLAIN=1 python tools/loop_only.py 100 2>/dev/null | tail -1; done > $o/plain$1.log
+    python tools/dbg/train_kernels.py 2>/dev/null | tail -2 >> $o/plain$1.log ;;
+  *) echo "unknown step $step" ;;
+esac
