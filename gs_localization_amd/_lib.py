@@ -57,6 +57,26 @@ class SpecState(C.Structure):
                 ("skip", _i), ("last_speculative", _i), ("n_speculative", _i), ("n_failed", _i)]
 
 
+class ForwardArgs(C.Structure):
+    """mirror of `gsr_forward_args` (include/gsr.h): one pointer across the ctypes boundary instead of 34 arguments"""
+    _fields_ = [("state", _vp), ("geometry_buffer", RESIZE_FN), ("geometry_ctx", _vp), ("binning_buffer", RESIZE_FN), ("binning_ctx", _vp),
+                ("image_buffer", RESIZE_FN), ("image_ctx", _vp), ("P", _i), ("D", _i), ("M", _i), ("background", _vp), ("width", _i), ("height", _i),
+                ("means3D", _vp), ("shs", _vp), ("colors_precomp", _vp), ("opacities", _vp), ("scales", _vp), ("scale_modifier", _f),
+                ("rotations", _vp), ("cov3D_precomp", _vp), ("viewmatrix", _vp), ("projmatrix", _vp), ("cam_pos", _vp), ("tan_fovx", _f),
+                ("tan_fovy", _f), ("prefiltered", _i), ("out_color", _vp), ("out_depth", _vp), ("out_alpha", _vp), ("radii", _vp), ("debug", _i),
+                ("n_touched", _vp), ("stream", _vp)]
+
+
+class BackwardArgs(C.Structure):
+    """mirror of `gsr_backward_args` (include/gsr.h)"""
+    _fields_ = [("P", _i), ("D", _i), ("M", _i), ("R", _i), ("background", _vp), ("width", _i), ("height", _i), ("means3D", _vp), ("shs", _vp),
+                ("colors_precomp", _vp), ("alphas", _vp), ("scales", _vp), ("scale_modifier", _f), ("rotations", _vp), ("cov3D_precomp", _vp),
+                ("viewmatrix", _vp), ("projmatrix", _vp), ("campos", _vp), ("tan_fovx", _f), ("tan_fovy", _f), ("radii", _vp),
+                ("geom_buffer", _vp), ("binning_buffer", _vp), ("img_buffer", _vp), ("dL_dpix", _vp), ("dL_ddepths", _vp), ("dL_dalphas", _vp),
+                ("dL_dmean2D", _vp), ("dL_dconic", _vp), ("dL_dopacity", _vp), ("dL_dcolor", _vp), ("dL_dmean3D", _vp), ("dL_dcov3D", _vp),
+                ("dL_dsh", _vp), ("dL_dscale", _vp), ("dL_drot", _vp), ("debug", _i), ("pose_mode", _i), ("dL_dtau", _vp), ("stream", _vp)]
+
+
 class RefineArgs(C.Structure):
     """mirror of `gsr_refine_args` (include/gsr.h)"""
     _fields_ = [
@@ -86,7 +106,7 @@ class RefineArgs(C.Structure):
 
 
 # the GSR_ABI_VERSION these ctypes mirrors (SpecState, RefineArgs, the pose-state layout) were written for
-ABI_VERSION = 2
+ABI_VERSION = 3
 REFINE_NO_LEAN, REFINE_SH_SEPARATE, REFINE_NO_BALANCE, REFINE_LOG_REDO, REFINE_DETERMINISTIC = 1, 2, 4, 8, 16
 
 
@@ -96,6 +116,8 @@ SIGNATURES.update({
     "gsr_pose_init": (_i, [_vp, _vp, _vp]),
     "gsr_pose_step": (_i, [_vp, _vp, _vp, _vp, _f, _f, _vp]),
     "gsr_refine": (_i, [C.POINTER(RefineArgs), C.POINTER(_i), C.POINTER(_i)]),
+    "gsr_forward_packed": (_i, [C.POINTER(ForwardArgs)]),
+    "gsr_backward_packed": (_i, [C.POINTER(BackwardArgs)]),
     "gsr_debug_lean_check": (_i, [C.POINTER(RefineArgs), C.POINTER(C.c_longlong)]),
     "gsr_debug_lam_offset": (C.c_size_t, [_i]),
 })

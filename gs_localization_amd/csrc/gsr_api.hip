@@ -951,6 +951,26 @@ int gsr_forward_speculative(gsr_spec_state* s, GSR_FWD_PARAMS)
 
 int gsr_backward(GSR_BWD_PARAMS) { const PassCtx cx = dropin_ctx(debug); return backward_impl(cx, GSR_BWD_PASS); }
 
+// one struct pointer across the foreign-function boundary instead of 34 / 40 arguments (include/gsr.h)
+int gsr_forward_packed(const gsr_forward_args* a)
+{
+    if (!a) return fail(GSR_E_INVALID, "gsr_forward_packed: NULL argument%s", "");
+    return gsr_forward_speculative(a->state, a->geometry_buffer, a->geometry_ctx, a->binning_buffer, a->binning_ctx, a->image_buffer, a->image_ctx,
+                                   a->P, a->D, a->M, a->background, a->width, a->height, a->means3D, a->shs, a->colors_precomp, a->opacities,
+                                   a->scales, a->scale_modifier, a->rotations, a->cov3D_precomp, a->viewmatrix, a->projmatrix, a->cam_pos,
+                                   a->tan_fovx, a->tan_fovy, a->prefiltered, a->out_color, a->out_depth, a->out_alpha, a->radii, a->debug,
+                                   a->n_touched, a->stream);
+}
+int gsr_backward_packed(const gsr_backward_args* a)
+{
+    if (!a) return fail(GSR_E_INVALID, "gsr_backward_packed: NULL argument%s", "");
+    return gsr_backward(a->P, a->D, a->M, a->R, a->background, a->width, a->height, a->means3D, a->shs, a->colors_precomp, a->alphas, a->scales,
+                        a->scale_modifier, a->rotations, a->cov3D_precomp, a->viewmatrix, a->projmatrix, a->campos, a->tan_fovx, a->tan_fovy,
+                        a->radii, a->geom_buffer, a->binning_buffer, a->img_buffer, a->dL_dpix, a->dL_ddepths, a->dL_dalphas, a->dL_dmean2D,
+                        a->dL_dconic, a->dL_dopacity, a->dL_dcolor, a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, a->debug,
+                        a->pose_mode, a->dL_dtau, a->stream);
+}
+
 int gsr_tracking_loss(int width, int height, const float* image, const float* depth, const float* opacity,
                       const float* gt_image, const float* gt_depth, const uint8_t* grad_mask, const float* exposure,
                       float opacity_threshold, float depth_weight, int monocular, float* dL_dimage, float* dL_ddepth,

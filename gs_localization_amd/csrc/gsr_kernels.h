@@ -18,11 +18,14 @@ __device__ unsigned long long g_tim[4][GSR_TIM_WAVES][12];      // [kernel][wave
 #define GSR_T_TICK(slot) { const long long now_ = clock64(); t_acc_[slot] += now_ - t_prev_; t_prev_ = now_; }
 #define GSR_T_COUNT(slot, v) { t_acc_[slot] += (v); }
 #define GSR_T_FLUSH(base) t_acc_[9] = clock64() - t_start_; if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < GSR_TIM_WAVES) { for (int q_ = 0; q_ < 12; q_++) g_tim[(base) / 16][blockIdx.x * 4 + (threadIdx.x >> 6)][q_] += (unsigned long long)t_acc_[q_]; }
+// (workgroups of `wpb` waves)
+#define GSR_T_FLUSH_W(base, wpb) t_acc_[9] = clock64() - t_start_; if ((threadIdx.x & 63) == 0 && blockIdx.x * (wpb) + (threadIdx.x >> 6) < GSR_TIM_WAVES) { for (int q_ = 0; q_ < 12; q_++) g_tim[(base) / 16][blockIdx.x * (wpb) + (threadIdx.x >> 6)][q_] += (unsigned long long)t_acc_[q_]; }
 #else
 #define GSR_T_DECL
 #define GSR_T_TICK(slot)
 #define GSR_T_COUNT(slot, v)
 #define GSR_T_FLUSH(base)
+#define GSR_T_FLUSH_W(base, wpb)
 #endif
 
 // Device-side guards of the native refinement loop (gsr_refine).  The host enqueues kernel GROUPS (preprocess, compositing,
@@ -1350,6 +1353,7 @@ __global__ void __launch_bounds__(GSR_PBIN_THREADS) k_preprocess_bin(PreArgs a, 
     uint32_t* s_cnt = s_tb;
     uint32_t* s_base = s_tb + a.ntiles;
     const int tid = threadIdx.x;
+    GSR_T_DECL
     if (a.tile_order[0] != nullptr && blockIdx.x < 2) {      // native loop: this iteration's launch orders of the compositing kernels
         __shared__ uint32_t s_cls[GSR_BLOCK];
         tile_order_from_work(a.tile_work[blockIdx.x], a.tile_order[blockIdx.x], a.order_tiles, s_cls);
@@ -1372,22 +1376,30 @@ __global__ void __launch_bounds__(GSR_PBIN_THREADS) k_preprocess_bin(PreArgs a, 
     }
     TileBinArgs ta = {};
     ta.gx = a.gx; ta.gy = a.gy;
+    GSR_T_TICK(0)
     __syncthreads();
+    GSR_T_TICK(1)
     walk_rows<KPT>(ta, it, 0, a.gy, s_pref, [&](int tile, unsigned long long) { atomicAdd(&s_cnt[tile], 1u); });
+    GSR_T_TICK(2)
     __syncthreads();
+    GSR_T_TICK(3)
     for (int t = tid; t < a.ntiles; t += GSR_PBIN_THREADS) {
         const uint32_t c = s_cnt[t];
         s_base[t] = (c != 0u) ? atomicAdd(&a.tile_cursor[t * GSR_CURSOR_STRIDE], c) : 0u;
         s_cnt[t] = 0u;
     }
+    GSR_T_TICK(4)
     const int bh = (a.gy + bands - 1) / bands;
     for (int b0 = 0; b0 < a.gy; b0 += bh) {
         __syncthreads();
+        GSR_T_TICK(5)
         walk_rows<KPT>(ta, it, b0, min(a.gy, b0 + bh), s_pref, [&](int tile, unsigned long long key) {
             const uint32_t pos = s_base[tile] + atomicAdd(&s_cnt[tile], 1u);
             if (pos < (uint32_t)a.bin_cap) a.bins[(size_t)tile * (a.bin_cap + GSR_BIN_PAD) + pos] = key;
         });
+        GSR_T_TICK(6)
     }
+    GSR_T_FLUSH_W(32, GSR_PBIN_THREADS / 64)
 }
 
 // ---------------------------------------------------------------------------------------------

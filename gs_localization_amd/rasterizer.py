@@ -147,13 +147,21 @@ class _SpecCache(threading.local):
 _spec_cache = _SpecCache()
 
 
+_ENV = getattr(os.environ, "_data", None)      # posix: the bytes-keyed dict behind os.environ (a plain lookup instead of a raised and caught KeyError)
+
+
+def _env_has(name):
+    return (name.encode() in _ENV) if _ENV is not None else (name in os.environ)
+
+
 def speculation_enabled(pose_package):
     """Whether a drop-in forward carries depth bounds from one call to the next (gsr_forward_speculative).
     Default: on for the pose package (its caller renders the same frame fifty times, a few millimetres apart), off for
     package (A) (train.py picks a random camera every step: every guess would miss, and each cached state pins
     ~17 KB per tile of device memory).  GSR_SPECULATION=1 / 0 forces it on / off for both."""
-    v = os.environ.get("GSR_SPECULATION")
-    return bool(pose_package) if v is None else v != "0"
+    if not _env_has("GSR_SPECULATION"):
+        return bool(pose_package)
+    return os.environ.get("GSR_SPECULATION") != "0"
 
 
 def speculation_counters(device=None):
@@ -182,34 +190,83 @@ def _workspace_sizes(lib, P, W, H):
     return hit or None
 
 
+class _CallBlocks(threading.local):
+    """Per host thread (the forward runs on the caller's thread, the backward on autograd's worker): the argument blocks of
+    gsr_forward_packed / gsr_backward_packed and the three fixed-buffer descriptors, allocated once and updated in place.
+    ctypes converts and checks every argument of a call -- 34 of them cost ~100 us, more than the forward's launches; a struct
+    field assignment costs a quarter of a microsecond and the call itself carries one pointer."""
+
+    def __init__(self):
+        self.fa = _lib.ForwardArgs()
+        self.ba = _lib.BackwardArgs()
+        self.fb = (_lib.FixedBuffer * 3)()
+        self.fa_ref = C.byref(self.fa)
+        self.ba_ref = C.byref(self.ba)
+        self.fb_addr = [C.addressof(self.fb[k]) for k in range(3)]
+
+
+_blocks = _CallBlocks()
+_F32 = torch.float32
+
+
 def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp, rs, want_touched):
     lib = _lib.load()
-    _require_gpu(means3D)
+    if not means3D.is_cuda:
+        _require_gpu(means3D)
     if means3D.dim() != 2 or means3D.size(1) != 3:
         raise RuntimeError("means3D must have dimensions (num_points, 3)")
     dev = means3D.device
     P = means3D.size(0)
     H, W = int(rs.image_height), int(rs.image_width)
-    means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp = (
-        _f32c(t) for t in (means3D, sh, colors_precomp, opacities, scales, rotations, cov3Ds_precomp))
-    bg, view, proj, campos = (_f32c(t.to(dev)) for t in (rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos))
-    images = torch.empty((5, H, W), dtype=torch.float32, device=dev)      # one allocation: colour | depth | opacity
+    # (float32 + contiguous is the usual case: checked inline, converted only when needed)
+    ok = lambda t: t.dtype is _F32 and t.is_contiguous()
+    if not ok(means3D): means3D = _f32c(means3D)
+    if not ok(sh): sh = _f32c(sh)
+    if not ok(colors_precomp): colors_precomp = _f32c(colors_precomp)
+    if not ok(opacities): opacities = _f32c(opacities)
+    if not ok(scales): scales = _f32c(scales)
+    if not ok(rotations): rotations = _f32c(rotations)
+    if not ok(cov3Ds_precomp): cov3Ds_precomp = _f32c(cov3Ds_precomp)
+    bg, view, proj, campos = rs.bg, rs.viewmatrix, rs.projmatrix, rs.campos
+    if not (bg.device == dev and ok(bg)): bg = _f32c(bg.to(dev))
+    if not (view.device == dev and ok(view)): view = _f32c(view.to(dev))
+    if not (proj.device == dev and ok(proj)): proj = _f32c(proj.to(dev))
+    if not (campos.device == dev and ok(campos)): campos = _f32c(campos.to(dev))
+    images = torch.empty((5, H, W), dtype=_F32, device=dev)      # one allocation: colour | depth | opacity
     color, depth, alpha = images[0:3], images[3:4], images[4:5]
-    radii = torch.empty((P,), dtype=torch.int32, device=dev)
-    n_touched = torch.empty((P,), dtype=torch.int32, device=dev) if want_touched else None
-    M = sh.size(1) if sh.numel() != 0 else 0
+    ints = torch.empty((2 if want_touched else 1, P), dtype=torch.int32, device=dev)      # radii | n_touched
+    radii = ints[0]
+    n_touched = ints[1] if want_touched else None
+    n_sh = sh.numel()
+    M = sh.size(1) if n_sh != 0 else 0
     stream = torch.cuda.current_stream(dev).cuda_stream
-    spec = C.byref(_spec_cache.get(lib, dev, stream, W, H)) if (P > 0 and speculation_enabled(want_touched)) else None
-    dbg = int(bool(rs.debug)) | (2 if "GSR_SH_EAGER" in os.environ else 0)
-
-    def call(fn_g, ctx_g, fn_b, ctx_b, fn_i, ctx_i):
-        with torch.cuda.device(dev):
-            return lib.gsr_forward_speculative(spec, fn_g, ctx_g, fn_b, ctx_b, fn_i, ctx_i, P, int(rs.sh_degree), M, _ptr(bg),
-                                               W, H, _ptr(means3D), _ptr(sh), _ptr(colors_precomp), _ptr(opacities), _ptr(scales),
-                                               float(rs.scale_modifier), _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(view),
-                                               _ptr(proj), _ptr(campos), float(rs.tanfovx), float(rs.tanfovy),
-                                               int(bool(rs.prefiltered)), color.data_ptr(), depth.data_ptr(), alpha.data_ptr(),
-                                               _ptr(radii), dbg, _ptr(n_touched), stream)
+    blk = _blocks
+    a = blk.fa
+    a.state = C.addressof(_spec_cache.get(lib, dev, stream, W, H)) if (P > 0 and speculation_enabled(want_touched)) else None
+    a.P, a.D, a.M = P, int(rs.sh_degree), M
+    a.background = bg.data_ptr()
+    a.width, a.height = W, H
+    nz = P > 0
+    a.means3D = means3D.data_ptr() if nz else None
+    a.shs = sh.data_ptr() if n_sh != 0 else None
+    a.colors_precomp = colors_precomp.data_ptr() if colors_precomp.numel() != 0 else None
+    a.opacities = opacities.data_ptr() if nz else None
+    a.scales = scales.data_ptr() if scales.numel() != 0 else None
+    a.scale_modifier = float(rs.scale_modifier)
+    a.rotations = rotations.data_ptr() if rotations.numel() != 0 else None
+    a.cov3D_precomp = cov3Ds_precomp.data_ptr() if cov3Ds_precomp.numel() != 0 else None
+    a.viewmatrix, a.projmatrix, a.cam_pos = view.data_ptr(), proj.data_ptr(), campos.data_ptr()
+    a.tan_fovx, a.tan_fovy = float(rs.tanfovx), float(rs.tanfovy)
+    a.prefiltered = int(bool(rs.prefiltered))
+    base = images.data_ptr()
+    N4 = 4 * H * W
+    a.out_color, a.out_depth, a.out_alpha = base, base + 3 * N4, base + 4 * N4
+    a.radii = radii.data_ptr() if nz else None
+    a.debug = int(bool(rs.debug)) | (2 if _env_has("GSR_SH_EAGER") else 0)
+    a.n_touched = (ints.data_ptr() + 4 * P) if (want_touched and nz) else None
+    a.stream = stream
+    # (the library selects the device that owns means3D itself; torch's current device only matters for the allocations above,
+    # which name theirs explicitly)
 
     # The three workspaces.  Where their sizes are known before the call (per-tile bins: every image up to 2 048 tiles) they are
     # allocated here and handed over through the library's own fixed-buffer callback -- no callback into the interpreter; the
@@ -217,24 +274,28 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     # reference's is; a bin that overflowed).
     geom_t = bin_t = img_t = None
     rc = None
-    sizes = _workspace_sizes(lib, P, W, H) if P > 0 else None
+    sizes = _workspace_sizes(lib, P, W, H) if nz else None
     if sizes is not None:
         bufs = [torch.empty(n, dtype=torch.uint8, device=dev) for n in sizes]
-        fb = (_lib.FixedBuffer * 3)()
+        fb = blk.fb
         for k in range(3):
             fb[k].ptr, fb[k].capacity = bufs[k].data_ptr(), sizes[k]
         ff = _lib.fixed_buffer_fn()
-        rc = call(ff, C.addressof(fb[0]), ff, C.addressof(fb[1]), ff, C.addressof(fb[2]))
+        a.geometry_buffer = a.binning_buffer = a.image_buffer = ff
+        a.geometry_ctx, a.binning_ctx, a.image_ctx = blk.fb_addr
+        rc = lib.gsr_forward_packed(blk.fa_ref)
         if rc == _lib.E_ALLOC:
             rc = None
         else:
             geom_t, bin_t, img_t = bufs
     if rc is None:
         geom, binning, img = _Workspace(dev), _Workspace(dev), _Workspace(dev)
-        rc = call(geom.fn, geom.ctx, binning.fn, binning.ctx, img.fn, img.ctx)
+        a.geometry_buffer, a.binning_buffer, a.image_buffer = geom.fn, binning.fn, img.fn
+        a.geometry_ctx, a.binning_ctx, a.image_ctx = geom.ctx, binning.ctx, img.ctx
+        rc = lib.gsr_forward_packed(blk.fa_ref)
         _Workspace.raise_pending(geom, binning, img)          # e.g. torch's out-of-memory error, not a bare GSR_E_ALLOC
         geom_t, bin_t, img_t = geom.t, binning.t, img.t
-    num_rendered = _lib.check(rc)
+    num_rendered = rc if rc >= 0 else _lib.check(rc)
     saved = (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_t, bin_t, img_t, alpha,
              opacities)
     consts = (bg, view, proj, campos)
@@ -247,42 +308,63 @@ def _backward_impl(rs, num_rendered, saved, consts, grad_color, grad_depth, grad
     bg, view, proj, campos = consts
     dev = means3D.device
     P = means3D.size(0)
-    M = sh.size(1) if sh.numel() != 0 else 0
+    n_sh = sh.numel()
+    M = sh.size(1) if n_sh != 0 else 0
     H, W = int(rs.image_height), int(rs.image_width)
-    grad_color, grad_depth, grad_alpha = (_f32c(g) for g in (grad_color, grad_depth, grad_alpha))
+    ok = lambda t: t.dtype is _F32 and t.is_contiguous()
+    if not ok(grad_color): grad_color = _f32c(grad_color)
+    if not ok(grad_depth): grad_depth = _f32c(grad_depth)
+    if not ok(grad_alpha): grad_alpha = _f32c(grad_alpha)
     # All gradient tensors are slices of ONE allocation, the 16-byte-aligned ones first: the library then zero-fills the whole
     # block with a single memset instead of ten (host time is what the reference-style loop is short of).
     want_sh = bool(need["sh"] and M > 0)
-    shapes = [("conic", (P, 2, 2)), ("rot", (P, 4) if need["rotations"] else None), ("sh", (P, M, 3) if want_sh else None),
-              ("m2d", (P, 3)), ("m3d", (P, 3)), ("cov", (P, 6)), ("col", (P, 3)), ("scale", (P, 3) if need["scales"] else None),
-              ("opac", (P, 1)), ("tau", (8,) if pose_mode else None)]
-    total = sum(int(torch.Size(shp).numel()) for _, shp in shapes if shp is not None)
-    flat = torch.empty((total,), dtype=torch.float32, device=dev)
-    out, off = {}, 0
-    for name, shp in shapes:
-        if shp is None:
-            out[name] = None
-            continue
-        n = int(torch.Size(shp).numel())
-        out[name] = flat[off:off + n].view(shp)
-        off += n
-    dL_dconic, dL_drotations, dL_dsh, dL_dmeans2D, dL_dmeans3D, dL_dcov3D, dL_dcolors, dL_dscales, dL_dopacity = (
-        out[k] for k in ("conic", "rot", "sh", "m2d", "m3d", "cov", "col", "scale", "opac"))
-    dL_dtau = out["tau"][:6] if pose_mode else None
-    e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
-    stream = torch.cuda.current_stream(dev).cuda_stream
-    with torch.cuda.device(dev):
-        rc = lib.gsr_backward(P, int(rs.sh_degree), M, int(num_rendered), _ptr(bg), W, H, _ptr(means3D), _ptr(sh),
-                              _ptr(colors_precomp), _ptr(alpha), _ptr(scales), float(rs.scale_modifier),
-                              _ptr(rotations), _ptr(cov3Ds_precomp), _ptr(view), _ptr(proj), _ptr(campos),
-                              float(rs.tanfovx), float(rs.tanfovy), _ptr(radii), _ptr(geomBuffer), _ptr(binningBuffer),
-                              _ptr(imgBuffer), _ptr(grad_color), _ptr(grad_depth), _ptr(grad_alpha), _ptr(dL_dmeans2D),
-                              _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D), _ptr(dL_dcov3D),
-                              _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations), int(bool(rs.debug)) | (4 if "GSR_DETERMINISTIC" in os.environ else 0),
-                              1 if pose_mode else 0, _ptr(dL_dtau), stream)
-    _lib.check(rc)
+    want_rot, want_scale = bool(need["rotations"]), bool(need["scales"])
+    # floats per Gaussian, in block order: conic 4 | rot 4 | sh 3M | m2d 3 | m3d 3 | cov 6 | col 3 | scale 3 | opac 1   (+ 8 for tau)
+    widths = (4, 4 if want_rot else 0, 3 * M if want_sh else 0, 3, 3, 6, 3, 3 if want_scale else 0, 1)
+    total = P * sum(widths) + (8 if pose_mode else 0)
+    flat = torch.empty((total,), dtype=_F32, device=dev)
+    parts = flat.split([P * w for w in widths] + ([8] if pose_mode else []))
+    dL_dconic = parts[0].view(P, 2, 2)
+    dL_drotations = parts[1].view(P, 4) if want_rot else None
+    dL_dsh = parts[2].view(P, M, 3) if want_sh else None
+    dL_dmeans2D, dL_dmeans3D = parts[3].view(P, 3), parts[4].view(P, 3)
+    dL_dcov3D, dL_dcolors = parts[5].view(P, 6), parts[6].view(P, 3)
+    dL_dscales = parts[7].view(P, 3) if want_scale else None
+    dL_dopacity = parts[8].view(P, 1)
+    dL_dtau = parts[9][:6] if pose_mode else None
+    b = _blocks.ba
+    b.P, b.D, b.M, b.R = P, int(rs.sh_degree), M, int(num_rendered)
+    b.background = bg.data_ptr()
+    b.width, b.height = W, H
+    nz = P > 0
+    b.means3D = means3D.data_ptr() if nz else None
+    b.shs = sh.data_ptr() if n_sh != 0 else None
+    b.colors_precomp = colors_precomp.data_ptr() if colors_precomp.numel() != 0 else None
+    b.alphas = alpha.data_ptr()
+    b.scales = scales.data_ptr() if scales.numel() != 0 else None
+    b.scale_modifier = float(rs.scale_modifier)
+    b.rotations = rotations.data_ptr() if rotations.numel() != 0 else None
+    b.cov3D_precomp = cov3Ds_precomp.data_ptr() if cov3Ds_precomp.numel() != 0 else None
+    b.viewmatrix, b.projmatrix, b.campos = view.data_ptr(), proj.data_ptr(), campos.data_ptr()
+    b.tan_fovx, b.tan_fovy = float(rs.tanfovx), float(rs.tanfovy)
+    b.radii = radii.data_ptr() if nz else None
+    b.geom_buffer, b.binning_buffer, b.img_buffer = _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imgBuffer)
+    b.dL_dpix, b.dL_ddepths, b.dL_dalphas = grad_color.data_ptr(), grad_depth.data_ptr(), grad_alpha.data_ptr()
+    f0 = flat.data_ptr() if total else 0
+    offs, off = [], 0
+    for w in widths:
+        offs.append((f0 + 4 * off) if (w and nz) else None)
+        off += P * w
+    (b.dL_dconic, b.dL_drot, b.dL_dsh, b.dL_dmean2D, b.dL_dmean3D, b.dL_dcov3D, b.dL_dcolor, b.dL_dscale, b.dL_dopacity) = offs
+    b.debug = int(bool(rs.debug)) | (4 if _env_has("GSR_DETERMINISTIC") else 0)
+    b.pose_mode = 1 if pose_mode else 0
+    b.dL_dtau = (f0 + 4 * off) if pose_mode else None
+    b.stream = torch.cuda.current_stream(dev).cuda_stream
+    rc = lib.gsr_backward_packed(_blocks.ba_ref)
+    if rc < 0:
+        _lib.check(rc)
     if dL_dsh is None and need["sh"]:
-        dL_dsh = e(P, M, 3)
+        dL_dsh = torch.empty((P, M, 3), dtype=_F32, device=dev)
     return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau
 
 
@@ -394,8 +476,11 @@ def _check_inputs(shs, colors_precomp, scales, rotations, cov3D_precomp):
         raise Exception('Please provide exactly one of either scale/rotation pair or precomputed 3D covariance!')
 
 
+_EMPTY = torch.Tensor([])      # the reference's "absent" convention (an empty tensor); one shared instance instead of five per call
+
+
 def _empty_if_none(*ts):
-    return tuple(torch.Tensor([]) if t is None else t for t in ts)
+    return tuple(_EMPTY if t is None else t for t in ts)
 
 
 class GaussianRasterizer(nn.Module):

@@ -29,10 +29,11 @@
 extern "C" {
 #endif
 
-/* 2: gsr_refine_args gained `carry_state` (round 2) and the fields behind `stream` (flags, lean_min_P); stats_out is int[4];
+/* 3: gsr_forward_packed / gsr_backward_packed (one struct pointer instead of 34 / 40 arguments).
+ * 2: gsr_refine_args gained `carry_state` (round 2) and the fields behind `stream` (flags, lean_min_P); stats_out is int[4];
  *    pose-state words 41 (ticket) and 84..87 (Adam beta products); gsr_debug_lean_check.  A caller must compare
  *    gsr_abi_version() with the GSR_ABI_VERSION it was compiled against before it passes any struct. */
-#define GSR_ABI_VERSION 2
+#define GSR_ABI_VERSION 3
 
 enum {
     GSR_OK = 0,
@@ -174,6 +175,52 @@ int gsr_backward(int P, int D, int M, int R,
                  int pose_mode,
                  float* dL_dtau,
                  void* stream);
+
+/* The same two entry points for callers whose foreign-function layer is slow per ARGUMENT (Python's ctypes converts and checks
+ * every one of the 34 / 40 scalars and pointers: ~100 us per call, more than the launches): all arguments in one struct the caller
+ * keeps and updates in place, ONE pointer across the boundary.  Field for field the parameters of gsr_forward_speculative /
+ * gsr_backward above, same meaning, same order (rasterizer.h:31-89); nothing is retained after the call returns.
+ * (GSR_ABI_VERSION 3.) */
+typedef struct gsr_forward_args {
+    gsr_spec_state* state;             /* NULL: plain gsr_forward */
+    gsr_resize_fn geometry_buffer; void* geometry_ctx;
+    gsr_resize_fn binning_buffer; void* binning_ctx;
+    gsr_resize_fn image_buffer; void* image_ctx;
+    int P, D, M;
+    const float* background;
+    int width, height;
+    const float* means3D; const float* shs; const float* colors_precomp; const float* opacities;
+    const float* scales; float scale_modifier; const float* rotations; const float* cov3D_precomp;
+    const float* viewmatrix; const float* projmatrix; const float* cam_pos;
+    float tan_fovx, tan_fovy;
+    int prefiltered;
+    float* out_color; float* out_depth; float* out_alpha;
+    int* radii;
+    int debug;
+    int* n_touched;
+    void* stream;
+} gsr_forward_args;
+int gsr_forward_packed(const gsr_forward_args* args);
+
+typedef struct gsr_backward_args {
+    int P, D, M, R;
+    const float* background;
+    int width, height;
+    const float* means3D; const float* shs; const float* colors_precomp; const float* alphas;
+    const float* scales; float scale_modifier; const float* rotations; const float* cov3D_precomp;
+    const float* viewmatrix; const float* projmatrix; const float* campos;
+    float tan_fovx, tan_fovy;
+    const int* radii;
+    char* geom_buffer; char* binning_buffer; char* img_buffer;
+    const float* dL_dpix; const float* dL_ddepths; const float* dL_dalphas;
+    float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;
+    float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;
+    int debug;
+    int pose_mode;
+    float* dL_dtau;
+    void* stream;
+} gsr_backward_args;
+int gsr_backward_packed(const gsr_backward_args* args);
 
 /* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer.h:24-29, rasterizer_impl.cu:141-153).
  * present [P] uint8 (0/1). */

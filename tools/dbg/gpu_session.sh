@@ -24,5 +24,9 @@ case $step in
   plain)         # quick A/B numbers of the complete-list path: it/s + per-kernel HIP-event times
     for sc in s_1m_640 s_3m_cam s_3m_cam_1024; do SCENE=$sc LOOP_PLAIN=1 python tools/loop_only.py 100 2>/dev/null | tail -1; done > $o/plain$1.log
     python tools/dbg/train_kernels.py 2>/dev/null | tail -2 >> $o/plain$1.log ;;
+  timing)        # phase clocks of the complete-list path (diagnostic build; the box is thrown away afterwards)
+    GSR_TIMING=1 python gs_localization_amd/build.py > /dev/null 2>&1
+    for sc in ${@:-s_1m_640 s_3m_cam}; do echo "== $sc plain"; SCENE=$sc LOOP_PLAIN=1 python tools/phase_timing.py 2>/dev/null | grep -v amdgpu; done > $o/timing_plain.log
+    python gs_localization_amd/build.py > /dev/null 2>&1 ;;
   *) echo "unknown step $step" ;;
 esac

@@ -6,7 +6,7 @@ import numpy as np, torch
 from gs_localization_amd import _lib, scenes as S
 from tests import replay as PL
 lib = _lib.load(); dev = torch.device("cuda:0")
-sc = S.s_1m_640(); H, W = sc.H, sc.W
+sc = getattr(S, os.environ.get("SCENE", "s_1m_640"))(); H, W = sc.H, sc.W
 model = PL.GaussianMap.from_scene(sc, device=dev)
 bg = torch.zeros(3, device=dev)
 vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, dev), sc, dev)
@@ -29,19 +29,24 @@ ms = (C.c_double * nk)(); cnt = (C.c_longlong * nk)(); lib.gsr_profile_collect(m
 print({names[i]: (round(ms[i] / max(cnt[i], 1), 4), cnt[i]) for i in range(nk)})
 lib.gsr_debug_timing(out)
 v = [int(x) for x in out]
-nw = 1200 * 4 * ITERS        # waves (K7); the packed forward kernel has 2 per tile
+NT = ((W + 15) // 16) * ((H + 15) // 16)
+nw = NT * 4 * ITERS        # waves (K7); the packed forward kernel has 2 per tile
 def show(name, base, labels):
     print(name, "(cycles per wave, mean)")
     tot = 0
     for i, l in enumerate(labels):
         if l: print("  %-28s %10.0f" % (l, v[base + i] / nw)); tot += v[base + i] / nw if i < 9 else 0
     print("  %-28s %10.0f" % ("sum of phases", tot))
-nw = 1200 * 4 * ITERS
+nw = NT * 4 * ITERS
 show("k_render_fwd", 0, ["bins load", "sort + writeback", "batch top (barrier_and)", "staging gathers + barrier", "compaction", "compositing loop",
                          "after loop", "epilogue after barrier_or", "entries no live pixel needed", "(wave lifetime)", "batches", "loop iterations"])
-nw = 1200 * 4 * ITERS
+nw = NT * 4 * ITERS
 show("k_render_bwd_mfma", 16, ["prologue", "batch top barrier", "staging + barrier", "compaction", "weights (8 splats)", "mfma + lds atomics",
                                "(loop exit)", "barrier after groups", "recombine + global atomics", "(wave lifetime)", "batches", "list entries"])
+if os.environ.get("LOOP_PLAIN"):
+    nw = (sc.P + 2047) // 2048 * 8 * (ITERS + 0)      # k_preprocess_bin: 8 waves per 2 048 Gaussians
+    show("k_preprocess_bin", 32, ["geometry (preprocess_one x 4)", "barrier", "count walk", "barrier", "reserve (global atomics)", "barrier before a band", "emit walk (all bands)",
+                                  "", "", "(wave lifetime)", "", ""])
 nw = (sc.P + 255) // 256 * ITERS      # one wave per 256 Gaussians
 show("k_preprocess_lean", 32, ["bounds -> LDS + barrier", "conservative pass (4 x 64 Gaussians)", "exact pass on the compacted candidates", "", "",
                                "", "", "", "", "(wave lifetime)", "candidates", ""])
