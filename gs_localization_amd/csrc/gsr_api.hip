@@ -107,6 +107,7 @@ struct Geom {   // per-Gaussian state carried from forward to backward
     gsr::SurvLists surv;      // work lists of the forward's survivors (k_preprocess -> k_sh_color, k_preprocess_bwd)
     float* rec;               // packed splat records (GSR_REC_*), P + 1
     float* lam;               // per-Gaussian float4 (mean, bound on sqrt(lambda_max(Sigma))) (PreArgs::lam), valid whenever cov3D holds every covariance
+    uint8_t* aflag;           // 2 n bytes: "the compositing backward added to this Gaussian's record / to its colour sums" (K7 sets, K8 clears)
 };
 size_t carve_geom(char* base, int P, Geom& g)
 {
@@ -124,6 +125,7 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.surv.n = c.take<uint32_t>((size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE);
     g.surv.ids = c.take<uint32_t>((size_t)GSR_SURV_LISTS * g.surv.cap);
     g.lam = c.take<float>(4 * n);
+    g.aflag = c.take<uint8_t>(2 * n);
     return c.size();
 }
 
@@ -845,6 +847,7 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         ProfScope psz(K_BWD_ZERO, st);
         HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * (cx.det ? 2 * sizeof(long long) : sizeof(float)), st));
         if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, (cx.det ? 16 : 8) * GSR_TAU_SLOTS * sizeof(double), st));
+        HIPCHK(hipMemsetAsync(g.aflag, 0, 2 * (size_t)P, st));
     }
     {
         ProfScope psb(K_RENDER_BWD, st);
@@ -853,8 +856,8 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         const bool balanced = cx.balance && cx.native_loop && ntiles <= GSR_ORDER_MAX_TILES;
         const uint32_t* order = balanced ? im.tile_order[1] : nullptr;
         uint32_t* work = balanced ? im.tile_work[1] : nullptr;
-        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0);
-        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0);
+        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag);
+        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag);
 #undef GSR_BWD_ARGS
     }
     LAUNCHCHK("k_render_bwd");
@@ -873,6 +876,7 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     pb.dL_dmean3D = dL_dmean3D; pb.dL_dcov3D = dL_dcov3D; pb.dL_dsh = dL_dsh; pb.dL_dscale = dL_dscale; pb.dL_drot = dL_drot;
     pb.pose = pose_mode ? 1 : 0; pb.tau_acc = g.tau_acc;
     pb.dirty = cx.native_loop ? g.dirty : nullptr;
+    pb.aflag = g.aflag;
     pb.guard = cx.guard;
     pb.ticket = cx.ticket; pb.fold = cx.fold;
     if (pb.ticket) pb.fold.tau_acc = g.tau_acc;
@@ -1138,6 +1142,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             // K7's accumulator records: cleared once here, afterwards K8 clears every record it consumes
             HIPCHK(hipMemsetAsync(gg.acc, 0, Pn * GSR_ACC_STRIDE * (cx.det ? 2 * sizeof(long long) : sizeof(float)), st));
             HIPCHK(hipMemsetAsync(gg.dirty, 0, Pn, st));
+            HIPCHK(hipMemsetAsync(gg.aflag, 0, 2 * Pn, st));
         }
         if (a->init_R) {
             if (!a->init_T || !a->init_exposure_a || !a->init_exposure_b) return fail(GSR_E_INVALID, "gsr_refine: init_R, init_T, init_exposure_a/b go together%s", "");

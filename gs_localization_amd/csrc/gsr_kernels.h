@@ -17,6 +17,17 @@ __device__ unsigned long long g_tim[4][GSR_TIM_WAVES][12];      // [kernel][wave
 #define GSR_T_DECL long long t_prev_ = clock64(); const long long t_start_ = t_prev_; long long t_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
 #define GSR_T_TICK(slot) { const long long now_ = clock64(); t_acc_[slot] += now_ - t_prev_; t_prev_ = now_; }
 #define GSR_T_COUNT(slot, v) { t_acc_[slot] += (v); }
+// -DGSR_TIMING_ORDER: slots 4 / 6 / 7 of k_render_fwd show the lazy ordering's sub-phases (sample + threshold search, gather pass, sort)
+// instead; what they usually hold is added to slot 5
+#define GSR_T_PARAMS , long long& t_prev_, long long (&t_acc_)[12]
+#define GSR_T_ARGS , t_prev_, t_acc_
+#ifdef GSR_TIMING_ORDER
+#define GSR_TO(slot) 5
+#define GSR_T_TICK_O(slot) GSR_T_TICK(slot)
+#else
+#define GSR_TO(slot) slot
+#define GSR_T_TICK_O(slot)
+#endif
 #define GSR_T_FLUSH(base) t_acc_[9] = clock64() - t_start_; if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < GSR_TIM_WAVES) { for (int q_ = 0; q_ < 12; q_++) g_tim[(base) / 16][blockIdx.x * 4 + (threadIdx.x >> 6)][q_] += (unsigned long long)t_acc_[q_]; }
 // (workgroups of `wpb` waves)
 #define GSR_T_FLUSH_W(base, wpb) t_acc_[9] = clock64() - t_start_; if ((threadIdx.x & 63) == 0 && blockIdx.x * (wpb) + (threadIdx.x >> 6) < GSR_TIM_WAVES) { for (int q_ = 0; q_ < 12; q_++) g_tim[(base) / 16][blockIdx.x * (wpb) + (threadIdx.x >> 6)][q_] += (unsigned long long)t_acc_[q_]; }
@@ -26,6 +37,10 @@ __device__ unsigned long long g_tim[4][GSR_TIM_WAVES][12];      // [kernel][wave
 #define GSR_T_COUNT(slot, v)
 #define GSR_T_FLUSH(base)
 #define GSR_T_FLUSH_W(base, wpb)
+#define GSR_T_TICK_O(slot)
+#define GSR_TO(slot) slot
+#define GSR_T_PARAMS
+#define GSR_T_ARGS
 #endif
 
 // Device-side guards of the native refinement loop (gsr_refine).  The host enqueues kernel GROUPS (preprocess, compositing,
@@ -1102,6 +1117,9 @@ __global__ void __launch_bounds__(64) k_sh_color(PreArgs a)
 // are in flight -- 16 waves per workgroup, two workgroups per CU -- while the LDS counters still aggregate a few thousand
 // Gaussians.
 #define GSR_TBIN_THREADS 1024
+#ifndef GSR_RESERVE_ROT
+#define GSR_RESERVE_ROT 67u      // workgroup b starts its reservation atomics at tile (b x this) mod ntiles (0: everybody at tile 0)
+#endif
 struct TileBinArgs {
     int P, gx, gy, ntiles, gpb;                    // gpb: Gaussians per workgroup (multiple of GSR_TBIN_THREADS)
     int copies;                                    // private copies of the per-tile counters (1 ... GSR_TBIN_COPIES)
@@ -1306,10 +1324,23 @@ __global__ void __launch_bounds__(GSR_TBIN_THREADS) k_tile_emit(TileBinArgs a, i
         uint32_t* s_base = s_tb + a.ntiles;
         const size_t copy = (size_t)(blockIdx.x % a.copies) * a.ntiles;
         const uint16_t* row = a.block_counts + (size_t)blockIdx.x * a.ntiles;
-        for (int t = threadIdx.x; t < a.ntiles; t += GSR_TBIN_THREADS) {
-            const uint32_t c = row[t];          // what this workgroup counted for the tile (k_tile_count): reserve that much
-            s_base[t] = (c != 0u) ? a.tile_offset[t] + a.tile_start[copy + t] + atomicAdd(&a.tile_fill[copy + t], c) : 0u;
-            s_cnt[t] = 0u;
+        // (four returning atomics in flight per lane, every workgroup starting at another tile: see k_preprocess_bin)
+        const int rot = (int)((blockIdx.x * GSR_RESERVE_ROT) % (uint32_t)a.ntiles);
+        for (int t0 = threadIdx.x; t0 < a.ntiles; t0 += 4 * GSR_TBIN_THREADS) {
+            int tt[4];
+            uint32_t c[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int t = t0 + j * GSR_TBIN_THREADS;
+                tt[j] = (t < a.ntiles) ? ((t + rot >= a.ntiles) ? t + rot - a.ntiles : t + rot) : -1;
+                c[j] = (tt[j] >= 0) ? row[tt[j]] : 0u;          // what this workgroup counted for the tile (k_tile_count): reserve that much
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                b[j] = (c[j] != 0u) ? a.tile_offset[tt[j]] + a.tile_start[copy + tt[j]] + atomicAdd(&a.tile_fill[copy + tt[j]], c[j]) : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (tt[j] >= 0) { s_base[tt[j]] = b[j]; s_cnt[tt[j]] = 0u; }
         }
         WalkItem it[KPT];
         walk_load<KPT>(a, 0, it);
@@ -1383,10 +1414,26 @@ __global__ void __launch_bounds__(GSR_PBIN_THREADS) k_preprocess_bin(PreArgs a, 
     GSR_T_TICK(2)
     __syncthreads();
     GSR_T_TICK(3)
-    for (int t = tid; t < a.ntiles; t += GSR_PBIN_THREADS) {
-        const uint32_t c = s_cnt[t];
-        s_base[t] = (c != 0u) ? atomicAdd(&a.tile_cursor[t * GSR_CURSOR_STRIDE], c) : 0u;
-        s_cnt[t] = 0u;
+    // One returning atomic per (workgroup, tile): four in flight per lane (a round trip to the memory-side atomic unit is ~10 k
+    // cycles: one after the other they were a fifth of this kernel), and every workgroup starts at another tile so that the
+    // chip's ~500 workgroups do not walk the cursors in lockstep.
+    {
+        const int rot = (int)((blockIdx.x * GSR_RESERVE_ROT) % (uint32_t)a.ntiles);
+        for (int t0 = tid; t0 < a.ntiles; t0 += 4 * GSR_PBIN_THREADS) {
+            int tt[4];
+            uint32_t c[4], b[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int t = t0 + j * GSR_PBIN_THREADS;
+                tt[j] = (t < a.ntiles) ? ((t + rot >= a.ntiles) ? t + rot - a.ntiles : t + rot) : -1;
+                c[j] = (tt[j] >= 0) ? s_cnt[tt[j]] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; j++) b[j] = (c[j] != 0u) ? atomicAdd(&a.tile_cursor[tt[j] * GSR_CURSOR_STRIDE], c[j]) : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (tt[j] >= 0) { s_base[tt[j]] = b[j]; s_cnt[tt[j]] = 0u; }
+        }
     }
     GSR_T_TICK(4)
     const int bh = (a.gy + bands - 1) / bands;
@@ -1506,6 +1553,11 @@ struct SplatLDS {
 #define GSR_SLICE_FIRST 512        // GSR_LIST_EXACT: the first slice aims at this many keys (most tiles saturate within it),
 #define GSR_SLICE_ALL 1024         // unless the whole segment is no longer than this; later slices take up to GSR_LSORT_CAP
 #define GSR_SEL_BITS 11            // radix of the selection histogram (2048 counters, aliased onto the key buffer)
+#ifndef GSR_SLICE_WANT0
+#define GSR_SLICE_WANT0 200        // sample_slice: keys the first slice aims at (<= 256 sort in registers), the second, the later ones
+#endif
+#define GSR_SLICE_WANT1 448
+#define GSR_SLICE_WANT2 1800
 
 // Bitonic sort of s_keys[0, npow) (npow a power of two >= 64), ascending; all GSR_BLOCK threads.
 // (measured: a rank sort and a variant with wave-local steps and 3 barriers instead of 45 are no faster --
@@ -1625,6 +1677,109 @@ __device__ __forceinline__ void select_slice(const unsigned long long* __restric
     }
 }
 
+// Lazy slices, round 4: pick the next slice with ONE pass over the tile's keys instead of two to four.
+// select_slice above finds an exact rank threshold by most-significant-digit radix selection: every pass re-reads the tile's ~2 800
+// keys from global memory and pushes each through an LDS atomic (64 k of a wave's 154 k cycles on S-1M-640's complete lists, 141 k of
+// 237 k on S-3M-cam's; 157 MB of HBM traffic per launch for 27 MB of keys).  But a slice does not need an exact rank -- any depth
+// threshold that admits "a couple of hundred" keys will do.  So: the first 1 024 keys of the segment (arrival order, i.e. a sample
+// that is unrelated to depth) go through LDS into registers, sixteen per lane, in EVERY wave; each wave bisects on the depth bits
+// until the sample count below the threshold matches the wanted share (wave ballots + scalar popcounts: no barrier, no atomics,
+// the four waves arrive at the same threshold because they run the same arithmetic on the same data); then one coalesced pass over
+// all keys gathers those at or below the threshold into s_keys with a ballot prefix per wave (one LDS atomic per wave and 256 keys).
+// Returns the number gathered (block-uniform; 0 = sample empty, > cap = the caller must retry with a smaller share or fall back to
+// select_slice -- thousands of keys sharing one depth).  hi = the slice's upper key bound.  s_samp: 1 024 words of LDS.
+__device__ __forceinline__ int sample_slice(const unsigned long long* __restrict__ keys, int total, bool first, unsigned long long lo, int remaining,
+                                            int want, int cap, uint32_t* s_samp, unsigned long long* s_keys, unsigned long long& hi GSR_T_PARAMS)
+{
+    __shared__ uint32_t s_fill;
+    const int tid = threadIdx.x, lane = tid & 63;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int i = tid + GSR_BLOCK * j;
+        uint32_t d = 0xFFFFFFFFu;
+        if (i < total) {
+            const unsigned long long k = keys[i];
+            if (first || k > lo) d = (uint32_t)(k >> 32);
+        }
+        s_samp[i] = d;
+    }
+    if (tid == 0) s_fill = 0u;
+    __syncthreads();
+    uint32_t v[16];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const uint4 x = reinterpret_cast<const uint4*>(s_samp)[lane + 64 * q];
+        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+    }
+    int nvalid = 0;
+    uint32_t vmin = 0xFFFFFFFFu, vmax = 0u;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        const bool ok = v[q] != 0xFFFFFFFFu;
+        nvalid += (int)__popcll(__ballot(ok));
+        vmin = min(vmin, v[q]);
+        vmax = ok ? max(vmax, v[q]) : vmax;
+    }
+    if (nvalid == 0) { hi = lo; return 0; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        vmin = min(vmin, (uint32_t)__shfl_xor((int)vmin, off, 64));
+        vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off, 64));
+    }
+    uint32_t pivot;
+    if (remaining <= want) pivot = 0xFFFFFFFEu;              // everything that is left
+    else {
+        // share of the sample that stands for `want` of the `remaining` keys; accepted up to an eighth above it
+        const int r = max(1, min(nvalid, (int)(((long long)want * nvalid + remaining - 1) / remaining)));
+        const int tol = r >> 3;
+        uint32_t lo_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)vmin), hi_b = (uint32_t)__builtin_amdgcn_readfirstlane((int)vmax);
+        // Bisection on the depth bits: invariant count(<= hi_b) >= r, count(< lo_b) < r; it stops as soon as a probe's count lies in
+        // [r, r + r / 8] -- eight to ten probes, each sixteen compares per lane and their ballots' popcounts on the scalar unit.
+        // (Interpolating the probe between the bracket's counts, on the depth values, needs three or four probes and measured the
+        // same: the phase is the sample's round trip through memory, not the probes.)
+        while (lo_b < hi_b) {
+            const uint32_t mid = lo_b + ((hi_b - lo_b) >> 1);
+            int c = 0;
+#pragma unroll
+            for (int q = 0; q < 16; q++) c += (int)__popcll(__ballot(v[q] <= mid));
+            if (c >= r) { hi_b = mid; if (c <= r + tol) break; }
+            else lo_b = mid + 1u;
+        }
+        pivot = hi_b;
+    }
+    hi = ((unsigned long long)pivot << 32) | 0xFFFFFFFFull;
+    GSR_T_TICK_O(4)
+    for (int i0 = 0; i0 < total; i0 += 4 * GSR_BLOCK) {
+        unsigned long long k[4];
+        bool in[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = i0 + j * GSR_BLOCK + tid;
+            k[j] = (i < total) ? keys[i] : 0ull;
+            in[j] = i < total && (first || k[j] > lo) && (uint32_t)(k[j] >> 32) <= pivot;
+        }
+        // one LDS atomic per wave and 1 024 keys: the four ballots' counts are reserved together
+        unsigned long long mk[4];
+        uint32_t cnt4 = 0u;
+#pragma unroll
+        for (int j = 0; j < 4; j++) { mk[j] = __ballot(in[j]); cnt4 += (uint32_t)__popcll(mk[j]); }
+        if (cnt4 != 0u) {                                    // wave-uniform
+            uint32_t base = 0u;
+            if (lane == 0) base = atomicAdd(&s_fill, cnt4);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t pos = base + (uint32_t)__popcll(mk[j] & ((1ull << lane) - 1ull));
+                if (in[j] && pos < (uint32_t)cap) s_keys[pos] = k[j];
+                base += (uint32_t)__popcll(mk[j]);
+            }
+        }
+    }
+    __syncthreads();
+    GSR_T_TICK_O(6)
+    return (int)s_fill;
+}
+
 // (5 workgroups per CU keep every tile of a 640x480 image resident in one round: 96 registers.  The slice-ordering variant
 // with the n_touched counters needs a few more and gets 4 per CU rather than spilling.)
 template <bool TOUCHED, int LIST>
@@ -1689,7 +1844,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     // A bin longer than the in-LDS sort takes (a tile that does not saturate -- the edge of the scene's coverage, a
     // semi-transparent region -- has no depth bound and gets its complete list) is ordered lazily, slice by slice, like a
     // segment of the exact bins; only a bin that overflowed its capacity fails the forward.
-    const bool lazy = (LIST == GSR_LIST_EXACT) || (LIST == GSR_LIST_BINS && total > GSR_LSORT_CAP) || (LIST == GSR_LIST_BINS_FULL && total > GSR_SLICE_ALL);
+    const bool lazy = (LIST == GSR_LIST_EXACT) || (LIST == GSR_LIST_BINS && total > GSR_LSORT_CAP) || (LIST == GSR_LIST_BINS_FULL && total > GSR_BLOCK);
     if (kBins && total > bin_cap) {          // block-uniform: entries were dropped; the host redoes the forward with complete lists
         if (tid == 0) {
             atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);
@@ -1740,7 +1895,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
 
     // GSR_LIST_EXACT: `consumed` entries of the segment are ordered (and written to point_list) so far; the keys of the
     // current slice sit in s_keys[0, m).  The other modes make one pass with m = total.
-    int consumed = 0, m = total;
+    int consumed = 0, m = total, slice_no = 0;
     unsigned long long slice_lo = 0ull;
   for (bool first_slice = true;; first_slice = false) {
     if (lazy) {
@@ -1749,26 +1904,49 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         const unsigned long long* seg = bins + range.x;
         const int remaining = total - consumed;
         unsigned long long slice_hi = ~0ull;
-        m = remaining;
-        if (remaining > (first_slice ? GSR_SLICE_ALL : GSR_LSORT_CAP))
-            select_slice(seg, total, first_slice, slice_lo, first_slice ? GSR_SLICE_FIRST : GSR_LSORT_CAP,
-                         reinterpret_cast<uint32_t*>(s_keys), slice_hi, m);
-        if (m <= 0) {          // cannot happen with distinct keys (the index is part of them): corrupted bins -- fail loudly, never spin
-            if (tid == 0) atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);
-            break;
+        // slice sizes: the first aims at a couple of hundred keys (most tiles saturate within it, and up to 256 keys sort in
+        // registers); a tile that wants more wants much more
+        int want = (slice_no == 0) ? GSR_SLICE_WANT0 : ((slice_no == 1) ? GSR_SLICE_WANT1 : GSR_SLICE_WANT2);
+        m = -1;
+        for (int attempt = 0; attempt < 3 && m < 0; attempt++) {
+            const int got = sample_slice(seg, total, first_slice, slice_lo, remaining, want, GSR_LSORT_CAP, reinterpret_cast<uint32_t*>(s.a), s_keys, slice_hi GSR_T_ARGS);
+            if (got >= 1 && got <= GSR_LSORT_CAP) m = got;
+            else if (got == 0) break;                                      // the sampled front of the segment is used up
+            else { want = max(16, want >> 2); __syncthreads(); }          // too many at or below the threshold: a smaller share
         }
-        __shared__ uint32_t s_fill;
-        if (tid == 0) s_fill = 0u;
-        int npow = 64;
-        while (npow < m) npow <<= 1;
-        __syncthreads();
-        for (int i = tid; i < total; i += GSR_BLOCK) {
-            const unsigned long long k = seg[i];
-            if ((first_slice || k > slice_lo) && k <= slice_hi) s_keys[atomicAdd(&s_fill, 1u)] = k;
+        if (m < 0) {
+            // thousands of keys at one depth, or nothing left in the sampled front of the segment: exact radix selection
+            m = remaining;
+            slice_hi = ~0ull;
+            if (remaining > GSR_LSORT_CAP)
+                select_slice(seg, total, first_slice, slice_lo, GSR_LSORT_CAP, reinterpret_cast<uint32_t*>(s_keys), slice_hi, m);
+            if (m <= 0) {          // cannot happen with distinct keys (the index is part of them): corrupted bins -- fail loudly, never spin
+                if (tid == 0) atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);
+                break;
+            }
+            __shared__ uint32_t s_fill2;
+            if (tid == 0) s_fill2 = 0u;
+            __syncthreads();
+            for (int i = tid; i < total; i += GSR_BLOCK) {
+                const unsigned long long k = seg[i];
+                if ((first_slice || k > slice_lo) && k <= slice_hi) s_keys[atomicAdd(&s_fill2, 1u)] = k;
+            }
+            __syncthreads();
         }
-        for (int i = m + tid; i < npow; i += GSR_BLOCK) s_keys[i] = ~0ull;
-        __syncthreads();
-        lds_bitonic_sort(s_keys, npow);
+        slice_no++;
+        if (m <= GSR_BLOCK) {
+            sort_block_keys((tid < m) ? s_keys[tid] : ~0ull, s_keys);
+            overhead += 3;
+        } else {
+            int npow = 512;
+            while (npow < m) npow <<= 1;
+            for (int i = m + tid; i < npow; i += GSR_BLOCK) s_keys[i] = ~0ull;
+            __syncthreads();
+            lds_bitonic_sort(s_keys, npow);
+            const int lg = 31 - __builtin_clz((unsigned)npow);
+            overhead += 2 + (lg * (lg + 1) / 2) * max(1, npow >> 9) / 7;
+        }
+        GSR_T_TICK_O(7)
         for (int i = tid; i < m; i += GSR_BLOCK) point_list[range.x + consumed + i] = (uint32_t)s_keys[i];
         slice_lo = slice_hi;
     }
@@ -1778,37 +1956,56 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         GSR_T_COUNT(10, 1)
         const int n = min(GSR_BLOCK, m - base);
         overhead += 3;
-        if (tid < n) {
-            const uint32_t id = (LIST != GSR_LIST_SORTED) ? (uint32_t)s_keys[base + tid]
-                                                           : (pack_qm ? (point_list[range.x + base + tid] & 0x0FFFFFFFu) : point_list[range.x + base + tid]);
-            const float4* r = reinterpret_cast<const float4*>(rec + (size_t)id * GSR_REC_STRIDE);
-            const float4 r0 = r[0], r1 = r[1];
-            float4 r2;
-            if (kFull && lz.shs != nullptr) {
-                // (LazySH: another workgroup of this launch may be publishing this quad right now.  It is read and written as ONE
-                // 16-byte access -- a volatile vector access, which the compiler neither splits nor reorders nor repeats; on gfx950 an
-                // aligned global_load / store_dwordx4 is a single transaction on one cache line, so a reader sees either the
-                // unevaluated quad (w = 0) or the complete one (w = 1).  Two tiles that both find w = 0 both evaluate the colour and
-                // store the same bits; the same goes for the byte they store into `clamped`.)
-                const gsr_f32x4 q = *reinterpret_cast<const volatile gsr_f32x4*>(r + 2);
-                r2 = make_float4(q[0], q[1], q[2], q[3]);
-            } else r2 = r[2];
-            if (kFull && lz.shs != nullptr && r2.w == 0.f) {      // first tile to stage this splat: its colour (LazySH)
-                uint8_t cb;
-                const float3 pm = make_float3(lz.means[3 * (size_t)id], lz.means[3 * (size_t)id + 1], lz.means[3 * (size_t)id + 2]);
-                const float3 c = sh16_vector_ok(lz.M, lz.shs)
-                                     ? sh_row16_to_rgb(lz.D, pm, lz.campos, reinterpret_cast<const float4*>(lz.shs) + (size_t)id * GSR_SH16_ROW4, cb)
-                                     : sh_to_rgb(lz.D, lz.M, pm, lz.campos, lz.shs + (size_t)id * lz.M * 3, cb);
-                r2 = make_float4(c.x, c.y, c.z, 1.f);
-                *reinterpret_cast<volatile gsr_f32x4*>(lz.rec + (size_t)id * GSR_REC_STRIDE + 8) = (gsr_f32x4){c.x, c.y, c.z, 1.f};
-                lz.clamped[id] = cb;
+        {
+            const bool have = tid < n;
+            uint32_t id = 0u;
+            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
+            if (have) {
+                id = (LIST != GSR_LIST_SORTED) ? (uint32_t)s_keys[base + tid]
+                                                : (pack_qm ? (point_list[range.x + base + tid] & 0x0FFFFFFFu) : point_list[range.x + base + tid]);
+                const float4* r = reinterpret_cast<const float4*>(rec + (size_t)id * GSR_REC_STRIDE);
+                r0 = r[0]; r1 = r[1];
+                if (kFull && lz.shs != nullptr) {
+                    // (LazySH: another workgroup of this launch may be publishing this quad right now.  It is read and written as ONE
+                    // 16-byte access -- a volatile vector access, which the compiler neither splits nor reorders nor repeats; on gfx950 an
+                    // aligned global_load / store_dwordx4 is a single transaction on one cache line, so a reader sees either the
+                    // unevaluated quad (w = 0) or the complete one (w = 1).  Two tiles that both find w = 0 both evaluate the colour and
+                    // store the same bits; the same goes for the byte they store into `clamped`.)
+                    const gsr_f32x4 q = *reinterpret_cast<const volatile gsr_f32x4*>(r + 2);
+                    r2 = make_float4(q[0], q[1], q[2], q[3]);
+                } else r2 = r[2];
             }
-            const uint32_t qm = quadrant_mask(r0.x, r0.y, r1.x * (-2.0f / GSR_LOG2E), r0.z * (-1.0f / GSR_LOG2E), r0.w * (-2.0f / GSR_LOG2E), r1.y,
-                                              tx * GSR_TILE, ty * GSR_TILE);
-            if (LIST != GSR_LIST_SORTED && pack_qm) point_list[range.x + consumed + base + tid] = id | (qm << 28);
-            s.a[tid] = r0;
-            s.b[tid] = make_float4(r1.x, r1.y, __uint_as_float(id), __uint_as_float(qm));
-            s.c[tid] = make_float4(r2.x, r2.y, r2.z, r1.z);
+#if GSR_TIMING
+            if (kFull) { asm volatile("" :: "v"(r0.x), "v"(r1.x), "v"(r2.w)); GSR_T_TICK(0) GSR_T_COUNT(8, (have && r2.w == 0.f) ? 1 : 0) }
+#endif
+            if (kFull && lz.shs != nullptr) {          // first tile to stage a splat: its colour (LazySH)
+                const bool need = have && r2.w == 0.f;
+                // (measured in round 4: taking the lanes that need a colour sixteen at a time, their rows as coalesced streams through an
+                // LDS slab, one channel of one row per lane -- TWICE as slow, 55 k against 25 k cycles per wave: the phase is a chain of
+                // memory round trips of ~8 k cycles each while every tile of the image stages at the same time, and the chunks add
+                // round trips; the per-lane row loads below put all of them in flight at once)
+                if (need) {
+                    uint8_t cb;
+                    const float3 pm = make_float3(lz.means[3 * (size_t)id], lz.means[3 * (size_t)id + 1], lz.means[3 * (size_t)id + 2]);
+                    const float3 c = sh16_vector_ok(lz.M, lz.shs)
+                                         ? sh_row16_to_rgb(lz.D, pm, lz.campos, reinterpret_cast<const float4*>(lz.shs) + (size_t)id * GSR_SH16_ROW4, cb)
+                                         : sh_to_rgb(lz.D, lz.M, pm, lz.campos, lz.shs + (size_t)id * lz.M * 3, cb);
+                    r2 = make_float4(c.x, c.y, c.z, 1.f);
+                    *reinterpret_cast<volatile gsr_f32x4*>(lz.rec + (size_t)id * GSR_REC_STRIDE + 8) = (gsr_f32x4){c.x, c.y, c.z, 1.f};
+                    lz.clamped[id] = cb;
+                }
+            }
+#if GSR_TIMING
+            if (kFull) { GSR_T_TICK(1) }
+#endif
+            if (have) {
+                const uint32_t qm = quadrant_mask(r0.x, r0.y, r1.x * (-2.0f / GSR_LOG2E), r0.z * (-1.0f / GSR_LOG2E), r0.w * (-2.0f / GSR_LOG2E), r1.y,
+                                                  tx * GSR_TILE, ty * GSR_TILE);
+                if (LIST != GSR_LIST_SORTED && pack_qm) point_list[range.x + consumed + base + tid] = id | (qm << 28);
+                s.a[tid] = r0;
+                s.b[tid] = make_float4(r1.x, r1.y, __uint_as_float(id), __uint_as_float(qm));
+                s.c[tid] = make_float4(r2.x, r2.y, r2.z, r1.z);
+            }
         }
         __syncthreads();
         GSR_T_TICK(3)
@@ -1821,7 +2018,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             if (hit) s.list[wv][cnt + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
             cnt += (int)__popcll(mk);
         }
-        GSR_T_TICK(4)
+        GSR_T_TICK(GSR_TO(4))
         const int full = cnt & ~7;
         for (int g0 = 0; g0 < full; g0 += 8) {
             if (__all(T <= 0.f)) break;                // whole wave finished: stop early
@@ -1908,7 +2105,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     // GSR_LIST_EXACT: the tile's range is what has been ORDERED -- all that the backward pass and a re-compositing of
     // these lists (n_touched) can need: no pixel looks beyond the slice in which the last one terminated
     if (lazy && tid == 0) ranges[tile] = make_uint2(range.x, range.x + (uint32_t)min(consumed, total));
-    GSR_T_TICK(6)
+    GSR_T_TICK(GSR_TO(6))
     if (tile_work != nullptr) {      // this tile's weight in the next iteration's launch order
         __shared__ int s_walk[4];
         if (lane == 0) s_walk[wv] = walked;
@@ -2008,7 +2205,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             }
         }
     }
-    GSR_T_TICK(7)
+    GSR_T_TICK(GSR_TO(7))
     GSR_T_FLUSH(0)
 }
 
@@ -2087,8 +2284,12 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                                                                const float* __restrict__ dL_dpix, const float* __restrict__ dL_ddepths,
                                                                const float* __restrict__ dL_dalphas, float* __restrict__ acc,
                                                                LoopGuard guard, const uint32_t* __restrict__ tile_order,
-                                                               uint32_t* __restrict__ tile_work, const float* __restrict__ rec, int P, int pack_qm, int det)
+                                                               uint32_t* __restrict__ tile_work, const float* __restrict__ rec, int P, int pack_qm, int det,
+                                                               uint8_t* __restrict__ aflag)
 {
+    // (aflag, 2 P bytes: [id] = some tile added to this Gaussian's record, [P + id] = ... to its colour sums.  Idempotent plain
+    // byte stores -- every writer stores 1 -- that tell the chain-rule kernel which of the forward's survivors have anything to do,
+    // without its reading every survivor's 48-byte record: on complete lists nine survivors in ten were never blended.)
     __shared__ BwdMfmaLDS s;
     const GSR_CONST_AS float* crec = (const GSR_CONST_AS float*)rec;      // (constant address space + wave-uniform offsets: s_load)
     if (guard.frozen()) return;
@@ -2319,6 +2520,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             q[7] = -0.5f * o * syy;
             q[8] = M0;
             q[9] = m[3];
+            const bool nzc = q[0] != 0.f || q[1] != 0.f || q[2] != 0.f;
+            const bool nz = nzc || q[3] != 0.f || q[4] != 0.f || q[5] != 0.f || q[6] != 0.f || q[7] != 0.f || q[8] != 0.f || (POSE && q[9] != 0.f);
+            if (nz) aflag[id] = (uint8_t)1;
+            if (nzc) aflag[(size_t)P + id] = (uint8_t)1;
         }
         __syncthreads();
         // ... and flush them: one lane per (splat, quantity), so that a wave instruction adds runs of consecutive
@@ -2685,6 +2890,7 @@ struct PreBwdArgs {
     // iteration to the next: bit 0 = this Gaussian's small gradient rows hold values, bit 1 = its dL_dsh row does.
     // A row is re-zeroed only when it held values and gets none this time, instead of 300 MB of memsets per call.
     uint8_t* dirty;
+    uint8_t* aflag;                                       // 2 P bytes, set by k_render_bwd_mfma: has sums / has colour sums; cleared here as consumed
     LoopGuard guard;
     SurvLists surv; // the forward's work lists (k_preprocess): the only Gaussians whose records can hold anything
     // Native loop only (ticket nullable): the workgroup that finishes LAST runs the pose step (Adam, update_pose, camera
@@ -2898,12 +3104,14 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             const bool in = c0 + (uint32_t)lane < n;
             const int idx = in ? (int)(c0 == first_c0 ? first_entry : list[c0 + lane]) : 0;
             c0 += step;
-            float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
-            if (in) acc_load<DET>(a.acc, (size_t)idx, r0, r1, r2);
-            const bool active = in && (r0.x != 0.f || r0.y != 0.f || r0.z != 0.f || r0.w != 0.f || r1.x != 0.f || r1.y != 0.f ||
-                                       r1.z != 0.f || r1.w != 0.f || r2.x != 0.f || r2.y != 0.f);
+            // (round 4: the compositing backward flags the Gaussians it added anything to -- two bytes per survivor here instead of its
+            // 48-byte record: complete lists make every visible Gaussian a survivor and nine in ten of them were never blended)
+            const uint8_t fa = in ? a.aflag[idx] : (uint8_t)0, fc = in ? a.aflag[(size_t)a.P + idx] : (uint8_t)0;
+            const bool active = fa != 0;
             // zero colour gradient => zero SH gradient whatever the coefficients are: their row is not even read
-            const bool has_col = active && (r0.x != 0.f || r0.y != 0.f || r0.z != 0.f);
+            const bool has_col = active && fc != 0;
+            if (fa != 0) a.aflag[idx] = (uint8_t)0;                       // consumed: clean for the next backward
+            if (fc != 0) a.aflag[(size_t)a.P + idx] = (uint8_t)0;
             // The gradient tensors are zero wherever nothing is written: the host zero-fills them per call, or (native
             // loop) once per frame, after which the dirty bits say which rows hold values from the iteration before.
             // (Rows of Gaussians that are not on this iteration's lists were cleared by k_preprocess.)
@@ -2912,12 +3120,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
                 const uint8_t now = (uint8_t)((active ? 1 : 0) | (has_col ? 2 : 0));
                 if (now != was) a.dirty[idx] = now;
             }
-            if (active) {
-                a.dL_dcolor[3 * (size_t)idx] = r0.x; a.dL_dcolor[3 * (size_t)idx + 1] = r0.y; a.dL_dcolor[3 * (size_t)idx + 2] = r0.z;
-                a.dL_dmean2D[3 * (size_t)idx] = r0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = r1.x;
-                reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(r1.y, r1.z, 0.f, r1.w);
-                a.dL_dopacity[idx] = r2.x;
-            } else if (was & 1) zero_grad_rows(rows, (size_t)idx, true, false);      // no gradient any more
+            if (!active && (was & 1)) zero_grad_rows(rows, (size_t)idx, true, false);      // no gradient any more
             if ((was & 2) && !has_col) zero_grad_rows(rows, (size_t)idx, false, true);       // had an SH gradient last iteration, has none now
             const unsigned long long mk = __ballot(active);
             if (active) s_q[qn + (int)__popcll(mk & ((1ull << lane) - 1ull))] = (uint32_t)idx | (has_col ? 0x80000000u : 0u);
@@ -2937,6 +3140,10 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         if (active) {
             acc_load<DET>(a.acc, (size_t)idx, r0, r1, r2);
             if (a.dirty != nullptr) acc_clear<DET>(a.acc, (size_t)idx);      // native loop: leave the record clean for the next iteration's K7 (no 48 MB memset)
+            a.dL_dcolor[3 * (size_t)idx] = r0.x; a.dL_dcolor[3 * (size_t)idx + 1] = r0.y; a.dL_dcolor[3 * (size_t)idx + 2] = r0.z;
+            a.dL_dmean2D[3 * (size_t)idx] = r0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = r1.x;
+            reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(r1.y, r1.z, 0.f, r1.w);
+            a.dL_dopacity[idx] = r2.x;
         }
         const unsigned long long colmask = __ballot(has_col);
         // Every per-Gaussian read of the round is requested here, in FRONT of the SH rows, so that one round trip covers them all

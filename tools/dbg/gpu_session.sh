@@ -28,5 +28,8 @@ case $step in
     GSR_TIMING=1 python gs_localization_amd/build.py > /dev/null 2>&1
     for sc in ${@:-s_1m_640 s_3m_cam}; do echo "== $sc plain"; SCENE=$sc LOOP_PLAIN=1 python tools/phase_timing.py 2>/dev/null | grep -v amdgpu; done > $o/timing_plain.log
     python gs_localization_amd/build.py > /dev/null 2>&1 ;;
+  tail)          # the slowest waves of k_render_fwd on complete lists, by phase (diagnostic build)
+    GSR_TIMING=1 GSR_DEFS="-DGSR_TIMING_ORDER $TAILDEFS" python gs_localization_amd/build.py > $o/tail_build.log 2>&1
+    for sc in ${@:-s_1m_640}; do echo "== $sc"; SCENE=$sc LOOP_PLAIN=1 python tools/dbg/tail_rows.py; done > $o/tail.log 2>&1 ;;
   *) echo "unknown step $step" ;;
 esac
