@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the CPU port on one thread on S-800k-chess (minutes)")
     ap.add_argument("--no-train-leg", action="store_true")
+    ap.add_argument("--no-cam-leg", action="store_true", help="skip BASELINE.json config 3 (S-3M-cam, 852x480 and 1024x576)")
     ap.add_argument("--pose-only", action="store_true", help="skip the Gaussian-parameter gradients (not the headline)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend for N > 1; gloo (collectives on host tensors) lets the N > 1 code path be rehearsed on a box with one GPU")
@@ -220,22 +221,25 @@ def main():
     # ---- (b) the native loop (gsr_refine), one frame at a time; per-kernel breakdown from a separate short run
     frs = [PL.FusedRefiner(model, H, W, device=dev, gaussian_grads=not args.pose_only) for _ in range(F)]
 
-    def native(f, iters, stop=False, speculative=True, warm=None):
-        # warm=None: the refiner's default -- a frame starts from the depth bounds its predecessor on this refiner left behind
-        # (consecutive frames of a sequence; here: the same frame again), verified on the device like every speculation
-        return frs[f].refine(vps[f], config, inits[f][:3, :3].clone(), inits[f][:3, 3].clone(), background, iters=iters,
+    def native(f, iters, stop=False, speculative=True, warm=None, frame=None):
+        # warm=None: the refiner's default -- a frame starts from the depth bounds its PREDECESSOR on this refiner left behind
+        # (consecutive frames of a sequence), verified on the device like every speculation.  The predecessor is always another
+        # query frame here (another start pose): refiner slot f takes frame `frame` (default f).
+        g = f if frame is None else frame % F
+        return frs[f].refine(vps[g], config, inits[g][:3, :3].clone(), inits[g][:3, 3].clone(), background, iters=iters,
                              stop_on_converged=stop, speculative=speculative, warm_start=warm)
 
     def timed_single(spec, iters=K, warm=None):
-        native(0, Wm, speculative=spec)
+        native(0, Wm, speculative=spec, frame=1)           # the predecessor: frame 1 (its bounds are what a warm start gets)
         barrier(); torch.cuda.synchronize()
         t = time.perf_counter()
-        native(0, iters, speculative=spec, warm=warm)
+        native(0, iters, speculative=spec, warm=warm, frame=0)
         torch.cuda.synchronize(); barrier()
         return time.perf_counter() - t
+    # (every leg: the best of three)
     elapsed_single = min(timed_single(True) for _ in range(3))
-    elapsed_plain = timed_single(False)
-    elapsed_cold = timed_single(True, warm=False)          # first iteration bins completely (no bounds from a previous frame)
+    elapsed_plain = min(timed_single(False) for _ in range(3))
+    elapsed_cold = min(timed_single(True, warm=False) for _ in range(3))          # first iteration bins completely (no bounds from a previous frame)
     # per-call fixed cost: one K-iteration call against the marginal cost of an iteration inside a long call
     elapsed_long = min(timed_single(True, iters=4 * K) for _ in range(2))
     steady_ms = 1e3 * (elapsed_long - elapsed_single) / (3 * K)
@@ -257,15 +261,17 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
     results = [None] * F
 
-    def worker(f, iters, stop):
+    def worker(f, iters, stop, shift):
         try:
             with torch.cuda.stream(streams[f]):
-                results[f] = native(f, iters, stop)
+                results[(f + shift) % F] = native(f, iters, stop, frame=f + shift)
         except Exception as ex:      # re-raised in the main thread
-            results[f] = ex
+            results[(f + shift) % F] = ex
 
-    def run_all(iters, stop=False):
-        ts = [threading.Thread(target=worker, args=(f, iters, stop)) for f in range(F)]
+    def run_all(iters, stop=False, shift=0):
+        # (shift: refiner slot f takes frame f + shift -- every repeat hands each refiner another frame than the one whose depth
+        # bounds it still holds, as consecutive frames of a sequence would)
+        ts = [threading.Thread(target=worker, args=(f, iters, stop, shift)) for f in range(F)]
         [t.start() for t in ts]
         [t.join() for t in ts]
         for e in results:
@@ -282,7 +288,7 @@ def main():
     for rep in range(max(1, args.repeats)):
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run_all(K)
+        run_all(K, shift=rep + 1)
         torch.cuda.synchronize(); barrier()
         elapsed_runs.append(time.perf_counter() - t0)
         if rep == 0:
@@ -315,11 +321,15 @@ def main():
     te0, re0 = PL.pose_errors(w2c_gt[:3, :3], w2c_gt[:3, 3], w2c_init[:3, :3], w2c_init[:3, 3])
     res = shard.gather_results(torch.tensor(rows, dtype=torch.float64, device=coll_dev), world * F, rank, world)
 
-    train = None
-    if rank == 0 and world == 1 and not args.no_train_leg:
+    train, cam = None, None
+    if rank == 0 and world == 1 and not (args.no_train_leg and args.no_cam_leg):
         del frs, vps, model
         torch.cuda.empty_cache()
-        train = train_step_leg()
+        if not args.no_cam_leg:
+            cam = cam_step_leg(lib, dev)
+            torch.cuda.empty_cache()
+        if not args.no_train_leg:
+            train = train_step_leg(lib)
 
     if rank == 0:
         res = res.cpu().numpy()
@@ -336,8 +346,21 @@ def main():
                 iter_traffic = sum(tj[k] for k in loop_kernels)
         except Exception:
             pass
+        loop_valu_frac = None
         try:
-            issue = json.load(open(os.path.join(ROOT, "profiles", "issue.json"))).get(dominant)
+            ij = json.load(open(os.path.join(ROOT, "profiles", "issue.json")))
+            d_ = ij.get(dominant)
+            if d_:      # two different pipes, reported side by side (never summed: MFMA and VALU instructions of different waves overlap)
+                issue = {"valu_issue_frac": d_["valu_issue_frac"], "mfma_pipe_frac": d_["mfma_pipe_frac"],
+                         "binding_pipe": "valu" if d_["valu_issue_frac"] >= d_["mfma_pipe_frac"] else "mfma"}
+            # whole steady-state iteration: wave-level vector instructions x 4 cycles each over the chip's 1 024 SIMDs at 2.4 GHz,
+            # against the measured time per iteration (single frame)
+            lk = (("preprocess_lean",) if "preprocess_lean" in ij else ("preprocess_fwd", "sh_color")) + ("render_fwd", "render_bwd", "preprocess_bwd")
+            if all(k in ij and "valu_insts_per_launch" in ij[k] for k in lk):
+                insts = sum(ij[k]["valu_insts_per_launch"] for k in lk)
+                loop_valu_frac = {"valu_wave_insts_per_iter": insts,
+                                  "single_frame": insts * 4.0 / (1024 * 2.4e9) / (steady_ms * 1e-3),
+                                  "at_value": insts * 4.0 / (1024 * 2.4e9) / (elapsed / (F * K))}
         except Exception:
             pass
         iters_total = world * F * K
@@ -365,7 +388,11 @@ def main():
                        "algorithmic_bytes_per_iter": total_bytes, "frames_in_flight_per_gpu": F,
                        "iterations_per_step": F, "gaussian_grads": not args.pose_only,
                        "parallelism": f"frames: {world} GPU x {F} in flight",
-                       "loop": "native gsr_refine (render, tracking loss, backward, Adam, update_pose per iteration)"},
+                       "loop": "native gsr_refine (render, tracking loss, backward, Adam, update_pose per iteration)",
+                       "iterations_per_call": K,
+                       "warm_policy": "every refinement call starts from the depth bounds ANOTHER query frame (another start pose) left in its "
+                                      "refiner's workspace, verified on the device; single_frame_cold_start_iters_per_s has no bounds to start from",
+                       "timing": "value = first of `repeats` timed regions; single-frame / plain / cold legs = best of three calls"},
             "value_repeats": [iters_total / e for e in elapsed_runs],
             "single_frame_iters_per_s": single,
             "single_frame_cold_start_iters_per_s": world * K / elapsed_cold,
@@ -392,8 +419,11 @@ def main():
                          # (avg_launch_ms is a launch of the timed region, where F frames share the GPU; a frame alone:)
                          "frac_single_frame": (per_kernel_bytes[dominant] / (native_ms[True][dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS)
                                               if native_ms[True][dominant] > 0 else None,
-                         # what the kernel is actually bound by: vector + matrix issue slots (rocprofv3 SQ pass, profiles/issue.json)
+                         # what the kernel is actually bound by (rocprofv3 SQ pass, profiles/issue.json): its vector-issue and
+                         # matrix-pipe utilisations, two pipes side by side; and the whole loop's vector-issue fraction
+                         "bound_measured": "valu_issue",
                          "issue_frac": issue,
+                         "loop_valu_issue_frac": loop_valu_frac,
                          # whole iteration: HBM bytes per steady-state iteration (sum of the loop's kernels, profiles/traffic.json)
                          # and that traffic at the measured single-frame / in-flight rates against the HBM peak
                          "iter_traffic_bytes": iter_traffic,
@@ -406,6 +436,8 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["cpu_baseline_other_scenes"] = cpu_more
+        if cam is not None:
+            out["cam_step"] = cam
         if train is not None:
             out["train_step"] = train
         print(json.dumps(out), flush=True)
@@ -466,19 +498,127 @@ def cpu_baseline_other_scenes(full):
     return out
 
 
-def train_step_leg():
+def _profile_ms(lib, fn, n):
+    """per-kernel HIP-event milliseconds per call of fn() (all launches of each kernel id), n calls"""
+    nk = lib.gsr_profile_kernel_count()
+    names = [lib.gsr_profile_kernel_name(i).decode() for i in range(nk)]
+    lib.gsr_profile_enable((1 << nk) - 1)
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    ms = (C.c_double * nk)()
+    cnt = (C.c_longlong * nk)()
+    lib.gsr_profile_collect(ms, cnt)
+    lib.gsr_profile_enable(0)
+    return {names[i]: ms[i] / n for i in range(nk)}, {names[i]: int(cnt[i]) for i in range(nk)}
+
+
+def _stats_of(lib, grad_fn, P, W, H):
+    """(V, R under the reference's bounding rule, list entries ordered, R_eff of the own binning) of the forward behind grad_fn"""
+    from gs_localization_amd import _lib
+    sv = grad_fn.saved_tensors
+    st = (C.c_longlong * 4)()
+    _lib.check(lib.gsr_forward_stats(P, W, H, sv[5].data_ptr(), sv[7].data_ptr(), sv[9].data_ptr(), st, torch.cuda.current_stream().cuda_stream))
+    return tuple(int(st[i]) for i in range(4))
+
+
+def _roofline(kernels_ms, bytes_per_kernel, profile_json, note):
+    """`roofline` sub-object of a secondary workload: the kernel the step spends most time in, its SURVEY 8(d) bytes over its HIP-event
+    duration against the HBM peak, and the counter traffic of the committed rocprofv3 pass (profiles/<profile_json>) if it is there."""
+    dom = max(bytes_per_kernel, key=lambda k: kernels_ms.get(k, 0.0))
+    ms = kernels_ms.get(dom, 0.0)
+    ach = bytes_per_kernel[dom] / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", profile_json)))
+        traffic = tj.get(dom, {}).get("hbm_bytes_corrected")
+    except Exception:
+        pass
+    return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
+            "algorithmic_bytes_per_launch": bytes_per_kernel[dom], "avg_launch_ms": ms, "bound_measured": "valu_issue / wave latency (profiles/)", "note": note}
+
+
+def cam_step_leg(lib, dev):
+    """BASELINE.json config 3 (S-3M-cam: 3 M Gaussians, SH3, z in [2, 60] m) at the size BASELINE quotes (852x480)
+    and at the size the reference's Cambridge script really renders (1024x576, cambridge_localize_full.py:366): refinement
+    iterations/s of the native loop, speculative and with complete lists, 20 iterations per call like that script (:65), per-kernel
+    times, and a roofline line for the kernel each spends most time in."""
+    from gs_localization_amd import scenes as S
+    from tests import replay as PL
+    rows = []
+    bg = torch.zeros(3, dtype=torch.float32, device=dev)
+    for make, prof in ((S.s_3m_cam, "cam"), (S.s_3m_cam_1024, "cam1024")):
+        sc = make()
+        W, H, M = sc.W, sc.H, sc.shs.shape[1]
+        N, ntiles = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+        model = PL.GaussianMap.from_scene(sc, device=dev)
+        frames = [PL.make_frame(sc, model, dev, bg, uid=u) for u in (0, 1)]
+        inits = [PL.perturbed_start(2000 + u, device=dev) for u in (0, 1)]
+        pkg = PL.render(frames[0], model, bg)
+        V, R, R_ord, R_eff = _stats_of(lib, pkg["render"].grad_fn, sc.P, W, H)
+        del pkg
+        fr = PL.FusedRefiner(model, H, W, device=dev)
+        K = 20
+
+        def call(g, iters, spec, warm=None):
+            return fr.refine(frames[g], PL.TRACKING_CONFIG, inits[g][:3, :3].clone(), inits[g][:3, 3].clone(), bg, iters=iters,
+                             stop_on_converged=False, speculative=spec, warm_start=warm)
+        res = {}
+        for spec in (True, False):
+            best = 1e9
+            for _ in range(3):
+                call(1, 3, spec)                      # the predecessor frame: its bounds are what the warm start gets
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                call(0, K, spec)
+                torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            kms, _ = _profile_ms(lib, lambda: call(0, K, spec), 2)
+            res[spec] = (K / best, {k: round(v / K, 4) for k, v in kms.items() if v > 0})
+        per, _ = algorithmic_bytes(sc.P, V, R, R_eff, N, M, ntiles)
+        loop_kernels = {k: per[k] for k in ("render_fwd", "render_bwd", "preprocess_bwd", "preprocess_fwd")}
+        rows.append({"scene": sc.name, "width": W, "height": H, "gaussians": sc.P, "tiles": ntiles, "V": V, "R": R, "R_eff_own_binning": R_eff,
+                     "list_entries_ordered": R_ord, "iterations_per_call": K,
+                     "speculative_iters_per_s": res[True][0], "plain_iters_per_s": res[False][0],
+                     "kernels_ms_per_iter_speculative": res[True][1], "kernels_ms_per_iter_plain": res[False][1],
+                     "roofline": _roofline({k: v for k, v in res[True][1].items()}, loop_kernels, f"r04_{prof}_spec_traffic.json",
+                                           "speculative loop; R_eff of the own (culled) binning: no CPU oracle run at 3 M Gaussians"),
+                     "roofline_plain": _roofline({k: v for k, v in res[False][1].items()}, loop_kernels, f"r04_{prof}_plain_traffic.json",
+                                                 "complete lists in every iteration")})
+        del fr, frames, model
+        torch.cuda.empty_cache()
+    return {"workload": "S-3M-cam pose refinement (BASELINE.json configs[3]), native loop, one frame at a time, 20 iterations per call", "per_size": rows}
+
+
+def train_step_leg(lib):
     """BASELINE.json config 4 (train.py, S-train-garden): ms per step through package (A) + the fused loss epilogue + torch Adam,
-    at three sizes of the model (1296x840, SH degree 1, white background, random camera per step)."""
+    at three sizes of the model (1296x840, SH degree 1, white background, random camera per step); per-kernel times and a roofline
+    line of the rasterizer at 1.5 M."""
     from tests.train_replay import TrainReplay, time_steps
     rows = []
+    roof, kernels = None, None
     for P in (200_000, 800_000, 1_500_000):
         tr = TrainReplay(P0=P, P1=P, densify_from=10**9)
-        r, _ = time_steps(tr, 1, 30, warm=5)
+        r, it = time_steps(tr, 1, 30, warm=5)
         rows.append({k: (round(float(v), 4) if not isinstance(v, int) else v) for k, v in r.items()})
+        if P == 1_500_000:
+            state = {"it": it}
+
+            def one():
+                tr.step(state["it"]); state["it"] += 1
+            kms, _ = _profile_ms(lib, one, 10)
+            kernels = {k: round(v, 4) for k, v in kms.items() if v > 0}
+            out = tr.render(tr.views[0])
+            V, R, R_ord, R_eff = _stats_of(lib, out["image"].grad_fn, tr.P, tr.W, tr.H)
+            N, ntiles = tr.W * tr.H, ((tr.W + 15) // 16) * ((tr.H + 15) // 16)
+            per, _ = algorithmic_bytes(tr.P, V, R, R_eff, N, 4, ntiles)
+            roof = _roofline(kms, {k: per[k] for k in ("render_fwd", "render_bwd", "preprocess_bwd", "preprocess_fwd", "tile_emit")},
+                             "r04_train_traffic.json", f"V={V} R={R} R_eff(own binning)={R_eff}, {ntiles} tiles")
+            del out
         del tr
         torch.cuda.empty_cache()
     return {"workload": "train.py step, 1296x840, SH1, white background, random camera per step, grad_depth != 0 (tests/train_replay.py)",
-            "per_P": rows}
+            "per_P": rows, "kernels_ms_per_step_1500000": kernels, "roofline": roof}
 
 
 if __name__ == "__main__":

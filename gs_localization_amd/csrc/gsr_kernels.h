@@ -1376,13 +1376,21 @@ __global__ void __launch_bounds__(GSR_TBIN_THREADS) k_tile_emit(TileBinArgs a, i
 // ---------------------------------------------------------------------------------------------
 #define GSR_PBIN_THREADS 512
 #define GSR_PBIN_KPT 4             // 2 048 Gaussians per workgroup: enough for the LDS counters to aggregate, two workgroups per CU
+// Round 4 tried three other shapes of the reserve / emit half of this kernel, all measured on the MI355X and all slower or equal
+// (HISTORY.md, round 4): (a) keys staged tile-major in 96 KB of LDS and flushed as whole 32-byte sectors, eight lanes per run -- one
+// workgroup per CU is left, whose six barrier-separated phases have nobody to overlap with (same duration); (b) every (workgroup,
+// tile) run padded to whole sectors with the key ~0 and ONE unbanded walk -- the walk is bound by the issue of its scattered 8-byte
+// stores either way (48 k cycles against 42 k with two bands) and the padding stores cost another 40 k; (c) the reservation atomics
+// issued early and consumed after the walk -- issuing them is what takes the time.  What stayed: four reservation atomics in flight
+// per lane, the cursor as a 64-bit (slots, keys) pair (the compositing kernel copes with padding keys), workgroups staggered over the tiles.
 __global__ void __launch_bounds__(GSR_PBIN_THREADS) k_preprocess_bin(PreArgs a, int bands)
 {
     extern __shared__ uint32_t s_tb[];        // [0, ntiles) running count, [ntiles, 2 ntiles) where this workgroup's keys of the tile start
     __shared__ uint32_t s_pref[GSR_PBIN_THREADS];
     constexpr int KPT = GSR_PBIN_KPT, gpb = GSR_PBIN_KPT * GSR_PBIN_THREADS;
+    const int nt = a.ntiles;
     uint32_t* s_cnt = s_tb;
-    uint32_t* s_base = s_tb + a.ntiles;
+    uint32_t* s_base = s_tb + nt;
     const int tid = threadIdx.x;
     GSR_T_DECL
     if (a.tile_order[0] != nullptr && blockIdx.x < 2) {      // native loop: this iteration's launch orders of the compositing kernels
@@ -1390,7 +1398,7 @@ __global__ void __launch_bounds__(GSR_PBIN_THREADS) k_preprocess_bin(PreArgs a, 
         tile_order_from_work(a.tile_work[blockIdx.x], a.tile_order[blockIdx.x], a.order_tiles, s_cls);
     }
     if (a.guard.poisoned()) return;
-    for (int t = tid; t < a.ntiles; t += GSR_PBIN_THREADS) s_cnt[t] = 0u;
+    for (int t = tid; t < nt; t += GSR_PBIN_THREADS) s_cnt[t] = 0u;
     if (blockIdx.x == 0 && tid == 0) {      // the null splat
         float4* nr = reinterpret_cast<float4*>(a.rec + (size_t)a.P * GSR_REC_STRIDE);
         nr[0] = make_float4(0.f, 0.f, 0.f, 0.f); nr[1] = nr[0]; nr[2] = nr[0];
@@ -1414,25 +1422,27 @@ __global__ void __launch_bounds__(GSR_PBIN_THREADS) k_preprocess_bin(PreArgs a, 
     GSR_T_TICK(2)
     __syncthreads();
     GSR_T_TICK(3)
-    // One returning atomic per (workgroup, tile): four in flight per lane (a round trip to the memory-side atomic unit is ~10 k
-    // cycles: one after the other they were a fifth of this kernel), and every workgroup starts at another tile so that the
-    // chip's ~500 workgroups do not walk the cursors in lockstep.
     {
-        const int rot = (int)((blockIdx.x * GSR_RESERVE_ROT) % (uint32_t)a.ntiles);
-        for (int t0 = tid; t0 < a.ntiles; t0 += 4 * GSR_PBIN_THREADS) {
+        // one returning atomic per (workgroup, tile), four in flight per lane, every workgroup starting at another tile; the cursor
+        // is a (slots, keys) pair: both grow by the run's length here (a producer that pads its runs adds more slots than keys)
+        const int rot = (int)((blockIdx.x * GSR_RESERVE_ROT) % (uint32_t)nt);
+        unsigned long long* cur = reinterpret_cast<unsigned long long*>(a.tile_cursor);
+        for (int t0 = tid; t0 < nt; t0 += 4 * GSR_PBIN_THREADS) {
             int tt[4];
-            uint32_t c[4], b[4];
+            uint32_t c[4];
+            unsigned long long old[4];
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const int t = t0 + j * GSR_PBIN_THREADS;
-                tt[j] = (t < a.ntiles) ? ((t + rot >= a.ntiles) ? t + rot - a.ntiles : t + rot) : -1;
+                tt[j] = (t < nt) ? ((t + rot >= nt) ? t + rot - nt : t + rot) : -1;
                 c[j] = (tt[j] >= 0) ? s_cnt[tt[j]] : 0u;
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++) b[j] = (c[j] != 0u) ? atomicAdd(&a.tile_cursor[tt[j] * GSR_CURSOR_STRIDE], c[j]) : 0u;
+            for (int j = 0; j < 4; j++)
+                old[j] = (c[j] != 0u) ? atomicAdd(&cur[(size_t)tt[j] * (GSR_CURSOR_STRIDE / 2)], ((unsigned long long)c[j] << 32) | (unsigned long long)c[j]) : 0ull;
 #pragma unroll
             for (int j = 0; j < 4; j++)
-                if (tt[j] >= 0) { s_base[tt[j]] = b[j]; s_cnt[tt[j]] = 0u; }
+                if (tt[j] >= 0) { s_base[tt[j]] = (uint32_t)old[j]; s_cnt[tt[j]] = 0u; }
         }
     }
     GSR_T_TICK(4)
@@ -1633,7 +1643,7 @@ __device__ __forceinline__ void select_slice(const unsigned long long* __restric
         __syncthreads();
         for (int i = tid; i < total; i += GSR_BLOCK) {
             const unsigned long long k = keys[i];
-            const bool in = (first || k > lo) && (prefix_bits == 0 || (k >> (64 - prefix_bits)) == prefix);
+            const bool in = (first || k > lo) && k != ~0ull && (prefix_bits == 0 || (k >> (64 - prefix_bits)) == prefix);      // (~0: padding)
             if (in) atomicAdd(&s_hist[(uint32_t)(k >> shift) & (uint32_t)(nbins - 1)], 1u);
         }
         __syncthreads();
@@ -1688,7 +1698,7 @@ __device__ __forceinline__ void select_slice(const unsigned long long* __restric
 // all keys gathers those at or below the threshold into s_keys with a ballot prefix per wave (one LDS atomic per wave and 256 keys).
 // Returns the number gathered (block-uniform; 0 = sample empty, > cap = the caller must retry with a smaller share or fall back to
 // select_slice -- thousands of keys sharing one depth).  hi = the slice's upper key bound.  s_samp: 1 024 words of LDS.
-__device__ __forceinline__ int sample_slice(const unsigned long long* __restrict__ keys, int total, bool first, unsigned long long lo, int remaining,
+__device__ __forceinline__ int sample_slice(const unsigned long long* __restrict__ keys, int total /* slots, padding keys ~0 included */, bool first, unsigned long long lo, int remaining,
                                             int want, int cap, uint32_t* s_samp, unsigned long long* s_keys, unsigned long long& hi GSR_T_PARAMS)
 {
     __shared__ uint32_t s_fill;
@@ -1821,21 +1831,32 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     const int pix_id = W * py + px;
     const float pxf = (float)px, pyf = (float)py;
     uint2 range;
+    int nslots = 0;      // memory extent of the tile's unordered keys (>= their number: padding keys ~0 in fixed-capacity complete bins)
     constexpr bool kBins = (LIST == GSR_LIST_BINS || LIST == GSR_LIST_BINS_FULL);
     constexpr bool kFull = (LIST == GSR_LIST_EXACT || LIST == GSR_LIST_BINS_FULL);      // complete lists: lazy ordering, lazy SH colours
     if (kBins) {
         // one lane reads the tile's cursor and clears it for the next iteration's appends (no memset); everybody else
         // gets the count through LDS
-        __shared__ uint32_t s_cursor;
-        if (tid == 0) { s_cursor = tile_cursor[tile * GSR_CURSOR_STRIDE]; tile_cursor[tile * GSR_CURSOR_STRIDE] = 0u; }
+        // (word 0: slots handed out in the bin; word 1, GSR_LIST_BINS_FULL only: the keys among them -- k_preprocess_bin pads every
+        // workgroup's run to whole 32-byte sectors with the key ~0)
+        __shared__ uint32_t s_cursor[2];
+        if (tid == 0) {
+            const uint32_t slots = tile_cursor[tile * GSR_CURSOR_STRIDE];
+            s_cursor[0] = slots;
+            s_cursor[1] = (LIST == GSR_LIST_BINS_FULL) ? tile_cursor[tile * GSR_CURSOR_STRIDE + 1] : slots;
+            tile_cursor[tile * GSR_CURSOR_STRIDE] = 0u;
+            if (LIST == GSR_LIST_BINS_FULL) tile_cursor[tile * GSR_CURSOR_STRIDE + 1] = 0u;
+        }
         __syncthreads();
         range.x = (uint32_t)tile * (uint32_t)(bin_cap + GSR_BIN_PAD);
-        range.y = range.x + s_cursor;
+        range.y = range.x + s_cursor[1];
+        nslots = (int)s_cursor[0];
     } else if (LIST == GSR_LIST_EXACT) {
         range.x = tile_cursor[tile];
         range.y = tile_cursor[tile + 1];
     } else range = ranges[tile];
     const int total = (int)(range.y - range.x);
+    if (!kBins) nslots = total;
     // (one plain store per tile.  A grand total added up here with one atomic per tile cost 16 us: 1 200 same-address atomics queue
     // up at the memory side and every workgroup's next barrier waits for its own)
     if (LIST == GSR_LIST_BINS_FULL && tile_total != nullptr && tid == 0) tile_total[tile] = (uint32_t)total;
@@ -1844,8 +1865,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     // A bin longer than the in-LDS sort takes (a tile that does not saturate -- the edge of the scene's coverage, a
     // semi-transparent region -- has no depth bound and gets its complete list) is ordered lazily, slice by slice, like a
     // segment of the exact bins; only a bin that overflowed its capacity fails the forward.
-    const bool lazy = (LIST == GSR_LIST_EXACT) || (LIST == GSR_LIST_BINS && total > GSR_LSORT_CAP) || (LIST == GSR_LIST_BINS_FULL && total > GSR_BLOCK);
-    if (kBins && total > bin_cap) {          // block-uniform: entries were dropped; the host redoes the forward with complete lists
+    const bool lazy = (LIST == GSR_LIST_EXACT) || (LIST == GSR_LIST_BINS && total > GSR_LSORT_CAP) || (LIST == GSR_LIST_BINS_FULL && nslots > GSR_BLOCK);
+    if (kBins && nslots > bin_cap) {          // block-uniform: entries were dropped; the host redoes the forward with complete lists
         if (tid == 0) {
             atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);
             // The group enqueued behind this one bins with the bounds THIS forward records (it is the device-side retry): a tile
@@ -1865,9 +1886,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         // this tile's bin arrives unsorted: order it by (depth bits, index) in LDS, keep it there
         // for the staging below and write the sorted indices (and the tile's range) back for the backward pass
         if (tid == 0) ranges[tile] = range;
-        if (total <= GSR_BLOCK) {          // one key per thread: register sort + merge by counting (the common case of the native loop)
+        if (nslots <= GSR_BLOCK) {          // one key per thread: register sort + merge by counting (the common case of the native loop)
             GSR_T_TICK(0)
-            sort_block_keys((tid < total) ? bins[range.x + tid] : ~0ull, s_keys);
+            sort_block_keys((tid < nslots) ? bins[range.x + tid] : ~0ull, s_keys);
             overhead += 2;
         } else {
             int npow = 512;
@@ -1909,7 +1930,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         int want = (slice_no == 0) ? GSR_SLICE_WANT0 : ((slice_no == 1) ? GSR_SLICE_WANT1 : GSR_SLICE_WANT2);
         m = -1;
         for (int attempt = 0; attempt < 3 && m < 0; attempt++) {
-            const int got = sample_slice(seg, total, first_slice, slice_lo, remaining, want, GSR_LSORT_CAP, reinterpret_cast<uint32_t*>(s.a), s_keys, slice_hi GSR_T_ARGS);
+            const int got = sample_slice(seg, nslots, first_slice, slice_lo, remaining, want, GSR_LSORT_CAP, reinterpret_cast<uint32_t*>(s.a), s_keys, slice_hi GSR_T_ARGS);
             if (got >= 1 && got <= GSR_LSORT_CAP) m = got;
             else if (got == 0) break;                                      // the sampled front of the segment is used up
             else { want = max(16, want >> 2); __syncthreads(); }          // too many at or below the threshold: a smaller share
@@ -1919,7 +1940,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             m = remaining;
             slice_hi = ~0ull;
             if (remaining > GSR_LSORT_CAP)
-                select_slice(seg, total, first_slice, slice_lo, GSR_LSORT_CAP, reinterpret_cast<uint32_t*>(s_keys), slice_hi, m);
+                select_slice(seg, nslots, first_slice, slice_lo, GSR_LSORT_CAP, reinterpret_cast<uint32_t*>(s_keys), slice_hi, m);
             if (m <= 0) {          // cannot happen with distinct keys (the index is part of them): corrupted bins -- fail loudly, never spin
                 if (tid == 0) atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);
                 break;
@@ -1927,9 +1948,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             __shared__ uint32_t s_fill2;
             if (tid == 0) s_fill2 = 0u;
             __syncthreads();
-            for (int i = tid; i < total; i += GSR_BLOCK) {
+            for (int i = tid; i < nslots; i += GSR_BLOCK) {
                 const unsigned long long k = seg[i];
-                if ((first_slice || k > slice_lo) && k <= slice_hi) s_keys[atomicAdd(&s_fill2, 1u)] = k;
+                if ((first_slice || k > slice_lo) && k <= slice_hi && k != ~0ull) s_keys[atomicAdd(&s_fill2, 1u)] = k;
             }
             __syncthreads();
         }

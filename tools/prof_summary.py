@@ -117,7 +117,11 @@ def main():
                 g = lambda n: d.get(n, 0.0) / max(cnt[k].get(n, 1), 1)
                 busy = max(g("SQ_BUSY_CU_CYCLES"), 1.0)
                 valu, mfma = g("SQ_INSTS_VALU") / busy, g("SQ_VALU_MFMA_BUSY_CYCLES") / 4.0 / busy
-                issue[k] = {"valu_issue_frac": valu, "mfma_pipe_frac": mfma, "sum": valu + mfma, "valu_insts_per_wave": g("SQ_INSTS_VALU") / max(g("SQ_WAVES"), 1.0),
+                # (two different pipes: waves of one SIMD overlap their MFMA and VALU instructions, so the two fractions are NOT added up --
+                # the binding one is the larger)
+                issue[k] = {"valu_issue_frac": valu, "mfma_pipe_frac": mfma, "binding_pipe": "valu" if valu >= mfma else "mfma",
+                            "valu_insts_per_launch": g("SQ_INSTS_VALU"), "waves_per_launch": g("SQ_WAVES"), "busy_cu_cycles_per_launch": busy,
+                            "valu_insts_per_wave": g("SQ_INSTS_VALU") / max(g("SQ_WAVES"), 1.0),
                             "lds_insts_per_wave": g("SQ_INSTS_LDS") / max(g("SQ_WAVES"), 1.0), "mfma_insts_per_wave": g("SQ_INSTS_MFMA") / max(g("SQ_WAVES"), 1.0)}
                 f.write(f"| {k} | {cnt[k].get('SQ_WAVES', 0)} | {g('SQ_WAVES'):.0f} | {g('SQ_INSTS_VALU') / 1e6:.2f} M | {g('SQ_INSTS_MFMA') / 1e6:.2f} M | "
                         f"{g('SQ_INSTS_LDS') / 1e6:.2f} M | {busy / 1e6:.1f} M | {valu:.2f} | {mfma:.2f} | {issue[k]['valu_insts_per_wave']:.0f} |\n")
