@@ -216,7 +216,29 @@ def main():
             if it_ >= 10:
                 fw += t1 - t0; bw += t2 - t1
         host_us = {"forward": 1e6 * fw / 50, "backward_incl_two_torch_sums": 1e6 * bw / 50, "scene": "2 000 Gaussians, 64x48: GPU work negligible"}
-        del tiny, tmodel, tvp, tpkg
+        # ... and the library's own share of it: the rasterizer module called directly with settings built once (render() spends the
+        # rest on the camera matrices, the settings tuple and a zeros_like -- the reference's Python), backward with ready-made
+        # gradient images through torch.autograd.backward (no loss kernels)
+        from diff_gaussian_rasterization_pose import GaussianRasterizationSettings as _RS, GaussianRasterizer as _RZ
+        rs = _RS(image_height=int(tvp.image_height), image_width=int(tvp.image_width), tanfovx=math.tan(0.5 * tvp.FoVx), tanfovy=math.tan(0.5 * tvp.FoVy),
+                 bg=background, scale_modifier=1.0, viewmatrix=tvp.world_view_transform, projmatrix=tvp.full_proj_transform,
+                 projmatrix_raw=tvp.projection_matrix, sh_degree=tmodel.active_sh_degree, campos=tvp.camera_center, prefiltered=False, debug=False)
+        rz = _RZ(raster_settings=rs)
+        m2d = torch.zeros_like(tmodel.get_xyz, requires_grad=True)
+        gi, gd = torch.ones((3, tiny.H, tiny.W), device=dev), torch.ones((1, tiny.H, tiny.W), device=dev)
+        fw = bw = 0.0
+        for it_ in range(60):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            o_ = rz(means3D=tmodel.get_xyz, means2D=m2d, opacities=tmodel.get_opacity, shs=tmodel.get_features, colors_precomp=None,
+                    scales=tmodel.get_scaling, rotations=tmodel.get_rotation, cov3D_precomp=None, theta=tvp.cam_rot_delta, rho=tvp.cam_trans_delta)
+            torch.cuda.synchronize(); t1 = time.perf_counter()
+            torch.autograd.backward([o_[0], o_[2]], [gi, gd])
+            torch.cuda.synchronize(); t2 = time.perf_counter()
+            if it_ >= 10:
+                fw += t1 - t0; bw += t2 - t1
+        host_us["rasterizer_module_forward"] = 1e6 * fw / 50
+        host_us["rasterizer_module_backward"] = 1e6 * bw / 50
+        del tiny, tmodel, tvp, tpkg, o_
 
     # ---- (b) the native loop (gsr_refine), one frame at a time; per-kernel breakdown from a separate short run
     frs = [PL.FusedRefiner(model, H, W, device=dev, gaussian_grads=not args.pose_only) for _ in range(F)]

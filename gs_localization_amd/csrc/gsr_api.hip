@@ -345,6 +345,32 @@ int select_device_of(const void* p, int* dev_out = nullptr)
     return GSR_OK;
 }
 
+// Zero fills of a stateless forward / backward: the small ones (counters, flags, cursors -- a few KB to a few hundred KB each) leave as
+// ONE kernel launch instead of one hipMemsetAsync each (every enqueue costs the host 5-8 us; the reference-style Python loop is
+// host-bound); large ranges keep the runtime's fill kernel.
+struct ZeroList {
+    gsr::ClearRanges cr = {};
+    int k = 0;
+    size_t small_words = 0;
+    int add(void* ptr, size_t bytes, hipStream_t st)
+    {
+        if (!ptr || bytes == 0) return GSR_OK;
+        if (bytes > (256u << 10) || (bytes & 3u) != 0 || k >= 10) { HIPCHK(hipMemsetAsync(ptr, 0, bytes, st)); return GSR_OK; }
+        cr.p[k] = static_cast<uint32_t*>(ptr); cr.n[k] = (uint32_t)(bytes / 4); k++;
+        small_words += bytes / 4;
+        return GSR_OK;
+    }
+    int flush(hipStream_t st)
+    {
+        if (k == 0) return GSR_OK;
+        const int blocks = (int)std::min<size_t>(256, std::max<size_t>(1, small_words / 2048));
+        hipLaunchKernelGGL(gsr::k_refine_init, dim3(blocks), dim3(GSR_BLOCK), 0, st, cr);
+        hipError_t e_ = hipGetLastError();
+        if (e_ != hipSuccess) return fail(GSR_E_HIP, "launch of %s failed: %s", "k_refine_init", hipGetErrorString(e_));
+        return GSR_OK;
+    }
+};
+
 }  // namespace
 
 extern "C" {
@@ -571,7 +597,8 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     pa.dirty = cx.native_loop ? g.dirty : nullptr;
     pa.rows = cx.rows;
     // (inside gsr_refine the list counters are cleared by the chain-rule kernel's last workgroup, once every consumer is done)
-    if (!cx.native_loop) HIPCHK(hipMemsetAsync(g.surv.n, 0, (size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE * sizeof(uint32_t), st));
+    ZeroList zl;
+    if (!cx.native_loop) { rc = zl.add(g.surv.n, (size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE * sizeof(uint32_t), st); if (rc != GSR_OK) return rc; }
     // Two ways to a tile's list.  With depth bounds from a previous forward (speculation) the few surviving instances are
     // appended to fixed-capacity per-tile bins by the preprocess itself; without them every instance is binned exactly
     // (count -> scan -> emit) and the compositing kernel orders each tile's segment lazily.  (More than 65 536 tiles: the
@@ -615,10 +642,12 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     // (on the by-tile path inside gsr_refine these words are cleared by the kernels that consume them: the tile cursors
     // by the compositing kernel, the superblock bounds by the pose step)
     if (sp.mode != 0 && !(by_tile && cx.native_loop)) {
-        HIPCHK(hipMemsetAsync(im.fail, 0, im.clear_words * sizeof(uint32_t), st));
-        HIPCHK(hipMemsetAsync(zbc_next, 0, (size_t)im.nsb * sizeof(float), st));
-    } else if (full_bins && !cx.native_loop)      // (the stateless entry points get a fresh image buffer per call: flag + cursors)
-        HIPCHK(hipMemsetAsync(im.fail, 0, im.clear_words * sizeof(uint32_t), st));
+        rc = zl.add(im.fail, im.clear_words * sizeof(uint32_t), st); if (rc != GSR_OK) return rc;
+        rc = zl.add(zbc_next, (size_t)im.nsb * sizeof(float), st); if (rc != GSR_OK) return rc;
+    } else if (full_bins && !cx.native_loop) {     // (the stateless entry points get a fresh image buffer per call: flag + cursors)
+        rc = zl.add(im.fail, im.clear_words * sizeof(uint32_t), st); if (rc != GSR_OK) return rc;
+    }
+    rc = zl.flush(st); if (rc != GSR_OK) return rc;
     {
         ProfScope ps(K_PREPROCESS, st);
         pa.zbc_lds = (pa.zbc != nullptr && im.nsb <= 4096) ? im.nsb : 0;
@@ -813,7 +842,9 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
 
     // Gradient tensors are zero-filled on the side stream while K7 runs; K8/K9 then only writes non-zero rows.
     // (the native loop zero-fills once per frame and keeps the tensors consistent through the dirty bits)
-    SideLease side_lease(!(debug || cx.native_loop), dev);
+    // (a side stream only pays when there is something sizeable to overlap: below ~100 k Gaussians the fork / join events cost the
+    // host more than the fill takes)
+    SideLease side_lease(!(debug || cx.native_loop) && P >= 100000, dev);
     Side* side = side_lease.sd;
     hipStream_t zs = side ? side->st : st;
     if (side) {
@@ -843,11 +874,13 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         }
     }
     if (side) HIPCHK(hipEventRecord(side->join, side->st));
-    if (!cx.native_loop) {      // accumulators of K7 (atomically summed)
+    if (!cx.native_loop) {      // accumulators of K7 (atomically summed), its flags
         ProfScope psz(K_BWD_ZERO, st);
-        HIPCHK(hipMemsetAsync(g.acc, 0, (size_t)P * GSR_ACC_STRIDE * (cx.det ? 2 * sizeof(long long) : sizeof(float)), st));
-        if (pose_mode) HIPCHK(hipMemsetAsync(g.tau_acc, 0, (cx.det ? 16 : 8) * GSR_TAU_SLOTS * sizeof(double), st));
-        HIPCHK(hipMemsetAsync(g.aflag, 0, 2 * (size_t)P, st));
+        ZeroList zl;
+        rc = zl.add(g.acc, (size_t)P * GSR_ACC_STRIDE * (cx.det ? 2 * sizeof(long long) : sizeof(float)), st); if (rc != GSR_OK) return rc;
+        if (pose_mode) { rc = zl.add(g.tau_acc, (cx.det ? 16 : 8) * GSR_TAU_SLOTS * sizeof(double), st); if (rc != GSR_OK) return rc; }
+        rc = zl.add(g.aflag, (2 * (size_t)P + 3) & ~(size_t)3, st); if (rc != GSR_OK) return rc;
+        rc = zl.flush(st); if (rc != GSR_OK) return rc;
     }
     {
         ProfScope psb(K_RENDER_BWD, st);
@@ -1101,6 +1134,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     CachedBuf gb{a->geometry_buffer, a->geometry_ctx, nullptr, 0}, bb{a->binning_buffer, a->binning_ctx, nullptr, 0},
         ib{a->image_buffer, a->image_ctx, nullptr, 0};
     float* ps = a->pose_state;
+    const bool host_mirror = a->pose_state_host != nullptr && a->init_R != nullptr;
     *iters_done = 0;
     *converged = 0;
     uint32_t* poison = reinterpret_cast<uint32_t*>(ps + GSR_PS_POISON);
@@ -1146,7 +1180,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         }
         if (a->init_R) {
             if (!a->init_T || !a->init_exposure_a || !a->init_exposure_b) return fail(GSR_E_INVALID, "gsr_refine: init_R, init_T, init_exposure_a/b go together%s", "");
-            hipLaunchKernelGGL(k_pose_load, dim3(1), dim3(64), 0, st, ps, a->init_R, a->init_T, a->init_exposure_a, a->init_exposure_b, a->projmatrix_raw);
+            hipLaunchKernelGGL(k_pose_load, dim3(1), dim3(64), 0, st, ps, a->init_R, a->init_T, a->init_exposure_a, a->init_exposure_b, a->projmatrix_raw,
+                               a->pose_state_host ? h_status + 16 : (float*)nullptr);
             { const int debug = 0; LAUNCHCHK("k_pose_load"); }
         }
         cx.rows = GradRows{a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor, a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, a->M};
@@ -1228,6 +1263,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         cx.fold.st = ps; cx.fold.dL_dtau = a->dL_dtau; cx.fold.dL_dtau_out = a->dL_dtau; cx.fold.loss_out = a->loss_out;
         cx.fold.proj_raw = a->projmatrix_raw; cx.fold.lr = a->lr; cx.fold.conv_thr = a->converged_threshold; cx.fold.loss_zero = a->loss_out;
         cx.fold.host_status = const_cast<uint32_t*>(slot_of(g)); cx.fold.seq = g + 1; cx.fold.loss_shards = imv.loss_shards;
+        cx.fold.host_state = host_mirror ? h_status + 16 : nullptr;
         cx.fold.clear_b = (mode != 0) ? imv.zbc[par(g) ^ 1] : nullptr; cx.fold.clear_n = imv.nsb;
         // n_touched is wanted for the LAST forward only (see the end): a group that may be the last counts it itself
         const bool count_touched = maybe_last && a->n_touched != nullptr;
@@ -1364,7 +1400,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                            im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{}, 0u, (uint32_t*)nullptr, (a->P < (1 << 28)) ? 1 : 0, (uint32_t*)nullptr);
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
-    if (a->pose_state_host) HIPCHK(hipMemcpyAsync(h_status + 16, ps, GSR_POSE_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToHost, st));
+    // (with init_* the kernels have kept a mirror of the state in pinned memory -- k_pose_load and every pose step that ran: no copy)
+    if (a->pose_state_host && !host_mirror) HIPCHK(hipMemcpyAsync(h_status + 16, ps, GSR_POSE_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (a->pose_state_host) memcpy(a->pose_state_host, h_status + 16, GSR_POSE_STATE_FLOATS * sizeof(float));
     ctx_lease.clean = true;

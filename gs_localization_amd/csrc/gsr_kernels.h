@@ -2656,18 +2656,26 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_refine_init(ClearRanges c)
 }
 
 // gsr_refine_args.init_*: the whole initial state from the caller's device tensors (zeros, R, T, exposure, camera) in one launch
-__global__ void k_pose_load(float* st, const float* R0, const float* T0, const float* ea, const float* eb, const float* proj_raw)
+__global__ void __launch_bounds__(64) k_pose_load(float* st, const float* R0, const float* T0, const float* ea, const float* eb, const float* proj_raw, float* host_state)
 {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
+    // (host_state, nullable: the host's mirror of the pose state in pinned memory, see PoseStepArgs::host_state)
+    __shared__ float s_st[GSR_PS_SIZE];
+    const int lane = threadIdx.x;
+    for (int i = lane; i < GSR_PS_SIZE; i += 64) s_st[i] = 0.f;
+    __syncthreads();
+    if (lane == 0) {
         float R[9], T[3];
         for (int i = 0; i < 9; i++) R[i] = R0[i];
         for (int i = 0; i < 3; i++) T[i] = T0[i];
-        const float a = ea[0], b = eb[0];
-        for (int i = 0; i < GSR_PS_SIZE; i++) st[i] = 0.f;
-        for (int i = 0; i < 9; i++) st[GSR_PS_R + i] = R[i];
-        for (int i = 0; i < 3; i++) st[GSR_PS_T + i] = T[i];
-        st[GSR_PS_PARAM + 6] = a; st[GSR_PS_PARAM + 7] = b;
-        pose_write_camera(st, R, T, proj_raw);
+        for (int i = 0; i < 9; i++) s_st[GSR_PS_R + i] = R[i];
+        for (int i = 0; i < 3; i++) s_st[GSR_PS_T + i] = T[i];
+        s_st[GSR_PS_PARAM + 6] = ea[0]; s_st[GSR_PS_PARAM + 7] = eb[0];
+        pose_write_camera(s_st, R, T, proj_raw);
+    }
+    __syncthreads();
+    for (int i = lane; i < GSR_PS_SIZE; i += 64) {
+        st[i] = s_st[i];
+        if (host_state != nullptr) host_state[i] = s_st[i];
     }
 }
 
@@ -2709,6 +2717,8 @@ struct PoseStepArgs {
     float* st; const float* dL_dtau; double* tau_acc; float* dL_dtau_out; const float* loss_out; const float* proj_raw;
     float lr, conv_thr; float* loss_zero; uint32_t* host_status; int seq; float* loss_shards; float* clear_b; int clear_n;
     int det;        // deterministic option: tau_acc holds 12 fixed-point world-frame sums per slot, loss_shards fixed-point sums
+    float* host_state;      // nullable, pinned host memory, GSR_PS_SIZE floats: every step that runs mirrors the new state there, so that the
+                            // call can hand the final pose back without a device-to-host copy in front of its last synchronisation
 };
 struct alignas(16) PoseStepLDS { float st[GSR_PS_SIZE]; float t6[8]; float loss[4]; float proj[16]; };
 template <bool DET>      // (compile time: the deterministic option's branches cost the default path's serial tail 2 k cycles as run-time tests)
@@ -2876,7 +2886,10 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
         __syncthreads();
         conv_out = s.st[GSR_PS_CONV];
         for (int i = lane; i < GSR_PS_SIZE; i += 64)
-            if (i != GSR_PS_POISON && i != GSR_PS_TICKET) st[i] = s.st[i];           // (those two words belong to other kernels and the host)
+            if (i != GSR_PS_POISON && i != GSR_PS_TICKET) {           // (those two words belong to other kernels and the host)
+                st[i] = s.st[i];
+                if (q.host_state != nullptr) q.host_state[i] = s.st[i];
+            }
         if (q.loss_zero != nullptr && lane < 4) q.loss_zero[lane] = 0.f;
     } else conv_out = st[GSR_PS_CONV];
     if (lane == 0 && q.host_status != nullptr) {

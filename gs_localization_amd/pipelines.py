@@ -106,7 +106,7 @@ class FusedRefiner:
         self._carry_versions = None      # torch's in-place-modification counters of those tensors when the last call returned
         self._conv_cache = {}
         self._state_host = (C.c_float * _lib.POSE_STATE_FLOATS)()
-        self._state_host_t = torch.from_numpy(np.frombuffer(self._state_host, dtype=np.float32))      # (a view: no copy per call)
+        self._state_host_np = np.frombuffer(self._state_host, dtype=np.float32)      # (a view: no copy per call)
         # gsr_refine_args: everything that does not change from call to call is filled in once
         p = lambda t: None if t is None else t.data_ptr()
         a = _lib.RefineArgs()
@@ -127,6 +127,11 @@ class FusedRefiner:
         self._stats = (C.c_int * 4)(0, 0, 0, 0)
         a.stats_out = self._stats
         self._args = a
+        # Once the three workspaces have their size (after the first call) they are handed over as FIXED buffers (include/gsr.h,
+        # gsr_fixed_buffer_resize): the library's size requests then never enter the interpreter (three ctypes callbacks per call
+        # otherwise); a request that no longer fits fails the call with GSR_E_ALLOC, which is repeated once with growing buffers.
+        self._fb = (_lib.FixedBuffer * 3)()
+        self._fb_addr = [C.addressof(self._fb[k]) for k in range(3)]
 
     def _tensor_versions(self):
         ts = (self.means3D, self.scales, self.rots, self.g_alpha, self.g_m2d, self.g_conic, self.g_opac, self.g_col, self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot)
@@ -151,12 +156,11 @@ class FusedRefiner:
     def _env_flags():
         """GSR_NO_LEAN / GSR_SH_SEPARATE / GSR_NO_BALANCE / GSR_DEBUG_TILES / GSR_DETERMINISTIC of the environment ->
         gsr_refine_args.flags (the library itself reads no environment variable on this path)."""
-        import os
         from . import _lib
-        env = os.environ
-        return ((_lib.REFINE_NO_LEAN if "GSR_NO_LEAN" in env else 0) | (_lib.REFINE_SH_SEPARATE if "GSR_SH_SEPARATE" in env else 0) |
-                (_lib.REFINE_NO_BALANCE if "GSR_NO_BALANCE" in env else 0) | (_lib.REFINE_LOG_REDO if "GSR_DEBUG_TILES" in env else 0) |
-                (_lib.REFINE_DETERMINISTIC if "GSR_DETERMINISTIC" in env else 0))
+        from .rasterizer import _env_has as has
+        return ((_lib.REFINE_NO_LEAN if has("GSR_NO_LEAN") else 0) | (_lib.REFINE_SH_SEPARATE if has("GSR_SH_SEPARATE") else 0) |
+                (_lib.REFINE_NO_BALANCE if has("GSR_NO_BALANCE") else 0) | (_lib.REFINE_LOG_REDO if has("GSR_DEBUG_TILES") else 0) |
+                (_lib.REFINE_DETERMINISTIC if has("GSR_DETERMINISTIC") else 0))
 
     def refine(self, viewpoint, config, initial_R, initial_T, background, iters=50, lr=0.001, converged_threshold=1e-4,
                stop_on_converged=True, speculative=True, bound_margin=None, warm_start=None, count_instances=False,
@@ -166,7 +170,10 @@ class FusedRefiner:
         # speculative=True: exact optimisation (include/gsr.h, gsr_refine_args.speculative): ~9x fewer binned
         # instances and ~7x fewer SH rows on S-1M-640.
         viewpoint.update_RT(initial_R, initial_T)
-        f32d = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        def f32d(t):          # float32, contiguous, on the device: usually it already is
+            if t.dtype is torch.float32 and t.device == dev and t.is_contiguous():
+                return t.detach() if t.requires_grad else t
+            return t.detach().to(device=dev, dtype=torch.float32).contiguous()
         # the start pose goes to the library as the camera's own device tensors (gsr_refine_args.init_*: the pose state is
         # built by one launch inside the call; reading R, T and the exposure back to build it on the host would cost four
         # stream synchronisations, five tiny torch copies cost five launches)
@@ -223,27 +230,51 @@ class FusedRefiner:
         a.flags = self._env_flags() if flags is None else int(flags)
         a.lean_min_P = int(lean_min_P)
         n_done, conv = C.c_int(0), C.c_int(0)
-        with torch.cuda.device(dev):
+        ws = self.ws
+        fixed = all(w.t.numel() > 0 for w in ws)
+        if fixed:
+            ff = _lib.fixed_buffer_fn()
+            for k in range(3):
+                self._fb[k].ptr, self._fb[k].capacity = ws[k].t.data_ptr(), ws[k].t.numel()
+            a.geometry_buffer = a.binning_buffer = a.image_buffer = ff
+            a.geometry_ctx, a.binning_ctx, a.image_ctx = self._fb_addr
+        else:
+            a.geometry_buffer, a.binning_buffer, a.image_buffer = ws[0].fn, ws[1].fn, ws[2].fn
+            a.geometry_ctx, a.binning_ctx, a.image_ctx = ws[0].key, ws[1].key, ws[2].key
+        cur = torch.cuda.current_device()
+        if cur != dev.index:
+            torch.cuda.set_device(dev)
+        try:
             rc = self.lib.gsr_refine(C.byref(a), C.byref(n_done), C.byref(conv))
-            type(self.ws[0]).raise_pending(*self.ws)
-            _lib.check(rc)
+            if fixed and rc == _lib.E_ALLOC:          # a workspace has to grow: once more through the growing callbacks
+                self._warm.value = 0
+                self._carry.value = 0
+                a.geometry_buffer, a.binning_buffer, a.image_buffer = ws[0].fn, ws[1].fn, ws[2].fn
+                a.geometry_ctx, a.binning_ctx, a.image_ctx = ws[0].key, ws[1].key, ws[2].key
+                rc = self.lib.gsr_refine(C.byref(a), C.byref(n_done), C.byref(conv))
+            type(ws[0]).raise_pending(*ws)
+            if rc < 0:
+                _lib.check(rc)
+        finally:
+            if cur != dev.index:
+                torch.cuda.set_device(cur)
         self._carry_versions = self._tensor_versions() + (float(scale_modifier),)
         self._last_args = a                                          # (gsr_debug_lean_check takes the same struct)
         self._keep = (R0, T0, ea0, eb0, proj_raw, gt_image, gt_depth, mask, bg)        # alive until the stream has drained
         # the final pose came back with the call (gsr_refine_args.pose_state_host): no second blocking read.  The camera gets
         # device tensors that are views of this call's state (no copy, no launch; host -> device uploads would each stall)
-        s = self._state_host_t
-        with torch.no_grad():
-            st = self.state
-            viewpoint.update_RT(st[0:9].view(3, 3), st[9:12])
-            viewpoint.exposure_a.data = st[18:19].view(viewpoint.exposure_a.shape)
-            viewpoint.exposure_b.data = st[19:20].view(viewpoint.exposure_b.shape)
-        self.last_info = {"fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]), "host_redos": int(stats[3])}
-        return viewpoint.R, viewpoint.T, {"iters": n_done.value, "converged": bool(conv.value), "loss": float(s[38]),
-                                          "fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]), "host_redos": int(stats[3]),
-                                          # (host copies of the final pose: no device read-back for the caller's error statistics)
-                                          "R_host": s[0:9].numpy().reshape(3, 3).copy(), "T_host": s[9:12].numpy().copy(),
-                                          "render": self.color, "depth": self.depth, "opacity": self.alpha}
+        s = self._state_host_np
+        st = self.state          # (views of a tensor that does not require grad: no autograd bookkeeping to switch off)
+        viewpoint.update_RT(st[0:9].view(3, 3), st[9:12])
+        viewpoint.exposure_a.data = st[18:19].view(viewpoint.exposure_a.shape)
+        viewpoint.exposure_b.data = st[19:20].view(viewpoint.exposure_b.shape)
+        info = {"iters": n_done.value, "converged": bool(conv.value), "loss": float(s[38]),
+                "fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]), "host_redos": int(stats[3]),
+                # (host copies of the final pose: no device read-back for the caller's error statistics)
+                "R_host": s[0:9].reshape(3, 3).copy(), "T_host": s[9:12].copy(),
+                "render": self.color, "depth": self.depth, "opacity": self.alpha}
+        self.last_info = info
+        return viewpoint.R, viewpoint.T, info
 
     def lean_check(self):
         """gsr_debug_lean_check on the state the last refine() left (tests): (settled, candidates, binned by the exact walk,

@@ -31,5 +31,8 @@ case $step in
   tail)          # the slowest waves of k_render_fwd on complete lists, by phase (diagnostic build)
     GSR_TIMING=1 GSR_DEFS="-DGSR_TIMING_ORDER $TAILDEFS" python gs_localization_amd/build.py > $o/tail_build.log 2>&1
     for sc in ${@:-s_1m_640}; do echo "== $sc"; SCENE=$sc LOOP_PLAIN=1 python tools/dbg/tail_rows.py; done > $o/tail.log 2>&1 ;;
+  timing_spec)   # phase clocks of the speculative loop (diagnostic build)
+    GSR_TIMING=1 python gs_localization_amd/build.py > /dev/null 2>&1
+    for sc in ${@:-s_1m_640}; do echo "== $sc speculative"; SCENE=$sc python tools/phase_timing.py 2>/dev/null | grep -v amdgpu; done > $o/timing_spec.log ;;
   *) echo "unknown step $step" ;;
 esac
