@@ -27,6 +27,7 @@ SIGNATURES = {
     "gsr_densification_stats": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsr_map_from_ply_rows": (_i, [_i, _vp, _i, C.POINTER(C.c_int), _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "gsr_geometry_bytes": (C.c_size_t, [_i]),
+    "gsr_geometry_bytes_det": (C.c_size_t, [_i]),
     "gsr_image_bytes": (C.c_size_t, [_i, _i]),
     "gsr_binning_bytes": (C.c_size_t, [_i]),
     "gsr_binning_bytes_bins": (C.c_size_t, [_i, _i, _i]),

@@ -109,7 +109,10 @@ struct Geom {   // per-Gaussian state carried from forward to backward
     float* lam;               // per-Gaussian float4 (mean, bound on sqrt(lambda_max(Sigma))) (PreArgs::lam), valid whenever cov3D holds every covariance
     uint8_t* aflag;           // 2 n bytes: "the compositing backward added to this Gaussian's record / to its colour sums" (K7 sets, K8 clears)
 };
-size_t carve_geom(char* base, int P, Geom& g)
+// `det`: the deterministic option's accumulator records are twelve PAIRS of 64-bit words (192 B) instead of twelve floats (48 B).
+// The records sit at the END of the workspace, so that every other array has the same place in either mode and only the size asked
+// for depends on it (every caller used to pay 192 B per Gaussian for an option only tests use).
+size_t carve_geom(char* base, int P, Geom& g, bool det = false)
 {
     Carver c(base);
     const size_t n = P > 0 ? (size_t)P : 1;
@@ -117,7 +120,6 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.clamped = c.take<uint8_t>(n);
     g.tiles_touched = c.take<uint32_t>(n);
     g.rects = c.take<ushort4>(n);
-    g.acc = c.take<float>(4 * GSR_ACC_STRIDE * n);      // (four times the floats: the deterministic option keeps a pair of 64-bit fixed-point words per quantity)
     g.dirty = c.take<uint8_t>(n);
     g.tau_acc = c.take<double>(16 * GSR_TAU_SLOTS);      // (second half: the deterministic option's world-frame sums 6 ... 11)
     g.rec = c.take<float>((n + 1) * GSR_REC_STRIDE);
@@ -126,6 +128,7 @@ size_t carve_geom(char* base, int P, Geom& g)
     g.surv.ids = c.take<uint32_t>((size_t)GSR_SURV_LISTS * g.surv.cap);
     g.lam = c.take<float>(4 * n);
     g.aflag = c.take<uint8_t>(2 * n);
+    g.acc = c.take<float>((det ? 4 : 1) * GSR_ACC_STRIDE * n);
     return c.size();
 }
 
@@ -468,7 +471,8 @@ int gsr_device_ok(void)
     return strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 0;
 }
 
-size_t gsr_geometry_bytes(int P) { Geom g; return carve_geom(nullptr, P, g); }
+size_t gsr_geometry_bytes(int P) { Geom g; return carve_geom(nullptr, P, g, false); }
+size_t gsr_geometry_bytes_det(int P) { Geom g; return carve_geom(nullptr, P, g, true); }
 size_t gsr_image_bytes(int width, int height) { Img im; return carve_img(nullptr, width, height, im); }
 size_t gsr_binning_bytes(int num_rendered) { Bin b; return carve_bin(nullptr, num_rendered, b); }
 size_t gsr_binning_bytes_bins(int P, int width, int height)
@@ -564,7 +568,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     const SpecCtx& sp = cx.spec;
 
     Geom g;
-    const size_t gbytes = carve_geom(nullptr, P, g);
+    const size_t gbytes = carve_geom(nullptr, P, g, cx.det);
     char* gptr = (char*)geometry_buffer(geometry_ctx, gbytes);
     if (!gptr) return fail(GSR_E_ALLOC, "geometry buffer callback returned NULL%s", "");
     carve_geom(gptr, P, g);
@@ -1160,7 +1164,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         // vouches for them (carried bit 0)
         const size_t Pn = (size_t)a->P;
         Geom gg;
-        char* gptr = (char*)cached_resize(&gb, carve_geom(nullptr, a->P, gg));
+        char* gptr = (char*)cached_resize(&gb, carve_geom(nullptr, a->P, gg, cx.det));
         if (!gptr) return fail(GSR_E_ALLOC, "geometry buffer callback returned NULL%s", "");
         carve_geom(gptr, a->P, gg);
         if (!(carried & 1)) {

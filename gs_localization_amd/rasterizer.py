@@ -176,14 +176,14 @@ def speculation_counters(device=None):
 _size_cache = {}
 
 
-def _workspace_sizes(lib, P, W, H):
+def _workspace_sizes(lib, P, W, H, det=False):
     """(geometry, binning, image) bytes of a forward whose lists go into per-tile bins, or None when the binning workspace cannot
     be sized up front (gsr_binning_bytes_bins == 0)"""
-    key = (P, W, H)
+    key = (P, W, H, det)
     hit = _size_cache.get(key)
     if hit is None:
         b = int(lib.gsr_binning_bytes_bins(P, W, H))
-        hit = (int(lib.gsr_geometry_bytes(P)), b, int(lib.gsr_image_bytes(W, H))) if b > 0 else False
+        hit = (int(lib.gsr_geometry_bytes_det(P) if det else lib.gsr_geometry_bytes(P)), b, int(lib.gsr_image_bytes(W, H))) if b > 0 else False
         if len(_size_cache) > 64:
             _size_cache.clear()
         _size_cache[key] = hit
@@ -262,7 +262,8 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     N4 = 4 * H * W
     a.out_color, a.out_depth, a.out_alpha = base, base + 3 * N4, base + 4 * N4
     a.radii = radii.data_ptr() if nz else None
-    a.debug = int(bool(rs.debug)) | (2 if _env_has("GSR_SH_EAGER") else 0)
+    det = _env_has("GSR_DETERMINISTIC")
+    a.debug = int(bool(rs.debug)) | (2 if _env_has("GSR_SH_EAGER") else 0) | (4 if det else 0)
     a.n_touched = (ints.data_ptr() + 4 * P) if (want_touched and nz) else None
     a.stream = stream
     # (the library selects the device that owns means3D itself; torch's current device only matters for the allocations above,
@@ -274,7 +275,7 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     # reference's is; a bin that overflowed).
     geom_t = bin_t = img_t = None
     rc = None
-    sizes = _workspace_sizes(lib, P, W, H) if nz else None
+    sizes = _workspace_sizes(lib, P, W, H, det) if nz else None
     if sizes is not None:
         bufs = [torch.empty(n, dtype=torch.uint8, device=dev) for n in sizes]
         fb = blk.fb
@@ -298,14 +299,14 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     num_rendered = rc if rc >= 0 else _lib.check(rc)
     saved = (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_t, bin_t, img_t, alpha,
              opacities)
-    consts = (bg, view, proj, campos)
+    consts = (bg, view, proj, campos, det)      # (det: this forward's geometry workspace has room for the deterministic backward's records)
     return num_rendered, color, radii, depth, alpha, n_touched, saved, consts
 
 
 def _backward_impl(rs, num_rendered, saved, consts, grad_color, grad_depth, grad_alpha, pose_mode, need):
     lib = _lib.load()
     colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer, alpha, _ = saved
-    bg, view, proj, campos = consts
+    bg, view, proj, campos, det = consts
     dev = means3D.device
     P = means3D.size(0)
     n_sh = sh.numel()
@@ -356,7 +357,8 @@ def _backward_impl(rs, num_rendered, saved, consts, grad_color, grad_depth, grad
         offs.append((f0 + 4 * off) if (w and nz) else None)
         off += P * w
     (b.dL_dconic, b.dL_drot, b.dL_dsh, b.dL_dmean2D, b.dL_dmean3D, b.dL_dcov3D, b.dL_dcolor, b.dL_dscale, b.dL_dopacity) = offs
-    b.debug = int(bool(rs.debug)) | (4 if _env_has("GSR_DETERMINISTIC") else 0)
+    # (deterministic sums only if the FORWARD already ran with the option: it sized the accumulator records)
+    b.debug = int(bool(rs.debug)) | (4 if det else 0)
     b.pose_mode = 1 if pose_mode else 0
     b.dL_dtau = (f0 + 4 * off) if pose_mode else None
     b.stream = torch.cuda.current_stream(dev).cuda_stream

@@ -61,7 +61,8 @@ typedef void* (*gsr_resize_fn)(void* ctx, size_t bytes);
  *   debug: bit 0 = the reference's debug flag (synchronise and check after every kernel, auxiliary.h:166-173);
  *       bit 1 (value 2) = diagnostics: SH colours of every visible Gaussian up front (k_sh_color) instead of lazily in the
  *       compositing kernel -- same results (tests/test_gpu_parity.py); the library reads no environment variable here.
- *       gsr_backward only: bit 2 (value 4) = the deterministic option, see GSR_REFINE_DETERMINISTIC.
+ *       bit 2 (value 4) = the deterministic option, see GSR_REFINE_DETERMINISTIC: gsr_backward sums in 64-bit fixed point; the FORWARD
+ *       whose buffers it will use must be given the bit too (it asks its geometry callback for the larger accumulator records).
  * Returns num_rendered (the `int rendered` of rasterize_points.cu:82) or a negative error.
  * Performs one blocking device->host read of num_rendered, like rasterizer_impl.cu:282. */
 int gsr_forward(gsr_resize_fn geometry_buffer, void* geometry_ctx,
@@ -230,6 +231,7 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
 /* Fixed-size parts of the workspace, for callers that pre-allocate instead of resizing
  * (replaces `required<GeometryState>(P)` etc., rasterizer_impl.h:66-72). */
 size_t gsr_geometry_bytes(int P);
+size_t gsr_geometry_bytes_det(int P);      /* with the deterministic option (debug bit 2 of BOTH passes / GSR_REFINE_DETERMINISTIC): 64-bit accumulator records */
 size_t gsr_image_bytes(int width, int height);
 size_t gsr_binning_bytes(int num_rendered);
 
@@ -362,7 +364,7 @@ typedef struct gsr_refine_args {
  * from the default mode's by rounding only.  Per-(tile, Gaussian) gradient sums are kept as a coarse word (2^-8, +-2^55) plus a
  * remainder word (2^-56): no practical range limit; a per-Gaussian pose term must stay below 2^31 in magnitude, a per-tile loss sum
  * below 2^33 (beyond that the integer wraps).  Costs 2-4 % of a speculative iteration, 15 % with complete lists; the geometry buffer
- * reserves 192 B per Gaussian for the accumulator records in either mode. */
+ * then holds 192 B of accumulator records per Gaussian instead of 48 (gsr_geometry_bytes_det). */
 #define GSR_REFINE_DETERMINISTIC 16u
 int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
 

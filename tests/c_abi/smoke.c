@@ -67,7 +67,8 @@ int main(void)
     CK(hipStreamCreate(&st));
 
     const int R = gsr_forward(resize_cb, &geom, resize_cb, &binning, resize_cb, &img, P, 0, 0, d_bg, W, H, d_means, NULL, d_col, d_opac, d_scales,
-                              1.0f, d_rots, NULL, d_view, d_proj, d_campos, tanx, tany, 0, out_color, out_depth, out_alpha, radii, 0, touched, st);
+                              1.0f, d_rots, NULL, d_view, d_proj, d_campos, tanx, tany, 0, out_color, out_depth, out_alpha, radii,
+                              /* debug bit 2: this forward's buffers will also feed a DETERMINISTIC backward below (64-bit accumulator records) */ 4, touched, st);
     if (R < 0) { fprintf(stderr, "gsr_forward: %s\n", gsr_last_error()); return 1; }
     CK(hipStreamSynchronize(st));
     static float h_color[3 * N], h_alpha[N];

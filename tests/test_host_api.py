@@ -35,7 +35,8 @@ def test_workspace_sizes():
     from gs_localization_amd import _lib
     lib = _lib.load()
     g1, g2 = lib.gsr_geometry_bytes(1000), lib.gsr_geometry_bytes(1_000_000)
-    assert 0 < g1 < g2 and g2 < 320 * 1_000_000      # (298 B per Gaussian: 192 of them the accumulator records, sized for the deterministic option)
+    assert 0 < g1 < g2 and g2 < 180 * 1_000_000      # (~160 B per Gaussian; the deterministic option's 64-bit accumulator records only on request)
+    assert g2 + 140 * 1_000_000 < lib.gsr_geometry_bytes_det(1_000_000) < 320 * 1_000_000
     assert lib.gsr_image_bytes(640, 480) >= 640 * 480 * 4 + 1200 * 8
     assert lib.gsr_binning_bytes(1_000_000) >= 12 * 1_000_000
 

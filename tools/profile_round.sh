@@ -4,7 +4,7 @@
 tag=$1
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 out=gpurun_out/prof_$tag; mkdir -p $out
-CMD="bench.py --steps 50 --warmup 2 --no-cpu-baseline --no-train-leg --repeats 1"
+CMD="bench.py --steps 50 --warmup 2 --no-cpu-baseline --no-train-leg --no-cam-leg --repeats 1"
 timeout 600 rocprofv3 --kernel-trace --stats -d $out/kt -o $tag --output-format csv -- python3 $CMD > $out/kt.log 2>&1
 CMD1="tools/loop_only.py 60"
 timeout 600 rocprofv3 --pmc FETCH_SIZE -d $out/fetch -o $tag --output-format csv -- python3 $CMD1 > $out/fetch.log 2>&1
