@@ -15,6 +15,7 @@ SIGNATURES = {
     "gsr_forward": (_i, [RESIZE_FN, _vp, RESIZE_FN, _vp, RESIZE_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp,
                          _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "gsr_spec_state_bytes": (C.c_size_t, [_i, _i]),
+    "gsr_spec_state_bounds_bytes": (C.c_size_t, [_i, _i]),
     "gsr_forward_speculative": (_i, [_vp, RESIZE_FN, _vp, RESIZE_FN, _vp, RESIZE_FN, _vp, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp,
                                      _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "gsr_backward": (_i, [_i, _i, _i, _i, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp,

@@ -747,7 +747,10 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
             ta.keys = b.keys;
             // bands: each band's share of the key array should fit the L2s (8 x 4 MB) with room to spare
             int bands = (int)(((size_t)R * 8 + (12u << 20) - 1) / (12u << 20));
-            bands = std::max(1, std::min(bands, std::min(gy, 16)));
+#ifndef GSR_EMIT_BANDS_MAX
+#define GSR_EMIT_BANDS_MAX 16
+#endif
+            bands = std::max(1, std::min(bands, std::min(gy, GSR_EMIT_BANDS_MAX)));
             ProfScope ps(K_TILE_EMIT, st);
             const size_t lds = (size_t)2 * ntiles * sizeof(uint32_t);
             if (agg && kpt <= 2) hipLaunchKernelGGL((k_tile_emit<true, 2>), dim3(tblocks), dim3(GSR_TBIN_THREADS), lds, st, ta, bands);
@@ -950,6 +953,14 @@ size_t gsr_spec_state_bytes(int width, int height)
 {
     if (width <= 0 || height <= 0) return 0;
     Img im; return carve_spec(nullptr, width, height, im, nullptr);
+}
+size_t gsr_spec_state_bounds_bytes(int width, int height)
+{
+    if (width <= 0 || height <= 0) return 0;
+    Img im;
+    char* base = reinterpret_cast<char*>((uintptr_t)4096);      // (never dereferenced: carve_spec only does pointer arithmetic)
+    carve_spec(base, width, height, im, nullptr);
+    return (size_t)(reinterpret_cast<char*>(im.fail) - base);
 }
 
 int gsr_forward_speculative(gsr_spec_state* s, GSR_FWD_PARAMS)

@@ -116,6 +116,10 @@ typedef struct gsr_spec_state {
     int n_speculative, n_failed;/* counters: verified / missed guesses */
 } gsr_spec_state;
 size_t gsr_spec_state_bytes(int width, int height);
+/* The leading bytes of a state's device buffer that hold the recorded depth bounds (the rest is scratch): a caller that keeps one
+ * state per camera seeds a NEW camera's state by copying that much from the state of the view it rendered last (and the host
+ * fields valid / parity) -- a guess like any other, verified like any other. */
+size_t gsr_spec_state_bounds_bytes(int width, int height);
 int gsr_forward_speculative(gsr_spec_state* state,
                             gsr_resize_fn geometry_buffer, void* geometry_ctx,
                             gsr_resize_fn binning_buffer, void* binning_ctx,

@@ -50,7 +50,7 @@ def _close_grads(ga, gb, pose):
 def test_nearby_render_is_speculative_and_identical(pose):
     sc = S.small(P=30000, W=160, H=128, sh_degree=3, seed=21, scale_med=0.04)
     grads = U.random_grads(sc, seed=3)
-    RZ._spec_cache.states.clear()
+    RZ._spec_cache.clear()
     first = _w2c([0, 0, 0, 0, 0, 0])
     near = _w2c([0.004, -0.003, 0.002, 0.002, -0.001, 0.0015])
     _run(sc, first, pose, True, grads)                       # no bounds yet: complete lists, records the bounds
@@ -70,7 +70,7 @@ def test_missed_guess_is_redone_and_backs_off():
     other = S.small(P=30000, W=160, H=128, sh_degree=2, seed=23, scale_med=0.04)       # same image size, other map,
     other.means3D *= np.float32(1.5); other.scales *= np.float32(1.5)                   # 1.5x further away: the bounds are useless
     grads = U.random_grads(sc, seed=4)
-    RZ._spec_cache.states.clear()
+    RZ._spec_cache.clear()
     _run(sc, _w2c([0] * 6), True, True, grads)
     o_s, g_s = _run(other, _w2c([0] * 6), True, True, grads)
     v, m = RZ.speculation_counters()
@@ -107,7 +107,7 @@ def test_python_loop_uses_the_speculation_and_matches_the_plain_loop():
     res = {}
     for spec in (False, True):
         os.environ["GSR_SPECULATION"] = "1" if spec else "0"
-        RZ._spec_cache.states.clear()
+        RZ._spec_cache.clear()
         vp = PL.make_frame(sc, model, dev, bg)
         R, T, _ = PL.python_loop(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), model, bg, iters=12)
         res[spec] = (R.detach().clone(), T.detach().clone(), RZ.speculation_counters())

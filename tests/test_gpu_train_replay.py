@@ -67,7 +67,7 @@ def test_train_loop_with_growing_model_matches_the_oracle_at_three_sizes():
     from gs_localization_amd import rasterizer as RZ
     from tests.train_replay import TrainReplay
     O.set_threads(min(64, os.cpu_count() or 1))
-    RZ._spec_cache.states.clear()
+    RZ._spec_cache.clear()
     # the cadence of train.py:147-149 compressed: P changes at iterations 2, 4, 6, 8, 10 (x1.5 each time, 0.2 M -> 1.5 M)
     tr = TrainReplay(P0=200_000, P1=1_500_000, densify_from=1, densification_interval=2, densify_until=12)
     sizes, checked = [], []
@@ -85,8 +85,11 @@ def test_train_loop_with_growing_model_matches_the_oracle_at_three_sizes():
     assert all(np.isfinite(losses))
     # consumers of the densification statistics saw this step's visible Gaussians (train.py:142-145)
     assert float(tr.denom.sum()) > 0 and float(tr.max_radii2D.max()) > 0
-    # package (A) does not speculate by default (random cameras: every guess would miss): plain forwards, reproducible bit
-    # for bit; switched on explicitly, the state built before P changed is still exact afterwards
+    # package (A) does not speculate by default (train.py: Adam moves every opacity between two visits of a view, most guesses would
+    # miss -- measured, rasterizer.speculation_enabled): plain forwards, reproducible bit for bit.  Switched on explicitly it keeps
+    # one state per CAMERA (the storage address of the camera's view matrix tensor); a view's second render is then speculative and
+    # bit-identical to its first; a state built before P changed is still exact afterwards.
+    assert RZ.speculation_counters() == (0, 0)
     with torch.no_grad():
         a = tr.render(tr.views[3])
         b = tr.render(tr.views[3])
@@ -94,12 +97,16 @@ def test_train_loop_with_growing_model_matches_the_oracle_at_three_sizes():
         os.environ["GSR_SPECULATION"] = "1"
         try:
             c = tr.render(tr.views[3])
+            assert RZ.speculation_counters() == (0, 0)          # first render of this camera with a state: complete lists, records bounds
             d = tr.render(tr.views[3])
-            e = tr.render(tr.views[3])
+            assert RZ.speculation_counters() == (1, 0)
+            e = tr.render(tr.views[5])                   # another camera: its own state, seeded with view 3's bounds (a guess like any other)
+            e2 = tr.render(tr.views[5])
             v1, m1 = RZ.speculation_counters()
         finally:
             os.environ.pop("GSR_SPECULATION", None)
+    assert torch.equal(e["image"], e2["image"]) and torch.equal(e["radii"], e2["radii"])
     for k in ("image", "depth", "alpha", "radii"):
-        for other in (b, c, d, e):
+        for other in (b, c, d):
             assert torch.equal(a[k], other[k]), k
-    assert v1 >= 2 and m1 == 0
+    assert v1 >= 2 and v1 + m1 >= 3

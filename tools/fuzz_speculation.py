@@ -44,7 +44,7 @@ for case in range(N):
     if "ONLY" in os.environ and case != int(os.environ["ONLY"]):
         continue
     # (a) drop-in packages: a walk of poses, small steps with an occasional jump
-    RZ._spec_cache.states.clear()
+    RZ._spec_cache.clear()
     pix_grads = U.random_grads(sc, seed=case)
     tau = np.zeros(6)
     for step in range(2 if BIG else 6):

@@ -73,7 +73,9 @@ def main():
     with open(os.path.join(ROOT, "profiles", f"{a.tag}_kernel_stats.md"), "w") as f:
         f.write(f"# rocprofv3 --kernel-trace --stats summary ({a.tag})\n\ncommand: `{a.cmd}`\n\n")
         f.write(f"{a.iters} refinement iterations under the profiler; total GPU kernel time {tot/1e6:.2f} ms "
-                f"= {tot/1e6/a.iters:.3f} ms/iteration\n\n| kernel | calls | avg us | us / iteration | % |\n|---|---|---|---|---|\n")
+                f"= {tot/1e6/a.iters:.3f} ms/iteration\n\n(rows that are not this library's kernels -- `__amd_rocclr_*`, `at::*` -- are the scene set-up of the "
+                f"command (host-to-device uploads in chunks, torch glue) and lie outside the timed loop; their 'us / iteration' is only total / iterations)\n\n"
+                f"| kernel | calls | avg us | us / iteration | % |\n|---|---|---|---|---|\n")
         for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:40]:
             f.write(f"| {k} | {c} | {t/c/1e3:.2f} | {t/a.iters/1e3:.1f} | {100*t/tot:.1f} |\n")
     traffic = {}

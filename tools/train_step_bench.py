@@ -13,7 +13,7 @@ W, H = int(os.environ.get("TW", 1296)), int(os.environ.get("TH", 840))
 
 def main():
     for P in (200_000, 800_000, 1_500_000):
-        RZ._spec_cache.states.clear()
+        RZ._spec_cache.clear()
         tr = TrainReplay(P0=P, P1=P, W=W, H=H, densify_from=10**9)
         r, _ = time_steps(tr, 1, 50, warm=5)
         print(f"train step {W}x{H} P={P:8d} SH1: {r['ms_per_step']:6.2f} ms/step; render() {r['render_fwd_ms']:.2f} ms of which the rasterizer forward {r['rasterizer_fwd_ms']:.2f} ms, "
@@ -22,7 +22,7 @@ def main():
         del tr
         torch.cuda.empty_cache()
     # the schedule: 700 steps, densification every 10 from step 50 on (65 changes of P)
-    RZ._spec_cache.states.clear()
+    RZ._spec_cache.clear()
     tr = TrainReplay(P0=200_000, P1=1_500_000, W=W, H=H, densify_from=50, densification_interval=10, densify_until=700)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for it in range(1, 701):
