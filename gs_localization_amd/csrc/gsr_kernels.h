@@ -1997,7 +1997,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                 } else r2 = r[2];
             }
 #if GSR_TIMING
-            if (kFull) { asm volatile("" :: "v"(r0.x), "v"(r1.x), "v"(r2.w)); GSR_T_TICK(0) GSR_T_COUNT(8, (have && r2.w == 0.f) ? 1 : 0) }
+            if (kFull) { asm volatile("" :: "v"(r0.x), "v"(r1.x), "v"(r2.w)); GSR_T_TICK(0) }
 #endif
             if (kFull && lz.shs != nullptr) {          // first tile to stage a splat: its colour (LazySH)
                 const bool need = have && r2.w == 0.f;
@@ -2072,7 +2072,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                 T = kill ? __uint_as_float(__float_as_uint(T) | 0x80000000u) : (valid ? test_T : T);      // kill: T -> -|T|
                 last_contributor = blend ? (uint32_t)(consumed + base + j + 1) : last_contributor;      // 1-based position in the tile list
 #if GSR_TIMING
-                if (__ballot(valid && alive0) == 0ull) GSR_T_COUNT(8, 1)      // entry that no live pixel of this wave could use
+                (void)alive0;
 #endif
                 if (TOUCHED) {
                     // pose package: count pixels where the splat was blended with T still > 0.5
@@ -2139,7 +2139,13 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         // Native loop bookkeeping: how deep did this tile have to look?  Next iteration's binning drops what
         // lies behind that (plus a margin); if a pixel is still unsaturated at the end of a list from which
         // entries were dropped, the speculation failed and the host redoes this forward with full lists.
+#if GSR_TIMING
+        const long long t_bar0_ = clock64();
+#endif
         const int unfinished = __syncthreads_or(inside && !done);
+#if GSR_TIMING
+        GSR_T_COUNT(8, clock64() - t_bar0_)      // slot 8: cycles this wave waited for the tile's other waves at the end of its walk
+#endif
         float zm = inside ? zneed : 0.f;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) zm = fmaxf(zm, __shfl_xor(zm, off, 64));

@@ -273,7 +273,7 @@ class FusedRefiner:
                 # (host copies of the final pose: no device read-back for the caller's error statistics)
                 "R_host": s[0:9].reshape(3, 3).copy(), "T_host": s[9:12].copy(),
                 "render": self.color, "depth": self.depth, "opacity": self.alpha}
-        self.last_info = info
+        self.last_info = {k: info[k] for k in ("fallbacks", "num_rendered", "lean_iters", "host_redos")}
         return viewpoint.R, viewpoint.T, info
 
     def lean_check(self):

@@ -473,3 +473,26 @@ def test_lazy_sh_colours_change_nothing(monkeypatch, pose):
         assert U.rel_l1(g1["tau"], g2["tau"]) <= 2e-6
     f, _ = U.oracle_run(sc, cam, None, pose=pose)
     _check_forward(o1, f, pose)
+
+
+def test_lazy_sh_colours_under_contention(monkeypatch):
+    """the lazy colours are published to the other workgroups of the SAME launch with a plain 16-byte store / load
+    (LazySH).  Hammer it: a few hundred faint splats, each covering a large part of a 640x480 image, so that hundreds of tiles
+    stage the same splat at the same moment -- every one of them either finds the colour unevaluated and evaluates the same bits,
+    or finds it complete.  Ten launches, each bit-identical to the eager evaluation (k_sh_color); clamped channels included; the
+    backward's clamp masks (written next to the colours) give the same gradients."""
+    sc = S.small(P=400, W=640, H=480, sh_degree=3, seed=77, scale_med=0.8)
+    sc.opacities[:] = np.clip(sc.opacities * 0.05, 0.004, 0.05)          # faint: every tile walks (and stages) most of the list
+    sc.shs[:, 0, :] -= 0.8
+    cam = U.scene_inputs(sc, np.eye(4))
+    grads = U.random_grads(sc, seed=77)
+    monkeypatch.setenv("GSR_SH_EAGER", "1")
+    o_ref, g_ref = U.hip_run(sc, cam, grads, pose=True)
+    monkeypatch.delenv("GSR_SH_EAGER")
+    assert (o_ref["radii"] > 100).sum() > 100           # the splats really are hundreds of pixels wide
+    for rep in range(10):
+        o, g = U.hip_run(sc, cam, grads, pose=True)
+        for k in ("color", "depth", "alpha", "radii", "n_touched"):
+            assert np.array_equal(o[k], o_ref[k]), (rep, k)
+        for k in ("means3D", "opacities", "sh", "scales", "rotations", "tau"):
+            assert U.rel_l1(g[k], g_ref[k]) <= 2e-5, (rep, k)          # (fp32 atomics reorder the sums of splats that span 1 200 tiles)

@@ -39,7 +39,7 @@ def show(name, base, labels):
     print("  %-28s %10.0f" % ("sum of phases", tot))
 nw = NT * 4 * ITERS
 show("k_render_fwd", 0, ["bins load", "sort + writeback", "batch top (barrier_and)", "staging gathers + barrier", "compaction", "compositing loop",
-                         "after loop", "epilogue after barrier_or", "entries no live pixel needed", "(wave lifetime)", "batches", "loop iterations"])
+                         "after loop", "epilogue (incl. the wait below)", "  of which: waiting for the tile's other waves", "(wave lifetime)", "batches", "loop iterations"])
 nw = NT * 4 * ITERS
 show("k_render_bwd_mfma", 16, ["prologue", "batch top barrier", "staging + barrier", "compaction", "weights (8 splats)", "mfma + lds atomics",
                                "(loop exit)", "barrier after groups", "recombine + global atomics", "(wave lifetime)", "batches", "list entries"])
