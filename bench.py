@@ -67,8 +67,9 @@ def main():
                     help="iterations per refinement call (the reference refines a frame for at most 50: 7scenes_localize_full_dslam.py:66)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
-    ap.add_argument("--frames-in-flight", type=int, default=12,
-                    help="query frames refined concurrently per GPU (measured on one MI355X, round 3: 9 650 it/s with 8, 10 100 with 12 or 16)")
+    ap.add_argument("--frames-in-flight", type=int, default=16,
+                    help="query frames refined concurrently per GPU, one HIP hardware queue each (measured on one MI355X, round 4, K = 20 / 50: "
+                         "8 frames 7 930-9 150 / 9 750-9 940 it/s, 12: 7 700-8 840 / 9 220-10 140, 16: 9 700-9 820 / 10 240-10 310, 20: 9 780-9 890 / 10 410-10 540)")
     ap.add_argument("--repeats", type=int, default=3, help="the timed region is run this many times; `value` is the first, the rest show the spread")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the CPU port on one thread on S-800k-chess (minutes)")
@@ -92,6 +93,12 @@ def main():
                "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    # F frames in flight = F HIP streams.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues
+    # (default 4): with twelve streams on four queues, kernels of three frames queue up behind each other in order.  One queue per
+    # frame in flight (at most 16), set before the first HIP call; an explicit setting in the environment wins.
+    # (measured on one MI355X, K = 20 / 50: 4 queues 8 710-8 810 / 9 930-9 970 it/s, 8 queues 9 290-9 550 / 10 160-10 380, 16 queues
+    # 9 170-9 850 / 10 300-10 480; single frame unchanged)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(16, args.frames_in_flight))))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -283,19 +290,32 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
     results = [None] * F
 
-    def worker(f, iters, stop, shift):
-        try:
-            with torch.cuda.stream(streams[f]):
-                results[(f + shift) % F] = native(f, iters, stop, frame=f + shift)
-        except Exception as ex:      # re-raised in the main thread
-            results[(f + shift) % F] = ex
+    # F persistent host threads (one per frame slot, each with its own stream), released together: starting a thread costs ~0.1 ms,
+    # which inside a timed region of K = 20 iterations (25 ms) would be a few per cent of it
+    job = {"iters": 0, "stop": False, "shift": 0, "quit": False}
+    gate_in, gate_out = threading.Barrier(F + 1), threading.Barrier(F + 1)
+
+    def worker(f):
+        while True:
+            gate_in.wait()
+            if job["quit"]:
+                return
+            shift = job["shift"]
+            try:
+                with torch.cuda.stream(streams[f]):
+                    results[(f + shift) % F] = native(f, job["iters"], job["stop"], frame=f + shift)
+            except Exception as ex:      # re-raised in the main thread
+                results[(f + shift) % F] = ex
+            gate_out.wait()
+    pool = [threading.Thread(target=worker, args=(f,), daemon=True) for f in range(F)]
+    [t.start() for t in pool]
 
     def run_all(iters, stop=False, shift=0):
         # (shift: refiner slot f takes frame f + shift -- every repeat hands each refiner another frame than the one whose depth
         # bounds it still holds, as consecutive frames of a sequence would)
-        ts = [threading.Thread(target=worker, args=(f, iters, stop, shift)) for f in range(F)]
-        [t.start() for t in ts]
-        [t.join() for t in ts]
+        job.update(iters=iters, stop=stop, shift=shift)
+        gate_in.wait()
+        gate_out.wait()
         for e in results:
             if isinstance(e, Exception):
                 raise e
@@ -343,6 +363,9 @@ def main():
     te0, re0 = PL.pose_errors(w2c_gt[:3, :3], w2c_gt[:3, 3], w2c_init[:3, :3], w2c_init[:3, 3])
     res = shard.gather_results(torch.tensor(rows, dtype=torch.float64, device=coll_dev), world * F, rank, world)
 
+    job["quit"] = True
+    gate_in.wait()
+    [t.join() for t in pool]
     train, cam = None, None
     if rank == 0 and world == 1 and not (args.no_train_leg and args.no_cam_leg):
         del frs, vps, model
@@ -410,6 +433,7 @@ def main():
                        "algorithmic_bytes_per_iter": total_bytes, "frames_in_flight_per_gpu": F,
                        "iterations_per_step": F, "gaussian_grads": not args.pose_only,
                        "parallelism": f"frames: {world} GPU x {F} in flight",
+                       "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "loop": "native gsr_refine (render, tracking loss, backward, Adam, update_pose per iteration)",
                        "iterations_per_call": K,
                        "warm_policy": "every refinement call starts from the depth bounds ANOTHER query frame (another start pose) left in its "
@@ -553,7 +577,9 @@ def _roofline(kernels_ms, bytes_per_kernel, profile_json, note):
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", profile_json)))
-        traffic = tj.get(dom, {}).get("hbm_bytes_corrected")
+        # (the profiler names the preprocess kernels apart; the library's timing id "preprocess_fwd" covers all three)
+        alias = {"preprocess_fwd": ("preprocess_bin", "preprocess_lean", "preprocess_fwd")}.get(dom, (dom,))
+        traffic = next((tj[k]["hbm_bytes_corrected"] for k in alias if k in tj), None)
     except Exception:
         pass
     return {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": traffic,

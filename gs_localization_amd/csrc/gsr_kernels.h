@@ -1098,9 +1098,10 @@ __global__ void __launch_bounds__(64) k_sh_color(PreArgs a)
 //                  total, which the host reads to size them: the reference's one blocking read, rasterizer_impl.cu:282);
 //   k_tile_emit    the same walk again: a workgroup reserves its share of each tile's segment with one returning atomic
 //                  per (workgroup, tile) and scatters its (depth bits << 32 | index) keys there, in no particular order;
-//   compositing    k_render_fwd<.., 2> orders a tile's segment lazily, front to back: it SELECTS the nearest few
-//                  hundred keys (radix histogram over the key bits, in LDS), sorts those (bitonic, in LDS), composites
-//                  them, and only goes back for the next slice while some pixel of the tile is still unsaturated.
+//   compositing    k_render_fwd<.., 2> orders a tile's segment lazily, front to back: it SELECTS the nearest couple of
+//                  hundred keys (a depth threshold from a sample, one gather pass: sample_slice), sorts those (in registers
+//                  up to 256, bitonic in LDS above), composites them, and only goes back for the next slice while some pixel
+//                  of the tile is still unsaturated.
 // The order inside a tile is (depth bits, index) -- what the reference's stable sort of (tile | depth) keys gives -- as
 // far as the walk gets; the sorted prefix is written out for the backward pass, which never reads beyond the deepest
 // contributor.
@@ -1559,9 +1560,7 @@ struct SplatLDS {
 #define GSR_LIST_BINS 1
 #define GSR_LIST_EXACT 2
 #define GSR_LIST_BINS_FULL 3       // a bin like GSR_LIST_BINS holding the tile's COMPLETE list (k_preprocess_bin): treated like a segment
-                                   // of the exact bins -- lazy slices above GSR_SLICE_ALL keys, lazy SH colours
-#define GSR_SLICE_FIRST 512        // GSR_LIST_EXACT: the first slice aims at this many keys (most tiles saturate within it),
-#define GSR_SLICE_ALL 1024         // unless the whole segment is no longer than this; later slices take up to GSR_LSORT_CAP
+                                   // of the exact bins -- lazy slices above one register sort's worth of keys (256), lazy SH colours
 #define GSR_SEL_BITS 11            // radix of the selection histogram (2048 counters, aliased onto the key buffer)
 #ifndef GSR_SLICE_WANT0
 #define GSR_SLICE_WANT0 200        // sample_slice: keys the first slice aims at (<= 256 sort in registers), the second, the later ones

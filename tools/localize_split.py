@@ -54,6 +54,8 @@ def main():
             port = sk.getsockname()[1]
         sys.exit(subprocess.call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
                                   "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]))
+    # one hardware queue per frame in flight (the HIP runtime's default is four for all of a process's streams; see bench.py)
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(max(4, min(16, args.in_flight))))
     rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("LOCAL_RANK", 0), ("WORLD_SIZE", 1)))
     if args.gpus and args.gpus != world:
         sys.exit(f"localize_split.py: --gpus {args.gpus} but WORLD_SIZE={world}")
