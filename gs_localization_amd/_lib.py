@@ -104,6 +104,7 @@ class RefineArgs(C.Structure):
         ("flags", C.c_uint), ("lean_min_P", _i),
         ("init_R", _vp), ("init_T", _vp), ("init_exposure_a", _vp), ("init_exposure_b", _vp),
         ("pose_state_host", C.POINTER(_f)),
+        ("colors_precomp", _vp), ("cov3D_precomp", _vp),
     ]
 
 

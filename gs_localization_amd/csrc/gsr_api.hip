@@ -1285,15 +1285,15 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         last_counted = count_touched;
         cx.used_full_bins = &last_full;
         int R = forward_impl(cx, cached_resize, &gb, cached_resize, &bb, cached_resize, &ib, a->P, a->D, a->M, a->background,
-                             a->width, a->height, a->means3D, a->shs, nullptr, a->opacities, a->scales, a->scale_modifier,
-                             a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
+                             a->width, a->height, a->means3D, a->shs, a->colors_precomp, a->opacities, a->scales, a->scale_modifier,
+                             a->rotations, a->cov3D_precomp, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ, ps + GSR_PS_CAMPOS, a->tan_fovx,
                              a->tan_fovy, 0, a->out_color, a->out_depth, a->out_alpha, a->radii, 0, count_touched ? a->n_touched : nullptr, a->stream);
         if (R < 0) return R;
         last_R = R;
         last_local = (mode == 1) || last_full;      // a forward that bins into per-tile bins does not bring its instance count to the host
         // (the tracking loss was evaluated in the compositing kernel's epilogue: cx.floss)
-        int rc2 = backward_impl(cx, a->P, a->D, a->M, R, a->background, a->width, a->height, a->means3D, a->shs, nullptr, a->out_alpha,
-                                a->scales, a->scale_modifier, a->rotations, nullptr, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ,
+        int rc2 = backward_impl(cx, a->P, a->D, a->M, R, a->background, a->width, a->height, a->means3D, a->shs, a->colors_precomp, a->out_alpha,
+                                a->scales, a->scale_modifier, a->rotations, a->cov3D_precomp, ps + GSR_PS_VIEW, ps + GSR_PS_PROJ,
                                 ps + GSR_PS_CAMPOS, a->tan_fovx, a->tan_fovy, a->radii, (char*)gb.ptr, (char*)bb.ptr, (char*)ib.ptr,
                                 a->dL_dimage, a->dL_ddepth, a->dL_dalpha, a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor,
                                 a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, 0, 1, a->dL_dtau, a->stream);

@@ -68,7 +68,10 @@ class FusedRefiner:
     same when max_iters is reached; on early convergence its images (render / depth / opacity, radii, n_touched) are those
     of one more forward at the FINAL pose -- the converged update is below 1e-4, so the two differ by less than that step."""
 
-    def __init__(self, Model, image_height, image_width, device="cuda:0", gaussian_grads=True):
+    def __init__(self, Model, image_height, image_width, device="cuda:0", gaussian_grads=True, colors_precomp=None, cov3D_precomp=None):
+        """colors_precomp [P, 3] / cov3D_precomp [P, 6] (optional): the precomputed-input modes of render() (B)
+        (tools/__init__.py:85-112, pipe.convert_SHs_python / pipe.compute_cov3D_python) -- used instead of the map's SH
+        coefficients / scales and rotations; `g_col` / `g_cov` are then their gradients."""
         import ctypes as C
         from . import _lib
         from .rasterizer import _Workspace, _f32c
@@ -79,12 +82,14 @@ class FusedRefiner:
         self.model = Model
         dev = self.dev
         self.means3D = _f32c(Model.get_xyz.detach())
-        self.shs = _f32c(Model.get_features.detach())
+        self.colors_pre = None if colors_precomp is None else _f32c(colors_precomp.detach().to(dev))
+        self.cov_pre = None if cov3D_precomp is None else _f32c(cov3D_precomp.detach().to(dev))
+        self.shs = _f32c(Model.get_features.detach()) if self.colors_pre is None else None
         self.opac = _f32c(Model.get_opacity.detach())
         sc = Model.get_scaling.detach()
-        self.scales = _f32c(sc.repeat(1, 3) if sc.shape[-1] == 1 else sc)
-        self.rots = _f32c(Model.get_rotation.detach())
-        P, M = self.means3D.shape[0], self.shs.shape[1]
+        self.scales = _f32c(sc.repeat(1, 3) if sc.shape[-1] == 1 else sc) if self.cov_pre is None else None
+        self.rots = _f32c(Model.get_rotation.detach()) if self.cov_pre is None else None
+        P, M = self.means3D.shape[0], (self.shs.shape[1] if self.shs is not None else 0)
         self.P, self.M = P, M
         e = lambda *s, dt=torch.float32: torch.empty(s, dtype=dt, device=dev)
         H, W = self.H, self.W
@@ -93,7 +98,9 @@ class FusedRefiner:
         self.g_img, self.g_depth, self.g_alpha = e(3, H, W), e(1, H, W), e(1, H, W)
         self.g_m2d, self.g_conic, self.g_opac, self.g_col = e(P, 3), e(P, 4), e(P, 1), e(P, 3)
         if gaussian_grads:
-            self.g_m3d, self.g_cov, self.g_sh, self.g_scale, self.g_rot = e(P, 3), e(P, 6), e(P, M, 3), e(P, 3), e(P, 4)
+            self.g_m3d, self.g_cov = e(P, 3), e(P, 6)
+            self.g_sh = e(P, M, 3) if M > 0 else None
+            self.g_scale, self.g_rot = (e(P, 3), e(P, 4)) if self.cov_pre is None else (None, None)
         else:
             self.g_m3d = self.g_cov = self.g_sh = self.g_scale = self.g_rot = None
         self.g_tau, self.loss_out = e(6), e(4)
@@ -112,6 +119,7 @@ class FusedRefiner:
         a = _lib.RefineArgs()
         a.P, a.M = self.P, self.M
         a.means3D, a.shs, a.opacities, a.scales, a.rotations = map(p, (self.means3D, self.shs, self.opac, self.scales, self.rots))
+        a.colors_precomp, a.cov3D_precomp = p(self.colors_pre), p(self.cov_pre)
         a.width, a.height = self.W, self.H
         a.pose_state = p(self.state)
         a.pose_state_host = self._state_host

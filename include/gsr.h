@@ -29,7 +29,8 @@
 extern "C" {
 #endif
 
-/* 3: gsr_forward_packed / gsr_backward_packed (one struct pointer instead of 34 / 40 arguments).
+/* 3: gsr_forward_packed / gsr_backward_packed (one struct pointer instead of 34 / 40 arguments); gsr_refine_args gained
+ *    colors_precomp / cov3D_precomp at its end; gsr_geometry_bytes_det, gsr_spec_state_bounds_bytes.
  * 2: gsr_refine_args gained `carry_state` (round 2) and the fields behind `stream` (flags, lean_min_P); stats_out is int[4];
  *    pose-state words 41 (ticket) and 84..87 (Adam beta products); gsr_debug_lean_check.  A caller must compare
  *    gsr_abi_version() with the GSR_ABI_VERSION it was compiled against before it passes any struct. */
@@ -355,6 +356,12 @@ typedef struct gsr_refine_args {
      * returns -- the call ends with a stream synchronisation anyway, so this costs one small copy and saves the caller a second
      * blocking read of the pose (update_RT of 7scenes_localize_full_dslam.py:84). */
     float* pose_state_host;
+    /* ---- appended with GSR_ABI_VERSION 3 ---- */
+    /* The precomputed-input modes of render() (B) (gs_localization/pipelines/tools/__init__.py:85-112: pipe.convert_SHs_python /
+     * pipe.compute_cov3D_python), nullable.  colors_precomp [P,3]: used instead of `shs` (pass shs = NULL, M = 0, dL_dsh = NULL;
+     * dL_dcolor is then the gradient of these colours).  cov3D_precomp [P,6]: used instead of `scales` / `rotations` (pass both NULL,
+     * dL_dscale = dL_drot = NULL; dL_dcov3D is the gradient of these covariances, and dL/dtau's covariance term uses them). */
+    const float* colors_precomp; const float* cov3D_precomp;
 } gsr_refine_args;
 /* diagnostic switches of gsr_refine (tests / tools; the results must not depend on any of them) */
 #define GSR_REFINE_NO_LEAN     1u   /* k_preprocess + k_sh_color in every iteration instead of k_preprocess_lean */

@@ -552,3 +552,63 @@ def test_host_redo_of_a_warm_started_call_survives_an_overflowing_complete_list_
     assert torch.allclose(fr.depth, pkg["depth"], atol=2e-3)
     assert torch.allclose(fr.alpha, pkg["opacity"], atol=2e-4)
     assert int((fr.radii != pkg["radii"]).sum()) <= max(2, int(5e-5 * fr.radii.numel()))
+
+
+def test_native_loop_with_precomputed_inputs_matches_the_python_loop():
+    """render() (B) can be configured to hand the rasterizer precomputed colours and / or covariances instead of SH coefficients
+    and scale / rotation (tools/__init__.py:85-112: pipe.convert_SHs_python, pipe.compute_cov3D_python).  gsr_refine_args expresses
+    both since ABI 3 (missing item 4): the native loop in each mode against the reference-style Python loop on the pose
+    package in the same mode -- same poses, and the gradients of the precomputed tensors it maintains against a fresh backward."""
+    import math
+    from tests import replay as PL
+    from diff_gaussian_rasterization_pose import GaussianRasterizationSettings, GaussianRasterizer
+    sc = S.small(P=15000, W=128, H=96, sh_degree=2, seed=61, scale_med=0.04)
+    model, bg, view, init = _setup(sc, seed=6)
+    rng = np.random.default_rng(62)
+    q = sc.rotations.astype(np.float64)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    Rm = np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - r * z), 2 * (x * z + r * y), 2 * (x * y + r * z), 1 - 2 * (x * x + z * z),
+                   2 * (y * z - r * x), 2 * (x * z - r * y), 2 * (y * z + r * x), 1 - 2 * (x * x + y * y)], 1).reshape(-1, 3, 3)
+    M = Rm * sc.scales.astype(np.float64)[:, None, :]
+    Sig = M @ M.transpose(0, 2, 1)
+    cov6 = torch.tensor(np.stack([Sig[:, 0, 0], Sig[:, 0, 1], Sig[:, 0, 2], Sig[:, 1, 1], Sig[:, 1, 2], Sig[:, 2, 2]], 1).astype(np.float32), device=DEV)
+    cols = torch.tensor(rng.uniform(0.0, 1.0, (sc.P, 3)).astype(np.float32), device=DEV)
+
+    def render(frame, colors, cov):
+        means2D = torch.zeros_like(model.get_xyz, requires_grad=True)
+        rs = GaussianRasterizationSettings(
+            image_height=sc.H, image_width=sc.W, tanfovx=math.tan(0.5 * frame.FoVx), tanfovy=math.tan(0.5 * frame.FoVy), bg=bg, scale_modifier=1.0,
+            viewmatrix=frame.world_view_transform, projmatrix=frame.full_proj_transform, projmatrix_raw=frame.projection_matrix,
+            sh_degree=model.active_sh_degree, campos=frame.camera_center, prefiltered=False, debug=False)
+        return GaussianRasterizer(rs)(means3D=model.get_xyz, means2D=means2D, opacities=model.get_opacity,
+                                      shs=None if colors is not None else model.get_features, colors_precomp=colors,
+                                      scales=None if cov is not None else model.get_scaling, rotations=None if cov is not None else model.get_rotation,
+                                      cov3D_precomp=cov, theta=frame.cam_rot_delta, rho=frame.cam_trans_delta)
+
+    for colors, cov in ((cols, None), (None, cov6), (cols, cov6)):
+        c_ = None if colors is None else colors.clone().requires_grad_(True)
+        v_ = None if cov is None else cov.clone().requires_grad_(True)
+        vp = view()
+        vp.update_RT(init[:3, :3].clone(), init[:3, 3].clone())
+        opt = PL.pose_adam(vp)
+        for _ in range(6):
+            img, radii, depth, opac, nt = render(vp, c_, v_)
+            opt.zero_grad()
+            if c_ is not None: c_.grad = None
+            if v_ is not None: v_.grad = None
+            PL.tracking_loss(PL.TRACKING_CONFIG, img, depth, opac, vp).backward()
+            last_pose = (vp.R.clone(), vp.T.clone())
+            with torch.no_grad():
+                opt.step()
+                PL.apply_pose_delta(vp)
+        fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV, colors_precomp=colors, cov3D_precomp=cov)
+        R2, T2, info = fr.refine(view(), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=6, stop_on_converged=False)
+        assert info["iters"] == 6
+        assert torch.allclose(vp.R, R2, atol=2e-5) and torch.allclose(vp.T, T2, atol=2e-5), (colors is not None, cov is not None)
+        # the gradient tensors the loop maintains are those of its LAST backward (at the pose before the last update)
+        if c_ is not None:
+            assert U.rel_l1(fr.g_col.cpu().numpy(), c_.grad.cpu().numpy()) <= 2e-4
+            assert fr.g_sh is None
+        if v_ is not None:
+            assert U.rel_l1(fr.g_cov.cpu().numpy(), v_.grad.cpu().numpy()) <= 2e-4
+            assert fr.g_scale is None and fr.g_rot is None
