@@ -34,5 +34,9 @@ case $step in
   timing_spec)   # phase clocks of the speculative loop (diagnostic build)
     GSR_TIMING=1 python gs_localization_amd/build.py > /dev/null 2>&1
     for sc in ${@:-s_1m_640}; do echo "== $sc speculative"; SCENE=$sc python tools/phase_timing.py 2>/dev/null | grep -v amdgpu; done > $o/timing_spec.log ;;
+  fuzz)          # randomised campaigns: per-pixel parity against the oracle, speculation bit for bit under the deterministic option
+    CASES=${1:-300} SEED=${2:-4001} timeout 2400 python tools/fuzz_parity.py 2>&1 | grep -v amdgpu | tail -6 > $o/fuzz_parity.log
+    CASES=${1:-300} SEED=${2:-4002} timeout 2400 python tools/fuzz_speculation.py 2>&1 | grep -v amdgpu | tail -4 > $o/fuzz_spec.log
+    BIG=1 CASES=60 SEED=${2:-4003} timeout 2400 python tools/fuzz_speculation.py 2>&1 | grep -v amdgpu | tail -4 > $o/fuzz_spec_big.log ;;
   *) echo "unknown step $step" ;;
 esac
