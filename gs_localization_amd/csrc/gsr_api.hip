@@ -136,10 +136,8 @@ size_t carve_geom(char* base, int P, Geom& g, bool det = false)
 // back to per-instance atomics in HBM.  At most kTileBinMaxGroups workgroups share the Gaussians (tile_bin_gpb).
 constexpr int kTileBinLdsTiles = 16 * 1024;
 constexpr int kTileBinMaxGroups = 2048;
-#ifndef GSR_FULL_BIN_MAX_TILES
-#define GSR_FULL_BIN_MAX_TILES 2048
-#endif
-constexpr int kFullBinMaxTiles = GSR_FULL_BIN_MAX_TILES;      // k_preprocess_bin (complete lists in one kernel) up to this many tiles
+// (re-measured in round 4 with 4 608: the training step's forward 190 us slower -- bins of 4 096 overflow there --, S-3M-cam at 1024x576 1 380 against 1 674 it/s)
+constexpr int kFullBinMaxTiles = 2048;      // k_preprocess_bin (complete lists in one kernel) up to this many tiles
 
 struct Img {
     uint32_t* n_contrib; uint2* ranges;
@@ -210,7 +208,7 @@ int bin_capacity(int ntiles) { return ntiles <= 4096 ? 4 * GSR_LSORT_CAP : GSR_L
 int full_bin_capacity(int P, int ntiles)
 {
     long long want = 8ll * P / (ntiles > 0 ? ntiles : 1);
-    int cap = (ntiles > 2048) ? 2 * GSR_LSORT_CAP : 4 * GSR_LSORT_CAP;
+    int cap = 4 * GSR_LSORT_CAP;
     while (cap < want && cap < (1 << 20)) cap <<= 1;
     return cap;
 }
