@@ -1830,7 +1830,6 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     const int pix_id = W * py + px;
     const float pxf = (float)px, pyf = (float)py;
     uint2 range;
-    unsigned long long key0 = ~0ull;
     int nslots = 0;      // memory extent of the tile's unordered keys (>= their number: padding keys ~0 in fixed-capacity complete bins)
     constexpr bool kBins = (LIST == GSR_LIST_BINS || LIST == GSR_LIST_BINS_FULL);
     constexpr bool kFull = (LIST == GSR_LIST_EXACT || LIST == GSR_LIST_BINS_FULL);      // complete lists: lazy ordering, lazy SH colours
@@ -1840,9 +1839,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         // (word 0: slots handed out in the bin; word 1, GSR_LIST_BINS_FULL only: the keys among them -- k_preprocess_bin pads every
         // workgroup's run to whole 32-byte sectors with the key ~0)
         __shared__ uint32_t s_cursor[2];
-        // (the bin's first 256 keys are requested NOW, next to the cursor: the bin's memory exists whatever its fill, and the common
-        // case -- a speculative list of at most 256 keys, one per thread -- then sorts without a second trip to memory)
-        key0 = bins[(size_t)tile * (size_t)(bin_cap + GSR_BIN_PAD) + tid];
+        // (requesting the bin's first 256 keys here, next to the cursor, instead of one round trip behind it: measured, no difference)
         if (tid == 0) {
             const uint32_t slots = tile_cursor[tile * GSR_CURSOR_STRIDE];
             s_cursor[0] = slots;
@@ -1891,7 +1888,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         if (tid == 0) ranges[tile] = range;
         if (nslots <= GSR_BLOCK) {          // one key per thread: register sort + merge by counting (the common case of the native loop)
             GSR_T_TICK(0)
-            sort_block_keys((tid < nslots) ? key0 : ~0ull, s_keys);
+            sort_block_keys((tid < nslots) ? bins[range.x + tid] : ~0ull, s_keys);
             overhead += 2;
         } else {
             int npow = 512;
