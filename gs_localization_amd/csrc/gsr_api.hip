@@ -676,7 +676,10 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
             // lists (~5 us on S-1M-640), so as few as keep a band's scattered 8-byte stores inside the L2s until their lines are
             // complete -- measured on the MI355X: 1 band 4 040 it/s, 2 bands 4 180, 3 bands 4 110, 5 bands 3 960 (S-1M-640, plain loop)
             int bands = (int)(((size_t)P * 20 + (12u << 20) - 1) / (12u << 20));
-            bands = std::max(1, std::min(bands, std::min(gy, 4)));
+#ifndef GSR_BIN_BANDS_MAX
+#define GSR_BIN_BANDS_MAX 4
+#endif
+            bands = std::max(1, std::min(bands, std::min(gy, GSR_BIN_BANDS_MAX)));
             const int gpb = GSR_PBIN_KPT * GSR_PBIN_THREADS;
             hipLaunchKernelGGL(k_preprocess_bin, dim3(std::max((P + gpb - 1) / gpb, balanced ? 2 : 1)), dim3(GSR_PBIN_THREADS),
                                (size_t)2 * ntiles * sizeof(uint32_t), st, pa, bands);

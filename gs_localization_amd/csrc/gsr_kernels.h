@@ -1375,6 +1375,11 @@ __global__ void __launch_bounds__(GSR_TBIN_THREADS) k_tile_emit(TileBinArgs a, i
 // on the host.  A tile that overflows its bin makes the compositing kernel report GSR_FAIL_OVERFLOW and the host falls back
 // to the exact count -> scan -> emit path.  k_render_fwd<.., GSR_LIST_BINS_FULL> orders such a bin lazily, like a segment.
 // ---------------------------------------------------------------------------------------------
+#ifndef GSR_CURSOR64
+#define GSR_CURSOR64 0             // 1: the tile cursor as a (slots, keys) pair behind one 64-bit atomic (for producers that pad their runs; the
+                                   // compositing kernel copes with padding keys); 0: one 32-bit word, slots = keys -- measured 3 % faster on
+                                   // S-1M-640's complete lists (4 290 against 4 170 it/s), 1-2 % on S-3M-cam
+#endif
 #define GSR_PBIN_THREADS 512
 #define GSR_PBIN_KPT 4             // 2 048 Gaussians per workgroup: enough for the LDS counters to aggregate, two workgroups per CU
 // Round 4 tried three other shapes of the reserve / emit half of this kernel, all measured on the MI355X and all slower or equal
@@ -1383,7 +1388,7 @@ __global__ void __launch_bounds__(GSR_TBIN_THREADS) k_tile_emit(TileBinArgs a, i
 // tile) run padded to whole sectors with the key ~0 and ONE unbanded walk -- the walk is bound by the issue of its scattered 8-byte
 // stores either way (48 k cycles against 42 k with two bands) and the padding stores cost another 40 k; (c) the reservation atomics
 // issued early and consumed after the walk -- issuing them is what takes the time.  What stayed: four reservation atomics in flight
-// per lane, the cursor as a 64-bit (slots, keys) pair (the compositing kernel copes with padding keys), workgroups staggered over the tiles.
+// per lane, workgroups staggered over the tiles, and a compositing kernel that copes with padding keys (GSR_CURSOR64).
 __global__ void __launch_bounds__(GSR_PBIN_THREADS) k_preprocess_bin(PreArgs a, int bands)
 {
     extern __shared__ uint32_t s_tb[];        // [0, ntiles) running count, [ntiles, 2 ntiles) where this workgroup's keys of the tile start
@@ -1439,8 +1444,13 @@ __global__ void __launch_bounds__(GSR_PBIN_THREADS) k_preprocess_bin(PreArgs a, 
                 c[j] = (tt[j] >= 0) ? s_cnt[tt[j]] : 0u;
             }
 #pragma unroll
-            for (int j = 0; j < 4; j++)
+            for (int j = 0; j < 4; j++) {
+#if GSR_CURSOR64
                 old[j] = (c[j] != 0u) ? atomicAdd(&cur[(size_t)tt[j] * (GSR_CURSOR_STRIDE / 2)], ((unsigned long long)c[j] << 32) | (unsigned long long)c[j]) : 0ull;
+#else
+                old[j] = (c[j] != 0u) ? (unsigned long long)atomicAdd(&a.tile_cursor[(size_t)tt[j] * GSR_CURSOR_STRIDE], c[j]) : 0ull;
+#endif
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++)
                 if (tt[j] >= 0) { s_base[tt[j]] = (uint32_t)old[j]; s_cnt[tt[j]] = 0u; }
@@ -1843,7 +1853,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         if (tid == 0) {
             const uint32_t slots = tile_cursor[tile * GSR_CURSOR_STRIDE];
             s_cursor[0] = slots;
-            s_cursor[1] = (LIST == GSR_LIST_BINS_FULL) ? tile_cursor[tile * GSR_CURSOR_STRIDE + 1] : slots;
+            s_cursor[1] = (LIST == GSR_LIST_BINS_FULL && GSR_CURSOR64) ? tile_cursor[tile * GSR_CURSOR_STRIDE + 1] : slots;
             tile_cursor[tile * GSR_CURSOR_STRIDE] = 0u;
             if (LIST == GSR_LIST_BINS_FULL) tile_cursor[tile * GSR_CURSOR_STRIDE + 1] = 0u;
         }
