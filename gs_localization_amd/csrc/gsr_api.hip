@@ -928,8 +928,11 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     {
         ProfScope ps(K_PREPROCESS_BWD, st);
         pb.surv = g.surv;
-        if (cx.det) hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(surv_grid(P, GSR_K8_RESIDENT)), dim3(64), 0, st, pb);
-        else hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(surv_grid(P, GSR_K8_RESIDENT)), dim3(64), 0, st, pb);
+        // (launching only as many waves as the survivors' lists have chunks -- 256 instead of 2 048 in a speculative iteration --
+        // was measured in round 4: 24.0 against 24.3 us; the waves that find nothing cost nothing)
+        const int k8_grid = surv_grid(P, GSR_K8_RESIDENT);
+        if (cx.det) hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(k8_grid), dim3(64), 0, st, pb);
+        else hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(k8_grid), dim3(64), 0, st, pb);
     }
     LAUNCHCHK("k_preprocess_bwd");
     if (pose_mode && !cx.native_loop) {
