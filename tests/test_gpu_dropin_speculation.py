@@ -164,3 +164,50 @@ def test_spec_state_contract_through_the_c_abi():
     assert torch.equal(c0, c1) and torch.equal(c0, c2)
     rc3, _ = call(C.byref(st), sc.W + 16, sc.H)
     assert rc3 < 0 and b"another image size" in lib.gsr_last_error()
+
+
+def test_per_camera_states_and_their_memory_budget(monkeypatch):
+    """Package (A) with the speculation switched on keeps one state per camera (the storage address of the view matrix tensor), a new
+    camera's state starts from the bounds of the view rendered last, and states beyond GSR_SPEC_CACHE_MB are dropped oldest first.
+    Whatever the cache does, every render equals the plain one."""
+    import torch
+    import diff_gaussian_rasterization as pkg
+    monkeypatch.setenv("GSR_SPECULATION", "1")
+    sc = S.small(P=20000, W=160, H=128, sh_degree=2, seed=41, scale_med=0.04)
+    dev = "cuda:0"
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=dev)
+    means3D, opac, shs, scales, rots, bg = t(sc.means3D), t(sc.opacities), t(sc.shs), t(sc.scales), t(sc.rotations), t(sc.bg)
+    cams = []
+    for k in range(4):                                       # four persistent cameras, a few millimetres apart
+        c = U.scene_inputs(sc, _w2c([0.003 * k, -0.002 * k, 0.001 * k, 0.001 * k, 0.0, 0.0005 * k]))
+        cams.append(dict(view=t(c["view"]), proj=t(c["proj"]), campos=t(c["campos"])))
+
+    def render(c):
+        rs = pkg.GaussianRasterizationSettings(image_height=sc.H, image_width=sc.W, tanfovx=sc.tanfovx, tanfovy=sc.tanfovy, bg=bg, scale_modifier=1.0,
+                                               viewmatrix=c["view"], projmatrix=c["proj"], sh_degree=sc.sh_degree, campos=c["campos"],
+                                               prefiltered=False, debug=False)
+        with torch.no_grad():
+            return pkg.GaussianRasterizer(rs)(means3D=means3D, means2D=torch.zeros_like(means3D), opacities=opac, shs=shs, colors_precomp=None,
+                                              scales=scales, rotations=rots, cov3D_precomp=None)
+    monkeypatch.setenv("GSR_SPECULATION", "0")
+    plain = [render(c) for c in cams]
+    monkeypatch.setenv("GSR_SPECULATION", "1")
+    RZ._spec_cache.clear()
+    for rnd in range(3):
+        for c, ref in zip(cams, plain):
+            out = render(c)
+            for a, b in zip(out, ref):
+                assert torch.equal(a, b)
+    assert len(RZ._spec_cache.states) == 4                   # one state per camera
+    v, m = RZ.speculation_counters()
+    assert v >= 8 + 3 and m == 0                             # every revisit speculated; so did the first visits of cameras 2-4 (seeded)
+    # a budget of two states: the cache never holds more, and the renders stay right
+    one = next(iter(RZ._spec_cache.states.values()))[1].numel()
+    monkeypatch.setenv("GSR_SPEC_CACHE_MB", str(max(1, (2 * one + (1 << 20) - 1) >> 20)))
+    RZ._spec_cache.clear()
+    for rnd in range(2):
+        for c, ref in zip(cams, plain):
+            out = render(c)
+            assert torch.equal(out[0], ref[0]) and torch.equal(out[1], ref[1])
+            assert RZ._spec_cache.bytes <= (int(os.environ["GSR_SPEC_CACHE_MB"]) << 20)
+    assert len(RZ._spec_cache.states) <= 2

@@ -74,6 +74,21 @@ def test_ragged_and_tiny_splits(tmp_path):
         assert res.shape == (n_frames, 5) and torch.equal(res[:, 0], torch.arange(n_frames, dtype=torch.float64))
 
 
+def test_a_group_of_one_rank_still_runs_its_collectives(tmp_path):
+    """`torch.distributed.run --nproc-per-node 1` builds a process group of ONE rank: the frame queue then counts in the rendezvous
+    store and the result gather goes through the backend's all_gather (that is how the RCCL path is executed on a one-GPU box,
+    tests/test_gpu_multirank.py); same rows as without a group."""
+    out = str(tmp_path / "one.pt")
+    mp.spawn(_worker, args=(1, 29790, 9, "queue", 2, out), nprocs=1, join=True)
+    res = torch.load(out)["res"]
+    assert res.shape == (9, 5) and torch.equal(res[:, 0], torch.arange(9, dtype=torch.float64))
+    from gs_localization_amd import shard
+    assert not shard.group_active()
+    local, _ = shard.run_split(9, lambda slot, f: (0.001 * f, 0.1 * f, 1.0), 0, 1, slots=2)
+    plain = shard.gather_results(local, 9, 0, 1)
+    assert torch.allclose(plain[:, :3], res[:, :3])
+
+
 def test_shard_is_a_partition():
     from gs_localization_amd import shard
     for n in (0, 1, 5, 16, 17):
