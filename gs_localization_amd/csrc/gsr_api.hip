@@ -531,6 +531,16 @@ int allow_large_lds(int dev)
                      height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, \
                      projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii, debug, n_touched, stream
 
+// Work-balanced launch order of the compositing kernels outside the native loop (k_tile_order): pays when there are more tiles
+// than resident workgroups (256 CUs x 5), i.e. when the order in which tiles START decides how long the last one runs.
+#ifndef GSR_STATELESS_BALANCE_MIN_TILES
+#define GSR_STATELESS_BALANCE_MIN_TILES 1536      // (0: never)
+#endif
+static inline bool stateless_balanced(const PassCtx& cx, int ntiles)
+{
+    return GSR_STATELESS_BALANCE_MIN_TILES > 0 && !cx.native_loop && ntiles >= GSR_STATELESS_BALANCE_MIN_TILES && ntiles <= GSR_STATELESS_BALANCE_MAX_TILES;
+}
+
 int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
 {
     (void)prefiltered;   // the reference only uses it to trap on a culled point (auxiliary.h:152-156)
@@ -598,6 +608,8 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     pa.rec = g.rec;
     const bool balanced = cx.balance && cx.native_loop && ntiles <= GSR_ORDER_MAX_TILES && !sp.state;
     for (int k = 0; k < 2; k++) { pa.tile_work[k] = balanced ? im.tile_work[k] : nullptr; pa.tile_order[k] = balanced ? im.tile_order[k] : nullptr; }
+    // the stateless entry points: no previous iteration to learn the tiles' weights from -- see k_tile_order
+    const bool stateless_balance = stateless_balanced(cx, ntiles);
     pa.order_tiles = ntiles;
     pa.dirty = cx.native_loop ? g.dirty : nullptr;
     pa.rows = cx.rows;
@@ -767,10 +779,14 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     {
         ProfScope psr(K_RENDER_FWD, st);
         const bool local = by_tile || full_bins;
+        // (stateless: the tiles' work is recorded for the backward's launch order, k_tile_order.  The forward itself keeps the natural
+        // order: list LENGTHS, known after the scan, are a poor predictor of a tile's work -- measured at the train step's 4 293 tiles /
+        // 1.5 M Gaussians: 214 against 216 us, where the order by the TRUE work would give 150 against 180 on a second run of the
+        // same frame -- and nothing better is known before the kernel has run)
 #define GSR_FWD_ARGS im.ranges, local ? bl.vals : b.vals, local ? (const unsigned long long*)bl.bins : (const unsigned long long*)b.keys, \
                      local ? im.tile_cursor : im.tile_offset, width, height, gx, ntiles, (const float*)g.rec, background, out_color, out_depth, out_alpha, im.n_contrib, n_touched, \
                      zb_next, zb_prev, cx.guard.poison ? const_cast<uint32_t*>(cx.guard.poison) : im.fail, \
-                     sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], balanced ? im.tile_work[0] : (uint32_t*)nullptr, bin_cap, \
+                     sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], (balanced || stateless_balance) ? im.tile_work[0] : (uint32_t*)nullptr, bin_cap, \
                      LazySH{pa.lazy_sh ? shs : nullptr, means3D, cam_pos, D, M, g.clamped, g.rec}, (cx.guard.poison ? cx.guard.tag << 2 : 0u), \
                      full_bins ? im.tile_count : (uint32_t*)nullptr, (P < (1 << 28)) ? 1 : 0, \
                      (cx.native_loop && !sp.state && sp.mode != 0) ? im.tile_hold : (uint32_t*)nullptr
@@ -888,10 +904,27 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     if (!cx.native_loop) {      // accumulators of K7 (atomically summed), its flags
         ProfScope psz(K_BWD_ZERO, st);
         ZeroList zl;
-        rc = zl.add(g.acc, (size_t)P * GSR_ACC_STRIDE * (cx.det ? 2 * sizeof(long long) : sizeof(float)), st); if (rc != GSR_OK) return rc;
+        // (a large map: only the survivors' records, through the work lists -- k_backward_prologue)
+#ifndef GSR_ACC_CLEAR_MIN_P
+#define GSR_ACC_CLEAR_MIN_P 100000
+#endif
+        const bool by_list = P >= GSR_ACC_CLEAR_MIN_P;
+        if (!by_list) {
+            rc = zl.add(g.acc, (size_t)P * GSR_ACC_STRIDE * (cx.det ? 2 * sizeof(long long) : sizeof(float)), st); if (rc != GSR_OK) return rc;
+            rc = zl.add(g.aflag, (2 * (size_t)P + 3) & ~(size_t)3, st); if (rc != GSR_OK) return rc;
+        }
         if (pose_mode) { rc = zl.add(g.tau_acc, (cx.det ? 16 : 8) * GSR_TAU_SLOTS * sizeof(double), st); if (rc != GSR_OK) return rc; }
-        rc = zl.add(g.aflag, (2 * (size_t)P + 3) & ~(size_t)3, st); if (rc != GSR_OK) return rc;
         rc = zl.flush(st); if (rc != GSR_OK) return rc;
+        // one launch: the survivors' records cleared through the work lists and, in its first workgroup, K7's launch order (k_backward_prologue)
+        const bool order_wanted = stateless_balanced(cx, ntiles);
+        if (by_list || order_wanted) {
+            const int clear_blocks = by_list ? surv_grid(P, 512) : 0;          // (1 024-entry chunks)
+            if (cx.det) hipLaunchKernelGGL(k_backward_prologue<true>, dim3(clear_blocks + (order_wanted ? 1 : 0)), dim3(GSR_TILE_ORDER_THREADS), 0, st, g.surv, g.acc, g.aflag, P,
+                                           clear_blocks, (const uint32_t*)im.tile_work[0], order_wanted ? im.tile_order[1] : (uint32_t*)nullptr, ntiles);
+            else hipLaunchKernelGGL(k_backward_prologue<false>, dim3(clear_blocks + (order_wanted ? 1 : 0)), dim3(GSR_TILE_ORDER_THREADS), 0, st, g.surv, g.acc, g.aflag, P,
+                                    clear_blocks, (const uint32_t*)im.tile_work[0], order_wanted ? im.tile_order[1] : (uint32_t*)nullptr, ntiles);
+            LAUNCHCHK("k_backward_prologue");
+        }
     }
     {
         ProfScope psb(K_RENDER_BWD, st);
@@ -900,6 +933,7 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         const bool balanced = cx.balance && cx.native_loop && ntiles <= GSR_ORDER_MAX_TILES;
         const uint32_t* order = balanced ? im.tile_order[1] : nullptr;
         uint32_t* work = balanced ? im.tile_work[1] : nullptr;
+        if (stateless_balanced(cx, ntiles)) order = im.tile_order[1];      // heaviest tiles first, by what this call's forward measured (k_backward_prologue)
         if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag);
         else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag);
 #undef GSR_BWD_ARGS
@@ -1600,7 +1634,7 @@ int gsr_training_loss(int width, int height, const float* image, const float* gt
         for (int x = 0; x < 11; x++) sa.w[x] = g[x] / sum;
     }
     const dim3 grid((width + GSR_SSIM_T - 1) / GSR_SSIM_T, (height + GSR_SSIM_T - 1) / GSR_SSIM_T, 3);
-    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(GSR_SSIM_T * GSR_SSIM_T), 0, st, sa);
+    hipLaunchKernelGGL(k_ssim_fwd, grid, dim3(GSR_SSIM_THREADS), 0, st, sa);
     LAUNCHCHK("k_ssim_fwd");
     PearsonArgs pa;
     pa.n = (int)N; pa.depth = depth; pa.pseudo = pseudo_depth; pa.sums = sums; pa.weight = depth_weight; pa.dL_ddepth = dL_ddepth;
@@ -1612,7 +1646,7 @@ int gsr_training_loss(int width, int height, const float* image, const float* gt
     }
     hipLaunchKernelGGL(k_train_loss_finish, dim3(depth ? (eb < 1024 ? eb : 1024) : 1), dim3(GSR_BLOCK), 0, st, pa, (const double*)sums);
     LAUNCHCHK("k_train_loss_finish");
-    hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(GSR_SSIM_T * GSR_SSIM_T), 0, st, sa);
+    hipLaunchKernelGGL(k_ssim_bwd, grid, dim3(GSR_SSIM_THREADS), 0, st, sa);
     LAUNCHCHK("k_ssim_bwd");
     return 0;
 }

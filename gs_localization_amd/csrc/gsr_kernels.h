@@ -375,7 +375,9 @@ __device__ __forceinline__ float3 sh_row16_to_rgb(int deg, float3 pos, const flo
 // permutation is correct) -- three barriers, about a microsecond.  (With more tiles than resident workgroups the order is heaviest-first: the classic list-scheduling rule.)
 // ---------------------------------------------------------------------------------------------
 #define GSR_ORDER_MAX_TILES 65536
-__device__ __forceinline__ void tile_order_from_work(const uint32_t* __restrict__ work, uint32_t* __restrict__ order, int ntiles, uint32_t* s_cls /*[256]*/)
+// (cls_of(t): the weight class of tile t, 0 ... 255, 255 = heaviest)
+template <class ClsOf>
+__device__ __forceinline__ void tile_order_from(ClsOf&& cls_of, uint32_t* __restrict__ order, int ntiles, uint32_t* s_cls /*[256]*/)
 {
     // (the first GSR_BLOCK threads of the workgroup do the work; a wider workgroup's other threads only keep the barriers company)
     __shared__ uint32_t s_wsum[4];
@@ -383,7 +385,7 @@ __device__ __forceinline__ void tile_order_from_work(const uint32_t* __restrict_
     const bool act = tid < GSR_BLOCK;
     if (act) s_cls[tid] = 0u;
     __syncthreads();
-    for (int t = tid; act && t < ntiles; t += GSR_BLOCK) atomicAdd(&s_cls[255u - min(work[t], 255u)], 1u);      // class 0 = heaviest
+    for (int t = tid; act && t < ntiles; t += GSR_BLOCK) atomicAdd(&s_cls[255u - min((uint32_t)cls_of(t), 255u)], 1u);      // slot 0 = heaviest
     __syncthreads();
     const uint32_t mine = act ? s_cls[tid] : 0u;
     uint32_t incl = mine;
@@ -399,11 +401,90 @@ __device__ __forceinline__ void tile_order_from_work(const uint32_t* __restrict_
     if (act) s_cls[tid] = start;                                        // first rank of class tid
     __syncthreads();
     for (int t = tid; act && t < ntiles; t += GSR_BLOCK) {
-        const int r = (int)atomicAdd(&s_cls[255u - min(work[t], 255u)], 1u);          // rank, heaviest first
+        const int r = (int)atomicAdd(&s_cls[255u - min((uint32_t)cls_of(t), 255u)], 1u);          // rank, heaviest first
         // rank r goes to block (r / 256) * 256 + snake(r % 256)
         const int row = r >> 8, i = r & 255;
         const int in_row = min(256, ntiles - (row << 8));
         order[(row << 8) + ((row & 1) ? (in_row - 1 - i) : i)] = (uint32_t)t;
+    }
+}
+__device__ __forceinline__ void tile_order_from_work(const uint32_t* __restrict__ work, uint32_t* __restrict__ order, int ntiles, uint32_t* s_cls /*[256]*/)
+{
+    tile_order_from([&](int t) { return work[t]; }, order, ntiles, s_cls);
+}
+// The stateless entry points (one forward + one backward per call, another camera every time: train.py) have no previous iteration
+// to learn the tiles' weights from.  Their compositing BACKWARD is ordered by what the forward of the same call measured (its
+// walk + ordering cost per tile, tile_work): this kernel, one workgroup in front of k_render_bwd_mfma (train step, 4 293 tiles,
+// 1.5 M Gaussians: 202 against 262 us).  The weights are scaled so that the heaviest tile lands in the top class.
+// One workgroup of 1 024 lanes; every tile's weight is loaded once, all loads in flight together.  Counting sort like tile_order_from, but over
+// 4 096 classes: (weight scaled to 8 bits) x (tile number mod 16) -- tiles of equal weight may come in any order, and the extra bits
+// keep the lanes of a wave off each other's counters (neighbouring tiles weigh about the same: with 256 classes the LDS atomics of a
+// wave hit a handful of addresses and serialise -- 19 us for 4 293 tiles; three strided passes over global memory on 256 lanes: 30 us).
+#define GSR_TILE_ORDER_THREADS 1024
+#define GSR_TILE_ORDER_PER_LANE 16
+#define GSR_STATELESS_BALANCE_MAX_TILES (GSR_TILE_ORDER_THREADS * GSR_TILE_ORDER_PER_LANE)
+__device__ __forceinline__ void tile_order_block(const uint32_t* __restrict__ work, uint32_t* __restrict__ order, int ntiles)
+{
+    __shared__ uint32_t s_cls[4096];
+    __shared__ uint16_t s_c[GSR_STATELESS_BALANCE_MAX_TILES];
+    __shared__ uint32_t s_wsum[GSR_TILE_ORDER_THREADS / 64];
+    __shared__ uint32_t s_max;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) s_max = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; k++) s_cls[tid + k * GSR_TILE_ORDER_THREADS] = 0u;
+    uint32_t v[GSR_TILE_ORDER_PER_LANE];
+    uint32_t m = 0u;
+#pragma unroll
+    for (int k = 0; k < GSR_TILE_ORDER_PER_LANE; k++) {
+        const int t = tid + k * GSR_TILE_ORDER_THREADS;
+        v[k] = (t < ntiles) ? work[t] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < GSR_TILE_ORDER_PER_LANE; k++) m = max(m, v[k]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    __syncthreads();
+    if (lane == 0) atomicMax(&s_max, m);
+    __syncthreads();
+    const int shift = max(0, 24 - (int)__clz(s_max | 1u));          // (work >> shift) <= 255
+#pragma unroll
+    for (int k = 0; k < GSR_TILE_ORDER_PER_LANE; k++) {
+        const int t = tid + k * GSR_TILE_ORDER_THREADS;
+        if (t < ntiles) {
+            const uint32_t c = ((255u - (v[k] >> shift)) << 4) | ((uint32_t)t & 15u);      // class 0 = heaviest
+            s_c[t] = (uint16_t)c;
+            atomicAdd(&s_cls[c], 1u);
+        }
+    }
+    __syncthreads();
+    {   // exclusive prefix sum over the 4 096 classes: four per lane
+        uint32_t c4[4], mine = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { c4[k] = s_cls[4 * tid + k]; mine += c4[k]; }
+        uint32_t incl = mine;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t o = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += o;
+        }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        uint32_t start = incl - mine;
+        for (int w = 0; w < wv; w++) start += s_wsum[w];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { s_cls[4 * tid + k] = start; start += c4[k]; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < GSR_TILE_ORDER_PER_LANE; k++) {
+        const int t = tid + k * GSR_TILE_ORDER_THREADS;
+        if (t < ntiles) {
+            const int r = (int)atomicAdd(&s_cls[s_c[t]], 1u);          // rank, heaviest first; block (r / 256) * 256 + snake(r % 256) as in tile_order_from
+            const int row = r >> 8, i = r & 255;
+            const int in_row = min(256, ntiles - (row << 8));
+            order[(row << 8) + ((row & 1) ? (in_row - 1 - i) : i)] = (uint32_t)t;
+        }
     }
 }
 
@@ -3118,6 +3199,35 @@ __device__ __forceinline__ void acc_clear(float* acc, size_t idx)
 #pragma unroll
     for (int i = 0; i < (DET ? 11 : 3); i++) rec[i] = z;
 }
+// Stateless backward, one launch in front of k_render_bwd_mfma:
+//   * K7's accumulator records and flags must start from zero, and only the survivors of the forward can be on a tile's list -- their
+//     records are cleared by walking the work lists (1.5 M Gaussians of which a third to a half are survivors: 48 B each instead of
+//     a 72 MB memset; acc == nullptr: the host cleared them).  Workgroup w: sub-list w mod GSR_SURV_LISTS, 1 024-entry chunks
+//     w / GSR_SURV_LISTS, ... in steps of clear_blocks / GSR_SURV_LISTS;
+//   * the FIRST workgroup computes K7's launch order from the work the forward measured (tile_order_block; order == nullptr: none).
+//     On its own that is a 19 us kernel for 4 293 tiles (one workgroup, a chain of dependent phases); here it hides behind the clearing.
+template <bool DET>
+__global__ void __launch_bounds__(GSR_TILE_ORDER_THREADS) k_backward_prologue(SurvLists surv, float* acc, uint8_t* aflag, int P, int clear_blocks,
+                                                                              const uint32_t* __restrict__ work, uint32_t* __restrict__ order, int ntiles)
+{
+    const int first = (order != nullptr) ? 1 : 0;
+    if ((int)blockIdx.x < first) {          // (block-uniform)
+        tile_order_block(work, order, ntiles);
+        return;
+    }
+    const uint32_t b = blockIdx.x - (uint32_t)first;
+    if ((int)b >= clear_blocks) return;
+    const uint32_t sl = b & (GSR_SURV_LISTS - 1);
+    const uint32_t n = surv.n[sl * GSR_SURV_CSTRIDE];
+    const uint32_t* __restrict__ list = surv.ids + (size_t)sl * surv.cap;
+    const uint32_t step = ((uint32_t)clear_blocks / GSR_SURV_LISTS) * GSR_TILE_ORDER_THREADS;
+    for (uint32_t c = (b / GSR_SURV_LISTS) * GSR_TILE_ORDER_THREADS + threadIdx.x; c < n; c += step) {
+        const size_t idx = list[c];
+        acc_clear<DET>(acc, idx);
+        aflag[idx] = (uint8_t)0;
+        aflag[(size_t)P + idx] = (uint8_t)0;
+    }
+}
 template <bool DET>
 __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
 {
@@ -3568,14 +3678,16 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_knn_search(int P, const float4* _
 // SSIM: 11x11 Gaussian window (sigma 1.5), zero padding, per channel.  Every statistic of _ssim is a window
 // filter of x, y, xx, yy, xy, so the map is a function F(mu1, mu2, Exx, Eyy, Exy) per pixel and
 //   dSSIM/dx(q) = sum_p w(p - q) [ F_mu1(p) + 2 x(q) F_Exx(p) + y(q) F_Exy(p) ] / (3N):
-// pass 1 (k_ssim_fwd) filters the five inputs (separable, 26x26 halo tile in LDS), evaluates the map, sums it
+// pass 1 (k_ssim_fwd) filters the five inputs (separable, 42x42 halo tile in LDS), evaluates the map, sums it
 // and the L1 term, and stores the three partial-derivative maps; pass 2 (k_ssim_bwd) filters those maps with
 // the same (symmetric) window and assembles dL/dimage including the L1 sign term.  HBM traffic per pixel and
 // channel: 8 B in + 12 B out, then 12 B + 8 B in + 4 B out.
 // ---------------------------------------------------------------------------------------------
 #define GSR_SSIM_R 5
-#define GSR_SSIM_T 16
-#define GSR_SSIM_H (GSR_SSIM_T + 2 * GSR_SSIM_R)      // 26
+#define GSR_SSIM_T 32                                  // output tile: 32 x 32 pixels per workgroup of 256 lanes, four pixels per lane
+#define GSR_SSIM_H (GSR_SSIM_T + 2 * GSR_SSIM_R)      // 42
+#define GSR_SSIM_S (GSR_SSIM_H + 2)                    // row stride of the staged halo tile (16-byte aligned rows)
+#define GSR_SSIM_THREADS 256
 struct SsimArgs {
     int W, H;
     const float* img; const float* gt;       // [3, H, W]
@@ -3585,19 +3697,37 @@ struct SsimArgs {
     float* dL_dimage;
     float w[2 * GSR_SSIM_R + 1];             // gaussian(11, 1.5), normalised (loss_utils.py:23-25)
 };
+// Round 4: 16 x 16 tiles with one pixel per lane took 169 us at 1296 x 840 (595 vector instructions per wave, 2.6x halo reads, every
+// tap an LDS read).  Now 32 x 32 tiles: the horizontal pass hands a lane FOUR neighbouring outputs of a halo row -- 14 inputs read
+// once (vector LDS reads), their squares and product formed once -- and the vertical pass four neighbouring rows of a column (14
+// LDS reads per quantity for 44 FMAs).  Sums are taken in the same tap order as before (k = 0 ... 10), so every map value keeps its bits.
+#define GSR_SSIM_HPASS(NQ, LOAD14, STORE)                                                                                    \
+    for (int it = tid; it < GSR_SSIM_H * (GSR_SSIM_T / 4); it += GSR_SSIM_THREADS) {                                         \
+        const int r = it / (GSR_SSIM_T / 4), c0 = 4 * (it - r * (GSR_SSIM_T / 4));                                           \
+        float in[NQ][14];                                                                                                    \
+        LOAD14                                                                                                               \
+        float acc[NQ][4];                                                                                                    \
+        _Pragma("unroll") for (int q = 0; q < NQ; q++)                                                                       \
+            _Pragma("unroll") for (int o = 0; o < 4; o++) {                                                                  \
+                float t = 0.f;                                                                                               \
+                _Pragma("unroll") for (int k = 0; k < 2 * GSR_SSIM_R + 1; k++) t += a.w[k] * in[q][o + k];                   \
+                acc[q][o] = t;                                                                                               \
+            }                                                                                                                \
+        STORE                                                                                                                \
+    }
 
-__global__ void __launch_bounds__(GSR_SSIM_T * GSR_SSIM_T) k_ssim_fwd(SsimArgs a)
+__global__ void __launch_bounds__(GSR_SSIM_THREADS) k_ssim_fwd(SsimArgs a)
 {
-    __shared__ float s_x[GSR_SSIM_H][GSR_SSIM_H + 1], s_y[GSR_SSIM_H][GSR_SSIM_H + 1];
-    __shared__ float s_h[5][GSR_SSIM_H][GSR_SSIM_T + 1];       // horizontally filtered x, y, xx, yy, xy
+    __shared__ __attribute__((aligned(16))) float s_x[GSR_SSIM_H][GSR_SSIM_S], s_y[GSR_SSIM_H][GSR_SSIM_S];
+    __shared__ __attribute__((aligned(16))) float s_h[5][GSR_SSIM_H][GSR_SSIM_T];       // horizontally filtered x, y, xx, yy, xy
     __shared__ double s_red[4][2];
-    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    const int tid = threadIdx.x;
     const int ch = blockIdx.z;
     const int x0 = blockIdx.x * GSR_SSIM_T, y0 = blockIdx.y * GSR_SSIM_T;
     const size_t N = (size_t)a.W * a.H;
     const float* img = a.img + ch * N;
     const float* gt = a.gt + ch * N;
-    for (int i = tid; i < GSR_SSIM_H * GSR_SSIM_H; i += GSR_SSIM_T * GSR_SSIM_T) {
+    for (int i = tid; i < GSR_SSIM_H * GSR_SSIM_H; i += GSR_SSIM_THREADS) {
         const int r = i / GSR_SSIM_H, c = i - r * GSR_SSIM_H;
         const int gx = x0 + c - GSR_SSIM_R, gy = y0 + r - GSR_SSIM_R;
         const bool in = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;          // zero padding (F.conv2d padding = 5)
@@ -3605,44 +3735,66 @@ __global__ void __launch_bounds__(GSR_SSIM_T * GSR_SSIM_T) k_ssim_fwd(SsimArgs a
         s_y[r][c] = in ? gt[(size_t)gy * a.W + gx] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < GSR_SSIM_H * GSR_SSIM_T; i += GSR_SSIM_T * GSR_SSIM_T) {
-        const int r = i / GSR_SSIM_T, c = i - r * GSR_SSIM_T;
-        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2 * GSR_SSIM_R + 1; k++) {
-            const float wx = a.w[k], xv = s_x[r][c + k], yv = s_y[r][c + k];
-            sx += wx * xv; sy += wx * yv; sxx += wx * (xv * xv); syy += wx * (yv * yv); sxy += wx * (xv * yv);
+    // (in[0] = x, in[1] = y, in[2] = xx, in[3] = yy, in[4] = xy over the lane's 14 halo columns)
+#define GSR_SSIM_LOAD_FWD                                                                                                    \
+        _Pragma("unroll") for (int v = 0; v < 3; v++) {                                                                      \
+            const float4 xv = *reinterpret_cast<const float4*>(&s_x[r][c0 + 4 * v]);                                        \
+            const float4 yv = *reinterpret_cast<const float4*>(&s_y[r][c0 + 4 * v]);                                        \
+            in[0][4 * v] = xv.x; in[0][4 * v + 1] = xv.y; in[0][4 * v + 2] = xv.z; in[0][4 * v + 3] = xv.w;                  \
+            in[1][4 * v] = yv.x; in[1][4 * v + 1] = yv.y; in[1][4 * v + 2] = yv.z; in[1][4 * v + 3] = yv.w;                  \
+        }                                                                                                                    \
+        { const float2 xv = *reinterpret_cast<const float2*>(&s_x[r][c0 + 12]); in[0][12] = xv.x; in[0][13] = xv.y;          \
+          const float2 yv = *reinterpret_cast<const float2*>(&s_y[r][c0 + 12]); in[1][12] = yv.x; in[1][13] = yv.y; }        \
+        _Pragma("unroll") for (int j = 0; j < 14; j++) {                                                                     \
+            in[2][j] = in[0][j] * in[0][j]; in[3][j] = in[1][j] * in[1][j]; in[4][j] = in[0][j] * in[1][j];                  \
         }
-        s_h[0][r][c] = sx; s_h[1][r][c] = sy; s_h[2][r][c] = sxx; s_h[3][r][c] = syy; s_h[4][r][c] = sxy;
-    }
+#define GSR_SSIM_STORE5                                                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 5; q++)                                                                        \
+            *reinterpret_cast<float4*>(&s_h[q][r][c0]) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+    GSR_SSIM_HPASS(5, GSR_SSIM_LOAD_FWD, GSR_SSIM_STORE5)
+#undef GSR_SSIM_LOAD_FWD
+#undef GSR_SSIM_STORE5
     __syncthreads();
-    const int px = x0 + lx, py = y0 + ly;
-    const bool inside = px < a.W && py < a.H;
-    double l1 = 0.0, ss = 0.0;
-    if (inside) {
-        float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+    // vertical pass: lane = column lx, rows 4 ly ... 4 ly + 3
+    const int lx = tid & (GSR_SSIM_T - 1), ly = tid >> 5;
+    float f[5][4];
 #pragma unroll
-        for (int k = 0; k < 2 * GSR_SSIM_R + 1; k++) {
-            const float wy = a.w[k];
-            mu1 += wy * s_h[0][ly + k][lx]; mu2 += wy * s_h[1][ly + k][lx];
-            exx += wy * s_h[2][ly + k][lx]; eyy += wy * s_h[3][ly + k][lx]; exy += wy * s_h[4][ly + k][lx];
+    for (int q = 0; q < 5; q++) {
+        float col[14];
+#pragma unroll
+        for (int j = 0; j < 14; j++) col[j] = s_h[q][4 * ly + j][lx];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2 * GSR_SSIM_R + 1; k++) t += a.w[k] * col[o + k];
+            f[q][o] = t;
         }
-        const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
-        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-        const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
-        const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cd = mu1_sq + mu2_sq + C1, D = s1 + s2 + C2;
-        const float inv = 1.f / (Cd * D);
-        const float ssim = A * B * inv;
-        // F(mu1, mu2, Exx, Eyy, Exy) with s1 = Exx - mu1^2, s12 = Exy - mu1 mu2:
-        //   dF/dExx = -A B / (Cd D^2),  dF/dExy = 2 A / (Cd D),
-        //   dF/dmu1 = 2 mu2 B/(Cd D) - 2 mu2 A/(Cd D) ... collected below (chain through s1 and s12 included)
-        const float F_exx = -ssim / D;
-        const float F_exy = 2.f * A * inv;
-        const float F_mu1 = 2.f * mu2 * B * inv - 2.f * mu1 * ssim / Cd - 2.f * mu1 * F_exx - mu2 * F_exy;
-        const size_t o = ch * N + (size_t)py * a.W + px;
-        a.maps[o] = F_mu1; a.maps[3 * N + o] = F_exx; a.maps[6 * N + o] = F_exy;
-        ss = (double)ssim;
-        l1 = (double)fabsf(s_x[ly + GSR_SSIM_R][lx + GSR_SSIM_R] - s_y[ly + GSR_SSIM_R][lx + GSR_SSIM_R]);
+    }
+    const int px = x0 + lx;
+    double l1 = 0.0, ss = 0.0;
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int py = y0 + 4 * ly + o;
+        if (px < a.W && py < a.H) {
+            const float mu1 = f[0][o], mu2 = f[1][o], exx = f[2][o], eyy = f[3][o], exy = f[4][o];
+            const float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+            const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+            const float s1 = exx - mu1_sq, s2 = eyy - mu2_sq, s12 = exy - mu12;
+            const float A = 2.f * mu12 + C1, B = 2.f * s12 + C2, Cd = mu1_sq + mu2_sq + C1, D = s1 + s2 + C2;
+            const float inv = 1.f / (Cd * D);
+            const float ssim = A * B * inv;
+            // F(mu1, mu2, Exx, Eyy, Exy) with s1 = Exx - mu1^2, s12 = Exy - mu1 mu2:
+            //   dF/dExx = -A B / (Cd D^2),  dF/dExy = 2 A / (Cd D),
+            //   dF/dmu1 = 2 mu2 B/(Cd D) - 2 mu2 A/(Cd D) ... collected below (chain through s1 and s12 included)
+            const float F_exx = -ssim / D;
+            const float F_exy = 2.f * A * inv;
+            const float F_mu1 = 2.f * mu2 * B * inv - 2.f * mu1 * ssim / Cd - 2.f * mu1 * F_exx - mu2 * F_exy;
+            const size_t o_ = ch * N + (size_t)py * a.W + px;
+            a.maps[o_] = F_mu1; a.maps[3 * N + o_] = F_exx; a.maps[6 * N + o_] = F_exy;
+            ss += (double)ssim;
+            l1 += (double)fabsf(s_x[4 * ly + o + GSR_SSIM_R][lx + GSR_SSIM_R] - s_y[4 * ly + o + GSR_SSIM_R][lx + GSR_SSIM_R]);
+        }
     }
     l1 = wave_sum_d(l1); ss = wave_sum_d(ss);
     if ((tid & 63) == 0) { s_red[tid >> 6][0] = l1; s_red[tid >> 6][1] = ss; }
@@ -3653,15 +3805,15 @@ __global__ void __launch_bounds__(GSR_SSIM_T * GSR_SSIM_T) k_ssim_fwd(SsimArgs a
     }
 }
 
-__global__ void __launch_bounds__(GSR_SSIM_T * GSR_SSIM_T) k_ssim_bwd(SsimArgs a)
+__global__ void __launch_bounds__(GSR_SSIM_THREADS) k_ssim_bwd(SsimArgs a)
 {
-    __shared__ float s_m[3][GSR_SSIM_H][GSR_SSIM_H + 1];
-    __shared__ float s_h[3][GSR_SSIM_H][GSR_SSIM_T + 1];
-    const int tid = threadIdx.x, lx = tid & 15, ly = tid >> 4;
+    __shared__ __attribute__((aligned(16))) float s_m[3][GSR_SSIM_H][GSR_SSIM_S];
+    __shared__ __attribute__((aligned(16))) float s_h[3][GSR_SSIM_H][GSR_SSIM_T];
+    const int tid = threadIdx.x;
     const int ch = blockIdx.z;
     const int x0 = blockIdx.x * GSR_SSIM_T, y0 = blockIdx.y * GSR_SSIM_T;
     const size_t N = (size_t)a.W * a.H;
-    for (int i = tid; i < GSR_SSIM_H * GSR_SSIM_H; i += GSR_SSIM_T * GSR_SSIM_T) {
+    for (int i = tid; i < GSR_SSIM_H * GSR_SSIM_H; i += GSR_SSIM_THREADS) {
         const int r = i / GSR_SSIM_H, c = i - r * GSR_SSIM_H;
         const int gx = x0 + c - GSR_SSIM_R, gy = y0 + r - GSR_SSIM_R;
         const bool in = gx >= 0 && gx < a.W && gy >= 0 && gy < a.H;          // no output pixel outside the image
@@ -3670,33 +3822,51 @@ __global__ void __launch_bounds__(GSR_SSIM_T * GSR_SSIM_T) k_ssim_bwd(SsimArgs a
         for (int m = 0; m < 3; m++) s_m[m][r][c] = in ? a.maps[3 * m * N + o] : 0.f;
     }
     __syncthreads();
-    for (int i = tid; i < GSR_SSIM_H * GSR_SSIM_T; i += GSR_SSIM_T * GSR_SSIM_T) {
-        const int r = i / GSR_SSIM_T, c = i - r * GSR_SSIM_T;
-        float t0 = 0.f, t1 = 0.f, t2 = 0.f;
-#pragma unroll
-        for (int k = 0; k < 2 * GSR_SSIM_R + 1; k++) {
-            const float wx = a.w[k];
-            t0 += wx * s_m[0][r][c + k]; t1 += wx * s_m[1][r][c + k]; t2 += wx * s_m[2][r][c + k];
+#define GSR_SSIM_LOAD_BWD                                                                                                    \
+        _Pragma("unroll") for (int q = 0; q < 3; q++) {                                                                      \
+            _Pragma("unroll") for (int v = 0; v < 3; v++) {                                                                  \
+                const float4 mv = *reinterpret_cast<const float4*>(&s_m[q][r][c0 + 4 * v]);                                 \
+                in[q][4 * v] = mv.x; in[q][4 * v + 1] = mv.y; in[q][4 * v + 2] = mv.z; in[q][4 * v + 3] = mv.w;              \
+            }                                                                                                                \
+            const float2 mv = *reinterpret_cast<const float2*>(&s_m[q][r][c0 + 12]); in[q][12] = mv.x; in[q][13] = mv.y;     \
         }
-        s_h[0][r][c] = t0; s_h[1][r][c] = t1; s_h[2][r][c] = t2;
-    }
+#define GSR_SSIM_STORE3                                                                                                      \
+        _Pragma("unroll") for (int q = 0; q < 3; q++)                                                                        \
+            *reinterpret_cast<float4*>(&s_h[q][r][c0]) = make_float4(acc[q][0], acc[q][1], acc[q][2], acc[q][3]);
+    GSR_SSIM_HPASS(3, GSR_SSIM_LOAD_BWD, GSR_SSIM_STORE3)
+#undef GSR_SSIM_LOAD_BWD
+#undef GSR_SSIM_STORE3
     __syncthreads();
-    const int px = x0 + lx, py = y0 + ly;
-    if (px >= a.W || py >= a.H) return;
-    float g0 = 0.f, g1 = 0.f, g2 = 0.f;
+    const int lx = tid & (GSR_SSIM_T - 1), ly = tid >> 5;
+    float g[3][4];
 #pragma unroll
-    for (int k = 0; k < 2 * GSR_SSIM_R + 1; k++) {
-        const float wy = a.w[k];
-        g0 += wy * s_h[0][ly + k][lx]; g1 += wy * s_h[1][ly + k][lx]; g2 += wy * s_h[2][ly + k][lx];
+    for (int q = 0; q < 3; q++) {
+        float col[14];
+#pragma unroll
+        for (int j = 0; j < 14; j++) col[j] = s_h[q][4 * ly + j][lx];
+#pragma unroll
+        for (int o = 0; o < 4; o++) {
+            float t = 0.f;
+#pragma unroll
+            for (int k = 0; k < 2 * GSR_SSIM_R + 1; k++) t += a.w[k] * col[o + k];
+            g[q][o] = t;
+        }
     }
-    const size_t o = ch * N + (size_t)py * a.W + px;
-    const float x = a.img[o], y = a.gt[o];
+    const int px = x0 + lx;
     const float inv3n = 1.f / (3.f * (float)N);
-    const float d = x - y;
-    const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
-    // loss = (1 - lambda) mean|x - y| + lambda (1 - mean ssim_map)
-    a.dL_dimage[o] = (1.f - a.lambda_dssim) * sgn * inv3n - a.lambda_dssim * inv3n * (g0 + 2.f * x * g1 + y * g2);
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+        const int py = y0 + 4 * ly + o;
+        if (px >= a.W || py >= a.H) continue;
+        const size_t oo = ch * N + (size_t)py * a.W + px;
+        const float x = a.img[oo], y = a.gt[oo];
+        const float d = x - y;
+        const float sgn = (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f);
+        // loss = (1 - lambda) mean|x - y| + lambda (1 - mean ssim_map)
+        a.dL_dimage[oo] = (1.f - a.lambda_dssim) * sgn * inv3n - a.lambda_dssim * inv3n * (g[0][o] + 2.f * x * g[1][o] + y * g[2][o]);
+    }
 }
+#undef GSR_SSIM_HPASS
 
 // Pseudo-depth term of train.py:96-108: w_d * min(1 - rho(-m, d), 1 - rho(1 / (m + 200), d)), rho = Pearson
 // correlation over all pixels (torchmetrics pearson_corrcoef: cov / sqrt(var_x var_y), clamped to [-1, 1]).
