@@ -289,6 +289,7 @@ def main():
     # Only the dominant kernel is bracketed by HIP events (on the stream it is launched on).
     streams = [torch.cuda.Stream(device=dev) for _ in range(F)]
     results = [None] * F
+    spans = [None] * F          # (diagnostics: when each worker's call started and ended)
 
     # F persistent host threads (one per frame slot, each with its own stream), released together: starting a thread costs ~0.1 ms,
     # which inside a timed region of K = 20 iterations (25 ms) would be a few per cent of it
@@ -303,7 +304,19 @@ def main():
             shift = job["shift"]
             try:
                 with torch.cuda.stream(streams[f]):
-                    results[(f + shift) % F] = native(f, job["iters"], job["stop"], frame=f + shift)
+                    t_in = time.perf_counter()
+                    if job.get("queue") is not None:
+                        # a stream of frames: every worker takes the next frame when it is done with its own (what
+                        # tools/localize_split.py does with shard.FrameQueue) -- no worker waits for the slowest one's single frame
+                        while True:
+                            with job["lock"]:
+                                nxt = next(job["queue"], None)
+                            if nxt is None:
+                                break
+                            results[f] = native(f, job["iters"], job["stop"], frame=nxt)
+                    else:
+                        results[(f + shift) % F] = native(f, job["iters"], job["stop"], frame=f + shift)
+                    spans[f] = (t_in, time.perf_counter())
             except Exception as ex:      # re-raised in the main thread
                 results[(f + shift) % F] = ex
             gate_out.wait()
@@ -325,7 +338,7 @@ def main():
     # of the other frames in flight (measured: -5 % on `value`)
     lib.gsr_profile_sampling(16)
     lib.gsr_profile_enable(1 << names.index(dominant))
-    elapsed_runs = []
+    elapsed_runs, run_stats = [], []
     dom_ms, dom_n = 0.0, 0
     for rep in range(max(1, args.repeats)):
         barrier(); torch.cuda.synchronize()
@@ -333,6 +346,10 @@ def main():
         run_all(K, shift=rep + 1)
         torch.cuda.synchronize(); barrier()
         elapsed_runs.append(time.perf_counter() - t0)
+        run_stats.append({k: int(sum(r[2][k] for r in results)) for k in ("fallbacks", "host_redos", "lean_iters")})
+        if os.environ.get("GSR_BENCH_SPANS"):      # (diagnostics: the frames in flight do not get equal shares of the GPU -- see HISTORY.md, round 4)
+            print("rep", rep, "total %.2f ms; call starts (ms after t0) %s; ends %s" % (1e3 * elapsed_runs[-1],
+                  " ".join("%.2f" % (1e3 * (a - t0)) for a, _ in spans), " ".join("%.2f" % (1e3 * (b - t0)) for _, b in spans)), file=sys.stderr)
         if rep == 0:
             dom_ms, dom_n = collect()[dominant]
             lib.gsr_profile_enable(0)
@@ -351,6 +368,17 @@ def main():
         ranks_seen = int(round(float(ones.item())))
     if ranks_seen != args.gpus:
         sys.exit(f"bench.py: {ranks_seen} ranks took part, --gpus {args.gpus} expected")
+
+    # ---- the same K iterations per frame on a STREAM of frames (4 F of them through the F workers, next frame to whoever is free):
+    # reported next to `value`, whose timed region is one frame per worker and therefore ends with its slowest worker alone on the GPU
+    # (the frames in flight do not get equal shares of it: a third between the first and the last to finish, GSR_BENCH_SPANS=1)
+    job.update(queue=iter(range(1, 4 * F + 1)), lock=threading.Lock())
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_all(K)
+    torch.cuda.synchronize(); barrier()
+    elapsed_stream = time.perf_counter() - t0
+    job.update(queue=None)
 
     # ---- pose error of full 50-iteration refinements with the reference's early exit (untimed), all frames gathered
     run_all(50, stop=True)
@@ -440,6 +468,8 @@ def main():
                                       "refiner's workspace, verified on the device; single_frame_cold_start_iters_per_s has no bounds to start from",
                        "timing": "value = first of `repeats` timed regions; single-frame / plain / cold legs = best of three calls"},
             "value_repeats": [iters_total / e for e in elapsed_runs],
+            "value_repeats_stats": run_stats,
+            "stream_of_frames_iters_per_s": 4 * F * K / elapsed_stream,
             "single_frame_iters_per_s": single,
             "single_frame_cold_start_iters_per_s": world * K / elapsed_cold,
             # one refinement call of K iterations on one frame: its time, the marginal cost of an iteration inside a long call,

@@ -11,6 +11,7 @@
 #include <mutex>
 #include <atomic>
 #include <thread>
+#include <chrono>
 #include <algorithm>
 
 #include "gsr.h"
@@ -1170,13 +1171,31 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     // status is at most one group away); after that the thread yields between polls -- with several frames in flight per GPU
     // and eight GPUs per node, dozens of these loops share the host's cores -- and the stream is queried now and then so that
     // a failed launch cannot turn this into an endless wait.
+    // How long the last group took from status to status.  One frame alone: ~0.15 ms, and the host must have the group after next
+    // enqueued within that time -- it spins.  Many frames sharing the GPU (a thread per frame): milliseconds per group, and sixteen
+    // spinning threads are sixteen busy cores for nothing (a container with a CPU quota then throttles the whole process, which showed
+    // as frames falling behind their neighbours by a third): the thread sleeps between polls, an eighth of a group at a time.
+    double group_us = 0.0;
+    auto t_last = std::chrono::steady_clock::now();
     auto wait_status = [&](int g, uint32_t& word) -> int {
         volatile uint32_t* w = slot_of(g);
+#ifndef GSR_POLL_NAP
+#define GSR_POLL_NAP 1
+#endif
+        const long nap_us = (GSR_POLL_NAP && group_us > 600.0) ? (long)std::min(250.0, group_us / 8.0) : 0;
         for (unsigned spins = 0;; spins++) {
             const uint32_t v = *w;
-            if ((v >> 4) == (uint32_t)(g + 1)) { word = v; return 0; }
-            if (spins > 4096u) std::this_thread::yield();
-            if ((spins & 0x3FFFu) == 0x3FFFu) {
+            if ((v >> 4) == (uint32_t)(g + 1)) {
+                word = v;
+                const auto now = std::chrono::steady_clock::now();
+                const double dt = std::chrono::duration<double, std::micro>(now - t_last).count();
+                t_last = now;
+                group_us = (group_us == 0.0) ? dt : 0.75 * group_us + 0.25 * dt;
+                return 0;
+            }
+            if (nap_us > 0 && spins >= 64u) std::this_thread::sleep_for(std::chrono::microseconds(nap_us));
+            else if (spins > 4096u) std::this_thread::yield();
+            if ((nap_us > 0 && (spins & 0x3Fu) == 0x3Fu) || (spins & 0x3FFFu) == 0x3FFFu) {
                 const hipError_t q = hipStreamQuery(st);
                 if (q == hipSuccess) {          // everything enqueued has run: one last look, then give up
                     const uint32_t v2 = *w;
@@ -1205,7 +1224,14 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     cx.n_lean = &n_lean;
     // warm start: the previous call on this workspace left its last bounds in buffer warm_buf (0 / 1); iteration 0 must
     // READ that buffer, i.e. write the other one
-    const int warm_buf = (a->speculative && a->warm_state && (*a->warm_state == 1 || *a->warm_state == 2)) ? *a->warm_state - 1 : -1;
+    // (bits 8+ of the word: the adaptive margin the previous call ended with, in 1e-4 -- a 20-iteration call would otherwise spend all
+    // its iterations tightening it again: 6 800 it/s at m = 0.02 against 7 030 at 0.01 on S-1M-640)
+    const int warm_word = (a->speculative && a->warm_state) ? *a->warm_state : 0;
+    const int warm_buf = ((warm_word & 0xFF) == 1 || (warm_word & 0xFF) == 2) ? (warm_word & 0xFF) - 1 : -1;
+#ifndef GSR_CARRY_MARGIN
+#define GSR_CARRY_MARGIN 1
+#endif
+    const float warm_margin = GSR_CARRY_MARGIN ? (float)((warm_word >> 8) & 0xFFFF) * 1e-4f : 0.f;
     const int poff = (warm_buf >= 0) ? (warm_buf ^ 1) : 0;
     int n_fallbacks = 0, last_R = 0, fail_streak = 0, spec_resume = 0;
     bool last_local = false;
@@ -1280,7 +1306,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     // with m between 0.01 and 0.05 -- tightened by a fifth after eight verified iterations in a row, doubled when a
     // speculation fails (tight bounds mean shorter lists; a failure costs one forward with complete lists).
     const bool adaptive_margin = !(a->bound_margin_mul > 0.f);
-    float margin_m = 0.02f;
+    float margin_m = (warm_buf >= 0 && warm_margin >= 0.01f && warm_margin <= 0.05f) ? warm_margin : 0.02f;
     int margin_streak = 0;
     if (!adaptive_margin) { cx.spec.mul = a->bound_margin_mul; cx.spec.add = a->bound_margin_add; }
 
@@ -1462,7 +1488,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     if (a->pose_state_host) memcpy(a->pose_state_host, h_status + 16, GSR_POSE_STATE_FLOATS * sizeof(float));
     ctx_lease.clean = true;
     if (a->carry_state) *a->carry_state = (cov_cached ? 2 : 0) | 1;
-    if (a->warm_state) *a->warm_state = (a->speculative && last_enq >= 0) ? (par(last_enq) + 1) : 0;
+    if (a->warm_state)
+        *a->warm_state = (a->speculative && last_enq >= 0) ? ((par(last_enq) + 1) | (adaptive_margin ? ((int)lrintf(margin_m * 1e4f) << 8) : 0)) : 0;
     if (a->stats_out) {
         const bool want_count = a->stats_out[1] != -1;
         if (!want_count) last_R = -1;
@@ -1501,7 +1528,7 @@ int gsr_debug_lean_check(const gsr_refine_args* a, long long out[5])
     using namespace gsr;
     const int debug = 0;
     if (!a || !out) return fail(GSR_E_INVALID, "gsr_debug_lean_check: NULL argument%s", "");
-    if (!a->warm_state || *a->warm_state < 1 || *a->warm_state > 2 || !a->carry_state || !(*a->carry_state & 2))
+    if (!a->warm_state || (*a->warm_state & 0xFF) < 1 || (*a->warm_state & 0xFF) > 2 || !a->carry_state || !(*a->carry_state & 2))
         return fail(GSR_E_INVALID, "gsr_debug_lean_check: needs the warm_state / carry_state a speculative gsr_refine on these workspaces left%s", "");
     if (!a->pose_state || !a->means3D || !a->opacities || !a->geometry_buffer || !a->image_buffer || a->P <= 0)
         return fail(GSR_E_INVALID, "gsr_debug_lean_check: a required pointer is NULL%s", "");
@@ -1516,7 +1543,7 @@ int gsr_debug_lean_check(const gsr_refine_args* a, long long out[5])
     char* iptr = (char*)a->image_buffer(a->image_ctx, carve_img(nullptr, a->width, a->height, im));
     if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
     carve_img(iptr, a->width, a->height, im);
-    const int buf = *a->warm_state - 1;          // the bounds the last forward recorded: what the next iteration would bin with
+    const int buf = (*a->warm_state & 0xFF) - 1;          // the bounds the last forward recorded: what the next iteration would bin with
     const float* ps = a->pose_state;
     PreArgs pa = {};
     pa.P = a->P; pa.W = a->width; pa.H = a->height;

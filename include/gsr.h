@@ -332,7 +332,8 @@ typedef struct gsr_refine_args {
      * holds no depth bounds (the first iteration bins with the global sorts).  Pass the value the previous call on the
      * SAME image workspace (same size) left here to start speculating from that frame's bounds at once -- consecutive
      * frames of a sequence see almost the same depths.  As always the speculation is verified and redone if it
-     * fails, so a stale or unrelated set of bounds costs time, never exactness. */
+     * fails, so a stale or unrelated set of bounds costs time, never exactness.  (Opaque: the low byte names the bounds buffer,
+     * the bits above it carry the adaptive margin the call ended with, so that the next frame does not start widening again.) */
     int* warm_state;
     /* Nullable HOST int, in/out: what the previous call left behind that this one may rely on.  0 on input = nothing.
      * Pass back the value the previous call wrote here ONLY if nothing below was touched in between -- the same geometry

@@ -366,7 +366,7 @@ def test_warm_start_of_the_speculation_is_exact():
         R, T, info = fr.refine(vp, cfg, start[:3, :3].clone(), start[:3, 3].clone(), bg, iters=10, stop_on_converged=False, warm_start=warm)
         return R.clone(), T.clone(), dict(info), fr.color.clone()
     cold = run(init, False)
-    assert fr._warm.value in (1, 2)
+    assert (fr._warm.value & 0xFF) in (1, 2)
     warm_same = run(init, True)                        # bounds of the same frame
     near = torch.tensor(S.se3_exp([0.004, -0.003, 0.002, 0.002, -0.001, 0.001]), dtype=torch.float32, device=DEV) @ init
     cold_near = run(near, False)
@@ -535,7 +535,7 @@ def test_host_redo_of_a_warm_started_call_survives_an_overflowing_complete_list_
     fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
     # call 1 (cold): leaves depth bounds behind; its own complete-list forward overflows and goes through the exact path
     _, _, info1 = fr.refine(view(), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=3, stop_on_converged=False)
-    assert info1["fallbacks"] >= 1 and fr._warm.value in (1, 2)
+    assert info1["fallbacks"] >= 1 and (fr._warm.value & 0xFF) in (1, 2)
     # call 2 (warm): the first update "converges" (huge threshold) after a 0.05 rad / 5 cm step; the frozen forward at that pose
     # fails its verification somewhere, and the host's redo meets the overflowing bin
     vp = view()
