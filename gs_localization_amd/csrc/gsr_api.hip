@@ -369,7 +369,7 @@ struct ZeroList {
     {
         if (k == 0) return GSR_OK;
         const int blocks = (int)std::min<size_t>(256, std::max<size_t>(1, small_words / 2048));
-        hipLaunchKernelGGL(gsr::k_refine_init, dim3(blocks), dim3(GSR_BLOCK), 0, st, cr);
+        hipLaunchKernelGGL(gsr::k_refine_init, dim3(blocks), dim3(GSR_BLOCK), 0, st, cr, gsr::PoseLoadArgs{});
         hipError_t e_ = hipGetLastError();
         if (e_ != hipSuccess) return fail(GSR_E_HIP, "launch of %s failed: %s", "k_refine_init", hipGetErrorString(e_));
         return GSR_OK;
@@ -1262,11 +1262,11 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             HIPCHK(hipMemsetAsync(gg.dirty, 0, Pn, st));
             HIPCHK(hipMemsetAsync(gg.aflag, 0, 2 * Pn, st));
         }
+        PoseLoadArgs pl{};
         if (a->init_R) {
             if (!a->init_T || !a->init_exposure_a || !a->init_exposure_b) return fail(GSR_E_INVALID, "gsr_refine: init_R, init_T, init_exposure_a/b go together%s", "");
-            hipLaunchKernelGGL(k_pose_load, dim3(1), dim3(64), 0, st, ps, a->init_R, a->init_T, a->init_exposure_a, a->init_exposure_b, a->projmatrix_raw,
-                               a->pose_state_host ? h_status + 16 : (float*)nullptr);
-            { const int debug = 0; LAUNCHCHK("k_pose_load"); }
+            pl = PoseLoadArgs{ps, a->init_R, a->init_T, a->init_exposure_a, a->init_exposure_b, a->projmatrix_raw,
+                              a->pose_state_host ? h_status + 16 : (float*)nullptr};      // (loaded by k_refine_init's last workgroup below)
         }
         cx.rows = GradRows{a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor, a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, a->M};
         // image workspace: flags, cursors and both bound buffers start from zero; afterwards the kernels keep them so
@@ -1291,7 +1291,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             add(a->loss_out, 4);
             add(im0.tile_hold, (size_t)(im0.tile_work[1] - im0.tile_work[0]));
             static_assert(sizeof(cr.p) / sizeof(cr.p[0]) >= 10, "ClearRanges too small");
-            hipLaunchKernelGGL(k_refine_init, dim3(32), dim3(GSR_BLOCK), 0, st, cr);
+            hipLaunchKernelGGL(k_refine_init, dim3(32 + (pl.st != nullptr ? 1 : 0)), dim3(GSR_BLOCK), 0, st, cr, pl);
             { const int debug = 0; LAUNCHCHK("k_refine_init"); }
         }
         cx.balance = !(a->flags & GSR_REFINE_NO_BALANCE);
@@ -1484,7 +1484,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                            im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{}, 0u, (uint32_t*)nullptr, (a->P < (1 << 28)) ? 1 : 0, (uint32_t*)nullptr);
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
-    // (with init_* the kernels have kept a mirror of the state in pinned memory -- k_pose_load and every pose step that ran: no copy)
+    // (with init_* the kernels have kept a mirror of the state in pinned memory -- the pose load of k_refine_init and every pose step that ran: no copy)
     if (a->pose_state_host && !host_mirror) HIPCHK(hipMemcpyAsync(h_status + 16, ps, GSR_POSE_STATE_FLOATS * sizeof(float), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (a->pose_state_host) memcpy(a->pose_state_host, h_status + 16, GSR_POSE_STATE_FLOATS * sizeof(float));

@@ -2744,36 +2744,40 @@ __global__ void k_pose_init(float* st, const float* proj_raw)
 // buffers -- a hundred KB in all), in ONE launch instead of a dozen memsets: what a 20-iteration call spends on enqueueing those
 // is a fifth of an iteration each.  Ranges of 32-bit words; unused ranges have n = 0.
 struct ClearRanges { uint32_t* p[10]; uint32_t n[10]; };
-__global__ void __launch_bounds__(GSR_BLOCK) k_refine_init(ClearRanges c)
+// gsr_refine_args.init_*: the whole initial pose state from the caller's device tensors (zeros, R, T, exposure, camera); st == nullptr: none.
+// (host_state, nullable: the host's mirror of the pose state in pinned memory, see PoseStepArgs::host_state)
+struct PoseLoadArgs { float* st; const float* R0; const float* T0; const float* ea; const float* eb; const float* proj_raw; float* host_state; };
+__device__ __forceinline__ void pose_load_block(const PoseLoadArgs& q)          // all threads of the workgroup must call
 {
-    const uint32_t i0 = blockIdx.x * GSR_BLOCK + threadIdx.x, step = gridDim.x * GSR_BLOCK;
+    __shared__ float s_st[GSR_PS_SIZE];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < GSR_PS_SIZE; i += blockDim.x) s_st[i] = 0.f;
+    __syncthreads();
+    if (tid == 0) {
+        float R[9], T[3];
+        for (int i = 0; i < 9; i++) R[i] = q.R0[i];
+        for (int i = 0; i < 3; i++) T[i] = q.T0[i];
+        for (int i = 0; i < 9; i++) s_st[GSR_PS_R + i] = R[i];
+        for (int i = 0; i < 3; i++) s_st[GSR_PS_T + i] = T[i];
+        s_st[GSR_PS_PARAM + 6] = q.ea[0]; s_st[GSR_PS_PARAM + 7] = q.eb[0];
+        pose_write_camera(s_st, R, T, q.proj_raw);
+    }
+    __syncthreads();
+    for (int i = tid; i < GSR_PS_SIZE; i += blockDim.x) {
+        q.st[i] = s_st[i];
+        if (q.host_state != nullptr) q.host_state[i] = s_st[i];
+    }
+}
+// (the LAST workgroup loads the pose state when one is given -- one launch less in front of a call's first iteration; words of the
+// state that are also listed in the ranges are zero either way)
+__global__ void __launch_bounds__(GSR_BLOCK) k_refine_init(ClearRanges c, PoseLoadArgs q)
+{
+    if (q.st != nullptr && blockIdx.x == gridDim.x - 1) { pose_load_block(q); return; }
+    const uint32_t nb = gridDim.x - (q.st != nullptr ? 1u : 0u);
+    const uint32_t i0 = blockIdx.x * GSR_BLOCK + threadIdx.x, step = nb * GSR_BLOCK;
 #pragma unroll
     for (int r = 0; r < 10; r++)
         for (uint32_t i = i0; i < c.n[r]; i += step) c.p[r][i] = 0u;
-}
-
-// gsr_refine_args.init_*: the whole initial state from the caller's device tensors (zeros, R, T, exposure, camera) in one launch
-__global__ void __launch_bounds__(64) k_pose_load(float* st, const float* R0, const float* T0, const float* ea, const float* eb, const float* proj_raw, float* host_state)
-{
-    // (host_state, nullable: the host's mirror of the pose state in pinned memory, see PoseStepArgs::host_state)
-    __shared__ float s_st[GSR_PS_SIZE];
-    const int lane = threadIdx.x;
-    for (int i = lane; i < GSR_PS_SIZE; i += 64) s_st[i] = 0.f;
-    __syncthreads();
-    if (lane == 0) {
-        float R[9], T[3];
-        for (int i = 0; i < 9; i++) R[i] = R0[i];
-        for (int i = 0; i < 3; i++) T[i] = T0[i];
-        for (int i = 0; i < 9; i++) s_st[GSR_PS_R + i] = R[i];
-        for (int i = 0; i < 3; i++) s_st[GSR_PS_T + i] = T[i];
-        s_st[GSR_PS_PARAM + 6] = ea[0]; s_st[GSR_PS_PARAM + 7] = eb[0];
-        pose_write_camera(s_st, R, T, proj_raw);
-    }
-    __syncthreads();
-    for (int i = lane; i < GSR_PS_SIZE; i += 64) {
-        st[i] = s_st[i];
-        if (host_state != nullptr) host_state[i] = s_st[i];
-    }
 }
 
 // Adam (torch.optim.Adam defaults, one lr for the four groups of 7scenes_localize_full_dslam.py:33-64) on
