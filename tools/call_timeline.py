@@ -1,7 +1,7 @@
 """What one FusedRefiner.refine() call of K iterations costs next to K steady-state iterations (bench.py's per_call_overhead_ms),
 split into host phases.  usage: python tools/call_timeline.py [K] [calls]
 Under `rocprofv3 --kernel-trace` the kernel trace of the same run is what tools/kt_calls.py takes apart (one call = the kernels
-from one k_pose_load to the next)."""
+from one k_refine_init to the next)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,4 +1,4 @@
-"""Takes a rocprofv3 kernel trace of tools/call_timeline.py apart: one refine() call = the kernels from one k_pose_load to the
+"""Takes a rocprofv3 kernel trace of tools/call_timeline.py apart: one refine() call = the kernels from one k_refine_init to the
 next.  Prints, for the median call, when each kernel starts / how long it runs, and per call: wall (first start to last end),
 sum of kernel time, idle time.  usage: python tools/kt_calls.py <..._kernel_trace.csv> [K]"""
 import csv, sys
@@ -8,7 +8,7 @@ def nm(n): return n.split("gsr::")[1].split("(")[0][:34] if "gsr::" in n else n[
 calls, cur = [], None
 for r in rows:
     n = nm(r["Kernel_Name"])
-    if n.startswith("k_pose_load"):
+    if n.startswith("k_refine_init"):
         if cur: calls.append(cur)
         cur = []
     if cur is not None: cur.append((n, int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
