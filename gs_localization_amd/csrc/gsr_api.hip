@@ -700,7 +700,9 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
                                (size_t)2 * ntiles * sizeof(uint32_t), st, pa, bands);
         } else if (pa.lean) {
             // radii are not an output of this forward: conservative test for all Gaussians, exact geometry for the few it leaves
-            const int lblocks = std::max((P + GSR_LEAN_PER_LANE * GSR_BLOCK - 1) / (GSR_LEAN_PER_LANE * GSR_BLOCK), balanced ? 2 : 1);
+            // (whole windows of GSR_LEAN_WINDOW waves: the kernel deals the Gaussians of a window out segment by segment)
+            const int wblocks = GSR_LEAN_WINDOW / 4;
+            const int lblocks = std::max(((P + GSR_LEAN_PER_LANE * GSR_BLOCK - 1) / (GSR_LEAN_PER_LANE * GSR_BLOCK) + wblocks - 1) / wblocks * wblocks, balanced ? 2 : 1);
             // (LDS: the superblock bounds and the coarser levels the kernel builds behind them)
             hipLaunchKernelGGL(k_preprocess_lean, dim3(lblocks), dim3(GSR_BLOCK), bound_pyramid_floats(im.sbx, im.sby) * sizeof(float), st, pa);
         } else

@@ -176,8 +176,12 @@ __device__ __forceinline__ void row_span(const TileTest& t, int ty, int x0, int 
 #define GSR_SURV_CSTRIDE 64
 #ifndef GSR_LEAN_PER_LANE
 #define GSR_LEAN_PER_LANE 4      // Gaussians per lane of k_preprocess_lean
-static_assert(GSR_LEAN_PER_LANE * 256 == 1024, "surv_cap() and k_preprocess_bin's virtual blocks (idx >> 10) assume 1 024-Gaussian stretches: change them together");
+static_assert(GSR_LEAN_PER_LANE == 4 && GSR_LEAN_PER_LANE * 256 == 1024, "surv_cap() and k_preprocess_bin's virtual blocks (idx >> 10) assume 1 024-Gaussian stretches: change them together");
 #endif
+#ifndef GSR_LEAN_WINDOW
+#define GSR_LEAN_WINDOW 256      // (64: 58 / 128 us on the sorted S-1M-640 / S-3M-cam; 256: 45 / 68; 1 024: 43 / 68; random order: 35 / 60 whichever)
+#endif
+// ^ waves that share their Gaussians segment by segment (k_preprocess_lean); the grid is a multiple of a quarter of it
 #ifndef GSR_LEAN_POOL
 #define GSR_LEAN_POOL 1          // waves of a workgroup that pool their candidates for one exact pass (1, 2 or 4)
 #endif
@@ -984,13 +988,29 @@ __global__ void __launch_bounds__(GSR_BLOCK, GSR_LEAN_OCC) k_preprocess_lean(Pre
         float4* nr = reinterpret_cast<float4*>(a.rec + (size_t)a.P * GSR_REC_STRIDE);
         nr[0] = make_float4(0.f, 0.f, 0.f, 0.f); nr[1] = nr[0]; nr[2] = nr[0];
     }
-    const int base = (blockIdx.x * 4 + wv) * (GSR_LEAN_PER_LANE * 64);
+    // Which Gaussians a wave looks at: not 256 consecutive ones but sixteen SEGMENTS of sixteen, taken round-robin over all waves
+    // (segment s belongs to wave s mod #waves; a load instruction still moves four 256-byte runs).  Maps come in whatever order
+    // their training left them in -- spatially correlated, a Morton-sorted one in the extreme -- and the candidates of an iteration
+    // (the front layer of the scene) then sit in a few long index runs: with consecutive ranges the waves owning those runs went
+    // through the exact pass four times over while the others had nothing (k_preprocess_lean 164 instead of 34 us on a sorted
+    // S-1M-640, 289 instead of 60 on S-3M-cam; now 45 and 68).  Round-robin segments hand every wave the same share of every run.
+    // (round-robin inside windows of GSR_LEAN_WINDOW waves = 64 K Gaussians: over the whole map it costs the 16-byte stream its
+    // locality -- 64.6 instead of 60.0 us at 3 M Gaussians in random order)
+#ifndef GSR_LEAN_INTERLEAVE
+#define GSR_LEAN_INTERLEAVE 1
+#endif
+    const int wave_global = blockIdx.x * 4 + wv;
+    auto idx_of = [&](int k) {
+        return GSR_LEAN_INTERLEAVE ? ((wave_global / GSR_LEAN_WINDOW) * (GSR_LEAN_WINDOW * GSR_LEAN_PER_LANE * 64) +
+                                      ((4 * k + (lane >> 4)) * GSR_LEAN_WINDOW + (wave_global % GSR_LEAN_WINDOW)) * 16 + (lane & 15))
+                                   : (wave_global * (GSR_LEAN_PER_LANE * 64) + k * 64 + lane);
+    };
     int ncand = 0;                             // wave-uniform
     // (all the loads of the wave's Gaussians first: one round trip, not one per sub-chunk)
     float3 pk[GSR_LEAN_PER_LANE]; float sk[GSR_LEAN_PER_LANE]; uint8_t dk[GSR_LEAN_PER_LANE];
 #pragma unroll
     for (int k = 0; k < GSR_LEAN_PER_LANE; k++) {
-        const int idx = min(base + k * 64 + lane, a.P - 1);
+        const int idx = min(idx_of(k), a.P - 1);
         const float4 ml = reinterpret_cast<const float4*>(a.lam)[idx];      // (mean, extent bound): one coalesced 16-byte load
         pk[k] = make_float3(ml.x, ml.y, ml.z);
         sk[k] = ml.w;
@@ -999,7 +1019,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, GSR_LEAN_OCC) k_preprocess_lean(Pre
     const float wn2 = view_norm2_bound(a.view);
 #pragma unroll
     for (int k = 0; k < GSR_LEAN_PER_LANE; k++) {
-        const int idx = base + k * 64 + lane;
+        const int idx = idx_of(k);
         const bool live = idx < a.P;
         bool cand = false;
         if (live) {
@@ -1781,7 +1801,7 @@ __device__ __forceinline__ void select_slice(const unsigned long long* __restric
 // select_slice above finds an exact rank threshold by most-significant-digit radix selection: every pass re-reads the tile's ~2 800
 // keys from global memory and pushes each through an LDS atomic (64 k of a wave's 154 k cycles on S-1M-640's complete lists, 141 k of
 // 237 k on S-3M-cam's; 157 MB of HBM traffic per launch for 27 MB of keys).  But a slice does not need an exact rank -- any depth
-// threshold that admits "a couple of hundred" keys will do.  So: the first 1 024 keys of the segment (arrival order, i.e. a sample
+// threshold that admits "a couple of hundred" keys will do.  So: 1 024 keys of the segment (sixteen runs of 64 spread over it: a sample
 // that is unrelated to depth) go through LDS into registers, sixteen per lane, in EVERY wave; each wave bisects on the depth bits
 // until the sample count below the threshold matches the wanted share (wave ballots + scalar popcounts: no barrier, no atomics,
 // the four waves arrive at the same threshold because they run the same arithmetic on the same data); then one coalesced pass over
@@ -1793,12 +1813,21 @@ __device__ __forceinline__ int sample_slice(const unsigned long long* __restrict
 {
     __shared__ uint32_t s_fill;
     const int tid = threadIdx.x, lane = tid & 63;
+    // (sixteen runs of 64 keys spread evenly over the segment, not its first 1 024 keys: arrival order is only unrelated to depth while
+    // the MAP's order is unrelated to space -- on a Morton-sorted map every workgroup's run in a tile holds one depth range, the head of
+    // the segment says little about the rest, and the kernel took 94 instead of 75 us on S-1M-640, 212 instead of 114 on S-3M-cam)
+    const int nruns = (total + 63) >> 6;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int i = tid + GSR_BLOCK * j;
+        const int run = i >> 6;
+#ifndef GSR_SAMPLE_SPREAD
+#define GSR_SAMPLE_SPREAD 1
+#endif
+        const int pos = ((nruns <= 16 || !GSR_SAMPLE_SPREAD) ? run : (int)(((long long)run * nruns) >> 4)) * 64 + (i & 63);
         uint32_t d = 0xFFFFFFFFu;
-        if (i < total) {
-            const unsigned long long k = keys[i];
+        if (pos < total) {
+            const unsigned long long k = keys[pos];
             if (first || k > lo) d = (uint32_t)(k >> 32);
         }
         s_samp[i] = d;
