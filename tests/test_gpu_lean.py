@@ -82,6 +82,41 @@ def test_lean_kernel_live_on_a_small_map_changes_nothing(off_flag):
     assert bad == 0, (bad, first)
 
 
+def _morton_order(p, bits=10):
+    lo, hi = p.min(0), p.max(0)
+    q = np.minimum(((p - lo) / np.maximum(hi - lo, 1e-9) * (1 << bits)).astype(np.uint64), (1 << bits) - 1)
+    code = np.zeros(len(p), np.uint64)
+    for b in range(bits):
+        for a in range(3):
+            code |= ((q[:, a] >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b + a)
+    return np.argsort(code, kind="stable")
+
+
+def test_lean_kernel_on_a_spatially_sorted_map():
+    """A map in 3D Morton order: an iteration's candidates are a few long index runs (the kernel deals its Gaussians out in
+    segments so that no wave owns a whole run).  Same loop results as with k_preprocess, the conservative test settles nothing the
+    exact walk bins, and the permuted map gives the poses of the map in its draw order (a permutation only changes which of two
+    splats of EQUAL depth comes first)."""
+    from tests import replay as PL
+    sc = S.small(P=260000, W=208, H=160, sh_degree=2, seed=23, scale_med=0.02)
+    model0, bg, view0, init = _setup(sc, seed=4)
+    base = _run(PL.FusedRefiner(model0, sc.H, sc.W, device=DEV), view0(), init, bg, 8, flags=0)
+    perm = _morton_order(sc.means3D.astype(np.float64))
+    for k in ("means3D", "scales", "rotations", "opacities", "shs"):
+        setattr(sc, k, np.ascontiguousarray(getattr(sc, k)[perm]))
+    model, bg, view, init = _setup(sc, seed=4)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    lean = _run(fr, view(), init, bg, 8, flags=0)                       # 260 000 >= the product threshold: the lean kernel by default
+    off = _run(fr, view(), init, bg, 8, flags=_lib.REFINE_NO_LEAN)
+    assert lean["info"]["lean_iters"] >= 5 and off["info"]["lean_iters"] == 0, (lean["info"], off["info"])
+    _same_path(lean, off, "sorted map: lean vs off")
+    settled, cand, binned, bad, first = fr.lean_check()
+    assert bad == 0 and cand > 0, (bad, first, cand)
+    assert torch.allclose(lean["R"], base["R"], atol=2e-6) and torch.allclose(lean["T"], base["T"], atol=2e-6)
+    inv = torch.tensor(perm, device=DEV)
+    assert int((lean["radii"] != base["radii"][inv]).sum().item()) <= max(2, int(5e-5 * sc.P))
+
+
 def test_recorded_reference_loop_with_the_lean_kernel_live():
     """tests/test_gpu_refine.py::test_native_loop_follows_the_recorded_reference_loop with k_preprocess_lean in the loop: the
     poses after k bodies of the REFERENCE's loop (its loss, Adam, update_pose around the CPU oracle), to 2e-6."""
