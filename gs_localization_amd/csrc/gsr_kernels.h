@@ -1816,15 +1816,16 @@ __device__ __forceinline__ int sample_slice(const unsigned long long* __restrict
     // (sixteen runs of 64 keys spread evenly over the segment, not its first 1 024 keys: arrival order is only unrelated to depth while
     // the MAP's order is unrelated to space -- on a Morton-sorted map every workgroup's run in a tile holds one depth range, the head of
     // the segment says little about the rest, and the kernel took 94 instead of 75 us on S-1M-640, 212 instead of 114 on S-3M-cam)
-    const int nruns = (total + 63) >> 6;
+#ifndef GSR_SAMPLE_RUN
+#define GSR_SAMPLE_RUN 64          // keys per run of the sample (a power of two, 64 ... 1 024 = the head of the segment; measured on S-3M-cam's
+                                   // complete lists, random / Morton order: 64 -> 127 / 130 us, 256 -> 126 / 131, 1 024 -> 120 / 218)
+#endif
+    const int nruns = (total + GSR_SAMPLE_RUN - 1) / GSR_SAMPLE_RUN;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         const int i = tid + GSR_BLOCK * j;
-        const int run = i >> 6;
-#ifndef GSR_SAMPLE_SPREAD
-#define GSR_SAMPLE_SPREAD 1
-#endif
-        const int pos = ((nruns <= 16 || !GSR_SAMPLE_SPREAD) ? run : (int)(((long long)run * nruns) >> 4)) * 64 + (i & 63);
+        const int run = i / GSR_SAMPLE_RUN;
+        const int pos = ((nruns <= 1024 / GSR_SAMPLE_RUN) ? run : (int)(((long long)run * nruns) / (1024 / GSR_SAMPLE_RUN))) * GSR_SAMPLE_RUN + (i & (GSR_SAMPLE_RUN - 1));
         uint32_t d = 0xFFFFFFFFu;
         if (pos < total) {
             const unsigned long long k = keys[pos];
