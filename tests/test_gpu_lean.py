@@ -109,7 +109,8 @@ def test_lean_kernel_on_a_spatially_sorted_map():
     lean = _run(fr, view(), init, bg, 8, flags=0)                       # 260 000 >= the product threshold: the lean kernel by default
     off = _run(fr, view(), init, bg, 8, flags=_lib.REFINE_NO_LEAN)
     assert lean["info"]["lean_iters"] >= 5 and off["info"]["lean_iters"] == 0, (lean["info"], off["info"])
-    _same_path(lean, off, "sorted map: lean vs off")
+    # (260 000 sub-pixel splats: two runs of the loop end ~1e-7 apart and single pixels move by ~1e-3, see _same_path)
+    _same_path(lean, off, "sorted map: lean vs off", strict_pixels=False)
     settled, cand, binned, bad, first = fr.lean_check()
     assert bad == 0 and cand > 0, (bad, first, cand)
     assert torch.allclose(lean["R"], base["R"], atol=2e-6) and torch.allclose(lean["T"], base["T"], atol=2e-6)
