@@ -3127,7 +3127,7 @@ __device__ __forceinline__ float3 sh_color_backward(int deg, int M, float3 pos, 
 // compositing backward sums them (Qb appears once in the exponent).
 //   H  = dL/dC = -Q Gq Q,  Gq = [[gq.x, gq.y], [gq.y, gq.z]]          (derivative of the matrix inverse)
 //   G3 = dL/dSigma = M^T H M                                           (6 unique entries; out_G)
-//   D  = dL/dM = 2 H M Sigma = 2 N Sigma with N = H M
+//   D  = dL/dM = 2 H (M Sigma)
 //   dL/dJ = D Wc^T restricted to J's four non-constant entries, then dL/dt through J(t), then dL/dp = Wc^T dL/dt.
 __device__ __forceinline__ float3 covariance_chain(float3 p, const float* cov6, float3 Q, float3 gq, const float* view, float fx, float fy,
                                                    float tanx, float tany, float* out_G)
@@ -3152,11 +3152,19 @@ __device__ __forceinline__ float3 covariance_chain(float3 p, const float* cov6, 
     out_G[0] = m0[0] * n0[0] + m1[0] * n1[0]; out_G[1] = m0[0] * n0[1] + m1[0] * n1[1]; out_G[2] = m0[0] * n0[2] + m1[0] * n1[2];
     out_G[3] = m0[1] * n0[1] + m1[1] * n1[1]; out_G[4] = m0[1] * n0[2] + m1[1] * n1[2]; out_G[5] = m0[2] * n0[2] + m1[2] * n1[2];
     const float S[3][3] = {{cov6[0], cov6[1], cov6[2]}, {cov6[1], cov6[3], cov6[4]}, {cov6[2], cov6[4], cov6[5]}};
+    // (D = 2 H (M Sigma): the reference's order of the two products -- (H M) Sigma is the same matrix, with larger intermediate terms
+    // for thin splats)
+    float k0[3], k1[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        k0[k] = m0[0] * S[0][k] + m0[1] * S[1][k] + m0[2] * S[2][k];
+        k1[k] = m1[0] * S[0][k] + m1[1] * S[1][k] + m1[2] * S[2][k];
+    }
     float d0[3], d1[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
-        d0[k] = 2.f * (n0[0] * S[0][k] + n0[1] * S[1][k] + n0[2] * S[2][k]);
-        d1[k] = 2.f * (n1[0] * S[0][k] + n1[1] * S[1][k] + n1[2] * S[2][k]);
+        d0[k] = 2.f * (h00 * k0[k] + h01 * k1[k]);
+        d1[k] = 2.f * (h01 * k0[k] + h11 * k1[k]);
     }
     const float e00 = d0[0] * W00 + d0[1] * W01 + d0[2] * W02, e02 = d0[0] * W20 + d0[1] * W21 + d0[2] * W22;
     const float e11 = d1[0] * W10 + d1[1] * W11 + d1[2] * W12, e12 = d1[0] * W20 + d1[1] * W21 + d1[2] * W22;

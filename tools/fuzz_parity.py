@@ -20,7 +20,7 @@ def run(N=60, seed=1, only=None, verbose=True, needle=(12.0, 0.05)):
     failures = []
     os.environ["GSR_SPECULATION"] = os.environ.get("GSR_SPECULATION", "1")
     worst = dict(color=0.0, depth=0.0, alpha=0.0, grad=0.0, ratio=0.0)
-    flipped = 0; nbad = 0
+    flipped = 0; nbad = 0; nflipgrad = 0
     for case in range(N):
         W = int(rng.integers(17, 150)); H = int(rng.integers(17, 120))
         P = int(rng.choice([50, 400, 2500]))
@@ -58,6 +58,7 @@ def run(N=60, seed=1, only=None, verbose=True, needle=(12.0, 0.05)):
             truth = {k: v.grad.numpy() for k, v in dict(means3D=m, opacities=op, sh=sh, scales=scl, rotations=rot).items() if v.grad is not None}
             if pose and tau.grad is not None:
                 truth["tau"] = tau.grad.numpy()
+        case_flips = 0
         for rep in range(2):      # second render: speculative
             o, g = U.hip_run(sc, cam, grads, pose=pose)
             if not np.array_equal(o["radii"], f.radii):
@@ -69,7 +70,7 @@ def run(N=60, seed=1, only=None, verbose=True, needle=(12.0, 0.05)):
                 # blended by one side and skipped by the other -- up to alpha * T * colour on that pixel.  A handful of such
                 # pixels per image is rounding; more, or a larger jump, is a bug.  (That the tile / quadrant culling itself
                 # never drops a blended pair is checked bit-exactly by tools/cull_check.py.)
-                flips = int((dd > 3e-4).sum()); flipped += flips
+                flips = int((dd > 3e-4).sum()); flipped += flips; case_flips += flips
                 d = float(dd[dd <= 3e-4].max()) if (dd <= 3e-4).any() else 0.0
                 worst[k] = max(worst[k], d)
                 if flips > 4 or float(dd.max()) > 2e-2:
@@ -86,6 +87,17 @@ def run(N=60, seed=1, only=None, verbose=True, needle=(12.0, 0.05)):
                     for _ in range(2):
                         _f2, go2 = U.oracle_run(sc, cam, grads, pose=pose)
                         e_orc = max(e_orc, U.rel_l1(np.asarray(go2[k]).reshape(tr.shape), tr))
+                # (The float64 yardstick freezes the ORACLE's threshold decisions.  A pixel whose alpha lies within an ulp of 1/255 is blended
+                # by one fp32 path and skipped by the other -- the image check above counts those -- and under white-noise pixel gradients
+                # that one pixel is a visible share of a thin splat's gradient: seed 5001 case 269, needles, four flipped pixels, dL/dtau
+                # 3e-4 off with every other tensor within 2.3e-5, same numbers with all culling switched off.  A case WITH flipped pixels
+                # is therefore held to 1e-3 and reported separately.)
+                flip_case = case_flips > 0 and e_hip <= 1e-3
+                if flip_case and e_hip > max(5.0 * e_orc, 2e-4) and only is None:
+                    nflipgrad += 1
+                    if verbose:
+                        print("note: case", case, "rep", rep, k, "HIP", e_hip, "oracle", e_orc, "with", case_flips, "threshold-flipped pixel values")
+                    continue
                 if e_hip > max(5.0 * e_orc, 2e-4) or (only is not None and k in ("tau", "means3D")):
                     if verbose:
                         print("GRAD", case, rep, k, "HIP", e_hip, "oracle", e_orc, W, H, P, kind, deg)
@@ -98,8 +110,14 @@ def run(N=60, seed=1, only=None, verbose=True, needle=(12.0, 0.05)):
                         for i in top:
                             extra = (" z_view %.4f scale %s opacity %.3f" % (float((np.asarray(w2c)[:3, :3] @ sc.means3D[i] + np.asarray(w2c)[:3, 3])[2]), np.round(sc.scales[i], 4), float(sc.opacities[i]))) if tr.ndim > 1 and tr.shape[0] == sc.P else ""
                             print("   row", int(i), "HIP", np.round(gh[i], 5), "oracle", np.round(gor[i], 5), "float64", np.round(tr[i], 5), extra)
+                            if k == "means3D":      # (which input of the chain rule differs: the other per-Gaussian gradients of the same row)
+                                for k2 in ("means2D", "scales", "rotations", "opacities"):
+                                    if g.get(k2) is not None and go.get(k2) is not None:
+                                        a2, b2 = np.asarray(g[k2]).reshape(sc.P, -1)[i], np.asarray(go[k2]).reshape(sc.P, -1)[i]
+                                        t2 = truth[k2].reshape(sc.P, -1)[i] if k2 in truth else None
+                                        print("        ", k2, "HIP", np.round(a2, 5), "oracle", np.round(b2, 5), "" if t2 is None else ("float64 %s" % np.round(t2, 5)))
                         print("   share of the total |HIP - truth| in these rows: %.3f" % (rows[top].sum() / max(rows.sum(), 1e-30)))
-    summary = (f"{N} cases (seed {seed}), {nbad} gradient tensors more than 5x (and 2e-4) further from float64 than the oracle; worst per-pixel image "
+    summary = (f"{N} cases (seed {seed}), {nbad} gradient tensors more than 5x (and 2e-4) further from float64 than the oracle ({nflipgrad} more in cases with threshold-flipped pixels, within 1e-3); worst per-pixel image "
                f"differences {worst['color']:.2e} / {worst['depth']:.2e} / {worst['alpha']:.2e} (colour / depth / alpha, relative to max(1, |image|max); "
                f"{flipped} pixel values beyond that from threshold flips); gradients against float64 autograd: worst HIP error {worst['grad']:.2e}, "
                f"worst HIP error / oracle error {worst['ratio']:.1f}")
