@@ -37,6 +37,7 @@ SIGNATURES = {
     "gsr_profile_enable": (_i, [C.c_uint]),
     "gsr_profile_sampling": (_i, [C.c_uint]),
     "gsr_debug_timing": (_i, [C.POINTER(C.c_ulonglong)]),
+    "gsr_debug_tile_order": (_i, [_vp, _vp, _i, _vp]),
     "gsr_profile_collect": (_i, [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
     "gsr_profile_kernel_count": (_i, []),
     "gsr_profile_kernel_name": (C.c_char_p, [_i]),

@@ -1530,6 +1530,20 @@ size_t gsr_debug_lam_offset(int P)
     return (size_t)(reinterpret_cast<char*>(g.lam) - base);
 }
 
+int gsr_debug_tile_order(const unsigned* work, unsigned* order, int ntiles, void* stream)
+{
+    using namespace gsr;
+    const int debug = 0;
+    if (!work || !order || ntiles < 1 || ntiles > GSR_STATELESS_BALANCE_MAX_TILES) return fail(GSR_E_INVALID, "gsr_debug_tile_order: bad arguments%s", "");
+    int rc = select_device_of(work);
+    if (rc != GSR_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_backward_prologue<false>, dim3(1), dim3(GSR_TILE_ORDER_THREADS), 0, st, SurvLists{nullptr, nullptr, 0u}, (float*)nullptr, (uint8_t*)nullptr, 0,
+                       0, (const uint32_t*)work, (uint32_t*)order, ntiles);
+    LAUNCHCHK("k_backward_prologue (order only)");
+    return 0;
+}
+
 int gsr_debug_lean_check(const gsr_refine_args* a, long long out[5])
 {
     using namespace gsr;

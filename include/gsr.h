@@ -441,6 +441,10 @@ int gsr_profile_sampling(unsigned every);
 /* Diagnostic builds only (compiled with -DGSR_TIMING=1): copies out and clears 64 shader-clock phase totals
  * (slots 0-15 compositing forward, 16-31 compositing backward, 32-47 preprocess, 48-63 chain rule).  Returns -1 in product builds. */
 int gsr_debug_timing(unsigned long long* out64);
+/* Tests only: the launch order the stateless backward derives from the forward's per-tile work (heaviest tile first; image
+ * workspace, tiles 1 ... 16 384): order[0 .. ntiles) must come back a permutation of the tile numbers whatever work[] holds.
+ * Device pointers, uint32 each. */
+int gsr_debug_tile_order(const unsigned* work, unsigned* order, int ntiles, void* stream);
 int gsr_profile_collect(double* ms, long long* launches);
 int gsr_profile_kernel_count(void);
 const char* gsr_profile_kernel_name(int id);

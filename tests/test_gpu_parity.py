@@ -496,3 +496,31 @@ def test_lazy_sh_colours_under_contention(monkeypatch):
             assert np.array_equal(o[k], o_ref[k]), (rep, k)
         for k in ("means3D", "opacities", "sh", "scales", "rotations", "tau"):
             assert U.rel_l1(g[k], g_ref[k]) <= 2e-5, (rep, k)          # (fp32 atomics reorder the sums of splats that span 1 200 tiles)
+
+
+@pytest.mark.parametrize("ntiles", [1, 255, 1536, 4293, 16384])
+def test_backward_launch_order_is_a_permutation_heaviest_first(ntiles):
+    """k_backward_prologue's first workgroup (gsr_debug_tile_order): whatever the forward left in tile_work -- zeros, one value for
+    all, huge values, a fresh buffer's garbage -- the order is a permutation of the tiles, and (for weights that differ by more than
+    the 8-bit class width) heavier tiles come in earlier rows of 256."""
+    import torch
+    from gs_localization_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(ntiles)
+    cases = {"zeros": np.zeros(ntiles, np.uint32), "equal": np.full(ntiles, 77, np.uint32),
+             "random": rng.integers(0, 5000, ntiles).astype(np.uint32), "huge": rng.integers(0, 2**32 - 1, ntiles, dtype=np.uint64).astype(np.uint32),
+             "ramp": np.arange(ntiles, dtype=np.uint32)}
+    for name, w in cases.items():
+        work = torch.from_numpy(w.view(np.int32)).to("cuda:0")
+        order = torch.full((ntiles,), -1, dtype=torch.int32, device="cuda:0")
+        _lib.check(lib.gsr_debug_tile_order(work.data_ptr(), order.data_ptr(), ntiles, None))
+        torch.cuda.synchronize()
+        o = order.cpu().numpy().astype(np.int64)
+        assert np.array_equal(np.sort(o), np.arange(ntiles)), (name, ntiles)
+        if name in ("random", "ramp", "huge") and ntiles > 512:
+            # rows of 256 launch slots: the lightest tile of an earlier row is not lighter than the heaviest of a later one by more than a class
+            ww = w.astype(np.float64)[o]
+            cls = ww.max() / 255.0 + 1.0
+            rows = [ww[i:i + 256] for i in range(0, ntiles, 256)]
+            for a, b in zip(rows[:-1], rows[1:]):
+                assert a.min() >= b.max() - 2 * cls, (name, ntiles)
