@@ -532,7 +532,7 @@ int allow_large_lds(int dev)
                      height, means3D, shs, colors_precomp, opacities, scales, scale_modifier, rotations, cov3D_precomp, viewmatrix, \
                      projmatrix, cam_pos, tan_fovx, tan_fovy, prefiltered, out_color, out_depth, out_alpha, radii, debug, n_touched, stream
 
-// Work-balanced launch order of the compositing kernels outside the native loop (k_tile_order): pays when there are more tiles
+// Work-balanced launch order of the compositing kernels outside the native loop (tile_order_block in k_backward_prologue): pays when there are more tiles
 // than resident workgroups (256 CUs x 5), i.e. when the order in which tiles START decides how long the last one runs.
 #ifndef GSR_STATELESS_BALANCE_MIN_TILES
 #define GSR_STATELESS_BALANCE_MIN_TILES 1536      // (0: never)
@@ -609,7 +609,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     pa.rec = g.rec;
     const bool balanced = cx.balance && cx.native_loop && ntiles <= GSR_ORDER_MAX_TILES && !sp.state;
     for (int k = 0; k < 2; k++) { pa.tile_work[k] = balanced ? im.tile_work[k] : nullptr; pa.tile_order[k] = balanced ? im.tile_order[k] : nullptr; }
-    // the stateless entry points: no previous iteration to learn the tiles' weights from -- see k_tile_order
+    // the stateless entry points: no previous iteration to learn the tiles' weights from -- see tile_order_block
     const bool stateless_balance = stateless_balanced(cx, ntiles);
     pa.order_tiles = ntiles;
     pa.dirty = cx.native_loop ? g.dirty : nullptr;
@@ -784,7 +784,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     {
         ProfScope psr(K_RENDER_FWD, st);
         const bool local = by_tile || full_bins;
-        // (stateless: the tiles' work is recorded for the backward's launch order, k_tile_order.  The forward itself keeps the natural
+        // (stateless: the tiles' work is recorded for the backward's launch order, tile_order_block.  The forward itself keeps the natural
         // order: list LENGTHS, known after the scan, are a poor predictor of a tile's work -- measured at the train step's 4 293 tiles /
         // 1.5 M Gaussians: 214 against 216 us, where the order by the TRUE work would give 150 against 180 on a second run of the
         // same frame -- and nothing better is known before the kernel has run)

@@ -231,7 +231,7 @@ class FusedRefiner:
         stats = self._stats
         stats[0], stats[1], stats[2], stats[3] = 0, (0 if count_instances else -1), 0, 0
         a.stream = stream
-        # a fresh pose state per call (k_pose_load fills all of it): the pose handed back below is a VIEW of it, not a copy -- three
+        # a fresh pose state per call (the pose load of k_refine_init fills all of it): the pose handed back below is a VIEW of it, not a copy -- three
         # tiny torch kernels per call, each behind a host-side launch gap with the GPU idle (0.1 ms of a 3 ms call)
         self.state = torch.empty(_lib.POSE_STATE_FLOATS, dtype=torch.float32, device=dev)
         a.pose_state = self.state.data_ptr()
