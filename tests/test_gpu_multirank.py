@@ -35,8 +35,9 @@ def test_bench_gpus_flag_launches_the_ranks():
     assert two["config"]["parallelism"].startswith("frames: 2 GPU")
     # both ranks share one GPU here: the aggregate stays within a factor of three of the single rank's (5-iteration calls: noisy)
     assert one["value"] / 3.0 <= two["value"] <= 3.0 * one["value"], (one["value"], two["value"])
-    for k in ("roofline", "single_frame_iters_per_s", "per_call_overhead_ms", "steady_state_ms_per_iter"):
+    for k in ("roofline", "single_frame_iters_per_s", "per_call_overhead_ms", "steady_state_ms_per_iter", "stream_of_frames_iters_per_s", "value_repeats_stats"):
         assert k in two
+    assert two["stream_of_frames_iters_per_s"] > 0 and one["stream_of_frames_iters_per_s"] > 0
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
