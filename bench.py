@@ -75,6 +75,8 @@ def main():
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the CPU port on one thread on S-800k-chess (minutes)")
     ap.add_argument("--no-train-leg", action="store_true")
     ap.add_argument("--no-cam-leg", action="store_true", help="skip BASELINE.json config 3 (S-3M-cam, 852x480 and 1024x576)")
+    ap.add_argument("--no-variants-leg", action="store_true", help="skip the structured variants of the headline scene (object / walls / S-room-640)")
+    ap.add_argument("--only-variants", default=None, help="diagnostics: run ONLY the scene_variants leg (comma-separated names, or 'all') and print it")
     ap.add_argument("--pose-only", action="store_true", help="skip the Gaussian-parameter gradients (not the headline)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend for N > 1; gloo (collectives on host tensors) lets the N > 1 code path be rehearsed on a box with one GPU")
@@ -122,6 +124,10 @@ def main():
     from tests import replay as PL      # the reference-style Python loop on the drop-in packages (test infrastructure)
     lib = _lib.load()
     assert lib.gsr_device_ok() == 1, "no gfx950 device"
+    if args.only_variants:
+        only = None if args.only_variants == "all" else set(args.only_variants.split(","))
+        print(json.dumps({"scene_variants": scene_variants_leg(lib, dev, K=args.steps, only=only)}), flush=True)
+        return
 
     K, Wm, F = args.steps, max(args.warmup, 1), max(args.frames_in_flight, 1)
     sc = S.s_1m_640(P=args.gaussians)
@@ -394,10 +400,13 @@ def main():
     job["quit"] = True
     gate_in.wait()
     [t.join() for t in pool]
-    train, cam = None, None
-    if rank == 0 and world == 1 and not (args.no_train_leg and args.no_cam_leg):
+    train, cam, variants = None, None, None
+    if rank == 0 and world == 1 and not (args.no_train_leg and args.no_cam_leg and args.no_variants_leg):
         del frs, vps, model
         torch.cuda.empty_cache()
+        if not args.no_variants_leg:
+            variants = scene_variants_leg(lib, dev, K=K)
+            torch.cuda.empty_cache()
         if not args.no_cam_leg:
             cam = cam_step_leg(lib, dev)
             torch.cuda.empty_cache()
@@ -512,6 +521,8 @@ def main():
         if cpu is not None:
             out["cpu_baseline"] = cpu
             out["cpu_baseline_other_scenes"] = cpu_more
+        if variants is not None:
+            out["scene_variants"] = variants
         if cam is not None:
             out["cam_step"] = cam
         if train is not None:
@@ -666,6 +677,68 @@ def cam_step_leg(lib, dev):
         del fr, frames, model
         torch.cuda.empty_cache()
     return {"workload": "S-3M-cam pose refinement (BASELINE.json configs[3]), native loop, one frame at a time, 20 iterations per call", "per_size": rows}
+
+
+def scene_variants_leg(lib, dev, K=50, only=None):
+    """Structured variants of the headline scene (gs_localization_amd/scenes.py: "object" = half of the map inside a cone a tenth
+    of the image wide, "walls" = two thin depth layers, "room" = S-room-640, a box room of flattened splats with bimodal
+    opacities -- the nearest stand-in for a trained indoor map): refinement iterations/s of the native loop on ONE frame,
+    speculative and with complete lists, K iterations per call, per-kernel times, and a roofline line for the kernel each
+    spends most time in.  A uniform random cloud (S-1M-640, `value`) is the friendliest scene this path can get."""
+    from gs_localization_amd import scenes as S
+    from tests import replay as PL
+    rows = []
+    bg = torch.zeros(3, dtype=torch.float32, device=dev)
+    for vname, make in S.VARIANTS.items():
+        if only is not None and vname not in only:
+            continue
+        sc = make()
+        W, H, M = sc.W, sc.H, sc.shs.shape[1]
+        N, ntiles = W * H, ((W + 15) // 16) * ((H + 15) // 16)
+        model = PL.GaussianMap.from_scene(sc, device=dev)
+        frames = [PL.make_frame(sc, model, dev, bg, uid=u) for u in (0, 1)]
+        inits = [PL.perturbed_start(1000 + u, device=dev) for u in (0, 1)]
+        pkg = PL.render(frames[0], model, bg)
+        V, R, R_ord, R_eff = _stats_of(lib, pkg["render"].grad_fn, sc.P, W, H)
+        del pkg
+        fr = PL.FusedRefiner(model, H, W, device=dev)
+
+        def call(g, iters, spec, warm=None):
+            return fr.refine(frames[g], PL.TRACKING_CONFIG, inits[g][:3, :3].clone(), inits[g][:3, 3].clone(), bg, iters=iters,
+                             stop_on_converged=False, speculative=spec, warm_start=warm)
+        res = {}
+        for spec in (True, False):
+            best, info = 1e9, None
+            for _ in range(3):
+                call(1, 5, spec)                      # the predecessor frame: its bounds are what the warm start gets
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                _, _, inf = call(0, K, spec)
+                torch.cuda.synchronize()
+                el = time.perf_counter() - t0
+                if el < best:
+                    best, info = el, {k: inf[k] for k in ("fallbacks", "host_redos", "lean_iters")}
+            kms, _ = _profile_ms(lib, lambda: call(0, K, spec), 2)
+            res[spec] = (K / best, {k: round(v / K, 4) for k, v in kms.items() if v > 0}, info)
+        # pose error of a full refinement with the reference's early exit
+        Rr, Tt, inf = fr.refine(frames[0], PL.TRACKING_CONFIG, inits[0][:3, :3].clone(), inits[0][:3, 3].clone(), bg, iters=50, stop_on_converged=True)
+        te, re = PL.pose_errors(np.eye(3), np.zeros(3), inf["R_host"], inf["T_host"])
+        per, _ = algorithmic_bytes(sc.P, V, R, R_eff, N, M, ntiles)
+        loop_kernels = {k: per[k] for k in ("render_fwd", "render_bwd", "preprocess_bwd", "preprocess_fwd")}
+        rows.append({"scene": sc.name, "variant": vname, "width": W, "height": H, "gaussians": sc.P, "tiles": ntiles, "V": V, "R": R,
+                     "R_eff_own_binning": R_eff, "list_entries_ordered": R_ord, "iterations_per_call": K,
+                     "speculative_iters_per_s": res[True][0], "plain_iters_per_s": res[False][0],
+                     "speculative_call_stats": res[True][2], "plain_call_stats": res[False][2],
+                     "pose_err_cm_deg_after_refinement": [100.0 * te, re], "refine_iters": inf["iters"],
+                     "kernels_ms_per_iter_speculative": res[True][1], "kernels_ms_per_iter_plain": res[False][1],
+                     "roofline": _roofline({k: v for k, v in res[True][1].items()}, loop_kernels, f"r05_{vname}_spec_traffic.json",
+                                           "speculative loop, one frame; R_eff of the own (culled) binning"),
+                     "roofline_plain": _roofline({k: v for k, v in res[False][1].items()}, loop_kernels, f"r05_{vname}_plain_traffic.json",
+                                                 "complete lists in every iteration")})
+        del fr, frames, model
+        torch.cuda.empty_cache()
+    return {"workload": f"structured variants of S-1M-640 (1 M Gaussians, 640x480, SH3), native loop, one frame at a time, {K} iterations per call",
+            "per_scene": rows}
 
 
 def train_step_leg(lib):

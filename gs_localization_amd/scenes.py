@@ -126,6 +126,131 @@ def s_50k_fern(seed=0):
     return _draw("S-50k-fern", 50_000, 504, 378, 400.0, 400.0, 0.5, 6.0, 0.03, 0.6, 3, seed)
 
 
+# ---------------------------------------------------------------------------------------------
+# Structured variants of the headline scene (round 5).  Every scene of SURVEY.md 8(d) is a uniform random cloud; a trained
+# indoor map is surfaces and objects.  These keep S-1M-640's camera, size and per-splat distributions and change only WHERE the
+# splats are (and, for the room, their shape), so that their rates read against the headline's.
+# ---------------------------------------------------------------------------------------------
+def s_1m_640_object(P=1_000_000, seed=0, vseed=11):
+    """S-1M-640 with half of the map inside a cone around the optical axis a tenth of the image wide: ~60 of the 1 200 tiles
+    carry most of the compositing work (a dense object in front of a sparse scene)."""
+    sc = s_1m_640(P, seed)
+    rng = np.random.default_rng(vseed)
+    m = sc.means3D.astype(np.float64)
+    sel = rng.random(P) < 0.5
+    z = m[sel, 2]
+    n = int(sel.sum())
+    m[sel, 0] = rng.normal(0, 0.03, n) * z
+    m[sel, 1] = rng.normal(0, 0.03, n) * z
+    sc.means3D = np.ascontiguousarray(m, np.float32)
+    sc.name = "S-1M-640-object"
+    return sc
+
+
+def s_1m_640_walls(P=1_000_000, seed=0, vseed=11):
+    """S-1M-640 with every splat on one of two thin fronto-parallel layers (z = 3 m and 5 m, 2 cm thick): a depth bound per
+    tile cannot tell coplanar splats apart."""
+    sc = s_1m_640(P, seed)
+    rng = np.random.default_rng(vseed)
+    m = sc.means3D.astype(np.float64)
+    lay = rng.random(P) < 0.5
+    zz = np.where(lay, 3.0, 5.0) + rng.normal(0, 0.02, P)
+    m[:, 0] *= zz / m[:, 2]
+    m[:, 1] *= zz / m[:, 2]
+    m[:, 2] = zz
+    sc.means3D = np.ascontiguousarray(m, np.float32)
+    sc.name = "S-1M-640-walls"
+    return sc
+
+
+def _quat_from_frame(t1, t2, n):
+    """(w, x, y, z) of the rotation whose columns are (t1, t2, n), row-wise for arrays [K, 3]."""
+    R = np.stack([t1, t2, n], axis=2)                       # [K, 3, 3], columns = local axes
+    tr = R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]
+    q = np.empty((R.shape[0], 4))
+    # numerically safe branch per row (largest of w, x, y, z)
+    cand = np.stack([tr, R[:, 0, 0], R[:, 1, 1], R[:, 2, 2]], 1)
+    which = cand.argmax(1)
+    for k in range(4):
+        s_ = which == k
+        if not s_.any():
+            continue
+        r = R[s_]
+        if k == 0:
+            s4 = np.sqrt(1.0 + r[:, 0, 0] + r[:, 1, 1] + r[:, 2, 2]) * 2
+            q[s_] = np.stack([0.25 * s4, (r[:, 2, 1] - r[:, 1, 2]) / s4, (r[:, 0, 2] - r[:, 2, 0]) / s4, (r[:, 1, 0] - r[:, 0, 1]) / s4], 1)
+        elif k == 1:
+            s4 = np.sqrt(1.0 + r[:, 0, 0] - r[:, 1, 1] - r[:, 2, 2]) * 2
+            q[s_] = np.stack([(r[:, 2, 1] - r[:, 1, 2]) / s4, 0.25 * s4, (r[:, 0, 1] + r[:, 1, 0]) / s4, (r[:, 0, 2] + r[:, 2, 0]) / s4], 1)
+        elif k == 2:
+            s4 = np.sqrt(1.0 - r[:, 0, 0] + r[:, 1, 1] - r[:, 2, 2]) * 2
+            q[s_] = np.stack([(r[:, 0, 2] - r[:, 2, 0]) / s4, (r[:, 0, 1] + r[:, 1, 0]) / s4, 0.25 * s4, (r[:, 1, 2] + r[:, 2, 1]) / s4], 1)
+        else:
+            s4 = np.sqrt(1.0 - r[:, 0, 0] - r[:, 1, 1] + r[:, 2, 2]) * 2
+            q[s_] = np.stack([(r[:, 1, 0] - r[:, 0, 1]) / s4, (r[:, 0, 2] + r[:, 2, 0]) / s4, (r[:, 1, 2] + r[:, 2, 1]) / s4, 0.25 * s4], 1)
+    return q / np.linalg.norm(q, axis=1, keepdims=True)
+
+
+def s_room_640(P=1_000_000, seed=0):
+    """S-room-640: the nearest honest stand-in for a trained indoor map (7-Scenes chess) that can be drawn without data.
+    A box room 6 x 3 x 8 m around the camera (identity pose, looking down +z; the wall behind the camera is part of the map and
+    never visible) with six pieces of box furniture; every splat lies ON a surface, flattened (its extent along the surface
+    normal is a tenth of its tangential extents, the normal is one of its principal axes, random in-plane rotation), with 5 mm of
+    positional noise along the normal; opacities are bimodal (two thirds near-opaque, one third faint), as trained maps are.
+    640x480, fx = fy = 525, SH degree 3, 1 M Gaussians."""
+    rng = np.random.default_rng(seed)
+    W, H, fx = 640, 480, 525.0
+    # surfaces: (origin, edge u, edge v, normal) -- rectangles; sampled in proportion to their area
+    rects = []
+
+    def box(lo, hi, inward):
+        lo, hi = np.asarray(lo, float), np.asarray(hi, float)
+        d = hi - lo
+        sgn = -1.0 if inward else 1.0
+        for ax in range(3):
+            u, v = (ax + 1) % 3, (ax + 2) % 3
+            eu, ev = np.zeros(3), np.zeros(3)
+            eu[u], ev[v] = d[u], d[v]
+            for side, o in ((0, lo), (1, lo + np.eye(3)[ax] * d[ax])):
+                n = np.zeros(3)
+                n[ax] = (1.0 if side else -1.0) * sgn
+                rects.append((o.copy(), eu, ev, n))
+    box((-3.0, -1.5, -2.0), (3.0, 1.5, 6.0), inward=True)                    # the room
+    furniture = [((-2.6, 0.3, 2.2), (-1.2, 1.5, 3.6)), ((0.9, 0.6, 1.6), (2.3, 1.5, 2.4)), ((-0.6, 0.9, 3.0), (0.6, 1.5, 4.2)),
+                 ((1.6, -0.4, 4.4), (2.9, 1.5, 5.6)), ((-2.9, -0.9, 4.8), (-1.9, 1.5, 5.9)), ((-0.4, 0.2, 1.2), (0.2, 0.9, 1.5))]
+    n_room = len(rects)
+    for lo, hi in furniture:
+        box(lo, hi, inward=False)
+    area = np.array([np.linalg.norm(np.cross(eu, ev)) for _, eu, ev, _ in rects])
+    area[n_room:] *= 3.0                                                       # objects are mapped more densely than bare walls
+    which = rng.choice(len(rects), size=P, p=area / area.sum())
+    a, b = rng.random(P), rng.random(P)
+    O = np.stack([r[0] for r in rects])[which]
+    EU = np.stack([r[1] for r in rects])[which]
+    EV = np.stack([r[2] for r in rects])[which]
+    Nn = np.stack([r[3] for r in rects])[which]
+    pos = O + a[:, None] * EU + b[:, None] * EV + rng.normal(0, 0.005, P)[:, None] * Nn
+    t1 = EU / np.linalg.norm(EU, axis=1, keepdims=True)
+    t2 = np.cross(Nn, t1)
+    phi = rng.uniform(0, 2 * np.pi, P)
+    c, s_ = np.cos(phi)[:, None], np.sin(phi)[:, None]
+    u1, u2 = c * t1 + s_ * t2, -s_ * t1 + c * t2                               # in-plane axes; (u1, u2, n) is right-handed
+    q = _quat_from_frame(u1, u2, Nn)
+    tang = np.exp(rng.normal(math.log(0.02), 0.5, (P, 2)))
+    scale = np.concatenate([tang, 0.1 * tang.mean(1, keepdims=True)], 1)
+    strong = rng.random(P) < (2.0 / 3.0)
+    logit = np.where(strong, rng.normal(3.0, 1.0, P), rng.normal(-2.5, 1.0, P))
+    opacity = 1.0 / (1.0 + np.exp(-logit))
+    amp = np.array([1.0] + [0.1] * 15)
+    sh = rng.normal(0, 1, (P, 16, 3)) * amp[None, :, None]
+    f = lambda x: np.ascontiguousarray(x, np.float32)
+    return Scene(name="S-room-640", W=W, H=H, fx=fx, fy=fx, cx=W / 2.0, cy=H / 2.0, znear=0.01, zfar=100.0, sh_degree=3,
+                 means3D=f(pos), scales=f(scale), rotations=f(q), opacities=f(opacity[:, None]), shs=f(sh))
+
+
+VARIANTS = {"object": s_1m_640_object, "walls": s_1m_640_walls, "room": s_room_640}
+
+
 def small(P=512, W=64, H=48, sh_degree=3, seed=1, scale_med=0.05, fx=None):
     """Small parity-test scene; same distributions, larger splats so that tiles fill up."""
     fx = fx if fx is not None else 0.8 * W

@@ -616,6 +616,32 @@ static void cov3d_backward(int idx, const float* scale, float mod, const float* 
 #undef A
 }
 
+/* The two per-Gaussian stages of K9 on their own, so that tests/test_oracle_pinning.py can hold them against autograd through the
+ * reference's own Python (eval_sh, build_scaling_rotation / strip_symmetric: tests/golden/make_golden.py) -- the same static
+ * functions gso_backward calls below, nothing restated. */
+void gso_sh_backward_stage(int P, int D, int M, const float* means3D, const float* campos, const float* shs,
+                           const uint8_t* clamped /*P*3*/, const float* dL_dcolor /*P*3*/, float* dL_dsh /*P*M*3*/,
+                           float* dL_dmean /*P*3: the view-direction term only*/)
+{
+    for (int idx = 0; idx < P; idx++) {
+        vec3 g = sh_backward(idx, D, M, means3D, campos, shs, clamped, dL_dcolor, dL_dsh);
+        dL_dmean[3 * idx] = g.x; dL_dmean[3 * idx + 1] = g.y; dL_dmean[3 * idx + 2] = g.z;
+    }
+}
+
+void gso_sh_forward_stage(int P, int D, int M, const float* means3D, const float* campos, const float* shs,
+                          float* rgb /*P*3*/, uint8_t* clamped /*P*3*/)
+{
+    for (int idx = 0; idx < P; idx++) sh_to_rgb(idx, D, M, means3D, campos, shs, clamped, rgb + 3 * (size_t)idx);
+}
+
+void gso_cov3d_backward_stage(int P, const float* scales, float scale_modifier, const float* rotations,
+                              const float* dL_dcov3D /*P*6*/, float* dL_dscale /*P*3*/, float* dL_drot /*P*4*/)
+{
+    for (int idx = 0; idx < P; idx++)
+        cov3d_backward(idx, scales + 3 * (size_t)idx, scale_modifier, rotations + 4 * (size_t)idx, dL_dcov3D, dL_dscale, dL_drot);
+}
+
 /*
  * Backward.  pose_mode = 0 : package (A) semantics, bit-faithful to the vendored code.
  *            pose_mode = 1 : package (B): additionally (i) the per-Gaussian depth z_i receives

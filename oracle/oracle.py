@@ -138,6 +138,35 @@ def backward(fwd, grad_color, grad_depth, grad_alpha, pose_mode=False):
     return g
 
 
+def sh_stage(means3D, campos, shs, sh_degree, dL_dcolor=None):
+    """K1's SH colour stage and K9's SH backward stage on their own (tests/test_oracle_pinning.py):
+    returns (rgb [P,3], clamped [P,3] bool) and, given dL_dcolor, also (dL_dsh [P,M,3], dL_dmean [P,3] = the view-direction term)."""
+    L = lib()
+    means3D, campos, shs = _f32(means3D), _f32(campos), _f32(shs)
+    P, M = shs.shape[0], shs.shape[1]
+    rgb = np.zeros((P, 3), np.float32)
+    clamped = np.zeros((P, 3), np.uint8)
+    L.gso_sh_forward_stage(C.c_int(P), C.c_int(sh_degree), C.c_int(M), _p(means3D), _p(campos), _p(shs), _p(rgb), _p(clamped))
+    if dL_dcolor is None:
+        return rgb, clamped.astype(bool)
+    g = _f32(dL_dcolor)
+    dsh = np.zeros((P, M, 3), np.float32)
+    dmean = np.zeros((P, 3), np.float32)
+    L.gso_sh_backward_stage(C.c_int(P), C.c_int(sh_degree), C.c_int(M), _p(means3D), _p(campos), _p(shs), _p(clamped), _p(g), _p(dsh), _p(dmean))
+    return rgb, clamped.astype(bool), dsh, dmean
+
+
+def cov3d_backward_stage(scales, rotations, dL_dcov3D, scale_modifier=1.0):
+    """K9's covariance stage on its own: dL/dcov3D (6-vector) -> (dL/dscale [P,3], dL/drot [P,4])."""
+    L = lib()
+    scales, rotations, g = _f32(scales), _f32(rotations), _f32(dL_dcov3D)
+    P = scales.shape[0]
+    ds = np.zeros((P, 3), np.float32)
+    dq = np.zeros((P, 4), np.float32)
+    L.gso_cov3d_backward_stage(C.c_int(P), _p(scales), C.c_float(scale_modifier), _p(rotations), _p(g), _p(ds), _p(dq))
+    return ds, dq
+
+
 def mark_visible(means3D, viewmatrix, projmatrix):
     means3D = _f32(means3D)
     out = np.zeros(means3D.shape[0], np.uint8)

@@ -97,6 +97,31 @@ def main():
         cfg = {"Training": {"monocular": mono, "alpha": 0.99, "opacity_threshold": 0.99}}
         loss = desc.get_loss_tracking(cfg, torch.tensor(image), torch.tensor(depth), torch.tensor(opacity), vp)
         out[f"loss_mono{int(mono)}"] = np.float64(loss.item())
+    # ---- round 5: BACKWARD of the SH and covariance stages, by autograd THROUGH the reference's own functions (K9: backward.cu:20-139,
+    # 278-341).  New draws come after every earlier one, so the vectors above keep their bits.
+    g_col = rng.normal(0, 1, (P, 3)).astype(np.float32)
+    out["shb_dL_dcolor"] = g_col
+    for deg in range(4):
+        M = (deg + 1) ** 2
+        m_t = torch.tensor(means, dtype=torch.float64, requires_grad=True)
+        sh_t = torch.tensor(shs[:, :M], dtype=torch.float64, requires_grad=True)
+        dd = m_t - torch.tensor(campos, dtype=torch.float64)
+        dd = dd / dd.norm(dim=1, keepdim=True)                       # render(): dir_pp / dir_pp.norm (gaussian_renderer/__init__.py:75-77)
+        rgb = torch.clamp_min(sh_utils.eval_sh(deg, sh_t.transpose(1, 2), dd) + 0.5, 0.0)
+        (rgb * torch.tensor(g_col, dtype=torch.float64)).sum().backward()
+        out[f"shb_dL_dsh_deg{deg}"] = sh_t.grad.numpy()
+        out[f"shb_dL_dmean_deg{deg}"] = (m_t.grad if m_t.grad is not None else torch.zeros_like(m_t)).numpy()      # (degree 0 does not look at the direction)
+        out[f"shb_rgb64_deg{deg}"] = rgb.detach().numpy()
+    g_cov = rng.normal(0, 1, (P, 6)).astype(np.float32)
+    out["covb_dL_dcov"] = g_cov
+    for mod in (1.0, 0.7):
+        s_t = torch.tensor(scales, dtype=torch.float64, requires_grad=True)
+        q_t = torch.tensor(rots, dtype=torch.float64, requires_grad=True)
+        Lm = gen.build_scaling_rotation(mod * s_t, q_t)
+        cov = gen.strip_symmetric(Lm @ Lm.transpose(1, 2))
+        (cov * torch.tensor(g_cov, dtype=torch.float64)).sum().backward()
+        out[f"covb_dL_dscale_mod{mod}"] = s_t.grad.numpy()
+        out[f"covb_dL_drot_mod{mod}"] = q_t.grad.numpy()              # (build_rotation normalises q inside: the tangential part of dL/dq)
     out.update(loss_image=image, loss_depth=depth, loss_opacity=opacity, loss_gt=gt, loss_gt_depth=gt_depth,
                loss_grad_mask=grad_mask, loss_exposure=np.array([0.05, -0.02], np.float32))
     np.savez_compressed(OUT, **out)
