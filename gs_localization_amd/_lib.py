@@ -4,7 +4,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsr_hip.so")
+LIB_PATH = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "libgsr_hip.so")      # (GSR_LIB_PATH: a diagnostic build, see build.py)
 
 RESIZE_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
@@ -110,11 +110,11 @@ class RefineArgs(C.Structure):
 
 
 # the GSR_ABI_VERSION these ctypes mirrors (SpecState, RefineArgs, the pose-state layout) were written for
-ABI_VERSION = 3
+ABI_VERSION = 4
 REFINE_NO_LEAN, REFINE_SH_SEPARATE, REFINE_NO_BALANCE, REFINE_LOG_REDO, REFINE_DETERMINISTIC = 1, 2, 4, 8, 16
 
 
-POSE_STATE_FLOATS = 96
+POSE_STATE_FLOATS = 112
 SIGNATURES.update({
     "gsr_tracking_loss": (_i, [_i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _f, _f, _i, _vp, _vp, _vp, _vp, _vp]),
     "gsr_pose_init": (_i, [_vp, _vp, _vp]),

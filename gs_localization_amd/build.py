@@ -7,7 +7,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "gsr_api.hip")
 DEPS = [SRC] + [os.path.join(_HERE, "csrc", f) for f in ("gsr_kernels.h", "gsr_device.h")] + [os.path.join(_ROOT, "include", "gsr.h")]
-OUT = os.path.join(_HERE, "libgsr_hip.so")
+# GSR_LIB_PATH: diagnostic builds (GSR_TIMING, GSR_DEFS=...) go to a path of their own and are loaded from there (_lib.py reads the
+# same variable), so that an experiment never leaves a non-default library where the tests and bench.py look for the product build.
+OUT = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "libgsr_hip.so")
 
 
 def hipcc():
@@ -28,6 +30,8 @@ def build(force=False, verbose=False):
            # instructions; building the register pairs costs more v_mov than the packed maths saves (K6 55 -> 50 us)
            "-fno-slp-vectorize",
            "-I" + os.path.join(_ROOT, "include"), "-o", OUT, SRC]
+    if (os.environ.get("GSR_TIMING") or os.environ.get("GSR_DEFS")) and not os.environ.get("GSR_LIB_PATH") and not os.environ.get("GSR_ALLOW_INPLACE_VARIANT"):
+        raise RuntimeError("a diagnostic build (GSR_TIMING / GSR_DEFS) must not overwrite the product library: set GSR_LIB_PATH=<other file>")
     if os.environ.get("GSR_TIMING"):      # diagnostic build: per-phase clocks inside the compositing kernels
         cmd.insert(1, "-DGSR_TIMING=1")
     if os.environ.get("GSR_DEFS"):        # experiments: extra -D switches, e.g. GSR_DEFS="-DGSR_K8_SPAN=384"

@@ -522,6 +522,30 @@ int allow_large_lds(int dev)
     return GSR_OK;
 }
 
+// The deterministic option widens K7's accumulator records from 48 to 192 bytes per Gaussian, and it is the FORWARD that sizes the
+// geometry workspace.  A backward that asks for the option on a workspace whose forward ran without it would write 144 P bytes past
+// the end.  The stateless forwards therefore note (workspace address -> sized for the option?) in a small process-wide
+// table and the backward refuses the mismatch; a workspace the table no longer knows (256 forwards ago) is taken at the caller's word.
+struct DetNote { const void* geom; bool det; };
+std::mutex g_det_mu;
+DetNote g_det_notes[256];
+unsigned g_det_next = 0;
+void note_geometry(const void* geom, bool det)
+{
+    if (!geom) return;
+    std::lock_guard<std::mutex> lk(g_det_mu);
+    for (DetNote& n : g_det_notes)
+        if (n.geom == geom) { n.det = det; return; }
+    g_det_notes[g_det_next++ & 255u] = DetNote{geom, det};
+}
+int geometry_sized_for_det(const void* geom)          // 1 / 0, -1 = unknown
+{
+    std::lock_guard<std::mutex> lk(g_det_mu);
+    for (const DetNote& n : g_det_notes)
+        if (n.geom == geom) return n.det ? 1 : 0;
+    return -1;
+}
+
 #define GSR_FWD_PARAMS gsr_resize_fn geometry_buffer, void* geometry_ctx, gsr_resize_fn binning_buffer, void* binning_ctx,                 \
                        gsr_resize_fn image_buffer, void* image_ctx, int P, int D, int M, const float* background, int width, int height,    \
                        const float* means3D, const float* shs, const float* colors_precomp, const float* opacities, const float* scales,    \
@@ -584,6 +608,7 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     char* gptr = (char*)geometry_buffer(geometry_ctx, gbytes);
     if (!gptr) return fail(GSR_E_ALLOC, "geometry buffer callback returned NULL%s", "");
     carve_geom(gptr, P, g);
+    if (!cx.native_loop) note_geometry(gptr, cx.det);      // (gsr_backward checks it: see geometry_sized_for_det)
     Img im;
     const size_t ibytes = carve_img(nullptr, width, height, im);
     char* iptr = (char*)image_buffer(image_ctx, ibytes);
@@ -1047,7 +1072,14 @@ int gsr_forward_speculative(gsr_spec_state* s, GSR_FWD_PARAMS)
     return R;
 }
 
-int gsr_backward(GSR_BWD_PARAMS) { const PassCtx cx = dropin_ctx(debug); return backward_impl(cx, GSR_BWD_PASS); }
+int gsr_backward(GSR_BWD_PARAMS)
+{
+    const PassCtx cx = dropin_ctx(debug);
+    if (cx.det && geometry_sized_for_det(geom_buffer) == 0)
+        return fail(GSR_E_INVALID, "gsr_backward: debug bit 2 (deterministic sums) needs a geometry workspace whose FORWARD ran with the same bit "
+                                   "(it sizes the 64-bit accumulator records: gsr_geometry_bytes_det)%s", "");
+    return backward_impl(cx, GSR_BWD_PASS);
+}
 
 // one struct pointer across the foreign-function boundary instead of 34 / 40 arguments (include/gsr.h)
 int gsr_forward_packed(const gsr_forward_args* a)

@@ -1650,6 +1650,58 @@ struct FusedLoss {
 };
 __device__ __forceinline__ float sgnf(float d) { return (d > 0.f) ? 1.f : ((d < 0.f) ? -1.f : 0.f); }
 
+// ---------------------------------------------------------------------------------------------
+// Heavy tiles split across workgroups (round 5; native loop, speculative lists).
+// A tile is one workgroup and a pixel's compositing is a dependent chain: on a structured scene (a dense object, a wall seen at a
+// grazing angle) a handful of tiles need lists ten times the mean, ONE of their four waves walks them while the other three wait
+// at the batch barriers, and both compositing kernels last as long as that wave (S-room-640: K6 576 us, K7 676 us for work that
+// would take ~100 us spread evenly; phase clocks in profiles/r05_phase_clocks.md).  Such a tile is cut into `nseg` DEPTH RANGES,
+// one workgroup ("segment") each:
+//   * every segment derives the same nseg - 1 depth pivots from the same 1 024-key sample of the tile's bin (same arithmetic on
+//     the same data: no communication), gathers the keys of its own range, orders them (<= 2 048) and stages their records;
+//   * pass A walks them for the per-pixel product Tl of (1 - alpha) over the valid entries only -- no colours, no termination --
+//     and publishes it; a segment then multiplies its predecessors' products in segment order into Ts, its pixels' transmittance
+//     at its first entry; pass C is the normal walk started at Ts.  Transmittance is carried as Ts x Tl (Tl restarts at 1 in every
+//     segment) and a pixel terminates where Ts x Tl x (1 - alpha) < 1e-4: by monotonicity that is the case somewhere in segment s
+//     exactly if Ts(s + 1) < 1e-4, so every later segment knows a pixel is finished from the products alone;
+//   * a segment leaves a record per pixel (Ts, signed end transmittance, its colour / depth sums, last contributor, depth
+//     needed) and its ordered index list at its place in the tile's list; the segment that finishes LAST (a ticket per tile)
+//     adds the records up in segment order and runs the normal epilogue (images, fused loss, depth bounds, verification);
+//   * k_render_bwd_mfma walks the segments in parallel too: segment s starts behind its last entry with T = Ts(s + 1) and the
+//     "composited behind me" value (sum of the later segments' colour sums . dL/dpixel) / Ts(s + 1).
+// Against the unsplit walk the results differ by rounding only (T as a product of per-segment products instead of one running
+// product): the deterministic option therefore never splits, and parity against the oracle is tested with splitting live
+// (tests/test_gpu_split.py).  A block of the launch is (tile, segment, nseg) from `list`; which tiles are split how far is decided
+// on the device from the work the previous iteration's forward measured (seg_list_build).
+// Waiting is only ever for LOWER-numbered blocks of the same launch (a tile's segments sit in consecutive blocks, ascending), which
+// the dispatcher has started earlier: no deadlock as long as workgroups are started in block order; every wait is bounded anyway.
+// ---------------------------------------------------------------------------------------------
+#define GSR_SEG_REC_Q 10           // floats per pixel and segment: Tl, Ts, end T (signed), r, g, b, depth sums, last contributor, depth needed, work
+#define GSR_SEG_MAX 32             // segments per tile at most
+#define GSR_SEG_SHARE_MAX 1365     // a tile is only split while (its keys / nseg) stays below this: a range must fit the in-LDS sort (2 048) with room for sampling noise
+struct SegCtl {
+    const uint32_t* list;          // per block: tile | segment << 16 | nseg << 24; ~0: nothing to do.  nullptr: no splitting, blockIdx -> tile as before
+    uint32_t* cnt;                 // per block: (epoch << 16) | keys of the segment + 1 (low half 0: its tile was not split after all)
+    uint32_t* pub;                 // per block: (epoch << 2) | 1 once the segment's Tl are out
+    float* rec;                    // per block: GSR_SEG_REC_Q x 256 floats
+    uint32_t* ticket;              // per tile: [2 t] segments that have read the bin's cursor, [2 t + 1] segments that have finished
+    uint32_t* nosplit;             // per tile: forwards this tile still goes unsplit (a range once exceeded the in-LDS sort)
+    uint32_t epoch;                // tag of this launch's group (flags of earlier launches never match)
+};
+__device__ __forceinline__ void seg_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float seg_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void seg_store_u(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t seg_load_u(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// waits (bounded) until *p == want; false: gave up
+__device__ __forceinline__ bool seg_wait(const uint32_t* p, uint32_t want)
+{
+    for (uint32_t spins = 0; spins < (1u << 21); spins++) {
+        if (seg_load_u(p) == want) return true;
+        __builtin_amdgcn_s_sleep(8);
+    }
+    return false;
+}
+
 // Record layout: what the walk reads per list entry is a (16 B), the first half of b (8 B) and c (16 B), and the fields sit
 // where the packed fp32 instructions want their operand PAIRS: (x, y) - (px, py), (B2, C2) * dy, (r, g) * w, (b, depth) * w are
 // one v_pk_* each -- same IEEE operations, two per issue slot.
@@ -1926,7 +1978,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                                                           float margin_mul, float margin_add, float* __restrict__ zbc_next,
                                                           int sbx, FusedLoss fl, const uint32_t* __restrict__ tile_order,
                                                           uint32_t* __restrict__ tile_work, int bin_cap, LazySH lz, uint32_t fail_tag,
-                                                          uint32_t* __restrict__ tile_total, int pack_qm, uint32_t* __restrict__ tile_hold)
+                                                          uint32_t* __restrict__ tile_total, int pack_qm, uint32_t* __restrict__ tile_hold, SegCtl sg)
 {
     // (tile_hold, nullable, native loop: per tile, for how many more forwards it goes without a depth bound after it failed a
     // verification -- see where the bounds are recorded)
@@ -1943,7 +1995,14 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     __shared__ unsigned long long s_keys[LIST != GSR_LIST_SORTED ? GSR_LSORT_CAP : 1];
     GSR_T_DECL
     // (tile_order: the native loop's work-balanced launch order, see tile_order_from_work; otherwise XCD-contiguous runs of tiles)
-    const int tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_remap(blockIdx.x, ntiles);
+    // (sg.list: this launch's blocks are (tile, segment) pairs, heaviest tiles first -- see SegCtl; nseg == 1: an ordinary tile)
+    int tile;
+    uint32_t seg = 0u, nseg = 1u;
+    if (LIST == GSR_LIST_BINS && sg.list != nullptr) {
+        const uint32_t e = sg.list[blockIdx.x];
+        if (e == 0xFFFFFFFFu) return;
+        tile = (int)(e & 0xFFFFu); seg = (e >> 16) & 0xFFu; nseg = e >> 24;
+    } else tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_remap(blockIdx.x, ntiles);
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int px = tx * GSR_TILE + (wv & 1) * 8 + (tid & 7), py = ty * GSR_TILE + (wv >> 1) * 8 + ((tid >> 3) & 7);
@@ -1965,8 +2024,16 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             const uint32_t slots = tile_cursor[tile * GSR_CURSOR_STRIDE];
             s_cursor[0] = slots;
             s_cursor[1] = (LIST == GSR_LIST_BINS_FULL && GSR_CURSOR64) ? tile_cursor[tile * GSR_CURSOR_STRIDE + 1] : slots;
-            tile_cursor[tile * GSR_CURSOR_STRIDE] = 0u;
-            if (LIST == GSR_LIST_BINS_FULL) tile_cursor[tile * GSR_CURSOR_STRIDE + 1] = 0u;
+            bool clear = true;
+            if (LIST == GSR_LIST_BINS && nseg > 1u) {          // a split tile: every segment reads the cursor, the last reader clears it
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                clear = atomicAdd(&sg.ticket[2 * tile], 1u) == nseg - 1u;
+                if (clear) sg.ticket[2 * tile] = 0u;
+            }
+            if (clear) {
+                tile_cursor[tile * GSR_CURSOR_STRIDE] = 0u;
+                if (LIST == GSR_LIST_BINS_FULL) tile_cursor[tile * GSR_CURSOR_STRIDE + 1] = 0u;
+            }
         }
         __syncthreads();
         range.x = (uint32_t)tile * (uint32_t)(bin_cap + GSR_BIN_PAD);
@@ -2727,7 +2794,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
 #define GSR_PS_VIEW 48
 #define GSR_PS_PROJ 64
 #define GSR_PS_CAMPOS 80
-#define GSR_PS_SIZE 96
+#define GSR_PS_PREV 96        // [96..104] R, [105..107] T, [108..109] exposure a, b as they were BEFORE the most recent pose step: the pose of the
+                              // last forward / backward that ran (round 5: lets a test hold the loop's maintained gradients against the oracle at that pose)
+#define GSR_PS_SIZE 112
 
 // view / proj / campos from (R, T): world_view_transform, full_proj_transform, camera_center of
 // gs_localization/pipelines/tools/camera_utils.py:144-158 without the two 4x4 inversions.  Everything is read into
@@ -2895,6 +2964,9 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
     if (run) {
         s.st[lane] = va;
         if (lane < GSR_PS_SIZE - 64) s.st[64 + lane] = vb;
+        // (the pose and exposure this group's forward and backward ran with: GSR_PS_PREV; a wave executes in order, no barrier needed)
+        if (lane < 12) s.st[GSR_PS_PREV + lane] = va;
+        if (lane == GSR_PS_PARAM + 6 || lane == GSR_PS_PARAM + 7) s.st[GSR_PS_PREV + 12 + lane - (GSR_PS_PARAM + 6)] = va;
         if (q.tau_acc != nullptr && det) {
             double sw[12];
 #pragma unroll

@@ -280,6 +280,10 @@ class FusedRefiner:
                 "fallbacks": int(stats[0]), "num_rendered": int(stats[1]), "lean_iters": int(stats[2]), "host_redos": int(stats[3]),
                 # (host copies of the final pose: no device read-back for the caller's error statistics)
                 "R_host": s[0:9].reshape(3, 3).copy(), "T_host": s[9:12].copy(),
+                # the pose and exposure the LAST forward / backward of the call ran with (the state before the final update; pose-state
+                # words 96..109): what `render` / `depth` / `opacity` below and the gradient tensors g_* belong to when max_iters was reached
+                "R_last_forward_host": s[96:105].reshape(3, 3).copy(), "T_last_forward_host": s[105:108].copy(),
+                "exposure_last_forward_host": s[108:110].copy(),
                 "render": self.color, "depth": self.depth, "opacity": self.alpha}
         self.last_info = {k: info[k] for k in ("fallbacks", "num_rendered", "lean_iters", "host_redos")}
         return viewpoint.R, viewpoint.T, info

@@ -34,7 +34,7 @@ extern "C" {
  * 2: gsr_refine_args gained `carry_state` (round 2) and the fields behind `stream` (flags, lean_min_P); stats_out is int[4];
  *    pose-state words 41 (ticket) and 84..87 (Adam beta products); gsr_debug_lean_check.  A caller must compare
  *    gsr_abi_version() with the GSR_ABI_VERSION it was compiled against before it passes any struct. */
-#define GSR_ABI_VERSION 3
+#define GSR_ABI_VERSION 4
 
 enum {
     GSR_OK = 0,
@@ -281,11 +281,13 @@ int gsr_tracking_loss(int width, int height, const float* image, const float* de
  *   [18] exposure_a [19] exposure_b [20..27] Adam exp_avg [28..35] Adam exp_avg_sq [36] Adam step
  *   [37] converged [38] last loss [39] |tau| [40] poison word of gsr_refine (uint32) [41] workgroup ticket of gsr_refine (uint32)
  *   [48..63] viewmatrix [64..79] projmatrix [80..82] campos [84..87] beta1^step, beta2^step as two doubles (Adam's bias corrections)
+ *   [96..104] R, [105..107] T, [108] exposure_a, [109] exposure_b BEFORE the most recent pose step, i.e. the pose the last executed
+ *   forward / backward ran with (GSR_ABI_VERSION 4; zeros until a step has run)
  * All zeros + R, T (+ exposure) is a valid initial state.
  * (viewmatrix/projmatrix/campos are what gsr_forward / gsr_backward take).
  * gsr_pose_init fills [48..82] from R, T and projmatrix_raw (16 floats, P^T row-major), replacing
  * Camera.world_view_transform / full_proj_transform / camera_center (tools/camera_utils.py:144-158). */
-#define GSR_POSE_STATE_FLOATS 96
+#define GSR_POSE_STATE_FLOATS 112
 int gsr_pose_init(float* pose_state, const float* projmatrix_raw, void* stream);
 
 /* One optimiser step + update_pose on the device.  Replaces torch.optim.Adam.step() over the four

@@ -222,6 +222,34 @@ def test_dropin_backward_is_reproducible(monkeypatch):
         assert U.rel_l1(a[k].cpu().numpy(), default[k].cpu().numpy()) <= 2e-5, (k, U.rel_l1(a[k].cpu().numpy(), default[k].cpu().numpy()))
 
 
+def test_backward_refuses_the_option_on_a_workspace_its_forward_did_not_size_for_it(monkeypatch):
+    """The deterministic option's accumulator records are four times the default ones and the FORWARD sizes the geometry workspace:
+    a backward with debug bit 2 behind a forward without it must be refused (GSR_E_INVALID), not write 144 P bytes past the buffer."""
+    from gs_localization_amd import rasterizer as RZ
+    sc = S.small(P=4000, W=96, H=64, sh_degree=1, seed=5, scale_med=0.05)
+    cam = U.scene_inputs(sc, np.eye(4))
+    t = lambda a: torch.tensor(np.asarray(a, np.float32), device=DEV)
+    rs = RZ.GaussianRasterizationSettingsPose(image_height=sc.H, image_width=sc.W, tanfovx=sc.tanfovx, tanfovy=sc.tanfovy, bg=t(sc.bg), scale_modifier=1.0,
+                                              viewmatrix=t(cam["view"]), projmatrix=t(cam["proj"]), projmatrix_raw=t(cam["proj_raw"]), sh_degree=1,
+                                              campos=t(cam["campos"]), prefiltered=False, debug=False)
+    e = torch.Tensor([]).to(DEV)
+    monkeypatch.delenv("GSR_DETERMINISTIC", raising=False)
+    R, color, radii, depth, alpha, nt, saved, consts = RZ._forward_impl(t(sc.means3D), t(sc.shs), e, t(sc.opacities), t(sc.scales), t(sc.rotations), e, rs, True)
+    assert consts[4] is False
+    need = dict(sh=True, scales=True, rotations=True)
+    gi, gd, ga = torch.ones_like(color), torch.ones_like(depth), torch.zeros_like(alpha)
+    with pytest.raises(RuntimeError, match="deterministic"):
+        RZ._backward_impl(rs, R, saved, consts[:4] + (True,), gi, gd, ga, True, need)
+    # ... and the pair that belongs together still works, in either mode
+    out = RZ._backward_impl(rs, R, saved, consts, gi, gd, ga, True, need)
+    assert torch.isfinite(out[8]).all()
+    monkeypatch.setenv("GSR_DETERMINISTIC", "1")
+    R2, color2, _, depth2, alpha2, _, saved2, consts2 = RZ._forward_impl(t(sc.means3D), t(sc.shs), e, t(sc.opacities), t(sc.scales), t(sc.rotations), e, rs, True)
+    assert consts2[4] is True
+    out2 = RZ._backward_impl(rs, R2, saved2, consts2, gi, gd, ga, True, need)
+    assert U.rel_l1(out2[8].cpu().numpy(), out[8].cpu().numpy()) <= 1e-5
+
+
 def test_deterministic_sums_have_the_range_for_large_splats_under_unit_pixel_gradients(monkeypatch):
     """Splats hundreds of pixels wide under white-noise pixel gradients of unit variance: the conic's per-tile moment sums reach 1e8 ...
     1e10 and cancel over the tiles (test_gpu_parity.py::test_large_images).  The first version of the option kept one 2^-40 word per

@@ -193,6 +193,90 @@ def test_native_loop_at_baseline_size(name):
     assert U.rel_l1(tau_got, tau_ref) <= 2e-4, U.rel_l1(tau_got, tau_ref)
 
 
+def _camera_of_the_pose_state(R, T, proj_raw):
+    """view / proj / campos exactly as pose_write_camera (gsr_kernels.h) builds them from fp32 R, T: same operations, same order, fp32."""
+    R, T, P = np.asarray(R, np.float32), np.asarray(T, np.float32), np.asarray(proj_raw, np.float32).reshape(4, 4)
+    view = np.zeros((4, 4), np.float32)
+    view[:3, :3] = R.T
+    view[3, :3] = T
+    view[3, 3] = 1.0
+    proj = np.zeros((4, 4), np.float32)
+    for i in range(4):
+        for j in range(4):
+            acc = np.float32(0.0)
+            for k in range(4):
+                acc = np.float32(acc + np.float32(view[i, k] * P[k, j]))
+            proj[i, j] = acc
+    campos = np.array([-np.float32(np.float32(np.float32(R[0, c] * T[0]) + np.float32(R[1, c] * T[1])) + np.float32(R[2, c] * T[2])) for c in range(3)], np.float32)
+    return view, proj, campos
+
+
+# (name -> scene; the structured variants of round 5 next to the BASELINE sizes)
+_DIRECT = dict(_FULL, **{"S-1M-640-object": S.s_1m_640_object, "S-1M-640-walls": S.s_1m_640_walls, "S-room-640": S.s_room_640})
+
+
+@pytest.mark.parametrize("name", list(_DIRECT))
+def test_headline_path_against_the_oracle_at_the_pose_of_its_last_forward(name):
+    """VERDICT r4, parity item 1: the path `value` is measured on -- gsr_refine with speculative lists, k_preprocess_lean, the fused
+    tracking loss and gradient tensors maintained row by row -- held against the CPU oracle DIRECTLY, at full size, not through the
+    drop-in backward.  The call leaves the pose and exposure its last forward / backward ran with in the pose state (words 96..109);
+    the oracle renders at exactly that camera (the fp32 matrices pose_write_camera builds) and back-propagates the pixel gradients
+    of the reference's tracking loss evaluated on the loop's own images.  Bars: images <= 1e-4 rel-L1, radii exact, every
+    Gaussian-parameter gradient <= 2e-5, dL/dtau <= 1e-5 -- and per ROW (U.row_errors), so that an aggregate cannot hide bad rows."""
+    import os
+    from oracle import oracle as O
+    from tests import replay as PL
+    O.set_threads(min(64, os.cpu_count() or 1))
+    sc = _DIRECT[name]()
+    model, bg, view, init = _setup(sc, seed=3)
+    cfg = PL.TRACKING_CONFIG
+    K = 12
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    vp = view()
+    gt_image, gt_depth = vp.original_image.clone(), vp.depth.clone()
+    run = _run(fr, vp, init, bg, K, flags=0)
+    info = run["info"]
+    assert info["iters"] == K and info["lean_iters"] >= 1, info
+    Rl, Tl, ex = info["R_last_forward_host"], info["T_last_forward_host"], info["exposure_last_forward_host"]
+    assert abs(np.linalg.det(Rl.astype(np.float64)) - 1) < 1e-5 and not np.allclose(Rl, info["R_host"], atol=0, rtol=0)
+    vm, pm, cp = _camera_of_the_pose_state(Rl, Tl, S.camera_matrices(sc)[2])
+    f = O.forward(sc.means3D, sc.opacities, vm, pm, cp, sc.W, sc.H, sc.tanfovx, sc.tanfovy, sc.bg, sh_degree=sc.sh_degree, shs=sc.shs,
+                  scales=sc.scales, rotations=sc.rotations, want_n_touched=True)
+    img, dep, opa = (run[k].cpu().numpy() for k in ("color", "depth", "alpha"))
+    assert np.array_equal(run["radii"].cpu().numpy(), f.radii), int((run["radii"].cpu().numpy() != f.radii).sum())
+    for k, a, b in (("color", img, f.color), ("depth", dep, f.depth), ("alpha", opa, f.alpha)):
+        assert U.rel_l1(a, b) <= 1e-4, (k, U.rel_l1(a, b))
+    # the reference's tracking loss (descent_utils.py:85-123, pinned by tests/test_pose_golden.py) on the LOOP's images, autograd
+    class _V:
+        pass
+    v = _V()
+    v.exposure_a = torch.tensor([float(ex[0])], device=DEV)
+    v.exposure_b = torch.tensor([float(ex[1])], device=DEV)
+    v.original_image, v.depth, v.grad_mask = gt_image, gt_depth, torch.ones((1, sc.H, sc.W), dtype=torch.bool, device=DEV)
+    ti, td = run["color"].clone().requires_grad_(True), run["depth"].clone().requires_grad_(True)
+    PL.tracking_loss(cfg, ti, td, run["alpha"], v).backward()
+    gi, gd = ti.grad.cpu().numpy(), td.grad.cpu().numpy()
+    # ... which is what the compositing kernel's fused epilogue handed the backward
+    assert U.rel_l1(fr.g_img.cpu().numpy(), gi) <= 1e-6 and U.rel_l1(fr.g_depth.cpu().numpy(), gd) <= 1e-6
+    go = O.backward(f, gi, gd, np.zeros((1, sc.H, sc.W), np.float32), pose_mode=True)
+    assert U.rel_l1(fr.g_tau.cpu().numpy(), go["tau"]) <= 1e-5, U.rel_l1(fr.g_tau.cpu().numpy(), go["tau"])
+    report = {}
+    for k, ok in (("m3d", "means3D"), ("sh", "sh"), ("opac", "opacities"), ("scale", "scales"), ("rot", "rotations")):
+        a, b = getattr(fr, "g_" + k).cpu().numpy(), go[ok]
+        e = U.rel_l1(a.reshape(b.shape), b)
+        worst, share, at = U.row_errors(a.reshape(b.shape), b)
+        report[k] = (e, worst, share, at)
+    print(name, {k: ("%.2e" % v[0], "worst row %.3f" % v[1], "rows > 1e-3: %.2e" % v[2]) for k, v in report.items()})
+    for k, (e, worst, share, at) in report.items():
+        assert e <= 2e-5, (k, e)
+        # per row: a threshold flip (alpha within an ulp of 1/255, T of 1e-4: v_exp_f32 against expf) moves one pixel of one splat --
+        # per-cent level on a splat that covers a handful of pixels, never more; and it happens to a few rows in ten thousand
+        assert worst <= ROW_WORST and share <= ROW_SHARE, (k, worst, share, at)
+
+
+ROW_WORST, ROW_SHARE = 0.1, 2e-4      # (measured on the six scenes, round 5: worst row <= 0.035, share of rows above 1e-3 <= 2.5e-5)
+
+
 def _adversarial(kind):
     """(scene, scale_modifier) whose true screen-space extents differ from what max(scale) of a unit-quaternion Gaussian
     suggests"""

@@ -1,9 +1,10 @@
 #!/bin/bash
+# (variant builds go to GSR_LIB_PATH and are loaded from there: the product library is never overwritten -- build.py, _lib.py)
 # usage: tools/dbg/ab_so.sh build_ab/base.so build_ab/pk.so ...  -- same-box A/B of prebuilt libraries: bench value / single-frame
 # loop and the native loop's kernel times, alternating twice
 for rep in 1 2; do
 for v in "$@"; do
-  cp "$v" gs_localization_amd/libgsr_hip.so; touch gs_localization_amd/libgsr_hip.so
+  export GSR_LIB_PATH="$v"
   echo "variant [$v] rep $rep"
   timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train-leg --repeats 3 2>/dev/null | python -c "
 import sys, json

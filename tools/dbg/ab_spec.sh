@@ -1,10 +1,11 @@
 #!/bin/bash
+# (variant builds go to GSR_LIB_PATH and are loaded from there: the product library is never overwritten -- build.py, _lib.py)
 # usage (GPU box): tools/dbg/ab_spec.sh "<defs A>" "<defs B>" ...  -- same-box A/B of builds (GSR_DEFS) on the speculative loop:
 # wall time per iteration and per-kernel HIP-event times (tools/loop_profile.py); each variant twice, interleaved
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
 for v in "$@"; do
-  GSR_DEFS="$v" python gs_localization_amd/build.py > /dev/null 2>&1
+  export GSR_LIB_PATH=/tmp/gsr_variant.so; GSR_DEFS="$v" python gs_localization_amd/build.py > /dev/null 2>&1
   echo "variant [$v] rep $rep"
   timeout 300 python tools/loop_profile.py 2>&1 | grep -v amdgpu.ids | grep "spec True" | tail -1 | grep -o "wall ms/iter [0-9.]*\|'preprocess_fwd': [0-9.]*\|'render_fwd': [0-9.]*\|'render_bwd': [0-9.]*\|'preprocess_bwd': [0-9.]*" | paste - - - - -
 done

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (variant builds go to GSR_LIB_PATH and are loaded from there: the product library is never overwritten -- build.py, _lib.py)
 # usage (GPU box, via gpurun): tools/dbg/gpu_session.sh <step> [...]  -- the round's GPU sessions, one named step per call;
 # everything lands in gpurun_out/r04/<step>*.log
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
@@ -25,14 +26,14 @@ case $step in
     for sc in s_1m_640 s_3m_cam s_3m_cam_1024; do SCENE=$sc LOOP_PLAIN=1 python tools/loop_only.py 100 2>/dev/null | tail -1; done > $o/plain$1.log
     python tools/dbg/train_kernels.py 2>/dev/null | tail -2 >> $o/plain$1.log ;;
   timing)        # phase clocks of the complete-list path (diagnostic build; the box is thrown away afterwards)
-    GSR_TIMING=1 python gs_localization_amd/build.py > /dev/null 2>&1
+    export GSR_LIB_PATH=/tmp/gsr_timing.so; GSR_TIMING=1 python gs_localization_amd/build.py > /dev/null 2>&1
     for sc in ${@:-s_1m_640 s_3m_cam}; do echo "== $sc plain"; SCENE=$sc LOOP_PLAIN=1 python tools/phase_timing.py 2>/dev/null | grep -v amdgpu; done > $o/timing_plain.log
-    python gs_localization_amd/build.py > /dev/null 2>&1 ;;
+    unset GSR_LIB_PATH ;;
   tail)          # the slowest waves of k_render_fwd on complete lists, by phase (diagnostic build)
-    GSR_TIMING=1 GSR_DEFS="-DGSR_TIMING_ORDER $TAILDEFS" python gs_localization_amd/build.py > $o/tail_build.log 2>&1
+    export GSR_LIB_PATH=/tmp/gsr_timing.so; GSR_TIMING=1 GSR_DEFS="-DGSR_TIMING_ORDER $TAILDEFS" python gs_localization_amd/build.py > $o/tail_build.log 2>&1
     for sc in ${@:-s_1m_640}; do echo "== $sc"; SCENE=$sc LOOP_PLAIN=1 python tools/dbg/tail_rows.py; done > $o/tail.log 2>&1 ;;
   timing_spec)   # phase clocks of the speculative loop (diagnostic build)
-    GSR_TIMING=1 python gs_localization_amd/build.py > /dev/null 2>&1
+    export GSR_LIB_PATH=/tmp/gsr_timing.so; GSR_TIMING=1 python gs_localization_amd/build.py > /dev/null 2>&1
     for sc in ${@:-s_1m_640}; do echo "== $sc speculative"; SCENE=$sc python tools/phase_timing.py 2>/dev/null | grep -v amdgpu; done > $o/timing_spec.log ;;
   fuzz)          # randomised campaigns: per-pixel parity against the oracle, speculation bit for bit under the deterministic option
     CASES=${1:-300} SEED=${2:-4001} timeout 2400 python tools/fuzz_parity.py 2>&1 | grep -v amdgpu | tail -6 > $o/fuzz_parity.log
