@@ -111,7 +111,7 @@ class RefineArgs(C.Structure):
 
 # the GSR_ABI_VERSION these ctypes mirrors (SpecState, RefineArgs, the pose-state layout) were written for
 ABI_VERSION = 4
-REFINE_NO_LEAN, REFINE_SH_SEPARATE, REFINE_NO_BALANCE, REFINE_LOG_REDO, REFINE_DETERMINISTIC = 1, 2, 4, 8, 16
+REFINE_NO_LEAN, REFINE_SH_SEPARATE, REFINE_NO_BALANCE, REFINE_LOG_REDO, REFINE_DETERMINISTIC, REFINE_NO_SPLIT, REFINE_NO_DILATE = 1, 2, 4, 8, 16, 32, 64
 
 
 POSE_STATE_FLOATS = 112
@@ -123,6 +123,7 @@ SIGNATURES.update({
     "gsr_forward_packed": (_i, [C.POINTER(ForwardArgs)]),
     "gsr_backward_packed": (_i, [C.POINTER(BackwardArgs)]),
     "gsr_debug_lean_check": (_i, [C.POINTER(RefineArgs), C.POINTER(C.c_longlong)]),
+    "gsr_debug_seg_stats": (_i, [C.POINTER(RefineArgs), C.POINTER(C.c_longlong)]),
     "gsr_debug_lam_offset": (C.c_size_t, [_i]),
 })
 

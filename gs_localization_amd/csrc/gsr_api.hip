@@ -151,8 +151,14 @@ struct Img {
     float* loss_shards;                                   // native loop: GSR_LOSS_SHARDS x 16 floats (fused tracking loss)
     uint32_t* tile_work[2]; uint32_t* tile_order[2];      // native loop: per-tile work of the last forward [0] / backward [1] compositing -> their launch orders
     uint32_t* tile_hold;                                  // native loop: forwards a tile still goes without a depth bound after a failed verification
+    // native loop, heavy tiles split across workgroups (gsr::SegCtl): launch list, per-block words and records, per-tile tickets
+    uint32_t* seg_list[2]; uint32_t* seg_cnt; uint32_t* seg_pub; uint32_t* seg_ticket; uint32_t* seg_nosplit; uint32_t* seg_len; float* seg_rec; int seg_budget;
 };
-size_t carve_img(char* base, int W, int H, Img& im)
+// Blocks the compositing kernels are launched with when tiles may be split: every tile once + room for the heavy ones' extra segments
+constexpr int kSegMaxTiles = 4096;
+int seg_budget_of(int ntiles) { return ntiles <= kSegMaxTiles ? 2 * ntiles : 0; }      // (every block without work costs the launch a little: S-1M-640, no tile split, 3 x: +1.3 us per kernel)
+// (seg: with the split-tile arrays -- at the END, so that everything else has the same place either way; only gsr_refine asks for them)
+size_t carve_img(char* base, int W, int H, Img& im, bool seg = false)
 {
     Carver c(base);
     const int gx = (W + GSR_TILE - 1) / GSR_TILE, gy = (H + GSR_TILE - 1) / GSR_TILE;
@@ -182,6 +188,18 @@ size_t carve_img(char* base, int W, int H, Img& im)
     im.tile_work[0] = c.take<uint32_t>(nt); im.tile_work[1] = c.take<uint32_t>(nt);      // (contiguous: one memset)
     im.tile_order[0] = c.take<uint32_t>(nt); im.tile_order[1] = c.take<uint32_t>(nt);
     im.tile_hold = c.take<uint32_t>(nt);
+    im.seg_budget = seg ? seg_budget_of((int)nt) : 0;
+    im.seg_list[0] = im.seg_list[1] = im.seg_cnt = im.seg_pub = im.seg_ticket = im.seg_nosplit = im.seg_len = nullptr; im.seg_rec = nullptr;
+    if (im.seg_budget > 0) {
+        im.seg_list[0] = c.take<uint32_t>((size_t)im.seg_budget);      // (a launch walks one list while its extra workgroup builds the other)
+        im.seg_list[1] = c.take<uint32_t>((size_t)im.seg_budget);
+        im.seg_cnt = c.take<uint32_t>((size_t)im.seg_budget);          // cnt | pub | ticket | nosplit are contiguous: one clear
+        im.seg_pub = c.take<uint32_t>((size_t)im.seg_budget);
+        im.seg_ticket = c.take<uint32_t>(2 * nt);
+        im.seg_nosplit = c.take<uint32_t>(nt);
+        im.seg_len = c.take<uint32_t>(nt);
+        im.seg_rec = c.take<float>((size_t)im.seg_budget * GSR_SEG_REC_Q * GSR_BLOCK);
+    }
     return c.size();
 }
 
@@ -246,6 +264,10 @@ struct PassCtx {
     bool exact_bins = false;       // complete lists through count -> scan -> emit (after a bin of k_preprocess_bin overflowed; diagnostics)
     bool* used_full_bins = nullptr;   // out: this forward binned its complete lists into fixed-capacity bins (k_preprocess_bin)
     bool det = false;              // deterministic option (GSR_REFINE_DETERMINISTIC / debug bit 2 of the backward): integer sums across workgroups
+    bool seg = false;              // native loop: the image workspace has the split-tile arrays (gsr::SegCtl) and speculative forwards may use them
+    bool* seg_used = nullptr;      // out (forward) / in (backward): this group's compositing kernels run the split-tile launch list
+    bool seg_ready = false;        // the previous group's backward built a launch list for this one (list[spec.parity ^ 1])
+    uint32_t hold_after = 2u;      // native loop: failed verifications of a tile before it is left with its complete list for a while (k_render_fwd, tile_hold)
 };
 // gsr_forward_speculative: bounds, flags, cursors and the unsorted bins live in the caller's persistent state buffer
 // instead of the per-call image / binning buffers (which then only hold what the backward reads)
@@ -610,10 +632,10 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     carve_geom(gptr, P, g);
     if (!cx.native_loop) note_geometry(gptr, cx.det);      // (gsr_backward checks it: see geometry_sized_for_det)
     Img im;
-    const size_t ibytes = carve_img(nullptr, width, height, im);
+    const size_t ibytes = carve_img(nullptr, width, height, im, cx.seg);
     char* iptr = (char*)image_buffer(image_ctx, ibytes);
     if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
-    carve_img(iptr, width, height, im);
+    carve_img(iptr, width, height, im, cx.seg);
     unsigned long long* state_bins = nullptr;
     if (sp.state) carve_spec(sp.state, width, height, im, &state_bins);
 
@@ -680,6 +702,14 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
         if (state_bins) { bl.vals = reinterpret_cast<uint32_t*>(lptr); bl.bins = state_bins; }
         else carve_bin_local(lptr, ntiles, bin_cap, bl);
     }
+    // Heavy tiles split across workgroups (gsr::SegCtl): the speculative iterations of the native loop, on the launch list the previous
+    // group's backward built from the work its forward measured.
+    const bool use_seg = cx.seg && cx.seg_ready && by_tile && balanced && im.seg_budget > 0 && !sp.state && cx.guard.poison != nullptr;
+    if (cx.seg_used) *cx.seg_used = use_seg;
+    gsr::SegCtl sg = {};
+    if (use_seg) sg = gsr::SegCtl{im.seg_list[sp.parity ^ 1], im.seg_cnt, im.seg_pub, im.seg_rec, im.seg_ticket, im.seg_nosplit, cx.guard.tag, im.seg_len};
+    else if (cx.seg && balanced && im.seg_budget > 0) sg.len = im.seg_len;      // (every forward of the loop reports how much of each tile's list it ordered)
+    sg.hold_after = cx.hold_after;
     pa.tile_cursor = (by_tile || full_bins) ? im.tile_cursor : nullptr;
     pa.bins = bl.bins;
     pa.tile_count = (by_tile || full_bins) ? nullptr : im.tile_count;
@@ -819,10 +849,10 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
                      sp.mul, sp.add, zbc_next, im.sbx, cx.floss, (const uint32_t*)pa.tile_order[0], (balanced || stateless_balance) ? im.tile_work[0] : (uint32_t*)nullptr, bin_cap, \
                      LazySH{pa.lazy_sh ? shs : nullptr, means3D, cam_pos, D, M, g.clamped, g.rec}, (cx.guard.poison ? cx.guard.tag << 2 : 0u), \
                      full_bins ? im.tile_count : (uint32_t*)nullptr, (P < (1 << 28)) ? 1 : 0, \
-                     (cx.native_loop && !sp.state && sp.mode != 0) ? im.tile_hold : (uint32_t*)nullptr
+                     (cx.native_loop && !sp.state && sp.mode != 0) ? im.tile_hold : (uint32_t*)nullptr, sg
         if (by_tile) {
-            if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
-            else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+            if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS>), dim3(use_seg ? im.seg_budget : ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+            else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS>), dim3(use_seg ? im.seg_budget : ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
         } else if (full_bins) {
             if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS_FULL>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
             else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS_FULL>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
@@ -895,7 +925,7 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     Geom g; carve_geom(geom_buffer, P, g);
     // (the ordered index lists sit at the start of the binning buffer on both binning paths; ranges[] says where)
     const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer);
-    Img im; carve_img(img_buffer, width, height, im);
+    Img im; carve_img(img_buffer, width, height, im, cx.seg);
 
     // Gradient tensors are zero-filled on the side stream while K7 runs; K8/K9 then only writes non-zero rows.
     // (the native loop zero-fills once per frame and keeps the tensors consistent through the dirty bits)
@@ -964,8 +994,17 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         const uint32_t* order = balanced ? im.tile_order[1] : nullptr;
         uint32_t* work = balanced ? im.tile_work[1] : nullptr;
         if (stateless_balanced(cx, ntiles)) order = im.tile_order[1];      // heaviest tiles first, by what this call's forward measured (k_backward_prologue)
-        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag);
-        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag);
+        // (the forward of this group split its heavy tiles: the same launch list, the same blocks -- gsr::SegCtl)
+        const bool use_seg = cx.seg && cx.seg_used && *cx.seg_used && im.seg_budget > 0;
+        const gsr::SegCtl sg = use_seg ? gsr::SegCtl{im.seg_list[cx.spec.parity ^ 1], im.seg_cnt, im.seg_pub, im.seg_rec, im.seg_ticket, im.seg_nosplit, cx.guard.tag, im.seg_len} : gsr::SegCtl{};
+        const int kgrid = use_seg ? im.seg_budget : ntiles;
+        // (... and one more workgroup builds the next group's list from the work this group's forward measured; the forward's order array is
+        // its scratch: the next forward either runs the list or has the preprocess kernel compute its order afresh)
+        const bool build = cx.seg && im.seg_budget > 0 && cx.native_loop && balanced;
+        const gsr::SegBuild sb = build ? gsr::SegBuild{im.tile_work[0], im.tile_order[0], im.seg_list[cx.spec.parity], im.seg_nosplit, ntiles, im.seg_budget, kgrid, im.seg_len,
+                                                        (cx.spec.mode != 0 && !cx.spec.state && !(cx.flags & GSR_REFINE_NO_DILATE)) ? im.zb[cx.spec.parity] : (float*)nullptr, im.zbc[cx.spec.parity], gx, gy, im.sbx} : gsr::SegBuild{};
+        if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(kgrid + (build ? 1 : 0)), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag, sg, sb);
+        else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(kgrid + (build ? 1 : 0)), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag, sg, sb);
 #undef GSR_BWD_ARGS
     }
     LAUNCHCHK("k_render_bwd");
@@ -1256,6 +1295,12 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     cx.flags = a->flags;
     cx.det = (a->flags & GSR_REFINE_DETERMINISTIC) != 0;
     if (a->lean_min_P > 0) cx.lean_min_P = a->lean_min_P;
+    // heavy tiles split across workgroups (gsr::SegCtl): speculative loops, not under the deterministic option (a split tile's sums round
+    // differently from the unsplit walk's, and that option promises the same bits whatever the lists looked like)
+    cx.seg = a->speculative && !cx.det && !(a->flags & GSR_REFINE_NO_SPLIT) &&
+             seg_budget_of(((a->width + GSR_TILE - 1) / GSR_TILE) * ((a->height + GSR_TILE - 1) / GSR_TILE)) > 0;
+    bool seg_used = false, seg_built = false;
+    cx.seg_used = &seg_used;
     int n_lean = 0;
     cx.n_lean = &n_lean;
     // warm start: the previous call on this workspace left its last bounds in buffer warm_buf (0 / 1); iteration 0 must
@@ -1305,9 +1350,9 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         cx.rows = GradRows{a->dL_dmean2D, a->dL_dconic, a->dL_dopacity, a->dL_dcolor, a->dL_dmean3D, a->dL_dcov3D, a->dL_dsh, a->dL_dscale, a->dL_drot, a->M};
         // image workspace: flags, cursors and both bound buffers start from zero; afterwards the kernels keep them so
         Img im0;
-        char* iptr = (char*)cached_resize(&ib, carve_img(nullptr, a->width, a->height, im0));
+        char* iptr = (char*)cached_resize(&ib, carve_img(nullptr, a->width, a->height, im0, cx.seg));
         if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
-        carve_img(iptr, a->width, a->height, im0);
+        carve_img(iptr, a->width, a->height, im0, cx.seg);
         if (!(carried & 1)) HIPCHK(hipMemsetAsync(a->dL_dalpha, 0, (size_t)a->width * a->height * sizeof(float), st));      // no gradient flows into opacity; nothing writes it afterwards
         {   // the small arrays, one launch (k_refine_init)
             ClearRanges cr = {};
@@ -1323,8 +1368,13 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             if (warm_buf != 0) add(im0.zbc[0], (size_t)im0.nsb);
             if (warm_buf != 1) add(im0.zbc[1], (size_t)im0.nsb);
             add(a->loss_out, 4);
-            add(im0.tile_hold, (size_t)(im0.tile_work[1] - im0.tile_work[0]));
-            static_assert(sizeof(cr.p) / sizeof(cr.p[0]) >= 10, "ClearRanges too small");
+            // (a warm-started call keeps what the previous frame learned about its tiles: one that sits on the edge of saturation -- an
+            // object's silhouette in front of a wall two metres behind -- fails a verification once and is then binned completely for a
+            // while; S-room-640 has dozens of them, and every call used to find them again, one failed forward each)
+            if (warm_buf < 0) add(im0.tile_hold, (size_t)(im0.tile_work[1] - im0.tile_work[0]));
+            // (split tiles: the per-block count / publication words, the per-tile tickets and hold counters -- carved back to back)
+            if (im0.seg_budget > 0) add(im0.seg_cnt, (size_t)(reinterpret_cast<uint32_t*>(im0.seg_rec) - im0.seg_cnt));
+            static_assert(sizeof(cr.p) / sizeof(cr.p[0]) >= 11, "ClearRanges too small");
             hipLaunchKernelGGL(k_refine_init, dim3(32 + (pl.st != nullptr ? 1 : 0)), dim3(GSR_BLOCK), 0, st, cr, pl);
             { const int debug = 0; LAUNCHCHK("k_refine_init"); }
         }
@@ -1373,9 +1423,15 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         cx.guard.tag = (uint32_t)(g + 1);
         cx.cov_cache = cov_cached ? 2 : 1;
         cov_cached = true;
+        cx.seg_ready = seg_built;      // (the group enqueued before this one left a launch list for it)
+#ifndef GSR_HOLD_AFTER
+#define GSR_HOLD_AFTER 1u
+#endif
+        cx.hold_after = (g == 0 && warm_buf >= 0) ? 2u : GSR_HOLD_AFTER;
+        seg_built = cx.seg && cx.balance;
         const bool maybe_last = (logical == a->max_iters - 1);
         cx.lean = (mode == 1) && !maybe_last;
-        Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv);
+        Img imv; carve_img((char*)ib.ptr, a->width, a->height, imv, cx.seg);
         imv_loop = imv;
         // Adam + update_pose run in the chain-rule kernel's last workgroup (no launch of their own); they also finish the fp64
         // dL/dtau reduction, clear the superblock bounds buffer the next group accumulates into and publish the status
@@ -1518,7 +1574,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
                            reinterpret_cast<uint32_t*>(bb.ptr), (const unsigned long long*)nullptr, (uint32_t*)nullptr, a->width,
                            a->height, gx, gx * gy, (const float*)g.rec, a->background, a->out_color, a->out_depth, a->out_alpha, im.n_contrib,
                            a->n_touched, (float*)nullptr, (const float*)nullptr, im.fail, 1.f, 0.f, (float*)nullptr,
-                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{}, 0u, (uint32_t*)nullptr, (a->P < (1 << 28)) ? 1 : 0, (uint32_t*)nullptr);
+                           im.sbx, FusedLoss{}, (const uint32_t*)nullptr, (uint32_t*)nullptr, 0, LazySH{}, 0u, (uint32_t*)nullptr, (a->P < (1 << 28)) ? 1 : 0, (uint32_t*)nullptr, SegCtl{});
         LAUNCHCHK("k_render_fwd (n_touched)");
     }
     // (with init_* the kernels have kept a mirror of the state in pinned memory -- the pose load of k_refine_init and every pose step that ran: no copy)
@@ -1573,6 +1629,36 @@ int gsr_debug_tile_order(const unsigned* work, unsigned* order, int ntiles, void
     hipLaunchKernelGGL(k_backward_prologue<false>, dim3(1), dim3(GSR_TILE_ORDER_THREADS), 0, st, SurvLists{nullptr, nullptr, 0u}, (float*)nullptr, (uint8_t*)nullptr, 0,
                        0, (const uint32_t*)work, (uint32_t*)order, ntiles);
     LAUNCHCHK("k_backward_prologue (order only)");
+    return 0;
+}
+
+int gsr_debug_seg_stats(const gsr_refine_args* a, long long out[4])
+{
+    using namespace gsr;
+    if (!a || !out) return fail(GSR_E_INVALID, "gsr_debug_seg_stats: NULL argument%s", "");
+    if (!a->image_buffer || !a->pose_state || a->width <= 0 || a->height <= 0) return fail(GSR_E_INVALID, "gsr_debug_seg_stats: a required pointer is NULL%s", "");
+    hipStream_t st = (hipStream_t)a->stream;
+    int rc = select_device_of(a->pose_state);
+    if (rc != GSR_OK) return rc;
+    Img im;
+    char* iptr = (char*)a->image_buffer(a->image_ctx, carve_img(nullptr, a->width, a->height, im, true));
+    if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
+    carve_img(iptr, a->width, a->height, im, true);
+    out[0] = out[1] = out[2] = 0; out[3] = im.seg_budget;
+    if (im.seg_budget <= 0) return 0;
+    // (the list the call's last speculative group walked: the one its predecessor built -- the parity the warm-state word remembers)
+    const int last_par = a->warm_state ? ((*a->warm_state & 0xFF) - 1) : -1;
+    if (last_par < 0 || last_par > 1) return fail(GSR_E_INVALID, "gsr_debug_seg_stats: needs the warm_state a speculative gsr_refine on these workspaces left%s", "");
+    std::vector<uint32_t> list((size_t)im.seg_budget);
+    HIPCHK(hipMemcpyAsync(list.data(), im.seg_list[last_par ^ 1], list.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint32_t e : list) {
+        if (e == 0xFFFFFFFFu) continue;
+        out[0]++;
+        const uint32_t sgi = (e >> 16) & 0xFFu, k = e >> 24;
+        if (k > 1u && sgi == 0u) out[1]++;
+        if ((long long)k > out[2]) out[2] = k;
+    }
     return 0;
 }
 

@@ -492,6 +492,93 @@ __device__ __forceinline__ void tile_order_block(const uint32_t* __restrict__ wo
     }
 }
 
+// Launch list of the compositing kernels when heavy tiles are split (SegCtl): the tiles in the work-balanced order computed just
+// before (order[]), each with nseg consecutive blocks.  A tile is split when the work its forward measured one iteration earlier
+// (the longest of its four waves' walks, in groups of eight entries, plus its ordering overhead) is more than twice L = max(mean
+// work, GSR_SEG_WORK_MIN): into ceil(work / L) segments -- the point is the launch's critical path, and splitting everything
+// would only add pass A to everybody's bill (a scene whose tiles are all equally heavy is left alone).  The blocks must fit the
+// launch (budget >= ntiles): L grows until they do.  One workgroup; the first GSR_BLOCK threads work.
+#define GSR_SEG_WORK_MIN 24u
+#define GSR_SEG_KEYS 192u          // keys per segment the launch list aims at
+#ifndef GSR_BWD_SEG_MERGE
+#define GSR_BWD_SEG_MERGE 1u       // forward segments per workgroup of the backward compositing kernel (measured, S-1M-640-object: 1 -> 93 us, 2 -> 106, 3 -> 129)
+#endif
+#define GSR_SEG_MAX 32             // segments per tile at most
+#define GSR_SEG_BUILD_MAX_TILES 4096      // (16 launch positions per thread, kept in registers)
+__device__ __forceinline__ void seg_list_build(const uint32_t* __restrict__ work, const uint32_t* __restrict__ order, uint32_t* __restrict__ list,
+                                               uint32_t* __restrict__ nosplit, int ntiles, int budget, const uint32_t* __restrict__ len)
+{
+    __shared__ uint32_t s_sum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const bool act = tid < GSR_BLOCK;
+    auto block_sum = [&](uint32_t v) -> uint32_t {          // every thread of the workgroup must call
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += (uint32_t)__shfl_xor((int)v, off, 64);
+        __syncthreads();
+        if (act && lane == 0) s_sum[wv] = v;
+        __syncthreads();
+        return s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3];
+    };
+    // launch positions are dealt to the threads in contiguous chunks (a prefix sum over the chunks gives every tile its first block);
+    // a thread's tiles, their work and hold counters are read once, all loads in flight together
+    constexpr int kPer = GSR_SEG_BUILD_MAX_TILES / GSR_BLOCK;
+    const int chunk = (ntiles + GSR_BLOCK - 1) / GSR_BLOCK;
+    const int p0 = min(tid * chunk, ntiles), np = act ? min(chunk, ntiles - p0) : 0;
+    uint32_t tl[kPer], wk[kPer], hold[kPer], ln[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; i++) tl[i] = (i < np) ? order[p0 + i] : 0u;
+#pragma unroll
+    for (int i = 0; i < kPer; i++) { wk[i] = (i < np) ? work[tl[i]] : 0u; hold[i] = (i < np) ? nosplit[tl[i]] : 0u; ln[i] = (i < np) ? len[tl[i]] : 0u; }
+    uint32_t mine = 0u;
+#pragma unroll
+    for (int i = 0; i < kPer; i++) mine += wk[i];
+    const uint32_t mean = block_sum(mine) / (uint32_t)max(ntiles, 1);
+    uint32_t L = max(mean, GSR_SEG_WORK_MIN);
+    // (WHETHER a tile is split is a matter of its work against the mean; into HOW MANY segments also of its list's length: a segment of
+    // up to GSR_BLOCK keys sorts in registers and is staged once for both passes -- measured, S-1M-640-object / S-room-640: segments of
+    // 500 - 1 300 keys cost more than a whole median tile, most of it barriers between their staging batches and the LDS sort)
+    uint32_t Lk = GSR_SEG_KEYS;
+    auto nseg_of = [&](uint32_t w, uint32_t h, uint32_t n) -> uint32_t {
+        if (w <= 2u * L || h != 0u) return 1u;
+        return min((uint32_t)GSR_SEG_MAX, max((w + L - 1u) / L, (n + Lk - 1u) / Lk));
+    };
+    uint32_t total = 0u, local = 0u;
+    for (int round = 0; round < 16; round++) {
+        local = 0u;
+#pragma unroll
+        for (int i = 0; i < kPer; i++) local += (i < np) ? nseg_of(wk[i], hold[i], ln[i]) : 0u;
+        total = block_sum(local);
+        if (total <= (uint32_t)budget) break;
+        L += (L >> 1) + 1u;          // (the blocks must fit the launch: fewer, longer segments)
+        Lk += (Lk >> 1);
+    }
+    if (total > (uint32_t)budget) {          // (cannot happen with budget >= ntiles; then nobody is split)
+        L = 0x3FFFFFFFu;
+        local = (uint32_t)np;
+        total = block_sum(local);
+    }
+    uint32_t incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t o = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    __syncthreads();
+    if (act && lane == 63) s_sum[wv] = incl;
+    __syncthreads();
+    uint32_t at = incl - local;
+    for (int w = 0; act && w < wv; w++) at += s_sum[w];
+#pragma unroll
+    for (int i = 0; i < kPer; i++)
+        if (i < np) {
+            const uint32_t k = nseg_of(wk[i], hold[i], ln[i]);
+            for (uint32_t q = 0; q < k; q++) list[at + q] = tl[i] | (q << 16) | (k << 24);
+            at += k;
+            if (hold[i] != 0u) nosplit[tl[i]] = hold[i] - 1u;
+        }
+    for (int b = (int)total + tid; b < budget; b += blockDim.x) list[b] = 0xFFFFFFFFu;
+}
+
 // What the walk keeps per Gaussian between its passes over the image (registers): the span test without the terms only
 // needed once, the clipped rectangle, the key.
 struct WalkItem {
@@ -1677,7 +1764,6 @@ __device__ __forceinline__ float sgnf(float d) { return (d > 0.f) ? 1.f : ((d < 
 // the dispatcher has started earlier: no deadlock as long as workgroups are started in block order; every wait is bounded anyway.
 // ---------------------------------------------------------------------------------------------
 #define GSR_SEG_REC_Q 10           // floats per pixel and segment: Tl, Ts, end T (signed), r, g, b, depth sums, last contributor, depth needed, work
-#define GSR_SEG_MAX 32             // segments per tile at most
 #define GSR_SEG_SHARE_MAX 1365     // a tile is only split while (its keys / nseg) stays below this: a range must fit the in-LDS sort (2 048) with room for sampling noise
 struct SegCtl {
     const uint32_t* list;          // per block: tile | segment << 16 | nseg << 24; ~0: nothing to do.  nullptr: no splitting, blockIdx -> tile as before
@@ -1687,7 +1773,49 @@ struct SegCtl {
     uint32_t* ticket;              // per tile: [2 t] segments that have read the bin's cursor, [2 t + 1] segments that have finished
     uint32_t* nosplit;             // per tile: forwards this tile still goes unsplit (a range once exceeded the in-LDS sort)
     uint32_t epoch;                // tag of this launch's group (flags of earlier launches never match)
+    uint32_t* len;                 // per tile, out (nullable): list entries this forward ordered for the tile -- how long its next bin will be, roughly
+    uint32_t hold_after;           // (rides along: after how many failed verifications in a call a tile keeps its complete list for a while -- see tile_hold)
 };
+// The NEXT iteration's launch list is built by one extra workgroup of k_render_bwd_mfma (block `block`, which does nothing else) from the
+// work this iteration's forward measured -- next to the longest kernel of the loop, off everybody's critical path (in the preprocess
+// kernel, whose workgroups are all resident from the start, it ran last and cost the loop 3.4 us).  Two lists: a launch walks one while
+// it builds the other.  list == nullptr: nothing to build.
+struct SegBuild {
+    const uint32_t* work; uint32_t* order; uint32_t* list; uint32_t* nosplit; int ntiles, budget, block; const uint32_t* len;
+    // The same workgroup also widens the depth bounds this group's forward recorded where they jump (zb nullable): a tile next to one
+    // that needed to look much deeper -- or did not saturate at all -- takes its neighbour's bound.  An object's silhouette in front of a
+    // wall two metres behind moves by a fraction of a pixel per iteration; the tile it moves INTO had saturated on the object and now
+    // has a pixel that needs the wall: a failed verification, i.e. a wasted forward, almost every iteration (S-room-640: 28 of 50).
+    // Deeper bounds only make lists longer: results cannot depend on it.
+    float* zb; float* zbc; int gx, gy, sbx;
+};
+#ifndef GSR_BOUND_DILATE_RATIO
+#define GSR_BOUND_DILATE_RATIO 1.25f
+#endif
+__device__ __forceinline__ void dilate_bounds(const SegBuild& sb, float* scratch /* ntiles floats */)
+{
+    const int nt = sb.gx * sb.gy;
+    for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+        const int tx = t % sb.gx, ty = t / sb.gx;
+        const float mine = sb.zb[t];
+        float nb = 0.f;
+        for (int dy = -1; dy <= 1; dy++)
+            for (int dx = -1; dx <= 1; dx++) {
+                const int x = tx + dx, y = ty + dy;
+                if ((dx != 0 || dy != 0) && x >= 0 && x < sb.gx && y >= 0 && y < sb.gy) nb = fmaxf(nb, sb.zb[y * sb.gx + x]);
+            }
+        scratch[t] = (nb > mine * GSR_BOUND_DILATE_RATIO + 0.25f) ? nb : mine;
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nt; t += blockDim.x) {
+        const float v = scratch[t];
+        if (v != sb.zb[t]) {
+            sb.zb[t] = v;
+            const int tx = t % sb.gx, ty = t / sb.gx;
+            atomicMax(reinterpret_cast<int*>(sb.zbc) + (ty >> 2) * sb.sbx + (tx >> 2), __float_as_int(v));
+        }
+    }
+}
 __device__ __forceinline__ void seg_store(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ float seg_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void seg_store_u(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -2050,10 +2178,23 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     if (LIST == GSR_LIST_BINS_FULL && tile_total != nullptr && tid == 0) tile_total[tile] = (uint32_t)total;
     int walked = 0, overhead = 0;      // -> tile_work: groups of eight this wave composited; staging / ordering cost in the same unit
 
+    // A tile the launch list wants split (SegCtl) is only split if its bin allows it -- no overflow, more than one staging batch, and
+    // a share per segment that fits the in-LDS sort.  Every segment takes this decision from the same numbers; if it is "no",
+    // segment 0 handles the tile like any other and says so in its count word (k_render_bwd_mfma reads it), the others leave.
+    bool split = false;
+    if (LIST == GSR_LIST_BINS && nseg > 1u) {
+        split = nslots <= bin_cap && total > GSR_BLOCK && total <= (int)nseg * GSR_SEG_SHARE_MAX;
+        if (!split) {
+            if (seg != 0u) return;
+            nseg = 1u;
+            if (tid == 0) seg_store_u(&sg.cnt[blockIdx.x], sg.epoch << 16);
+        }
+    }
+
     // A bin longer than the in-LDS sort takes (a tile that does not saturate -- the edge of the scene's coverage, a
     // semi-transparent region -- has no depth bound and gets its complete list) is ordered lazily, slice by slice, like a
     // segment of the exact bins; only a bin that overflowed its capacity fails the forward.
-    const bool lazy = (LIST == GSR_LIST_EXACT) || (LIST == GSR_LIST_BINS && total > GSR_LSORT_CAP) || (LIST == GSR_LIST_BINS_FULL && nslots > GSR_BLOCK);
+    const bool lazy = !split && ((LIST == GSR_LIST_EXACT) || (LIST == GSR_LIST_BINS && total > GSR_LSORT_CAP) || (LIST == GSR_LIST_BINS_FULL && nslots > GSR_BLOCK));
     if (kBins && nslots > bin_cap) {          // block-uniform: entries were dropped; the host redoes the forward with complete lists
         if (tid == 0) {
             atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);
@@ -2070,7 +2211,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         }
         return;
     }
-    if (kBins && !lazy) {
+    if (kBins && !lazy && !split) {
         // this tile's bin arrives unsorted: order it by (depth bits, index) in LDS, keep it there
         // for the staging below and write the sorted indices (and the tile's range) back for the backward pass
         if (tid == 0) ranges[tile] = range;
@@ -2104,9 +2245,310 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
 
     // GSR_LIST_EXACT: `consumed` entries of the segment are ordered (and written to point_list) so far; the keys of the
     // current slice sit in s_keys[0, m).  The other modes make one pass with m = total.
+    // ---- one segment of a split tile (see SegCtl) ----
+    if (LIST == GSR_LIST_BINS && split) {
+        __shared__ uint32_t s_sp_fill, s_sp_last;
+        __shared__ int s_sp_walk[4];
+        const uint32_t first = blockIdx.x - seg;          // block of the tile's segment 0
+        const unsigned long long* keys = bins + range.x;
+        float* myrec = sg.rec + (size_t)blockIdx.x * (GSR_SEG_REC_Q * GSR_BLOCK);
+        const uint32_t pub_word = (sg.epoch << 2) | 1u;
+        // (1) the sample every segment of the tile draws alike (sixteen runs of 64 keys spread over the bin, as sample_slice) and
+        // this segment's depth range (lo, hi]: pivot j = a depth with j / nseg of the sample at or below it
+        uint32_t* s_samp = reinterpret_cast<uint32_t*>(s.a);
+        const int nruns = (total + GSR_SAMPLE_RUN - 1) / GSR_SAMPLE_RUN;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int i = tid + GSR_BLOCK * j;
+            const int run = i / GSR_SAMPLE_RUN;
+            const int pos = ((nruns <= 1024 / GSR_SAMPLE_RUN) ? run : (int)(((long long)run * nruns) / (1024 / GSR_SAMPLE_RUN))) * GSR_SAMPLE_RUN + (i & (GSR_SAMPLE_RUN - 1));
+            s_samp[i] = (pos < total) ? (uint32_t)(keys[pos] >> 32) : 0xFFFFFFFFu;
+        }
+        if (tid == 0) s_sp_fill = 0u;
+        __syncthreads();
+        uint32_t lo_d = 0u, hi_d = 0xFFFFFFFEu;
+        {
+            uint32_t v[16];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const uint4 x = reinterpret_cast<const uint4*>(s_samp)[lane + 64 * q];
+                v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+            }
+            int nvalid = 0;
+            uint32_t vmin = 0xFFFFFFFFu, vmax = 0u;
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                const bool ok = v[q] != 0xFFFFFFFFu;
+                nvalid += (int)__popcll(__ballot(ok));
+                vmin = min(vmin, v[q]);
+                vmax = ok ? max(vmax, v[q]) : vmax;
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                vmin = min(vmin, (uint32_t)__shfl_xor((int)vmin, off, 64));
+                vmax = max(vmax, (uint32_t)__shfl_xor((int)vmax, off, 64));
+            }
+            const uint32_t vmin_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)vmin), vmax_u = (uint32_t)__builtin_amdgcn_readfirstlane((int)vmax);
+            // (the tolerance stays below a quarter of the distance between two pivots' ranks, so that consecutive pivots come out in order;
+            // the same function of the same data in every wave of every segment: neighbours agree on their common pivot)
+            auto pivot = [&](uint32_t j) -> uint32_t {
+                const int r = max(1, (int)(((long long)j * nvalid) / (int)nseg));
+                const int tol = (nvalid / (int)nseg) >> 2;
+                uint32_t lo_b = vmin_u, hi_b = vmax_u;
+                while (lo_b < hi_b) {
+                    const uint32_t mid = lo_b + ((hi_b - lo_b) >> 1);
+                    int c = 0;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) c += (int)__popcll(__ballot(v[q] <= mid));
+                    if (c >= r) { hi_b = mid; if (c <= r + tol) break; }
+                    else lo_b = mid + 1u;
+                }
+                return hi_b;
+            };
+            if (seg > 0u) lo_d = pivot(seg);
+            if (seg + 1u < nseg) hi_d = pivot(seg + 1u);
+        }
+        GSR_T_COUNT(10, 1000)      // (timing build: marks the rows of split segments)
+        GSR_T_TICK(0)
+        // (2) one pass over the bin gathers the range's keys (ballot prefix per wave, one LDS atomic per wave and 1 024 keys)
+        for (int i0 = 0; i0 < total; i0 += 4 * GSR_BLOCK) {
+            unsigned long long k[4];
+            bool in[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const int i = i0 + j * GSR_BLOCK + tid;
+                k[j] = (i < total) ? keys[i] : 0ull;
+                const uint32_t d = (uint32_t)(k[j] >> 32);
+                in[j] = i < total && (seg == 0u || d > lo_d) && d <= hi_d;
+            }
+            unsigned long long mk[4];
+            uint32_t cnt4 = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { mk[j] = __ballot(in[j]); cnt4 += (uint32_t)__popcll(mk[j]); }
+            if (cnt4 != 0u) {
+                uint32_t at = 0u;
+                if (lane == 0) at = atomicAdd(&s_sp_fill, cnt4);
+                at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const uint32_t pos = at + (uint32_t)__popcll(mk[j] & ((1ull << lane) - 1ull));
+                    if (in[j] && pos < (uint32_t)GSR_LSORT_CAP) s_keys[pos] = k[j];
+                    at += (uint32_t)__popcll(mk[j]);
+                }
+            }
+        }
+        __syncthreads();
+        int m = (int)s_sp_fill;
+        GSR_T_TICK(1)
+        if (m > GSR_LSORT_CAP) {
+            // (a range beyond the in-LDS sort: thousands of keys at one depth, or a sample far off.  The forward fails -- it is redone --
+            // and the tile goes unsplit for a while; this segment carries on as an empty one so that nobody waits for it in vain)
+            if (tid == 0) { atomicMax(fail, fail_tag | GSR_FAIL_BOUND); sg.nosplit[tile] = 64u; }
+            m = 0;
+        }
+        if (tid == 0) seg_store_u(&sg.cnt[blockIdx.x], (sg.epoch << 16) | (uint32_t)(m + 1));
+        // (3) order
+        if (m <= GSR_BLOCK) {
+            sort_block_keys((tid < m) ? s_keys[tid] : ~0ull, s_keys);
+            overhead += 3;
+        } else {
+            int npow = 512;
+            while (npow < m) npow <<= 1;
+            for (int i = m + tid; i < npow; i += GSR_BLOCK) s_keys[i] = ~0ull;
+            __syncthreads();
+            lds_bitonic_sort(s_keys, npow);
+            const int lg = 31 - __builtin_clz((unsigned)npow);
+            overhead += 2 + (lg * (lg + 1) / 2) * max(1, npow >> 9) / 7;
+        }
+        // (4) pass 0: Tl, the product of (1 - alpha) over this pixel's valid entries; pass 1: the walk proper from Ts
+        GSR_T_TICK(2)
+        const gsr_f32x2 pxy2 = {pxf, pyf};
+        const bool one_batch = m <= GSR_BLOCK;      // staged once, kept for both passes
+        float Tl = 1.f, Ts = 0.f, Tc = 0.f, Tl2 = 1.f;
+        uint32_t basepos = 0u;
+        int cntw = 0;
+        // (segment 0 knows its Ts -- 1 -- and goes straight to pass 1; the Tl it publishes afterwards is that walk's own chain, or 0 for a
+        // pixel that terminated in it: all a later segment needs to know of such a pixel is that it is finished)
+        for (int pass = (seg == 0u ? 1 : 0); pass < 2; pass++) {
+            if (pass == 1 && seg > 0u) {
+                seg_store(&myrec[tid], Tl);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __syncthreads();
+                if (tid == 0) seg_store_u(&sg.pub[blockIdx.x], pub_word);
+                float t = inside ? 1.f : 0.f;
+                bool ok = true;
+                for (uint32_t q = 0; q < seg; q++) {
+                    ok = seg_wait(&sg.pub[first + q], pub_word) && ok;
+                    t = t * seg_load(&sg.rec[(size_t)(first + q) * (GSR_SEG_REC_Q * GSR_BLOCK) + tid]);
+                    basepos += (seg_load_u(&sg.cnt[first + q]) & 0xFFFFu) - 1u;
+                }
+                if (!ok && tid == 0) atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);      // (never seen; a forward that gave up waiting must not count)
+                GSR_T_TICK(5)
+                Ts = t;
+                Tc = (t >= 0.0001f) ? t : -t;          // below 1e-4: this pixel terminated in an earlier segment
+                if (one_batch && tid < m) {
+                    const float4 b4 = s.b[tid];
+                    point_list[range.x + basepos + tid] = pack_qm ? (__float_as_uint(b4.z) | (__float_as_uint(b4.w) << 28)) : __float_as_uint(b4.z);
+                }
+            } else if (pass == 1) {          // segment 0
+                Ts = inside ? 1.f : 0.f;
+                Tc = Ts;
+            }
+            for (int base = 0; base < m; base += GSR_BLOCK) {
+                if (pass == 1) { if (__syncthreads_and(Tc <= 0.f)) break; }
+                else if (base > 0) __syncthreads();
+                const int n = min(GSR_BLOCK, m - base);
+                if (pass == 0 || !one_batch || seg == 0u) {
+                    overhead += 3;
+                    if (tid < n) {
+                        const uint32_t id = (uint32_t)s_keys[base + tid];
+                        const float4* r = reinterpret_cast<const float4*>(rec + (size_t)id * GSR_REC_STRIDE);
+                        const float4 r0 = r[0], r1 = r[1], r2 = r[2];
+                        const uint32_t qm = quadrant_mask(r0.x, r0.y, r1.x * (-2.0f / GSR_LOG2E), r0.z * (-1.0f / GSR_LOG2E), r0.w * (-2.0f / GSR_LOG2E), r1.y,
+                                                          tx * GSR_TILE, ty * GSR_TILE);
+                        if (pass == 1) point_list[range.x + basepos + base + tid] = pack_qm ? (id | (qm << 28)) : id;
+                        s.a[tid] = r0;
+                        s.b[tid] = make_float4(r1.x, r1.y, __uint_as_float(id), __uint_as_float(qm));
+                        s.c[tid] = make_float4(r2.x, r2.y, r2.z, r1.z);
+                    }
+                    __syncthreads();
+                    cntw = 0;
+                    for (int c0 = 0; c0 < n; c0 += 64) {
+                        const int jj = c0 + lane;
+                        const bool hit = jj < n && ((__float_as_uint(s.b[min(jj, GSR_BLOCK - 1)].w) >> wv) & 1u);
+                        const unsigned long long mk = __ballot(hit);
+                        if (hit) s.list[wv][cntw + __popcll(mk & ((1ull << lane) - 1ull))] = (uint8_t)jj;
+                        cntw += (int)__popcll(mk);
+                    }
+                }
+                // (the walks: eight entries per step from one 8-byte read of the wave's list, like the unsplit kernel's)
+                const int full = cntw & ~7;
+                GSR_T_TICK(3)
+                if (pass == 0) {
+                    auto body0 = [&](int j) {
+                        const float4 A = s.a[j];
+                        const float2 B = *reinterpret_cast<const float2*>(&s.b[j]);
+                        const gsr_f32x2 d = (gsr_f32x2){A.x, A.y} - pxy2;
+                        const gsr_f32x2 tu = (gsr_f32x2){A.z, A.w} * (gsr_f32x2){d.y, d.y};
+                        const float p2 = __builtin_fmaf(d.x, __builtin_fmaf(B.x, d.x, tu.x), tu.y * d.y);
+                        const float G = __builtin_amdgcn_exp2f(p2);
+                        const float alpha = fminf(0.99f, B.y * G);
+                        const bool valid = !(alpha < 1.0f / 255.0f) && !(p2 > 0.0f);
+                        Tl = valid ? Tl * (1.f - alpha) : Tl;
+                    };
+                    for (int g0 = 0; g0 < full; g0 += 8) {
+                        const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(&s.list[wv][g0]);
+                        const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)packed);
+                        const uint32_t phi = __builtin_amdgcn_readfirstlane((uint32_t)(packed >> 32));
+#pragma unroll
+                        for (int sidx = 0; sidx < 8; sidx++) body0((int)(((sidx < 4 ? plo : phi) >> (8 * (sidx & 3))) & 0xFFu));
+                    }
+                    for (int k0 = full; k0 < cntw; k0++) body0(__builtin_amdgcn_readfirstlane((int)s.list[wv][k0]));
+                    GSR_T_TICK(4)
+                } else {
+                    float zlast = 0.f;
+                    auto body1 = [&](int j) {
+                        const float4 A = s.a[j];
+                        const float2 B = *reinterpret_cast<const float2*>(&s.b[j]);
+                        const float4 Cc = s.c[j];
+                        const gsr_f32x2 d = (gsr_f32x2){A.x, A.y} - pxy2;
+                        const gsr_f32x2 tu = (gsr_f32x2){A.z, A.w} * (gsr_f32x2){d.y, d.y};
+                        const float p2 = __builtin_fmaf(d.x, __builtin_fmaf(B.x, d.x, tu.x), tu.y * d.y);
+                        const float G = __builtin_amdgcn_exp2f(p2);
+                        const float alpha = fminf(0.99f, B.y * G);
+                        const bool valid = !(alpha < 1.0f / 255.0f) && !(p2 > 0.0f);
+                        const float Tln = Tl2 * (1.f - alpha);          // the same chain as pass 0, bit for bit
+                        const float test_T = Ts * Tln;
+                        const bool alive = Tc > 0.f;
+                        const bool kill = valid && alive && test_T < 0.0001f;
+                        const bool blend = valid && alive && !kill;
+                        const float w = blend ? alpha * Tc : 0.f;
+                        Crg = __builtin_elementwise_fma((gsr_f32x2){Cc.x, Cc.y}, (gsr_f32x2){w, w}, Crg);
+                        Cbd = __builtin_elementwise_fma((gsr_f32x2){Cc.z, Cc.w}, (gsr_f32x2){w, w}, Cbd);
+                        Tc = kill ? -Tc : (blend ? test_T : Tc);
+                        Tl2 = valid ? Tln : Tl2;
+                        last_contributor = blend ? (uint32_t)(basepos + base + j + 1) : last_contributor;
+                        zlast = Cc.w;
+                        if (TOUCHED) {      // pose package: pixels where the splat was blended with T still > 0.5 (as the unsplit walk counts them)
+                            const int c = (int)__popcll(__ballot(valid && alive && test_T > 0.5f));
+                            if (c != 0 && lane == 0) atomicAdd(&n_touched[__float_as_uint(s.b[j].z)], c);
+                        }
+                    };
+                    for (int g0 = 0; g0 < full; g0 += 8) {
+                        if (__all(Tc <= 0.f)) break;
+                        walked++;
+                        const unsigned long long packed = *reinterpret_cast<const unsigned long long*>(&s.list[wv][g0]);
+                        const uint32_t plo = __builtin_amdgcn_readfirstlane((uint32_t)packed);
+                        const uint32_t phi = __builtin_amdgcn_readfirstlane((uint32_t)(packed >> 32));
+                        const bool alive0 = Tc > 0.f;
+#pragma unroll
+                        for (int sidx = 0; sidx < 8; sidx++) body1((int)(((sidx < 4 ? plo : phi) >> (8 * (sidx & 3))) & 0xFFu));
+                        zneed = alive0 ? zlast : zneed;          // (depth needed: rounded up to the group of eight, like the unsplit walk)
+                    }
+                    for (int k0 = full; k0 < cntw; k0++) {
+                        if (__all(Tc <= 0.f)) break;
+                        const bool alive0 = Tc > 0.f;
+                        body1(__builtin_amdgcn_readfirstlane((int)s.list[wv][k0]));
+                        zneed = alive0 ? zlast : zneed;
+                    }
+                    GSR_T_TICK(6)
+                }
+            }
+        }
+        if (seg == 0u) {
+            seg_store(&myrec[tid], (Tc > 0.f) ? Tl2 : 0.f);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) seg_store_u(&sg.pub[blockIdx.x], pub_word);
+        }
+        // the segment's record; then the ticket: who finishes last adds the tile up
+        seg_store(&myrec[1 * GSR_BLOCK + tid], Ts);
+        seg_store(&myrec[2 * GSR_BLOCK + tid], Tc);
+        seg_store(&myrec[3 * GSR_BLOCK + tid], Crg.x);
+        seg_store(&myrec[4 * GSR_BLOCK + tid], Crg.y);
+        seg_store(&myrec[5 * GSR_BLOCK + tid], Cbd.x);
+        seg_store(&myrec[6 * GSR_BLOCK + tid], Cbd.y);
+        seg_store(&myrec[7 * GSR_BLOCK + tid], __uint_as_float(last_contributor));
+        seg_store(&myrec[8 * GSR_BLOCK + tid], inside ? zneed : 0.f);
+        if (lane == 0) s_sp_walk[wv] = walked;
+        __syncthreads();
+        if (tid == 0) seg_store(&myrec[9 * GSR_BLOCK], (float)(max(max(s_sp_walk[0], s_sp_walk[1]), max(s_sp_walk[2], s_sp_walk[3])) + 1 + overhead));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const bool last = atomicAdd(&sg.ticket[2 * tile + 1], 1u) == nseg - 1u;
+            if (last) sg.ticket[2 * tile + 1] = 0u;
+            s_sp_last = last ? 1u : 0u;
+        }
+        __syncthreads();
+        GSR_T_TICK(7)
+        if (s_sp_last == 0u) { GSR_T_FLUSH(0) return; }
+        {
+            float Tfin = inside ? 1.f : 0.f, zn = 0.f, work = 0.f;
+            bool dead = false;
+            uint32_t lastc = 0u, tot = 0u;
+            gsr_f32x2 crg = {0.f, 0.f}, cbd = {0.f, 0.f};
+            for (uint32_t q = 0; q < nseg; q++) {
+                const float* r = sg.rec + (size_t)(first + q) * (GSR_SEG_REC_Q * GSR_BLOCK);
+                const float te = seg_load(r + 2 * GSR_BLOCK + tid);
+                if (!dead) { Tfin = te; dead = te <= 0.f; }
+                crg += (gsr_f32x2){seg_load(r + 3 * GSR_BLOCK + tid), seg_load(r + 4 * GSR_BLOCK + tid)};
+                cbd += (gsr_f32x2){seg_load(r + 5 * GSR_BLOCK + tid), seg_load(r + 6 * GSR_BLOCK + tid)};
+                lastc = max(lastc, __float_as_uint(seg_load(r + 7 * GSR_BLOCK + tid)));
+                zn = fmaxf(zn, seg_load(r + 8 * GSR_BLOCK + tid));
+                work += seg_load(r + 9 * GSR_BLOCK);
+                tot += (seg_load_u(&sg.cnt[first + q]) & 0xFFFFu) - 1u;
+            }
+            T = Tfin; Crg = crg; Cbd = cbd; last_contributor = lastc; zneed = zn;
+            walked = (int)work; overhead = 0;
+            if (tid == 0) { ranges[tile] = make_uint2(range.x, range.x + tot); if (sg.len != nullptr) sg.len[tile] = tot; }
+        }
+        GSR_T_TICK(8)
+    }
     int consumed = 0, m = total, slice_no = 0;
     unsigned long long slice_lo = 0ull;
   for (bool first_slice = true;; first_slice = false) {
+    if (split) break;          // (a split tile's finalising segment: straight to the epilogue)
     if (lazy) {
         if (consumed >= total) break;
         if (__syncthreads_and(T <= 0.f)) break;          // every pixel of the tile has terminated: the rest is never ordered
@@ -2314,6 +2756,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     // GSR_LIST_EXACT: the tile's range is what has been ORDERED -- all that the backward pass and a re-compositing of
     // these lists (n_touched) can need: no pixel looks beyond the slice in which the last one terminated
     if (lazy && tid == 0) ranges[tile] = make_uint2(range.x, range.x + (uint32_t)min(consumed, total));
+    if (sg.len != nullptr && !split && tid == 0) sg.len[tile] = (uint32_t)(lazy ? min(consumed, total) : total);
     GSR_T_TICK(GSR_TO(6))
     if (tile_work != nullptr) {      // this tile's weight in the next iteration's launch order
         __shared__ int s_walk[4];
@@ -2348,11 +2791,14 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                 // time it saturates it fails every other forward (measured on poses 0.3 m / 10 deg off the map's reference view: 33
                 // failed groups in a 50-iteration refinement).  A tile that failed TWICE in a call keeps its complete list for the next
                 // GSR_HOLD_FORWARDS forwards -- its own list only; everybody else keeps speculating.
-                // (the FIRST failure of a tile in a call is not held: a warm start from another frame's bounds fails in many
-                // tiles once, and their retry records good bounds)
+                // (a failure in the FIRST forward of a warm-started call is not held -- hold_after = 2 there: another frame's bounds fail in
+                // many tiles once, and their retry records good bounds.  Later in a call the first failure is held (round 5; was the second):
+                // a tile on an object's silhouette, where a pixel saturates in one iteration and needs the wall two metres behind in the next,
+                // failed twice before it was left alone -- S-room-640: 30 failed forwards in a 50-iteration call)
                 const uint32_t word = tile_hold[tile];
                 uint32_t hold = word & 0xFFu, nfail = word >> 8;
-                if (failed_here) { nfail++; hold = (nfail >= 2u) ? GSR_HOLD_FORWARDS : 0u; }
+                // (a tile that keeps failing is left alone for longer each time: 32, 64, 128, 255 forwards)
+                if (failed_here) { nfail = min(nfail + 1u, 0xFFFFu); hold = (nfail >= sg.hold_after) ? min(255u, GSR_HOLD_FORWARDS << min(nfail - sg.hold_after, 3u)) : 0u; }
                 else if (hold > 0u) hold--;
                 if (failed_here || (word & 0xFFu) != 0u) tile_hold[tile] = (nfail << 8) | hold;
                 if (hold > 0u) bound = __builtin_huge_valf();
@@ -2500,16 +2946,52 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
                                                                const float* __restrict__ dL_dalphas, float* __restrict__ acc,
                                                                LoopGuard guard, const uint32_t* __restrict__ tile_order,
                                                                uint32_t* __restrict__ tile_work, const float* __restrict__ rec, int P, int pack_qm, int det,
-                                                               uint8_t* __restrict__ aflag)
+                                                               uint8_t* __restrict__ aflag, SegCtl sg, SegBuild sb)
 {
     // (aflag, 2 P bytes: [id] = some tile added to this Gaussian's record, [P + id] = ... to its colour sums.  Idempotent plain
     // byte stores -- every writer stores 1 -- that tell the chain-rule kernel which of the forward's survivors have anything to do,
     // without its reading every survivor's 48-byte record: on complete lists nine survivors in ten were never blended.)
     __shared__ BwdMfmaLDS s;
     const GSR_CONST_AS float* crec = (const GSR_CONST_AS float*)rec;      // (constant address space + wave-uniform offsets: s_load)
+    if (sb.list != nullptr && (int)blockIdx.x == sb.block) {          // (also on a frozen iteration: its retry runs the list)
+        __shared__ uint32_t s_cls2[GSR_BLOCK];
+        tile_order_from_work(sb.work, sb.order, sb.ntiles, s_cls2);
+        __syncthreads();
+        seg_list_build(sb.work, sb.order, sb.list, sb.nosplit, sb.ntiles, sb.budget, sb.len);
+        if (sb.zb != nullptr) {
+            __syncthreads();
+            dilate_bounds(sb, reinterpret_cast<float*>(sb.order));      // (the order array has served its purpose)
+        }
+        return;
+    }
     if (guard.frozen()) return;
     GSR_T_DECL
-    const int tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_remap(blockIdx.x, ntiles);
+    // (sg.list: the forward's launch list, see SegCtl -- a split tile's segments are walked by as many workgroups, each over its own
+    // window [lo_pos, hi_pos) of the tile's ordered list, back to front, started from what the forward's records say about the
+    // window's far end)
+    int tile;
+    uint32_t seg = 0u, nseg = 1u;
+    if (sg.list != nullptr) {
+        const uint32_t e = sg.list[blockIdx.x];
+        if (e == 0xFFFFFFFFu) return;
+        tile = (int)(e & 0xFFFFu); seg = (e >> 16) & 0xFFu; nseg = e >> 24;
+    } else tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_remap(blockIdx.x, ntiles);
+    const uint32_t first = blockIdx.x - seg;
+    uint32_t lo_pos = 0u, hi_pos = 0x7FFFFFFFu, seg_end = seg + 1u;      // (seg_end: one past the last forward segment of this workgroup's window)
+    if (nseg > 1u) {
+        if ((sg.cnt[first] & 0xFFFFu) == 0u) {          // the forward did not split this tile after all: segment 0 has all of it
+            if (seg != 0u) return;
+            nseg = 1u;
+        } else {
+            // (this kernel's per-workgroup costs -- pixel gradients in, B operands, a recombination per batch -- want longer windows than the
+            // forward's one-batch segments: a workgroup takes GSR_BWD_SEG_MERGE consecutive segments, the others leave)
+            if (seg % GSR_BWD_SEG_MERGE != 0u) return;
+            for (uint32_t q = 0; q < seg; q++) lo_pos += (sg.cnt[first + q] & 0xFFFFu) - 1u;
+            hi_pos = lo_pos;
+            seg_end = min(seg + GSR_BWD_SEG_MERGE, nseg);
+            for (uint32_t q = seg; q < seg_end; q++) hi_pos += (sg.cnt[first + q] & 0xFFFFu) - 1u;
+        }
+    }
     const int tx = tile % gx, ty = tile / gx;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const int px = tx * GSR_TILE + (wv & 1) * 8 + (tid & 7), py = ty * GSR_TILE + (wv >> 1) * 8 + ((tid >> 3) & 7);
@@ -2551,10 +3033,27 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
     for (int off = 32; off > 0; off >>= 1) m = max(m, __shfl_xor(m, off, 64));
     if (lane == 0) s.wmax[wv] = m;
     __syncthreads();
-    const int total = max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3]));
+    // (total: one past the deepest list position this workgroup has to look at -- the tile's deepest contributor, or the end of its window)
+    const int total = min(max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3])), (int)hi_pos);
     const int wave_max = s.wmax[wv];
+    if (total <= (int)lo_pos) return;          // (a window behind everything the tile's pixels needed; block-uniform)
 
     float av = 0.f, lv = 0.f, last_alpha = 0.f, om_last = 1.f;      // the "composited behind me" recurrence, see the loop body (om_last = 1 - last_alpha)
+    if (nseg > 1u && seg_end < nseg && inside && (uint32_t)last_contributor > hi_pos) {
+        // this pixel goes on behind the window: its transmittance at the window's far end is the next segment's Ts, and what lies behind,
+        // composited as seen from there, is (the later segments' sums) / Ts -- for the value v = colour . dL/dpixel + depth dL/ddepth - dL/dalpha
+        // the walk's recurrence carries (k_render_fwd's records, see SegCtl)
+        const size_t rs = (size_t)GSR_SEG_REC_Q * GSR_BLOCK;
+        const float Tb = sg.rec[(size_t)(first + seg_end) * rs + 1 * GSR_BLOCK + tid];
+        float cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f;
+        for (uint32_t q = seg_end; q < nseg; q++) {
+            const float* r = sg.rec + (size_t)(first + q) * rs;
+            cr += r[3 * GSR_BLOCK + tid]; cg += r[4 * GSR_BLOCK + tid]; cb += r[5 * GSR_BLOCK + tid]; cd += r[6 * GSR_BLOCK + tid];
+        }
+        T = Tb;
+        // (in double: one value carries the whole window's "behind" -- the sum's cancellations would otherwise be its error)
+        av = (float)((((double)dpx * cr + (double)dpy * cg) + ((double)dpz * cb + (double)dLd * cd)) / (double)Tb - (double)dLa * (1.0 - (double)T_final / (double)Tb));
+    }
     const bool simple = __all(dLa == 0.f && nTf_bg == 0.f) != 0;
     int walked = 0;                                  // groups of eight list entries this wave has gone through (-> tile_work)
     const float ddelx_dx = 0.5f * W, ddely_dy = 0.5f * H;
@@ -2572,12 +3071,12 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
 
     GSR_T_TICK(0)
     int nbatch = 0;
-    for (int base = 0, taken = 0; base < total; base += taken) {
+    for (int base = 0, taken = 0; base < total - (int)lo_pos; base += taken) {
         __syncthreads();
         GSR_T_TICK(1)
         GSR_T_COUNT(10, 1)
         nbatch++;
-        const int n = min(GSR_BWD_STAGE, total - base);
+        const int n = min(GSR_BWD_STAGE, total - (int)lo_pos - base);
         if (tid < n) {
             const uint32_t e = point_list[range.x + (total - 1 - base - tid)];
             if (pack_qm) {          // the forward left this tile's quadrant mask of the splat in the entry (k_render_fwd, pack_qm)
@@ -2764,7 +3263,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         }
         GSR_T_TICK(8)
     }
-    if (tile_work != nullptr) {      // this tile's weight in the next iteration's launch order: its longest wave + a share for the staging
+    if (tile_work != nullptr && nseg == 1u) {      // this tile's weight in the next iteration's launch order: its longest wave + a share for the staging
         if (lane == 0) s.wmax[wv] = walked;
         __syncthreads();
         if (tid == 0) tile_work[tile] = (uint32_t)(max(max(s.wmax[0], s.wmax[1]), max(s.wmax[2], s.wmax[3])) + 2 * nbatch);
@@ -2842,7 +3341,7 @@ __global__ void k_pose_init(float* st, const float* proj_raw)
 // Every small array a gsr_refine call wants cleared before its first iteration (flags, cursors, counters, partial sums, bounds
 // buffers -- a hundred KB in all), in ONE launch instead of a dozen memsets: what a 20-iteration call spends on enqueueing those
 // is a fifth of an iteration each.  Ranges of 32-bit words; unused ranges have n = 0.
-struct ClearRanges { uint32_t* p[10]; uint32_t n[10]; };
+struct ClearRanges { uint32_t* p[12]; uint32_t n[12]; };
 // gsr_refine_args.init_*: the whole initial pose state from the caller's device tensors (zeros, R, T, exposure, camera); st == nullptr: none.
 // (host_state, nullable: the host's mirror of the pose state in pinned memory, see PoseStepArgs::host_state)
 struct PoseLoadArgs { float* st; const float* R0; const float* T0; const float* ea; const float* eb; const float* proj_raw; float* host_state; };
@@ -2875,7 +3374,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_refine_init(ClearRanges c, PoseLo
     const uint32_t nb = gridDim.x - (q.st != nullptr ? 1u : 0u);
     const uint32_t i0 = blockIdx.x * GSR_BLOCK + threadIdx.x, step = nb * GSR_BLOCK;
 #pragma unroll
-    for (int r = 0; r < 10; r++)
+    for (int r = 0; r < 12; r++)
         for (uint32_t i = i0; i < c.n[r]; i += step) c.p[r][i] = 0u;
 }
 

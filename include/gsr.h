@@ -29,7 +29,9 @@
 extern "C" {
 #endif
 
-/* 3: gsr_forward_packed / gsr_backward_packed (one struct pointer instead of 34 / 40 arguments); gsr_refine_args gained
+/* 4: the pose state is 112 floats (words 96..109: pose and exposure of the last executed forward / backward); GSR_REFINE_NO_SPLIT;
+ *    gsr_debug_seg_stats; gsr_backward refuses debug bit 2 on a geometry workspace whose forward ran without it.
+ * 3: gsr_forward_packed / gsr_backward_packed (one struct pointer instead of 34 / 40 arguments); gsr_refine_args gained
  *    colors_precomp / cov3D_precomp at its end; gsr_geometry_bytes_det, gsr_spec_state_bounds_bytes.
  * 2: gsr_refine_args gained `carry_state` (round 2) and the fields behind `stream` (flags, lean_min_P); stats_out is int[4];
  *    pose-state words 41 (ticket) and 84..87 (Adam beta products); gsr_debug_lean_check.  A caller must compare
@@ -380,6 +382,13 @@ typedef struct gsr_refine_args {
  * below 2^33 (beyond that the integer wraps).  Costs 2-4 % of a speculative iteration, 15 % with complete lists; the geometry buffer
  * then holds 192 B of accumulator records per Gaussian instead of 48 (gsr_geometry_bytes_det). */
 #define GSR_REFINE_DETERMINISTIC 16u
+/* Diagnostics: never split a heavy tile's list across workgroups.  (By default the speculative iterations of a loop cut the list of a
+ * tile whose compositing took more than twice the mean into depth ranges that as many workgroups walk in parallel -- same results up
+ * to the rounding of a transmittance carried as a product of per-range products; the deterministic option implies this flag.) */
+#define GSR_REFINE_NO_SPLIT 32u
+/* Diagnostics: do not widen the speculative depth bounds at depth discontinuities (a tile next to one that had to look much deeper takes
+ * its neighbour's bound: fewer failed verifications along silhouettes).  Never changes a result either way. */
+#define GSR_REFINE_NO_DILATE 64u
 int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
 
 /* Differential check of k_preprocess_lean's conservative test (tests only; replaces nothing in the reference -- it guards the
@@ -391,6 +400,11 @@ int gsr_refine(const gsr_refine_args* args, int* iters_done, int* converged);
  * leaves, out[2] = Gaussians the exact walk bins into at least one tile, out[3] = VIOLATIONS: settled although the exact walk
  * bins them (must be 0), out[4] = index of the first violation or -1.  Blocking. */
 int gsr_debug_lean_check(const gsr_refine_args* args, long long out[5]);
+/* Tests only: what the LAST speculative iteration of the gsr_refine call that just returned on these workspaces did about heavy tiles
+ * (see GSR_REFINE_NO_SPLIT).  out[0] = blocks of its compositing launches that had work, out[1] = tiles cut into more than one depth
+ * range, out[2] = the largest number of ranges of a tile, out[3] = blocks the launches had room for (0: this image size is never
+ * split).  Blocking. */
+int gsr_debug_seg_stats(const gsr_refine_args* args, long long out[4]);
 /* Byte offset of the per-Gaussian (mean, extent bound) quads inside a geometry workspace of gsr_geometry_bytes(P) bytes (tests only:
  * tests/test_gpu_lean.py overwrites the bounds to see the check above fail). */
 size_t gsr_debug_lam_offset(int P);
