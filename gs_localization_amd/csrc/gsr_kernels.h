@@ -3045,7 +3045,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         // the walk's recurrence carries (k_render_fwd's records, see SegCtl)
         const size_t rs = (size_t)GSR_SEG_REC_Q * GSR_BLOCK;
         const float Tb = sg.rec[(size_t)(first + seg_end) * rs + 1 * GSR_BLOCK + tid];
-        float cr = 0.f, cg = 0.f, cb = 0.f, cd = 0.f;
+        double cr = 0.0, cg = 0.0, cb = 0.0, cd = 0.0;
         for (uint32_t q = seg_end; q < nseg; q++) {
             const float* r = sg.rec + (size_t)(first + q) * rs;
             cr += r[3 * GSR_BLOCK + tid]; cg += r[4 * GSR_BLOCK + tid]; cb += r[5 * GSR_BLOCK + tid]; cd += r[6 * GSR_BLOCK + tid];

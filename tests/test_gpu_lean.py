@@ -237,6 +237,9 @@ def test_headline_path_against_the_oracle_at_the_pose_of_its_last_forward(name):
     run = _run(fr, vp, init, bg, K, flags=0)
     info = run["info"]
     assert info["iters"] == K and info["lean_iters"] >= 1, info
+    if name in ("S-room-640", "S-1M-640-object"):          # heavy tiles were split across workgroups in the iteration compared below
+        blocks, ntiles_split, kmax, budget = fr.seg_stats()
+        assert ntiles_split >= 20 and kmax >= 4, (blocks, ntiles_split, kmax, budget)
     Rl, Tl, ex = info["R_last_forward_host"], info["T_last_forward_host"], info["exposure_last_forward_host"]
     assert abs(np.linalg.det(Rl.astype(np.float64)) - 1) < 1e-5 and not np.allclose(Rl, info["R_host"], atol=0, rtol=0)
     vm, pm, cp = _camera_of_the_pose_state(Rl, Tl, S.camera_matrices(sc)[2])
@@ -271,7 +274,15 @@ def test_headline_path_against_the_oracle_at_the_pose_of_its_last_forward(name):
         assert e <= 2e-5, (k, e)
         # per row: a threshold flip (alpha within an ulp of 1/255, T of 1e-4: v_exp_f32 against expf) moves one pixel of one splat --
         # per-cent level on a splat that covers a handful of pixels, never more; and it happens to a few rows in ten thousand
-        assert worst <= ROW_WORST and share <= ROW_SHARE, (k, worst, share, at)
+        # (S-room-640 runs with a tenth of its tiles split across workgroups: there the backward restarts the "composited behind me"
+        # value of a window from the forward's sums instead of carrying the oracle's fp32 recurrence through the whole list -- as
+        # accurate, but no longer the SAME rounding as the oracle's, and where the splats behind a faint one have nearly its colour the
+        # difference (v - behind) is all rounding: measured 1.9e-4 of the opacity rows above 1e-3 against 2.5e-5 unsplit)
+        # ... and its transmittances round differently from the oracle's running product, so a pixel whose T (1 - alpha) lies within an ulp
+        # of the 1e-4 termination threshold blends one splat more or less than the oracle's: on a splat of a handful of pixels that one
+        # pixel is tens of per cent of the row (seen: 0.04 - 0.21 from run to run, one row in a million)
+        room = name == "S-room-640"
+        assert worst <= (5 * ROW_WORST if room else ROW_WORST) and share <= (5 * ROW_SHARE if room else ROW_SHARE), (k, worst, share, at)
 
 
 ROW_WORST, ROW_SHARE = 0.1, 2e-4      # (measured on the six scenes, round 5: worst row <= 0.035, share of rows above 1e-3 <= 2.5e-5)
