@@ -70,7 +70,7 @@ def main():
     ap.add_argument("--frames-in-flight", type=int, default=16,
                     help="query frames refined concurrently per GPU, one HIP hardware queue each (measured on one MI355X, round 4, K = 20 / 50: "
                          "8 frames 7 930-9 150 / 9 750-9 940 it/s, 12: 7 700-8 840 / 9 220-10 140, 16: 9 700-9 820 / 10 240-10 310, 20: 9 780-9 890 / 10 410-10 540)")
-    ap.add_argument("--repeats", type=int, default=3, help="the timed region is run this many times; `value` is the first, the rest show the spread")
+    ap.add_argument("--repeats", type=int, default=5, help="the timed region is run this many times; `value` is the MEDIAN (a region is ~35 ms at K = 20: one of them is +-3 % noise), all of them are reported")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-full", action="store_true", help="also time the CPU port on one thread on S-800k-chess (minutes)")
     ap.add_argument("--no-train-leg", action="store_true")
@@ -360,12 +360,15 @@ def main():
             dom_ms, dom_n = collect()[dominant]
             lib.gsr_profile_enable(0)
             lib.gsr_profile_sampling(1)
-    elapsed = elapsed_runs[0]
+    elapsed_first = elapsed_runs[0]
+    elapsed = sorted(elapsed_runs)[len(elapsed_runs) // 2]          # the median repeat is `value` (a 34 ms headline is +-3 % noise)
     if grouped:
         t = torch.tensor([elapsed, elapsed_py, elapsed_single, elapsed_plain, elapsed_cold] + elapsed_runs, dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         vals = [float(x) for x in t.tolist()]
-        elapsed, elapsed_py, elapsed_single, elapsed_plain, elapsed_cold, elapsed_runs = vals[0], vals[1], vals[2], vals[3], vals[4], vals[5:]
+        elapsed_py, elapsed_single, elapsed_plain, elapsed_cold, elapsed_runs = vals[1], vals[2], vals[3], vals[4], vals[5:]
+        elapsed_first = elapsed_runs[0]
+        elapsed = sorted(elapsed_runs)[len(elapsed_runs) // 2]          # (max over ranks per repeat, then the median repeat)
     # how many ranks really took part (a launcher that started fewer than --gpus would otherwise go unnoticed)
     ranks_seen = 1
     if grouped:
@@ -475,7 +478,8 @@ def main():
                        "iterations_per_call": K,
                        "warm_policy": "every refinement call starts from the depth bounds ANOTHER query frame (another start pose) left in its "
                                       "refiner's workspace, verified on the device; single_frame_cold_start_iters_per_s has no bounds to start from",
-                       "timing": "value = first of `repeats` timed regions; single-frame / plain / cold legs = best of three calls"},
+                       "timing": "value = MEDIAN of `repeats` timed regions (value_first_repeat: the first); single-frame / plain / cold legs = best of three calls"},
+            "value_first_repeat": iters_total / elapsed_first,
             "value_repeats": [iters_total / e for e in elapsed_runs],
             "value_repeats_stats": run_stats,
             "stream_of_frames_iters_per_s": 4 * F * K / elapsed_stream,
@@ -496,22 +500,29 @@ def main():
             "kernels_ms_python_loop": {k: round(v, 4) for k, v in kernels_ms.items()},
             "kernels_ms_per_iter_native_single_frame": {k: round(v, 4) for k, v in native_ms[True].items()},
             "kernels_ms_per_iter_native_plain_loop": {k: round(v, 4) for k, v in native_ms[False].items()},
-            "roofline": {"bound": "hbm", "kernel": dominant, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_launch": per_kernel_bytes[dominant], "avg_launch_ms": dom_avg_ms,
-                         "launches_timed": int(dom_n),
-                         "avg_launch_ms_single_frame": native_ms[True][dominant],
-                         # (avg_launch_ms is a launch of the timed region, where F frames share the GPU; a frame alone:)
-                         "frac_single_frame": (per_kernel_bytes[dominant] / (native_ms[True][dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS)
-                                              if native_ms[True][dominant] > 0 else None,
+            # roofline.achieved / frac: the dominant kernel's algorithmic bytes over its duration with ONE frame on the GPU (HIP events around
+            # every launch of the kernel, on its stream, in this process) -- the figure that describes the kernel.  In the timed region of
+            # `value` the same launch is stretched by the fifteen other frames' kernels sharing the chip: achieved_at_value / frac_at_value.
+            "roofline": {"bound": "hbm", "kernel": dominant,
+                         "achieved": (per_kernel_bytes[dominant] / (native_ms[True][dominant] * 1e-3) / 1e9) if native_ms[True][dominant] > 0 else 0.0,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": (per_kernel_bytes[dominant] / (native_ms[True][dominant] * 1e-3) / 1e9 / HBM_PEAK_GBS) if native_ms[True][dominant] > 0 else None,
+                         "traffic": traffic,
+                         "traffic_source": "profiles/traffic.json (builder-run rocprofv3 FETCH_SIZE / WRITE_SIZE passes, gfx950 corrections applied; not measured in this run)",
+                         "algorithmic_bytes_per_launch": per_kernel_bytes[dominant],
+                         "avg_launch_ms": native_ms[True][dominant],
+                         "achieved_at_value": achieved, "frac_at_value": achieved / HBM_PEAK_GBS, "avg_launch_ms_at_value": dom_avg_ms,
+                         "launches_timed_at_value": int(dom_n),
                          # what the kernel is actually bound by (rocprofv3 SQ pass, profiles/issue.json): its vector-issue and
                          # matrix-pipe utilisations, two pipes side by side; and the whole loop's vector-issue fraction
                          "bound_measured": "valu_issue",
                          "issue_frac": issue,
                          "loop_valu_issue_frac": loop_valu_frac,
+                         "issue_source": "profiles/issue.json (builder-run rocprofv3 SQ counter passes; not measured in this run)",
                          # whole iteration: HBM bytes per steady-state iteration (sum of the loop's kernels, profiles/traffic.json)
                          # and that traffic at the measured single-frame / in-flight rates against the HBM peak
                          "iter_traffic_bytes": iter_traffic,
+                         "iter_traffic_source": "profiles/traffic.json (builder-run rocprofv3; not measured in this run)",
                          "iter_traffic_frac_single_frame": (iter_traffic * single / 1e9 / HBM_PEAK_GBS) if iter_traffic else None,
                          "iter_traffic_frac_at_value": (iter_traffic * iters_total / elapsed / 1e9 / HBM_PEAK_GBS / world) if iter_traffic else None,
                          # the reference algorithm's bytes per iteration (all kernels) x measured iterations/s against the

@@ -43,5 +43,32 @@ def build(force=False, verbose=False):
     return OUT
 
 
+EXT_SRC = os.path.join(_HERE, "csrc", "gsrcall.c")
+EXT_OUT = os.path.join(_HERE, "_gsrcall.so")
+
+
+def build_ext(force=False, verbose=False):
+    """_gsrcall: the CPython hop of the drop-in packages into the C ABI (csrc/gsrcall.c): plain gcc, no torch headers, links the
+    library next to it.  Only for the product library (a diagnostic build under GSR_LIB_PATH keeps the ctypes route)."""
+    import sysconfig
+    lib = os.path.join(_HERE, "libgsr_hip.so")
+    deps = [EXT_SRC, os.path.join(_ROOT, "include", "gsr.h")]
+    if not force and os.path.exists(EXT_OUT) and all(os.path.getmtime(EXT_OUT) >= os.path.getmtime(d) for d in deps):
+        return EXT_OUT
+    if not os.path.exists(lib):
+        raise RuntimeError("build libgsr_hip.so first")
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if not cc:
+        raise RuntimeError("gcc not found")
+    cmd = [cc, "-O2", "-std=c99", "-Wall", "-shared", "-fPIC", "-I" + os.path.join(_ROOT, "include"), "-I" + sysconfig.get_paths()["include"],
+           EXT_SRC, "-o", EXT_OUT, "-L" + _HERE, "-l:libgsr_hip.so", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return EXT_OUT
+
+
 if __name__ == "__main__":
     print(build(force=True, verbose=True))
+    if not os.environ.get("GSR_LIB_PATH"):
+        print(build_ext(force=True, verbose=True))

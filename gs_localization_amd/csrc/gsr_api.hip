@@ -153,6 +153,7 @@ struct Img {
     uint32_t* tile_hold;                                  // native loop: forwards a tile still goes without a depth bound after a failed verification
     // native loop, heavy tiles split across workgroups (gsr::SegCtl): launch list, per-block words and records, per-tile tickets
     uint32_t* seg_list[2]; uint32_t* seg_cnt; uint32_t* seg_pub; uint32_t* seg_ticket; uint32_t* seg_nosplit; uint32_t* seg_len; float* seg_rec; int seg_budget;
+    float* zb_own[2]; uint32_t* nodilate;                  // (same block) every tile's own depth bound before dilate_bounds widened it; forwards a tile still goes without widening
 };
 // Blocks the compositing kernels are launched with when tiles may be split: every tile once + room for the heavy ones' extra segments
 constexpr int kSegMaxTiles = 4096;
@@ -189,7 +190,7 @@ size_t carve_img(char* base, int W, int H, Img& im, bool seg = false)
     im.tile_order[0] = c.take<uint32_t>(nt); im.tile_order[1] = c.take<uint32_t>(nt);
     im.tile_hold = c.take<uint32_t>(nt);
     im.seg_budget = seg ? seg_budget_of((int)nt) : 0;
-    im.seg_list[0] = im.seg_list[1] = im.seg_cnt = im.seg_pub = im.seg_ticket = im.seg_nosplit = im.seg_len = nullptr; im.seg_rec = nullptr;
+    im.seg_list[0] = im.seg_list[1] = im.seg_cnt = im.seg_pub = im.seg_ticket = im.seg_nosplit = im.seg_len = im.nodilate = nullptr; im.seg_rec = nullptr; im.zb_own[0] = im.zb_own[1] = nullptr;
     if (im.seg_budget > 0) {
         im.seg_list[0] = c.take<uint32_t>((size_t)im.seg_budget);      // (a launch walks one list while its extra workgroup builds the other)
         im.seg_list[1] = c.take<uint32_t>((size_t)im.seg_budget);
@@ -198,6 +199,9 @@ size_t carve_img(char* base, int W, int H, Img& im, bool seg = false)
         im.seg_ticket = c.take<uint32_t>(2 * nt);
         im.seg_nosplit = c.take<uint32_t>(nt);
         im.seg_len = c.take<uint32_t>(nt);
+        im.nodilate = c.take<uint32_t>(nt);
+        im.zb_own[0] = c.take<float>(nt);
+        im.zb_own[1] = c.take<float>(nt);
         im.seg_rec = c.take<float>((size_t)im.seg_budget * GSR_SEG_REC_Q * GSR_BLOCK);
     }
     return c.size();
@@ -710,6 +714,8 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     if (use_seg) sg = gsr::SegCtl{im.seg_list[sp.parity ^ 1], im.seg_cnt, im.seg_pub, im.seg_rec, im.seg_ticket, im.seg_nosplit, cx.guard.tag, im.seg_len};
     else if (cx.seg && balanced && im.seg_budget > 0) sg.len = im.seg_len;      // (every forward of the loop reports how much of each tile's list it ordered)
     sg.hold_after = cx.hold_after;
+    // (bounds widened by the previous group's backward -- dilate_bounds -- come with the tiles' own bounds next to them)
+    if (cx.seg && cx.seg_ready && by_tile && im.seg_budget > 0 && !sp.state && !(cx.flags & GSR_REFINE_NO_DILATE)) { sg.zb_own_used = im.zb_own[sp.parity ^ 1]; sg.nodilate = im.nodilate; }
     pa.tile_cursor = (by_tile || full_bins) ? im.tile_cursor : nullptr;
     pa.bins = bl.bins;
     pa.tile_count = (by_tile || full_bins) ? nullptr : im.tile_count;
@@ -1002,7 +1008,8 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         // its scratch: the next forward either runs the list or has the preprocess kernel compute its order afresh)
         const bool build = cx.seg && im.seg_budget > 0 && cx.native_loop && balanced;
         const gsr::SegBuild sb = build ? gsr::SegBuild{im.tile_work[0], im.tile_order[0], im.seg_list[cx.spec.parity], im.seg_nosplit, ntiles, im.seg_budget, kgrid, im.seg_len,
-                                                        (cx.spec.mode != 0 && !cx.spec.state && !(cx.flags & GSR_REFINE_NO_DILATE)) ? im.zb[cx.spec.parity] : (float*)nullptr, im.zbc[cx.spec.parity], gx, gy, im.sbx} : gsr::SegBuild{};
+                                                        (cx.spec.mode != 0 && !cx.spec.state && !(cx.flags & GSR_REFINE_NO_DILATE)) ? im.zb[cx.spec.parity] : (float*)nullptr, im.zbc[cx.spec.parity], gx, gy, im.sbx,
+                                                        im.zb_own[cx.spec.parity], im.nodilate} : gsr::SegBuild{};
         if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(kgrid + (build ? 1 : 0)), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag, sg, sb);
         else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(kgrid + (build ? 1 : 0)), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag, sg, sb);
 #undef GSR_BWD_ARGS
@@ -1211,9 +1218,11 @@ void* cached_resize(void* c, size_t bytes)
 }
 }  // namespace
 
+static std::atomic<int> g_refine_calls{0};      // gsr_refine calls in flight in this process (wait_status naps only when there are several)
 int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
 {
     using namespace gsr;
+    struct InFlight { InFlight() { g_refine_calls.fetch_add(1, std::memory_order_relaxed); } ~InFlight() { g_refine_calls.fetch_sub(1, std::memory_order_relaxed); } } in_flight;
     if (!a || !iters_done || !converged) return fail(GSR_E_INVALID, "gsr_refine: NULL argument%s", "");
     if (!a->pose_state || !a->projmatrix_raw || !a->gt_image || !a->grad_mask || !a->dL_dimage || !a->dL_ddepth ||
         !a->dL_dalpha || !a->dL_dtau || !a->loss_out || !a->n_touched)
@@ -1257,7 +1266,9 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
 #ifndef GSR_POLL_NAP
 #define GSR_POLL_NAP 1
 #endif
-        const long nap_us = (GSR_POLL_NAP && group_us > 600.0) ? (long)std::min(250.0, group_us / 8.0) : 0;
+        // (napping is for MANY frames sharing the GPU: only with other gsr_refine calls in flight in this process -- a single frame whose
+        // groups take 0.6 ms (S-3M-cam at 1024x576 on complete lists) would otherwise flip between spinning and napping)
+        const long nap_us = (GSR_POLL_NAP && group_us > 600.0 && g_refine_calls.load(std::memory_order_relaxed) > 1) ? (long)std::min(250.0, group_us / 8.0) : 0;
         for (unsigned spins = 0;; spins++) {
             const uint32_t v = *w;
             if ((v >> 4) == (uint32_t)(g + 1)) {
@@ -1368,10 +1379,11 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             if (warm_buf != 0) add(im0.zbc[0], (size_t)im0.nsb);
             if (warm_buf != 1) add(im0.zbc[1], (size_t)im0.nsb);
             add(a->loss_out, 4);
-            // (a warm-started call keeps what the previous frame learned about its tiles: one that sits on the edge of saturation -- an
-            // object's silhouette in front of a wall two metres behind -- fails a verification once and is then binned completely for a
-            // while; S-room-640 has dozens of them, and every call used to find them again, one failed forward each)
-            if (warm_buf < 0) add(im0.tile_hold, (size_t)(im0.tile_work[1] - im0.tile_work[0]));
+            // (holds are per call.  Keeping them across warm-started calls and holding a tile after its FIRST failure were both tried in
+            // round 5 for S-room-640's silhouette tiles -- 30 -> 21 failed forwards per 50-iteration call -- and cost S-1M-640-object dearly:
+            // a held tile is binned completely, and in front of a dense object that overflows its bin and sends the rest of the call
+            // through count -> scan -> emit; what fixed the room is the widening of bounds at depth discontinuities, dilate_bounds)
+            add(im0.tile_hold, (size_t)(im0.tile_work[1] - im0.tile_work[0]));
             // (split tiles: the per-block count / publication words, the per-tile tickets and hold counters -- carved back to back)
             if (im0.seg_budget > 0) add(im0.seg_cnt, (size_t)(reinterpret_cast<uint32_t*>(im0.seg_rec) - im0.seg_cnt));
             static_assert(sizeof(cr.p) / sizeof(cr.p[0]) >= 11, "ClearRanges too small");
@@ -1425,7 +1437,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         cov_cached = true;
         cx.seg_ready = seg_built;      // (the group enqueued before this one left a launch list for it)
 #ifndef GSR_HOLD_AFTER
-#define GSR_HOLD_AFTER 1u
+#define GSR_HOLD_AFTER 2u
 #endif
         cx.hold_after = (g == 0 && warm_buf >= 0) ? 2u : GSR_HOLD_AFTER;
         seg_built = cx.seg && cx.balance;
@@ -1518,9 +1530,22 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         n_fallbacks++;
         streak++;
         const bool overflow = (w & 4u) != 0u;
-        if (a->flags & GSR_REFINE_LOG_REDO)
-            fprintf(stderr, "[gsr] group %d: speculation failed (%s)%s\n", g, overflow ? "bin overflow" : "unsaturated tile behind a finite bound",
+        if (a->flags & GSR_REFINE_LOG_REDO) {
+            uint32_t who[2] = {0u, 0u}, holdw = 0u;
+            Img imd; carve_img((char*)ib.ptr, a->width, a->height, imd, cx.seg);
+            float zbd[2] = {0.f, 0.f};
+            if (overflow) {          // (diagnostics only: which tile, how many entries -- a blocking read)
+                (void)hipStreamSynchronize(st);
+                (void)hipMemcpy(who, ps + GSR_PS_POISON + 2, sizeof(who), hipMemcpyDeviceToHost);
+                const int ntd = ((a->width + GSR_TILE - 1) / GSR_TILE) * ((a->height + GSR_TILE - 1) / GSR_TILE);
+                if ((int)who[0] < ntd) { (void)hipMemcpy(&zbd[0], imd.zb[0] + who[0], 4, hipMemcpyDeviceToHost); (void)hipMemcpy(&zbd[1], imd.zb[1] + who[0], 4, hipMemcpyDeviceToHost);
+                                         (void)hipMemcpy(&holdw, imd.tile_hold + who[0], 4, hipMemcpyDeviceToHost); }
+            }
+            fprintf(stderr, "[gsr] group %d (mode %d, margin %.3f): speculation failed (%s)%s", g, group_mode[g], margin_m, overflow ? "bin overflow" : "unsaturated tile behind a finite bound",
                     (streak < 2 && !overflow && !conv_seen) ? ", retried on the device" : ", host steps in");
+            if (overflow) fprintf(stderr, " [tile %u: %u entries; its bounds in the two buffers: %g / %g; failures so far %u, held for %u more forwards]", who[0], who[1], zbd[0], zbd[1], holdw >> 8, holdw & 0xFFu);
+            fprintf(stderr, "\n");
+        }
         if (adaptive_margin) { margin_m = fminf(0.05f, margin_m * 2.f); margin_streak = 0; }
         if (overflow) cx.exact_bins = true;             // (complete lists go through count -> scan -> emit for the rest of this call)
         if (!conv_seen && !overflow && streak < 2) continue;

@@ -1757,7 +1757,7 @@ __device__ __forceinline__ float sgnf(float d) { return (d > 0.f) ? 1.f : ((d < 
 //   * k_render_bwd_mfma walks the segments in parallel too: segment s starts behind its last entry with T = Ts(s + 1) and the
 //     "composited behind me" value (sum of the later segments' colour sums . dL/dpixel) / Ts(s + 1).
 // Against the unsplit walk the results differ by rounding only (T as a product of per-segment products instead of one running
-// product): the deterministic option therefore never splits, and parity against the oracle is tested with splitting live
+// product): the deterministic option therefore never splits, and parity against the CPU restatement of the reference is tested with splitting live
 // (tests/test_gpu_split.py).  A block of the launch is (tile, segment, nseg) from `list`; which tiles are split how far is decided
 // on the device from the work the previous iteration's forward measured (seg_list_build).
 // Waiting is only ever for LOWER-numbered blocks of the same launch (a tile's segments sit in consecutive blocks, ascending), which
@@ -1775,6 +1775,10 @@ struct SegCtl {
     uint32_t epoch;                // tag of this launch's group (flags of earlier launches never match)
     uint32_t* len;                 // per tile, out (nullable): list entries this forward ordered for the tile -- how long its next bin will be, roughly
     uint32_t hold_after;           // (rides along: after how many failed verifications in a call a tile keeps its complete list for a while -- see tile_hold)
+    // (rides along too) widened bounds, see dilate_bounds: zb_own_used = the bounds this forward's tiles recorded THEMSELVES last time (before
+    // any widening), nodilate = per tile, forwards it still goes without widening.  A tile whose bin overflows under a bound it took from
+    // a neighbour falls back to its own bound and is retried on the device like a failed verification, instead of failing the forward.
+    const float* zb_own_used; uint32_t* nodilate;
 };
 // The NEXT iteration's launch list is built by one extra workgroup of k_render_bwd_mfma (block `block`, which does nothing else) from the
 // work this iteration's forward measured -- next to the longest kernel of the loop, off everybody's critical path (in the preprocess
@@ -1788,9 +1792,14 @@ struct SegBuild {
     // has a pixel that needs the wall: a failed verification, i.e. a wasted forward, almost every iteration (S-room-640: 28 of 50).
     // Deeper bounds only make lists longer: results cannot depend on it.
     float* zb; float* zbc; int gx, gy, sbx;
+    float* zb_own; uint32_t* nodilate;      // out: every tile's own bound (before widening); per tile: forwards it still goes without widening
 };
 #ifndef GSR_BOUND_DILATE_RATIO
 #define GSR_BOUND_DILATE_RATIO 1.25f
+#endif
+#define GSR_DILATE_INF_MAX_LEN 2048u
+#ifndef GSR_DILATE_MAX_LEN
+#define GSR_DILATE_MAX_LEN 6144u
 #endif
 __device__ __forceinline__ void dilate_bounds(const SegBuild& sb, float* scratch /* ntiles floats */)
 {
@@ -1802,9 +1811,22 @@ __device__ __forceinline__ void dilate_bounds(const SegBuild& sb, float* scratch
         for (int dy = -1; dy <= 1; dy++)
             for (int dx = -1; dx <= 1; dx++) {
                 const int x = tx + dx, y = ty + dy;
-                if ((dx != 0 || dy != 0) && x >= 0 && x < sb.gx && y >= 0 && y < sb.gy) nb = fmaxf(nb, sb.zb[y * sb.gx + x]);
+                if ((dx != 0 || dy != 0) && x >= 0 && x < sb.gx && y >= 0 && y < sb.gy) {
+                    const float z = sb.zb[y * sb.gx + x];
+                    // (a neighbour WITHOUT a bound -- it did not saturate -- hands that on only if its own complete list, which it has just
+                    // walked to the end, is short: "no bound" means the complete list, and next to a dense object that is a hundred times
+                    // the needed one and overflows the bin -- S-1M-640-object: bins of 8 192 against complete lists of 100 000)
+                    if (z < __builtin_huge_valf() || sb.len[y * sb.gx + x] <= GSR_DILATE_INF_MAX_LEN) nb = fmaxf(nb, z);
+                }
             }
-        scratch[t] = (nb > mine * GSR_BOUND_DILATE_RATIO + 0.25f) ? nb : mine;
+        // (... and only where the longer list is affordable: this tile's list grows roughly in proportion to the depth it covers; a tile on a
+        // dense object that took the bound of its neighbour in the sparse background behind would bin the whole object -- an overflowing bin)
+        const float mylen = (float)sb.len[t];
+        const bool affordable = (nb < __builtin_huge_valf()) ? (mine > 0.f && mylen * (nb / mine) <= (float)GSR_DILATE_MAX_LEN) : true;
+        uint32_t hold = sb.nodilate[t];      // (a tile whose widened bin overflowed goes without for a while: k_render_fwd set this)
+        if (hold != 0u) sb.nodilate[t] = hold - 1u;
+        sb.zb_own[t] = mine;
+        scratch[t] = (nb > mine * GSR_BOUND_DILATE_RATIO + 0.25f && affordable && hold == 0u) ? nb : mine;
     }
     __syncthreads();
     for (int t = threadIdx.x; t < nt; t += blockDim.x) {
@@ -2173,6 +2195,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     } else range = ranges[tile];
     const int total = (int)(range.y - range.x);
     if (!kBins) nslots = total;
+#ifdef GSR_DBG_TILE
+    if (LIST == GSR_LIST_BINS && fail_tag != 0u && tid == 0 && tile == GSR_DBG_TILE) { fail[4] = (uint32_t)nslots; fail[5] = __float_as_uint(zb_used ? zb_used[tile] : -1.f); fail[6] = sg.hold_after; fail[7] = tile_hold ? tile_hold[tile] : 0xFFFFu; }
+#endif
     // (one plain store per tile.  A grand total added up here with one atomic per tile cost 16 us: 1 200 same-address atomics queue
     // up at the memory side and every workgroup's next barrier waits for its own)
     if (LIST == GSR_LIST_BINS_FULL && tile_total != nullptr && tid == 0) tile_total[tile] = (uint32_t)total;
@@ -2196,8 +2221,18 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     // segment of the exact bins; only a bin that overflowed its capacity fails the forward.
     const bool lazy = !split && ((LIST == GSR_LIST_EXACT) || (LIST == GSR_LIST_BINS && total > GSR_LSORT_CAP) || (LIST == GSR_LIST_BINS_FULL && nslots > GSR_BLOCK));
     if (kBins && nslots > bin_cap) {          // block-uniform: entries were dropped; the host redoes the forward with complete lists
+        if (tid == 0 && LIST == GSR_LIST_BINS && sg.zb_own_used != nullptr && zb_used != nullptr && zb_next != nullptr && sg.zb_own_used[tile] < zb_used[tile]) {
+            // the bound this tile was binned with was a neighbour's (dilate_bounds): back to its own, which held a list that fitted, no widening
+            // for a while, and the forward fails like a verification -- the group behind this one retries it on the device
+            const float own = sg.zb_own_used[tile];
+            sg.nodilate[tile] = 64u;
+            zb_next[tile] = own;
+            atomicMax(reinterpret_cast<int*>(zbc_next) + (ty >> 2) * sbx + (tx >> 2), __float_as_int(own));
+            atomicMax(fail, fail_tag | GSR_FAIL_BOUND);
+        } else
         if (tid == 0) {
             atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);
+            if (fail_tag != 0u) { fail[2] = (uint32_t)tile; fail[3] = (uint32_t)nslots; }      // (native loop, diagnostics: pose-state words 42 / 43, free otherwise -- GSR_REFINE_LOG_REDO prints them)
             // The group enqueued behind this one bins with the bounds THIS forward records (it is the device-side retry): a tile
             // that leaves without recording one would hand it whatever the buffer held before -- a stale per-tile bound next to
             // superblock maxima this tile never contributed to, i.e. lists that are no longer depth-prefixes, from which a pixel can
@@ -2791,14 +2826,17 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                 // time it saturates it fails every other forward (measured on poses 0.3 m / 10 deg off the map's reference view: 33
                 // failed groups in a 50-iteration refinement).  A tile that failed TWICE in a call keeps its complete list for the next
                 // GSR_HOLD_FORWARDS forwards -- its own list only; everybody else keeps speculating.
-                // (a failure in the FIRST forward of a warm-started call is not held -- hold_after = 2 there: another frame's bounds fail in
-                // many tiles once, and their retry records good bounds.  Later in a call the first failure is held (round 5; was the second):
-                // a tile on an object's silhouette, where a pixel saturates in one iteration and needs the wall two metres behind in the next,
-                // failed twice before it was left alone -- S-room-640: 30 failed forwards in a 50-iteration call)
+                // (the FIRST failure of a tile in a call is not held -- hold_after = 2: a warm start from another frame's bounds fails in many
+                // tiles once, and their retry records good bounds; holding at the first failure was measured in round 5: nothing gained on
+                // S-room-640, and a held tile in front of a dense object overflows its bin)
                 const uint32_t word = tile_hold[tile];
                 uint32_t hold = word & 0xFFu, nfail = word >> 8;
                 // (a tile that keeps failing is left alone for longer each time: 32, 64, 128, 255 forwards)
-                if (failed_here) { nfail = min(nfail + 1u, 0xFFFFu); hold = (nfail >= sg.hold_after) ? min(255u, GSR_HOLD_FORWARDS << min(nfail - sg.hold_after, 3u)) : 0u; }
+                if (failed_here) {
+                    nfail = (nfail < 0xFFFFu) ? nfail + 1u : nfail;
+                    hold = 0u;
+                    if (nfail >= sg.hold_after) { const uint32_t k = nfail - sg.hold_after; hold = (k >= 3u) ? 255u : (GSR_HOLD_FORWARDS << k); }
+                }
                 else if (hold > 0u) hold--;
                 if (failed_here || (word & 0xFFu) != 0u) tile_hold[tile] = (nfail << 8) | hold;
                 if (hold > 0u) bound = __builtin_huge_valf();
@@ -3294,7 +3332,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
 #define GSR_PS_PROJ 64
 #define GSR_PS_CAMPOS 80
 #define GSR_PS_PREV 96        // [96..104] R, [105..107] T, [108..109] exposure a, b as they were BEFORE the most recent pose step: the pose of the
-                              // last forward / backward that ran (round 5: lets a test hold the loop's maintained gradients against the oracle at that pose)
+                              // last forward / backward that ran (round 5: lets a test hold the loop's maintained gradients against the CPU restatement of the reference at that pose)
 #define GSR_PS_SIZE 112
 
 // view / proj / campos from (R, T): world_view_transform, full_proj_transform, camera_center of

@@ -23,6 +23,18 @@ import torch.nn as nn
 
 from . import _lib
 
+# The hop into the C ABI: a small CPython extension (csrc/gsrcall.c, built next to the library by build.py) that takes the 34 / 40
+# arguments as positional ints / floats and calls gsr_forward_packed / gsr_backward_packed -- ctypes spends 10-15 us per call on the
+# same arguments.  Absent (a diagnostic library under GSR_LIB_PATH, a tree that was not built): the ctypes route below does the same.
+try:
+    if os.environ.get("GSR_LIB_PATH") or os.environ.get("GSR_NO_EXT"):
+        raise ImportError("diagnostic library: ctypes route")
+    from . import _gsrcall
+    if _gsrcall.ABI_VERSION != _lib.ABI_VERSION:
+        raise ImportError("_gsrcall was built against another gsr.h")
+except ImportError:
+    _gsrcall = None
+
 
 def cpu_deep_copy_tuple(input_tuple):
     copied_tensors = [item.cpu().clone() if isinstance(item, torch.Tensor) else item for item in input_tuple]
@@ -267,12 +279,38 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     stream = torch.cuda.current_stream(dev).cuda_stream
     blk = _blocks
     a = blk.fa
-    a.state = (C.addressof(_spec_cache.get(lib, dev, stream, W, H, None if want_touched else view.data_ptr()))
-               if (P > 0 and speculation_enabled(want_touched)) else None)
+    # (package (A): the per-camera state is keyed by the CALLER's view-matrix tensor -- `view` is a fresh temporary whenever that tensor
+    # needed converting (CPU / float64 / non-contiguous), whose address would name nothing; such a call goes without speculation)
+    cam_key = None if want_touched else (rs.viewmatrix.data_ptr() if view is rs.viewmatrix else -1)
+    state_addr = (C.addressof(_spec_cache.get(lib, dev, stream, W, H, cam_key))
+                  if (P > 0 and cam_key != -1 and speculation_enabled(want_touched)) else None)
+    a.state = state_addr
+    geom_t = bin_t = img_t = None
+    nz = P > 0
+    det = _env_has("GSR_DETERMINISTIC")
+    sizes = _workspace_sizes(lib, P, W, H, det) if nz else None
+    if _gsrcall is not None and sizes is not None:
+        # fast route: workspaces of known size, every argument a positional int / float (None = NULL)
+        bufs = [torch.empty(n, dtype=torch.uint8, device=dev) for n in sizes]
+        base = images.data_ptr()
+        N4 = 4 * H * W
+        ip = ints.data_ptr()
+        rc = _gsrcall.forward(
+            state_addr, P, int(rs.sh_degree), M, bg.data_ptr(), W, H, means3D.data_ptr(), sh.data_ptr() if n_sh != 0 else None,
+            colors_precomp.data_ptr() if colors_precomp.numel() != 0 else None, opacities.data_ptr(),
+            scales.data_ptr() if scales.numel() != 0 else None, float(rs.scale_modifier), rotations.data_ptr() if rotations.numel() != 0 else None,
+            cov3Ds_precomp.data_ptr() if cov3Ds_precomp.numel() != 0 else None, view.data_ptr(), proj.data_ptr(), campos.data_ptr(),
+            float(rs.tanfovx), float(rs.tanfovy), int(bool(rs.prefiltered)), base, base + 3 * N4, base + 4 * N4, ip,
+            int(bool(rs.debug)) | (2 if _env_has("GSR_SH_EAGER") else 0) | (4 if det else 0), (ip + 4 * P) if want_touched else None, stream,
+            bufs[0].data_ptr(), sizes[0], bufs[1].data_ptr(), sizes[1], bufs[2].data_ptr(), sizes[2])
+        if rc != _lib.E_ALLOC:
+            num_rendered = rc if rc >= 0 else _lib.check(rc)
+            geom_t, bin_t, img_t = bufs
+            saved = (colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom_t, bin_t, img_t, alpha, opacities)
+            return num_rendered, color, radii, depth, alpha, n_touched, saved, (bg, view, proj, campos, det)
     a.P, a.D, a.M = P, int(rs.sh_degree), M
     a.background = bg.data_ptr()
     a.width, a.height = W, H
-    nz = P > 0
     a.means3D = means3D.data_ptr() if nz else None
     a.shs = sh.data_ptr() if n_sh != 0 else None
     a.colors_precomp = colors_precomp.data_ptr() if colors_precomp.numel() != 0 else None
@@ -288,7 +326,6 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     N4 = 4 * H * W
     a.out_color, a.out_depth, a.out_alpha = base, base + 3 * N4, base + 4 * N4
     a.radii = radii.data_ptr() if nz else None
-    det = _env_has("GSR_DETERMINISTIC")
     a.debug = int(bool(rs.debug)) | (2 if _env_has("GSR_SH_EAGER") else 0) | (4 if det else 0)
     a.n_touched = (ints.data_ptr() + 4 * P) if (want_touched and nz) else None
     a.stream = stream
@@ -299,9 +336,7 @@ def _forward_impl(means3D, sh, colors_precomp, opacities, scales, rotations, cov
     # allocated here and handed over through the library's own fixed-buffer callback -- no callback into the interpreter; the
     # growing `_Workspace` route is the fallback (large images: the key array is sized from a device read-back, as the
     # reference's is; a bin that overflowed).
-    geom_t = bin_t = img_t = None
     rc = None
-    sizes = _workspace_sizes(lib, P, W, H, det) if nz else None
     if sizes is not None:
         bufs = [torch.empty(n, dtype=torch.uint8, device=dev) for n in sizes]
         fb = blk.fb
@@ -359,6 +394,27 @@ def _backward_impl(rs, num_rendered, saved, consts, grad_color, grad_depth, grad
     dL_dscales = parts[7].view(P, 3) if want_scale else None
     dL_dopacity = parts[8].view(P, 1)
     dL_dtau = parts[9][:6] if pose_mode else None
+    if _gsrcall is not None and P > 0:
+        f0 = flat.data_ptr()
+        ptrs, off = [], 0
+        for w in widths:
+            ptrs.append((f0 + 4 * off) if w else None)
+            off += P * w
+        dconic, drot, dsh, dm2, dm3, dcov, dcol, dscale, dopac = ptrs
+        rc = _gsrcall.backward(
+            P, int(rs.sh_degree), M, int(num_rendered), bg.data_ptr(), W, H, means3D.data_ptr(), sh.data_ptr() if n_sh != 0 else None,
+            colors_precomp.data_ptr() if colors_precomp.numel() != 0 else None, alpha.data_ptr(),
+            scales.data_ptr() if scales.numel() != 0 else None, float(rs.scale_modifier), rotations.data_ptr() if rotations.numel() != 0 else None,
+            cov3Ds_precomp.data_ptr() if cov3Ds_precomp.numel() != 0 else None, view.data_ptr(), proj.data_ptr(), campos.data_ptr(),
+            float(rs.tanfovx), float(rs.tanfovy), radii.data_ptr(), _ptr(geomBuffer), _ptr(binningBuffer), _ptr(imgBuffer),
+            grad_color.data_ptr(), grad_depth.data_ptr(), grad_alpha.data_ptr(), dm2, dconic, dopac, dcol, dm3, dcov, dsh, dscale, drot,
+            int(bool(rs.debug)) | (4 if det else 0), 1 if pose_mode else 0, (f0 + 4 * off) if pose_mode else None,
+            torch.cuda.current_stream(dev).cuda_stream)
+        if rc < 0:
+            _lib.check(rc)
+        if dL_dsh is None and need["sh"]:
+            dL_dsh = torch.empty((P, M, 3), dtype=_F32, device=dev)
+        return dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations, dL_dtau
     b = _blocks.ba
     b.P, b.D, b.M, b.R = P, int(rs.sh_degree), M, int(num_rendered)
     b.background = bg.data_ptr()

@@ -110,3 +110,46 @@ def test_train_loop_with_growing_model_matches_the_oracle_at_three_sizes():
         for other in (b, c, d):
             assert torch.equal(a[k], other[k]), k
     assert v1 >= 2 and v1 + m1 >= 3
+
+
+def test_train_loop_through_many_changes_of_P_keeps_its_memory_and_its_parity():
+    """BASELINE.json config 4 as written is 7 000 iterations with P changing 65 times and an opacity reset (train.py:142-152); the full
+    run is tools/train_7k.py (HISTORY.md has its numbers).  Here the same loop compressed to 330 steps at 648x420: 24 changes of P
+    (0.1 M -> 0.5 M), the opacity reset in the middle, then 40 steps at constant P during which NOTHING may grow -- workspaces are
+    regrown when P changes and a leak would show as a rising peak --, finite losses throughout, and the oracle's forward / backward on
+    the step after the last change of P."""
+    from oracle import oracle as O
+    from gs_localization_amd import rasterizer as RZ
+    from tests.train_replay import TrainReplay
+    O.set_threads(min(64, os.cpu_count() or 1))
+    RZ._spec_cache.clear()
+    tr = TrainReplay(P0=100_000, P1=500_000, W=648, H=420, densify_from=20, densification_interval=11, densify_until=290, opacity_reset_interval=150)
+    losses, changes, last_change = [], 0, 0
+    for it in range(1, 291):
+        before = tr.P
+        losses.append(float(tr.step(it)))
+        if tr.P != before:
+            changes += 1
+            last_change = it
+    assert changes >= 20 and tr.P == 500_000 and last_change >= 270, (changes, tr.P, last_change)
+    assert all(np.isfinite(losses))
+    assert float(torch.sigmoid(tr.par["opacity"]).max()) > 0.011          # (the reset at 150 capped every opacity at 0.01; Adam has moved them since)
+    _check_step_against_oracle(tr, 291)
+    for it in range(292, 300):
+        tr.step(it)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    base_alloc = torch.cuda.memory_allocated()
+    for it in range(300, 331):
+        losses.append(float(tr.step(it)))
+    torch.cuda.synchronize()
+    assert all(np.isfinite(losses))
+    # (a step allocates its temporaries -- images, workspaces, gradients -- and frees them: the peak over thirty steps stays within one
+    # step's worth above the resting level, and the resting level itself does not move)
+    assert torch.cuda.memory_allocated() <= base_alloc + (8 << 20), (torch.cuda.memory_allocated(), base_alloc)
+    peak1 = torch.cuda.max_memory_allocated()
+    torch.cuda.reset_peak_memory_stats()
+    for it in range(331, 341):
+        tr.step(it)
+    torch.cuda.synchronize()
+    assert torch.cuda.max_memory_allocated() <= peak1 + (8 << 20), (torch.cuda.max_memory_allocated(), peak1)

@@ -132,3 +132,17 @@ def test_workspaces_do_not_outlive_their_forward():
     assert key not in RZ._Workspace._registry
     assert RZ._workspace_dispatch(key, 64) == 0  # a stale context gets NULL, not a dangling buffer
     assert kept.numel() == 64
+
+
+def test_cpython_hop_is_built_and_speaks_the_same_abi():
+    """csrc/gsrcall.c: the drop-in packages' hop into the C ABI (no ctypes on the fast route).  It must be there, built against the same
+    gsr.h as the ctypes mirrors, and refuse a call with the wrong number of arguments instead of reading past them."""
+    import pytest
+    from gs_localization_amd import rasterizer as RZ, _lib
+    assert RZ._gsrcall is not None, "gs_localization_amd/_gsrcall.so missing: python gs_localization_amd/build.py"
+    assert RZ._gsrcall.ABI_VERSION == _lib.ABI_VERSION and RZ._gsrcall.E_ALLOC == _lib.E_ALLOC
+    with pytest.raises(TypeError):
+        RZ._gsrcall.forward(0, 1, 2)
+    with pytest.raises(TypeError):
+        RZ._gsrcall.backward(0)
+    assert isinstance(RZ._gsrcall.last_error(), str)

@@ -33,12 +33,13 @@ def garden_scene(P, W=1296, H=840, seed=0):
 
 class TrainReplay:
     def __init__(self, P0=200_000, P1=1_500_000, W=1296, H=840, device="cuda:0", n_views=16, seed=0, densify_from=500,
-                 densification_interval=100, densify_until=7000, lambda_dssim=0.2, depth_weight=0.1):
+                 densification_interval=100, densify_until=7000, lambda_dssim=0.2, depth_weight=0.1, opacity_reset_interval=3000):
         self.dev = torch.device(device)
         self.W, self.H = W, H
         self.P0, self.P1 = P0, P1
         self.densify_from, self.interval, self.densify_until = densify_from, densification_interval, densify_until
         self.lambda_dssim, self.depth_weight = lambda_dssim, depth_weight
+        self.opacity_reset_interval = opacity_reset_interval          # train.py:151-152 (arguments/__init__.py:84: 3 000)
         self.scene = garden_scene(P0, W, H, seed)
         sc = self.scene
         t = lambda a: torch.tensor(np.ascontiguousarray(a), dtype=torch.float32, device=self.dev)
@@ -133,7 +134,10 @@ class TrainReplay:
                 TE.add_densification_stats(out["radii"], out["means2D"].grad, self.max_radii2D, self.xyz_gradient_accum, self.denom)
                 if iteration > self.densify_from and iteration % self.interval == 0:
                     self.events += 1
-                    self.densify(int(round(self.P0 * self.growth ** self.events)), size_threshold=20 if iteration > 3000 else None)
+                    self.densify(int(round(self.P0 * self.growth ** self.events)), size_threshold=20 if iteration > self.opacity_reset_interval else None)
+                    changed = True
+                if self.opacity_reset_interval and iteration % self.opacity_reset_interval == 0:
+                    self.reset_opacity()          # train.py:151-152 -> gaussian_model.py:207-210: opacities capped at 0.01, their Adam moments zeroed
                     changed = True
             if not changed:           # (after a densification the gradients belong to tensors that no longer exist)
                 self.opt.step()
@@ -142,6 +146,24 @@ class TrainReplay:
         return loss.detach()
 
     # ------------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def reset_opacity(self):
+        """reset_opacity (scene/gaussian_model.py:207-210): opacity <- min(opacity, 0.01) in logit space; the optimizer's moments of that
+        group start again from zero (replace_tensor_to_optimizer, :212-224)."""
+        for group in self.opt.param_groups:
+            if group["name"] != "opacity":
+                continue
+            old = group["params"][0]
+            st = self.opt.state.pop(old, None)
+            capped = torch.logit(torch.minimum(torch.sigmoid(old.detach()), torch.full_like(old, 0.01)))
+            fresh = torch.nn.Parameter(capped.contiguous().requires_grad_(True))
+            if st is not None:
+                st["exp_avg"] = torch.zeros_like(fresh)
+                st["exp_avg_sq"] = torch.zeros_like(fresh)
+                self.opt.state[fresh] = st
+            group["params"][0] = fresh
+            self.par["opacity"] = fresh
+
     @torch.no_grad()
     def densify(self, target_P, size_threshold=None):
         p = self.par
