@@ -133,7 +133,7 @@ def test_train_loop_through_many_changes_of_P_keeps_its_memory_and_its_parity():
             last_change = it
     assert changes >= 20 and tr.P == 500_000 and last_change >= 270, (changes, tr.P, last_change)
     assert all(np.isfinite(losses))
-    assert float(torch.sigmoid(tr.par["opacity"]).max()) > 0.011          # (the reset at 150 capped every opacity at 0.01; Adam has moved them since)
+    assert float(torch.sigmoid(tr.par["opacity"].detach()).max()) > 0.011          # (the reset at 150 capped every opacity at 0.01; Adam has moved them since)
     _check_step_against_oracle(tr, 291)
     for it in range(292, 300):
         tr.step(it)
