@@ -272,6 +272,11 @@ struct PassCtx {
     bool* seg_used = nullptr;      // out (forward) / in (backward): this group's compositing kernels run the split-tile launch list
     bool seg_ready = false;        // the previous group's backward built a launch list for this one (list[spec.parity ^ 1])
     uint32_t hold_after = 2u;      // native loop: failed verifications of a tile before it is left with its complete list for a while (k_render_fwd, tile_hold)
+    // Blocks of a launch list.  A list is built one group ahead (by the previous group's backward) for a launch whose size the host
+    // fixed when it enqueued THAT group: seg_grid = blocks this group's compositing kernels are launched with (what its list was built
+    // for), seg_grid_next = what the list this group builds may use.  Both 0: the workspace's full budget.
+    int seg_grid = 0, seg_grid_next = 0;
+    uint32_t* seg_host_total = nullptr;      // pinned: blocks the most recently built list holds (the host's hint for later launches)
 };
 // gsr_forward_speculative: bounds, flags, cursors and the unsorted bins live in the caller's persistent state buffer
 // instead of the per-call image / binning buffers (which then only hold what the backward reads)
@@ -857,8 +862,9 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
                      full_bins ? im.tile_count : (uint32_t*)nullptr, (P < (1 << 28)) ? 1 : 0, \
                      (cx.native_loop && !sp.state && sp.mode != 0) ? im.tile_hold : (uint32_t*)nullptr, sg
         if (by_tile) {
-            if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS>), dim3(use_seg ? im.seg_budget : ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
-            else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS>), dim3(use_seg ? im.seg_budget : ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+            const int fgrid = use_seg ? ((cx.seg_grid > 0 && cx.seg_grid <= im.seg_budget) ? cx.seg_grid : im.seg_budget) : ntiles;
+            if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS>), dim3(fgrid), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
+            else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS>), dim3(fgrid), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
         } else if (full_bins) {
             if (n_touched) hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_BINS_FULL>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
             else hipLaunchKernelGGL((k_render_fwd<false, GSR_LIST_BINS_FULL>), dim3(ntiles), dim3(GSR_BLOCK), 0, st, GSR_FWD_ARGS);
@@ -1003,13 +1009,14 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         // (the forward of this group split its heavy tiles: the same launch list, the same blocks -- gsr::SegCtl)
         const bool use_seg = cx.seg && cx.seg_used && *cx.seg_used && im.seg_budget > 0;
         const gsr::SegCtl sg = use_seg ? gsr::SegCtl{im.seg_list[cx.spec.parity ^ 1], im.seg_cnt, im.seg_pub, im.seg_rec, im.seg_ticket, im.seg_nosplit, cx.guard.tag, im.seg_len} : gsr::SegCtl{};
-        const int kgrid = use_seg ? im.seg_budget : ntiles;
+        const int kgrid = use_seg ? ((cx.seg_grid > 0 && cx.seg_grid <= im.seg_budget) ? cx.seg_grid : im.seg_budget) : ntiles;
+        const int next_budget = (cx.seg_grid_next > 0 && cx.seg_grid_next <= im.seg_budget) ? cx.seg_grid_next : im.seg_budget;
         // (... and one more workgroup builds the next group's list from the work this group's forward measured; the forward's order array is
         // its scratch: the next forward either runs the list or has the preprocess kernel compute its order afresh)
         const bool build = cx.seg && im.seg_budget > 0 && cx.native_loop && balanced;
-        const gsr::SegBuild sb = build ? gsr::SegBuild{im.tile_work[0], im.tile_order[0], im.seg_list[cx.spec.parity], im.seg_nosplit, ntiles, im.seg_budget, kgrid, im.seg_len,
+        const gsr::SegBuild sb = build ? gsr::SegBuild{im.tile_work[0], im.tile_order[0], im.seg_list[cx.spec.parity], im.seg_nosplit, ntiles, next_budget, kgrid, im.seg_len,
                                                         (cx.spec.mode != 0 && !cx.spec.state && !(cx.flags & GSR_REFINE_NO_DILATE)) ? im.zb[cx.spec.parity] : (float*)nullptr, im.zbc[cx.spec.parity], gx, gy, im.sbx,
-                                                        im.zb_own[cx.spec.parity], im.nodilate} : gsr::SegBuild{};
+                                                        im.zb_own[cx.spec.parity], im.nodilate, cx.seg_host_total} : gsr::SegBuild{};
         if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(kgrid + (build ? 1 : 0)), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag, sg, sb);
         else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(kgrid + (build ? 1 : 0)), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag, sg, sb);
 #undef GSR_BWD_ARGS
@@ -1250,6 +1257,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     float* h_status = ctx_lease.c->h_status;
     auto slot_of = [&](int g) { return reinterpret_cast<volatile uint32_t*>(h_status + 8 * (g & 1)); };
     *slot_of(0) = 0u; *slot_of(1) = 0u;
+    *reinterpret_cast<volatile uint32_t*>(h_status + 6) = 0u;          // (blocks the most recent split-tile launch list holds: see seg_grid)
     // Waits until the pose step of group `g` has published its status word (sequence bits == g + 1) and returns it in `word`.
     // The kernel writes the slot itself, so there is no copy and no event.  A few thousand polls cover the common case (the
     // status is at most one group away); after that the thread yields between polls -- with several frames in flight per GPU
@@ -1311,7 +1319,9 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     cx.seg = a->speculative && !cx.det && !(a->flags & GSR_REFINE_NO_SPLIT) &&
              seg_budget_of(((a->width + GSR_TILE - 1) / GSR_TILE) * ((a->height + GSR_TILE - 1) / GSR_TILE)) > 0;
     bool seg_used = false, seg_built = false;
+    int seg_next_grid = 0;
     cx.seg_used = &seg_used;
+    cx.seg_host_total = reinterpret_cast<uint32_t*>(h_status + 6);
     int n_lean = 0;
     cx.n_lean = &n_lean;
     // warm start: the previous call on this workspace left its last bounds in buffer warm_buf (0 / 1); iteration 0 must
@@ -1436,6 +1446,16 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         cx.cov_cache = cov_cached ? 2 : 1;
         cov_cached = true;
         cx.seg_ready = seg_built;      // (the group enqueued before this one left a launch list for it)
+        // launch sizes: this group runs the list its predecessor built for `seg_next_grid` blocks; the list it builds itself may use what
+        // the most recent finished builder needed (+ an eighth + 64), never less than a block per tile, never more than the workspace holds
+        cx.seg_grid = seg_next_grid;
+        {
+            const int nt_ = ((a->width + GSR_TILE - 1) / GSR_TILE) * ((a->height + GSR_TILE - 1) / GSR_TILE);
+            const int budget_ = seg_budget_of(nt_);
+            const uint32_t hint = *reinterpret_cast<volatile uint32_t*>(h_status + 6);
+            seg_next_grid = (hint == 0u) ? budget_ : std::min(budget_, std::max(nt_, (int)(hint + hint / 8u + 64u)));
+            cx.seg_grid_next = seg_next_grid;
+        }
 #ifndef GSR_HOLD_AFTER
 #define GSR_HOLD_AFTER 2u
 #endif

@@ -506,7 +506,8 @@ __device__ __forceinline__ void tile_order_block(const uint32_t* __restrict__ wo
 #define GSR_SEG_MAX 32             // segments per tile at most
 #define GSR_SEG_BUILD_MAX_TILES 4096      // (16 launch positions per thread, kept in registers)
 __device__ __forceinline__ void seg_list_build(const uint32_t* __restrict__ work, const uint32_t* __restrict__ order, uint32_t* __restrict__ list,
-                                               uint32_t* __restrict__ nosplit, int ntiles, int budget, const uint32_t* __restrict__ len)
+                                               uint32_t* __restrict__ nosplit, int ntiles, int budget, const uint32_t* __restrict__ len,
+                                               uint32_t* __restrict__ host_total)
 {
     __shared__ uint32_t s_sum[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -577,6 +578,7 @@ __device__ __forceinline__ void seg_list_build(const uint32_t* __restrict__ work
             if (hold[i] != 0u) nosplit[tl[i]] = hold[i] - 1u;
         }
     for (int b = (int)total + tid; b < budget; b += blockDim.x) list[b] = 0xFFFFFFFFu;
+    if (host_total != nullptr && tid == 0) *reinterpret_cast<volatile uint32_t*>(host_total) = total;
 }
 
 // What the walk keeps per Gaussian between its passes over the image (registers): the span test without the terms only
@@ -1793,6 +1795,7 @@ struct SegBuild {
     // Deeper bounds only make lists longer: results cannot depend on it.
     float* zb; float* zbc; int gx, gy, sbx;
     float* zb_own; uint32_t* nodilate;      // out: every tile's own bound (before widening); per tile: forwards it still goes without widening
+    uint32_t* host_total;                   // out (nullable, pinned host memory): blocks the list holds -- the host sizes later launches by it
 };
 #ifndef GSR_BOUND_DILATE_RATIO
 #define GSR_BOUND_DILATE_RATIO 1.25f
@@ -2995,7 +2998,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         __shared__ uint32_t s_cls2[GSR_BLOCK];
         tile_order_from_work(sb.work, sb.order, sb.ntiles, s_cls2);
         __syncthreads();
-        seg_list_build(sb.work, sb.order, sb.list, sb.nosplit, sb.ntiles, sb.budget, sb.len);
+        seg_list_build(sb.work, sb.order, sb.list, sb.nosplit, sb.ntiles, sb.budget, sb.len, sb.host_total);
         if (sb.zb != nullptr) {
             __syncthreads();
             dilate_bounds(sb, reinterpret_cast<float*>(sb.order));      // (the order array has served its purpose)
