@@ -736,7 +736,16 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     rc = zl.flush(st); if (rc != GSR_OK) return rc;
     {
         ProfScope ps(K_PREPROCESS, st);
-        pa.zbc_lds = (pa.zbc != nullptr && im.nsb <= 4096) ? im.nsb : 0;
+        // (the bounds the conservative tests look at: per tile while they fit the LDS comfortably -- 4 096 tiles: 16 KB + the coarser levels --,
+        // per 4 x 4-tile superblock above that)
+// (measured in round 5 with 4 096: nothing gained -- S-1M-640-object's preprocess kernel 72.7 us either way, the uniform cloud's +1 us for
+// the larger table -- so it is off; -DGSR_PYR_TILES_MAX=4096 builds it)
+#ifndef GSR_PYR_TILES_MAX
+#define GSR_PYR_TILES_MAX 0
+#endif
+        pa.pyr_tiles = (pa.zbc != nullptr && pa.zb != nullptr && ntiles <= GSR_PYR_TILES_MAX) ? 1 : 0;
+        pa.zbc_lds = pa.pyr_tiles ? ntiles : ((pa.zbc != nullptr && im.nsb <= 4096) ? im.nsb : 0);
+        const size_t pyr_bytes = (pa.zbc_lds > 0 ? (pa.pyr_tiles ? bound_pyramid_floats(gx, gy) : bound_pyramid_floats(im.sbx, im.sby)) : 0) * sizeof(float);
         // (k_preprocess_lean trades parallelism for instruction count -- a wave per 256 Gaussians: it pays from a few hundred thousand
         // Gaussians on; a 50 k map keeps the one-lane-per-Gaussian kernel: 8 270 against 7 015 it/s)
         // (cov_cache == 2: the workspace holds every Gaussian's covariance AND the extent bound the conservative test reads)
@@ -770,9 +779,9 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
             const int wblocks = GSR_LEAN_WINDOW / 4;
             const int lblocks = std::max(((P + GSR_LEAN_PER_LANE * GSR_BLOCK - 1) / (GSR_LEAN_PER_LANE * GSR_BLOCK) + wblocks - 1) / wblocks * wblocks, balanced ? 2 : 1);
             // (LDS: the superblock bounds and the coarser levels the kernel builds behind them)
-            hipLaunchKernelGGL(k_preprocess_lean, dim3(lblocks), dim3(GSR_BLOCK), bound_pyramid_floats(im.sbx, im.sby) * sizeof(float), st, pa);
+            hipLaunchKernelGGL(k_preprocess_lean, dim3(lblocks), dim3(GSR_BLOCK), pyr_bytes, st, pa);
         } else
-            hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(GSR_BLOCK), (pa.zbc_lds > 0 ? bound_pyramid_floats(im.sbx, im.sby) : 0) * sizeof(float), st, pa);
+            hipLaunchKernelGGL(k_preprocess, dim3(blocks), dim3(GSR_BLOCK), pyr_bytes, st, pa);
     }
     LAUNCHCHK("k_preprocess");
     // SH colours only feed the compositing kernel: fork them onto the side stream, join before K6.  (Not on the
@@ -1738,6 +1747,7 @@ int gsr_debug_lean_check(const gsr_refine_args* a, long long out[5])
     pa.fx = a->width / (2.0f * a->tan_fovx); pa.fy = a->height / (2.0f * a->tan_fovy);
     pa.cov3D_pre = g.cov3D; pa.lam = g.lam;
     pa.zb = im.zb[buf]; pa.zbc = im.zbc[buf]; pa.sbx = im.sbx; pa.sby = im.sby;
+    pa.pyr_tiles = (pa.gx * pa.gy <= GSR_PYR_TILES_MAX) ? 1 : 0;
     pa.zb_mul = 1.05f; pa.zb_add = 0.05f;
     unsigned long long* d = reinterpret_cast<unsigned long long*>(im.loss_shards);      // scratch (gsr_refine clears these words when it starts)
     HIPCHK(hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), st));

@@ -258,7 +258,8 @@ struct PreArgs {
     const float* zb;                       // speculative per-tile depth bounds of the native loop (nullable): the depth each
     float zb_mul, zb_add;                  // tile had to look at; an instance is kept if z <= zb * zb_mul + zb_add
     const float* zbc; int sbx, sby;        // the same per 4x4-tile superblock (max of its tiles): quick reject; sbx x sby superblocks
-    int zbc_lds;                           // k_preprocess: number of superblock bounds staged in LDS (0: read from global)
+    int zbc_lds;                           // k_preprocess: number of bounds staged in LDS (0: read the superblock bounds from global)
+    int pyr_tiles;                         // ... 1: they are the per-TILE bounds zb (gx x gy, round 5), 0: the per-superblock bounds zbc (sbx x sby)
     int lean;                              // k_preprocess: radii of this forward are not an output (see the kernel)
     // bin-by-tile path (nullable): per-tile append cursors and fixed-capacity bins of (depth bits << 32 | index)
     uint32_t* tile_cursor; unsigned long long* bins; int bin_cap;      // (bin_cap: entries per bin; bins sit bin_cap + GSR_BIN_PAD entries apart)
@@ -644,12 +645,15 @@ __device__ __forceinline__ float view_norm2_bound(const float* view)
 // conservative pass took 45 k cycles instead of 22 k: that pass, not the exact one, was the kernel's slow tail,
 // profiles/r03_phase_clocks.md.)  Coarser cells only make the test more conservative.
 // (largest superblock bound under the non-empty tile rectangle [x0, x1) x [y0, y1))
+// (shift: 2 = the finest level's cells are 4 x 4-tile superblocks, 0 = they are tiles -- round 5: a splat inside a dense object one
+// superblock wide saw its neighbours' deep background bounds and stayed a candidate: half a million candidates per iteration on
+// S-1M-640-object, the preprocess kernel at 72 us against 35 on the uniform cloud)
 template <bool MIP>
-__device__ __forceinline__ float rect_bound_max(const float* zbc, int sbx, int sby, int x0, int y0, int x1, int y1)
+__device__ __forceinline__ float rect_bound_max(const float* zbc, int sbx, int sby, int x0, int y0, int x1, int y1, int shift = 2)
 {
     float zc = 0.f;
     if (MIP) {
-        int sx0 = x0 >> 2, sx1 = (x1 - 1) >> 2, sy0 = y0 >> 2, sy1 = (y1 - 1) >> 2, w = sbx, h = sby, off = 0;
+        int sx0 = x0 >> shift, sx1 = (x1 - 1) >> shift, sy0 = y0 >> shift, sy1 = (y1 - 1) >> shift, w = sbx, h = sby, off = 0;
         while (sx1 - sx0 > 2 || sy1 - sy0 > 2) {
             off += w * h; w = (w + 1) >> 1; h = (h + 1) >> 1;
             sx0 >>= 1; sx1 >>= 1; sy0 >>= 1; sy1 >>= 1;
@@ -659,8 +663,8 @@ __device__ __forceinline__ float rect_bound_max(const float* zbc, int sbx, int s
 #pragma unroll
             for (int dx = 0; dx < 3; dx++) zc = fmaxf(zc, zbc[off + min(sy0 + dy, sy1) * w + min(sx0 + dx, sx1)]);
     } else {
-        for (int sy = y0 >> 2; sy <= (y1 - 1) >> 2; sy++)
-            for (int sx = x0 >> 2; sx <= (x1 - 1) >> 2; sx++) zc = fmaxf(zc, zbc[sy * sbx + sx]);
+        for (int sy = y0 >> shift; sy <= (y1 - 1) >> shift; sy++)
+            for (int sx = x0 >> shift; sx <= (x1 - 1) >> shift; sx++) zc = fmaxf(zc, zbc[sy * sbx + sx]);
     }
     return zc;
 }
@@ -680,7 +684,7 @@ __device__ __forceinline__ bool lean_candidate(const PreArgs& a, float3 p, float
     int x0, y0, x1, y1;
     get_rect(pxf, pyf, (int)rb, a.gx, a.gy, x0, y0, x1, y1);
     if ((x1 - x0) * (y1 - y0) == 0) return false;
-    const float zc = rect_bound_max<MIP>(zbc, a.sbx, a.sby, x0, y0, x1, y1);
+    const float zc = a.pyr_tiles ? rect_bound_max<MIP>(zbc, a.gx, a.gy, x0, y0, x1, y1, 0) : rect_bound_max<MIP>(zbc, a.sbx, a.sby, x0, y0, x1, y1, 2);
     return !(pview.z > zc * a.zb_mul + a.zb_add);
 }
 // Appends the coarser levels behind the sbx x sby superblock bounds in s (LDS, all threads of the workgroup; s[0, sbx * sby) staged
@@ -814,8 +818,9 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
                     if (a.zb != nullptr) {
                         // behind the bound of every superblock the rectangle overlaps => behind every tile's bound
                         // (s_zbc: the bounds in LDS with the coarser levels behind them, build_bound_pyramid; otherwise global memory)
-                        const float zc = (s_zbc != nullptr && a.zbc_lds > 0) ? rect_bound_max<true>(s_zbc, a.sbx, a.sby, x0, y0, x1, y1)
-                                                                              : rect_bound_max<false>(a.zbc, a.sbx, a.sby, x0, y0, x1, y1);
+                        const float zc = (s_zbc != nullptr && a.zbc_lds > 0) ? (a.pyr_tiles ? rect_bound_max<true>(s_zbc, a.gx, a.gy, x0, y0, x1, y1, 0)
+                                                                                             : rect_bound_max<true>(s_zbc, a.sbx, a.sby, x0, y0, x1, y1, 2))
+                                                                              : rect_bound_max<false>(a.zbc, a.sbx, a.sby, x0, y0, x1, y1, 2);
                         far_everywhere = pview.z > zc * a.zb_mul + a.zb_add;
                     }
                     if (a.bins == nullptr || wout != nullptr) {
@@ -904,6 +909,9 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
                 f_pos[k] = (uint32_t)a.bin_cap;
                 if (f_in[k]) {
                     atomicAdd(&ocnt[f_src[k]], 1u);
+                    // (appends of one wave to the SAME tile grouped into one atomic -- a wave-uniform loop of ballots over up to 12 / 32 distinct
+                    // tiles per sub-round -- were measured in round 5 for S-1M-640-object, whose hot tiles take ~4 000 appends per iteration:
+                    // this kernel 75 -> 78 / 86 us there, 36 -> 44 / 47 us on the uniform cloud.  The queue at the hot cursors is not what it waits for.)
                     f_pos[k] = atomicAdd(&a.tile_cursor[f_tile[k] * GSR_CURSOR_STRIDE], 1u);
                 }
             }
@@ -1024,9 +1032,10 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
     if (a.guard.poisoned()) return;
     GSR_T_DECL
     if (a.zbc_lds > 0) {
-        for (int i = tid; i < a.zbc_lds; i += GSR_BLOCK) s_zbc[i] = a.zbc[i];
+        const float* bsrc = a.pyr_tiles ? a.zb : a.zbc;
+        for (int i = tid; i < a.zbc_lds; i += GSR_BLOCK) s_zbc[i] = bsrc[i];
         __syncthreads();
-        build_bound_pyramid(s_zbc, a.sbx, a.sby);
+        build_bound_pyramid(s_zbc, a.pyr_tiles ? a.gx : a.sbx, a.pyr_tiles ? a.gy : a.sby);
     }
     const int idx = blockIdx.x * GSR_BLOCK + tid;
     if (a.tile_count != nullptr && idx < a.ntiles) a.tile_count[idx] = 0u;      // (k_tile_count adds into them next)
@@ -1068,9 +1077,12 @@ __global__ void __launch_bounds__(GSR_BLOCK, GSR_LEAN_OCC) k_preprocess_lean(Pre
     }
     if (a.guard.poisoned()) return;
     GSR_T_DECL
-    for (int i = tid; i < a.zbc_lds; i += GSR_BLOCK) s_zbc[i] = a.zbc[i];
+    {
+        const float* bsrc = a.pyr_tiles ? a.zb : a.zbc;
+        for (int i = tid; i < a.zbc_lds; i += GSR_BLOCK) s_zbc[i] = bsrc[i];
+    }
     __syncthreads();
-    build_bound_pyramid(s_zbc, a.sbx, a.sby);
+    build_bound_pyramid(s_zbc, a.pyr_tiles ? a.gx : a.sbx, a.pyr_tiles ? a.gy : a.sby);
     GSR_T_TICK(0)
     const bool frozen = a.guard.frozen();
     if (blockIdx.x == 0 && tid == 0) {      // the null splat
@@ -1185,8 +1197,9 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_lean_check(PreArgs a, unsigned lo
     bool cand = false;
     uint32_t cnt = 0;
     if (pview.z > 0.2f) {
-        // (the bounds without the coarser levels k_preprocess_lean adds in LDS: what this settles is a superset of what the kernel settles)
-        cand = lean_candidate<false>(a, p, pview, a.lam[4 * (size_t)idx + 3], view_norm2_bound(a.view), a.zbc);
+        // (the bounds without the coarser levels k_preprocess_lean adds in LDS -- the exact maximum over the rectangle's tiles, or over its
+        // superblocks where the kernel starts from those: what this settles is a superset of what the kernel settles)
+        cand = lean_candidate<false>(a, p, pview, a.lam[4 * (size_t)idx + 3], view_norm2_bound(a.view), a.pyr_tiles ? a.zb : a.zbc);
         const float4 ph = xform4x4(p, a.proj);
         const float pw = 1.0f / (ph.w + 0.0000001f);
         const float3 pproj = make_float3(ph.x * pw, ph.y * pw, ph.z * pw);
