@@ -500,7 +500,12 @@ __device__ __forceinline__ void tile_order_block(const uint32_t* __restrict__ wo
 // would only add pass A to everybody's bill (a scene whose tiles are all equally heavy is left alone).  The blocks must fit the
 // launch (budget >= ntiles): L grows until they do.  One workgroup; the first GSR_BLOCK threads work.
 #define GSR_SEG_WORK_MIN 24u
+#ifndef GSR_SEG_KEYS
 #define GSR_SEG_KEYS 192u          // keys per segment the launch list aims at
+#endif
+#ifndef GSR_SEG_SPLIT_HALVES
+#define GSR_SEG_SPLIT_HALVES 4u    // a tile is split when its work exceeds this many HALVES of L = max(mean work, GSR_SEG_WORK_MIN)
+#endif
 #ifndef GSR_BWD_SEG_MERGE
 #define GSR_BWD_SEG_MERGE 1u       // forward segments per workgroup of the backward compositing kernel (measured, S-1M-640-object: 1 -> 93 us, 2 -> 106, 3 -> 129)
 #endif
@@ -541,7 +546,7 @@ __device__ __forceinline__ void seg_list_build(const uint32_t* __restrict__ work
     // 500 - 1 300 keys cost more than a whole median tile, most of it barriers between their staging batches and the LDS sort)
     uint32_t Lk = GSR_SEG_KEYS;
     auto nseg_of = [&](uint32_t w, uint32_t h, uint32_t n) -> uint32_t {
-        if (w <= 2u * L || h != 0u) return 1u;
+        if (2u * w <= GSR_SEG_SPLIT_HALVES * L || h != 0u) return 1u;
         return min((uint32_t)GSR_SEG_MAX, max((w + L - 1u) / L, (n + Lk - 1u) / Lk));
     };
     uint32_t total = 0u, local = 0u;
@@ -3007,7 +3012,12 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
     // without its reading every survivor's 48-byte record: on complete lists nine survivors in ten were never blended.)
     __shared__ BwdMfmaLDS s;
     const GSR_CONST_AS float* crec = (const GSR_CONST_AS float*)rec;      // (constant address space + wave-uniform offsets: s_load)
-    if (sb.list != nullptr && (int)blockIdx.x == sb.block) {          // (also on a frozen iteration: its retry runs the list)
+    // (the extra workgroup is block 0, everybody else's number is blockIdx.x - 1: dispatched first, its serial chain -- order, list, bounds --
+    // runs next to the whole launch.  As the LAST block it started only when a slot came free, i.e. after the first round of tiles on an
+    // image with more tiles than resident workgroups, and the launch ended that much later: S-3M-cam 852x480 / 1024x576, K7 68 -> 86 /
+    // 78 -> 106 us)
+    const uint32_t bid = blockIdx.x - (sb.list != nullptr ? 1u : 0u);
+    if (sb.list != nullptr && blockIdx.x == 0u) {          // (also on a frozen iteration: its retry runs the list)
         __shared__ uint32_t s_cls2[GSR_BLOCK];
         tile_order_from_work(sb.work, sb.order, sb.ntiles, s_cls2);
         __syncthreads();
@@ -3026,11 +3036,11 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
     int tile;
     uint32_t seg = 0u, nseg = 1u;
     if (sg.list != nullptr) {
-        const uint32_t e = sg.list[blockIdx.x];
+        const uint32_t e = sg.list[bid];
         if (e == 0xFFFFFFFFu) return;
         tile = (int)(e & 0xFFFFu); seg = (e >> 16) & 0xFFu; nseg = e >> 24;
-    } else tile = tile_order ? (int)tile_order[blockIdx.x] : xcd_remap(blockIdx.x, ntiles);
-    const uint32_t first = blockIdx.x - seg;
+    } else tile = tile_order ? (int)tile_order[bid] : xcd_remap((int)bid, ntiles);
+    const uint32_t first = bid - seg;
     uint32_t lo_pos = 0u, hi_pos = 0x7FFFFFFFu, seg_end = seg + 1u;      // (seg_end: one past the last forward segment of this workgroup's window)
     if (nseg > 1u) {
         if ((sg.cnt[first] & 0xFFFFu) == 0u) {          // the forward did not split this tile after all: segment 0 has all of it
