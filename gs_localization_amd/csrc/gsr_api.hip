@@ -109,11 +109,23 @@ struct Geom {   // per-Gaussian state carried from forward to backward
     float* rec;               // packed splat records (GSR_REC_*), P + 1
     float* lam;               // per-Gaussian float4 (mean, bound on sqrt(lambda_max(Sigma))) (PreArgs::lam), valid whenever cov3D holds every covariance
     uint8_t* aflag;           // 2 n bytes: "the compositing backward added to this Gaussian's record / to its colour sums" (K7 sets, K8 clears)
+    // Native loop (carve_geom(..., loop = true)): what one iteration hands from its forward to its chain-rule kernel exists TWICE and the
+    // kernel groups alternate (gsr::PreBwdArgs::role): set [0] is the arrays above, set [1] sits behind them.  select_set() points the
+    // plain members at one set and o_* at the other.
+    gsr::SurvLists surv2[2]; uint8_t* aflag2[2]; float* acc2[2]; float* rec2[2]; uint8_t* clamped2[2];
+    gsr::SurvLists o_surv; uint8_t* o_aflag; float* o_acc; float* o_rec; uint8_t* o_clamped;
+    float* prev_cam;          // 35 floats: the camera in front of the most recent pose step (gsr::PoseStepArgs::prev_cam)
+    uint32_t* final_done;     // one word (gsr::PreBwdArgs::final_done)
+    void select_set(int k)
+    {
+        surv = surv2[k]; aflag = aflag2[k]; acc = acc2[k]; rec = rec2[k]; clamped = clamped2[k];
+        o_surv = surv2[k ^ 1]; o_aflag = aflag2[k ^ 1]; o_acc = acc2[k ^ 1]; o_rec = rec2[k ^ 1]; o_clamped = clamped2[k ^ 1];
+    }
 };
 // `det`: the deterministic option's accumulator records are twelve PAIRS of 64-bit words (192 B) instead of twelve floats (48 B).
 // The records sit at the END of the workspace, so that every other array has the same place in either mode and only the size asked
 // for depends on it (every caller used to pay 192 B per Gaussian for an option only tests use).
-size_t carve_geom(char* base, int P, Geom& g, bool det = false)
+size_t carve_geom(char* base, int P, Geom& g, bool det = false, bool loop = false)
 {
     Carver c(base);
     const size_t n = P > 0 ? (size_t)P : 1;
@@ -129,7 +141,22 @@ size_t carve_geom(char* base, int P, Geom& g, bool det = false)
     g.surv.ids = c.take<uint32_t>((size_t)GSR_SURV_LISTS * g.surv.cap);
     g.lam = c.take<float>(4 * n);
     g.aflag = c.take<uint8_t>(2 * n);
+    g.surv2[0] = g.surv; g.aflag2[0] = g.aflag; g.rec2[0] = g.rec; g.clamped2[0] = g.clamped;
+    g.surv2[1] = g.surv; g.aflag2[1] = g.aflag; g.rec2[1] = g.rec; g.clamped2[1] = g.clamped;
+    g.prev_cam = nullptr; g.final_done = nullptr;
+    if (loop) {      // (in front of the records, whose size depends on `det`: a loop passes the same `det` to every carving of its workspace)
+        g.surv2[1].n = c.take<uint32_t>((size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE);
+        g.surv2[1].ids = c.take<uint32_t>((size_t)GSR_SURV_LISTS * g.surv.cap);
+        g.aflag2[1] = c.take<uint8_t>(2 * n);
+        g.rec2[1] = c.take<float>((n + 1) * GSR_REC_STRIDE);
+        g.clamped2[1] = c.take<uint8_t>(n);
+        g.prev_cam = c.take<float>(64);
+        g.final_done = reinterpret_cast<uint32_t*>(g.prev_cam ? g.prev_cam + 48 : nullptr);
+    }
     g.acc = c.take<float>((det ? 4 : 1) * GSR_ACC_STRIDE * n);
+    g.acc2[0] = g.acc; g.acc2[1] = g.acc;
+    if (loop) g.acc2[1] = c.take<float>((det ? 4 : 1) * GSR_ACC_STRIDE * n);
+    g.select_set(0);
     return c.size();
 }
 
@@ -268,6 +295,8 @@ struct PassCtx {
     bool exact_bins = false;       // complete lists through count -> scan -> emit (after a bin of k_preprocess_bin overflowed; diagnostics)
     bool* used_full_bins = nullptr;   // out: this forward binned its complete lists into fixed-capacity bins (k_preprocess_bin)
     bool det = false;              // deterministic option (GSR_REFINE_DETERMINISTIC / debug bit 2 of the backward): integer sums across workgroups
+    gsr::PreBwdArgs* pb_out = nullptr;   // native loop: the chain-rule kernel's arguments of this group, kept for the final pass (gsr_refine)
+    int set = 0;                   // native loop: which of the two sets of work lists / flags / records / splat records this group uses (Geom::select_set)
     bool seg = false;              // native loop: the image workspace has the split-tile arrays (gsr::SegCtl) and speculative forwards may use them
     bool* seg_used = nullptr;      // out (forward) / in (backward): this group's compositing kernels run the split-tile launch list
     bool seg_ready = false;        // the previous group's backward built a launch list for this one (list[spec.parity ^ 1])
@@ -635,10 +664,11 @@ int forward_impl(const PassCtx& cx, GSR_FWD_PARAMS)
     const SpecCtx& sp = cx.spec;
 
     Geom g;
-    const size_t gbytes = carve_geom(nullptr, P, g, cx.det);
+    const size_t gbytes = carve_geom(nullptr, P, g, cx.det, cx.native_loop);
     char* gptr = (char*)geometry_buffer(geometry_ctx, gbytes);
     if (!gptr) return fail(GSR_E_ALLOC, "geometry buffer callback returned NULL%s", "");
-    carve_geom(gptr, P, g);
+    carve_geom(gptr, P, g, cx.det, cx.native_loop);
+    if (cx.native_loop) g.select_set(cx.set);
     if (!cx.native_loop) note_geometry(gptr, cx.det);      // (gsr_backward checks it: see geometry_sized_for_det)
     Img im;
     const size_t ibytes = carve_img(nullptr, width, height, im, cx.seg);
@@ -943,7 +973,8 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     const int ntiles = gx * gy;
     const float focal_y = height / (2.0f * tan_fovy);
     const float focal_x = width / (2.0f * tan_fovx);
-    Geom g; carve_geom(geom_buffer, P, g);
+    Geom g; carve_geom(geom_buffer, P, g, cx.det, cx.native_loop);
+    if (cx.native_loop) g.select_set(cx.set);
     // (the ordered index lists sit at the start of the binning buffer on both binning paths; ranges[] says where)
     const uint32_t* point_list = reinterpret_cast<const uint32_t*>(binning_buffer);
     Img im; carve_img(img_buffer, width, height, im, cx.seg);
@@ -1047,13 +1078,17 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     pb.pose = pose_mode ? 1 : 0; pb.tau_acc = g.tau_acc;
     pb.dirty = cx.native_loop ? g.dirty : nullptr;
     pb.aflag = g.aflag;
+    pb.role = cx.native_loop ? 1 : 0;
+    pb.o_surv = g.o_surv; pb.o_aflag = g.o_aflag; pb.o_acc = g.o_acc; pb.o_rec = g.o_rec; pb.o_clamped = g.o_clamped;
+    pb.o_cam = g.prev_cam; pb.final_done = g.final_done;
     pb.guard = cx.guard;
     pb.ticket = cx.ticket; pb.fold = cx.fold;
-    if (pb.ticket) pb.fold.tau_acc = g.tau_acc;
+    if (pb.ticket) { pb.fold.tau_acc = g.tau_acc; pb.fold.prev_cam = g.prev_cam; }
     pb.fold.det = cx.det ? 1 : 0;
     {
         ProfScope ps(K_PREPROCESS_BWD, st);
         pb.surv = g.surv;
+        if (cx.pb_out) *cx.pb_out = pb;
         // (launching only as many waves as the survivors' lists have chunks -- 256 instead of 2 048 in a speculative iteration --
         // was measured in round 4: 24.0 against 24.3 us; the waves that find nothing cost nothing)
         const int k8_grid = surv_grid(P, GSR_K8_RESIDENT);
@@ -1353,9 +1388,9 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         // vouches for them (carried bit 0)
         const size_t Pn = (size_t)a->P;
         Geom gg;
-        char* gptr = (char*)cached_resize(&gb, carve_geom(nullptr, a->P, gg, cx.det));
+        char* gptr = (char*)cached_resize(&gb, carve_geom(nullptr, a->P, gg, cx.det, true));
         if (!gptr) return fail(GSR_E_ALLOC, "geometry buffer callback returned NULL%s", "");
-        carve_geom(gptr, a->P, gg);
+        carve_geom(gptr, a->P, gg, cx.det, true);
         if (!(carried & 1)) {
             HIPCHK(hipMemsetAsync(a->dL_dmean2D, 0, Pn * 3 * sizeof(float), st));
             HIPCHK(hipMemsetAsync(a->dL_dconic, 0, Pn * 4 * sizeof(float), st));
@@ -1367,9 +1402,11 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             if (a->dL_dscale) HIPCHK(hipMemsetAsync(a->dL_dscale, 0, Pn * 3 * sizeof(float), st));
             if (a->dL_drot) HIPCHK(hipMemsetAsync(a->dL_drot, 0, Pn * 4 * sizeof(float), st));
             // K7's accumulator records: cleared once here, afterwards K8 clears every record it consumes
-            HIPCHK(hipMemsetAsync(gg.acc, 0, Pn * GSR_ACC_STRIDE * (cx.det ? 2 * sizeof(long long) : sizeof(float)), st));
+            for (int k = 0; k < 2; k++) {
+                HIPCHK(hipMemsetAsync(gg.acc2[k], 0, Pn * GSR_ACC_STRIDE * (cx.det ? 2 * sizeof(long long) : sizeof(float)), st));
+                HIPCHK(hipMemsetAsync(gg.aflag2[k], 0, 2 * Pn, st));
+            }
             HIPCHK(hipMemsetAsync(gg.dirty, 0, Pn, st));
-            HIPCHK(hipMemsetAsync(gg.aflag, 0, 2 * Pn, st));
         }
         PoseLoadArgs pl{};
         if (a->init_R) {
@@ -1390,7 +1427,9 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             auto add = [&](void* ptr, size_t words) { cr.p[k] = static_cast<uint32_t*>(ptr); cr.n[k] = (uint32_t)words; k++; };
             add(ps + GSR_PS_CONV, 5);                                                   // converged, loss, |tau|, poison, ticket
             add(gg.tau_acc, 2 * 16 * GSR_TAU_SLOTS);                                    // (doubles) then kept clean by the pose step
-            add(gg.surv.n, (size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE);                  // ... and the work-list counters by the chain-rule kernel
+            add(gg.surv2[0].n, (size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE);              // ... and the work-list counters by the chain-rule kernel
+            add(gg.surv2[1].n, (size_t)GSR_SURV_LISTS * GSR_SURV_CSTRIDE);
+            add(gg.final_done, 1);
             add(im0.fail, im0.clear_words);
             add(im0.loss_shards, GSR_LOSS_SHARDS * 16);
             add(im0.tile_work[0], (size_t)(im0.tile_work[1] - im0.tile_work[0]) * 2);
@@ -1405,7 +1444,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             add(im0.tile_hold, (size_t)(im0.tile_work[1] - im0.tile_work[0]));
             // (split tiles: the per-block count / publication words, the per-tile tickets and hold counters -- carved back to back)
             if (im0.seg_budget > 0) add(im0.seg_cnt, (size_t)(reinterpret_cast<uint32_t*>(im0.seg_rec) - im0.seg_cnt));
-            static_assert(sizeof(cr.p) / sizeof(cr.p[0]) >= 11, "ClearRanges too small");
+            static_assert(sizeof(cr.p) / sizeof(cr.p[0]) >= 13, "ClearRanges too small");
             hipLaunchKernelGGL(k_refine_init, dim3(32 + (pl.st != nullptr ? 1 : 0)), dim3(GSR_BLOCK), 0, st, cr, pl);
             { const int debug = 0; LAUNCHCHK("k_refine_init"); }
         }
@@ -1439,6 +1478,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     int last_enq = -1;            // last group whose forward was enqueued: its bounds are the newest
     bool last_full = false;       // ... binned complete lists into fixed-capacity bins (k_preprocess_bin)
     bool last_counted = false;    // ... and it already counted n_touched
+    gsr::PreBwdArgs pb_hist[4] = {};      // the chain-rule launches of the last groups (the final pass below reuses the last stepped one's)
     auto enqueue = [&](int g, int logical, int mode) -> int {
         last_enq = g;
         if (adaptive_margin) {
@@ -1454,6 +1494,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         cx.guard.tag = (uint32_t)(g + 1);
         cx.cov_cache = cov_cached ? 2 : 1;
         cov_cached = true;
+        cx.set = g & 1;                  // (work lists, flags, records, splat records: two sets, see Geom)
+        cx.pb_out = &pb_hist[g & 3];
         cx.seg_ready = seg_built;      // (the group enqueued before this one left a launch list for it)
         // launch sizes: this group runs the list its predecessor built for `seg_next_grid` blocks; the list it builds itself may use what
         // the most recent finished builder needed (+ an eighth + 64), never less than a block per tile, never more than the workspace holds
@@ -1512,6 +1554,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     int streak = 0;                // failed groups in a row
     int n_host_redo = 0;           // forwards the HOST had to redo with complete lists (everything else was retried on the device)
     bool conv_seen = false;        // (stop_on_converged) an update reported convergence: what follows is the frozen render at the final pose
+    int last_step_g = -1;
     bool final_rendered = false;   // ... and that render has been enqueued / verified
     auto enqueue_next = [&](int logical, int mode) -> int {
         const int rc2 = enqueue(enq, logical, mode);
@@ -1522,6 +1565,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     };
     auto after_success = [&](int g, uint32_t w) {      // bookkeeping for a group that passed its verification
         streak = 0;
+        if (!conv_seen) last_step_g = g;                // (the last group whose pose step ran: its records become the gradient rows)
         if (group_mode[g] == 1) {
             fail_streak = 0;
             if (adaptive_margin && ++margin_streak >= 8) { margin_m = fmaxf(0.01f, margin_m * 0.8f); margin_streak = 0; }
@@ -1614,6 +1658,19 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         }
     }
     *iters_done = succ;
+    if (last_step_g >= 0) {
+        // The gradients of the Gaussians' own parameters: rows written once, from the records of the last iteration whose pose step
+        // ran (PreBwdArgs::role).  When the loop converged with a frozen forward behind that iteration, that group's launch has done it
+        // already (and says so in *final_done).
+        gsr::PreBwdArgs f = pb_hist[last_step_g & 3];
+        f.role = 2; f.ticket = nullptr; f.guard = gsr::LoopGuard{nullptr, nullptr, 0u};
+        f.o_surv = f.surv; f.o_aflag = f.aflag; f.o_acc = f.acc; f.o_rec = f.rec; f.o_clamped = f.clamped;
+        ProfScope pfs(K_PREPROCESS_BWD, st);
+        const int k8_grid = surv_grid(a->P, GSR_K8_RESIDENT);
+        if (cx.det) hipLaunchKernelGGL(k_preprocess_bwd<true>, dim3(k8_grid), dim3(64), 0, st, f);
+        else hipLaunchKernelGGL(k_preprocess_bwd<false>, dim3(k8_grid), dim3(64), 0, st, f);
+        LAUNCHCHK("k_preprocess_bwd (final pass)");
+    }
     if (last_enq >= 0 && !last_counted && a->n_touched && gb.ptr && bb.ptr && ib.ptr) {
         // n_touched (fifth output of the pose package's forward) is only wanted for the LAST forward, and counting it
         // costs every iteration's compositing kernel an eighth of its instructions: the loop runs the variant
@@ -1621,7 +1678,8 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         // lists, same geometry, same order: the images it rewrites are bit-identical.  (The last forward ordered its
         // lists as far as its pixels needed them, which is as far as this pass walks.)
         const int gx = (a->width + GSR_TILE - 1) / GSR_TILE, gy = (a->height + GSR_TILE - 1) / GSR_TILE;
-        Geom g; carve_geom((char*)gb.ptr, a->P, g);
+        Geom g; carve_geom((char*)gb.ptr, a->P, g, cx.det, true);
+        g.select_set(last_enq & 1);
         Img im; carve_img((char*)ib.ptr, a->width, a->height, im);
         HIPCHK(hipMemsetAsync(a->n_touched, 0, (size_t)a->P * sizeof(int), st));
         hipLaunchKernelGGL((k_render_fwd<true, GSR_LIST_SORTED>), dim3(gx * gy), dim3(GSR_BLOCK), 0, st, im.ranges,

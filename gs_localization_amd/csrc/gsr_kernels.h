@@ -3405,7 +3405,7 @@ __global__ void k_pose_init(float* st, const float* proj_raw)
 // Every small array a gsr_refine call wants cleared before its first iteration (flags, cursors, counters, partial sums, bounds
 // buffers -- a hundred KB in all), in ONE launch instead of a dozen memsets: what a 20-iteration call spends on enqueueing those
 // is a fifth of an iteration each.  Ranges of 32-bit words; unused ranges have n = 0.
-struct ClearRanges { uint32_t* p[12]; uint32_t n[12]; };
+struct ClearRanges { uint32_t* p[14]; uint32_t n[14]; };
 // gsr_refine_args.init_*: the whole initial pose state from the caller's device tensors (zeros, R, T, exposure, camera); st == nullptr: none.
 // (host_state, nullable: the host's mirror of the pose state in pinned memory, see PoseStepArgs::host_state)
 struct PoseLoadArgs { float* st; const float* R0; const float* T0; const float* ea; const float* eb; const float* proj_raw; float* host_state; };
@@ -3438,7 +3438,7 @@ __global__ void __launch_bounds__(GSR_BLOCK) k_refine_init(ClearRanges c, PoseLo
     const uint32_t nb = gridDim.x - (q.st != nullptr ? 1u : 0u);
     const uint32_t i0 = blockIdx.x * GSR_BLOCK + threadIdx.x, step = nb * GSR_BLOCK;
 #pragma unroll
-    for (int r = 0; r < 12; r++)
+    for (int r = 0; r < 14; r++)
         for (uint32_t i = i0; i < c.n[r]; i += step) c.p[r][i] = 0u;
 }
 
@@ -3482,6 +3482,8 @@ struct PoseStepArgs {
     int det;        // deterministic option: tau_acc holds 12 fixed-point world-frame sums per slot, loss_shards fixed-point sums
     float* host_state;      // nullable, pinned host memory, GSR_PS_SIZE floats: every step that runs mirrors the new state there, so that the
                             // call can hand the final pose back without a device-to-host copy in front of its last synchronisation
+    float* prev_cam;        // nullable, 35 floats: view (16), projection (16), camera position (3) as they were BEFORE this step -- the camera of
+                            // the iteration whose records the final pass of k_preprocess_bwd turns into gradient rows (PreBwdArgs::role)
 };
 struct alignas(16) PoseStepLDS { float st[GSR_PS_SIZE]; float t6[8]; float loss[4]; float proj[16]; };
 template <bool DET>      // (compile time: the deterministic option's branches cost the default path's serial tail 2 k cycles as run-time tests)
@@ -3530,6 +3532,11 @@ __device__ __forceinline__ void pose_step_wave(const PoseStepArgs& q, LoopGuard 
         // (the pose and exposure this group's forward and backward ran with: GSR_PS_PREV; a wave executes in order, no barrier needed)
         if (lane < 12) s.st[GSR_PS_PREV + lane] = va;
         if (lane == GSR_PS_PARAM + 6 || lane == GSR_PS_PARAM + 7) s.st[GSR_PS_PREV + 12 + lane - (GSR_PS_PARAM + 6)] = va;
+        if (q.prev_cam != nullptr) {
+            static_assert(GSR_PS_VIEW == 48 && GSR_PS_PROJ == 64 && GSR_PS_CAMPOS == 80, "prev_cam is copied by lane from these places");
+            if (lane >= GSR_PS_VIEW) q.prev_cam[lane - GSR_PS_VIEW] = va;
+            if (lane < 19) q.prev_cam[16 + lane] = vb;
+        }
         if (q.tau_acc != nullptr && det) {
             double sw[12];
 #pragma unroll
@@ -3693,6 +3700,19 @@ struct PreBwdArgs {
     uint8_t* aflag;                                       // 2 P bytes, set by k_render_bwd_mfma: has sums / has colour sums; cleared here as consumed
     LoopGuard guard;
     SurvLists surv; // the forward's work lists (k_preprocess): the only Gaussians whose records can hold anything
+    // Native loop (role != 0): the gradients of the Gaussians' own parameters are read by nobody before the call returns, so an
+    // iteration's launch only computes dL/dtau (no gradient rows, no dirty bits, nothing consumed) and the rows are written ONCE, from
+    // the records of the last iteration whose pose step ran.  For that the groups alternate between two sets of work lists / flags /
+    // records: a group's launch walks its OWN set for dL/dtau and clears what its predecessor left in the OTHER one (o_*), whose list
+    // counters its last workgroup returns to zero for the forward after next.
+    //   role 1  a group's launch.  Not frozen: dL/dtau from the own set, the other set cleared.  Poisoned (this group's forward failed
+    //           its verification): the other set cleared.  Converged: the group in front of this one was the last iteration -- its set
+    //           (o_*) gets the full treatment, rows and dirty bits, once (*final_done), before a later frozen forward reuses its lists.
+    //   role 2  launched by the host behind the last group: the full treatment of o_* unless *final_done says it has been given.
+    int role;
+    SurvLists o_surv; uint8_t* o_aflag; float* o_acc; uint32_t* final_done;
+    const float* o_rec; const uint8_t* o_clamped;      // (the splat records and SH clamp flags of that set's forward ...
+    const float* o_cam;                                // ... and its camera: PoseStepArgs::prev_cam)
     // Native loop only (ticket nullable): the workgroup that finishes LAST runs the pose step (Adam, update_pose, camera
     // matrices, status for the host) right here instead of in a launch of its own: every workgroup bumps the ticket once its
     // dL/dtau sums are out; whoever draws the last number sees all of them.
@@ -3914,18 +3934,40 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     const int lane = threadIdx.x;
     const bool frozen = a.guard.frozen();      // (a frozen iteration still takes its ticket: the last workgroup publishes the status)
     if (frozen && a.ticket == nullptr) return;
+    // What this launch does (block-uniform; PreBwdArgs::role).  final_done is only ever written by the last workgroup of a launch,
+    // after every workgroup has drawn its ticket: all workgroups of one launch read the same value.
+    const bool conv = a.role == 1 && a.guard.conv != nullptr && *a.guard.conv != 0.f;
+    const bool final_pass = (a.role == 2 || conv) && *a.final_done == 0u;
+    if (a.role == 2 && !final_pass) return;
+    const bool walk = final_pass || !frozen;
+    const bool rows_on = a.role == 0 || final_pass;      // gradient rows and dirty bits written, flags and records consumed
+    const bool tau_on = a.pose != 0 && !final_pass;
+    const bool clear_other = a.role == 1 && !conv;       // (a poisoned group does this part too)
+    const SurvLists wl = final_pass ? a.o_surv : a.surv;
+    uint8_t* const wflag = final_pass ? a.o_aflag : a.aflag;
+    float* const wacc = final_pass ? a.o_acc : a.acc;
+    const float* const wrec = final_pass ? a.o_rec : a.rec;
+    const uint8_t* const wclamped = final_pass ? a.o_clamped : a.clamped;
+    const float* const view = final_pass ? a.o_cam : a.view;
+    const float* const proj = final_pass ? a.o_cam + 16 : a.proj;
+    const float* const campos = final_pass ? a.o_cam + 32 : a.campos;
+    uint8_t* const dirty = rows_on ? a.dirty : nullptr;
+    float* const o_dsh = rows_on ? a.dL_dsh : nullptr;
+    // (the other set's list length, asked for up front: the wait for it hides behind the walk)
+    const uint32_t rb = gridDim.x - 1u - blockIdx.x;      // reversed: the workgroups with chain-rule work sit at the front of the lists
+    const uint32_t o_n = clear_other ? a.o_surv.n[(rb & (GSR_SURV_LISTS - 1)) * GSR_SURV_CSTRIDE] : 0u;
     float tw[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};      // world-frame sums behind dL/dtau, see (6) below
     long long twi[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};  // ... DET: in fixed point (which Gaussians share a lane depends on the lists' order)
     long long twn = 0;                                         // ... and how many terms were not finite (word 7 of the slot: the pose step reports NaN)
     GSR_T_DECL
-  if (!frozen) {
+  if (walk) {
     // SH rows in (and dL_dsh rows out) as 16-B-per-lane streams of whole 192-B rows through LDS
     const bool staged = (a.shs != nullptr) && sh16_vector_ok(a.M, a.shs) &&
                         (a.dL_dsh == nullptr || (reinterpret_cast<uintptr_t>(a.dL_dsh) & 15u) == 0);
     const GradRows rows = {a.dL_dmean2D, a.dL_dconic, a.dL_dopacity, a.dL_dcolor, a.dL_dmean3D, a.dL_dcov3D, a.dL_dsh, a.dL_dscale, a.dL_drot, a.M};
     const uint32_t sl = blockIdx.x & (GSR_SURV_LISTS - 1);
-    const uint32_t n = a.surv.n[sl * GSR_SURV_CSTRIDE];
-    const uint32_t* __restrict__ list = a.surv.ids + (size_t)sl * a.surv.cap;
+    const uint32_t n = wl.n[sl * GSR_SURV_CSTRIDE];
+    const uint32_t* __restrict__ list = wl.ids + (size_t)sl * wl.cap;
     const uint32_t step = (gridDim.x / GSR_SURV_LISTS) * GSR_K8_ROWS;
     uint32_t c0 = (blockIdx.x / GSR_SURV_LISTS) * GSR_K8_ROWS;
     // (the first chunk of the list is requested together with the list's length -- inside the sub-list's allocation whatever the
@@ -3943,19 +3985,19 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             c0 += step;
             // (round 4: the compositing backward flags the Gaussians it added anything to -- two bytes per survivor here instead of its
             // 48-byte record: complete lists make every visible Gaussian a survivor and nine in ten of them were never blended)
-            const uint8_t fa = in ? a.aflag[idx] : (uint8_t)0, fc = in ? a.aflag[(size_t)a.P + idx] : (uint8_t)0;
+            const uint8_t fa = in ? wflag[idx] : (uint8_t)0, fc = in ? wflag[(size_t)a.P + idx] : (uint8_t)0;
             const bool active = fa != 0;
             // zero colour gradient => zero SH gradient whatever the coefficients are: their row is not even read
             const bool has_col = active && fc != 0;
-            if (fa != 0) a.aflag[idx] = (uint8_t)0;                       // consumed: clean for the next backward
-            if (fc != 0) a.aflag[(size_t)a.P + idx] = (uint8_t)0;
+            if (rows_on && fa != 0) wflag[idx] = (uint8_t)0;                       // consumed: clean for the next backward
+            if (rows_on && fc != 0) wflag[(size_t)a.P + idx] = (uint8_t)0;
             // The gradient tensors are zero wherever nothing is written: the host zero-fills them per call, or (native
             // loop) once per frame, after which the dirty bits say which rows hold values from the iteration before.
             // (Rows of Gaussians that are not on this iteration's lists were cleared by k_preprocess.)
-            const uint8_t was = (a.dirty != nullptr && in) ? a.dirty[idx] : (uint8_t)0;
-            if (a.dirty != nullptr && in) {
+            const uint8_t was = (dirty != nullptr && in) ? dirty[idx] : (uint8_t)0;
+            if (dirty != nullptr && in) {
                 const uint8_t now = (uint8_t)((active ? 1 : 0) | (has_col ? 2 : 0));
-                if (now != was) a.dirty[idx] = now;
+                if (now != was) dirty[idx] = now;
             }
             if (!active && (was & 1)) zero_grad_rows(rows, (size_t)idx, true, false);      // no gradient any more
             if ((was & 2) && !has_col) zero_grad_rows(rows, (size_t)idx, false, true);       // had an SH gradient last iteration, has none now
@@ -3975,12 +4017,14 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         const bool has_col = (qe >> 31) != 0u;
         float4 r0 = make_float4(0.f, 0.f, 0.f, 0.f), r1 = r0, r2 = r0;
         if (active) {
-            acc_load<DET>(a.acc, (size_t)idx, r0, r1, r2);
-            if (a.dirty != nullptr) acc_clear<DET>(a.acc, (size_t)idx);      // native loop: leave the record clean for the next iteration's K7 (no 48 MB memset)
-            a.dL_dcolor[3 * (size_t)idx] = r0.x; a.dL_dcolor[3 * (size_t)idx + 1] = r0.y; a.dL_dcolor[3 * (size_t)idx + 2] = r0.z;
-            a.dL_dmean2D[3 * (size_t)idx] = r0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = r1.x;
-            reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(r1.y, r1.z, 0.f, r1.w);
-            a.dL_dopacity[idx] = r2.x;
+            acc_load<DET>(wacc, (size_t)idx, r0, r1, r2);
+            if (dirty != nullptr) acc_clear<DET>(wacc, (size_t)idx);      // native loop, final pass: leave the record clean for the next call's K7 (no 48 MB memset)
+            if (rows_on) {
+                a.dL_dcolor[3 * (size_t)idx] = r0.x; a.dL_dcolor[3 * (size_t)idx + 1] = r0.y; a.dL_dcolor[3 * (size_t)idx + 2] = r0.z;
+                a.dL_dmean2D[3 * (size_t)idx] = r0.w; a.dL_dmean2D[3 * (size_t)idx + 1] = r1.x;
+                reinterpret_cast<float4*>(a.dL_dconic)[idx] = make_float4(r1.y, r1.z, 0.f, r1.w);
+                a.dL_dopacity[idx] = r2.x;
+            }
         }
         const unsigned long long colmask = __ballot(has_col);
         // Every per-Gaussian read of the round is requested here, in FRONT of the SH rows, so that one round trip covers them all
@@ -3988,14 +4032,14 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         float cov6[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         float3 mean = make_float3(0.f, 0.f, 0.f);
         SplatRec sr = {};
-        const bool want_sr = a.scales && (a.dL_dscale || a.dL_drot);
+        const bool want_sr = rows_on && a.scales && (a.dL_dscale || a.dL_drot);
         float s3[3] = {0.f, 0.f, 0.f};
         float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
         if (active) {
 #pragma unroll
             for (int i = 0; i < 6; i++) cov6[i] = a.cov3D[6 * (size_t)idx + i];
             mean = make_float3(a.means[3 * idx], a.means[3 * idx + 1], a.means[3 * idx + 2]);
-            sr = load_splat_rec(a.rec, (uint32_t)idx);
+            sr = load_splat_rec(wrec, (uint32_t)idx);
             if (want_sr) {
                 s3[0] = a.scales[3 * idx]; s3[1] = a.scales[3 * idx + 1]; s3[2] = a.scales[3 * idx + 2];
                 q = reinterpret_cast<const float4*>(a.rots)[idx];
@@ -4019,14 +4063,14 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             const float3 co = make_float3(sr.a, sr.b, sr.c);
             // (1) conic gradient -> covariance gradient and the mean's share through the projected covariance
             float G[6];
-            const float3 g_cov = covariance_chain(mean, cov6, make_float3(co.x, co.y, co.z), make_float3(r1.y, r1.z, r1.w), a.view, a.fx, a.fy,
+            const float3 g_cov = covariance_chain(mean, cov6, make_float3(co.x, co.y, co.z), make_float3(r1.y, r1.z, r1.w), view, a.fx, a.fy,
                                                   a.tanx, a.tany, G);
-            if (a.dL_dcov3D) {      // the reference's 6-vector counts each off-diagonal entry twice
+            if (rows_on && a.dL_dcov3D) {      // the reference's 6-vector counts each off-diagonal entry twice
                 float* o = a.dL_dcov3D + 6 * (size_t)idx;
                 o[0] = G[0]; o[1] = 2.f * G[1]; o[2] = 2.f * G[2]; o[3] = G[3]; o[4] = 2.f * G[4]; o[5] = G[5];
             }
             // (2) screen-space mean gradient through the perspective division (backward.cu:346-372)
-            const float* P = a.proj;
+            const float* P = proj;
             const float hx = P[0] * mean.x + P[4] * mean.y + P[8] * mean.z + P[12], hy = P[1] * mean.x + P[5] * mean.y + P[9] * mean.z + P[13];
             const float hw = P[3] * mean.x + P[7] * mean.y + P[11] * mean.z + P[15];
             const float rw = 1.0f / (hw + 0.0000001f);
@@ -4038,7 +4082,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             float3 g_geo = make_float3(g_cov.x + g_m2d.x, g_cov.y + g_m2d.y, g_cov.z + g_m2d.z);
             if (a.pose) {
                 const float dz = r2.y;
-                g_geo.x += a.view[2] * dz; g_geo.y += a.view[6] * dz; g_geo.z += a.view[10] * dz;
+                g_geo.x += view[2] * dz; g_geo.y += view[6] * dz; g_geo.z += view[10] * dz;
             }
             GSR_T_TICK(2)
             // (4) colour gradient -> SH coefficients and the view direction's share of the mean gradient
@@ -4046,13 +4090,13 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             if (a.shs && has_col) {
                 const float3 dcol = make_float3(r0.x, r0.y, r0.z);
                 if (staged)
-                    g_sh = sh_color_backward(a.D, 16, mean, a.campos, my_row, a.clamped[idx], dcol, a.dL_dsh ? my_row : nullptr);
+                    g_sh = sh_color_backward(a.D, 16, mean, campos, my_row, wclamped[idx], dcol, o_dsh ? my_row : nullptr);
                 else
-                    g_sh = sh_color_backward(a.D, a.M, mean, a.campos, a.shs + (size_t)idx * a.M * 3, a.clamped[idx], dcol,
-                                             a.dL_dsh ? a.dL_dsh + (size_t)idx * a.M * 3 : nullptr);
+                    g_sh = sh_color_backward(a.D, a.M, mean, campos, a.shs + (size_t)idx * a.M * 3, wclamped[idx], dcol,
+                                             o_dsh ? o_dsh + (size_t)idx * a.M * 3 : nullptr);
             }
             GSR_T_TICK(3)
-            if (a.dL_dmean3D) {
+            if (rows_on && a.dL_dmean3D) {
                 a.dL_dmean3D[3 * (size_t)idx] = g_geo.x + g_sh.x;
                 a.dL_dmean3D[3 * (size_t)idx + 1] = g_geo.y + g_sh.y;
                 a.dL_dmean3D[3 * (size_t)idx + 2] = g_geo.z + g_sh.z;
@@ -4071,7 +4115,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             //   a = (X_12, X_20, X_01) of the antisymmetric X = Sigma G - G Sigma (how the covariance turns with the camera).
             // Everything per Gaussian is kept in the WORLD frame -- p_C x (Wc g) = Wc (p x g) + trans x (Wc g) -- and the
             // rotation is applied once per wave to the sums (tw: rho part, g_geo, p x g_geo, a).
-            if (a.pose) {
+            if (tau_on) {
                 // P = Sigma G; X_ij = P_ij - P_ji
                 const float P01 = cov6[0] * G[1] + cov6[1] * G[3] + cov6[2] * G[4], P10 = cov6[1] * G[0] + cov6[3] * G[1] + cov6[4] * G[2];
                 const float P02 = cov6[0] * G[2] + cov6[1] * G[4] + cov6[2] * G[5], P20 = cov6[2] * G[0] + cov6[4] * G[1] + cov6[5] * G[2];
@@ -4087,7 +4131,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             }
         }
         GSR_T_TICK(4)
-        if (staged && a.dL_dsh) {
+        if (staged && o_dsh) {
             __syncthreads();
 #pragma unroll
             for (int i = 0; i < GSR_SH16_ROW4; i++) {
@@ -4095,7 +4139,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
                 const int r = j / GSR_SH16_ROW4, part = j - r * GSR_SH16_ROW4;
                 const int rid = __shfl(idx, r, 64);
                 if ((colmask >> r) & 1ull)
-                    reinterpret_cast<float4*>(a.dL_dsh)[(size_t)rid * GSR_SH16_ROW4 + part] = s_sh[r * GSR_SH16_LDS4 + part];
+                    reinterpret_cast<float4*>(o_dsh)[(size_t)rid * GSR_SH16_ROW4 + part] = s_sh[r * GSR_SH16_LDS4 + part];
             }
         }
         // the rest of the queue moves to the front
@@ -4106,7 +4150,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
         __syncthreads();
         GSR_T_TICK(5)
     }
-    if (a.pose) {
+    if (tau_on) {
         // wave reduction in fp64, rotation into the camera frame, then one fp64 atomic per wave and component into one of
         // GSR_TAU_SLOTS partial sums (64 B apart: thousands of waves adding into six words would queue up at the memory-side atomic unit)
         // (a wave that queued nothing -- seven in eight of them in a speculative iteration -- has nothing to add)
@@ -4132,7 +4176,7 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             for (int i = 0; i < 12; i++) sw[i] = wave_sum_d_to_lane63((double)tw[i]);
         }
         if (!DET && lane == 63 && wave_any) {
-            const float* vm = a.view;
+            const float* vm = view;
             double tau[6], wg[3];
 #pragma unroll
             for (int r = 0; r < 3; r++) {
@@ -4150,6 +4194,20 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     }
     GSR_T_TICK(6)
   }
+    if (clear_other) {
+        // what the group in front of this one left in ITS set: flags and records of the Gaussians its compositing backward added to
+        // (this group's own compositing backward has run on the other set; the next group's will run on this one)
+        const uint32_t* __restrict__ list2 = a.o_surv.ids + (size_t)(rb & (GSR_SURV_LISTS - 1)) * a.o_surv.cap;
+        const uint32_t step2 = (gridDim.x / GSR_SURV_LISTS) * GSR_K8_ROWS;
+        for (uint32_t c = (rb / GSR_SURV_LISTS) * GSR_K8_ROWS; c < o_n; c += step2) {
+            if (c + (uint32_t)lane < o_n) {
+                const size_t idx = list2[c + (uint32_t)lane];
+                const uint8_t fa = a.o_aflag[idx], fc = a.o_aflag[(size_t)a.P + idx];
+                if (fa != 0) { a.o_aflag[idx] = (uint8_t)0; acc_clear<DET>(a.o_acc, idx); }
+                if (fc != 0) a.o_aflag[(size_t)a.P + idx] = (uint8_t)0;
+            }
+        }
+    }
     if (a.ticket != nullptr) {
         // Two levels: ~2000 workgroups drawing from ONE counter would queue up at the memory-side atomic unit for longer
         // than the kernel runs (measured: +54 us).  Workgroups sharing a dL/dtau slot (blockIdx mod 64) count in the unused
@@ -4171,7 +4229,10 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
             // last of all: everybody's sums are in (read below with agent-scope atomic loads, past this CU's L1)
             if (lane == 0) *a.ticket = 0u;             // (the next launch starts counting from zero)
             reinterpret_cast<uint32_t*>(&a.tau_acc[lane * 8 + 6])[0] = 0u;      // the group counters too, also on a frozen iteration
-            a.surv.n[lane * GSR_SURV_CSTRIDE] = 0u;    // every workgroup is past its work list: the next forward appends from zero
+            // every workgroup is past the other set's work list, which holds nothing any more: the forward after next appends from zero
+            // (role 1 is the only one with a ticket; the own set's counters are returned by the next group's launch)
+            a.o_surv.n[lane * GSR_SURV_CSTRIDE] = 0u;
+            if (final_pass && lane == 0) *a.final_done = 1u;
             pose_step_wave<DET>(a.fold, a.guard, s_pose);
             GSR_T_TICK(8)
         }

@@ -303,3 +303,62 @@ def test_survivor_sublists_hold_a_fully_visible_map():
     _bit_equal(spec, plain, "speculative vs complete lists, fully visible map")
     Rp, Tp, _ = PL.python_loop(PL.make_frame(sc, model, DEV, bg), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), model, bg, iters=4)
     assert torch.allclose(plain["R"], Rp, atol=2e-6) and torch.allclose(plain["T"], Tp, atol=2e-6)
+
+
+@pytest.mark.parametrize("spec", [True, False])
+def test_gradient_rows_after_an_early_exit_are_those_of_the_last_stepped_iteration(spec):
+    """The loop writes the gradients of the Gaussians' own parameters ONCE per call, from the records of the last iteration whose
+    pose step ran (gsr::PreBwdArgs::role).  Three ways to get there must give the same bits: (a) the iterations are used up (the
+    host launches the final pass), (b) the loop converges early, a frozen forward at the final pose runs behind the last
+    iteration and ITS chain-rule launch does the final pass -- from the other set of lists / records / splat records and the camera
+    the pose step saved, (c) it converges in its very last iteration (no frozen forward; host).  A second call on the same
+    workspaces must find them clean."""
+    from tests import replay as PL
+    sc = S.small(P=20000, W=160, H=120, sh_degree=3, seed=5, scale_med=0.03)
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    init = PL.perturbed_start(0, device=DEV)
+    view = lambda: PL.make_frame(sc, model, DEV, bg)
+    cfg = PL.TRACKING_CONFIG
+
+    def call(fr, iters, **kw):
+        R, T, info = fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=iters, flags=DET, speculative=spec,
+                               warm_start=False, **kw)
+        torch.cuda.synchronize()
+        out = dict(R=R.clone(), T=T.clone(), info=info)
+        for k in GRADS:
+            out["g_" + k] = getattr(fr, "g_" + k).clone()
+        return out
+
+    # (b): a threshold the update norm falls below after a few iterations
+    k, early, frB = None, None, None
+    for thr in (2.0e-3, 1.8e-3, 1.5e-3, 1.2e-3, 1.0e-3):
+        frB = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+        early = call(frB, 30, converged_threshold=thr)
+        if early["info"]["converged"] and 2 <= early["info"]["iters"] <= 25:
+            k = early["info"]["iters"]
+            break
+    assert k is not None, early["info"]
+    # (a): exactly k iterations, no early exit
+    frA = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    full = call(frA, k, stop_on_converged=False)
+    assert float(full["g_m3d"].abs().sum()) > 0 and float(full["g_sh"].abs().sum()) > 0
+    _bit_equal(full, early, "iterations used up / early exit with a frozen forward behind it")
+    # (c): converges in the last iteration it was given
+    frC = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    last = call(frC, k, converged_threshold=thr)
+    assert last["info"]["converged"] and last["info"]["iters"] == k
+    _bit_equal(full, last, "iterations used up / convergence in the last one")
+    # the workspaces of (b) and (c) serve another call like fresh ones
+    init2 = PL.perturbed_start(7, device=DEV)
+    def again(fr):
+        R, T, info = fr.refine(view(), cfg, init2[:3, :3].clone(), init2[:3, 3].clone(), bg, iters=3, flags=DET, speculative=spec,
+                               stop_on_converged=False, warm_start=False)
+        torch.cuda.synchronize()
+        out = dict(R=R.clone(), T=T.clone(), info=info)
+        for kk in GRADS:
+            out["g_" + kk] = getattr(fr, "g_" + kk).clone()
+        return out
+    fresh = again(PL.FusedRefiner(model, sc.H, sc.W, device=DEV))
+    _bit_equal(fresh, again(frB), "second call on the workspaces of an early exit")
+    _bit_equal(fresh, again(frC), "second call on the workspaces of a convergence in the last iteration")
