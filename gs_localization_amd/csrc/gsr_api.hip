@@ -184,7 +184,10 @@ struct Img {
 };
 // Blocks the compositing kernels are launched with when tiles may be split: every tile once + room for the heavy ones' extra segments
 constexpr int kSegMaxTiles = 4096;
-int seg_budget_of(int ntiles) { return ntiles <= kSegMaxTiles ? 2 * ntiles : 0; }      // (every block without work costs the launch a little: S-1M-640, no tile split, 3 x: +1.3 us per kernel)
+#ifndef GSR_SEG_BUDGET_MUL
+#define GSR_SEG_BUDGET_MUL 3
+#endif
+int seg_budget_of(int ntiles) { return ntiles <= kSegMaxTiles ? GSR_SEG_BUDGET_MUL * ntiles : 0; }      // (every block without work costs the launch a little: S-1M-640, no tile split, 3 x: +1.3 us per kernel)
 // (seg: with the split-tile arrays -- at the END, so that everything else has the same place either way; only gsr_refine asks for them)
 size_t carve_img(char* base, int W, int H, Img& im, bool seg = false)
 {
@@ -468,7 +471,11 @@ int gsr_debug_timing(unsigned long long* out48)          // (64 entries since th
         out48[k * 16 + 14] = life.empty() ? 0 : life[life.size() / 2];
         out48[k * 16 + 15] = life.empty() ? 0 : life[life.size() * 99 / 100];
     }
-    if (const char* dump = getenv("GSR_TIM_DUMP")) {          // raw per-wave rows: "<kernel> <row> <12 slots>" (diagnostics)
+    if (const char* dump = getenv("GSR_TIM_DUMP")) {          // raw per-wave rows: "<kernel> <row> <12 slots> <12 slots of the last launch> <first, last instant of the row's last launch, 100 MHz>" (diagnostics)
+        static std::vector<unsigned long long> sp((size_t)4 * GSR_TIM_WAVES * 2);
+        if (hipMemcpyFromSymbol(sp.data(), HIP_SYMBOL(gsr::g_tim_span), sp.size() * 8) != hipSuccess) return -2;
+        static std::vector<unsigned long long> la((size_t)4 * GSR_TIM_WAVES * 12);
+        if (hipMemcpyFromSymbol(la.data(), HIP_SYMBOL(gsr::g_tim_last), la.size() * 8) != hipSuccess) return -2;
         if (FILE* f = fopen(dump, "w")) {
             for (int k = 0; k < 4; k++)
                 for (size_t w = 0; w < GSR_TIM_WAVES; w++) {
@@ -476,7 +483,8 @@ int gsr_debug_timing(unsigned long long* out48)          // (64 entries since th
                     if (r[9] == 0ull) continue;
                     fprintf(f, "%d %zu", k, w);
                     for (int q = 0; q < 12; q++) fprintf(f, " %llu", r[q]);
-                    fprintf(f, "\n");
+                    for (int q = 0; q < 12; q++) fprintf(f, " %llu", la[((size_t)k * GSR_TIM_WAVES + w) * 12 + q]);
+                    fprintf(f, " %llu %llu\n", sp[((size_t)k * GSR_TIM_WAVES + w) * 2], sp[((size_t)k * GSR_TIM_WAVES + w) * 2 + 1]);
                 }
             fclose(f);
         }
@@ -1050,13 +1058,16 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         const bool use_seg = cx.seg && cx.seg_used && *cx.seg_used && im.seg_budget > 0;
         const gsr::SegCtl sg = use_seg ? gsr::SegCtl{im.seg_list[cx.spec.parity ^ 1], im.seg_cnt, im.seg_pub, im.seg_rec, im.seg_ticket, im.seg_nosplit, cx.guard.tag, im.seg_len} : gsr::SegCtl{};
         const int kgrid = use_seg ? ((cx.seg_grid > 0 && cx.seg_grid <= im.seg_budget) ? cx.seg_grid : im.seg_budget) : ntiles;
+        // (work measured by a forward with COMPLETE lists says little about the speculative forward that follows -- its ordering overhead is
+        // that of lists several times as long: the list built from it splits nobody.  Round 5: S-1M-640-walls, whose speculative iterations
+        // never split a tile, had 460 of its 1 200 tiles split in the iteration after each complete-list forward.)
         const int next_budget = (cx.seg_grid_next > 0 && cx.seg_grid_next <= im.seg_budget) ? cx.seg_grid_next : im.seg_budget;
         // (... and one more workgroup builds the next group's list from the work this group's forward measured; the forward's order array is
         // its scratch: the next forward either runs the list or has the preprocess kernel compute its order afresh)
         const bool build = cx.seg && im.seg_budget > 0 && cx.native_loop && balanced;
         const gsr::SegBuild sb = build ? gsr::SegBuild{im.tile_work[0], im.tile_order[0], im.seg_list[cx.spec.parity], im.seg_nosplit, ntiles, next_budget, kgrid, im.seg_len,
                                                         (cx.spec.mode != 0 && !cx.spec.state && !(cx.flags & GSR_REFINE_NO_DILATE)) ? im.zb[cx.spec.parity] : (float*)nullptr, im.zbc[cx.spec.parity], gx, gy, im.sbx,
-                                                        im.zb_own[cx.spec.parity], im.nodilate, cx.seg_host_total} : gsr::SegBuild{};
+                                                        im.zb_own[cx.spec.parity], im.nodilate, (cx.spec.mode == 2) ? 0 : 1, cx.seg_host_total} : gsr::SegBuild{};
         if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(kgrid + (build ? 1 : 0)), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag, sg, sb);
         else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(kgrid + (build ? 1 : 0)), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag, sg, sb);
 #undef GSR_BWD_ARGS

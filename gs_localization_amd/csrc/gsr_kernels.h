@@ -14,7 +14,11 @@ namespace gsr {
 #if GSR_TIMING
 #define GSR_TIM_WAVES (16384 * 4)
 __device__ unsigned long long g_tim[4][GSR_TIM_WAVES][12];      // [kernel][wave][slot]: every wave owns its row, no atomics
-#define GSR_T_DECL long long t_prev_ = clock64(); const long long t_start_ = t_prev_; long long t_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0};
+// ... and, of the LAST launch only (overwritten, not added): the wave's first and last instant on the 100 MHz wall clock -- a timeline of
+// one launch's workgroups (tools/dbg/timeline.py: is a kernel's duration its throughput or the tail of one chain?)
+__device__ unsigned long long g_tim_span[4][GSR_TIM_WAVES][2];
+__device__ unsigned long long g_tim_last[4][GSR_TIM_WAVES][12];      // ... and its phase slots
+#define GSR_T_DECL long long t_prev_ = clock64(); const long long t_start_ = t_prev_; long long t_acc_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}; const unsigned long long t_wall0_ = wall_clock64();
 #define GSR_T_TICK(slot) { const long long now_ = clock64(); t_acc_[slot] += now_ - t_prev_; t_prev_ = now_; }
 #define GSR_T_COUNT(slot, v) { t_acc_[slot] += (v); }
 // -DGSR_TIMING_ORDER: slots 4 / 6 / 7 of k_render_fwd show the lazy ordering's sub-phases (sample + threshold search, gather pass, sort)
@@ -28,9 +32,9 @@ __device__ unsigned long long g_tim[4][GSR_TIM_WAVES][12];      // [kernel][wave
 #define GSR_TO(slot) slot
 #define GSR_T_TICK_O(slot)
 #endif
-#define GSR_T_FLUSH(base) t_acc_[9] = clock64() - t_start_; if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < GSR_TIM_WAVES) { for (int q_ = 0; q_ < 12; q_++) g_tim[(base) / 16][blockIdx.x * 4 + (threadIdx.x >> 6)][q_] += (unsigned long long)t_acc_[q_]; }
+#define GSR_T_FLUSH(base) t_acc_[9] = clock64() - t_start_; if ((threadIdx.x & 63) == 0 && blockIdx.x * 4 + (threadIdx.x >> 6) < GSR_TIM_WAVES) { for (int q_ = 0; q_ < 12; q_++) { g_tim[(base) / 16][blockIdx.x * 4 + (threadIdx.x >> 6)][q_] += (unsigned long long)t_acc_[q_]; g_tim_last[(base) / 16][blockIdx.x * 4 + (threadIdx.x >> 6)][q_] = (unsigned long long)t_acc_[q_]; } g_tim_span[(base) / 16][blockIdx.x * 4 + (threadIdx.x >> 6)][0] = t_wall0_; g_tim_span[(base) / 16][blockIdx.x * 4 + (threadIdx.x >> 6)][1] = wall_clock64(); }
 // (workgroups of `wpb` waves)
-#define GSR_T_FLUSH_W(base, wpb) t_acc_[9] = clock64() - t_start_; if ((threadIdx.x & 63) == 0 && blockIdx.x * (wpb) + (threadIdx.x >> 6) < GSR_TIM_WAVES) { for (int q_ = 0; q_ < 12; q_++) g_tim[(base) / 16][blockIdx.x * (wpb) + (threadIdx.x >> 6)][q_] += (unsigned long long)t_acc_[q_]; }
+#define GSR_T_FLUSH_W(base, wpb) t_acc_[9] = clock64() - t_start_; if ((threadIdx.x & 63) == 0 && blockIdx.x * (wpb) + (threadIdx.x >> 6) < GSR_TIM_WAVES) { for (int q_ = 0; q_ < 12; q_++) { g_tim[(base) / 16][blockIdx.x * (wpb) + (threadIdx.x >> 6)][q_] += (unsigned long long)t_acc_[q_]; g_tim_last[(base) / 16][blockIdx.x * (wpb) + (threadIdx.x >> 6)][q_] = (unsigned long long)t_acc_[q_]; } g_tim_span[(base) / 16][blockIdx.x * (wpb) + (threadIdx.x >> 6)][0] = t_wall0_; g_tim_span[(base) / 16][blockIdx.x * (wpb) + (threadIdx.x >> 6)][1] = wall_clock64(); }
 #else
 #define GSR_T_DECL
 #define GSR_T_TICK(slot)
@@ -504,8 +508,20 @@ __device__ __forceinline__ void tile_order_block(const uint32_t* __restrict__ wo
 #define GSR_SEG_KEYS 192u          // keys per segment the launch list aims at
 #endif
 #ifndef GSR_SEG_SPLIT_HALVES
-#define GSR_SEG_SPLIT_HALVES 4u    // a tile is split when its work exceeds this many HALVES of L = max(mean work, GSR_SEG_WORK_MIN)
+#define GSR_SEG_SPLIT_HALVES 2u    // a tile is split when its work exceeds this many HALVES of L = max(mean work, GSR_SEG_WORK_MIN) ...
 #endif
+#ifndef GSR_SEG_SPLIT_MIN_WORK
+#define GSR_SEG_SPLIT_MIN_WORK 48u // ... and this much in absolute terms (groups of eight entries) ...
+#endif
+#ifndef GSR_SEG_SPLIT_SURE
+#define GSR_SEG_SPLIT_SURE 3u      // ... or, whatever its absolute size, this many halves of L
+#endif
+// (round 5, tools/dbg/timeline.py on S-room-640: with the threshold at 2 L the launches ended with a dozen UNSPLIT tiles of 1-2 L that had
+// been running since the first microsecond -- a workgroup shares its SIMDs with four others, so a tile of 800 entries in one 8x8 block
+// is a 190 us chain while the sum of all lifetimes is worth 110 us of the machine.  Thresholds measured (it/s: S-room-640 / S-1M-640-object
+// / S-1M-640): 2 L 1 545 / 3 938 / 6 700; 1.5 L 1 601 / 4 072 / 6 759; 1 L 1 772 / 4 062 / 6 503 (eight tiles of the uniform cloud split
+// in two: a split tile is a longer chain than the same tile whole unless it is heavy in absolute terms); 1 L above 48 groups, 1.5 L
+// below, room for 3 blocks per tile: 1 847 / 4 077 / 6 734 -- kept.  Raising the wave priority of the launch's front (s_setprio) did nothing.)
 #ifndef GSR_BWD_SEG_MERGE
 #define GSR_BWD_SEG_MERGE 1u       // forward segments per workgroup of the backward compositing kernel (measured, S-1M-640-object: 1 -> 93 us, 2 -> 106, 3 -> 129)
 #endif
@@ -513,7 +529,7 @@ __device__ __forceinline__ void tile_order_block(const uint32_t* __restrict__ wo
 #define GSR_SEG_BUILD_MAX_TILES 4096      // (16 launch positions per thread, kept in registers)
 __device__ __forceinline__ void seg_list_build(const uint32_t* __restrict__ work, const uint32_t* __restrict__ order, uint32_t* __restrict__ list,
                                                uint32_t* __restrict__ nosplit, int ntiles, int budget, const uint32_t* __restrict__ len,
-                                               uint32_t* __restrict__ host_total)
+                                               uint32_t* __restrict__ host_total, bool split_ok)
 {
     __shared__ uint32_t s_sum[4];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -539,14 +555,24 @@ __device__ __forceinline__ void seg_list_build(const uint32_t* __restrict__ work
     uint32_t mine = 0u;
 #pragma unroll
     for (int i = 0; i < kPer; i++) mine += wk[i];
-    const uint32_t mean = block_sum(mine) / (uint32_t)max(ntiles, 1);
-    uint32_t L = max(mean, GSR_SEG_WORK_MIN);
+    const uint32_t all_work = block_sum(mine);
+    const uint32_t mean = all_work / (uint32_t)max(ntiles, 1);
+    uint32_t L = split_ok ? max(mean, GSR_SEG_WORK_MIN) : 0x3FFFFFFFu;      // (!split_ok: the list is the plain order, one block per tile)
+    // A SKEWED launch -- a tenth or more of all work sits in tiles above 2 L -- ends with a long tail of its upper-middle tiles as well
+    // (see GSR_SEG_SPLIT_HALVES): there the threshold drops to 1 L / 1.5 L.  A launch of roughly equal tiles has half of them above the mean
+    // by definition; splitting those buys nothing (S-1M-640-walls in the iterations right after a complete-list forward: 570 of 1 200 tiles).
+    uint32_t heavy = 0u;
+#pragma unroll
+    for (int i = 0; i < kPer; i++) heavy += (wk[i] > 2u * L) ? wk[i] : 0u;
+    heavy = block_sum(heavy);
+    const bool skewed = (unsigned long long)heavy * 10ull >= (unsigned long long)all_work;
+    const uint32_t halves = skewed ? GSR_SEG_SPLIT_HALVES : 4u, sure = skewed ? GSR_SEG_SPLIT_SURE : 4u;
     // (WHETHER a tile is split is a matter of its work against the mean; into HOW MANY segments also of its list's length: a segment of
     // up to GSR_BLOCK keys sorts in registers and is staged once for both passes -- measured, S-1M-640-object / S-room-640: segments of
     // 500 - 1 300 keys cost more than a whole median tile, most of it barriers between their staging batches and the LDS sort)
     uint32_t Lk = GSR_SEG_KEYS;
     auto nseg_of = [&](uint32_t w, uint32_t h, uint32_t n) -> uint32_t {
-        if (2u * w <= GSR_SEG_SPLIT_HALVES * L || h != 0u) return 1u;
+        if (2u * w <= halves * L || (w <= GSR_SEG_SPLIT_MIN_WORK && 2u * w <= sure * L) || h != 0u) return 1u;
         return min((uint32_t)GSR_SEG_MAX, max((w + L - 1u) / L, (n + Lk - 1u) / Lk));
     };
     uint32_t total = 0u, local = 0u;
@@ -1813,6 +1839,7 @@ struct SegBuild {
     // Deeper bounds only make lists longer: results cannot depend on it.
     float* zb; float* zbc; int gx, gy, sbx;
     float* zb_own; uint32_t* nodilate;      // out: every tile's own bound (before widening); per tile: forwards it still goes without widening
+    int split_ok;                           // 0: this group's work figures are not a speculative forward's -- the list it builds splits nobody
     uint32_t* host_total;                   // out (nullable, pinned host memory): blocks the list holds -- the host sizes later launches by it
 };
 #ifndef GSR_BOUND_DILATE_RATIO
@@ -3021,7 +3048,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         __shared__ uint32_t s_cls2[GSR_BLOCK];
         tile_order_from_work(sb.work, sb.order, sb.ntiles, s_cls2);
         __syncthreads();
-        seg_list_build(sb.work, sb.order, sb.list, sb.nosplit, sb.ntiles, sb.budget, sb.len, sb.host_total);
+        seg_list_build(sb.work, sb.order, sb.list, sb.nosplit, sb.ntiles, sb.budget, sb.len, sb.host_total, sb.split_ok != 0);
         if (sb.zb != nullptr) {
             __syncthreads();
             dilate_bounds(sb, reinterpret_cast<float*>(sb.order));      // (the order array has served its purpose)

@@ -237,8 +237,8 @@ def test_headline_path_against_the_oracle_at_the_pose_of_its_last_forward(name):
     run = _run(fr, vp, init, bg, K, flags=0)
     info = run["info"]
     assert info["iters"] == K and info["lean_iters"] >= 1, info
+    blocks, ntiles_split, kmax, budget = fr.seg_stats()
     if name in ("S-room-640", "S-1M-640-object"):          # heavy tiles were split across workgroups in the iteration compared below
-        blocks, ntiles_split, kmax, budget = fr.seg_stats()
         assert ntiles_split >= 20 and kmax >= 4, (blocks, ntiles_split, kmax, budget)
     Rl, Tl, ex = info["R_last_forward_host"], info["T_last_forward_host"], info["exposure_last_forward_host"]
     assert abs(np.linalg.det(Rl.astype(np.float64)) - 1) < 1e-5 and not np.allclose(Rl, info["R_host"], atol=0, rtol=0)
@@ -270,8 +270,14 @@ def test_headline_path_against_the_oracle_at_the_pose_of_its_last_forward(name):
         worst, share, at = U.row_errors(a.reshape(b.shape), b)
         report[k] = (e, worst, share, at)
     print(name, {k: ("%.2e" % v[0], "worst row %.3f" % v[1], "rows > 1e-3: %.2e" % v[2]) for k, v in report.items()})
+    # Tiles split across workgroups: a split tile's backward restarts every depth range from sums the forward left, in double, instead of
+    # carrying the reference's fp32 recurrences through the whole list -- it rounds differently from the oracle, and on lists of many
+    # hundreds of entries it is the ORACLE's recurrences (T by repeated division, backward.cu:516) that are 1-2e-5 from float64, not the
+    # split path (6e-7 ... 1.1e-6): tests/test_gpu_split.py::test_split_backward_against_float64_autograd.  With a tenth or more of the
+    # tiles split the aggregate bar is therefore 5e-5 (measured: S-room-640 <= 3.1e-5 with 350 of 1 200 tiles split).
+    bar = 5e-5 if ntiles_split * 10 >= 1200 else 2e-5
     for k, (e, worst, share, at) in report.items():
-        assert e <= 2e-5, (k, e)
+        assert e <= bar, (k, e, ntiles_split)
         # per row: a threshold flip (alpha within an ulp of 1/255, T of 1e-4: v_exp_f32 against expf) moves one pixel of one splat --
         # per-cent level on a splat that covers a handful of pixels, never more; and it happens to a few rows in ten thousand
         # (S-room-640 runs with a tenth of its tiles split across workgroups: there the backward restarts the "composited behind me"
@@ -281,7 +287,7 @@ def test_headline_path_against_the_oracle_at_the_pose_of_its_last_forward(name):
         # ... and its transmittances round differently from the oracle's running product, so a pixel whose T (1 - alpha) lies within an ulp
         # of the 1e-4 termination threshold blends one splat more or less than the oracle's: on a splat of a handful of pixels that one
         # pixel is tens of per cent of the row (seen: 0.04 - 0.21 from run to run, one row in a million)
-        room = name == "S-room-640"
+        room = ntiles_split * 10 >= 1200
         assert worst <= (5 * ROW_WORST if room else ROW_WORST) and share <= (5 * ROW_SHARE if room else ROW_SHARE), (k, worst, share, at)
 
 

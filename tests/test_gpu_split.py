@@ -38,35 +38,43 @@ def test_split_loop_equals_the_unsplit_loop_up_to_rounding(make, P):
     fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
     split = _run(fr, view(), init, bg, K, flags=0, lean_min_P=1)
     blocks, ntiles_split, kmax, budget = fr.seg_stats()
-    assert budget == 2 * 1200 and ntiles_split >= 5 and kmax >= 3 and blocks >= 1200 + 2 * ntiles_split, (blocks, ntiles_split, kmax, budget)
+    assert budget == 3 * 1200 and ntiles_split >= 5 and kmax >= 3 and blocks >= 1200 + ntiles_split, (blocks, ntiles_split, kmax, budget)
     g_split = {k: getattr(fr, "g_" + k).detach().clone() for k in ("m3d", "sh", "opac", "scale", "rot", "tau")}
     fr2 = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
     plain = _run(fr2, view(), init, bg, K, flags=_lib.REFINE_NO_SPLIT, lean_min_P=1)
     assert split["info"]["fallbacks"] <= plain["info"]["fallbacks"] + 2, (split["info"], plain["info"])
     assert torch.allclose(split["R"], plain["R"], atol=2e-6) and torch.allclose(split["T"], plain["T"], atol=2e-6)
-    # images: as a whole to 2e-5, 99.9 % of the pixels within 5e-4 -- and a handful may differ by up to a per cent: a pixel terminates where
+    # images: as a whole to 5e-5, 99.9 % of the pixels within 5e-4 -- and a handful may differ by up to a per cent: a pixel terminates where
     # T (1 - alpha) < 1e-4, the split walk carries T as a product of per-range products, and where the two roundings fall on different
     # sides of the threshold one walk blends a last splat of weight up to alpha T ~ 1e-2 that the other does not (the same flip
     # separates any two fp32 evaluation orders; the oracle comparison below holds the split walk to the same per-pixel bars as the unsplit)
     for k, scale in (("color", 1.0), ("alpha", 1.0), ("depth", 10.0)):
         d = (split[k] - plain[k]).abs()
-        assert float(d.sum() / plain[k].abs().sum().clamp_min(1e-30)) <= 2e-5, k
+        assert float(d.sum() / plain[k].abs().sum().clamp_min(1e-30)) <= 5e-5, k      # (half the 1e-4 parity bar; measured 2.4e-5 with a quarter of the tiles split)
         assert float(torch.quantile(d.flatten().float(), 0.999)) <= scale * 5e-4, k
-        assert int((d > scale * 5e-3).sum().item()) <= 8 and float(d.max()) <= scale * 5e-2, (k, int((d > scale * 5e-3).sum().item()), float(d.max()))
+        # (S-room-640's opacities are bimodal: a pixel behind two opaque splats has T (1 - alpha) = 0.01 x 0.01, EXACTLY the 1e-4 threshold
+        # in real arithmetic -- which side it falls on is decided by the last bit of T, and the third splat weighs up to 1e-2: seen 23 - 89
+        # of the 921 600 values from run to run)
+        assert int((d > scale * 5e-3).sum().item()) <= max(32, int(3e-4 * d.numel())) and float(d.max()) <= scale * 5e-2, (k, int((d > scale * 5e-3).sum().item()), float(d.max()))
     nt = int(plain["n_touched"].sum().item())
-    assert int((split["n_touched"] - plain["n_touched"]).abs().sum().item()) <= max(2, int(1e-4 * nt))
+    # (each loop is held to 1e-4 of the oracle's count in the direct tests; between two loops twice that.  Measured 1.1e-4 with a quarter
+    # of the tiles split: T > 0.5 decided by the last bit of a T carried as a product of per-range products)
+    assert int((split["n_touched"] - plain["n_touched"]).abs().sum().item()) <= max(2, int(2e-4 * nt))
     assert int((split["radii"] != plain["radii"]).sum().item()) <= max(2, int(5e-5 * split["radii"].numel()))
     for k in g_split:
         a, b = g_split[k].cpu().numpy(), getattr(fr2, "g_" + k).detach().cpu().numpy()
         # (two runs of the loop end ~1e-7 apart in pose, which moves the gradients of a loss made of sign functions by a few 1e-5:
         # the bar of tests/test_gpu_lean.py's loop-against-loop comparisons; the oracle comparison at 2e-5 is the direct test's)
-        assert U.rel_l1(a, b) <= 2e-4, (k, U.rel_l1(a, b))
+        # (... and a pixel on the other side of the 1e-4 threshold -- see above -- changes colour by up to 1e-2, enough to flip the sign of its
+        # L1 residual: measured 3.6e-4 with a quarter of the tiles split.  A secondary check; each loop is held to the oracle at ITS pose.)
+        assert U.rel_l1(a, b) <= 1e-3, (k, U.rel_l1(a, b))
 
 
 def test_split_forward_and_backward_against_the_oracle_on_a_mid_size_room():
-    """One speculative iteration with split tiles, checked against the CPU oracle at the pose it ran with: the second forward of a
-    two-iteration call (the first bins completely and measures the tiles' work; the second is speculative, split, and the call's last,
-    so its images, n_touched and gradient tensors are what the call returns)."""
+    """One speculative iteration with split tiles, checked against the CPU oracle at the pose it ran with: the third forward of a
+    three-iteration call (the first bins completely; the second is speculative and measures the tiles' work -- the work figures of a
+    complete-list forward split nobody --; the third is speculative, split, and the call's last, so its images, n_touched and gradient
+    tensors are what the call returns)."""
     import os
     from oracle import oracle as O
     from tests import replay as PL
@@ -77,11 +85,11 @@ def test_split_forward_and_backward_against_the_oracle_on_a_mid_size_room():
     fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
     vp = view()
     gt_image, gt_depth = vp.original_image.clone(), vp.depth.clone()
-    run = _run(fr, vp, init, bg, 2, flags=0, lean_min_P=1)
+    run = _run(fr, vp, init, bg, 3, flags=0, lean_min_P=1)
     blocks, ntiles_split, kmax, budget = fr.seg_stats()
     assert ntiles_split >= 5 and kmax >= 3, (blocks, ntiles_split, kmax)
     info = run["info"]
-    assert info["iters"] == 2 and info["fallbacks"] <= 1, {k: info[k] for k in ("iters", "fallbacks")}      # (a failed speculation's retry runs the split list too)
+    assert info["iters"] == 3 and info["fallbacks"] <= 3, {k: info[k] for k in ("iters", "fallbacks")}      # (a failed speculation's retry runs the split list too)
     vm, pm, cp = _camera_of_the_pose_state(info["R_last_forward_host"], info["T_last_forward_host"], S.camera_matrices(sc)[2])
     f = O.forward(sc.means3D, sc.opacities, vm, pm, cp, sc.W, sc.H, sc.tanfovx, sc.tanfovy, sc.bg, sh_degree=sc.sh_degree, shs=sc.shs,
                   scales=sc.scales, rotations=sc.rotations, want_n_touched=True)
@@ -103,7 +111,9 @@ def test_split_forward_and_backward_against_the_oracle_on_a_mid_size_room():
     assert U.rel_l1(fr.g_tau.cpu().numpy(), go["tau"]) <= 1e-5, U.rel_l1(fr.g_tau.cpu().numpy(), go["tau"])
     for k, ok in (("m3d", "means3D"), ("sh", "sh"), ("opac", "opacities"), ("scale", "scales"), ("rot", "rotations")):
         a, b = getattr(fr, "g_" + k).cpu().numpy(), go[ok]
-        assert U.rel_l1(a.reshape(b.shape), b) <= 2e-5, (k, U.rel_l1(a.reshape(b.shape), b))
+        # (5e-5 where a tenth of the tiles is split: the fp32 oracle's own distance from float64 on long lists, see
+        # test_split_backward_against_float64_autograd below and tests/test_gpu_lean.py)
+        assert U.rel_l1(a.reshape(b.shape), b) <= (5e-5 if ntiles_split >= 120 else 2e-5), (k, U.rel_l1(a.reshape(b.shape), b), ntiles_split)
         worst, share, at = U.row_errors(a.reshape(b.shape), b)
         assert worst <= 0.5 and share <= 1e-3, (k, worst, share, at)      # (bars of the full-size S-room-640 comparison, tests/test_gpu_lean.py)
 
@@ -117,3 +127,75 @@ def test_the_deterministic_option_never_splits():
     b = _run(fr, view(), init, bg, 6, flags=_lib.REFINE_DETERMINISTIC, lean_min_P=1, speculative=False)
     assert torch.equal(a["R"], b["R"]) and torch.equal(a["T"], b["T"])
     assert torch.equal(a["color"], b["color"]) and torch.equal(a["depth"], b["depth"]) and torch.equal(a["n_touched"], b["n_touched"])
+
+
+def _heavy_left(P=9000, W=96, H=64, seed=5, opac=0.2):
+    """A small scene with a few very heavy tiles: three quarters of the (faint) splats in front of the left third of the image."""
+    sc = S.small(P=P, W=W, H=H, sh_degree=1, seed=seed, scale_med=0.04)
+    r = np.random.default_rng(seed + 1)
+    m = sc.means3D.copy()
+    sel = r.random(P) < 0.75
+    z = m[sel, 2]
+    m[sel, 0] = (r.uniform(-1.0, -0.4, sel.sum()) * sc.tanfovx * z).astype(np.float32)
+    sc.means3D = np.ascontiguousarray(m)
+    sc.opacities = np.ascontiguousarray((sc.opacities * opac).astype(np.float32))
+    sc.name = "heavy-left"
+    return sc
+
+
+def _float64_gradients(sc, info, gi, gd):
+    """(oracle forward, oracle gradients, float64-autograd gradients) at the pose of the loop's last forward, for the pixel gradients gi, gd"""
+    from oracle import oracle as O, autograd_ref as AG
+    from tests.test_gpu_lean import _camera_of_the_pose_state
+    vm, pm, cp = _camera_of_the_pose_state(info["R_last_forward_host"], info["T_last_forward_host"], S.camera_matrices(sc)[2])
+    f = O.forward(sc.means3D, sc.opacities, vm, pm, cp, sc.W, sc.H, sc.tanfovx, sc.tanfovy, sc.bg, sh_degree=sc.sh_degree, shs=sc.shs,
+                  scales=sc.scales, rotations=sc.rotations, want_n_touched=True)
+    go = O.backward(f, gi, gd, np.zeros((1, sc.H, sc.W), np.float32), pose_mode=True)
+    w2c = np.eye(4)
+    w2c[:3, :3], w2c[:3, 3] = info["R_last_forward_host"].astype(np.float64), info["T_last_forward_host"].astype(np.float64)
+    t = lambda a: torch.tensor(np.asarray(a, np.float64), requires_grad=True)
+    leaves = dict(means3D=t(sc.means3D), opacities=t(sc.opacities), sh=t(sc.shs), scales=t(sc.scales), rotations=t(sc.rotations))
+    tau = torch.zeros(6, dtype=torch.float64, requires_grad=True)
+    col, dep, _, _ = AG.render_autograd(f.state(), f.radii, leaves["means3D"], leaves["opacities"], torch.tensor(w2c),
+                                        torch.tensor(np.asarray(S.camera_matrices(sc)[2], np.float64).T), sc.W, sc.H, sc.tanfovx, sc.tanfovy,
+                                        torch.tensor(sc.bg.astype(np.float64)), sh_degree=sc.sh_degree, tau=tau, depth_to_mean=True,
+                                        shs=leaves["sh"], scales=leaves["scales"], rotations=leaves["rotations"])
+    assert np.abs(col.detach().numpy() - f.color).max() < 2e-5          # (no threshold decision flipped between fp32 and fp64)
+    ((col * torch.tensor(gi.astype(np.float64))).sum() + (dep * torch.tensor(gd[0].astype(np.float64))).sum()).backward()
+    g64 = {k: v.grad.numpy() for k, v in leaves.items()}
+    g64["tau"] = tau.grad.numpy()
+    return f, go, g64
+
+
+def test_split_backward_against_float64_autograd():
+    """Whose rounding is it?  A split tile's backward restarts every depth range from sums the forward left (in double) instead of
+    carrying the reference's fp32 recurrences -- T recovered by repeated division, the colour behind by repeated blending,
+    backward.cu:499-516 -- through the whole list, so on long lists it no longer rounds like the fp32 oracle does and sits up to 2e-5
+    from it (tools/fuzz_split.py).  Held against float64 autograd of the same frozen decisions (oracle/autograd_ref.py) on tiles that
+    blend up to 2 600 splats per pixel, it is the ORACLE that is 2e-5 from the truth (and the unsplit walk with it, to 1e-6); the split
+    path is within 1e-6 of float64.  Measured (round 5, tools/dbg/split_f64.py): split 6e-7 ... 1.1e-6, oracle and unsplit loop
+    1.2e-5 ... 2.4e-5."""
+    from tests import replay as PL
+    sc = _heavy_left()
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    init = PL.perturbed_start(3, device=DEV)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    R, T, info = fr.refine(PL.make_frame(sc, model, DEV, bg), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=5,
+                           stop_on_converged=False, lean_min_P=1, warm_start=False)
+    torch.cuda.synchronize()
+    blocks, ntiles_split, kmax, budget = fr.seg_stats()
+    assert ntiles_split >= 4 and kmax >= 3, (blocks, ntiles_split, kmax, budget)
+    gi, gd = fr.g_img.cpu().numpy(), fr.g_depth.cpu().numpy()
+    assert np.abs(gi).sum() > 0
+    f, go, g64 = _float64_gradients(sc, info, gi, gd)
+    assert f.state()["n_contrib"].max() > 1500
+    report = {}
+    for k, ok in (("m3d", "means3D"), ("sh", "sh"), ("opac", "opacities"), ("scale", "scales"), ("rot", "rotations"), ("tau", "tau")):
+        a = getattr(fr, "g_" + k).cpu().numpy().reshape(g64[ok].shape)
+        report[k] = (U.rel_l1(a, g64[ok]), U.rel_l1(go[ok].reshape(g64[ok].shape), g64[ok]), U.rel_l1(a, go[ok].reshape(g64[ok].shape)))
+    print({k: tuple("%.1e" % x for x in v) for k, v in report.items()})
+    for k, (loop64, oracle64, loop_oracle) in report.items():
+        assert loop64 <= 5e-6, (k, loop64)                      # the split path against the truth
+        assert loop64 <= oracle64, (k, loop64, oracle64)        # ... at least as close to it as the fp32 restatement of the reference
+        assert loop_oracle <= 1e-4, (k, loop_oracle)

@@ -81,12 +81,27 @@ for case in range(CASES):
     for k, ok in (("m3d", "means3D"), ("sh", "sh"), ("opac", "opacities"), ("scale", "scales"), ("rot", "rotations")):
         errs[k] = U.rel_l1(getattr(fr, "g_" + k).cpu().numpy().reshape(go[ok].shape), go[ok])
     bad = (errs["radii"] != 0 or max(errs["color"], errs["depth"], errs["alpha"]) > 1e-4 or errs["n_touched"] > 1e-4 or errs["tau"] > 1e-5 or
-           max(errs[k] for k in ("m3d", "sh", "opac", "scale", "rot")) > 2e-5 or max(dT, dR) > 2e-5)
+           max(errs[k] for k in ("m3d", "sh", "opac", "scale", "rot")) > (5e-5 if st[1] * 4 > st[3] // 3 else 2e-5) or max(dT, dR) > 2e-5)
+    # (a case with more than a quarter of its tiles split is held to 5e-5: on long lists the fp32 oracle itself is 2e-5 from float64 -- its
+    # T by repeated division, backward.cu:516 -- and the split path, which restarts each depth range from double-precision sums, is not:
+    # tests/test_gpu_split.py::test_split_backward_against_float64_autograd; BOTH=1 prints the unsplit loop's distance next to it)
     for k, e in errs.items():
         worst[k] = max(worst.get(k, 0), e)
     worst["dT"] = max(worst.get("dT", 0), dT)
     print("%s case %d %s P=%d seed=%d K=%d seg=%s fallbacks=%d/%d  dT %.1e  " % ("FAIL" if bad else "ok  ", case, kind, P, seed, K, st, info["fallbacks"], runs["nosplit"]["info"]["fallbacks"], dT) +
           " ".join("%s %.1e" % (k, e) for k, e in errs.items()), flush=True)
+    if os.environ.get("BOTH"):          # the unsplit loop against the oracle at ITS last pose: is the split path further from the oracle than the unsplit one?
+        b = runs["nosplit"]
+        frb, infb = b["fr"], b["info"]
+        vm, pm, cp = _camera_of_the_pose_state(infb["R_last_forward_host"], infb["T_last_forward_host"], S.camera_matrices(sc)[2])
+        fb = O.forward(sc.means3D, sc.opacities, vm, pm, cp, sc.W, sc.H, sc.tanfovx, sc.tanfovy, sc.bg, sh_degree=sc.sh_degree, shs=sc.shs, scales=sc.scales, rotations=sc.rotations)
+        exb = infb["exposure_last_forward_host"]
+        v.exposure_a, v.exposure_b = torch.tensor([float(exb[0])], device=dev), torch.tensor([float(exb[1])], device=dev)
+        ti, td = b["color"].clone().requires_grad_(True), b["depth"].clone().requires_grad_(True)
+        PL.tracking_loss(PL.TRACKING_CONFIG, ti, td, b["alpha"], v).backward()
+        gb = O.backward(fb, ti.grad.cpu().numpy(), td.grad.cpu().numpy(), np.zeros((1, sc.H, sc.W), np.float32), pose_mode=True)
+        print("      unsplit loop against the oracle:", " ".join("%s %.1e" % (k, U.rel_l1(getattr(frb, "g_" + k).cpu().numpy().reshape(gb[ok].shape), gb[ok]))
+                                                                 for k, ok in (("m3d", "means3D"), ("sh", "sh"), ("opac", "opacities"), ("scale", "scales"), ("rot", "rotations"))), flush=True)
     del model, runs, fr, a
     torch.cuda.empty_cache()
 print("cases", CASES, "with split tiles", n_split_cases, "worst", {k: float("%.2e" % v) for k, v in worst.items()}, "in %.0f s" % (time.time() - t_start))
