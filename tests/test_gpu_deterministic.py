@@ -58,7 +58,7 @@ def _loop_variants(sc, K, seed, lean_min_P=0):
     return spec1, spec2, nolean, plain, default
 
 
-def _check_variants(spec1, spec2, nolean, plain, default, K):
+def _check_variants(spec1, spec2, nolean, plain, default, K, grad_bar=2e-4):
     assert spec1["info"]["lean_iters"] >= 1 and nolean["info"]["lean_iters"] == 0 and plain["info"]["lean_iters"] == 0, spec1["info"]
     _bit_equal(spec1, spec2, "two deterministic runs")
     _bit_equal(spec1, nolean, "speculative vs GSR_REFINE_NO_LEAN")
@@ -68,7 +68,7 @@ def _check_variants(spec1, spec2, nolean, plain, default, K):
     assert torch.allclose(spec1["R"], default["R"], atol=2e-6) and torch.allclose(spec1["T"], default["T"], atol=2e-6)
     for k in ("m3d", "sh", "opac", "scale", "rot", "tau"):
         a, b = spec1["g_" + k].cpu().numpy(), default["g_" + k].cpu().numpy()
-        assert U.rel_l1(a, b) <= 2e-4, (k, U.rel_l1(a, b))
+        assert U.rel_l1(a, b) <= grad_bar, (k, U.rel_l1(a, b))
 
 
 def test_loop_variants_agree_bit_for_bit_small_map():
@@ -79,6 +79,16 @@ def test_loop_variants_agree_bit_for_bit_small_map():
 def test_loop_variants_agree_bit_for_bit_at_the_headline_size():
     """S-1M-640 (BASELINE.json configs[1]): 12 iterations, the product's own thresholds (the lean kernel runs: P >= 200 000)."""
     _check_variants(*_loop_variants(S.s_1m_640(), 12, seed=3), 12)
+
+
+@pytest.mark.parametrize("name", ["object", "walls", "room"])
+def test_loop_variants_agree_bit_for_bit_on_the_structured_scenes(name):
+    """the structured variants of the headline scene (gs_localization_amd/scenes.py) in the bit-for-bit set, at full
+    size -- speculative lists (with the depth bounds widened at discontinuities, verification failures and device-side retries these
+    scenes provoke) against GSR_REFINE_NO_LEAN against complete lists.  The deterministic option never splits a tile; the default-mode
+    run next to it does (S-room-640, object), hence the wider bar on its gradients (tests/test_gpu_split.py: what two loops whose pixels
+    fall on different sides of the 1e-4 threshold differ by)."""
+    _check_variants(*_loop_variants(S.VARIANTS[name](), 8, seed=3), 8, grad_bar=1e-3)
 
 
 def test_diagnostic_switches_and_pose_only_mode_change_no_bit():
