@@ -3186,11 +3186,18 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
         GSR_T_COUNT(10, 1)
         nbatch++;
         const int n = min(GSR_BWD_STAGE, total - (int)lo_pos - base);
+        // (round 5: one vector load per staged entry pulls its record towards this CU before the walk's scalar loads ask for it one
+        // entry ahead.  With the SIMD's other waves to hide it the record's trip from HBM / the other XCDs' L2 never showed; at the end of a
+        // launch, and in a launch's second round of blocks, a wave is alone with it -- 4-5 k cycles per group of eight, timing build.
+        // S-room-640 K7 200 -> 170 us, walls 148 -> 142, S-1M-640 55.9 -> 55.5.)
+        float touch0 = 0.f, touch1 = 0.f;
         if (tid < n) {
             const uint32_t e = point_list[range.x + (total - 1 - base - tid)];
             if (pack_qm) {          // the forward left this tile's quadrant mask of the splat in the entry (k_render_fwd, pack_qm)
                 s.ids[tid] = e & 0x0FFFFFFFu;
                 s.qm[tid] = (uint8_t)(e >> 28);
+                const float* rr = rec + (size_t)(e & 0x0FFFFFFFu) * GSR_REC_STRIDE;
+                touch0 = rr[0]; touch1 = rr[11];
             } else {
                 const SplatRec sr = load_splat_rec(rec, e);
                 s.ids[tid] = e;
@@ -3225,6 +3232,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
             s.off[wv][cnt + lane] = (uint32_t)P * GSR_REC_STRIDE;
         }
         walked += (cnt + 7) >> 3;
+        asm volatile("" : : "v"(touch0), "v"(touch1));      // (the touches have arrived: the wait sits behind the list compaction)
         GSR_T_TICK(3)
         GSR_T_COUNT(11, cnt)
         for (int g0 = 0; g0 < cnt; g0 += 8) {
