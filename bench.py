@@ -474,7 +474,9 @@ def main():
                        "iterations_per_step": F, "gaussian_grads": not args.pose_only,
                        "parallelism": f"frames: {world} GPU x {F} in flight",
                        "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
-                       "loop": "native gsr_refine (render, tracking loss, backward, Adam, update_pose per iteration)",
+                       "loop": "native gsr_refine (render, tracking loss, backward, Adam, update_pose per iteration; dL/dtau every iteration, the gradient tensors "
+                               "of the Gaussians' own parameters -- which nobody can read before the call returns -- written once per call, from the last "
+                               "stepped iteration's records: what the reference's last loss.backward() leaves)",
                        "iterations_per_call": K,
                        "warm_policy": "every refinement call starts from the depth bounds ANOTHER query frame (another start pose) left in its "
                                       "refiner's workspace, verified on the device; single_frame_cold_start_iters_per_s has no bounds to start from",
