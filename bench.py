@@ -4,7 +4,9 @@
 
 One refinement iteration = one body of the reference's loop
 (gs_localization/pipelines/7scenes_localize_full_dslam.py:66-91): render() through the pose rasterizer
--> tracking loss -> backward (ALL Gaussian gradients + dL/dtau) -> Adam step -> update_pose ->
+-> tracking loss -> backward (dL/dtau every iteration; the gradient tensors of the Gaussians' own parameters, which
+nobody can read before the refinement call returns, are written once per call from the last stepped iteration's records --
+what the reference's last loss.backward() leaves; `config.loop`) -> Adam step -> update_pose ->
 convergence flag.  Query frames are independent, so every rank (GPU) refines its own frames against its
 own replica of the map (weak scaling, no data-path collective; one gather of the results at the end),
 and keeps F frames in flight (one host thread + one HIP stream each): the compositing kernels are chains of
