@@ -258,25 +258,29 @@ def main():
     # ---- (b) the native loop (gsr_refine), one frame at a time; per-kernel breakdown from a separate short run
     frs = [PL.FusedRefiner(model, H, W, device=dev, gaussian_grads=not args.pose_only) for _ in range(F)]
 
-    def native(f, iters, stop=False, speculative=True, warm=None, frame=None):
+    def native(f, iters, stop=False, speculative=True, warm=None, frame=None, flags=None):
         # warm=None: the refiner's default -- a frame starts from the depth bounds its PREDECESSOR on this refiner left behind
         # (consecutive frames of a sequence), verified on the device like every speculation.  The predecessor is always another
         # query frame here (another start pose): refiner slot f takes frame `frame` (default f).
         g = f if frame is None else frame % F
         return frs[f].refine(vps[g], config, inits[g][:3, :3].clone(), inits[g][:3, 3].clone(), background, iters=iters,
-                             stop_on_converged=stop, speculative=speculative, warm_start=warm)
+                             stop_on_converged=stop, speculative=speculative, warm_start=warm, flags=flags)
 
-    def timed_single(spec, iters=K, warm=None):
-        native(0, Wm, speculative=spec, frame=1)           # the predecessor: frame 1 (its bounds are what a warm start gets)
+    def timed_single(spec, iters=K, warm=None, flags=None):
+        native(0, Wm, speculative=spec, frame=1, flags=flags)           # the predecessor: frame 1 (its bounds are what a warm start gets)
         barrier(); torch.cuda.synchronize()
         t = time.perf_counter()
-        native(0, iters, speculative=spec, warm=warm, frame=0)
+        native(0, iters, speculative=spec, warm=warm, frame=0, flags=flags)
         torch.cuda.synchronize(); barrier()
         return time.perf_counter() - t
     # (every leg: the best of three)
     elapsed_single = min(timed_single(True) for _ in range(3))
     elapsed_plain = min(timed_single(False) for _ in range(3))
     elapsed_cold = min(timed_single(True, warm=False) for _ in range(3))          # first iteration bins completely (no bounds from a previous frame)
+    # (diagnostics, next to the headline: the same single-frame call with the Gaussian-parameter gradient rows written by EVERY iteration
+    # instead of once per call -- GSR_REFINE_GRADS_EVERY_ITERATION; same results, tests/test_gpu_deterministic.py)
+    from gs_localization_amd import _lib as _L
+    elapsed_rows_every = min(timed_single(True, flags=_L.REFINE_GRADS_EVERY_ITERATION) for _ in range(3))
     # per-call fixed cost: one K-iteration call against the marginal cost of an iteration inside a long call
     elapsed_long = min(timed_single(True, iters=4 * K) for _ in range(2))
     steady_ms = 1e3 * (elapsed_long - elapsed_single) / (3 * K)
@@ -488,6 +492,7 @@ def main():
             "value_repeats_stats": run_stats,
             "stream_of_frames_iters_per_s": 4 * F * K / elapsed_stream,
             "single_frame_iters_per_s": single,
+            "single_frame_iters_per_s_gradient_rows_every_iteration": world * K / elapsed_rows_every,
             "single_frame_cold_start_iters_per_s": world * K / elapsed_cold,
             # one refinement call of K iterations on one frame: its time, the marginal cost of an iteration inside a long call,
             # and what the call costs on top of K of those (host set-up, first iteration, the n_touched pass, final read-back)
@@ -718,9 +723,9 @@ def scene_variants_leg(lib, dev, K=50, only=None):
         del pkg
         fr = PL.FusedRefiner(model, H, W, device=dev)
 
-        def call(g, iters, spec, warm=None):
+        def call(g, iters, spec, warm=None, flags=None):
             return fr.refine(frames[g], PL.TRACKING_CONFIG, inits[g][:3, :3].clone(), inits[g][:3, 3].clone(), bg, iters=iters,
-                             stop_on_converged=False, speculative=spec, warm_start=warm)
+                             stop_on_converged=False, speculative=spec, warm_start=warm, flags=flags)
         res = {}
         for spec in (True, False):
             best, info = 1e9, None
@@ -735,6 +740,16 @@ def scene_variants_leg(lib, dev, K=50, only=None):
                     best, info = el, {k: inf[k] for k in ("fallbacks", "host_redos", "lean_iters")}
             kms, _ = _profile_ms(lib, lambda: call(0, K, spec), 2)
             res[spec] = (K / best, {k: round(v / K, 4) for k, v in kms.items() if v > 0}, info)
+        # (diagnostics: the speculative loop with the Gaussian-parameter gradient rows written by every iteration, GSR_REFINE_GRADS_EVERY_ITERATION)
+        from gs_localization_amd import _lib as _L
+        best_every = 1e9
+        for _ in range(3):
+            call(1, 5, True, flags=_L.REFINE_GRADS_EVERY_ITERATION)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            call(0, K, True, flags=_L.REFINE_GRADS_EVERY_ITERATION)
+            torch.cuda.synchronize()
+            best_every = min(best_every, time.perf_counter() - t0)
         # pose error of a full refinement with the reference's early exit
         Rr, Tt, inf = fr.refine(frames[0], PL.TRACKING_CONFIG, inits[0][:3, :3].clone(), inits[0][:3, 3].clone(), bg, iters=50, stop_on_converged=True)
         te, re = PL.pose_errors(np.eye(3), np.zeros(3), inf["R_host"], inf["T_host"])
@@ -743,6 +758,7 @@ def scene_variants_leg(lib, dev, K=50, only=None):
         rows.append({"scene": sc.name, "variant": vname, "width": W, "height": H, "gaussians": sc.P, "tiles": ntiles, "V": V, "R": R,
                      "R_eff_own_binning": R_eff, "list_entries_ordered": R_ord, "iterations_per_call": K,
                      "speculative_iters_per_s": res[True][0], "plain_iters_per_s": res[False][0],
+                     "speculative_iters_per_s_gradient_rows_every_iteration": K / best_every,
                      "speculative_call_stats": res[True][2], "plain_call_stats": res[False][2],
                      "pose_err_cm_deg_after_refinement": [100.0 * te, re], "refine_iters": inf["iters"],
                      "kernels_ms_per_iter_speculative": res[True][1], "kernels_ms_per_iter_plain": res[False][1],

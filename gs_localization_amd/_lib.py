@@ -112,6 +112,7 @@ class RefineArgs(C.Structure):
 # the GSR_ABI_VERSION these ctypes mirrors (SpecState, RefineArgs, the pose-state layout) were written for
 ABI_VERSION = 4
 REFINE_NO_LEAN, REFINE_SH_SEPARATE, REFINE_NO_BALANCE, REFINE_LOG_REDO, REFINE_DETERMINISTIC, REFINE_NO_SPLIT, REFINE_NO_DILATE = 1, 2, 4, 8, 16, 32, 64
+REFINE_GRADS_EVERY_ITERATION = 128      # diagnostics: the Gaussian-parameter gradient rows written by every iteration instead of once per call
 
 
 POSE_STATE_FLOATS = 112

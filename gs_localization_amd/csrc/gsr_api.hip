@@ -1090,6 +1090,7 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
     pb.dirty = cx.native_loop ? g.dirty : nullptr;
     pb.aflag = g.aflag;
     pb.role = cx.native_loop ? 1 : 0;
+    pb.rows_every = (cx.native_loop && (cx.flags & GSR_REFINE_GRADS_EVERY_ITERATION)) ? 1 : 0;
     pb.o_surv = g.o_surv; pb.o_aflag = g.o_aflag; pb.o_acc = g.o_acc; pb.o_rec = g.o_rec; pb.o_clamped = g.o_clamped;
     pb.o_cam = g.prev_cam; pb.final_done = g.final_done;
     pb.guard = cx.guard;
@@ -1669,7 +1670,7 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
         }
     }
     *iters_done = succ;
-    if (last_step_g >= 0) {
+    if (last_step_g >= 0 && !(a->flags & GSR_REFINE_GRADS_EVERY_ITERATION)) {
         // The gradients of the Gaussians' own parameters: rows written once, from the records of the last iteration whose pose step
         // ran (PreBwdArgs::role).  When the loop converged with a frozen forward behind that iteration, that group's launch has done it
         // already (and says so in *final_done).

@@ -3763,6 +3763,7 @@ struct PreBwdArgs {
     //           (o_*) gets the full treatment, rows and dirty bits, once (*final_done), before a later frozen forward reuses its lists.
     //   role 2  launched by the host behind the last group: the full treatment of o_* unless *final_done says it has been given.
     int role;
+    int rows_every;      // GSR_REFINE_GRADS_EVERY_ITERATION (diagnostics): role 1 launches write the rows themselves, no final pass
     SurvLists o_surv; uint8_t* o_aflag; float* o_acc; uint32_t* final_done;
     const float* o_rec; const uint8_t* o_clamped;      // (the splat records and SH clamp flags of that set's forward ...
     const float* o_cam;                                // ... and its camera: PoseStepArgs::prev_cam)
@@ -3990,12 +3991,15 @@ __global__ void __launch_bounds__(64) k_preprocess_bwd(PreBwdArgs a)
     // What this launch does (block-uniform; PreBwdArgs::role).  final_done is only ever written by the last workgroup of a launch,
     // after every workgroup has drawn its ticket: all workgroups of one launch read the same value.
     const bool conv = a.role == 1 && a.guard.conv != nullptr && *a.guard.conv != 0.f;
-    const bool final_pass = (a.role == 2 || conv) && *a.final_done == 0u;
+    // (rows_every: GSR_REFINE_GRADS_EVERY_ITERATION -- every iteration of the loop writes the rows itself, from its own set, like the
+    // stateless backward; there is no final pass then.  Diagnostics: both ways must leave the same bits.)
+    const bool every = a.rows_every != 0;
+    const bool final_pass = !every && (a.role == 2 || conv) && *a.final_done == 0u;
     if (a.role == 2 && !final_pass) return;
     const bool walk = final_pass || !frozen;
-    const bool rows_on = a.role == 0 || final_pass;      // gradient rows and dirty bits written, flags and records consumed
+    const bool rows_on = a.role == 0 || final_pass || every;      // gradient rows and dirty bits written, flags and records consumed
     const bool tau_on = a.pose != 0 && !final_pass;
-    const bool clear_other = a.role == 1 && !conv;       // (a poisoned group does this part too)
+    const bool clear_other = a.role == 1 && !conv && !every;       // (a poisoned group does this part too)
     const SurvLists wl = final_pass ? a.o_surv : a.surv;
     uint8_t* const wflag = final_pass ? a.o_aflag : a.aflag;
     float* const wacc = final_pass ? a.o_acc : a.acc;

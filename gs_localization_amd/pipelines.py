@@ -162,13 +162,14 @@ class FusedRefiner:
 
     @staticmethod
     def _env_flags():
-        """GSR_NO_LEAN / GSR_SH_SEPARATE / GSR_NO_BALANCE / GSR_DEBUG_TILES / GSR_DETERMINISTIC / GSR_NO_SPLIT / GSR_NO_DILATE of the environment ->
+        """GSR_NO_LEAN / GSR_SH_SEPARATE / GSR_NO_BALANCE / GSR_DEBUG_TILES / GSR_DETERMINISTIC / GSR_NO_SPLIT / GSR_NO_DILATE / GSR_GRADS_EVERY_ITERATION of the environment ->
         gsr_refine_args.flags (the library itself reads no environment variable on this path)."""
         from . import _lib
         from .rasterizer import _env_has as has
         return ((_lib.REFINE_NO_LEAN if has("GSR_NO_LEAN") else 0) | (_lib.REFINE_SH_SEPARATE if has("GSR_SH_SEPARATE") else 0) |
                 (_lib.REFINE_NO_BALANCE if has("GSR_NO_BALANCE") else 0) | (_lib.REFINE_LOG_REDO if has("GSR_DEBUG_TILES") else 0) |
-                (_lib.REFINE_DETERMINISTIC if has("GSR_DETERMINISTIC") else 0) | (_lib.REFINE_NO_SPLIT if has("GSR_NO_SPLIT") else 0) | (_lib.REFINE_NO_DILATE if has("GSR_NO_DILATE") else 0))
+                (_lib.REFINE_DETERMINISTIC if has("GSR_DETERMINISTIC") else 0) | (_lib.REFINE_NO_SPLIT if has("GSR_NO_SPLIT") else 0) | (_lib.REFINE_NO_DILATE if has("GSR_NO_DILATE") else 0) |
+                (_lib.REFINE_GRADS_EVERY_ITERATION if has("GSR_GRADS_EVERY_ITERATION") else 0))
 
     def refine(self, viewpoint, config, initial_R, initial_T, background, iters=50, lr=0.001, converged_threshold=1e-4,
                stop_on_converged=True, speculative=True, bound_margin=None, warm_start=None, count_instances=False,

@@ -318,7 +318,8 @@ def test_survivor_sublists_hold_a_fully_visible_map():
 @pytest.mark.parametrize("spec", [True, False])
 def test_gradient_rows_after_an_early_exit_are_those_of_the_last_stepped_iteration(spec):
     """The loop writes the gradients of the Gaussians' own parameters ONCE per call, from the records of the last iteration whose
-    pose step ran (gsr::PreBwdArgs::role).  Three ways to get there must give the same bits: (a) the iterations are used up (the
+    pose step ran (gsr::PreBwdArgs::role).  Three ways to get there must give the same bits -- the bits of a loop that writes the rows in
+    every iteration (GSR_REFINE_GRADS_EVERY_ITERATION) --: (a) the iterations are used up (the
     host launches the final pass), (b) the loop converges early, a frozen forward at the final pose runs behind the last
     iteration and ITS chain-rule launch does the final pass -- from the other set of lists / records / splat records and the camera
     the pose step saved, (c) it converges in its very last iteration (no frozen forward; host).  A second call on the same
@@ -331,8 +332,8 @@ def test_gradient_rows_after_an_early_exit_are_those_of_the_last_stepped_iterati
     view = lambda: PL.make_frame(sc, model, DEV, bg)
     cfg = PL.TRACKING_CONFIG
 
-    def call(fr, iters, **kw):
-        R, T, info = fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=iters, flags=DET, speculative=spec,
+    def call(fr, iters, flags=DET, **kw):
+        R, T, info = fr.refine(view(), cfg, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=iters, flags=flags, speculative=spec,
                                warm_start=False, **kw)
         torch.cuda.synchronize()
         out = dict(R=R.clone(), T=T.clone(), info=info)
@@ -354,6 +355,11 @@ def test_gradient_rows_after_an_early_exit_are_those_of_the_last_stepped_iterati
     full = call(frA, k, stop_on_converged=False)
     assert float(full["g_m3d"].abs().sum()) > 0 and float(full["g_sh"].abs().sum()) > 0
     _bit_equal(full, early, "iterations used up / early exit with a frozen forward behind it")
+    # ... and the same bits as a loop that writes the rows in EVERY iteration, the way a sequence of gsr_backward calls would
+    # (GSR_REFINE_GRADS_EVERY_ITERATION): writing them once is not a different result, only less work nobody could have observed
+    EVERY = DET | _lib.REFINE_GRADS_EVERY_ITERATION
+    _bit_equal(full, call(PL.FusedRefiner(model, sc.H, sc.W, device=DEV), k, flags=EVERY, stop_on_converged=False), "rows once / rows in every iteration")
+    _bit_equal(early, call(PL.FusedRefiner(model, sc.H, sc.W, device=DEV), 30, flags=EVERY, converged_threshold=thr), "rows once / every iteration, early exit")
     # (c): converges in the last iteration it was given
     frC = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
     last = call(frC, k, converged_threshold=thr)
