@@ -56,7 +56,7 @@ work: `render()` {h["forward"]:.0f} µs forward / {h["backward_incl_two_torch_su
 `train.py` step (config 4, 1296×840, SH1): {tr["per_P"][0]["ms_per_step"]:.2f} / {tr["per_P"][1]["ms_per_step"]:.2f} / {tr["per_P"][2]["ms_per_step"]:.2f} ms at 0.2 / 0.8 / 1.5 M Gaussians; at 1.5 M the rasterizer forward is
 {tr["per_P"][2]["rasterizer_fwd_ms"]:.2f} ms (preprocess {us(k15["preprocess_fwd"])} + count {us(k15["tile_count"])} + scan {us(k15["tile_scan"])} + emit {us(k15["tile_emit"])} + K6 {us(k15["render_fwd"])} µs (round 3: 240) and the blocking count read), the backward
 K7 {us(k15["render_bwd"])} (round 3: 283; launched heaviest tile first now) + K8 {us(k15["preprocess_bwd"])} µs (43), loss epilogue {tr["per_P"][2]["loss_epilogue_ms"]:.2f} ms, torch's Adam + statistics {tr["per_P"][2]["stats_and_adam_ms"]:.2f} ms.
-BASELINE config 4 as written (`tools/train_7k.py`, 7 000 steps, 64 changes of P from 0.2 to 1.5 M, opacity reset at 3 000): 17.9 s, 2.55 ms per step, 1 441 MiB peak.
+BASELINE config 4 as written (`tools/train_7k.py`, 7 000 steps, 64 changes of P from 0.2 to 1.5 M, opacity reset at 3 000): 17.5 s, 2.50 ms per step, 1 441 MiB peak (final kernels; 17.9 s / 2.55 ms before the record touches of K7).
 VERDICT r4's targets for the training forward (≤ 0.44 ms, no blocking read above 2 048 tiles) and `python_loop_iters_per_s` ≥ 650 are NOT met; HISTORY.md (round 5) has the host-time breakdown that says why the latter cannot be met from this side of the boundary.
 '''
 readme = f'''Round 5 on one MI355X (`bench.py` defaults: 50 iterations per refinement call as in the reference, {dd["config"]["frames_in_flight_per_gpu"]} frames in flight; gpurun boxes --
