@@ -110,7 +110,7 @@ class RefineArgs(C.Structure):
 
 
 # the GSR_ABI_VERSION these ctypes mirrors (SpecState, RefineArgs, the pose-state layout) were written for
-ABI_VERSION = 4
+ABI_VERSION = 5
 REFINE_NO_LEAN, REFINE_SH_SEPARATE, REFINE_NO_BALANCE, REFINE_LOG_REDO, REFINE_DETERMINISTIC, REFINE_NO_SPLIT, REFINE_NO_DILATE = 1, 2, 4, 8, 16, 32, 64
 REFINE_GRADS_EVERY_ITERATION = 128      # diagnostics: the Gaussian-parameter gradient rows written by every iteration instead of once per call
 
@@ -126,6 +126,9 @@ SIGNATURES.update({
     "gsr_debug_lean_check": (_i, [C.POINTER(RefineArgs), C.POINTER(C.c_longlong)]),
     "gsr_debug_seg_stats": (_i, [C.POINTER(RefineArgs), C.POINTER(C.c_longlong)]),
     "gsr_debug_lam_offset": (C.c_size_t, [_i]),
+    "gsr_grad_mask_bytes": (C.c_size_t, [_i, _i]),
+    "gsr_grad_mask": (_i, [_i, _i, _vp, _f, _vp, _i, _i, _vp, _vp, _vp, RESIZE_FN, _vp, _vp]),
+    "gsr_grad_mask_replica": (_i, [_i, _i, _vp, _f, _i, _i, _vp, RESIZE_FN, _vp, _vp]),
 })
 
 _lib = None

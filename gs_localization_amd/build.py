@@ -6,7 +6,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_HERE)
 SRC = os.path.join(_HERE, "csrc", "gsr_api.hip")
-DEPS = [SRC] + [os.path.join(_HERE, "csrc", f) for f in ("gsr_kernels.h", "gsr_device.h")] + [os.path.join(_ROOT, "include", "gsr.h")]
+DEPS = [SRC] + [os.path.join(_HERE, "csrc", f) for f in ("gsr_kernels.h", "gsr_device.h", "gsr_gradmask.h")] + [os.path.join(_ROOT, "include", "gsr.h")]
 # GSR_LIB_PATH: diagnostic builds (GSR_TIMING, GSR_DEFS=...) go to a path of their own and are loaded from there (_lib.py reads the
 # same variable), so that an experiment never leaves a non-default library where the tests and bench.py look for the product build.
 OUT = os.environ.get("GSR_LIB_PATH") or os.path.join(_HERE, "libgsr_hip.so")

@@ -16,6 +16,7 @@
 
 #include "gsr.h"
 #include "gsr_kernels.h"
+#include "gsr_gradmask.h"
 
 namespace {
 
@@ -1853,6 +1854,87 @@ size_t carve_knn(char* base, int P, KnnWs& w)
 }  // namespace
 
 size_t gsr_knn_bytes(int P) { KnnWs w; return carve_knn(nullptr, P, w); }
+
+// ---- the per-frame gradient mask (camera_utils.py:164-193 + the keypoint boxes of the scripts) ----
+namespace {
+const size_t kGmHistBytes = 3 * GSR_GM_BINS * sizeof(uint32_t);          // three histograms, then 256 B of result words, then the intensity image
+struct GmCarve { uint32_t* hist; float* median; float* intensity; };
+int gm_begin(int width, int height, const float* image, gsr_resize_fn workspace, void* workspace_ctx, float* intensity_out, hipStream_t st,
+             gsr::GradMaskArgs& a, GmCarve& cv)
+{
+    const int debug = 0;
+    using namespace gsr;
+    if (width < 2 || height < 2) return fail(GSR_E_INVALID, "gsr_grad_mask: the reflect padding needs an image of at least 2 x 2 pixels%s", "");
+    if ((long long)width * height > 0x7fffffffLL) return fail(GSR_E_INVALID, "gsr_grad_mask: image too large%s", "");
+    if (!image || !workspace) return fail(GSR_E_INVALID, "gsr_grad_mask: NULL pointer%s", "");
+    int rc = select_device_of(image);
+    if (rc != GSR_OK) return rc;
+    char* ws = (char*)workspace(workspace_ctx, gsr_grad_mask_bytes(width, height));
+    if (!ws) return fail(GSR_E_ALLOC, "workspace callback returned NULL%s", "");
+    cv.hist = reinterpret_cast<uint32_t*>(ws);
+    cv.median = reinterpret_cast<float*>(ws + kGmHistBytes);
+    cv.intensity = intensity_out ? intensity_out : reinterpret_cast<float*>(ws + kGmHistBytes + 256);
+    HIPCHK(hipMemsetAsync(ws, 0, kGmHistBytes + 256, st));
+    a.W = width; a.H = height; a.image = image; a.intensity = cv.intensity; a.hist = cv.hist;
+    a.rank = (uint32_t)(((long long)width * height - 1) / 2);
+    a.edge_threshold = 0.f; a.mask = nullptr; a.median_out = cv.median;
+    hipLaunchKernelGGL(k_gradmask_intensity, dim3((width + GSR_GM_TW - 1) / GSR_GM_TW, (height + GSR_GM_TH - 1) / GSR_GM_TH), dim3(256), 0, st, a);
+    LAUNCHCHK("k_gradmask_intensity");
+    return 0;
+}
+}  // namespace
+
+size_t gsr_grad_mask_bytes(int width, int height)
+{
+    return kGmHistBytes + 256 + (size_t)(width > 0 ? width : 0) * (size_t)(height > 0 ? height : 0) * sizeof(float);
+}
+
+int gsr_grad_mask(int width, int height, const float* image, float edge_threshold, const float* keypoints, int num_keypoints, int box_k,
+                  uint8_t* grad_mask, float* intensity_out, float* median_out, gsr_resize_fn workspace, void* workspace_ctx, void* stream)
+{
+    using namespace gsr;
+    const int debug = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (!grad_mask) return fail(GSR_E_INVALID, "gsr_grad_mask: NULL pointer%s", "");
+    if (num_keypoints < 0 || box_k < 0 || (num_keypoints > 0 && !keypoints)) return fail(GSR_E_INVALID, "gsr_grad_mask: keypoints%s", "");
+    GradMaskArgs a; GmCarve cv;
+    int rc = gm_begin(width, height, image, workspace, workspace_ctx, intensity_out, st, a, cv);
+    if (rc != 0) return rc;
+    a.edge_threshold = edge_threshold; a.mask = grad_mask;
+    if (median_out) a.median_out = median_out;
+    const long long n = (long long)width * height;
+    const int blocks = (int)std::min<long long>((n + 255) / 256, 1024);
+    hipLaunchKernelGGL(k_gradmask_hist<2>, dim3(blocks), dim3(256), 0, st, a);
+    LAUNCHCHK("k_gradmask_hist<2>");
+    hipLaunchKernelGGL(k_gradmask_hist<3>, dim3(blocks), dim3(256), 0, st, a);
+    LAUNCHCHK("k_gradmask_hist<3>");
+    hipLaunchKernelGGL(k_gradmask_threshold, dim3(blocks), dim3(256), 0, st, a);
+    LAUNCHCHK("k_gradmask_threshold");
+    if (num_keypoints > 0) {
+        hipLaunchKernelGGL(k_gradmask_boxes, dim3((num_keypoints + 3) / 4), dim3(256), 0, st, width, height, keypoints, num_keypoints, box_k / 2, grad_mask);
+        LAUNCHCHK("k_gradmask_boxes");
+    }
+    return 0;
+}
+
+int gsr_grad_mask_replica(int width, int height, const float* image, float edge_threshold, int rows, int cols, float* grad_mask,
+                          gsr_resize_fn workspace, void* workspace_ctx, void* stream)
+{
+    using namespace gsr;
+    const int debug = 0;
+    hipStream_t st = (hipStream_t)stream;
+    if (!grad_mask) return fail(GSR_E_INVALID, "gsr_grad_mask_replica: NULL pointer%s", "");
+    if (rows <= 0 || cols <= 0 || height / rows <= 0 || width / cols <= 0)
+        return fail(GSR_E_INVALID, "gsr_grad_mask_replica: every block of the rows x cols grid needs at least one pixel (the reference's block.median() raises on an empty block)%s", "");
+    GradMaskArgs a; GmCarve cv;
+    int rc = gm_begin(width, height, image, workspace, workspace_ctx, nullptr, st, a, cv);
+    if (rc != 0) return rc;
+    HIPCHK(hipMemcpyAsync(grad_mask, cv.intensity, (size_t)width * height * sizeof(float), hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_gradmask_replica, dim3(rows * cols), dim3(256), 0, st, width, height, width / cols, height / rows, cols,
+                       (const float*)cv.intensity, edge_threshold, grad_mask);
+    LAUNCHCHK("k_gradmask_replica");
+    return 0;
+}
 
 int gsr_dist2_knn3(int P, const float* points, float* mean_dist2, gsr_resize_fn workspace, void* workspace_ctx, void* stream)
 {

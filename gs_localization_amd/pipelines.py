@@ -308,6 +308,85 @@ class FusedRefiner:
         return tuple(int(x) for x in out)
 
 
+# ------------------------------------------------------------------ the per-frame gradient mask
+_GM_WORKSPACES = {}          # one scratch buffer per (device, stream): three histograms + the intensity image; grows to the largest frame seen
+
+
+def _gm_workspace(dev):
+    from .rasterizer import _Workspace
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)          # (calls on different streams may overlap: no shared scratch)
+    ws = _GM_WORKSPACES.get(key)
+    if ws is None:
+        ws = _GM_WORKSPACES[key] = _Workspace(dev)
+    return ws
+
+
+def grad_mask(original_image, edge_threshold, keypoints=None, box_k=10, return_intensity=False):
+    """`Camera.compute_grad_mask` (tools/camera_utils.py:164-193, every dataset type but "replica") and, with `keypoints`, the
+    `grad_mask | create_mask(keypoints, width, height, k)` step of the scripts (7scenes_localize_full_dslam.py:126-149,355-360)
+    as ONE C-ABI call (`gsr_grad_mask`): [3,H,W] float image on a HIP device -> bool [1,H,W] on that device.
+    keypoints: [K,2] (x, y) -- numpy, a list or a tensor (the scripts pass group['keypoints'][scores > 0.2]).
+    Raises on a CPU tensor: there is no CPU path."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    if not torch.is_tensor(original_image) or original_image.device.type != "cuda":
+        raise _lib.GsrError("grad_mask: original_image must be a tensor on the HIP device (there is no CPU fallback)")
+    dev = original_image.device
+    img = original_image.detach()
+    if img.dtype is not torch.float32 or not img.is_contiguous():
+        img = img.to(torch.float32).contiguous()
+    if img.dim() != 3 or img.shape[0] != 3:
+        raise ValueError("grad_mask: original_image must be [3, H, W]")
+    H, W = int(img.shape[1]), int(img.shape[2])
+    kp, nk = None, 0
+    if keypoints is not None and len(keypoints):
+        kp = torch.as_tensor(np.asarray(keypoints, np.float32) if not torch.is_tensor(keypoints) else keypoints, dtype=torch.float32).reshape(-1, 2)
+        kp = kp.to(dev, non_blocking=True).contiguous()
+        nk = int(kp.shape[0])
+    mask = torch.empty((1, H, W), dtype=torch.bool, device=dev)
+    inten = torch.empty((H, W), dtype=torch.float32, device=dev) if return_intensity else None
+    med = torch.empty(2, dtype=torch.float32, device=dev) if return_intensity else None
+    ws = _gm_workspace(dev)
+    p = lambda t: None if t is None else t.data_ptr()
+    with torch.cuda.device(dev):
+        rc = lib.gsr_grad_mask(W, H, p(img), float(edge_threshold), p(kp), nk, int(box_k), p(mask), p(inten), p(med), ws.fn, ws.key,
+                               torch.cuda.current_stream(dev).cuda_stream)
+    type(ws).raise_pending(ws)
+    _lib.check(rc)
+    return (mask, inten, med) if return_intensity else mask
+
+
+def grad_mask_replica(original_image, edge_threshold, rows=32, cols=32):
+    """the config["Dataset"]["type"] == "replica" branch of `Camera.compute_grad_mask` (tools/camera_utils.py:174-188): a FLOAT
+    [1,H,W] image, the reference's quirks included (include/gsr.h, `gsr_grad_mask_replica`)."""
+    from . import _lib
+    lib = _lib.load()
+    if not torch.is_tensor(original_image) or original_image.device.type != "cuda":
+        raise _lib.GsrError("grad_mask_replica: original_image must be a tensor on the HIP device (there is no CPU fallback)")
+    dev = original_image.device
+    img = original_image.detach().to(torch.float32).contiguous()
+    H, W = int(img.shape[1]), int(img.shape[2])
+    out = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+    ws = _gm_workspace(dev)
+    with torch.cuda.device(dev):
+        rc = lib.gsr_grad_mask_replica(W, H, img.data_ptr(), float(edge_threshold), int(rows), int(cols), out.data_ptr(), ws.fn, ws.key,
+                                       torch.cuda.current_stream(dev).cuda_stream)
+    type(ws).raise_pending(ws)
+    _lib.check(rc)
+    return out
+
+
+def compute_grad_mask(viewpoint, config, keypoints=None, box_k=10):
+    """Drop-in for `viewpoint.compute_grad_mask(config)` [+ the keypoint boxes]: sets and returns `viewpoint.grad_mask`."""
+    thr = config["Training"]["edge_threshold"]
+    if config.get("Dataset", {}).get("type") == "replica":
+        viewpoint.grad_mask = grad_mask_replica(viewpoint.original_image, thr)
+    else:
+        viewpoint.grad_mask = grad_mask(viewpoint.original_image, thr, keypoints, box_k)
+    return viewpoint.grad_mask
+
+
 def pose_errors(R_gt, t_gt, R, t):
     """(translation error [m], rotation error [deg]) as 7scenes_localize_full_dslam.py:368-377"""
     R_gt, t_gt, R, t = (np.asarray(x, np.float64) for x in (R_gt, t_gt, R, t))

@@ -36,7 +36,7 @@ extern "C" {
  * 2: gsr_refine_args gained `carry_state` (round 2) and the fields behind `stream` (flags, lean_min_P); stats_out is int[4];
  *    pose-state words 41 (ticket) and 84..87 (Adam beta products); gsr_debug_lean_check.  A caller must compare
  *    gsr_abi_version() with the GSR_ABI_VERSION it was compiled against before it passes any struct. */
-#define GSR_ABI_VERSION 4
+#define GSR_ABI_VERSION 5
 
 enum {
     GSR_OK = 0,
@@ -277,6 +277,31 @@ int gsr_tracking_loss(int width, int height, const float* image, const float* de
                       const float* gt_image, const float* gt_depth, const uint8_t* grad_mask,
                       const float* exposure, float opacity_threshold, float depth_weight, int monocular,
                       float* dL_dimage, float* dL_ddepth, float* dL_dalpha, float* out, void* stream);
+
+/* The per-frame gradient mask every localisation script refines under (GSR_ABI_VERSION 5).  Replaces
+ * Camera.compute_grad_mask (gs_localization/pipelines/tools/camera_utils.py:164-193; image_gradient / image_gradient_mask,
+ * tools/descent_utils.py:33-67, behind it) and the `viewpoint.grad_mask | create_mask(keypoints, k = 10)` step of the scripts
+ * (7scenes_localize_full_dslam.py:126-149,355-360):
+ *   gray = mean over the channels; Scharr gradients of the reflect-padded gray image, zeroed where a pixel of the 3 x 3
+ *   neighbourhood has |gray| <= 0.01; intensity = sqrt(gv^2 + gh^2);
+ *   grad_mask = intensity > median(intensity) * edge_threshold        (torch.median: the LOWER median, found exactly)
+ *   grad_mask |= a box of 2 (box_k / 2) + 1 pixels around (int(x), int(y)) of every keypoint.
+ *   image [3,H,W] float (device); keypoints: nullable device float [num_keypoints, 2] (x, y), every x, y > -1 (further outside
+ *   the image the reference's numpy slice bounds turn negative and wrap around; a box that leaves the image is clipped); grad_mask [H,W] uint8 0/1 -- what
+ *   gsr_tracking_loss / gsr_refine take; intensity_out: nullable device float [H,W] (the intensity image); median_out: nullable
+ *   device float[2] = {median, threshold}.  workspace: resize callback for gsr_grad_mask_bytes(width, height) bytes.
+ * Four launches (five with keypoints), no host synchronisation.  The mask is bit-identical to the reference's own Python run on
+ * torch's CPU backend for the committed fixtures (tests/golden/grad_mask_vectors.npz; arithmetic: csrc/gsr_gradmask.h). */
+size_t gsr_grad_mask_bytes(int width, int height);
+int gsr_grad_mask(int width, int height, const float* image, float edge_threshold, const float* keypoints, int num_keypoints, int box_k,
+                  uint8_t* grad_mask, float* intensity_out, float* median_out, gsr_resize_fn workspace, void* workspace_ctx, void* stream);
+/* The config["Dataset"]["type"] == "replica" branch of the same function (camera_utils.py:174-188): a rows x cols (32 x 32 there)
+ * grid of int(H / rows) x int(W / cols) blocks, each thresholded at its own lower median x edge_threshold.  The result is a FLOAT
+ * image as in the reference, quirks included: 1 / 0 inside the grid (the reference's two in-place writes run in sequence, so the
+ * ones are cleared again whenever 1 <= threshold), the raw intensity in the pixels right of / below the grid.  (No localisation
+ * script can take this branch -- their next line ORs the mask with a boolean one, which torch refuses for a float tensor.) */
+int gsr_grad_mask_replica(int width, int height, const float* image, float edge_threshold, int rows, int cols, float* grad_mask,
+                          gsr_resize_fn workspace, void* workspace_ctx, void* stream);
 
 /* Device-resident pose state: GSR_POSE_STATE_FLOATS floats, layout
  *   [0..8] R (row-major W2C rotation) [9..11] T [12..14] cam_rot_delta [15..17] cam_trans_delta

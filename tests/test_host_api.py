@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), n
         assert n in _lib.SIGNATURES, f"{n} missing from the ctypes signature table"
-    assert lib.gsr_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.gsr_abi_version() == _lib.ABI_VERSION == 5
     names_k = [lib.gsr_profile_kernel_name(i).decode() for i in range(lib.gsr_profile_kernel_count())]
     assert names_k == ["preprocess_fwd", "sh_color", "tile_count", "tile_scan", "tile_emit", "render_fwd", "bwd_zero", "render_bwd",
                        "preprocess_bwd", "pose_step"]
