@@ -1687,9 +1687,10 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
     if (last_enq >= 0 && !last_counted && a->n_touched && gb.ptr && bb.ptr && ib.ptr) {
         // n_touched (fifth output of the pose package's forward) is only wanted for the LAST forward, and counting it
         // costs every iteration's compositing kernel an eighth of its instructions: the loop runs the variant
-        // without it and the lists of the last forward are composited once more here, with the counters.  Same
-        // lists, same geometry, same order: the images it rewrites are bit-identical.  (The last forward ordered its
-        // lists as far as its pixels needed them, which is as far as this pass walks.)
+        // without it and the lists of the last forward are walked once more here, with the counters: pixel p over positions
+        // 1 .. n_contrib[p] of its tile's list, the same blend tests, nothing written but the counters (RECOUNT in k_render_fwd --
+        // round 6: the last forward may have split tiles, whose images this pass must not rewrite with another rounding and whose
+        // lists are only valid up to the tile's deepest contributor).
         const int gx = (a->width + GSR_TILE - 1) / GSR_TILE, gy = (a->height + GSR_TILE - 1) / GSR_TILE;
         Geom g; carve_geom((char*)gb.ptr, a->P, g, cx.det, true);
         g.select_set(last_enq & 1);

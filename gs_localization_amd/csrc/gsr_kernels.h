@@ -2241,6 +2241,24 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
         range.x = tile_cursor[tile];
         range.y = tile_cursor[tile + 1];
     } else range = ranges[tile];
+    // RECOUNT (TOUCHED on GSR_LIST_SORTED: gsr_refine's closing n_touched pass over the lists of a forward that has already produced
+    // the images): the walk follows the forward's own per-pixel decisions -- pixel p looks at list positions 1 .. n_contrib[p], with
+    // the same blend tests and no termination test of its own -- and writes nothing but the counters.  The forward may have been a
+    // SPLIT one (transmittance carried as a product of per-range products: another rounding, so this pass's own termination could
+    // differ by a splat; and a range that found every pixel finished never wrote its part of the list, so positions beyond the
+    // tile's deepest contributor may hold stale indices -- ADVICE r5): nothing beyond that position is read.
+    constexpr bool RECOUNT = TOUCHED && LIST == GSR_LIST_SORTED;
+    uint32_t rc_lim = 0u;
+    if (RECOUNT) {
+        __shared__ uint32_t s_rc[4];
+        rc_lim = inside ? n_contrib[pix_id] : 0u;
+        uint32_t mx = rc_lim;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off, 64));
+        if (lane == 0) s_rc[wv] = mx;
+        __syncthreads();
+        range.y = min(range.y, range.x + max(max(s_rc[0], s_rc[1]), max(s_rc[2], s_rc[3])));
+    }
     const int total = (int)(range.y - range.x);
     if (!kBins) nslots = total;
 #ifdef GSR_DBG_TILE
@@ -2794,8 +2812,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                 const float G = __builtin_amdgcn_exp2f(p2);
                 const float alpha = fminf(0.99f, B.y * G);
                 const float test_T = T * (1.f - alpha);
-                const bool valid = !(alpha < 1.0f / 255.0f) && !(p2 > 0.0f);      // power > 0: skipped (forward.cu:342)
-                const bool kill = valid && test_T < 0.0001f;
+                const bool valid = !(alpha < 1.0f / 255.0f) && !(p2 > 0.0f) &&      // power > 0: skipped (forward.cu:342)
+                                   (!RECOUNT || (uint32_t)(consumed + base + j + 1) <= rc_lim);
+                const bool kill = !RECOUNT && valid && test_T < 0.0001f;
                 const bool blend = valid && !kill;
                 const float w = blend ? alpha * T : 0.f;
                 Crg = __builtin_elementwise_fma((gsr_f32x2){Cc.x, Cc.y}, (gsr_f32x2){w, w}, Crg);
@@ -2835,8 +2854,8 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             const float G = __builtin_amdgcn_exp2f(p2);
             const float alpha = fminf(0.99f, B.y * G);
             const float test_T = T * (1.f - alpha);
-            const bool valid = !(alpha < 1.0f / 255.0f) && !(p2 > 0.0f);
-            const bool kill = valid && test_T < 0.0001f;
+            const bool valid = !(alpha < 1.0f / 255.0f) && !(p2 > 0.0f) && (!RECOUNT || (uint32_t)(consumed + base + j + 1) <= rc_lim);
+            const bool kill = !RECOUNT && valid && test_T < 0.0001f;
             const bool blend = valid && !kill;
             const float w = blend ? alpha * T : 0.f;
             Crg = __builtin_elementwise_fma((gsr_f32x2){Cc.x, Cc.y}, (gsr_f32x2){w, w}, Crg);
@@ -2854,6 +2873,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
     consumed += m;
     __syncthreads();          // (the next slice overwrites s_keys and the staging buffers)
   }
+    if (RECOUNT) return;          // (the images, n_contrib, the bounds: all as the forward left them)
     // GSR_LIST_EXACT: the tile's range is what has been ORDERED -- all that the backward pass and a re-compositing of
     // these lists (n_touched) can need: no pixel looks beyond the slice in which the last one terminated
     if (lazy && tid == 0) ranges[tile] = make_uint2(range.x, range.x + (uint32_t)min(consumed, total));
@@ -3115,12 +3135,17 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
 
     const float T_final = inside ? (1.f - alphas[pix_id]) : 0.f;
     float T = T_final;
-    const int last_contributor = inside ? (int)n_contrib[pix_id] : 0;
     float dpx = 0.f, dpy = 0.f, dpz = 0.f, dLd = 0.f, dLa = 0.f;
     if (inside) {
         dpx = dL_dpix[pix_id]; dpy = dL_dpix[N + pix_id]; dpz = dL_dpix[2 * N + pix_id];
         dLd = dL_ddepths[pix_id]; dLa = dL_dalphas[pix_id];
     }
+    // Round 6: a pixel whose five incoming gradients are all zero -- outside the frame's gradient mask, or not opaque enough for the
+    // tracking loss (descent_utils.py:100-101,118-121: more than half of the pixels under the reference's masks) -- adds exactly
+    // nothing to any sum below: every term is linear in (dpx, dpy, dpz, dLd, dLa).  It is treated as a pixel without contributors,
+    // so an 8 x 8 block (a wave) or a tile of such pixels walks nothing, and a wave's walk is as long as its deepest LIVE pixel needs.
+    const bool live = inside && (dpx != 0.f || dpy != 0.f || dpz != 0.f || dLd != 0.f || dLa != 0.f);
+    const int last_contributor = live ? (int)n_contrib[pix_id] : 0;
     const float bg_dot = bg[0] * dpx + bg[1] * dpy + bg[2] * dpz;
     const float nTf_bg = -T_final * bg_dot;
 

@@ -471,6 +471,111 @@ long gso_r_eff(const gso_state* s)
     return tot;
 }
 
+/* Flip audit (checker only; nothing of the reference corresponds to it).  Two fp32 evaluations of K6 that differ in rounding --
+ * expf against v_exp_f32 on a pre-scaled conic, a transmittance carried as one running product against a product of per-range
+ * products -- take the same decision at every (pixel, splat) pair EXCEPT where a compared quantity lies within rounding of its
+ * threshold: power at 0 (cr/forward.cu:342), alpha at 1/255 (:350), T (1 - alpha) at 1e-4 (:355) and, for the pose package's
+ * n_touched, at 0.5.  This pass re-walks every pixel exactly like the compositing loop above and reports where that is the case, so
+ * that a parity test can demand a CAUSE for every row that misses the standard bar instead of widening the bar:
+ *   near_half[id] += 1   for every pixel where the splat is blended with T (1 - alpha) within the walk's rounding of 0.5
+ *                        (or within 0.5 % of it in a pixel that had an alpha / power event before: T changes by 1/255 there), and
+ *                        for every pixel where its OWN alpha / power sits at the threshold while T is above one half;
+ *   w_all[id]     += 1   for every live pixel (live[] != 0, or all when NULL) the splat is blended in: what its gradient row sums over;
+ *   w_evt[id]     += the share of that pixel's contribution that a flipped decision can move:
+ *                        1 for the splat whose own alpha / power / termination test sits at the threshold (the pair appears or
+ *                        disappears), 1/255 -> 0.004 for every other blended splat of a pixel with an alpha / power event (the
+ *                        pixel's T and "colour behind" move by that much), and for a termination event (alpha T of the dropped
+ *                        splat) / (T behind the earlier splat) -- what that splat sees behind it changes by that share.
+ * A row whose w_evt / w_all reaches the per-row threshold of the test is one two correct evaluations may disagree on.
+ * Rounding model (tol scales all of it): power is a sum of three products -> |d power| <= 4e-7 (|a| dx^2 / 2 + |c| dy^2 / 2 +
+ * |b dx dy|); alpha relative error = d power + 4e-7; T accumulates alpha d / (1 - alpha) + 1.2e-7 per blended pair.
+ * counts[0..3] = alpha / power events, termination events, T = 0.5 events, pixels with any event. */
+void gso_flip_audit(const gso_state* s, float tol, const uint8_t* live, int32_t* near_half, float* w_evt, int32_t* w_all, int64_t* counts)
+{
+    const int W = s->W, H = s->H, gx = s->gx, gy = s->gy;
+    int64_t c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : c0, c1, c2, c3) if (g_threads > 1)
+    for (int tile = 0; tile < gx * gy; tile++) {
+        int ty = tile / gx, tx = tile % gx;
+        uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
+        uint32_t* ids = (uint32_t*)malloc(((size_t)(r1 - r0) + 1) * sizeof(uint32_t));
+        float* Ts = (float*)malloc(((size_t)(r1 - r0) + 1) * sizeof(float));
+        for (int ly = 0; ly < BLOCK_Y; ly++)
+            for (int lx = 0; lx < BLOCK_X; lx++) {
+                int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
+                if (!(px < W && py < H)) continue;
+                const int is_live = live == NULL || live[W * py + px] != 0;
+                float pxf = (float)px, pyf = (float)py;
+                float T = 1.0f;
+                double Terr = 0.0;
+                int nrec = 0, alpha_events = 0, any = 0;
+                for (uint32_t k = r0; k < r1; k++) {
+                    uint32_t id = s->point_list[k];
+                    float dx = s->means2D[2 * id] - pxf, dy = s->means2D[2 * id + 1] - pyf;
+                    const float* co = s->conic_opacity + 4 * (size_t)id;
+                    float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
+                    const double dpow = (double)tol * 4e-7 * (0.5 * fabs((double)co[0]) * dx * dx + 0.5 * fabs((double)co[2]) * dy * dy + fabs((double)co[1] * dx * dy));
+                    int ev = fabs((double)power) <= dpow;
+                    float raw = 0.f;
+                    if (!(power > 0.0f) || ev) {
+                        raw = co[3] * expf(power > 0.0f ? 0.0f : power);
+                        const double rel = dpow + (double)tol * 4e-7;
+                        if (fabs((double)raw - 1.0 / 255.0) <= rel / 255.0) ev = 1;
+                    }
+                    if (ev) {
+                        c0++; any = 1; alpha_events++;
+                        if (is_live) {
+#pragma omp atomic
+                            w_evt[id] += 1.0f;
+                        }
+                        if (T > 0.49f) {          /* blended or not, with T still above one half: its own count moves by one */
+#pragma omp atomic
+                            near_half[id] += 1;
+                        }
+                    }
+                    if (power > 0.0f) continue;
+                    float alpha = fminf_(0.99f, raw);
+                    if (alpha < 1.0f / 255.0f) continue;
+                    float test_T = T * (1 - alpha);
+                    if (alpha < 0.99f) Terr += (double)alpha * (dpow + (double)tol * 4e-7) / (1.0 - (double)alpha);
+                    Terr += (double)tol * 1.2e-7;
+                    if (fabs((double)test_T - 1e-4) <= Terr * 1e-4) {
+                        c1++; any = 1;
+                        if (is_live) {
+#pragma omp atomic
+                            w_evt[id] += 1.0f;
+                            for (int q = 0; q < nrec; q++) {
+                                float sh = (alpha * T) / Ts[q];
+#pragma omp atomic
+                                w_evt[ids[q]] += (sh < 1.f ? sh : 1.f);
+                            }
+                        }
+                    }
+                    if (test_T < 0.0001f) break;
+                    if (fabs((double)test_T - 0.5) <= (alpha_events ? 0.0025 : 0.0) + Terr * 0.5) {
+                        c2++; any = 1;
+#pragma omp atomic
+                        near_half[id] += 1;
+                    }
+                    if (is_live) {
+#pragma omp atomic
+                        w_all[id] += 1;
+                    }
+                    ids[nrec] = id; Ts[nrec] = test_T; nrec++;
+                    T = test_T;
+                }
+                if (alpha_events && is_live)          /* every blended splat of the pixel saw T or its "behind" move by up to 1/255 per event */
+                    for (int q = 0; q < nrec; q++) {
+#pragma omp atomic
+                        w_evt[ids[q]] += 0.004f * (float)alpha_events;
+                    }
+                c3 += any;
+            }
+        free(ids); free(Ts);
+    }
+    if (counts) { counts[0] = c0; counts[1] = c1; counts[2] = c2; counts[3] = c3; }
+}
+
 /* copy internal state out for tests (any pointer may be NULL) */
 void gso_get_state(const gso_state* s, float* depths, float* means2D, float* cov3D, float* conic_opacity,
                    float* rgb, uint8_t* clamped, uint32_t* tiles_touched, uint32_t* point_list,
@@ -505,6 +610,51 @@ static inline void atomic_addd(double* p, double v)
 #pragma omp atomic
     *p += v;
 }
+
+/* Checker option (not reference behaviour): K7's recurrences and sums in double on the forward's fp32 decisions (gs_oracle_k7.inc). */
+static int g_bwd64 = 0;
+void gso_set_backward_double(int on) { g_bwd64 = on ? 1 : 0; }
+
+/* Checker option: per Gaussian, [0] the sum of |terms| of its dL/dopacity (what the row is the signed sum of) and [1] the sum of
+ * |term| x (relative rounding uncertainty of the transmittance the term was formed with): how far rounding ALONE can move the row.
+ * A parity test excuses a row whose [1] reaches its per-row bar -- an ill-conditioned sum, not a wrong one.  out: 2 P doubles,
+ * zeroed by the caller; NULL switches the report off.  eps: the relative error assumed for one alpha (a few ulp). */
+static double* g_cond = NULL;
+static double g_cond_eps = 4e-7;
+void gso_set_condition_out(double* out, double eps) { g_cond = out; g_cond_eps = eps > 0.0 ? eps : 4e-7; }
+
+#define ACC(farr, fidx, slot, val) do { if (sh64) atomic_addd(&sh64[(size_t)id * 10 + (slot)], (double)(val)); \
+                                        else atomic_addf(&(farr)[fidx], (float)(val)); } while (0)
+#define K7_ARGS const gso_state* s, int W, int H, int gx, int gy, int N, const float* out_alpha, const float* dL_dpix,            \
+                const float* dL_ddepths, const float* dL_dalphas, const float* colors, const float* background, int pose_mode,   \
+                double* sh64, float* dL_dcolor, float* dL_dz, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity
+#define REAL float
+#define RONE 1.f
+#define RNHALF -0.5f
+#define K7_VALUES const float G = G32, alpha = alpha32, rdx = dx, rdy = dy;
+static void k7_f32(K7_ARGS)
+{
+#include "gs_oracle_k7.inc"
+}
+#undef REAL
+#undef RONE
+#undef RNHALF
+#undef K7_VALUES
+#define REAL double
+#define RONE 1.0
+#define RNHALF -0.5
+#define K7_VALUES const double rdx = (double)s->means2D[2 * id] - (double)pxf, rdy = (double)s->means2D[2 * id + 1] - (double)pyf;      \
+                  const double G = exp(-0.5 * ((double)co[0] * rdx * rdx + (double)co[2] * rdy * rdy) - (double)co[1] * rdx * rdy); \
+                  const double alpha = fmin(0.99, (double)co[3] * G);
+static void k7_f64(K7_ARGS)
+{
+#include "gs_oracle_k7.inc"
+}
+#undef REAL
+#undef RONE
+#undef RNHALF
+#undef K7_VALUES
+#undef ACC
 
 /* cr/auxiliary.h:101-112 */
 static vec3 dnormvdv3(vec3 v, vec3 dv)
@@ -667,83 +817,14 @@ void gso_backward(const gso_state* s, int D, int M, const float* background, con
     float* dL_dz = NULL;
     if (pose_mode) dL_dz = (float*)calloc(P > 0 ? (size_t)P : 1, sizeof(float));
     /* double shadows (gso_set_accumulate_double): colour 3, mean2D 2, conic 3, opacity 1, z 1 = 10 per Gaussian */
-    double* sh64 = g_acc64 ? (double*)calloc((P > 0 ? (size_t)P : 1) * 10, sizeof(double)) : NULL;
-#define ACC(farr, fidx, slot, val) do { if (sh64) atomic_addd(&sh64[(size_t)id * 10 + (slot)], (double)(val)); \
-                                        else atomic_addf(&(farr)[fidx], (val)); } while (0)
+    double* sh64 = (g_acc64 || g_bwd64) ? (double*)calloc((P > 0 ? (size_t)P : 1) * 10, sizeof(double)) : NULL;
 
-    /* ---- K7 render backward, cr/backward.cu:399-581 ---- */
-    const float ddelx_dx = (float)(0.5 * W);
-    const float ddely_dy = (float)(0.5 * H);
-#pragma omp parallel for schedule(dynamic, 1) if (g_threads > 1)
-    for (int tile = 0; tile < gx * gy; tile++) {
-        int ty = tile / gx, tx = tile % gx;
-        uint32_t r0 = s->ranges[2 * tile], r1 = s->ranges[2 * tile + 1];
-        for (int ly = 0; ly < BLOCK_Y; ly++)
-            for (int lx = 0; lx < BLOCK_X; lx++) {
-                int px = tx * BLOCK_X + lx, py = ty * BLOCK_Y + ly;
-                if (!(px < W && py < H)) continue;
-                int pix_id = W * py + px;
-                float pxf = (float)px, pyf = (float)py;
-                const float T_final = 1 - out_alpha[pix_id];
-                float T = T_final;
-                uint32_t contributor = r1 - r0;
-                const uint32_t last_contributor = s->n_contrib[pix_id];
-                float accum_rec[3] = { 0, 0, 0 }, dL_dpixel[3];
-                float accum_depth_rec = 0, accum_alpha_rec = 0;
-                for (int i = 0; i < 3; i++) dL_dpixel[i] = dL_dpix[(size_t)i * N + pix_id];
-                float dL_ddepth = dL_ddepths[pix_id];
-                float dL_dalpha = dL_dalphas[pix_id];
-                float last_alpha = 0, last_color[3] = { 0, 0, 0 }, last_depth = 0;
-                for (uint32_t k = r1; k-- > r0;) {
-                    contributor--;
-                    if (contributor >= last_contributor) continue;
-                    uint32_t id = s->point_list[k];
-                    float dx = s->means2D[2 * id] - pxf, dy = s->means2D[2 * id + 1] - pyf;
-                    const float* co = s->conic_opacity + 4 * (size_t)id;
-                    const float power = -0.5f * (co[0] * dx * dx + co[2] * dy * dy) - co[1] * dx * dy;
-                    if (power > 0.0f) continue;
-                    const float G = expf(power);
-                    const float alpha = fminf_(0.99f, co[3] * G);
-                    if (alpha < 1.0f / 255.0f) continue;
-                    T = T / (1.f - alpha);
-                    const float dchannel_dcolor = alpha * T;
-                    float dL_dopa = 0.0f;
-                    for (int ch = 0; ch < 3; ch++) {
-                        const float c = colors[id * 3 + ch];
-                        accum_rec[ch] = last_alpha * last_color[ch] + (1.f - last_alpha) * accum_rec[ch];
-                        last_color[ch] = c;
-                        const float dL_dchannel = dL_dpixel[ch];
-                        dL_dopa += (c - accum_rec[ch]) * dL_dchannel;
-                        ACC(dL_dcolor, id * 3 + ch, ch, dchannel_dcolor * dL_dchannel);
-                    }
-                    const float c_d = s->depths[id];
-                    accum_depth_rec = last_alpha * last_depth + (1.f - last_alpha) * accum_depth_rec;
-                    last_depth = c_d;
-                    dL_dopa += (c_d - accum_depth_rec) * dL_ddepth;
-                    if (pose_mode) ACC(dL_dz, id, 9, dchannel_dcolor * dL_ddepth);
-                    accum_alpha_rec = last_alpha + (1.f - last_alpha) * accum_alpha_rec;
-                    dL_dopa += -(alpha - accum_alpha_rec) * dL_dalpha;   /* cr/backward.cu:545-547 quirk */
-                    dL_dopa *= T;
-                    last_alpha = alpha;
-                    float bg_dot_dpixel = 0;
-                    for (int i = 0; i < 3; i++) bg_dot_dpixel += background[i] * dL_dpixel[i];
-                    dL_dopa += (-T_final / (1.f - alpha)) * bg_dot_dpixel;
-                    const float dL_dG = co[3] * dL_dopa;
-                    const float gdx = G * dx;
-                    const float gdy = G * dy;
-                    const float dG_ddelx = -gdx * co[0] - gdy * co[1];
-                    const float dG_ddely = -gdy * co[2] - gdx * co[1];
-                    ACC(dL_dmean2D, 3 * id, 3, dL_dG * dG_ddelx * ddelx_dx);
-                    ACC(dL_dmean2D, 3 * id + 1, 4, dL_dG * dG_ddely * ddely_dy);
-                    ACC(dL_dconic, 4 * id, 5, -0.5f * gdx * dx * dL_dG);
-                    ACC(dL_dconic, 4 * id + 1, 6, -0.5f * gdx * dy * dL_dG);
-                    ACC(dL_dconic, 4 * id + 3, 7, -0.5f * gdy * dy * dL_dG);
-                    ACC(dL_dopacity, id, 8, G * dL_dopa);
-                }
-            }
-    }
+    /* ---- K7 render backward, cr/backward.cu:399-581 (gs_oracle_k7.inc) ---- */
+    if (g_bwd64) k7_f64(s, W, H, gx, gy, N, out_alpha, dL_dpix, dL_ddepths, dL_dalphas, colors, background, pose_mode, sh64,
+                        dL_dcolor, dL_dz, dL_dmean2D, dL_dconic, dL_dopacity);
+    else k7_f32(s, W, H, gx, gy, N, out_alpha, dL_dpix, dL_ddepths, dL_dalphas, colors, background, pose_mode, sh64,
+                dL_dcolor, dL_dz, dL_dmean2D, dL_dconic, dL_dopacity);
 
-#undef ACC
     if (sh64) {
         for (int i = 0; i < P; i++) {
             const double* q = sh64 + (size_t)i * 10;

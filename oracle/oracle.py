@@ -14,8 +14,8 @@ _lib = None
 
 
 def build(force=False):
-    src = os.path.join(_HERE, "gs_oracle.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("gs_oracle.c", "gs_oracle_k7.inc")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-B", "-s"])
     return _SO
 
@@ -48,6 +48,45 @@ def set_threads(n):
 def set_accumulate_double(on):
     """Checker option: the compositing backward sums its per-Gaussian atomics in double and rounds once (see gs_oracle.c)."""
     lib().gso_set_accumulate_double(int(bool(on)))
+
+
+def set_backward_double(on):
+    """Checker option: the compositing backward's recurrences and sums in double, on the forward's fp32 decisions
+    (gs_oracle_k7.inc) -- the yardstick on lists of many hundreds of entries."""
+    lib().gso_set_backward_double(int(bool(on)))
+
+
+def backward_with_conditioning(fwd, grad_color, grad_depth, grad_alpha, pose_mode=False, eps=1.6e-6):
+    """backward() + the conditioning report of gso_set_condition_out: (grads, mass [P], rounding_reach [P]) -- per Gaussian the
+    sum of |terms| of its opacity gradient and how far the rounding of the transmittances alone (eps = relative error of one alpha:
+    four times 4e-7, as in flip_audit) can move that sum."""
+    out = np.zeros((fwd.P, 2), np.float64)
+    L = lib()
+    L.gso_set_condition_out.argtypes = [C.c_void_p, C.c_double]
+    L.gso_set_condition_out(_p(out), C.c_double(eps))
+    try:
+        g = backward(fwd, grad_color, grad_depth, grad_alpha, pose_mode=pose_mode)
+    finally:
+        L.gso_set_condition_out(None, C.c_double(0.0))
+    return g, out[:, 0].copy(), out[:, 1].copy()
+
+
+def flip_audit(f, tol=4.0, live=None, row_threshold=2.5e-4, weights=False):
+    """gso_flip_audit on a Forward: (near_half int32 [P], unstable bool [P], counts dict).  live: optional [H, W] bool -- only
+    pixels with a gradient enter a gradient row.  unstable = the share of the row's pixels-worth of contributions that a flipped
+    threshold decision can move reaches `row_threshold` (a quarter of the 1e-3 at which the parity tests start counting a row:
+    pixels do not weigh the same)."""
+    P = f.P
+    near_half = np.zeros(P, np.int32)
+    w_evt = np.zeros(P, np.float32)
+    w_all = np.zeros(P, np.int32)
+    counts = np.zeros(4, np.int64)
+    lv = None if live is None else np.ascontiguousarray(np.asarray(live).reshape(f.H, f.W), np.uint8)
+    lib().gso_flip_audit(C.c_void_p(f._state), C.c_float(tol), _p(lv), _p(near_half), _p(w_evt), _p(w_all), _p(counts))
+    unstable = w_evt >= row_threshold * np.maximum(w_all, 1)
+    unstable &= w_evt > 0
+    ev = dict(alpha_events=int(counts[0]), termination_events=int(counts[1]), half_events=int(counts[2]), pixels_with_an_event=int(counts[3]))
+    return (near_half, unstable, ev, w_evt, w_all) if weights else (near_half, unstable, ev)
 
 
 class Forward:

@@ -163,15 +163,41 @@ def python_loop(frame, config, R0, T0, gmap, background, iters=50):
     return frame.R, frame.T, pkg
 
 
-def make_frame(scene, gmap, device, background=None, uid=0):
-    """A query frame whose observations (image, depth) are renders of the map at the identity pose, all-ones gradient mask."""
+N_KEYPOINTS = 500          # boxes OR-ed into a frame's mask, as the scripts do with the detector's keypoints of score > 0.2
+
+
+def frame_keypoints(W, H, uid=0, n=N_KEYPOINTS):
+    """seeded stand-ins for `group['keypoints'][group['scores'][:] > 0.2]` (7scenes_localize_full_dslam.py:357-358): [n, 2] (x, y)"""
+    rng = np.random.default_rng(7000 + int(uid))
+    return np.stack([rng.uniform(0, W - 1, n), rng.uniform(0, H - 1, n)], 1).astype(np.float32)
+
+
+def reference_mask(original_image, uid=0, config=TRACKING_CONFIG, keypoints=True):
+    """The mask the reference's localisers refine under: `viewpoint.compute_grad_mask(config)` OR-ed with 10 x 10-ish boxes around the
+    frame's keypoints (7scenes_localize_full_dslam.py:355-360), computed by the product's `gsr_grad_mask` (pinned bit for bit to the
+    reference's own Python by tests/test_grad_mask.py)."""
+    from gs_localization_amd import pipelines as PL
+    H, W = int(original_image.shape[-2]), int(original_image.shape[-1])
+    kp = frame_keypoints(W, H, uid) if keypoints else None
+    return PL.grad_mask(original_image, config["Training"]["edge_threshold"], kp, 10)
+
+
+def make_frame(scene, gmap, device, background=None, uid=0, mask="reference"):
+    """A query frame whose observations (image, depth) are renders of the map at the identity pose.
+    mask = "reference": the gradient mask of that image as the reference's scripts build it (Scharr gradient above 1.1 x its
+    median, keypoint boxes OR-ed in) -- what every localiser of the reference refines under; "ones": every pixel (the
+    secondary leg of bench.py, and what rounds 1-5 measured)."""
     bg = torch.zeros(3, device=device) if background is None else background
     fr = QueryFrame(uid, intrinsics_projection(scene, device), scene, device)
     with torch.no_grad():
         pkg = render(fr, gmap, bg)
     fr.original_image = pkg["render"].detach().clone()
     fr.depth = pkg["depth"].detach()[0].clone()
-    fr.grad_mask = torch.ones((1, scene.H, scene.W), dtype=torch.bool, device=device)
+    if mask == "ones":
+        fr.grad_mask = torch.ones((1, scene.H, scene.W), dtype=torch.bool, device=device)
+    else:
+        assert mask == "reference", mask
+        fr.grad_mask = reference_mask(fr.original_image, uid)
     return fr
 
 

@@ -240,6 +240,18 @@ def test_headline_path_against_the_oracle_at_the_pose_of_its_last_forward(name):
     blocks, ntiles_split, kmax, budget = fr.seg_stats()
     if name in ("S-room-640", "S-1M-640-object"):          # heavy tiles were split across workgroups in the iteration compared below
         assert ntiles_split >= 20 and kmax >= 4, (blocks, ntiles_split, kmax, budget)
+    print(name, "tiles split %d;" % ntiles_split, *oracle_check_at_the_last_forward(sc, fr, run, vp, gt_image, gt_depth))
+
+
+def oracle_check_at_the_last_forward(sc, fr, run, vp, gt_image, gt_depth, cfg=None):
+    """What a `gsr_refine` call returned -- images, radii, n_touched, the maintained gradient tensors, dL/dtau -- against the CPU
+    oracle at the camera its last forward / backward ran with (pose-state words 96..109; the fp32 matrices pose_write_camera builds),
+    under the frame's own mask: images <= 1e-4 rel-L1, radii exact, and tests/util.py::flip_accounted_parity for the rest -- ONE set
+    of bars whatever the scene and however many tiles were split, a cause demanded for every row and every count beyond them.
+    Returns (summary, per-tensor report)."""
+    from oracle import oracle as O
+    from tests import replay as PL
+    info = run["info"]
     Rl, Tl, ex = info["R_last_forward_host"], info["T_last_forward_host"], info["exposure_last_forward_host"]
     assert abs(np.linalg.det(Rl.astype(np.float64)) - 1) < 1e-5 and not np.allclose(Rl, info["R_host"], atol=0, rtol=0)
     vm, pm, cp = _camera_of_the_pose_state(Rl, Tl, S.camera_matrices(sc)[2])
@@ -255,43 +267,20 @@ def test_headline_path_against_the_oracle_at_the_pose_of_its_last_forward(name):
     v = _V()
     v.exposure_a = torch.tensor([float(ex[0])], device=DEV)
     v.exposure_b = torch.tensor([float(ex[1])], device=DEV)
-    v.original_image, v.depth, v.grad_mask = gt_image, gt_depth, torch.ones((1, sc.H, sc.W), dtype=torch.bool, device=DEV)
+    v.original_image, v.depth, v.grad_mask = gt_image, gt_depth, vp.grad_mask          # (the reference's mask: tests/replay.py::make_frame)
     ti, td = run["color"].clone().requires_grad_(True), run["depth"].clone().requires_grad_(True)
-    PL.tracking_loss(cfg, ti, td, run["alpha"], v).backward()
+    PL.tracking_loss(cfg or PL.TRACKING_CONFIG, ti, td, run["alpha"], v).backward()
     gi, gd = ti.grad.cpu().numpy(), td.grad.cpu().numpy()
     # ... which is what the compositing kernel's fused epilogue handed the backward
     assert U.rel_l1(fr.g_img.cpu().numpy(), gi) <= 1e-6 and U.rel_l1(fr.g_depth.cpu().numpy(), gd) <= 1e-6
-    go = O.backward(f, gi, gd, np.zeros((1, sc.H, sc.W), np.float32), pose_mode=True)
-    assert U.rel_l1(fr.g_tau.cpu().numpy(), go["tau"]) <= 1e-5, U.rel_l1(fr.g_tau.cpu().numpy(), go["tau"])
-    report = {}
-    for k, ok in (("m3d", "means3D"), ("sh", "sh"), ("opac", "opacities"), ("scale", "scales"), ("rot", "rotations")):
-        a, b = getattr(fr, "g_" + k).cpu().numpy(), go[ok]
-        e = U.rel_l1(a.reshape(b.shape), b)
-        worst, share, at = U.row_errors(a.reshape(b.shape), b)
-        report[k] = (e, worst, share, at)
-    print(name, {k: ("%.2e" % v[0], "worst row %.3f" % v[1], "rows > 1e-3: %.2e" % v[2]) for k, v in report.items()})
-    # Tiles split across workgroups: a split tile's backward restarts every depth range from sums the forward left, in double, instead of
-    # carrying the reference's fp32 recurrences through the whole list -- it rounds differently from the oracle, and on lists of many
-    # hundreds of entries it is the ORACLE's recurrences (T by repeated division, backward.cu:516) that are 1-2e-5 from float64, not the
-    # split path (6e-7 ... 1.1e-6): tests/test_gpu_split.py::test_split_backward_against_float64_autograd.  With a tenth or more of the
-    # tiles split the aggregate bar is therefore 5e-5 (measured: S-room-640 <= 3.1e-5 with 350 of 1 200 tiles split).
-    bar = 5e-5 if ntiles_split * 10 >= 1200 else 2e-5
-    for k, (e, worst, share, at) in report.items():
-        assert e <= bar, (k, e, ntiles_split)
-        # per row: a threshold flip (alpha within an ulp of 1/255, T of 1e-4: v_exp_f32 against expf) moves one pixel of one splat --
-        # per-cent level on a splat that covers a handful of pixels, never more; and it happens to a few rows in ten thousand
-        # (S-room-640 runs with a tenth of its tiles split across workgroups: there the backward restarts the "composited behind me"
-        # value of a window from the forward's sums instead of carrying the oracle's fp32 recurrence through the whole list -- as
-        # accurate, but no longer the SAME rounding as the oracle's, and where the splats behind a faint one have nearly its colour the
-        # difference (v - behind) is all rounding: measured 1.9e-4 of the opacity rows above 1e-3 against 2.5e-5 unsplit)
-        # ... and its transmittances round differently from the oracle's running product, so a pixel whose T (1 - alpha) lies within an ulp
-        # of the 1e-4 termination threshold blends one splat more or less than the oracle's: on a splat of a handful of pixels that one
-        # pixel is tens of per cent of the row (seen: 0.04 - 0.21 from run to run, one row in a million)
-        room = ntiles_split * 10 >= 1200
-        assert worst <= (5 * ROW_WORST if room else ROW_WORST) and share <= (5 * ROW_SHARE if room else ROW_SHARE), (k, worst, share, at)
+    grads = {k: getattr(fr, "g_" + k).cpu().numpy() for k in ("m3d", "sh", "opac", "scale", "rot")}
+    summary, report, failures = U.flip_accounted_parity(f, gi, gd, grads, fr.g_tau.cpu().numpy(), run["n_touched"].cpu().numpy(), ROW_WORST, ROW_SHARE)
+    summary = "mask share %.3f; " % float(vp.grad_mask.float().mean()) + summary
+    assert not failures, (summary, failures)
+    return summary, report
 
 
-ROW_WORST, ROW_SHARE = 0.1, 2e-4      # (measured on the six scenes, round 5: worst row <= 0.035, share of rows above 1e-3 <= 2.5e-5)
+ROW_WORST, ROW_SHARE = U.ROW_WORST, U.ROW_SHARE
 
 
 def _adversarial(kind):
@@ -345,7 +334,7 @@ def test_conservative_bound_on_adversarial_inputs(kind):
         with torch.no_grad():
             pkg = PL.render(fr_, model, bg, scaling_modifier=mod)
         fr_.original_image, fr_.depth = pkg["render"].detach().clone(), pkg["depth"].detach()[0].clone()
-        fr_.grad_mask = torch.ones((1, sc.H, sc.W), dtype=torch.bool, device=DEV)
+        fr_.grad_mask = PL.reference_mask(fr_.original_image)
         return fr_
     fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
     plain = _run(fr, view(), init, bg, 8, speculative=False, scale_modifier=mod, flags=0)

@@ -25,8 +25,13 @@ def _check_forward(o, f, pose):
     assert U.rel_l1(o["depth"], f.depth) <= IMG_TOL
     assert U.rel_l1(o["alpha"], f.alpha) <= IMG_TOL
     if pose:
-        # a 1-ulp difference in exp() can flip the T>0.5 test on single pixels
-        assert np.abs(o["n_touched"].astype(np.int64) - f.n_touched).sum() <= max(2, 1e-4 * f.n_touched.sum())
+        # n_touched is an integer: bit-exact, except that a Gaussian's count may differ by the number of pixels in which its blend sits
+        # within rounding of a threshold -- T (1 - alpha) at 0.5, its own alpha at 1/255 with T above 0.5 (v_exp_f32 against expf): the
+        # oracle's flip audit names them (oracle/gs_oracle.c: gso_flip_audit); round 6, was max(2, 1e-4 x sum)
+        from oracle import oracle as O
+        near_half, _, _ = O.flip_audit(f)
+        dn = np.abs(o["n_touched"].astype(np.int64) - f.n_touched.astype(np.int64))
+        assert (dn <= near_half).all(), (int((dn > near_half).sum()), int(np.flatnonzero(dn > near_half)[0]))
 
 
 def _tracking_grads(sc, o, o_gt):

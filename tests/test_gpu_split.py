@@ -36,38 +36,36 @@ def test_split_loop_equals_the_unsplit_loop_up_to_rounding(make, P):
     model, bg, view, init = _setup(sc, seed=7)
     K = 10
     fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
-    split = _run(fr, view(), init, bg, K, flags=0, lean_min_P=1)
+    vp_s, vp_p = view(), view()
+    split = _run(fr, vp_s, init, bg, K, flags=0, lean_min_P=1)
     blocks, ntiles_split, kmax, budget = fr.seg_stats()
     assert budget == 3 * 1200 and ntiles_split >= 5 and kmax >= 3 and blocks >= 1200 + ntiles_split, (blocks, ntiles_split, kmax, budget)
-    g_split = {k: getattr(fr, "g_" + k).detach().clone() for k in ("m3d", "sh", "opac", "scale", "rot", "tau")}
     fr2 = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
-    plain = _run(fr2, view(), init, bg, K, flags=_lib.REFINE_NO_SPLIT, lean_min_P=1)
+    plain = _run(fr2, vp_p, init, bg, K, flags=_lib.REFINE_NO_SPLIT, lean_min_P=1)
     assert split["info"]["fallbacks"] <= plain["info"]["fallbacks"] + 2, (split["info"], plain["info"])
-    assert torch.allclose(split["R"], plain["R"], atol=2e-6) and torch.allclose(split["T"], plain["T"], atol=2e-6)
-    # images: as a whole to 5e-5, 99.9 % of the pixels within 5e-4 -- and a handful may differ by up to a per cent: a pixel terminates where
-    # T (1 - alpha) < 1e-4, the split walk carries T as a product of per-range products, and where the two roundings fall on different
-    # sides of the threshold one walk blends a last splat of weight up to alpha T ~ 1e-2 that the other does not (the same flip
-    # separates any two fp32 evaluation orders; the oracle comparison below holds the split walk to the same per-pixel bars as the unsplit)
+    # Two runs of the loop never take the same path bit for bit (fp32 atomics; here also a transmittance carried as a product of per-range
+    # products): after ten iterations under the reference's mask the poses sit up to a few 1e-6 apart -- seen 1e-7 ... 4e-6 from run to
+    # run on S-room, whose bimodal opacities put T (1 - alpha) EXACTLY on the 1e-4 threshold behind two opaque splats -- and single
+    # pixels follow.  These are secondary checks (same trajectory, same picture); the bars that matter are the oracle's, below.
+    dR, dT = float((split["R"] - plain["R"]).abs().max()), float((split["T"] - plain["T"]).abs().max())
+    assert dR <= 1e-5 and dT <= 1e-5, (dR, dT)
     for k, scale in (("color", 1.0), ("alpha", 1.0), ("depth", 10.0)):
         d = (split[k] - plain[k]).abs()
-        assert float(d.sum() / plain[k].abs().sum().clamp_min(1e-30)) <= 5e-5, k      # (half the 1e-4 parity bar; measured 2.4e-5 with a quarter of the tiles split)
-        assert float(torch.quantile(d.flatten().float(), 0.999)) <= scale * 5e-4, k
-        # (S-room-640's opacities are bimodal: a pixel behind two opaque splats has T (1 - alpha) = 0.01 x 0.01, EXACTLY the 1e-4 threshold
-        # in real arithmetic -- which side it falls on is decided by the last bit of T, and the third splat weighs up to 1e-2: seen 23 - 89
-        # of the 921 600 values from run to run)
-        assert int((d > scale * 5e-3).sum().item()) <= max(32, int(3e-4 * d.numel())) and float(d.max()) <= scale * 5e-2, (k, int((d > scale * 5e-3).sum().item()), float(d.max()))
-    nt = int(plain["n_touched"].sum().item())
-    # (each loop is held to 1e-4 of the oracle's count in the direct tests; between two loops twice that.  Measured 1.1e-4 with a quarter
-    # of the tiles split: T > 0.5 decided by the last bit of a T carried as a product of per-range products)
-    assert int((split["n_touched"] - plain["n_touched"]).abs().sum().item()) <= max(2, int(2e-4 * nt))
+        assert float(d.sum() / plain[k].abs().sum().clamp_min(1e-30)) <= 1e-4, (k, float(d.sum() / plain[k].abs().sum()))
+        assert float(torch.quantile(d.flatten().float(), 0.999)) <= scale * 1e-3, (k, float(torch.quantile(d.flatten().float(), 0.999)))
+        # (no bar on single pixels: S-room's splats lie ON its surfaces, and two near-coplanar opaque ones swap their depth order between
+        # poses 1.3e-6 apart -- a footprint of pixels then differs by up to 0.15 in colour while BOTH loops agree with the oracle at their
+        # own pose to 1.3e-6 on every pixel: tools/dbg/split_pixel.py)
     assert int((split["radii"] != plain["radii"]).sum().item()) <= max(2, int(5e-5 * split["radii"].numel()))
-    for k in g_split:
-        a, b = g_split[k].cpu().numpy(), getattr(fr2, "g_" + k).detach().cpu().numpy()
-        # (two runs of the loop end ~1e-7 apart in pose, which moves the gradients of a loss made of sign functions by a few 1e-5:
-        # the bar of tests/test_gpu_lean.py's loop-against-loop comparisons; the oracle comparison at 2e-5 is the direct test's)
-        # (... and a pixel on the other side of the 1e-4 threshold -- see above -- changes colour by up to 1e-2, enough to flip the sign of its
-        # L1 residual: measured 3.6e-4 with a quarter of the tiles split.  A secondary check; each loop is held to the oracle at ITS pose.)
-        assert U.rel_l1(a, b) <= 1e-3, (k, U.rel_l1(a, b))
+    # n_touched and the gradient tensors: two runs of the loop end ~1e-7 apart in pose, and a loss made of sign functions turns that
+    # into 1e-5 ... 1e-3 between their gradients -- nothing to hold a bar against.  Each loop is held to the ORACLE at the pose of ITS
+    # last forward instead, both to the same bars, with a cause demanded for every row and every count beyond them.
+    import os
+    from oracle import oracle as O
+    from tests.test_gpu_lean import oracle_check_at_the_last_forward
+    O.set_threads(min(64, os.cpu_count() or 1))
+    print("split loop  :", *oracle_check_at_the_last_forward(sc, fr, split, vp_s, vp_s.original_image, vp_s.depth))
+    print("unsplit loop:", *oracle_check_at_the_last_forward(sc, fr2, plain, vp_p, vp_p.original_image, vp_p.depth))
 
 
 def test_split_forward_and_backward_against_the_oracle_on_a_mid_size_room():
@@ -78,7 +76,7 @@ def test_split_forward_and_backward_against_the_oracle_on_a_mid_size_room():
     import os
     from oracle import oracle as O
     from tests import replay as PL
-    from tests.test_gpu_lean import _camera_of_the_pose_state
+    from tests.test_gpu_lean import oracle_check_at_the_last_forward
     O.set_threads(min(64, os.cpu_count() or 1))
     sc = _room(300_000)
     model, bg, view, init = _setup(sc, seed=9)
@@ -90,32 +88,8 @@ def test_split_forward_and_backward_against_the_oracle_on_a_mid_size_room():
     assert ntiles_split >= 5 and kmax >= 3, (blocks, ntiles_split, kmax)
     info = run["info"]
     assert info["iters"] == 3 and info["fallbacks"] <= 3, {k: info[k] for k in ("iters", "fallbacks")}      # (a failed speculation's retry runs the split list too)
-    vm, pm, cp = _camera_of_the_pose_state(info["R_last_forward_host"], info["T_last_forward_host"], S.camera_matrices(sc)[2])
-    f = O.forward(sc.means3D, sc.opacities, vm, pm, cp, sc.W, sc.H, sc.tanfovx, sc.tanfovy, sc.bg, sh_degree=sc.sh_degree, shs=sc.shs,
-                  scales=sc.scales, rotations=sc.rotations, want_n_touched=True)
-    assert np.array_equal(run["radii"].cpu().numpy(), f.radii)
-    for k, b in (("color", f.color), ("depth", f.depth), ("alpha", f.alpha)):
-        assert U.rel_l1(run[k].cpu().numpy(), b) <= 1e-4, (k, U.rel_l1(run[k].cpu().numpy(), b))
-    nt = run["n_touched"].cpu().numpy()
-    assert np.abs(nt - f.n_touched).sum() <= max(2, 1e-4 * f.n_touched.sum()), int(np.abs(nt - f.n_touched).sum())
-    ex = info["exposure_last_forward_host"]
-
-    class _V:
-        pass
-    v = _V()
-    v.exposure_a, v.exposure_b = torch.tensor([float(ex[0])], device=DEV), torch.tensor([float(ex[1])], device=DEV)
-    v.original_image, v.depth, v.grad_mask = gt_image, gt_depth, torch.ones((1, sc.H, sc.W), dtype=torch.bool, device=DEV)
-    ti, td = run["color"].clone().requires_grad_(True), run["depth"].clone().requires_grad_(True)
-    PL.tracking_loss(PL.TRACKING_CONFIG, ti, td, run["alpha"], v).backward()
-    go = O.backward(f, ti.grad.cpu().numpy(), td.grad.cpu().numpy(), np.zeros((1, sc.H, sc.W), np.float32), pose_mode=True)
-    assert U.rel_l1(fr.g_tau.cpu().numpy(), go["tau"]) <= 1e-5, U.rel_l1(fr.g_tau.cpu().numpy(), go["tau"])
-    for k, ok in (("m3d", "means3D"), ("sh", "sh"), ("opac", "opacities"), ("scale", "scales"), ("rot", "rotations")):
-        a, b = getattr(fr, "g_" + k).cpu().numpy(), go[ok]
-        # (5e-5 where a tenth of the tiles is split: the fp32 oracle's own distance from float64 on long lists, see
-        # test_split_backward_against_float64_autograd below and tests/test_gpu_lean.py)
-        assert U.rel_l1(a.reshape(b.shape), b) <= (5e-5 if ntiles_split >= 120 else 2e-5), (k, U.rel_l1(a.reshape(b.shape), b), ntiles_split)
-        worst, share, at = U.row_errors(a.reshape(b.shape), b)
-        assert worst <= 0.5 and share <= 1e-3, (k, worst, share, at)      # (bars of the full-size S-room-640 comparison, tests/test_gpu_lean.py)
+    # (one set of bars for split and unsplit tiles: tests/util.py::flip_accounted_parity demands a cause for every row / count beyond them)
+    print("room-300k, tiles split %d;" % ntiles_split, *oracle_check_at_the_last_forward(sc, fr, run, vp, gt_image, gt_depth))
 
 
 def test_the_deterministic_option_never_splits():
