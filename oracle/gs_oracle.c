@@ -842,6 +842,8 @@ void gso_backward(const gso_state* s, int D, int M, const float* background, con
 
     /* ---- K8 computeCov2DCUDA (cr/backward.cu:144-274) + K9 preprocessCUDA (:346-396) ---- */
     const float* cov3Ds = cov3D_precomp != NULL ? cov3D_precomp : s->cov3D;
+    /* (round 6: one Gaussian per iteration, nothing shared but the six fp64 pose sums -- parallel like the kernels it restates) */
+#pragma omp parallel for schedule(static) reduction(+ : tau[:6]) if (g_threads > 1)
     for (int idx = 0; idx < P; idx++) {
         if (!(s->radii[idx] > 0)) continue;
         const float* cov3D = cov3Ds + 6 * (size_t)idx;
