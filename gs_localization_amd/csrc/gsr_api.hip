@@ -1767,10 +1767,17 @@ int gsr_debug_seg_stats(const gsr_refine_args* a, long long out[4])
     int rc = select_device_of(a->pose_state);
     if (rc != GSR_OK) return rc;
     Img im;
+    out[0] = out[1] = out[2] = out[3] = 0;
+    // (only a call that RAN with the split arrays has them in its image workspace -- the same condition gsr_refine uses;
+    // asking the caller's callback for the larger carving after a deterministic / GSR_REFINE_NO_SPLIT / non-speculative call would grow
+    // or move a live workspace and read a launch list nobody wrote)
+    const bool det = (a->flags & GSR_REFINE_DETERMINISTIC) != 0;
+    if (!(a->speculative && !det && !(a->flags & GSR_REFINE_NO_SPLIT)) ||
+        seg_budget_of(((a->width + GSR_TILE - 1) / GSR_TILE) * ((a->height + GSR_TILE - 1) / GSR_TILE)) <= 0) return 0;
     char* iptr = (char*)a->image_buffer(a->image_ctx, carve_img(nullptr, a->width, a->height, im, true));
     if (!iptr) return fail(GSR_E_ALLOC, "image buffer callback returned NULL%s", "");
     carve_img(iptr, a->width, a->height, im, true);
-    out[0] = out[1] = out[2] = 0; out[3] = im.seg_budget;
+    out[3] = im.seg_budget;
     if (im.seg_budget <= 0) return 0;
     // (the list the call's last speculative group walked: the one its predecessor built -- the parity the warm-state word remembers)
     const int last_par = a->warm_state ? ((*a->warm_state & 0xFF) - 1) : -1;

@@ -1890,15 +1890,6 @@ __device__ __forceinline__ void seg_store(float* p, float v) { __hip_atomic_stor
 __device__ __forceinline__ float seg_load(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void seg_store_u(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ uint32_t seg_load_u(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-// waits (bounded) until *p == want; false: gave up
-__device__ __forceinline__ bool seg_wait(const uint32_t* p, uint32_t want)
-{
-    for (uint32_t spins = 0; spins < (1u << 21); spins++) {
-        if (seg_load_u(p) == want) return true;
-        __builtin_amdgcn_s_sleep(8);
-    }
-    return false;
-}
 
 // Record layout: what the walk reads per list entry is a (16 B), the first half of b (8 B) and c (16 B), and the fields sit
 // where the packed fp32 instructions want their operand PAIRS: (x, y) - (px, py), (B2, C2) * dy, (r, g) * w, (b, depth) * w are
@@ -2501,7 +2492,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
 #pragma unroll
                     for (uint32_t j = 0; j < 8u; j++) t = t * v[j];
                 }
-                if (!ok && tid == 0) atomicMax(fail, fail_tag | GSR_FAIL_OVERFLOW);      // (never seen; a forward that gave up waiting must not count)
+                // (never seen; a forward that gave up waiting must not count.  Reported as a failed SPECULATION, with the tile unsplit for the
+                // next 64 forwards -- not as a bin overflow, which would send the rest of the call through count -> scan -> emit: ADVICE r5)
+                if (!ok && tid == 0) { atomicMax(fail, fail_tag | GSR_FAIL_BOUND); sg.nosplit[tile] = 64u; }
                 GSR_T_TICK(5)
                 Ts = t;
                 Tc = (t >= 0.0001f) ? t : -t;          // below 1e-4: this pixel terminated in an earlier segment

@@ -118,12 +118,15 @@ def test_lean_kernel_on_a_spatially_sorted_map():
     assert int((lean["radii"] != base["radii"][inv]).sum().item()) <= max(2, int(5e-5 * sc.P))
 
 
-def test_recorded_reference_loop_with_the_lean_kernel_live():
+@pytest.mark.parametrize("fixture", ["pose_loop_vectors.npz", "masked_loop_vectors.npz"])
+def test_recorded_reference_loop_with_the_lean_kernel_live(fixture):
     """tests/test_gpu_refine.py::test_native_loop_follows_the_recorded_reference_loop with k_preprocess_lean in the loop: the
-    poses after k bodies of the REFERENCE's loop (its loss, Adam, update_pose around the CPU oracle), to 2e-6."""
+    poses after k bodies of the REFERENCE's loop (its loss, Adam, update_pose around the CPU oracle), to 2e-6 -- the loop recorded with
+    every pixel in the mask, and the one recorded under the reference's own per-frame mask."""
     import os
     from tests import replay as PL
-    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_loop_vectors.npz"))
+    from tests.test_pose_golden import loop_mask
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", fixture))
     P, W, H, deg, seed = (int(x) for x in g["loop_scene"])
     sc = S.small(P=P, W=W, H=H, sh_degree=deg, seed=seed, scale_med=float(g["loop_scale_med"]))
     model = PL.GaussianMap.from_scene(sc, device=DEV)
@@ -133,7 +136,7 @@ def test_recorded_reference_loop_with_the_lean_kernel_live():
         vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, DEV), sc, DEV)
         vp.original_image = torch.tensor(g["loop_gt_image"], device=DEV)
         vp.depth = torch.tensor(g["loop_gt_depth"], device=DEV)
-        vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=DEV)
+        vp.grad_mask = loop_mask(g, H, W).to(DEV)
         fr = PL.FusedRefiner(model, H, W, device=DEV)
         R, T, info = fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=k, lean_min_P=1, flags=0)
         # (iterations 1 ... k - 2 run the lean kernel; on this scene a couple of speculations fail and are redone with complete lists)

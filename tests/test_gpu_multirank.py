@@ -23,8 +23,10 @@ def _json_line(cmd, timeout=900):
     return json.loads(lines[0])
 
 
-BENCH = ["bench.py", "--steps", "5", "--warmup", "1", "--frames-in-flight", "2", "--repeats", "1", "--gaussians", "300000",
-         "--no-cpu-baseline", "--no-train-leg"]
+# (20-iteration calls, two warm-up calls, the median of five timed regions: a stable enough rate for the factor-of-three bound below --
+# with 5-iteration calls and one repeat the bound had to be a factor of eight and checked little beyond "the ranks launched")
+BENCH = ["bench.py", "--steps", "20", "--warmup", "2", "--frames-in-flight", "2", "--repeats", "5", "--gaussians", "300000",
+         "--no-cpu-baseline", "--no-train-leg", "--no-cam-leg", "--no-variants-leg"]
 
 
 def test_bench_gpus_flag_launches_the_ranks():
@@ -33,9 +35,8 @@ def test_bench_gpus_flag_launches_the_ranks():
     assert one["n_gpus"] == 1 and one["ranks_seen"] == 1 and one["collectives"].startswith("none")
     assert two["n_gpus"] == 2 and two["ranks_seen"] == 2
     assert two["config"]["parallelism"].startswith("frames: 2 GPU")
-    # both ranks share one GPU here: the aggregate stays within a factor of eight of the single rank's (a sanity bound, not a rate:
-    # 5-iteration calls in a freshly started process -- one run of round 5 had the single rank at 1 670 it/s next to 5 910 for the two)
-    assert one["value"] / 8.0 <= two["value"] <= 8.0 * one["value"], (one["value"], two["value"])
+    # both ranks share one GPU here: the aggregate stays within a factor of three of the single rank's
+    assert one["value"] / 3.0 <= two["value"] <= 3.0 * one["value"], (one["value"], two["value"])
     for k in ("roofline", "single_frame_iters_per_s", "per_call_overhead_ms", "steady_state_ms_per_iter", "stream_of_frames_iters_per_s", "value_repeats_stats"):
         assert k in two
     assert two["stream_of_frames_iters_per_s"] > 0 and one["stream_of_frames_iters_per_s"] > 0

@@ -11,6 +11,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.test_pose_golden import loop_mask
+
 from gs_localization_amd import scenes as S
 from tests import util as U
 
@@ -104,6 +106,19 @@ def test_pose_gradient_matches_float64_fixture(pose_golden, name):
     assert U.rel_l1(got["tau"], g[f"tau_{name}_expected"]) <= 1e-5
 
 
+def test_native_loop_follows_the_recorded_reference_loop_under_the_reference_mask():
+    """... and under the mask every localiser of the reference refines under: the loop recorded by tests/golden/make_masked_loop_golden.py
+    (Camera.compute_grad_mask | create_mask(keypoints) -> get_loss_tracking -> Adam -> update_pose, all the reference's own code around
+    the CPU oracle).  The product's gsr_grad_mask reproduces the recorded mask bit for bit from the recorded observation."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "masked_loop_vectors.npz"))
+    test_native_loop_follows_the_recorded_reference_loop(g)
+    from gs_localization_amd import pipelines as PLN
+    P, W, H, deg, seed = (int(x) for x in g["loop_scene"])
+    got = PLN.grad_mask(torch.tensor(g["loop_gt_image"], device=DEV), 1.1, g["loop_keypoints"], 10)
+    assert np.array_equal(got.cpu().numpy()[0], loop_mask(g, H, W).numpy()[0])
+
+
 def test_native_loop_follows_the_recorded_reference_loop(pose_golden):
     """gsr_refine, k iterations, against the pose after k bodies of the reference's loop (its get_loss_tracking, Adam and
     update_pose around the CPU oracle's render / backward; SURVEY.md 8(c) fixture 9).  Each iteration moves every pose
@@ -120,7 +135,7 @@ def test_native_loop_follows_the_recorded_reference_loop(pose_golden):
             vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, DEV), sc, DEV)
             vp.original_image = torch.tensor(g["loop_gt_image"], device=DEV)
             vp.depth = torch.tensor(g["loop_gt_depth"], device=DEV)
-            vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=DEV)
+            vp.grad_mask = loop_mask(g, H, W).to(DEV)
             fr = PL.FusedRefiner(model, H, W, device=DEV)
             R, T, info = fr.refine(vp, PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=k, speculative=spec)
             assert info["iters"] == k

@@ -1,0 +1,33 @@
+"""-m gpu : the reference's pipeline chained once, shortened -- train (300 steps of train.py's loop with densification) -> point_cloud.ply
+-> GaussianMap.from_ply -> per frame gsr_grad_mask + FusedRefiner.refine with the early exit, query frames rendered from the WORLD
+(tests/trained_map.py; the full-length run is tools/trained_map.py, numbers in DESIGN.md).  What no other test has: a map whose
+anisotropy, opacities and order are what training left, a residual that is real (the map is not the world), and the direct-oracle
+parity check on THAT map."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_train_save_load_localise_and_check_against_the_oracle(tmp_path):
+    from oracle import oracle as O
+    from tests import trained_map as TM
+    from tests.test_gpu_lean import oracle_check_at_the_last_forward, _run
+    path = str(tmp_path / "point_cloud" / "iteration_300" / "point_cloud.ply")
+    world, train = TM.train_room_map(path, steps=300, world_P=120_000, P0=30_000, P1=60_000, sh_degree=3, n_views=12)
+    assert train["P_last"] > 1.5 * train["P_first"] and train["loss_first_last"][1] < 0.7 * train["loss_first_last"][0], train
+    assert train["psnr_view0_db"] > 15.0, train
+    rep, (gmap, fr, frames, inits, bg) = TM.localise_against(path, world, n_frames=8, in_flight=4, start=(0.03, 2.0))
+    assert rep["map_gaussians"] == train["P_last"]
+    # started 3 cm / 2 deg off; a 300-step map is a rough one -- the refinement must still pull every frame in
+    assert rep["pose_err_cm_median"] < 0.6 * 3.0 and rep["pose_err_deg_median"] < 0.6 * 2.0, rep
+    assert 0.35 < rep["mask_share"] < 0.8, rep
+    print("trained map:", {k: rep[k] for k in ("pose_err_cm_median", "pose_err_deg_median", "iterations_used_median", "single_frame_iters_per_s", "in_flight_iters_per_s", "mask_share")}, train)
+    # direct-oracle parity on the trained map, at the pose of the call's last forward, under the frame's own mask
+    O.set_threads(min(64, os.cpu_count() or 1))
+    sc = TM.scene_of_map(gmap, world)
+    run = _run(fr, frames[0], inits[0], bg, 8, flags=0, lean_min_P=1)
+    print(*oracle_check_at_the_last_forward(sc, fr, run, frames[0], frames[0].original_image, frames[0].depth))

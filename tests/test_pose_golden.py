@@ -100,6 +100,35 @@ def test_oracle_pose_gradient_against_float64_reference_se3(pg, name):
     assert rel_l1(g["tau"], pg[f"tau_{name}_expected"]) <= 1e-5
 
 
+def loop_mask(g, H, W):
+    """the mask a recorded loop ran under: all pixels (pose_loop_vectors.npz, round 1) or the reference's own per-frame mask
+    (masked_loop_vectors.npz, round 6: compute_grad_mask | create_mask(keypoints), recorded from the reference's functions)"""
+    if "loop_mask_bits" not in g:
+        return torch.ones((1, H, W), dtype=torch.bool)
+    return torch.tensor(np.unpackbits(g["loop_mask_bits"])[:H * W].reshape(1, H, W).astype(bool))
+
+
+@pytest.fixture(scope="module")
+def pgm():
+    return np.load(os.path.join(HERE, "golden", "masked_loop_vectors.npz"))
+
+
+def test_recorded_masked_reference_loop_is_reproduced_by_the_replay_around_the_oracle(pgm):
+    """the same under the mask every localiser of the reference refines under (tests/golden/make_masked_loop_golden.py)"""
+    assert 0.3 < float(loop_mask(pgm, int(pgm["loop_scene"][2]), int(pgm["loop_scene"][1])).float().mean()) < 0.8
+    test_recorded_reference_loop_is_reproduced_by_the_replay_around_the_oracle(pgm)
+
+
+def test_recorded_mask_is_what_the_oracle_computes(pgm):
+    """the recorded mask itself (Camera.compute_grad_mask | create_mask, run by the reference's code) against oracle/grad_mask_oracle.py"""
+    from oracle import grad_mask_oracle as G
+    P, W, H, deg, seed = (int(x) for x in pgm["loop_scene"])
+    want = np.unpackbits(pgm["loop_mask_bits"])[:H * W].reshape(H, W).astype(bool)
+    want0 = np.unpackbits(pgm["loop_mask_without_boxes_bits"])[:H * W].reshape(H, W).astype(bool)
+    assert np.array_equal(G.compute_grad_mask(pgm["loop_gt_image"], 1.1), want0)
+    assert np.array_equal(G.compute_grad_mask(pgm["loop_gt_image"], 1.1, pgm["loop_keypoints"], 10), want)
+
+
 def test_recorded_reference_loop_is_reproduced_by_the_replay_around_the_oracle(pg):
     """SURVEY.md 8(c) fixture 9 on the CPU: replay.py's loss / Adam / pose update around the oracle's render and backward walk
     the same 8 poses the reference's own functions walked when the fixture was recorded."""
@@ -108,7 +137,7 @@ def test_recorded_reference_loop_is_reproduced_by_the_replay_around_the_oracle(p
     sc = S.small(P=P, W=W, H=H, sh_degree=deg, seed=seed, scale_med=float(pg["loop_scale_med"]))
     fr = RP.QueryFrame(0, RP.intrinsics_projection(sc, "cpu"), sc, "cpu")
     fr.original_image, fr.depth = torch.tensor(pg["loop_gt_image"]), torch.tensor(pg["loop_gt_depth"])
-    fr.grad_mask = torch.ones((1, H, W), dtype=torch.bool)
+    fr.grad_mask = loop_mask(pg, H, W)
     init = torch.tensor(pg["loop_init"])
     fr.update_RT(init[:3, :3].clone(), init[:3, 3].clone())
     opt = RP.pose_adam(fr)

@@ -137,9 +137,11 @@ class TrainReplay:
                     self.densify(int(round(self.P0 * self.growth ** self.events)), size_threshold=20 if iteration > self.opacity_reset_interval else None)
                     changed = True
                 if self.opacity_reset_interval and iteration % self.opacity_reset_interval == 0:
-                    self.reset_opacity()          # train.py:151-152 -> gaussian_model.py:207-210: opacities capped at 0.01, their Adam moments zeroed
-                    changed = True
-            if not changed:           # (after a densification the gradients belong to tensors that no longer exist)
+                    # train.py:151-152 -> gaussian_model.py:207-210: opacities capped at 0.01, their Adam moments zeroed.  The reference
+                    # steps the optimizer behind it all the same (train.py:155-157): only the replaced opacity tensor, which has no
+                    # gradient, is skipped
+                    self.reset_opacity()
+            if not changed:           # (after a densification every tensor is new and none has a gradient: the reference's step() is a no-op)
                 self.opt.step()
             self.opt.zero_grad(set_to_none=True)
         rec(4)
