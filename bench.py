@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--no-cam-leg", action="store_true", help="skip BASELINE.json config 3 (S-3M-cam, 852x480 and 1024x576)")
     ap.add_argument("--no-variants-leg", action="store_true", help="skip the structured variants of the headline scene (object / walls / S-room-640)")
     ap.add_argument("--only-variants", default=None, help="diagnostics: run ONLY the scene_variants leg (comma-separated names, or 'all') and print it")
+    ap.add_argument("--trained-map", type=int, default=0, metavar="STEPS",
+                    help="also run the reference's pipeline chained once (tests/trained_map.py: train STEPS steps -> point_cloud.ply -> from_ply -> masks + "
+                         "refinement with the early exit) and report it as `trained_map`; 7000 = BASELINE config 4's cadence (adds ~40 s); 0 = off")
     ap.add_argument("--pose-only", action="store_true", help="skip the Gaussian-parameter gradients (not the headline)")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl",
                     help="process-group backend for N > 1; gloo (collectives on host tensors) lets the N > 1 code path be rehearsed on a box with one GPU")
@@ -472,6 +475,15 @@ def main():
             torch.cuda.empty_cache()
         if not args.no_train_leg:
             train = train_step_leg(lib)
+    trained = None
+    if rank == 0 and world == 1 and args.trained_map > 0:
+        import tempfile
+        from tests import trained_map as TM
+        ply = os.path.join(tempfile.mkdtemp(prefix="gsr_map_"), "point_cloud", "iteration_%d" % args.trained_map, "point_cloud.ply")
+        tworld, treport = TM.train_room_map(ply, steps=args.trained_map)
+        lrep, _ = TM.localise_against(ply, tworld, n_frames=32, in_flight=F, start=(0.02, 1.0))
+        trained = {"workload": "train.py's loop on a synthetic room world -> point_cloud.ply -> GaussianMap.from_ply -> gsr_grad_mask + FusedRefiner.refine, early exit; "
+                               "query frames rendered from the WORLD; starts 2 cm / 1 deg off (tests/trained_map.py)", "train": treport, "localise": lrep}
 
     if rank == 0:
         res = res.cpu().numpy()
@@ -612,7 +624,7 @@ def main():
                "pose_err_cm_deg_median": [out["pose_err_cm_median"], out["pose_err_deg_median"]], "refine_iters_median": out["refine_iters_median"],
                "kernels_us_per_iter_single_frame": {k: round(1e3 * v, 1) for k, v in native_ms[True].items() if v > 0}}
         def _rows(leg):
-            return leg.get("per_scene", []) if isinstance(leg, dict) else []
+            return (leg.get("per_scene") or leg.get("per_size") or []) if isinstance(leg, dict) else []
         if variants is not None:
             sec["scene_variants_iters_per_s"] = {r_["variant"]: {"speculative": round(r_["speculative_iters_per_s"], 1), "complete_lists": round(r_["plain_iters_per_s"], 1),
                                                                  "speculative_gradient_rows_every_iteration": round(r_["speculative_iters_per_s_gradient_rows_every_iteration"], 1),
@@ -626,6 +638,12 @@ def main():
         out["config"]["secondary"] = {k: (round(v, 2) if isinstance(v, float) else v) for k, v in sec.items()}
         if cam is not None:
             out["cam_step"] = cam
+        if trained is not None:
+            out["trained_map"] = trained
+            out["config"]["trained_map"] = {"train_ms_per_step": round(trained["train"]["ms_per_step"], 3), "map_gaussians": trained["localise"]["map_gaussians"],
+                                           "pose_err_cm_deg_median": [round(trained["localise"]["pose_err_cm_median"], 3), round(trained["localise"]["pose_err_deg_median"], 4)],
+                                           "single_frame_iters_per_s": round(trained["localise"]["single_frame_iters_per_s"], 1),
+                                           "in_flight_iters_per_s": round(trained["localise"]["in_flight_iters_per_s"], 1)}
         if train is not None:
             out["train_step"] = train
         print(json.dumps(out), flush=True)
