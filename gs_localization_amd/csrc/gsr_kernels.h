@@ -3137,7 +3137,11 @@ __global__ void __launch_bounds__(GSR_BLOCK, 5) k_render_bwd_mfma(const uint2* _
     // tracking loss (descent_utils.py:100-101,118-121: more than half of the pixels under the reference's masks) -- adds exactly
     // nothing to any sum below: every term is linear in (dpx, dpy, dpz, dLd, dLa).  It is treated as a pixel without contributors,
     // so an 8 x 8 block (a wave) or a tile of such pixels walks nothing, and a wave's walk is as long as its deepest LIVE pixel needs.
+#ifdef GSR_NO_DEAD_PIXEL_SKIP          // (diagnostic builds: the A/B of this shortcut, HISTORY.md round 6)
+    const bool live = inside;
+#else
     const bool live = inside && (dpx != 0.f || dpy != 0.f || dpz != 0.f || dLd != 0.f || dLa != 0.f);
+#endif
     const int last_contributor = live ? (int)n_contrib[pix_id] : 0;
     const float bg_dot = bg[0] * dpx + bg[1] * dpy + bg[2] * dpz;
     const float nTf_bg = -T_final * bg_dot;

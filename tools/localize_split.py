@@ -42,6 +42,9 @@ def main():
                     help="query poses are scattered this far around the map's reference view.  The synthetic map is the frustum-shaped "
                          "cloud seen from that view: 0.3 m / 10 deg already looks past its edge (most tiles never saturate, no depth "
                          "bounds, complete lists: the stress case)")
+    ap.add_argument("--mask", choices=("reference", "ones"), default="reference",
+                    help="reference: every frame is refined under compute_grad_mask | create_mask(keypoints) as the reference's scripts build it "
+                         "(7scenes_localize_full_dslam.py:355-360), computed by gsr_grad_mask inside the timed loop; ones: every pixel (rounds 1-5)")
     ap.add_argument("--gpus", type=int, default=None, help="without a launcher: start this many ranks (torch.distributed.run) and exit with their status")
     ap.add_argument("--backend", choices=("nccl", "gloo"), default="nccl", help="gloo: the N > 1 path rehearsed on a box with one GPU (collectives on host tensors)")
     ap.add_argument("--device-index", type=int, default=None, help="GPU of this rank (default: LOCAL_RANK)")
@@ -108,6 +111,8 @@ def main():
         gt, init = frame_setup(f)
         with torch.cuda.stream(streams[slot]):
             fr = loaded.pop(f, None) or observe(f, gt)
+            if args.mask == "reference":          # (per frame, in front of its refinement, like viewpoint.compute_grad_mask(config) + the keypoint boxes)
+                fr.grad_mask = RP.reference_mask(fr.original_image, f)
             i0 = torch.tensor(init, dtype=torch.float32, device=dev)
             R, T, info = refiners[slot].refine(fr, RP.TRACKING_CONFIG, i0[:3, :3].clone(), i0[:3, 3].clone(), bg, iters=args.iters)
             te, re = RP.pose_errors(gt[:3, :3], gt[:3, 3], info["R_host"], info["T_host"])
@@ -139,7 +144,7 @@ def main():
         m = shard.median_errors(res)
         pr = torch.stack(per_rank).cpu().numpy()
         out = {"workload": f"synthetic test split: {args.frames} query frames within {args.spread[0]} m / {args.spread[1]} deg, {args.gaussians} Gaussians, 640x480, up to {args.iters} iterations each",
-               "n_gpus": world, "collectives": (args.backend if grouped else "none"), "frames_in_flight_per_gpu": F, "assign": args.assign, "frames_per_s": args.frames / wall,
+               "n_gpus": world, "collectives": (args.backend if grouped else "none"), "frames_in_flight_per_gpu": F, "assign": args.assign, "grad_mask": args.mask, "frames_per_s": args.frames / wall,
                "iterations_per_s": float(res[:, 3].sum()) / wall, "wall_s": wall,
                "median_trans_err_cm": 100.0 * m["median_t_m"], "median_rot_err_deg": m["median_R_deg"], "recall": m["recall"],
                "iterations_per_frame": {"min": float(res[:, 3].min()), "median": float(res[:, 3].median()), "max": float(res[:, 3].max())},

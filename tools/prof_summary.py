@@ -26,7 +26,9 @@ OURS = {"k_preprocess_lean": "preprocess_lean", "k_preprocess_bin": "preprocess_
         "k_tile_emit": "tile_emit", "k_tracking_loss": "tracking_loss", "k_pose_step": "pose_step", "k_pose_init": "pose_step",
         "k_tau_finish": "pose_step", "k_preprocess_bwd": "preprocess_bwd", "k_render_fwd": "render_fwd", "k_render_bwd": "render_bwd",
         "k_ssim_fwd": "ssim_fwd", "k_ssim_bwd": "ssim_bwd", "k_pearson_sums": "pearson_sums", "k_train_loss_finish": "train_loss_finish",
-        "k_densification_stats": "densification_stats", "k_backward_prologue": "backward_prologue"}
+        "k_densification_stats": "densification_stats", "k_backward_prologue": "backward_prologue",
+        "k_gradmask_intensity": "gradmask_intensity", "k_gradmask_hist": "gradmask_hist", "k_gradmask_threshold": "gradmask_threshold",
+        "k_gradmask_boxes": "gradmask_boxes", "k_gradmask_replica": "gradmask_replica"}
 
 
 def short(name):
