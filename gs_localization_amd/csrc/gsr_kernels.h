@@ -63,7 +63,9 @@ struct LoopGuard {
     __device__ __forceinline__ bool poisoned() const { return poison != nullptr && (*poison >> 2) == tag; }
     __device__ __forceinline__ bool frozen() const { return poisoned() || (conv != nullptr && *conv != 0.f); }
 };
+#ifndef GSR_HOLD_FORWARDS
 #define GSR_HOLD_FORWARDS 32u    // forwards a tile goes without a depth bound after failing a verification (native loop)
+#endif
 #define GSR_FAIL_BOUND 1u        // poison / fail word flags
 #define GSR_FAIL_OVERFLOW 2u
 
@@ -755,6 +757,9 @@ template <bool FLAT>
 __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, const bool live, const float* s_zbc, const int tid, const uint32_t sublist,
                                                uint32_t* s_flat = nullptr, WalkItem* wout = nullptr)
 {
+#if GSR_TIMING
+    const long long tp0_ = clock64();
+#endif
     bool vis = false, coop = false, own = false, store_cov = false;
     float3 p = make_float3(0.f, 0.f, 0.f);
     TileTest tt = {};
@@ -872,6 +877,9 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
             }
         }
     }
+#if GSR_TIMING
+    const long long tp1_ = clock64();
+#endif
     if (FLAT) {
         const int lane = tid & 63;
         const bool walker = own || coop;
@@ -938,11 +946,24 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
                 // behind everything this tile needed last iteration (+ margin): speculatively dropped
                 f_in[k] = f_in[k] && f_z[k] <= f_zb[k] * a.zb_mul + a.zb_add;
                 f_pos[k] = (uint32_t)a.bin_cap;
+#if GSR_TIMING
+                {   // (diagnostics: appends of this wave, and how many of them went to tiles without a depth bound)
+                    const uint32_t n_app = (uint32_t)__popcll(__ballot(f_in[k])), n_inf = (uint32_t)__popcll(__ballot(f_in[k] && !(f_zb[k] < __builtin_huge_valf())));
+                    if ((tid & 63) == 0 && s_flat != nullptr) { s_flat[133] += n_app; s_flat[134] += n_inf; }
+                }
+#endif
                 if (f_in[k]) {
                     atomicAdd(&ocnt[f_src[k]], 1u);
                     // (appends of one wave to the SAME tile grouped into one atomic -- a wave-uniform loop of ballots over up to 12 / 32 distinct
                     // tiles per sub-round -- were measured in round 5 for S-1M-640-object, whose hot tiles take ~4 000 appends per iteration:
-                    // this kernel 75 -> 78 / 86 us there, 36 -> 44 / 47 us on the uniform cloud.  The queue at the hot cursors is not what it waits for.)
+                    // this kernel 75 -> 78 / 86 us there, 36 -> 44 / 47 us on the uniform cloud.  Round 6 looked at the launches behind a failed
+                    // forward on that scene (2.1 ms and 0.73 ms instead of 30 us: a silhouette tile without a bound takes the 100-190 k splats
+                    // of the object behind it, one cursor, ~11 ns per same-address atomic -- tools/micro/atomic_scope.hip, tools/dbg/kt_longest.py,
+                    // lean_cold.py).  Three remedies built and measured, none kept: a coherent read of the cursor in front of the atomic
+                    // (skip once the bin has overflowed: the reads queue at the same memory-side word), one atomic per (wave, unbounded
+                    // tile) (a wave holds ~46 of those appends spread over its sub-rounds: a serial loop over the distinct tiles costs more
+                    // than it merges -- S-room-640 174 -> 198 us), and one dominant-tile group per sub-round (fewer than sixteen lanes share
+                    // a tile there: never taken).  The list of such a tile does not fit its bin anyway -- the call ends on the exact path.)
                     f_pos[k] = atomicAdd(&a.tile_cursor[f_tile[k] * GSR_CURSOR_STRIDE], 1u);
                 }
             }
@@ -1014,6 +1035,9 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
             if (lane == src) cnt = c_cnt;
         }
     }
+#if GSR_TIMING
+    const long long tp2_ = clock64();
+#endif
     if (vis) {
         // (what was dropped is not recorded: an instance can only be dropped from a tile whose bound is finite, and the
         // compositing kernel treats every such tile that ends unsaturated as a failed speculation)
@@ -1036,6 +1060,9 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
         const uint8_t d = a.dirty[idx];
         if (d != 0) { zero_grad_rows(a.rows, (size_t)idx, (d & 1) != 0, (d & 2) != 0); a.dirty[idx] = 0; }
     }
+#if GSR_TIMING
+    const long long tp3_ = clock64();
+#endif
     // k_preprocess_lean (a.sh_here): the wave's lanes are dense with survivors, so their colour is evaluated right here -- one
     // kernel (and one chain of dependent memory phases) less per iteration than with k_sh_color behind this one.
     if (FLAT && a.sh_here) asm volatile("" : : "v"(sh_touch0), "v"(sh_touch1));      // (keeps the two touches above alive up to here)
@@ -1047,6 +1074,12 @@ __device__ __forceinline__ void preprocess_one(const PreArgs& a, const int idx, 
         reinterpret_cast<float4*>(a.rec + (size_t)idx * GSR_REC_STRIDE)[2] = make_float4(c.x, c.y, c.z, 0.f);
         a.clamped[idx] = cb;
     }
+#if GSR_TIMING
+    if (FLAT && s_flat != nullptr && (tid & 63) == 0) {
+        const long long tp4_ = clock64();
+        s_flat[129] += (uint32_t)(tp1_ - tp0_); s_flat[130] += (uint32_t)(tp2_ - tp1_); s_flat[131] += (uint32_t)(tp3_ - tp2_); s_flat[132] += (uint32_t)(tp4_ - tp3_);
+    }
+#endif
 }
 
 __global__ void __launch_bounds__(GSR_BLOCK) k_preprocess(PreArgs a)
@@ -1100,7 +1133,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, GSR_LEAN_OCC) k_preprocess_lean(Pre
 {
     extern __shared__ float s_zbc[];      // a.zbc_lds floats: the superblock bounds
     __shared__ uint32_t s_cand[4][GSR_LEAN_PER_LANE * 64];
-    __shared__ uint32_t s_flat[4][132];      // (128 words per wave; word 128: diagnostics of the timing build)
+    __shared__ uint32_t s_flat[4][136];      // (128 words per wave; words 128-133: diagnostics of the timing build)
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (a.tile_order[0] != nullptr && blockIdx.x < 2) {      // (before the poison test: the orders must be permutations whatever happens)
         __shared__ uint32_t s_cls[GSR_BLOCK];
@@ -1174,7 +1207,7 @@ __global__ void __launch_bounds__(GSR_BLOCK, GSR_LEAN_OCC) k_preprocess_lean(Pre
     GSR_T_TICK(1)
     GSR_T_COUNT(10, ncand)
 #if GSR_TIMING
-    if (lane == 0) s_flat[wv][128] = 0u;
+    if (lane == 0) { s_flat[wv][128] = 0u; s_flat[wv][129] = 0u; s_flat[wv][130] = 0u; s_flat[wv][131] = 0u; s_flat[wv][132] = 0u; s_flat[wv][133] = 0u; s_flat[wv][134] = 0u; }
     __builtin_amdgcn_wave_barrier();
 #endif
 #if GSR_LEAN_POOL > 1
@@ -1210,6 +1243,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, GSR_LEAN_OCC) k_preprocess_lean(Pre
 #if GSR_TIMING
     __builtin_amdgcn_wave_barrier();
     GSR_T_COUNT(11, s_flat[wv][128])
+    // (sub-phases of the exact passes, summed over them: slots 3-6 = geometry incl. the hoisted loads | footprint walk + appends |
+    // survivors' list + dirty rows | SH colour)
+    GSR_T_COUNT(3, s_flat[wv][129]) GSR_T_COUNT(4, s_flat[wv][130]) GSR_T_COUNT(5, s_flat[wv][131]) GSR_T_COUNT(6, s_flat[wv][132])
+    GSR_T_COUNT(7, s_flat[wv][133]) GSR_T_COUNT(8, s_flat[wv][134])
 #endif
     GSR_T_FLUSH(32)
 }

@@ -12,7 +12,7 @@ bg = torch.zeros(3, device=dev)
 vp = PL.QueryFrame(0, PL.intrinsics_projection(sc, dev), sc, dev)
 with torch.no_grad():
     pkg = PL.render(vp, model, bg)
-vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); vp.grad_mask = torch.ones((1, H, W), dtype=torch.bool, device=dev)
+vp.original_image = pkg["render"].clone(); vp.depth = pkg["depth"][0].clone(); vp.grad_mask = PL.reference_mask(vp.original_image)
 init = torch.tensor(S.se3_exp([0.01, 0.01, 0.01, 0.01, 0.0, 0.0]), dtype=torch.float32, device=dev)
 fr = PL.FusedRefiner(model, H, W, device=dev)
 nk = lib.gsr_profile_kernel_count(); names = [lib.gsr_profile_kernel_name(i).decode() for i in range(nk)]
@@ -48,8 +48,8 @@ if os.environ.get("LOOP_PLAIN"):
     show("k_preprocess_bin", 32, ["geometry (preprocess_one x 4)", "barrier", "count walk", "barrier", "reserve (global atomics)", "barrier before a band", "emit walk (all bands)",
                                   "", "", "(wave lifetime)", "", ""])
 nw = (sc.P + 255) // 256 * ITERS      # one wave per 256 Gaussians
-show("k_preprocess_lean", 32, ["bounds -> LDS + barrier", "conservative pass (4 x 64 Gaussians)", "exact pass on the compacted candidates", "", "",
-                               "", "", "", "", "(wave lifetime)", "candidates", ""])
+show("k_preprocess_lean", 32, ["bounds -> LDS + barrier", "conservative pass (4 x 64 Gaussians)", "exact pass on the compacted candidates", "  geometry incl. hoisted loads",
+                               "  footprint walk + appends", "  survivors' list + dirty rows", "  SH colour", "", "", "(wave lifetime)", "candidates", "instances walked"])
 # (working waves of the chain-rule kernel: the ones that ran at least one round)
 rounds = max(v[48 + 10], 1)
 print("k_preprocess_bwd (cycles per ROUND of <= 64 Gaussians, mean over %d rounds = %.1f per launch; %d Gaussians per launch)" % (rounds, rounds / ITERS, v[48 + 11] / ITERS))
