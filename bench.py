@@ -6,7 +6,7 @@ One refinement iteration = one body of the reference's loop
 (gs_localization/pipelines/7scenes_localize_full_dslam.py:66-91): render() through the pose rasterizer
 -> tracking loss -> backward (dL/dtau every iteration; the gradient tensors of the Gaussians' own parameters, which
 nobody can read before the refinement call returns, are written once per call from the last stepped iteration's records --
-what the reference's last loss.backward() leaves; `config.loop`) -> Adam step -> update_pose ->
+what one loss.backward() of that iteration adds; `config.loop`) -> Adam step -> update_pose ->
 convergence flag.  Query frames are independent, so every rank (GPU) refines its own frames against its
 own replica of the map (weak scaling, no data-path collective; one gather of the results at the end),
 and keeps F frames in flight (one host thread + one HIP stream each): the compositing kernels are chains of
@@ -545,7 +545,7 @@ def main():
                        "hip_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "loop": "native gsr_refine (render, tracking loss, backward, Adam, update_pose per iteration; dL/dtau every iteration, the gradient tensors "
                                "of the Gaussians' own parameters -- which nobody can read before the call returns -- written once per call, from the last "
-                               "stepped iteration's records: what the reference's last loss.backward() leaves)",
+                               "stepped iteration's records: what ONE loss.backward() of that iteration adds -- the reference never zeroes the map tensors' .grad inside its loop, so there it is the sum over the iterations; nobody reads either)",
                        "iterations_per_call": K,
                        "grad_mask": "the reference's per-frame mask, computed by gsr_grad_mask inside every timed call: compute_grad_mask (camera_utils.py:164-193, "
                                     "edge_threshold 1.1) | create_mask over %d seeded keypoints, k = 10 (7scenes_localize_full_dslam.py:355-360)" % PL.N_KEYPOINTS,

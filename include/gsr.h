@@ -343,10 +343,12 @@ typedef struct gsr_refine_args {
     float* dL_dimage; float* dL_ddepth; float* dL_dalpha;
     float* dL_dmean2D; float* dL_dconic; float* dL_dopacity; float* dL_dcolor;
     float* dL_dmean3D; float* dL_dcov3D; float* dL_dsh; float* dL_dscale; float* dL_drot;   /* nullable: pose-only */
-    /* On return the nine gradient tensors above hold what the reference's LAST loss.backward() leaves in them: the gradients of the
-     * last iteration whose pose step ran (with the early exit that is the iteration whose update reported convergence, not the render
-     * at the final pose that follows it).  Nobody can read them before the call returns, so the iterations in between only compute
-     * dL/dtau and the rows are written once, from that iteration's records, when the loop ends. */
+    /* On return the nine gradient tensors above hold the gradients of the LAST iteration whose pose step ran, alone (with the early
+     * exit: the iteration whose update reported convergence, not the render at the final pose that follows it).  (Round 6, stated
+     * exactly: the reference's loop only calls pose_optimizer.zero_grad(), 7scenes_localize_full_dslam.py:78, so the .grad of its map
+     * tensors holds the SUM over all iterations; nobody reads that either.  What this call returns is what ONE loss.backward() of that
+     * last iteration adds.)  Nobody can read them before the call returns, so the iterations in between only compute dL/dtau and
+     * the rows are written once, from that iteration's records, when the loop ends. */
     float* dL_dtau; float* loss_out;
     gsr_resize_fn geometry_buffer; void* geometry_ctx;
     gsr_resize_fn binning_buffer; void* binning_ctx;
