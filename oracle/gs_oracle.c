@@ -616,7 +616,8 @@ static int g_bwd64 = 0;
 void gso_set_backward_double(int on) { g_bwd64 = on ? 1 : 0; }
 
 /* Checker option: per Gaussian, [0] the sum of |terms| of its dL/dopacity (what the row is the signed sum of) and [1] the sum of
- * |term| x (relative rounding uncertainty of the transmittance the term was formed with): how far rounding ALONE can move the row.
+ * |term| x (relative rounding uncertainty of the transmittance the term was formed with) + |G T| |behind| |dL/dpixel| x (roundings the
+ * "composited behind" recurrence has accumulated): how far rounding ALONE can move the row.
  * A parity test excuses a row whose [1] reaches its per-row bar -- an ill-conditioned sum, not a wrong one.  out: 2 P doubles,
  * zeroed by the caller; NULL switches the report off.  eps: the relative error assumed for one alpha (a few ulp). */
 static double* g_cond = NULL;
