@@ -1,6 +1,7 @@
 /* Plain-C consumer of include/gsr.h: what a maintainer's binding sees without torch or Python.
  * Renders 3 splats on a 48x32 image through gsr_forward, differentiates through gsr_backward (pose package), checks the
- * status codes, that the centre pixel is covered, that the image is finite and that dL/dtau is non-zero.
+ * status codes, that the centre pixel is covered, that the image is finite and that dL/dtau is non-zero; then the per-frame
+ * gradient mask of the localisers (gsr_grad_mask) on that image.
  * Build (tests/test_c_abi.py does it): gcc -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude smoke.c
  *                                      -L<repo>/gs_localization_amd -lgsr_hip -L/opt/rocm/lib -lamdhip64 -lm */
 #include <hip/hip_runtime_api.h>
@@ -123,6 +124,27 @@ int main(void)
     rc = gsr_forward(resize_cb, &geom, resize_cb, &binning, resize_cb, &img, P, 0, 0, d_bg, W, H, d_means, NULL, NULL, d_opac, d_scales, 1.0f, d_rots,
                      NULL, d_view, d_proj, d_campos, tanx, tany, 0, out_color, out_depth, out_alpha, radii, 0, NULL, st);
     if (rc != GSR_E_INVALID || strlen(gsr_last_error()) == 0) { fprintf(stderr, "missing colours must be GSR_E_INVALID with a message\n"); return 1; }
+    /* the per-frame gradient mask of the localisers (gsr_grad_mask, ABI 5) on the rendered image + one keypoint box: a picture of three
+     * splats on black has a median gradient of 0, so the mask is "any gradient at all" -- it must cover part of the frame, not all of
+     * it, and the box around (2, 2) -- an empty corner -- must be set */
+    {
+        buf_t scratch = {NULL, 0};
+        unsigned char *d_mask = NULL, h_mask[N];
+        const float kp[2] = {2.2f, 2.9f};
+        float* d_kp = upload(kp, 2);
+        CK(hipMalloc((void**)&d_mask, N));
+        rc = gsr_grad_mask(W, H, out_color, 1.1f, d_kp, 1, 10, d_mask, NULL, NULL, resize_cb, &scratch, NULL);
+        if (rc < 0) { fprintf(stderr, "gsr_grad_mask: %s\n", gsr_last_error()); return 1; }
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(h_mask, d_mask, N, hipMemcpyDeviceToHost));
+        int set = 0;
+        for (int i = 0; i < N; i++) { if (h_mask[i] > 1) { fprintf(stderr, "mask byte %d = %d\n", i, h_mask[i]); return 1; } set += h_mask[i]; }
+        if (!(set > 49 && set < N) || !h_mask[2 * W + 2] || !h_mask[0] || !h_mask[7 * W + 7] || h_mask[(H - 1) * W + W - 1]) {
+            fprintf(stderr, "unexpected mask: %d of %d pixels set\n", set, N); return 1; }
+        if (gsr_grad_mask(1, H, out_color, 1.1f, NULL, 0, 10, d_mask, NULL, NULL, resize_cb, &scratch, NULL) != GSR_E_INVALID) {
+            fprintf(stderr, "a 1-pixel-wide image must be GSR_E_INVALID (reflect padding)\n"); return 1; }
+        printf("grad mask: %d of %d pixels\n", set, N);
+    }
     printf("c abi smoke ok: R=%d alpha(centre)=%.3f |dL/dtau|=%.4g\n", R, h_alpha[centre], sqrt(tau_norm));
     return 0;
 }
