@@ -1907,7 +1907,11 @@ __device__ __forceinline__ void dilate_bounds(const SegBuild& sb, float* scratch
         // (... and only where the longer list is affordable: this tile's list grows roughly in proportion to the depth it covers; a tile on a
         // dense object that took the bound of its neighbour in the sparse background behind would bin the whole object -- an overflowing bin)
         const float mylen = (float)sb.len[t];
-        const bool affordable = (nb < __builtin_huge_valf()) ? (mine > 0.f && mylen * (nb / mine) <= (float)GSR_DILATE_MAX_LEN) : true;
+#ifndef GSR_DILATE_INF_OWN_MAX
+#define GSR_DILATE_INF_OWN_MAX 0xFFFFFFFFu      // (experiment, round 6: a BOUNDED tile takes "no bound" from a neighbour only if its own needed list is at most this long)
+#endif
+        const bool affordable = (nb < __builtin_huge_valf()) ? (mine > 0.f && mylen * (nb / mine) <= (float)GSR_DILATE_MAX_LEN)
+                                                              : (!(mine < __builtin_huge_valf()) || sb.len[t] <= GSR_DILATE_INF_OWN_MAX);
         uint32_t hold = sb.nodilate[t];      // (a tile whose widened bin overflowed goes without for a while: k_render_fwd set this)
         if (hold != 0u) sb.nodilate[t] = hold - 1u;
         sb.zb_own[t] = mine;
