@@ -2323,7 +2323,10 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
             // the bound this tile was binned with was a neighbour's (dilate_bounds): back to its own, which held a list that fitted, no widening
             // for a while, and the forward fails like a verification -- the group behind this one retries it on the device
             const float own = sg.zb_own_used[tile];
-            sg.nodilate[tile] = 64u;
+#ifndef GSR_NODILATE_HOLD
+#define GSR_NODILATE_HOLD 64u
+#endif
+            sg.nodilate[tile] = GSR_NODILATE_HOLD;
             zb_next[tile] = own;
             atomicMax(reinterpret_cast<int*>(zbc_next) + (ty >> 2) * sbx + (tx >> 2), __float_as_int(own));
             atomicMax(fail, fail_tag | GSR_FAIL_BOUND);

@@ -37,6 +37,12 @@
  *     (oracle/autograd_ref.py), not against an execution of the reference:
  *     "parity unpinned" for that part.
  *
+ * Checker options that restate nothing of the reference (round 6; they qualify comparisons AGAINST the restatement, tests/util.py::
+ * flip_accounted_parity): gso_flip_audit (which (pixel, splat) decisions sit within rounding of their thresholds),
+ * gso_set_backward_double (K7 on the forward's fp32 decisions with G, alpha, recurrences and sums in double: gs_oracle_k7.inc),
+ * gso_set_condition_out (how far rounding alone can move a Gaussian's opacity-gradient sum).  The per-frame gradient mask of the
+ * localisers is restated in oracle/grad_mask_oracle.py (numpy) and pinned bit for bit by the imported reference's own masks.
+ *
  * Arithmetic: fp32 everywhere, source-order evaluation, compiled with
  * -ffp-contract=off so that no FMA contraction is introduced.  Matrices follow
  * the reference's column-major (glm) convention: m[c][r].
