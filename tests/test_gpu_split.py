@@ -173,3 +173,41 @@ def test_split_backward_against_float64_autograd():
         assert loop64 <= 5e-6, (k, loop64)                      # the split path against the truth
         assert loop64 <= oracle64, (k, loop64, oracle64)        # ... at least as close to it as the fp32 restatement of the reference
         assert loop_oracle <= 1e-4, (k, loop_oracle)
+
+
+def test_early_exit_behind_a_split_forward_counts_n_touched_without_rewriting_the_images():
+    """on an early exit the caller gets the frozen forward at the final pose -- a forward that ran with split tiles --
+    and n_touched from a closing pass over its lists.  That pass must (a) leave the split forward's images, n_contrib and radii alone
+    (it used to re-composite them with the unsplit walk's rounding), (b) never read list positions no depth range wrote (a range that
+    found every pixel finished leaves its part of the list unwritten), (c) count what the forward blended: n_touched against the oracle
+    at the final pose, exact up to the pixels the flip audit names; images against the oracle as usual."""
+    import os
+    from oracle import oracle as O
+    from tests import replay as PL
+    from tests.test_gpu_lean import _camera_of_the_pose_state
+    O.set_threads(min(64, os.cpu_count() or 1))
+    sc = _room(300_000)
+    model, bg, view, init = _setup(sc, seed=11, trans=0.004, rot_deg=0.2)
+    fr = PL.FusedRefiner(model, sc.H, sc.W, device=DEV)
+    info = None
+    # (Adam's first steps move every component by lr: |tau| = sqrt(6) x 1e-3 = 2.45e-3, then less as signs start to flip: a threshold
+    # just below that is reached after a few speculative -- split -- iterations)
+    for thr in (2.4e-3, 2.3e-3, 2.2e-3, 2.1e-3, 2.0e-3, 1.8e-3, 1.6e-3, 1.4e-3):
+        R, T, info = fr.refine(view(), PL.TRACKING_CONFIG, init[:3, :3].clone(), init[:3, 3].clone(), bg, iters=30, converged_threshold=thr,
+                               stop_on_converged=True, warm_start=False, lean_min_P=1, flags=0)
+        torch.cuda.synchronize()
+        if info["converged"] and 4 <= info["iters"] < 30:
+            break
+    assert info["converged"] and 4 <= info["iters"] < 30, {k: info[k] for k in ("converged", "iters")}
+    blocks, ntiles_split, kmax, budget = fr.seg_stats()
+    assert ntiles_split >= 5, (blocks, ntiles_split, kmax)          # the frozen forward's launch list had split tiles
+    vm, pm, cp = _camera_of_the_pose_state(info["R_host"], info["T_host"], S.camera_matrices(sc)[2])
+    f = O.forward(sc.means3D, sc.opacities, vm, pm, cp, sc.W, sc.H, sc.tanfovx, sc.tanfovy, sc.bg, sh_degree=sc.sh_degree, shs=sc.shs,
+                  scales=sc.scales, rotations=sc.rotations, want_n_touched=True)
+    assert np.array_equal(fr.radii.cpu().numpy(), f.radii)
+    for k, a, b in (("color", fr.color, f.color), ("depth", fr.depth, f.depth), ("alpha", fr.alpha, f.alpha)):
+        assert U.rel_l1(a.cpu().numpy(), b) <= 1e-4, (k, U.rel_l1(a.cpu().numpy(), b))
+    near_half, _, events = O.flip_audit(f)
+    dn = np.abs(fr.n_touched.cpu().numpy().astype(np.int64) - f.n_touched.astype(np.int64))
+    assert (dn <= near_half).all(), (int((dn > near_half).sum()), int(dn.sum()), events)
+    assert int(fr.n_touched.sum().item()) > 1000
