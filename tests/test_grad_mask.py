@@ -174,3 +174,37 @@ def test_drop_in_compute_grad_mask_sets_the_attribute(gm):
     out = PL.compute_grad_mask(vp, cfg, keypoints=gm[name + "_keypoints"], box_k=10)
     assert out is vp.grad_mask and out.dtype is torch.bool and tuple(out.shape) == (1, H, W)
     assert np.array_equal(out.cpu().numpy()[0], unpack(gm[name + "_mask_with_boxes_bits"], H, W))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CASES)
+def test_hip_mask_against_the_same_torch_ops_on_this_device(gm, name):
+    """What an unchanged script would compute on THIS machine: the torch operations of compute_grad_mask (mean over channels, reflect
+    pad, two grouped 3x3 convolutions, the 3x3 validity convolution, sqrt, torch.median, the comparison -- restated here call for call,
+    camera_utils.py:164-193 / descent_utils.py:33-67) executed by PyTorch-ROCm on the GPU.  Its convolution (MIOpen) and its mean
+    (sum x fl(1/3)) round differently from torch's CPU backend, which the fixtures pin -- so this is not a bit-for-bit test: the two
+    masks may differ where the intensity sits within rounding of the threshold, and nowhere else."""
+    import torch
+    import torch.nn.functional as F
+    from gs_localization_amd import pipelines as PL
+    img = torch.tensor(case_image(gm, name), device="cuda:0")
+    thr = float(gm[name + "_edge_threshold"])
+    gray = img.mean(dim=0, keepdim=True)
+    conv_y = torch.tensor([[3, 0, -3], [10, 0, -10], [3, 0, -3]], dtype=torch.float32, device="cuda:0")
+    conv_x = torch.tensor([[3, 10, 3], [0, 0, 0], [-3, -10, -3]], dtype=torch.float32, device="cuda:0")
+    normalizer = 1.0 / torch.abs(conv_y).sum()
+    p = F.pad(gray, (1, 1, 1, 1), mode="reflect")[None]
+    gv = normalizer * F.conv2d(p, conv_x.view(1, 1, 3, 3))
+    gh = normalizer * F.conv2d(p, conv_y.view(1, 1, 3, 3))
+    ok = F.conv2d((torch.abs(p) > 0.01).float(), torch.ones((1, 1, 3, 3), device="cuda:0")) == 9
+    inten = torch.sqrt((gv[0] * ok[0]) ** 2 + (gh[0] * ok[0]) ** 2)
+    want = inten > inten.median() * thr
+    got, mine, med = PL.grad_mask(img, thr, return_intensity=True)
+    diff = (got != want)
+    # every differing pixel sits at the threshold: its intensity (either evaluation) within 1e-5 relative of it -- or, where the median
+    # itself is a rounding residue (the noise-free picture, 1e-8), within that residue
+    t = float(med[1])
+    at = (inten[0] - t).abs() <= 1e-5 * t + 4e-8
+    assert not (diff[0] & ~at).any(), (int(diff.sum()), int((diff[0] & ~at).sum()))
+    assert float(diff.float().mean()) <= 2e-2, float(diff.float().mean())          # (the noise-free picture: a flat region sits AT its residue median)
+    print(name, "pixels that differ from torch-on-ROCm:", int(diff.sum()), "of", diff.numel(), "(all at the threshold)")
