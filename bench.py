@@ -628,6 +628,7 @@ def main():
         if variants is not None:
             sec["scene_variants_iters_per_s"] = {r_["variant"]: {"speculative": round(r_["speculative_iters_per_s"], 1), "complete_lists": round(r_["plain_iters_per_s"], 1),
                                                                  "speculative_gradient_rows_every_iteration": round(r_["speculative_iters_per_s_gradient_rows_every_iteration"], 1),
+                                                                 "speculative_16_in_flight": round(r_["speculative_16_frames_in_flight"]["iters_per_s"], 1),
                                                                  "kernels_us": {k: round(1e3 * v, 1) for k, v in r_["kernels_ms_per_iter_speculative"].items()}}
                                                  for r_ in _rows(variants)}
         if cam is not None:
@@ -861,12 +862,41 @@ def scene_variants_leg(lib, dev, K=50, only=None):
         # pose error of a full refinement with the reference's early exit
         Rr, Tt, inf = fr.refine(frames[0], PL.TRACKING_CONFIG, inits[0][:3, :3].clone(), inits[0][:3, 3].clone(), bg, iters=50, stop_on_converged=True)
         te, re = PL.pose_errors(np.eye(3), np.zeros(3), inf["R_host"], inf["T_host"])
+        # Round 6: the same scene with SIXTEEN frames in flight (one refiner, stream and host thread each, as `value` runs the uniform
+        # cloud).  Until round 6 no bench line measured this, and split tiles made it collapse (S-room-640: 81 it/s) -- gsr_api.hip,
+        # GSR_SPLIT_MAX_CALLS.
+        FF = 16
+        ffr = [fr] + [PL.FusedRefiner(model, H, W, device=dev) for _ in range(FF - 1)]
+        fframes = frames + [PL.make_frame(sc, model, dev, bg, uid=u) for u in range(2, FF)]
+        finits = inits + [PL.perturbed_start(1000 + u, device=dev) for u in range(2, FF)]
+        fstreams = [torch.cuda.Stream(device=dev) for _ in range(FF)]
+        ffail = [0] * FF
+
+        def fworker(s_, iters_):
+            with torch.cuda.stream(fstreams[s_]):
+                _, _, inf_ = ffr[s_].refine(fframes[s_], PL.TRACKING_CONFIG, finits[s_][:3, :3].clone(), finits[s_][:3, 3].clone(), bg, iters=iters_, stop_on_converged=False)
+                ffail[s_] = inf_["fallbacks"]
+                fstreams[s_].synchronize()
+        best_ff = 1e9
+        for rep_ in range(3):
+            for s_ in range(FF):      # (predecessor: another frame, so that every timed call warm-starts from foreign bounds)
+                with torch.cuda.stream(fstreams[s_]):
+                    ffr[s_].refine(fframes[(s_ + 1) % FF], PL.TRACKING_CONFIG, finits[(s_ + 1) % FF][:3, :3].clone(), finits[(s_ + 1) % FF][:3, 3].clone(), bg, iters=5, stop_on_converged=False)
+            torch.cuda.synchronize()
+            th_ = [threading.Thread(target=fworker, args=(s_, K)) for s_ in range(FF)]
+            t0 = time.perf_counter()
+            [x.start() for x in th_]; [x.join() for x in th_]
+            torch.cuda.synchronize()
+            best_ff = min(best_ff, time.perf_counter() - t0)
+        in_flight = {"frames": FF, "iters_per_s": FF * K / best_ff, "failed_forwards_per_frame_mean": float(np.mean(ffail))}
+        del ffr, fframes
         per, _ = algorithmic_bytes(sc.P, V, R, R_eff, N, M, ntiles)
         loop_kernels = {k: per[k] for k in ("render_fwd", "render_bwd", "preprocess_bwd", "preprocess_fwd")}
         rows.append({"scene": sc.name, "variant": vname, "width": W, "height": H, "gaussians": sc.P, "tiles": ntiles, "V": V, "R": R,
                      "R_eff_own_binning": R_eff, "list_entries_ordered": R_ord, "iterations_per_call": K,
                      "speculative_iters_per_s": res[True][0], "plain_iters_per_s": res[False][0],
                      "speculative_iters_per_s_gradient_rows_every_iteration": K / best_every,
+                     "speculative_16_frames_in_flight": in_flight,
                      "speculative_call_stats": res[True][2], "plain_call_stats": res[False][2],
                      "pose_err_cm_deg_after_refinement": [100.0 * te, re], "refine_iters": inf["iters"],
                      "kernels_ms_per_iter_speculative": res[True][1], "kernels_ms_per_iter_plain": res[False][1],

@@ -282,6 +282,7 @@ size_t carve_bin_local(char* base, int ntiles, int cap, BinLocal& b)
 // ones, 2 = bin everything but record bounds.  parity picks the buffer that is written.
 struct SpecCtx { int mode = 0; int parity = 0; float mul = 1.05f, add = 0.05f; char* state = nullptr; };
 struct PassCtx {
+    bool split_ok_now = true;      // gsr_refine: may the launch list this group builds split heavy tiles?  (not with many calls in flight, see enqueue)
     bool native_loop = false;      // gsr_refine: gradient tensors and accumulators are maintained by the kernels, not re-zeroed here
     SpecCtx spec;
     gsr::LoopGuard guard = {nullptr, nullptr, 0u};      // device-side poison / converged words and this group's tag (see LoopGuard)
@@ -1068,7 +1069,7 @@ int backward_impl(const PassCtx& cx, GSR_BWD_PARAMS)
         const bool build = cx.seg && im.seg_budget > 0 && cx.native_loop && balanced;
         const gsr::SegBuild sb = build ? gsr::SegBuild{im.tile_work[0], im.tile_order[0], im.seg_list[cx.spec.parity], im.seg_nosplit, ntiles, next_budget, kgrid, im.seg_len,
                                                         (cx.spec.mode != 0 && !cx.spec.state && !(cx.flags & GSR_REFINE_NO_DILATE)) ? im.zb[cx.spec.parity] : (float*)nullptr, im.zbc[cx.spec.parity], gx, gy, im.sbx,
-                                                        im.zb_own[cx.spec.parity], im.nodilate, (cx.spec.mode == 2) ? 0 : 1, cx.seg_host_total} : gsr::SegBuild{};
+                                                        im.zb_own[cx.spec.parity], im.nodilate, (cx.spec.mode == 2 || !cx.split_ok_now) ? 0 : 1, cx.seg_host_total} : gsr::SegBuild{};
         if (pose_mode) hipLaunchKernelGGL(k_render_bwd_mfma<true>, dim3(kgrid + (build ? 1 : 0)), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag, sg, sb);
         else hipLaunchKernelGGL(k_render_bwd_mfma<false>, dim3(kgrid + (build ? 1 : 0)), dim3(GSR_BLOCK), 0, st, GSR_BWD_ARGS, cx.guard, order, work, (const float*)g.rec, P, (P < (1 << 28)) ? 1 : 0, cx.det ? 1 : 0, g.aflag, sg, sb);
 #undef GSR_BWD_ARGS
@@ -1501,6 +1502,19 @@ int gsr_refine(const gsr_refine_args* a, int* iters_done, int* converged)
             const float m = (g == 0 && warm_buf >= 0) ? GSR_WARM_MARGIN : margin_m;      // (bounds recorded for another frame: be generous)
             cx.spec.mul = 1.f + m; cx.spec.add = m;
         }
+        // Round 6: a split tile's segments WAIT for the lower-numbered blocks of their launch (the products of the ranges in front).  Workgroups
+        // of one launch start in order -- per XCD: block b goes to XCD b mod 8, each XCD takes its share when IT has room.  A launch alone on
+        // the GPU loads the eight alike; with eight or more refinement calls in flight (sixteen is bench.py's default) they drift apart, a
+        // range becomes resident while its predecessor still queues behind other calls' blocks on another XCD, spinning ranges fill the slots
+        // their predecessors need, and the bounded waits (seconds) were what ended it: S-room-640 2 811 it/s with four frames in flight, 130
+        // with eight, 81 with sixteen; a trained 800 k map 2 359 / 243 / 128 (tools/dbg/inflight_probe.py, trained_probe.py -- the
+        // scene_variants leg runs ONE frame and `value` runs a scene that splits nothing, so no bench line saw it).  With more than
+        // GSR_SPLIT_MAX_CALLS calls in flight the lists are built without splits (the other frames fill the GPU while a heavy tile's wave
+        // walks alone -- what splitting was for); everything else the builder block does (launch order, widened bounds) stays.
+#ifndef GSR_SPLIT_MAX_CALLS
+#define GSR_SPLIT_MAX_CALLS 4
+#endif
+        cx.split_ok_now = g_refine_calls.load(std::memory_order_relaxed) <= GSR_SPLIT_MAX_CALLS;
         *slot_of(g) = 0u;      // (nothing in flight writes this slot any more: group g - 2 has been settled)
         cx.spec.mode = mode;
         cx.spec.parity = par(g);

@@ -2516,7 +2516,9 @@ __global__ void __launch_bounds__(GSR_BLOCK, (TOUCHED && LIST != GSR_LIST_SORTED
                 // segment's 142 k cycles.  The products are still multiplied in segment order.)
                 static_assert(GSR_SEG_MAX <= 64, "one lane per predecessor");
                 bool ok = false;
-                for (uint32_t spins = 0; spins < (1u << 21); spins++) {          // (bounded: a forward that gave up waiting fails)
+                // (bounded: a forward that gave up waiting fails and the tile goes unsplit for a while.  Round 6: 2^13 polls ~ 10 ms, was 2^21 --
+                // seconds per stuck range when many calls share the GPU, see GSR_SPLIT_MAX_CALLS in gsr_api.hip)
+                for (uint32_t spins = 0; spins < (1u << 13); spins++) {
                     const bool mine = (uint32_t)lane >= seg || seg_load_u(&sg.pub[first + (uint32_t)lane]) == pub_word;
                     if (__all(mine)) { ok = true; break; }
                     __builtin_amdgcn_s_sleep(8);

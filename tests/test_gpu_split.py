@@ -211,3 +211,44 @@ def test_early_exit_behind_a_split_forward_counts_n_touched_without_rewriting_th
     dn = np.abs(fr.n_touched.cpu().numpy().astype(np.int64) - f.n_touched.astype(np.int64))
     assert (dn <= near_half).all(), (int((dn > near_half).sum()), int(dn.sum()), events)
     assert int(fr.n_touched.sum().item()) > 1000
+
+
+def test_many_frames_in_flight_on_a_scene_with_split_tiles_do_not_stall():
+    """Round 6: a split tile's depth ranges WAIT for the lower-numbered blocks of their launch.  Blocks of a launch start in order per XCD,
+    and with eight or more refinement calls sharing the GPU the XCDs drift apart: ranges spun for seconds on predecessors that queued
+    behind other calls' blocks (S-room-640: 2 811 it/s with four frames in flight, 130 with eight, 81 with sixteen; nothing measured it --
+    bench.py's structured variants ran one frame).  With more than GSR_SPLIT_MAX_CALLS calls in flight the launch lists are built
+    without splits.  Guard: eight frames in flight must be FASTER than one, not twenty times slower."""
+    import threading
+    import time
+    from tests import replay as PL
+    sc = _room(300_000)
+    model = PL.GaussianMap.from_scene(sc, device=DEV)
+    bg = torch.zeros(3, device=DEV)
+    F, K = 8, 20
+    frames = [PL.make_frame(sc, model, DEV, bg, uid=u) for u in range(F)]
+    inits = [PL.perturbed_start(1000 + u, device=DEV) for u in range(F)]
+    refs = [PL.FusedRefiner(model, sc.H, sc.W, device=DEV) for _ in range(F)]
+    streams = [torch.cuda.Stream(device=DEV) for _ in range(F)]
+    call = lambda s, f, k: refs[s].refine(frames[f], PL.TRACKING_CONFIG, inits[f][:3, :3].clone(), inits[f][:3, 3].clone(), bg, iters=k, stop_on_converged=False)
+
+    def run(nf):
+        for s in range(nf):
+            with torch.cuda.stream(streams[s]):
+                call(s, (s + 1) % F, 5)
+        torch.cuda.synchronize()
+
+        def worker(s):
+            with torch.cuda.stream(streams[s]):
+                call(s, s, K)
+                streams[s].synchronize()
+        th = [threading.Thread(target=worker, args=(s,)) for s in range(nf)]
+        t0 = time.perf_counter()
+        [x.start() for x in th]; [x.join() for x in th]
+        torch.cuda.synchronize()
+        return nf * K / (time.perf_counter() - t0)
+    run(F)          # (allocations)
+    one = max(run(1) for _ in range(2))
+    assert refs[0].seg_stats()[1] >= 5          # alone on the GPU the scene does split tiles
+    eight = max(run(F) for _ in range(2))
+    assert eight >= 1.1 * one, (one, eight)
