@@ -31,3 +31,16 @@ def test_train_save_load_localise_and_check_against_the_oracle(tmp_path):
     sc = TM.scene_of_map(gmap, world)
     run = _run(fr, frames[0], inits[0], bg, 8, flags=0, lean_min_P=1)
     print(*oracle_check_at_the_last_forward(sc, fr, run, frames[0], frames[0].original_image, frames[0].depth))
+    # ... and the unchanged-scripts route on the same map: the reference-style Python loop on the drop-in pose package (autograd, torch's Adam,
+    # update_pose; tests/replay.py) walks the same poses as the native loop
+    def fresh(f):
+        for t_ in (frames[f].exposure_a, frames[f].exposure_b, frames[f].cam_rot_delta, frames[f].cam_trans_delta):
+            t_.data = torch.zeros_like(t_.data)
+        return frames[f]
+    from tests import replay as RP
+    Rn, Tn, _ = fr.refine(fresh(1), RP.TRACKING_CONFIG, inits[1][:3, :3].clone(), inits[1][:3, 3].clone(), bg, iters=6, stop_on_converged=False, warm_start=False)
+    Rn, Tn = Rn.clone(), Tn.clone()
+    Rp, Tp, _ = RP.python_loop(fresh(1), RP.TRACKING_CONFIG, inits[1][:3, :3].clone(), inits[1][:3, 3].clone(), gmap, bg, iters=6)
+    # (2e-6 on the generators' scenes, tests/test_gpu_refine.py; here a tenth of the pixels carries the loss -- a rough map is rarely opaque
+    # enough for `opacity > 0.99` -- and two summation orders drift apart faster: seen 1.2e-6 ... 3.7e-6 after six iterations)
+    assert torch.allclose(Rn, Rp, atol=1e-5) and torch.allclose(Tn, Tp, atol=1e-5), (float((Rn - Rp).abs().max()), float((Tn - Tp).abs().max()))
