@@ -38,9 +38,19 @@ def test_train_save_load_localise_and_check_against_the_oracle(tmp_path):
             t_.data = torch.zeros_like(t_.data)
         return frames[f]
     from tests import replay as RP
+    from tests import util as U
+    # one iteration: the same dL/dtau (1e-5) and the same pose step; six iterations: the same trajectory up to what Adam makes of the
+    # last digits of a gradient that a tenth of the pixels carries (a rough map is rarely opaque enough for `opacity > 0.99`; the map
+    # itself differs from run to run -- training adds with fp32 atomics): seen 1e-6 ... 4e-5 of poses that move 1e-3 per step
+    R1, T1, _ = fr.refine(fresh(1), RP.TRACKING_CONFIG, inits[1][:3, :3].clone(), inits[1][:3, 3].clone(), bg, iters=1, stop_on_converged=False, warm_start=False)
+    R1, T1, tau_native = R1.clone(), T1.clone(), fr.g_tau.clone()
+    f1 = fresh(1)
+    f1.update_RT(inits[1][:3, :3].clone(), inits[1][:3, 3].clone())
+    RP.loop_iteration(f1, RP.TRACKING_CONFIG, gmap, bg, RP.pose_adam(f1))
+    tau_python = torch.cat([f1.cam_trans_delta.grad, f1.cam_rot_delta.grad])
+    assert U.rel_l1(tau_native.cpu().numpy(), tau_python.cpu().numpy()) <= 1e-5, U.rel_l1(tau_native.cpu().numpy(), tau_python.cpu().numpy())
+    assert torch.allclose(R1, f1.R, atol=2e-6) and torch.allclose(T1, f1.T, atol=2e-6)
     Rn, Tn, _ = fr.refine(fresh(1), RP.TRACKING_CONFIG, inits[1][:3, :3].clone(), inits[1][:3, 3].clone(), bg, iters=6, stop_on_converged=False, warm_start=False)
     Rn, Tn = Rn.clone(), Tn.clone()
     Rp, Tp, _ = RP.python_loop(fresh(1), RP.TRACKING_CONFIG, inits[1][:3, :3].clone(), inits[1][:3, 3].clone(), gmap, bg, iters=6)
-    # (2e-6 on the generators' scenes, tests/test_gpu_refine.py; here a tenth of the pixels carries the loss -- a rough map is rarely opaque
-    # enough for `opacity > 0.99` -- and two summation orders drift apart faster: seen 1.2e-6 ... 3.7e-6 after six iterations)
-    assert torch.allclose(Rn, Rp, atol=1e-5) and torch.allclose(Tn, Tp, atol=1e-5), (float((Rn - Rp).abs().max()), float((Tn - Tp).abs().max()))
+    assert torch.allclose(Rn, Rp, atol=2e-4) and torch.allclose(Tn, Tp, atol=2e-4), (float((Rn - Rp).abs().max()), float((Tn - Tp).abs().max()))
